@@ -1,0 +1,12 @@
+"""cobs_amd -- MI355X (gfx950) query engine for COBS bit-sliced signature indexes.
+
+Drop-in for ONE path of bingmann/cobs: `cobs_index.Search(path).search(query,
+threshold, num_results)` (reference python/module.cpp:367-386) /
+`cobs::ClassicSearch::search` (reference cobs/query/classic_search.cpp:403-505).
+All compute happens in libcobs_gpu.so (HIP, C ABI in include/cobs_gpu.h).
+"""
+from ._capi import CobsGpuError  # noqa: F401
+from .search import Batch, Search, SearchResult  # noqa: F401
+
+__version__ = "0.1.0"
+__all__ = ["Search", "SearchResult", "Batch", "CobsGpuError", "__version__"]

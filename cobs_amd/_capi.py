@@ -1,0 +1,116 @@
+"""ctypes binding of libcobs_gpu.so (the C ABI declared in include/cobs_gpu.h).
+
+The library is the product; this module only declares its entry points.  It
+fails loudly if the shared object is missing -- there is no Python or CPU
+fallback for any of the functions.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcobs_gpu.so")
+
+OK = 0
+ERR_OPEN, ERR_FORMAT, ERR_QUERY_TOO_SHORT, ERR_INVALID_BASE, ERR_QUERY_TOO_LONG = 1, 2, 3, 4, 5
+ERR_HIP, ERR_ARG, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_NO_DEVICE = 6, 7, 8, 9, 10
+
+STATUS_NAMES = {
+    0: "COBS_GPU_OK", 1: "COBS_GPU_ERR_OPEN", 2: "COBS_GPU_ERR_FORMAT",
+    3: "COBS_GPU_ERR_QUERY_TOO_SHORT", 4: "COBS_GPU_ERR_INVALID_BASE",
+    5: "COBS_GPU_ERR_QUERY_TOO_LONG", 6: "COBS_GPU_ERR_HIP", 7: "COBS_GPU_ERR_ARG",
+    8: "COBS_GPU_ERR_UNSUPPORTED", 9: "COBS_GPU_ERR_CAPACITY", 10: "COBS_GPU_ERR_NO_DEVICE",
+}
+
+
+class Options(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32),
+                ("shard_rank", C.c_uint32), ("shard_count", C.c_uint32),
+                ("waves_per_group", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("term_size", C.c_uint32), ("canonicalize", C.c_uint32),
+                ("num_pages", C.c_uint32), ("num_hashes", C.c_uint64), ("page_size", C.c_uint64),
+                ("row_size", C.c_uint64), ("counts_size", C.c_uint64), ("num_docs", C.c_uint64),
+                ("doc_offset", C.c_uint64), ("hbm_bytes", C.c_uint64),
+                ("first_page", C.c_uint32), ("end_page", C.c_uint32),
+                ("slot_begin", C.c_uint64), ("slot_count", C.c_uint64), ("local_offset", C.c_uint64)]
+
+
+class Hit(C.Structure):
+    _fields_ = [("file_no", C.c_uint32), ("doc", C.c_uint32), ("score", C.c_uint32)]
+
+
+class Synth(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("term_size", C.c_uint32), ("canonicalize", C.c_uint32),
+                ("num_pages", C.c_uint32), ("num_hashes", C.c_uint64), ("page_size", C.c_uint64),
+                ("num_docs", C.c_uint64), ("seed", C.c_uint64),
+                ("signature_sizes", C.POINTER(C.c_uint64))]
+
+
+# name -> (restype, argtypes): every symbol include/cobs_gpu.h declares
+_vp, _sz, _u32, _u64, _cp, _dbl, _int = (C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64,
+                                        C.c_char_p, C.c_double, C.c_int)
+SYMBOLS = {
+    "cobs_gpu_abi_version": (_u32, []),
+    "cobs_gpu_last_error": (_cp, []),
+    "cobs_gpu_device_count": (_int, []),
+    "cobs_gpu_open": (_int, [C.POINTER(_cp), _sz, C.POINTER(Options), C.POINTER(_vp)]),
+    "cobs_gpu_open_synthetic": (_int, [C.POINTER(Synth), C.POINTER(Options), C.POINTER(_vp)]),
+    "cobs_gpu_close": (None, [_vp]),
+    "cobs_gpu_num_files": (_sz, [_vp]),
+    "cobs_gpu_info": (_int, [_vp, _sz, C.POINTER(IndexInfo)]),
+    "cobs_gpu_signature_size": (_u64, [_vp, _sz, _u32]),
+    "cobs_gpu_doc_name": (_cp, [_vp, _sz, _u64]),
+    "cobs_gpu_total_counts": (_u64, [_vp]),
+    "cobs_gpu_local_counts": (_u64, [_vp]),
+    "cobs_gpu_read_row": (_int, [_vp, _sz, _u32, _u64, _vp, _sz]),
+    "cobs_gpu_search": (_int, [_vp, _cp, _sz, _dbl, _sz, C.POINTER(Hit), _sz, C.POINTER(_sz)]),
+    "cobs_gpu_search_batch": (_int, [_vp, C.POINTER(_cp), C.POINTER(_sz), _sz, _dbl, _sz,
+                                     C.POINTER(Hit), _sz, C.POINTER(_sz), C.POINTER(_sz)]),
+    "cobs_gpu_counts": (_int, [_vp, _cp, _sz, _vp, _sz]),
+    "cobs_gpu_batch_create": (_int, [_vp, _sz, _sz, C.POINTER(_vp)]),
+    "cobs_gpu_batch_destroy": (None, [_vp]),
+    "cobs_gpu_batch_set_queries": (_int, [_vp, C.POINTER(_cp), C.POINTER(_sz), _sz]),
+    "cobs_gpu_batch_run": (_int, [_vp, _dbl, _vp]),
+    "cobs_gpu_batch_sync": (_int, [_vp, _vp, C.POINTER(_sz)]),
+    "cobs_gpu_batch_counts_device": (_vp, [_vp, C.POINTER(_u32), C.POINTER(_u64)]),
+    "cobs_gpu_batch_counts_host": (_int, [_vp, _sz, _vp, _sz]),
+    "cobs_gpu_batch_hits_host": (_int, [_vp, _sz, _sz, C.POINTER(Hit), _sz, C.POINTER(_sz)]),
+    "cobs_gpu_batch_stats": (_int, [_vp, C.POINTER(_u64 * 4)]),
+    "cobs_gpu_batch_kernel_ms": (_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "cobs_gpu_timers": (_int, [_vp, C.POINTER(C.c_double * 5), _int]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libcobs_gpu.so and bind every declared symbol (raises if missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "cobs_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C cobs_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)       # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if lib.cobs_gpu_abi_version() != 1:
+        raise ImportError("cobs_amd: libcobs_gpu.so has an unexpected ABI version")
+    _lib = lib
+    return lib
+
+
+class CobsGpuError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("%s: %s" % (STATUS_NAMES.get(status, status), message))
+        self.status = status
+
+
+def check(status):
+    if status != OK:
+        raise CobsGpuError(status, load().cobs_gpu_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,93 @@
+// cobs_amd/csrc/device_types.hpp -- structures shared by host code and HIP kernels.
+#pragma once
+#include <cstdint>
+
+namespace cobs_amd {
+
+// One sub-index ("page" in the reference's compact index; a classic index is a
+// single page) as laid out in HBM.  Rows are `pitch` bytes apart (multiple of
+// 16), row `sig` (one past the last signature row) is all zero and is what
+// padded query terms point at.
+struct PageDev {
+    uint64_t base;         // byte offset of row 0 from the file's HBM blob
+    uint64_t sig;          // signature_size S_p (row index = hash % S_p), < 2^32
+    uint64_t magic;        // floor((2^64 - 1) / S_p) for the exact fast modulo
+    uint32_t slot0;        // first local score slot of this page (multiple of 8)
+    uint32_t doc0;         // file-level document id of the page's first document
+    uint32_t valid_bytes;  // row bytes that map to score slots (<= pitch)
+    uint32_t reserved;
+};
+
+// Arguments of the hashing kernel K1 for one index file.
+struct HashArgs {
+    const uint8_t* text;        // query characters, query q at text[span_off[q] ..]
+    const uint64_t* span_off;   // nq + 1 prefix sums of per-query thread spans
+    const uint32_t* q_len;      // characters per query
+    const uint64_t* blk_off;    // nq + 1 prefix sums of 8-term blocks per query
+    const PageDev* pages;       // local sub-indexes
+    uint32_t* table;            // row indices: [q][page][block][hash][8]
+    uint32_t* err_query;        // atomicMin of queries holding a non-ACGT base
+    uint32_t nq;
+    uint32_t npages;
+    uint32_t term_size;
+    uint32_t canonicalize;
+    uint32_t num_hashes;
+};
+
+// One selected (query, document) pair of the on-device threshold pass.
+struct HitDev {
+    uint32_t query;
+    uint32_t part;
+    uint32_t doc;
+    uint32_t score;
+};
+
+// Arguments of the scan kernel K2 for one index file.
+struct ScanArgs {
+    const uint8_t* blob;        // HBM blob of the file
+    const PageDev* pages;
+    const uint32_t* table;      // from K1
+    const uint64_t* blk_off;    // nq + 1
+    void* counts;               // u16 or u32 [nq][counts_stride]
+    const uint32_t* thresholds; // per query (this file) or nullptr = no selection
+    HitDev* hits;               // selection pool
+    uint32_t* hit_count;        // pool fill (may exceed hit_cap: overflow)
+    uint64_t counts_stride;     // elements per query row
+    uint64_t counts_offset;     // local slot offset of this file inside a row
+    uint32_t hit_cap;
+    uint32_t nq;
+    uint32_t npages;
+    uint32_t pitch;             // bytes between rows
+    uint32_t cpp;               // 16-byte chunks per row (pitch / 16)
+    uint32_t total_chunks;      // npages * cpp
+    uint32_t num_hashes;
+    uint32_t num_docs;          // documents of the file (ids >= this are padding)
+    uint32_t part;              // file number
+    uint32_t write_counts;      // 0: selection only
+};
+
+// procedural index fill
+struct SynthArgs {
+    uint8_t* blob;
+    const PageDev* pages;
+    uint64_t seed;
+    uint64_t row_bytes;         // file-level bytes per row of a sub-index
+    uint64_t col0;              // first file-level row byte held locally (classic column shards)
+    uint64_t num_docs;
+    uint64_t page_docs;         // documents per sub-index (compact: 8*page_size, classic: all)
+    uint32_t npages;
+    uint32_t first_page;        // file-level number of local page 0
+    uint32_t pitch;
+};
+
+struct RepitchArgs {
+    const uint8_t* src;         // staged raw rows: row r at src + r * src_pitch
+    uint8_t* dst;               // dst row r at dst + r * dst_pitch
+    uint64_t rows;
+    uint32_t src_pitch;
+    uint32_t dst_pitch;
+    uint32_t copy_bytes;        // bytes copied per row (rest of dst row zeroed)
+    uint32_t src_col0;          // first source byte of each row
+};
+
+}  // namespace cobs_amd

@@ -1,0 +1,903 @@
+// cobs_amd/csrc/engine.cpp -- host side of libcobs_gpu.so: index staging into
+// HBM, batch workspaces, kernel orchestration, result ranking, and the C ABI of
+// include/cobs_gpu.h.  There is no CPU fallback: without a HIP device every entry
+// point that needs one fails with COBS_GPU_ERR_NO_DEVICE.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/cobs_gpu.h"
+#include "device_types.hpp"
+#include "index_file.hpp"
+#include "kernels.hpp"
+
+using namespace cobs_amd;
+
+// ---------------------------------------------------------------------------
+// errors
+
+namespace {
+
+thread_local std::string g_last_error;
+
+cobs_gpu_status fail(cobs_gpu_status st, const std::string& msg) {
+    g_last_error = msg;
+    return st;
+}
+
+cobs_gpu_status hip_fail(hipError_t e, const char* what) {
+    std::string m = std::string(what) + ": " + hipGetErrorString(e);
+    const bool nodev = e == hipErrorNoDevice || e == hipErrorInvalidDevice ||
+                       e == hipErrorInsufficientDriver;
+    (void)hipGetLastError();
+    return fail(nodev ? COBS_GPU_ERR_NO_DEVICE : COBS_GPU_ERR_HIP, m);
+}
+
+#define HIP_TRY(expr)                                              \
+    do {                                                           \
+        hipError_t _e = (expr);                                    \
+        if (_e != hipSuccess) return hip_fail(_e, #expr);          \
+    } while (0)
+
+double now_s() {
+    using namespace std::chrono;
+    return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+
+uint64_t round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
+
+template <typename T>
+struct DevBuf {     // grow-only device allocation
+    T* p = nullptr;
+    size_t cap = 0;   // elements
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T));
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+};
+
+template <typename T>
+struct PinnedBuf {  // grow-only pinned host staging
+    T* p = nullptr;
+    size_t cap = 0;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipHostMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+};
+
+// One index file as resident on this device (possibly only a shard of it).
+struct Part {
+    IndexMeta meta;
+    uint32_t first_page = 0, end_page = 0;   // file-level sub-indexes held here
+    uint64_t col0 = 0, ncols = 0;            // row bytes [col0, col0+ncols) of each held sub-index
+    uint32_t pitch = 0, cpp = 0, nlocal = 0, total_chunks = 0, ntiles = 0;
+    uint8_t* d_blob = nullptr;
+    size_t blob_bytes = 0;
+    PageDev* d_pages = nullptr;
+    std::vector<PageDev> pages;
+    uint64_t doc_offset = 0;      // first global score slot of this file
+    uint64_t slot_begin = 0;      // file-level score slots computed here
+    uint64_t slot_count = 0;
+    uint64_t local_offset = 0;    // position of those slots in a local count row
+};
+
+}  // namespace
+
+struct cobs_gpu_index {
+    int device = 0;
+    uint32_t shard_rank = 0, shard_count = 1;
+    std::vector<Part> parts;
+    uint64_t total_counts = 0, local_counts = 0;
+    double timers[5] = {0, 0, 0, 0, 0};
+    cobs_gpu_batch* scratch = nullptr;    // workspace of the host-buffer search API
+    ~cobs_gpu_index();
+};
+
+namespace {
+
+struct PartWork {    // per-file device workspace of a batch
+    DevBuf<uint64_t> blk_off;
+    DevBuf<uint32_t> table;
+    DevBuf<uint32_t> thr;
+    std::vector<uint64_t> h_blk_off;
+    std::vector<uint32_t> h_thr;
+    uint64_t table_entries = 0;
+};
+
+}  // namespace
+
+struct cobs_gpu_batch {
+    cobs_gpu_index* ix = nullptr;
+    size_t max_queries = 0, max_len = 0;
+    size_t nq = 0;
+    std::vector<uint32_t> lens;
+    std::vector<uint64_t> span_off;
+    DevBuf<uint8_t> text;
+    DevBuf<uint64_t> d_span_off;
+    DevBuf<uint32_t> d_qlen;
+    PinnedBuf<uint8_t> h_text;
+    PinnedBuf<uint32_t> h_thr_stage;
+    std::vector<PartWork> work;
+    DevBuf<uint8_t> counts;
+    uint32_t elem_bytes = 2;
+    int planes = 0;
+    DevBuf<HitDev> hits;
+    DevBuf<uint32_t> flags;           // [0] first invalid query, [1] selected hits
+    uint32_t hit_cap = 0;
+    // last run
+    bool ran = false, selected = false, synced = false;
+    double threshold = 0.0;
+    uint32_t h_flags[2] = {0xFFFFFFFFu, 0};
+    std::vector<HitDev> h_hits;       // pool copy, sorted by query
+    std::vector<size_t> h_hit_off;
+    bool pool_fetched = false;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    uint64_t stats[4] = {0, 0, 0, 0};
+    ~cobs_gpu_batch() {
+        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    }
+};
+
+cobs_gpu_index::~cobs_gpu_index() {
+    delete scratch;
+    for (auto& p : parts) {
+        if (p.d_blob) (void)hipFree(p.d_blob);
+        if (p.d_pages) (void)hipFree(p.d_pages);
+    }
+}
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// index staging
+
+cobs_gpu_status select_device(const cobs_gpu_options* o, int* device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(COBS_GPU_ERR_NO_DEVICE,
+                    "no HIP device visible; libcobs_gpu has no CPU fallback");
+    }
+    int dev = 0;
+    if (o && o->device >= 0) {
+        dev = o->device;
+        if (dev >= n) return fail(COBS_GPU_ERR_ARG, "device ordinal out of range");
+        HIP_TRY(hipSetDevice(dev));
+    } else {
+        HIP_TRY(hipGetDevice(&dev));
+    }
+    *device = dev;
+    return COBS_GPU_OK;
+}
+
+// Decide which slice of the file this shard holds and lay out its pages.
+cobs_gpu_status plan_part(Part& pt, uint32_t rank, uint32_t count) {
+    const IndexMeta& m = pt.meta;
+    if (m.term_size == 0) return fail(COBS_GPU_ERR_FORMAT, "term_size is zero");
+    if (m.num_hashes == 0 || m.num_hashes > 64)
+        return fail(COBS_GPU_ERR_UNSUPPORTED, "num_hashes must be in 1..64");
+    if (m.canonicalize > 1)
+        return fail(COBS_GPU_ERR_FORMAT, "Unknown canonicalize value " + std::to_string(m.canonicalize));
+    for (uint64_t s : m.signature_sizes)
+        if (s == 0 || s >= 0xFFFFFFFFull)
+            return fail(COBS_GPU_ERR_UNSUPPORTED, "signature_size must be in 1..2^32-2");
+    if (m.counts_size() > 0xFFFFFFF0ull)
+        return fail(COBS_GPU_ERR_UNSUPPORTED, "more than 2^32 score slots in one file");
+    const uint64_t prb = m.page_row_bytes();
+    if (m.kind == IndexKind::Compact) {
+        const uint32_t P = m.num_pages();
+        pt.first_page = (uint32_t)((uint64_t)P * rank / count);
+        pt.end_page = (uint32_t)((uint64_t)P * (rank + 1) / count);
+        pt.col0 = 0;
+        pt.ncols = prb;
+        pt.slot_begin = (uint64_t)pt.first_page * 8 * prb;
+        pt.slot_count = (uint64_t)(pt.end_page - pt.first_page) * 8 * prb;
+    } else {
+        const uint64_t nch = (prb + 15) / 16;
+        const uint64_t c0 = nch * rank / count, c1 = nch * (rank + 1) / count;
+        pt.col0 = c0 * 16;
+        pt.ncols = std::min<uint64_t>(prb, c1 * 16) - std::min<uint64_t>(prb, pt.col0);
+        pt.first_page = 0;
+        pt.end_page = pt.ncols ? 1 : 0;
+        pt.slot_begin = pt.col0 * 8;
+        pt.slot_count = pt.ncols * 8;
+    }
+    pt.nlocal = pt.end_page - pt.first_page;
+    if (pt.ncols > 0xFFFFFFF0ull / 16) return fail(COBS_GPU_ERR_UNSUPPORTED, "row too wide");
+    pt.pitch = (uint32_t)round_up(pt.ncols, 16);
+    pt.cpp = pt.pitch / 16;
+    pt.total_chunks = pt.nlocal * pt.cpp;
+    pt.ntiles = (pt.total_chunks + 63) / 64;
+    pt.pages.resize(pt.nlocal);
+    uint64_t off = 0;
+    for (uint32_t lp = 0; lp < pt.nlocal; ++lp) {
+        const uint32_t fp = pt.first_page + lp;
+        PageDev& pd = pt.pages[lp];
+        pd.base = off;
+        pd.sig = m.signature_sizes[fp];
+        pd.magic = ~0ull / pd.sig;
+        pd.slot0 = (uint32_t)(lp * pt.ncols * 8);
+        pd.doc0 = (uint32_t)((m.kind == IndexKind::Compact ? (uint64_t)fp * 8 * prb : 0) + pt.col0 * 8);
+        pd.valid_bytes = (uint32_t)pt.ncols;
+        pd.reserved = 0;
+        off += round_up((pd.sig + 1) * (uint64_t)pt.pitch, 256);     // +1: the all-zero row
+    }
+    pt.blob_bytes = off;
+    return COBS_GPU_OK;
+}
+
+cobs_gpu_status alloc_part(Part& pt) {
+    if (pt.nlocal == 0) return COBS_GPU_OK;
+    HIP_TRY(hipMalloc((void**)&pt.d_blob, pt.blob_bytes));
+    HIP_TRY(hipMalloc((void**)&pt.d_pages, sizeof(PageDev) * pt.nlocal));
+    HIP_TRY(hipMemcpy(pt.d_pages, pt.pages.data(), sizeof(PageDev) * pt.nlocal, hipMemcpyHostToDevice));
+    return COBS_GPU_OK;
+}
+
+// Copy the held columns of every held sub-index from the mapped file into HBM.
+cobs_gpu_status upload_part(Part& pt, const uint8_t* file) {
+    const IndexMeta& m = pt.meta;
+    const uint64_t src_pitch = m.page_row_bytes();
+    DevBuf<uint8_t> stage;
+    for (uint32_t lp = 0; lp < pt.nlocal; ++lp) {
+        const PageDev& pd = pt.pages[lp];
+        const uint8_t* src = file + m.page_offset(pt.first_page + lp);
+        uint8_t* dst = pt.d_blob + pd.base;
+        if (src_pitch == pt.pitch && pt.col0 == 0) {
+            // rows are already 16-byte pitched: one straight copy
+            const uint64_t total = pd.sig * src_pitch;
+            const uint64_t step = 1ull << 30;
+            for (uint64_t o = 0; o < total; o += step)
+                HIP_TRY(hipMemcpy(dst + o, src + o, (size_t)std::min(step, total - o), hipMemcpyHostToDevice));
+        } else {
+            // stage raw rows, re-pitch on the device
+            const uint64_t rows_per = std::max<uint64_t>(1, (64ull << 20) / src_pitch);
+            HIP_TRY(stage.reserve((size_t)(std::min(rows_per, pd.sig) * src_pitch)));
+            for (uint64_t r = 0; r < pd.sig; r += rows_per) {
+                const uint64_t n = std::min(rows_per, pd.sig - r);
+                HIP_TRY(hipMemcpy(stage.p, src + r * src_pitch, (size_t)(n * src_pitch), hipMemcpyHostToDevice));
+                RepitchArgs ra;
+                ra.src = stage.p;
+                ra.dst = dst + r * pt.pitch;
+                ra.rows = n;
+                ra.src_pitch = (uint32_t)src_pitch;
+                ra.dst_pitch = pt.pitch;
+                ra.copy_bytes = (uint32_t)pt.ncols;
+                ra.src_col0 = (uint32_t)pt.col0;
+                HIP_TRY(launch_repitch(ra, nullptr));
+                HIP_TRY(hipDeviceSynchronize());
+            }
+        }
+        HIP_TRY(hipMemset(dst + pd.sig * (uint64_t)pt.pitch, 0, pt.pitch));   // zero row
+    }
+    return COBS_GPU_OK;
+}
+
+void finish_layout(cobs_gpu_index* ix) {
+    uint64_t g = 0, l = 0;
+    for (auto& p : ix->parts) {
+        p.doc_offset = g;
+        p.local_offset = l;
+        g += p.meta.counts_size();
+        l += p.slot_count;
+    }
+    ix->total_counts = g;
+    ix->local_counts = l;
+}
+
+cobs_gpu_status shard_of(const cobs_gpu_options* o, uint32_t* rank, uint32_t* count) {
+    *rank = 0;
+    *count = 1;
+    if (o && o->shard_count > 1) {
+        if (o->shard_rank >= o->shard_count) return fail(COBS_GPU_ERR_ARG, "shard_rank >= shard_count");
+        *rank = o->shard_rank;
+        *count = o->shard_count;
+    }
+    return COBS_GPU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// ranking (counts_to_result, reference classic_search.cpp:109-202)
+
+bool hit_before(const cobs_gpu_hit& a, const cobs_gpu_hit& b) {
+    if (a.score != b.score) return a.score > b.score;
+    if (a.file_no != b.file_no) return a.file_no < b.file_no;
+    return a.doc < b.doc;
+}
+
+bool doc_before(const cobs_gpu_hit& a, const cobs_gpu_hit& b) {
+    if (a.file_no != b.file_no) return a.file_no < b.file_no;
+    return a.doc < b.doc;
+}
+
+// total number of hashes of query `q` over all files: the reference's max_counts
+uint64_t total_hashes(const cobs_gpu_batch* b, size_t q) {
+    uint64_t n = 0;
+    for (const Part& p : b->ix->parts)
+        n += (uint64_t)(b->lens[q] - p.meta.term_size + 1) * p.meta.num_hashes;
+    return n;
+}
+
+uint32_t threshold_for(double threshold, uint64_t terms) {
+    // classic_search.cpp:446-448: std::ceil(threshold * T) in double
+    const double v = std::ceil(threshold * (double)terms);
+    if (!(v > 0)) return 0;
+    if (v >= 4294967295.0) return 0xFFFFFFFFu;
+    return (uint32_t)v;
+}
+
+}  // namespace
+
+// ===========================================================================
+// C ABI
+
+extern "C" {
+
+uint32_t cobs_gpu_abi_version(void) { return COBS_GPU_ABI_VERSION; }
+
+const char* cobs_gpu_last_error(void) { return g_last_error.c_str(); }
+
+int cobs_gpu_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+cobs_gpu_status cobs_gpu_open(const char* const* paths, size_t n_paths,
+                              const cobs_gpu_options* opts, cobs_gpu_index** out) {
+    if (!out) return fail(COBS_GPU_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!paths || n_paths == 0) return fail(COBS_GPU_ERR_ARG, "no index paths");
+    // parse all headers first: format errors are reported even without a device
+    std::vector<std::unique_ptr<MappedFile>> files;
+    std::unique_ptr<cobs_gpu_index> ix(new cobs_gpu_index);
+    for (size_t i = 0; i < n_paths; ++i) {
+        if (!paths[i]) return fail(COBS_GPU_ERR_ARG, "NULL path");
+        std::string err;
+        files.emplace_back(new MappedFile);
+        if (!files.back()->open(paths[i], err)) return fail(COBS_GPU_ERR_OPEN, err);
+        Part pt;
+        if (!parse_index_header(files.back()->data(), files.back()->size(), pt.meta, err))
+            return fail(COBS_GPU_ERR_FORMAT, std::string("Could not open index path \"") + paths[i] + "\": " + err);
+        ix->parts.push_back(std::move(pt));
+    }
+    cobs_gpu_status st = shard_of(opts, &ix->shard_rank, &ix->shard_count);
+    if (st != COBS_GPU_OK) return st;
+    for (auto& pt : ix->parts) {
+        st = plan_part(pt, ix->shard_rank, ix->shard_count);
+        if (st != COBS_GPU_OK) return st;
+    }
+    finish_layout(ix.get());
+    st = select_device(opts, &ix->device);
+    if (st != COBS_GPU_OK) return st;
+    for (size_t i = 0; i < ix->parts.size(); ++i) {
+        st = alloc_part(ix->parts[i]);
+        if (st != COBS_GPU_OK) return st;
+        st = upload_part(ix->parts[i], files[i]->data());
+        if (st != COBS_GPU_OK) return st;
+    }
+    *out = ix.release();
+    return COBS_GPU_OK;
+}
+
+cobs_gpu_status cobs_gpu_open_synthetic(const cobs_gpu_synth* d, const cobs_gpu_options* opts,
+                                        cobs_gpu_index** out) {
+    if (!out) return fail(COBS_GPU_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!d || !d->signature_sizes || d->num_pages == 0 || d->kind > 1)
+        return fail(COBS_GPU_ERR_ARG, "bad synthetic index description");
+    if (d->kind == 1 && d->page_size == 0) return fail(COBS_GPU_ERR_ARG, "page_size is zero");
+    if (d->kind == 0 && d->num_pages != 1) return fail(COBS_GPU_ERR_ARG, "classic index has one sub-index");
+    if (d->kind == 1 && d->num_docs > (uint64_t)d->num_pages * 8 * d->page_size)
+        return fail(COBS_GPU_ERR_ARG, "more documents than sub-index slots");
+    if (d->num_docs == 0 || d->num_docs > 0xFFFFFFF0ull) return fail(COBS_GPU_ERR_ARG, "bad num_docs");
+    std::unique_ptr<cobs_gpu_index> ix(new cobs_gpu_index);
+    Part pt;
+    pt.meta.kind = d->kind ? IndexKind::Compact : IndexKind::Classic;
+    pt.meta.term_size = d->term_size;
+    pt.meta.canonicalize = (uint8_t)d->canonicalize;
+    pt.meta.num_hashes = d->num_hashes;
+    pt.meta.header_page_size = d->kind ? d->page_size : 0;
+    pt.meta.signature_sizes.assign(d->signature_sizes, d->signature_sizes + d->num_pages);
+    pt.meta.doc_names.resize(d->num_docs);
+    char nm[32];
+    for (uint64_t i = 0; i < d->num_docs; ++i) {      // names as classic_construct_random, classic_index.cpp:668-670
+        std::snprintf(nm, sizeof nm, "file_%06u", (unsigned)i);
+        pt.meta.doc_names[i] = nm;
+    }
+    ix->parts.push_back(std::move(pt));
+    cobs_gpu_status st = shard_of(opts, &ix->shard_rank, &ix->shard_count);
+    if (st != COBS_GPU_OK) return st;
+    st = plan_part(ix->parts[0], ix->shard_rank, ix->shard_count);
+    if (st != COBS_GPU_OK) return st;
+    finish_layout(ix.get());
+    st = select_device(opts, &ix->device);
+    if (st != COBS_GPU_OK) return st;
+    Part& p = ix->parts[0];
+    st = alloc_part(p);
+    if (st != COBS_GPU_OK) return st;
+    if (p.nlocal) {
+        SynthArgs sa;
+        sa.blob = p.d_blob;
+        sa.pages = p.d_pages;
+        sa.seed = d->seed;
+        sa.row_bytes = p.meta.page_row_bytes();
+        sa.col0 = p.col0;
+        sa.num_docs = d->num_docs;
+        sa.page_docs = d->kind ? 8 * d->page_size : 0;
+        sa.npages = p.nlocal;
+        sa.first_page = p.first_page;
+        sa.pitch = p.pitch;
+        HIP_TRY(launch_synth(sa, nullptr));
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    *out = ix.release();
+    return COBS_GPU_OK;
+}
+
+void cobs_gpu_close(cobs_gpu_index* ix) { delete ix; }
+
+size_t cobs_gpu_num_files(const cobs_gpu_index* ix) { return ix ? ix->parts.size() : 0; }
+
+cobs_gpu_status cobs_gpu_info(const cobs_gpu_index* ix, size_t f, cobs_gpu_index_info* o) {
+    if (!ix || !o || f >= ix->parts.size()) return fail(COBS_GPU_ERR_ARG, "bad file number");
+    const Part& p = ix->parts[f];
+    std::memset(o, 0, sizeof *o);
+    o->kind = (uint32_t)p.meta.kind;
+    o->term_size = p.meta.term_size;
+    o->canonicalize = p.meta.canonicalize;
+    o->num_pages = p.meta.num_pages();
+    o->num_hashes = p.meta.num_hashes;
+    o->page_size = p.meta.page_size();
+    o->row_size = p.meta.row_size();
+    o->counts_size = p.meta.counts_size();
+    o->num_docs = p.meta.doc_names.size();
+    o->doc_offset = p.doc_offset;
+    o->hbm_bytes = p.blob_bytes;
+    o->first_page = p.first_page;
+    o->end_page = p.end_page;
+    o->slot_begin = p.slot_begin;
+    o->slot_count = p.slot_count;
+    o->local_offset = p.local_offset;
+    return COBS_GPU_OK;
+}
+
+uint64_t cobs_gpu_signature_size(const cobs_gpu_index* ix, size_t f, uint32_t page) {
+    if (!ix || f >= ix->parts.size() || page >= ix->parts[f].meta.num_pages()) return 0;
+    return ix->parts[f].meta.signature_sizes[page];
+}
+
+const char* cobs_gpu_doc_name(const cobs_gpu_index* ix, size_t f, uint64_t doc) {
+    if (!ix || f >= ix->parts.size() || doc >= ix->parts[f].meta.doc_names.size()) return "";
+    return ix->parts[f].meta.doc_names[doc].c_str();
+}
+
+uint64_t cobs_gpu_total_counts(const cobs_gpu_index* ix) { return ix ? ix->total_counts : 0; }
+uint64_t cobs_gpu_local_counts(const cobs_gpu_index* ix) { return ix ? ix->local_counts : 0; }
+
+cobs_gpu_status cobs_gpu_read_row(const cobs_gpu_index* ix, size_t f, uint32_t page, uint64_t row,
+                                  uint8_t* out, size_t n) {
+    if (!ix || !out || f >= ix->parts.size()) return fail(COBS_GPU_ERR_ARG, "bad argument");
+    const Part& p = ix->parts[f];
+    if (page < p.first_page || page >= p.end_page) return fail(COBS_GPU_ERR_ARG, "sub-index not held by this shard");
+    const PageDev& pd = p.pages[page - p.first_page];
+    if (row > pd.sig || n > p.pitch) return fail(COBS_GPU_ERR_ARG, "row or length out of range");
+    HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(hipMemcpy(out, p.d_blob + pd.base + row * (uint64_t)p.pitch, n, hipMemcpyDeviceToHost));
+    return COBS_GPU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// batches
+
+cobs_gpu_status cobs_gpu_batch_create(cobs_gpu_index* ix, size_t max_queries, size_t max_query_len,
+                                      cobs_gpu_batch** out) {
+    if (!ix || !out) return fail(COBS_GPU_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(ix->device));
+    std::unique_ptr<cobs_gpu_batch> b(new cobs_gpu_batch);
+    b->ix = ix;
+    b->max_queries = max_queries;
+    b->max_len = max_query_len;
+    b->work.resize(ix->parts.size());
+    for (auto& e : b->ev) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(b->flags.reserve(2));
+    *out = b.release();
+    return COBS_GPU_OK;
+}
+
+void cobs_gpu_batch_destroy(cobs_gpu_batch* b) { delete b; }
+
+cobs_gpu_status cobs_gpu_batch_set_queries(cobs_gpu_batch* b, const char* const* queries,
+                                           const size_t* lens, size_t nq) {
+    if (!b || (nq && (!queries || !lens))) return fail(COBS_GPU_ERR_ARG, "NULL argument");
+    cobs_gpu_index* ix = b->ix;
+    HIP_TRY(hipSetDevice(ix->device));
+    b->ran = false;
+    b->nq = 0;
+    if (nq >= 0xFFFFFFFEull) return fail(COBS_GPU_ERR_ARG, "too many queries");
+    // reference checks, classic_search.cpp:431-433 and :453-504
+    uint32_t max_term = 0, min_term = 0xFFFFFFFFu;
+    for (const Part& p : ix->parts) {
+        max_term = std::max(max_term, p.meta.term_size);
+        min_term = std::min(min_term, p.meta.term_size);
+    }
+    uint64_t max_terms = 1;
+    for (size_t q = 0; q < nq; ++q) {
+        if (!queries[q]) return fail(COBS_GPU_ERR_ARG, "NULL query");
+        if (lens[q] < max_term)
+            return fail(COBS_GPU_ERR_QUERY_TOO_SHORT, "query too short, needs to be at least " +
+                        std::to_string(max_term) + " characters long");
+        if (lens[q] - max_term >= 0xFFFFFFFFull || lens[q] >= 0xFFFFFFF0ull)
+            return fail(COBS_GPU_ERR_QUERY_TOO_LONG, "query too long");
+        max_terms = std::max<uint64_t>(max_terms, lens[q] - min_term + 1);
+    }
+    const int planes = scan_planes_for(max_terms);
+    if (planes < 0) return fail(COBS_GPU_ERR_QUERY_TOO_LONG, "query too long");
+    b->planes = planes;
+    b->elem_bytes = scan_score_bytes(planes);
+
+    // thread spans of K1: every character and every (padded) term of every file
+    b->lens.resize(nq);
+    b->span_off.resize(nq + 1);
+    uint64_t off = 0;
+    for (size_t q = 0; q < nq; ++q) {
+        b->lens[q] = (uint32_t)lens[q];
+        b->span_off[q] = off;
+        uint64_t span = lens[q];
+        for (const Part& p : ix->parts)
+            span = std::max<uint64_t>(span, round_up(lens[q] - p.meta.term_size + 1, 8));
+        off += round_up(span, 8);
+    }
+    b->span_off[nq] = off;
+    HIP_TRY(b->h_text.reserve((size_t)off));
+    std::memset(b->h_text.p, 0, (size_t)off);
+    for (size_t q = 0; q < nq; ++q) std::memcpy(b->h_text.p + b->span_off[q], queries[q], lens[q]);
+    HIP_TRY(b->text.reserve((size_t)off));
+    HIP_TRY(b->d_span_off.reserve(nq + 1));
+    HIP_TRY(b->d_qlen.reserve(nq));
+    if (off) HIP_TRY(hipMemcpy(b->text.p, b->h_text.p, (size_t)off, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->d_span_off.p, b->span_off.data(), 8 * (nq + 1), hipMemcpyHostToDevice));
+    if (nq) HIP_TRY(hipMemcpy(b->d_qlen.p, b->lens.data(), 4 * nq, hipMemcpyHostToDevice));
+
+    uint64_t algo_bytes = 0, lookups = 0, table_bytes = 0;
+    for (size_t f = 0; f < ix->parts.size(); ++f) {
+        const Part& p = ix->parts[f];
+        PartWork& w = b->work[f];
+        w.h_blk_off.resize(nq + 1);
+        uint64_t blk = 0;
+        for (size_t q = 0; q < nq; ++q) {
+            w.h_blk_off[q] = blk;
+            const uint64_t T = lens[q] - p.meta.term_size + 1;
+            blk += (T + 7) / 8;
+            lookups += T;
+            // T * H * (row bytes gathered) + score bytes written
+            algo_bytes += T * p.meta.num_hashes * (uint64_t)p.nlocal * p.ncols;
+        }
+        w.h_blk_off[nq] = blk;
+        w.table_entries = blk * 8 * p.meta.num_hashes * p.nlocal;
+        if (w.table_entries >= (1ull << 40)) return fail(COBS_GPU_ERR_CAPACITY, "batch too large");
+        table_bytes += w.table_entries * 4;
+        HIP_TRY(w.blk_off.reserve(nq + 1));
+        HIP_TRY(w.table.reserve((size_t)w.table_entries));
+        HIP_TRY(w.thr.reserve(nq));
+        HIP_TRY(hipMemcpy(w.blk_off.p, w.h_blk_off.data(), 8 * (nq + 1), hipMemcpyHostToDevice));
+    }
+    algo_bytes += (uint64_t)nq * ix->local_counts * b->elem_bytes;
+    HIP_TRY(b->counts.reserve((size_t)(nq * ix->local_counts * b->elem_bytes)));
+    // selection pool: room for 1024 hits per query, at least 1 Mi entries
+    const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(1u << 20, nq * 1024ull), 1ull << 26);
+    HIP_TRY(b->hits.reserve((size_t)want));
+    b->hit_cap = (uint32_t)b->hits.cap;
+    HIP_TRY(b->h_thr_stage.reserve(std::max<size_t>(nq * ix->parts.size(), 1)));
+    b->stats[0] = algo_bytes;
+    b->stats[1] = 0;
+    b->stats[2] = lookups;
+    b->stats[3] = table_bytes;
+    b->nq = nq;
+    return COBS_GPU_OK;
+}
+
+cobs_gpu_status cobs_gpu_batch_run(cobs_gpu_batch* b, double threshold, void* hip_stream) {
+    if (!b) return fail(COBS_GPU_ERR_ARG, "NULL batch");
+    cobs_gpu_index* ix = b->ix;
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIP_TRY(hipSetDevice(ix->device));
+    b->ran = false;
+    b->synced = false;
+    b->pool_fetched = false;
+    b->threshold = threshold;
+    b->selected = threshold > 0.0;
+    const size_t nq = b->nq;
+    // device flags: first invalid query = none, selected hits = 0
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)b->flags.p, (int)0xFFFFFFFFu, 1, st));
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(b->flags.p + 1), 0, 1, st));
+    if (b->selected) {
+        for (size_t f = 0; f < ix->parts.size(); ++f) {
+            uint32_t* stage = b->h_thr_stage.p + f * nq;
+            for (size_t q = 0; q < nq; ++q)
+                stage[q] = threshold_for(threshold, (uint64_t)b->lens[q] - ix->parts[f].meta.term_size + 1);
+            if (nq) HIP_TRY(hipMemcpyAsync(b->work[f].thr.p, stage, 4 * nq, hipMemcpyHostToDevice, st));
+        }
+    }
+    HIP_TRY(hipEventRecord(b->ev[0], st));
+    for (size_t f = 0; f < ix->parts.size(); ++f) {
+        const Part& p = ix->parts[f];
+        if (p.nlocal == 0 || nq == 0) continue;
+        HashArgs ha;
+        ha.text = b->text.p;
+        ha.span_off = b->d_span_off.p;
+        ha.q_len = b->d_qlen.p;
+        ha.blk_off = b->work[f].blk_off.p;
+        ha.pages = p.d_pages;
+        ha.table = b->work[f].table.p;
+        ha.err_query = b->flags.p;
+        ha.nq = (uint32_t)nq;
+        ha.npages = p.nlocal;
+        ha.term_size = p.meta.term_size;
+        ha.canonicalize = p.meta.canonicalize;
+        ha.num_hashes = (uint32_t)p.meta.num_hashes;
+        HIP_TRY(launch_hash(ha, b->span_off[nq], st));
+    }
+    HIP_TRY(hipEventRecord(b->ev[1], st));
+    uint64_t launches = 0;
+    for (size_t f = 0; f < ix->parts.size(); ++f) {
+        const Part& p = ix->parts[f];
+        if (p.nlocal == 0 || nq == 0) continue;
+        ScanArgs sa;
+        sa.blob = p.d_blob;
+        sa.pages = p.d_pages;
+        sa.table = b->work[f].table.p;
+        sa.blk_off = b->work[f].blk_off.p;
+        sa.counts = b->counts.p;
+        sa.thresholds = b->selected ? b->work[f].thr.p : nullptr;
+        sa.hits = b->hits.p;
+        sa.hit_count = b->flags.p + 1;
+        sa.counts_stride = ix->local_counts;
+        sa.counts_offset = p.local_offset;
+        sa.hit_cap = b->hit_cap;
+        sa.nq = (uint32_t)nq;
+        sa.npages = p.nlocal;
+        sa.pitch = p.pitch;
+        sa.cpp = p.cpp;
+        sa.total_chunks = p.total_chunks;
+        sa.num_hashes = (uint32_t)p.meta.num_hashes;
+        sa.num_docs = (uint32_t)p.meta.doc_names.size();
+        sa.part = (uint32_t)f;
+        sa.write_counts = 1;
+        // one launch covers at most 2^31-1 work-groups: split the queries if needed
+        const uint64_t per = std::max<uint64_t>(1, 0x7FFFFFFFull / std::max<uint32_t>(p.ntiles, 1));
+        if (nq > per) return fail(COBS_GPU_ERR_CAPACITY, "batch too large for one scan launch; use fewer queries");
+        HIP_TRY(launch_scan(sa, p.ntiles, b->planes, st));
+        ++launches;
+    }
+    HIP_TRY(hipEventRecord(b->ev[2], st));
+    b->stats[1] = launches;
+    b->ran = true;
+    return COBS_GPU_OK;
+}
+
+cobs_gpu_status cobs_gpu_batch_sync(cobs_gpu_batch* b, void* hip_stream, size_t* bad_query) {
+    if (!b) return fail(COBS_GPU_ERR_ARG, "NULL batch");
+    if (!b->ran) return fail(COBS_GPU_ERR_ARG, "batch has not been run");
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIP_TRY(hipSetDevice(b->ix->device));
+    HIP_TRY(hipMemcpyAsync(b->h_flags, b->flags.p, sizeof b->h_flags, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    b->synced = true;
+    if (b->h_flags[0] != 0xFFFFFFFFu) {
+        if (bad_query) *bad_query = b->h_flags[0];
+        return fail(COBS_GPU_ERR_INVALID_BASE,
+                    "Invalid DNA base pair in query string. Only ACGT are allowed. (query " +
+                    std::to_string(b->h_flags[0]) + ")");
+    }
+    return COBS_GPU_OK;
+}
+
+void* cobs_gpu_batch_counts_device(cobs_gpu_batch* b, uint32_t* elem_bytes, uint64_t* row_stride_bytes) {
+    if (!b) return nullptr;
+    if (elem_bytes) *elem_bytes = b->elem_bytes;
+    if (row_stride_bytes) *row_stride_bytes = b->ix->local_counts * b->elem_bytes;
+    return b->counts.p;
+}
+
+// local count row of query q, widened to u32, scattered into a global-layout vector
+static cobs_gpu_status fetch_counts(cobs_gpu_batch* b, size_t q, uint32_t* counts) {
+    cobs_gpu_index* ix = b->ix;
+    const uint64_t n = ix->local_counts;
+    std::vector<uint8_t> raw((size_t)(n * b->elem_bytes));
+    if (n) HIP_TRY(hipMemcpy(raw.data(), b->counts.p + q * n * b->elem_bytes, raw.size(), hipMemcpyDeviceToHost));
+    std::fill(counts, counts + ix->total_counts, 0u);
+    for (const Part& p : ix->parts) {
+        uint32_t* dst = counts + p.doc_offset + p.slot_begin;
+        if (b->elem_bytes == 2) {
+            const uint16_t* s = reinterpret_cast<const uint16_t*>(raw.data()) + p.local_offset;
+            for (uint64_t i = 0; i < p.slot_count; ++i) dst[i] = s[i];
+        } else {
+            const uint32_t* s = reinterpret_cast<const uint32_t*>(raw.data()) + p.local_offset;
+            for (uint64_t i = 0; i < p.slot_count; ++i) dst[i] = s[i];
+        }
+    }
+    return COBS_GPU_OK;
+}
+
+cobs_gpu_status cobs_gpu_batch_counts_host(cobs_gpu_batch* b, size_t q, uint32_t* counts, size_t cap) {
+    if (!b || !counts) return fail(COBS_GPU_ERR_ARG, "NULL argument");
+    if (!b->ran || !b->synced) return fail(COBS_GPU_ERR_ARG, "run and sync the batch first");
+    if (q >= b->nq) return fail(COBS_GPU_ERR_ARG, "query number out of range");
+    if (cap < b->ix->total_counts) return fail(COBS_GPU_ERR_CAPACITY, "counts buffer too small");
+    HIP_TRY(hipSetDevice(b->ix->device));
+    return fetch_counts(b, q, counts);
+}
+
+cobs_gpu_status cobs_gpu_batch_hits_host(cobs_gpu_batch* b, size_t q, size_t num_results,
+                                         cobs_gpu_hit* hits, size_t cap, size_t* n_hits) {
+    if (!b || !n_hits) return fail(COBS_GPU_ERR_ARG, "NULL argument");
+    if (!b->ran || !b->synced) return fail(COBS_GPU_ERR_ARG, "run and sync the batch first");
+    if (q >= b->nq) return fail(COBS_GPU_ERR_ARG, "query number out of range");
+    cobs_gpu_index* ix = b->ix;
+    HIP_TRY(hipSetDevice(ix->device));
+    std::vector<cobs_gpu_hit> sel;
+    const bool pool_ok = b->selected && b->h_flags[1] <= b->hit_cap;
+    if (pool_ok) {
+        if (!b->pool_fetched) {
+            b->h_hits.resize(b->h_flags[1]);
+            if (b->h_flags[1])
+                HIP_TRY(hipMemcpy(b->h_hits.data(), b->hits.p, sizeof(HitDev) * b->h_flags[1], hipMemcpyDeviceToHost));
+            std::stable_sort(b->h_hits.begin(), b->h_hits.end(),
+                             [](const HitDev& x, const HitDev& y) { return x.query < y.query; });
+            b->h_hit_off.assign(b->nq + 1, 0);
+            for (const HitDev& h : b->h_hits) b->h_hit_off[h.query + 1]++;
+            for (size_t i = 0; i < b->nq; ++i) b->h_hit_off[i + 1] += b->h_hit_off[i];
+            b->pool_fetched = true;
+        }
+        for (size_t i = b->h_hit_off[q]; i < b->h_hit_off[q + 1]; ++i)
+            sel.push_back(cobs_gpu_hit{b->h_hits[i].part, b->h_hits[i].doc, b->h_hits[i].score});
+    } else {
+        // threshold <= 0 (every document is a hit) or pool overflow: filter the counts on the host
+        std::vector<uint32_t> counts((size_t)ix->total_counts);
+        cobs_gpu_status st = fetch_counts(b, q, counts.data());
+        if (st != COBS_GPU_OK) return st;
+        for (size_t f = 0; f < ix->parts.size(); ++f) {
+            const Part& p = ix->parts[f];
+            const uint32_t thr = threshold_for(b->threshold, (uint64_t)b->lens[q] - p.meta.term_size + 1);
+            // only documents whose slots this shard computed
+            const uint64_t d0 = p.slot_begin;
+            const uint64_t d1 = std::min<uint64_t>(p.slot_begin + p.slot_count, p.meta.doc_names.size());
+            for (uint64_t d = d0; d < d1; ++d) {
+                const uint32_t s = counts[p.doc_offset + d];
+                if (s >= thr) sel.push_back(cobs_gpu_hit{(uint32_t)f, (uint32_t)d, s});
+            }
+        }
+    }
+    // classic_search.cpp:450-451,134-145
+    size_t want = num_results == 0 ? (size_t)ix->total_counts : std::min<size_t>(num_results, (size_t)ix->total_counts);
+    want = std::min(want, sel.size());
+    if (total_hashes(b, q) > 1)
+        std::partial_sort(sel.begin(), sel.begin() + want, sel.end(), hit_before);
+    else
+        std::partial_sort(sel.begin(), sel.begin() + want, sel.end(), doc_before);
+    *n_hits = want;
+    if (want > cap) return fail(COBS_GPU_ERR_CAPACITY, "hit buffer too small");
+    if (want && !hits) return fail(COBS_GPU_ERR_ARG, "NULL hit buffer");
+    std::copy(sel.begin(), sel.begin() + want, hits);
+    return COBS_GPU_OK;
+}
+
+cobs_gpu_status cobs_gpu_batch_stats(const cobs_gpu_batch* b, uint64_t out[4]) {
+    if (!b || !out) return fail(COBS_GPU_ERR_ARG, "NULL argument");
+    std::memcpy(out, b->stats, sizeof b->stats);
+    return COBS_GPU_OK;
+}
+
+cobs_gpu_status cobs_gpu_batch_kernel_ms(cobs_gpu_batch* b, float* scan_ms, float* hash_ms) {
+    if (!b) return fail(COBS_GPU_ERR_ARG, "NULL batch");
+    if (!b->ran || !b->synced) return fail(COBS_GPU_ERR_ARG, "run and sync the batch first");
+    float h = 0, s = 0;
+    HIP_TRY(hipEventElapsedTime(&h, b->ev[0], b->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&s, b->ev[1], b->ev[2]));
+    if (hash_ms) *hash_ms = h;
+    if (scan_ms) *scan_ms = s;
+    return COBS_GPU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// host-buffer search API
+
+static cobs_gpu_status run_host_batch(cobs_gpu_index* ix, const char* const* queries, const size_t* lens,
+                                      size_t nq, double threshold, size_t* bad_query) {
+    if (!ix->scratch) {
+        cobs_gpu_status st = cobs_gpu_batch_create(ix, 0, 0, &ix->scratch);
+        if (st != COBS_GPU_OK) return st;
+    }
+    cobs_gpu_batch* b = ix->scratch;
+    double t0 = now_s();
+    cobs_gpu_status st = cobs_gpu_batch_set_queries(b, queries, lens, nq);
+    if (st != COBS_GPU_OK) return st;
+    double t1 = now_s();
+    ix->timers[1] += t1 - t0;
+    st = cobs_gpu_batch_run(b, threshold, nullptr);
+    if (st != COBS_GPU_OK) return st;
+    st = cobs_gpu_batch_sync(b, nullptr, bad_query);
+    double t2 = now_s();
+    if (st == COBS_GPU_OK || st == COBS_GPU_ERR_INVALID_BASE) {
+        float sm = 0, hm = 0;
+        if (b->ran && cobs_gpu_batch_kernel_ms(b, &sm, &hm) == COBS_GPU_OK) {
+            ix->timers[0] += hm * 1e-3;
+            ix->timers[2] += sm * 1e-3;
+        }
+    }
+    (void)t2;
+    return st;
+}
+
+cobs_gpu_status cobs_gpu_search_batch(cobs_gpu_index* ix, const char* const* queries, const size_t* lens,
+                                      size_t nq, double threshold, size_t num_results,
+                                      cobs_gpu_hit* hits, size_t cap, size_t* hit_offsets,
+                                      size_t* bad_query) {
+    if (!ix || !hit_offsets) return fail(COBS_GPU_ERR_ARG, "NULL argument");
+    cobs_gpu_status st = run_host_batch(ix, queries, lens, nq, threshold, bad_query);
+    if (st != COBS_GPU_OK) return st;
+    size_t used = 0;
+    hit_offsets[0] = 0;
+    bool overflow = false;
+    for (size_t q = 0; q < nq; ++q) {
+        double t0 = now_s();
+        size_t n = 0;
+        st = cobs_gpu_batch_hits_host(ix->scratch, q, num_results, overflow ? nullptr : hits + used,
+                                      overflow ? 0 : cap - used, &n);
+        ix->timers[4] += now_s() - t0;
+        if (st == COBS_GPU_ERR_CAPACITY || (overflow && st == COBS_GPU_ERR_ARG)) overflow = true;
+        else if (st != COBS_GPU_OK) return st;
+        used += n;
+        hit_offsets[q + 1] = used;
+    }
+    if (overflow) return fail(COBS_GPU_ERR_CAPACITY, "hit buffer too small; hit_offsets[nq] holds the needed size");
+    return COBS_GPU_OK;
+}
+
+cobs_gpu_status cobs_gpu_search(cobs_gpu_index* ix, const char* query, size_t len, double threshold,
+                                size_t num_results, cobs_gpu_hit* hits, size_t cap, size_t* n_hits) {
+    if (!ix || !query || !n_hits) return fail(COBS_GPU_ERR_ARG, "NULL argument");
+    size_t offs[2] = {0, 0};
+    cobs_gpu_status st = cobs_gpu_search_batch(ix, &query, &len, 1, threshold, num_results, hits, cap, offs, nullptr);
+    *n_hits = offs[1];
+    return st;
+}
+
+cobs_gpu_status cobs_gpu_counts(cobs_gpu_index* ix, const char* query, size_t len, uint32_t* counts, size_t cap) {
+    if (!ix || !query || !counts) return fail(COBS_GPU_ERR_ARG, "NULL argument");
+    if (cap < ix->total_counts) return fail(COBS_GPU_ERR_CAPACITY, "counts buffer too small");
+    cobs_gpu_status st = run_host_batch(ix, &query, &len, 1, 0.0, nullptr);
+    if (st != COBS_GPU_OK) return st;
+    double t0 = now_s();
+    st = fetch_counts(ix->scratch, 0, counts);
+    ix->timers[3] += now_s() - t0;
+    return st;
+}
+
+cobs_gpu_status cobs_gpu_timers(cobs_gpu_index* ix, double out[5], int reset) {
+    if (!ix) return fail(COBS_GPU_ERR_ARG, "NULL index");
+    if (out) std::memcpy(out, ix->timers, sizeof ix->timers);
+    if (reset) std::memset(ix->timers, 0, sizeof ix->timers);
+    return COBS_GPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,634 @@
+// cobs_amd/csrc/kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the
+// COBS query path.  Nothing here is translated from the reference: its CPU code
+// gathers rows into a scratch buffer and expands every row BYTE into eight
+// counter lanes through a lookup table (reference cobs/query/classic_search.cpp:
+// 643-1022); at HBM speed that is VALU-bound.  Here each lane owns a 16-byte
+// column chunk (128 documents) of the bit-sliced matrix and keeps the
+// per-document counters bit-sliced as well ("vertical counters"): NP bit planes
+// per 32-bit column word, updated with a Harley-Seal carry-save adder tree, so a
+// gathered row costs ~4.4 VALU ops per 32 documents and the kernel stays on the
+// HBM roofline.
+//
+//   K1 hash_kernel    canonicalise + XXH64 + (hash % S_p) per sub-index
+//                     (create_hashes, classic_search.cpp:66-107; canonicalize_kmer,
+//                      util/query.cpp:143-199; modulo at
+//                      classic_index/mmap_search_file.cpp:35 and
+//                      compact_index/mmap_search_file.cpp:58)
+//   K2 scan_kernel    row gather + AND over the H hash rows + per-document count
+//                     (+ optional threshold selection)
+//                     (read_from_disk, aggregate_rows :279-307, compute_counts
+//                      :643-1022, threshold filter of counts_to_result :127-132)
+//   synth_kernel / repitch_kernel   index staging helpers.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "device_types.hpp"
+#include "kernels.hpp"
+
+namespace cobs_amd {
+
+// ---------------------------------------------------------------------------
+// small device helpers
+
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+
+// exact n % d with the precomputed m = floor((2^64-1)/d); the estimate
+// q = hi64(n*m) is at most 2 below the true quotient.
+__device__ __forceinline__ uint32_t fast_mod(uint64_t n, uint64_t d, uint64_t m) {
+    uint64_t q = __umul64hi(n, m);
+    uint64_t r = n - q * d;
+    if (r >= d) r -= d;
+    if (r >= d) r -= d;
+    return (uint32_t)r;
+}
+
+__device__ __forceinline__ uint32_t fwd_base(uint32_t c) {
+    return (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? c : 0u;
+}
+__device__ __forceinline__ uint32_t rev_base(uint32_t c) {
+    return c == 'A' ? (uint32_t)'T' : c == 'C' ? (uint32_t)'G' : c == 'G' ? (uint32_t)'C'
+         : c == 'T' ? (uint32_t)'A' : 0u;
+}
+
+// ---------------------------------------------------------------------------
+// K1: one thread per query position.
+
+constexpr uint64_t XP1 = 0x9E3779B185EBCA87ULL;
+constexpr uint64_t XP2 = 0xC2B2AE3D27D4EB4FULL;
+constexpr uint64_t XP3 = 0x165667B19E3779F9ULL;
+constexpr uint64_t XP4 = 0x85EBCA77C2B2AE63ULL;
+constexpr uint64_t XP5 = 0x27D4EB2F165667C5ULL;
+
+__device__ __forceinline__ uint64_t xround(uint64_t acc, uint64_t in) {
+    return rotl64(acc + in * XP2, 31) * XP1;
+}
+__device__ __forceinline__ uint64_t xmerge(uint64_t h, uint64_t v) {
+    return (h ^ xround(0, v)) * XP1 + XP4;
+}
+
+// canonical k-mer as a byte accessor: mode 0 raw, 1 forward-mapped, 2 reverse complement
+struct KmerView {
+    const uint8_t* p;
+    uint32_t k;
+    uint32_t mode;
+    __device__ __forceinline__ uint32_t at(uint32_t i) const {
+        if (mode == 0) return p[i];
+        if (mode == 1) return fwd_base(p[i]);
+        return rev_base(p[k - 1 - i]);
+    }
+    __device__ __forceinline__ uint64_t le64(uint32_t i) const {
+        uint64_t v = 0;
+#pragma unroll
+        for (uint32_t b = 0; b < 8; ++b) v |= (uint64_t)at(i + b) << (8 * b);
+        return v;
+    }
+    __device__ __forceinline__ uint64_t le32(uint32_t i) const {
+        uint64_t v = 0;
+#pragma unroll
+        for (uint32_t b = 0; b < 4; ++b) v |= (uint64_t)at(i + b) << (8 * b);
+        return v;
+    }
+};
+
+// XXH64 of the viewed k bytes (public xxHash specification; any k)
+__device__ uint64_t xxh64_view(const KmerView& kv, uint64_t seed) {
+    const uint32_t len = kv.k;
+    uint32_t pos = 0;
+    uint64_t h;
+    if (len >= 32) {
+        uint64_t v1 = seed + XP1 + XP2, v2 = seed + XP2, v3 = seed, v4 = seed - XP1;
+        do {
+            v1 = xround(v1, kv.le64(pos));
+            v2 = xround(v2, kv.le64(pos + 8));
+            v3 = xround(v3, kv.le64(pos + 16));
+            v4 = xround(v4, kv.le64(pos + 24));
+            pos += 32;
+        } while (pos + 32 <= len);
+        h = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
+        h = xmerge(h, v1); h = xmerge(h, v2); h = xmerge(h, v3); h = xmerge(h, v4);
+    } else {
+        h = seed + XP5;
+    }
+    h += (uint64_t)len;
+    while (pos + 8 <= len) {
+        h ^= xround(0, kv.le64(pos));
+        h = rotl64(h, 27) * XP1 + XP4;
+        pos += 8;
+    }
+    if (pos + 4 <= len) {
+        h ^= kv.le32(pos) * XP1;
+        h = rotl64(h, 23) * XP2 + XP3;
+        pos += 4;
+    }
+    while (pos < len) {
+        h ^= (uint64_t)kv.at(pos) * XP5;
+        h = rotl64(h, 11) * XP1;
+        pos++;
+    }
+    h ^= h >> 33; h *= XP2; h ^= h >> 29; h *= XP3; h ^= h >> 32;
+    return h;
+}
+
+__global__ __launch_bounds__(256) void hash_kernel(HashArgs a, uint64_t total_threads) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total_threads) return;
+    // query of this thread: last q with span_off[q] <= gid
+    uint32_t lo = 0, hi = a.nq;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (a.span_off[mid] <= gid) lo = mid; else hi = mid;
+    }
+    const uint32_t q = lo;
+    const uint64_t qbase = a.span_off[q];
+    const uint32_t i = (uint32_t)(gid - qbase);
+    const uint32_t len = a.q_len[q];
+    const uint8_t* text = a.text + qbase;
+    const uint32_t k = a.term_size;
+
+    // canonicalize == 1: any character outside ACGT makes the query invalid
+    // (the reference dies, classic_search.cpp:93-96).  Every character of a
+    // query of length >= k lies in some k-mer.
+    if (a.canonicalize != 0 && i < len) {
+        if (fwd_base(text[i]) == 0) atomicMin(a.err_query, q);
+    }
+
+    const uint64_t b0 = a.blk_off[q];
+    const uint32_t nblk = (uint32_t)(a.blk_off[q + 1] - b0);
+    const uint32_t T = len - k + 1;
+    if (i >= nblk * 8u) return;
+    const uint32_t H = a.num_hashes;
+    const uint32_t blk = i >> 3, sub = i & 7u;
+    uint32_t* out = a.table + (b0 * a.npages) * (8ull * H);
+
+    if (i >= T) {       // padding term: the all-zero row of every sub-index
+        for (uint32_t p = 0; p < a.npages; ++p) {
+            const uint32_t zr = (uint32_t)a.pages[p].sig;
+            uint32_t* o = out + ((uint64_t)p * nblk + blk) * (8ull * H) + sub;
+            for (uint32_t j = 0; j < H; ++j) o[j * 8] = zr;
+        }
+        return;
+    }
+
+    KmerView kv{text + i, k, 0u};
+    if (a.canonicalize != 0) {
+        // util/query.cpp:143-199: first strict difference between the forward
+        // base and the complement of the mirrored base decides; the middle base
+        // of an odd k is not compared; ties keep the forward k-mer.
+        uint32_t mode = 1;
+        for (uint32_t s = 0; s < k / 2; ++s) {
+            const int f = (int)fwd_base(text[i + s]);
+            const int r = (int)rev_base(text[i + k - 1 - s]);
+            if (f < r) break;
+            if (f > r) { mode = 2; break; }
+        }
+        kv.mode = mode;
+    }
+    for (uint32_t j = 0; j < H; ++j) {
+        const uint64_t h = xxh64_view(kv, (uint64_t)j);
+        for (uint32_t p = 0; p < a.npages; ++p) {
+            const PageDev pg = a.pages[p];
+            out[((uint64_t)p * nblk + blk) * (8ull * H) + j * 8 + sub] = fast_mod(h, pg.sig, pg.magic);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K2: gather + AND + bit-sliced count.
+//
+// Work-group = (query q, tile of 64 sixteen-byte column chunks); its NW waves
+// split the query's 8-term blocks round-robin and merge their partial plane
+// counters through LDS at the end.  Lane l of every wave owns chunk
+// tile*64 + l: 128 documents, held as 4 column words x NP bit planes.
+
+// carry-save adder: (h, l) = a + b + c per bit position.  gfx950 has a
+// three-input boolean op (v_bitop3_b32, 8-bit truth table), so majority (0xE8)
+// and parity (0x96) are one instruction each: a CSA is 2 VALU ops.
+__device__ __forceinline__ void csa(uint32_t& h, uint32_t& l, uint32_t a, uint32_t b, uint32_t c) {
+    const uint32_t hh = __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8);
+    const uint32_t ll = __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+    h = hh;
+    l = ll;
+}
+
+// fold eight gathered row words into planes 0..2 of one column word; returns the
+// carry into plane 3 ("eights")
+template <int NP>
+__device__ __forceinline__ uint32_t absorb8(uint32_t (&pl)[NP], uint32_t x0, uint32_t x1, uint32_t x2,
+                                            uint32_t x3, uint32_t x4, uint32_t x5, uint32_t x6,
+                                            uint32_t x7) {
+    uint32_t t2a, t2b, f4a, f4b, e8;
+    csa(t2a, pl[0], pl[0], x0, x1);
+    csa(t2b, pl[0], pl[0], x2, x3);
+    csa(f4a, pl[1], pl[1], t2a, t2b);
+    csa(t2a, pl[0], pl[0], x4, x5);
+    csa(t2b, pl[0], pl[0], x6, x7);
+    csa(f4b, pl[1], pl[1], t2a, t2b);
+    csa(e8, pl[2], pl[2], f4a, f4b);
+    return e8;
+}
+
+// ripple a carry into planes FROM..NP-1
+template <int NP, int FROM>
+__device__ __forceinline__ void ripple(uint32_t (&pl)[NP], uint32_t carry) {
+#pragma unroll
+    for (int k = FROM; k < NP; ++k) {
+        const uint32_t t = pl[k] & carry;
+        pl[k] ^= carry;
+        carry = t;
+    }
+}
+
+// eights[w] = carry-outs of one 8-row block for the lane's 4 column words
+template <int NP>
+__device__ __forceinline__ void absorb_block(uint32_t (&pl)[4][NP], const uint4 (&X)[8],
+                                             uint32_t (&e8)[4]) {
+    e8[0] = absorb8<NP>(pl[0], X[0].x, X[1].x, X[2].x, X[3].x, X[4].x, X[5].x, X[6].x, X[7].x);
+    e8[1] = absorb8<NP>(pl[1], X[0].y, X[1].y, X[2].y, X[3].y, X[4].y, X[5].y, X[6].y, X[7].y);
+    e8[2] = absorb8<NP>(pl[2], X[0].z, X[1].z, X[2].z, X[3].z, X[4].z, X[5].z, X[6].z, X[7].z);
+    e8[3] = absorb8<NP>(pl[3], X[0].w, X[1].w, X[2].w, X[3].w, X[4].w, X[5].w, X[6].w, X[7].w);
+}
+
+// one block on its own: its eights go straight into plane 3 and up
+template <int NP>
+__device__ __forceinline__ void retire_single(uint32_t (&pl)[4][NP], const uint32_t (&e8)[4]) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) ripple<NP, 3>(pl[w], e8[w]);
+}
+
+// two blocks: add both eights into plane 3 with one more CSA, ripple the sixteens
+template <int NP>
+__device__ __forceinline__ void retire_pair(uint32_t (&pl)[4][NP], const uint32_t (&ea)[4],
+                                            const uint32_t (&eb)[4]) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        uint32_t s16;
+        csa(s16, pl[w][3], pl[w][3], ea[w], eb[w]);
+        ripple<NP, 4>(pl[w], s16);
+    }
+}
+
+__device__ __forceinline__ uint4 load_row(const uint8_t* lane_base, uint32_t row, uint32_t pitch) {
+    return *reinterpret_cast<const uint4*>(lane_base + (uint64_t)row * pitch);
+}
+
+__device__ __forceinline__ void issue_rows(uint4 (&X)[8], const uint8_t* lane_base, uint32_t pitch,
+                                           const uint4& i0, const uint4& i1) {
+    X[0] = load_row(lane_base, i0.x, pitch);
+    X[1] = load_row(lane_base, i0.y, pitch);
+    X[2] = load_row(lane_base, i0.z, pitch);
+    X[3] = load_row(lane_base, i0.w, pitch);
+    X[4] = load_row(lane_base, i1.x, pitch);
+    X[5] = load_row(lane_base, i1.y, pitch);
+    X[6] = load_row(lane_base, i1.z, pitch);
+    X[7] = load_row(lane_base, i1.w, pitch);
+}
+
+__device__ __forceinline__ void and_rows(uint4 (&X)[8], const uint4 (&Y)[8]) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        X[t].x &= Y[t].x; X[t].y &= Y[t].y; X[t].z &= Y[t].z; X[t].w &= Y[t].w;
+    }
+}
+
+template <int NP, int NW, bool H1, typename OutT>
+__global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // merge buffers: [NW/2 (min 1)][NP][64 lanes] of uint4
+    uint4* mbuf = reinterpret_cast<uint4*>(smem);
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
+    const uint32_t tile = blockIdx.x / a.nq;         // tile-major: co-resident groups share a sub-index
+    const uint32_t q = blockIdx.x - tile * a.nq;
+
+    const uint32_t g = tile * 64u + lane;
+    const uint32_t gc = g < a.total_chunks ? g : a.total_chunks - 1u;
+    const uint32_t pg = gc / a.cpp;
+    const uint32_t ch = gc - pg * a.cpp;
+    const uint8_t* lane_base = a.blob + a.pages[pg].base + (uint64_t)ch * 16u;
+    const uint32_t pitch = a.pitch;
+
+    const uint64_t b0 = a.blk_off[q];
+    const uint32_t nblk = (uint32_t)(a.blk_off[q + 1] - b0);
+    const uint32_t H = H1 ? 1u : a.num_hashes;
+    // row indices of this lane's sub-index: [block][hash][8]
+    const uint32_t* tab = a.table + (b0 * a.npages + (uint64_t)pg * nblk) * (8ull * H);
+
+    uint32_t pl[4][NP];
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int k = 0; k < NP; ++k) pl[w][k] = 0u;
+
+    // this wave's blocks are wave, wave + NW, ...: nw of them (wave-uniform)
+    const uint32_t nw = nblk > wave ? (nblk - wave + NW - 1) / NW : 0u;
+    uint32_t ea[4], eb[4];
+    if constexpr (H1) {
+        // Three-stage software pipeline, branch-free in the steady state:
+        //   row indices of block i+2 | row loads of block i+1 | CSA of block i
+        // so that 8..16 row loads (8..16 KiB per wave) are always in flight.
+        if (nw > 0) {
+            uint4 XA[8], XB[8];
+            const uint32_t* tw = tab + (uint64_t)wave * 8u;
+            const uint64_t step = (uint64_t)NW * 8u;            // u32 entries between this wave's blocks
+            const uint32_t last = nw - 1;
+            const uint4* t0 = reinterpret_cast<const uint4*>(tw);
+            uint4 i0a = t0[0], i0b = t0[1];
+            issue_rows(XA, lane_base, pitch, i0a, i0b);
+            const uint4* t1 = reinterpret_cast<const uint4*>(tw + step * (last < 1u ? last : 1u));
+            uint4 i1a = t1[0], i1b = t1[1];
+            uint32_t i = 0;
+            for (; i + 2 < nw; i += 2) {
+                // XA in flight = block i, (i1a,i1b) = indices of block i+1
+                const uint4* tn = reinterpret_cast<const uint4*>(tw + step * (i + 2));
+                i0a = tn[0]; i0b = tn[1];
+                issue_rows(XB, lane_base, pitch, i1a, i1b);
+                absorb_block<NP>(pl, XA, ea);
+                const uint32_t nx = i + 3 < last ? i + 3 : last;
+                const uint4* tm = reinterpret_cast<const uint4*>(tw + step * nx);
+                i1a = tm[0]; i1b = tm[1];
+                issue_rows(XA, lane_base, pitch, i0a, i0b);
+                absorb_block<NP>(pl, XB, eb);
+                retire_pair<NP>(pl, ea, eb);
+            }
+            // XA in flight = block i; one or two blocks left
+            if (i + 1 < nw) {
+                issue_rows(XB, lane_base, pitch, i1a, i1b);
+                absorb_block<NP>(pl, XA, ea);
+                absorb_block<NP>(pl, XB, eb);
+                retire_pair<NP>(pl, ea, eb);
+            } else {
+                absorb_block<NP>(pl, XA, ea);
+                retire_single<NP>(pl, ea);
+            }
+        }
+    } else {
+        // general H: AND the H hash rows of each term first (aggregate_rows)
+        uint4 X[8], Y[8];
+        for (uint32_t i = 0; i < nw; ++i) {
+            const uint32_t blk = wave + i * NW;
+            const uint4* t = reinterpret_cast<const uint4*>(tab + (uint64_t)blk * 8u * H);
+            issue_rows(X, lane_base, pitch, t[0], t[1]);
+            for (uint32_t j = 1; j < H; ++j) {
+                issue_rows(Y, lane_base, pitch, t[2 * j], t[2 * j + 1]);
+                and_rows(X, Y);
+            }
+            absorb_block<NP>(pl, X, ea);
+            retire_single<NP>(pl, ea);
+        }
+    }
+
+    // ---- merge the NW partial counters (tree over waves, bit-sliced adds) ----
+#pragma unroll
+    for (int s = 1; s < NW; s <<= 1) {
+        uint4* buf = mbuf + (size_t)(wave / (2 * s)) * NP * 64;
+        if ((wave & (2 * s - 1)) == (uint32_t)s) {
+#pragma unroll
+            for (int k = 0; k < NP; ++k)
+                buf[k * 64 + lane] = make_uint4(pl[0][k], pl[1][k], pl[2][k], pl[3][k]);
+        }
+        __syncthreads();
+        if ((wave & (2 * s - 1)) == 0u) {
+            uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const uint4 o = buf[k * 64 + lane];
+                uint32_t h;
+                csa(h, pl[0][k], pl[0][k], o.x, c0); c0 = h;
+                csa(h, pl[1][k], pl[1][k], o.y, c1); c1 = h;
+                csa(h, pl[2][k], pl[2][k], o.z, c2); c2 = h;
+                csa(h, pl[3][k], pl[3][k], o.w, c3); c3 = h;
+            }
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+            mbuf[k * 64 + lane] = make_uint4(pl[0][k], pl[1][k], pl[2][k], pl[3][k]);
+    }
+    __syncthreads();
+
+    // ---- expand planes -> per-document counts; every thread handles row bytes ----
+    const uint32_t* planes = reinterpret_cast<const uint32_t*>(mbuf);   // [NP][64*4 words]
+    const uint32_t thr = a.thresholds ? a.thresholds[q] : 0u;
+    OutT* crow = reinterpret_cast<OutT*>(a.counts) + (uint64_t)q * a.counts_stride + a.counts_offset;
+    constexpr int BYTES_PER_THREAD = 1024 / (NW * 64);
+#pragma unroll 1
+    for (int it = 0; it < BYTES_PER_THREAD; ++it) {
+        const uint32_t b = threadIdx.x + it * (NW * 64);      // row byte inside the tile
+        const uint32_t chunk = b >> 4, cb = b & 15u;
+        const uint32_t gch = tile * 64u + chunk;
+        bool valid = gch < a.total_chunks;
+        const uint32_t gcc = valid ? gch : 0u;
+        const uint32_t p2 = gcc / a.cpp;
+        const uint32_t byte_in_page = (gcc - p2 * a.cpp) * 16u + cb;
+        const PageDev pd = a.pages[p2];
+        valid = valid && byte_in_page < pd.valid_bytes;
+
+        uint32_t cnt[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) cnt[d] = 0u;
+        const uint32_t sh = (cb & 3u) * 8u;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const uint32_t v = (planes[(k * 64 + chunk) * 4 + (cb >> 2)] >> sh) & 0xFFu;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) cnt[d] |= ((v >> d) & 1u) << k;
+        }
+        const uint32_t slot = pd.slot0 + byte_in_page * 8u;
+        if (valid && a.write_counts) {
+            if constexpr (sizeof(OutT) == 2) {
+                uint4 o;
+                o.x = cnt[0] | (cnt[1] << 16); o.y = cnt[2] | (cnt[3] << 16);
+                o.z = cnt[4] | (cnt[5] << 16); o.w = cnt[6] | (cnt[7] << 16);
+                *reinterpret_cast<uint4*>(crow + slot) = o;
+            } else {
+                *reinterpret_cast<uint4*>(crow + slot) = make_uint4(cnt[0], cnt[1], cnt[2], cnt[3]);
+                *reinterpret_cast<uint4*>(crow + slot + 4) = make_uint4(cnt[4], cnt[5], cnt[6], cnt[7]);
+            }
+        }
+        if (a.thresholds) {
+            // counts_to_result filter: score >= threshold over real documents only
+            const uint32_t doc = pd.doc0 + byte_in_page * 8u;
+            uint32_t mask = 0u;
+            if (valid) {
+#pragma unroll
+                for (int d = 0; d < 8; ++d)
+                    if (cnt[d] >= thr && doc + d < a.num_docs) mask |= 1u << d;
+            }
+            if (__any(mask != 0u)) {
+                const uint32_t n = __popc(mask);
+                uint32_t incl = n;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t t = __shfl_up(incl, off);
+                    if (lane >= (uint32_t)off) incl += t;
+                }
+                const uint32_t total = __shfl(incl, 63);
+                uint32_t base = 0u;
+                if (lane == 63u) base = atomicAdd(a.hit_count, total);
+                base = __shfl(base, 63);
+                uint32_t pos = base + incl - n;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    if (mask & (1u << d)) {
+                        if (pos < a.hit_cap) a.hits[pos] = HitDev{q, a.part, doc + d, cnt[d]};
+                        ++pos;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// procedural index bits (same definition as the checker's generator)
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ uint64_t synth_word(uint64_t seed, uint32_t page, uint64_t row, uint64_t w) {
+    const uint64_t key = mix64(seed ^ mix64(((uint64_t)page << 40) ^ row));
+    const uint64_t c = key + w * 6;
+    const uint64_t x = mix64(c) & mix64(c + 1);
+    const uint64_t y = mix64(c + 2) & mix64(c + 3) & mix64(c + 4) & mix64(c + 5);
+    return x | y;
+}
+
+// grid: blockIdx.y = local page, grid-stride over (row, 8-byte word) of that page
+__global__ __launch_bounds__(256) void synth_kernel(SynthArgs a) {
+    const uint32_t p = blockIdx.y;
+    const PageDev pd = a.pages[p];
+    const uint32_t wpr = a.pitch / 8u;                    // words per HBM row
+    const uint64_t nwords = (pd.sig + 1) * (uint64_t)wpr; // incl. the zero row
+    const uint32_t fpage = a.first_page + p;
+    const uint64_t first_doc = (uint64_t)fpage * a.page_docs;
+    const uint64_t live = a.num_docs > first_doc ? a.num_docs - first_doc : 0;   // real documents of the page
+    uint64_t* dst = reinterpret_cast<uint64_t*>(a.blob + pd.base);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t row = i / wpr;
+        const uint32_t w = (uint32_t)(i - row * wpr);
+        uint64_t v = 0;
+        if (row < pd.sig) {
+            const uint64_t fb = a.col0 + (uint64_t)w * 8u;     // file-level byte of this word
+            // local bytes beyond valid_bytes and file bytes beyond the row are zero
+            const uint64_t gw = fb >> 3;
+            uint64_t x = synth_word(a.seed, fpage, row, gw);
+            if ((fb & 7u) != 0) {      // column shard not 8-byte aligned: stitch two words
+                const uint64_t x2 = synth_word(a.seed, fpage, row, gw + 1);
+                const uint32_t s = (uint32_t)(fb & 7u) * 8u;
+                x = (x >> s) | (x2 << (64 - s));
+            }
+#pragma unroll
+            for (uint32_t b = 0; b < 8; ++b) {
+                const uint64_t lb = (uint64_t)w * 8u + b;      // local byte
+                const uint64_t gb = fb + b;                    // file-level byte
+                uint32_t byte = (uint32_t)(x >> (8 * b)) & 0xFFu;
+                if (lb >= pd.valid_bytes || gb >= a.row_bytes || gb * 8 >= live) byte = 0;
+                else if (gb * 8 + 8 > live) byte &= (1u << (uint32_t)(live - gb * 8)) - 1u;
+                v |= (uint64_t)byte << (8 * b);
+            }
+        }
+        dst[i] = v;
+    }
+}
+
+// staged raw rows -> pitched rows (16 bytes per thread), zero padding to the pitch
+__global__ __launch_bounds__(256) void repitch_kernel(RepitchArgs a) {
+    const uint32_t cpr = a.dst_pitch / 16u;
+    const uint64_t total = a.rows * cpr;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t row = i / cpr;
+        const uint32_t c = (uint32_t)(i - row * cpr);
+        const uint8_t* s = a.src + row * a.src_pitch + a.src_col0 + (uint64_t)c * 16u;
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (uint32_t b = 0; b < 16; ++b) {
+            if (c * 16u + b < a.copy_bytes) w[b >> 2] |= (uint32_t)s[b] << (8 * (b & 3u));
+        }
+        *reinterpret_cast<uint4*>(a.dst + row * a.dst_pitch + (uint64_t)c * 16u) =
+            make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+
+hipError_t launch_hash(const HashArgs& a, uint64_t total_threads, hipStream_t stream) {
+    if (total_threads == 0) return hipSuccess;
+    const uint64_t blocks = (total_threads + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(hash_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, a, total_threads);
+    return hipGetLastError();
+}
+
+template <int NP, int NW, bool H1, typename OutT>
+static hipError_t launch_scan_inst(const ScanArgs& a, uint32_t ntiles, hipStream_t stream) {
+    const uint64_t groups = (uint64_t)ntiles * a.nq;
+    if (groups == 0) return hipSuccess;
+    if (groups > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    constexpr size_t lds = (size_t)(NW >= 2 ? NW / 2 : 1) * NP * 64 * sizeof(uint4);
+    auto kern = scan_kernel<NP, NW, H1, OutT>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((uint32_t)groups), dim3(NW * 64), lds, stream, a);
+    return hipGetLastError();
+}
+
+template <int NP, typename OutT>
+static hipError_t launch_scan_np(const ScanArgs& a, uint32_t ntiles, bool h1, hipStream_t stream) {
+    return h1 ? launch_scan_inst<NP, 4, true, OutT>(a, ntiles, stream)
+              : launch_scan_inst<NP, 4, false, OutT>(a, ntiles, stream);
+}
+
+int scan_planes_for(uint64_t max_terms) {
+    int need = 1;
+    while (need < 64 && (max_terms >> need) != 0) ++need;     // bit width of max_terms
+    static const int avail[] = {4, 8, 10, 12, 16, 20, 24, 32};
+    for (int v : avail)
+        if (v >= need) return v;
+    return -1;
+}
+
+hipError_t launch_scan(const ScanArgs& a, uint32_t ntiles, int planes, hipStream_t stream) {
+    const bool h1 = a.num_hashes == 1;
+    switch (planes) {
+    case 4: return launch_scan_np<4, uint16_t>(a, ntiles, h1, stream);
+    case 8: return launch_scan_np<8, uint16_t>(a, ntiles, h1, stream);
+    case 10: return launch_scan_np<10, uint16_t>(a, ntiles, h1, stream);
+    case 12: return launch_scan_np<12, uint16_t>(a, ntiles, h1, stream);
+    case 16: return launch_scan_np<16, uint16_t>(a, ntiles, h1, stream);
+    case 20: return launch_scan_np<20, uint32_t>(a, ntiles, h1, stream);
+    case 24: return launch_scan_np<24, uint32_t>(a, ntiles, h1, stream);
+    case 32: return launch_scan_np<32, uint32_t>(a, ntiles, h1, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_synth(const SynthArgs& a, hipStream_t stream) {
+    if (a.npages == 0) return hipSuccess;
+    hipLaunchKernelGGL(synth_kernel, dim3(2048, a.npages), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_repitch(const RepitchArgs& a, hipStream_t stream) {
+    if (a.rows == 0) return hipSuccess;
+    const uint64_t total = a.rows * (a.dst_pitch / 16u);
+    uint64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(repitch_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace cobs_amd

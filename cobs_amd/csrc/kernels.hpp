@@ -1,0 +1,25 @@
+// cobs_amd/csrc/kernels.hpp -- host-callable launchers of the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+#include "device_types.hpp"
+
+namespace cobs_amd {
+
+// K1: one thread per query position (total_threads = span_off[nq]).
+hipError_t launch_hash(const HashArgs& a, uint64_t total_threads, hipStream_t stream);
+
+// Smallest instantiated plane count that can hold counts up to max_terms
+// (4, 8, 10, 12, 16 -> u16 scores; 20, 24, 32 -> u32 scores); -1 if none.
+int scan_planes_for(uint64_t max_terms);
+inline uint32_t scan_score_bytes(int planes) { return planes <= 16 ? 2u : 4u; }
+
+// K2: ntiles * nq work-groups of 4 waves.
+hipError_t launch_scan(const ScanArgs& a, uint32_t ntiles, int planes, hipStream_t stream);
+
+hipError_t launch_synth(const SynthArgs& a, hipStream_t stream);
+hipError_t launch_repitch(const RepitchArgs& a, hipStream_t stream);
+
+}  // namespace cobs_amd

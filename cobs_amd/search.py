@@ -1,0 +1,251 @@
+"""Host-side mirror of the reference's Python operator API for the query path.
+
+Reference: python/module.cpp:351-386 --
+    cobs_index.Search(path).search(query, threshold=0.0, num_results=0)
+        -> list[SearchResult(doc_name: str, score: int)]
+Same names, argument meaning and defaults.  Everything is computed by
+libcobs_gpu.so on the GPU; this file only marshals arguments.  Where the
+reference terminates the process on bad input (short query, non-ACGT base,
+unreadable index: classic_search.cpp:431-433, :93-96, :61-63) this mirror raises
+CobsGpuError carrying the C-ABI status instead.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _capi
+from ._capi import CobsGpuError, Hit, IndexInfo, Options, Synth, check
+
+
+class SearchResult:
+    """cobs::SearchResult (query/search.hpp:17-27) as exposed by python/module.cpp:351-362."""
+    __slots__ = ("doc_name", "score")
+
+    def __init__(self, doc_name="", score=0):
+        self.doc_name = doc_name
+        self.score = score
+
+    def __repr__(self):
+        return "SearchResult(doc_name=%r, score=%d)" % (self.doc_name, self.score)
+
+    def __eq__(self, other):
+        return (isinstance(other, SearchResult) and self.doc_name == other.doc_name
+                and self.score == other.score)
+
+
+def _as_bytes(q):
+    return q.encode("latin-1") if isinstance(q, str) else bytes(q)
+
+
+def _options(device, shard_rank, shard_count):
+    o = Options()
+    o.struct_size = C.sizeof(Options)
+    o.device = device
+    o.shard_rank = shard_rank
+    o.shard_count = shard_count
+    return o
+
+
+class Search:
+    """cobs_index.Search: open one or several index files (classic or compact,
+    auto-detected per file) and query them on the GPU."""
+
+    def __init__(self, path, device=-1, shard_rank=0, shard_count=1, _handle=None):
+        self._lib = _capi.load()
+        self._h = C.c_void_p()
+        if _handle is not None:
+            self._h = _handle
+            return
+        paths = [path] if isinstance(path, (str, bytes, os.PathLike)) else list(path)
+        arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+        opts = _options(device, shard_rank, shard_count)
+        check(self._lib.cobs_gpu_open(arr, len(paths), C.byref(opts), C.byref(self._h)))
+
+    @classmethod
+    def synthetic(cls, kind, signature_sizes, num_docs, page_size=0, term_size=31, canonicalize=1,
+                  num_hashes=1, seed=1, device=-1, shard_rank=0, shard_count=1):
+        """Procedural index generated directly in HBM (benchmark / large parity runs)."""
+        lib = _capi.load()
+        sigs = (C.c_uint64 * len(signature_sizes))(*[int(s) for s in signature_sizes])
+        d = Synth()
+        d.kind = 1 if kind in (1, "compact") else 0
+        d.term_size, d.canonicalize, d.num_pages = term_size, canonicalize, len(signature_sizes)
+        d.num_hashes, d.page_size, d.num_docs, d.seed = num_hashes, page_size, num_docs, seed
+        d.signature_sizes = C.cast(sigs, C.POINTER(C.c_uint64))
+        h = C.c_void_p()
+        opts = _options(device, shard_rank, shard_count)
+        check(lib.cobs_gpu_open_synthetic(C.byref(d), C.byref(opts), C.byref(h)))
+        return cls(None, _handle=h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cobs_gpu_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- geometry ------------------------------------------------------------
+    @property
+    def num_files(self):
+        return int(self._lib.cobs_gpu_num_files(self._h))
+
+    def info(self, file_no=0):
+        i = IndexInfo()
+        check(self._lib.cobs_gpu_info(self._h, file_no, C.byref(i)))
+        return i
+
+    @property
+    def total_counts(self):
+        return int(self._lib.cobs_gpu_total_counts(self._h))
+
+    @property
+    def local_counts(self):
+        return int(self._lib.cobs_gpu_local_counts(self._h))
+
+    def doc_name(self, file_no, doc):
+        return self._lib.cobs_gpu_doc_name(self._h, file_no, doc).decode()
+
+    def signature_size(self, file_no=0, page=0):
+        return int(self._lib.cobs_gpu_signature_size(self._h, file_no, page))
+
+    def read_row(self, file_no, page, row, nbytes):
+        out = np.zeros(nbytes, dtype=np.uint8)
+        check(self._lib.cobs_gpu_read_row(self._h, file_no, page, row, out.ctypes.data, nbytes))
+        return out
+
+    # -- queries -------------------------------------------------------------
+    def search(self, query, threshold=0.0, num_results=0):
+        """Same contract as cobs_index.Search.search (python/module.cpp:372-386)."""
+        return self.search_batch([query], threshold, num_results)[0]
+
+    def search_hits(self, queries, threshold=0.0, num_results=0):
+        """-> per query: list of (file_no, doc, score) in result order."""
+        qs = [_as_bytes(q) for q in queries]
+        nq = len(qs)
+        arr = (C.c_char_p * max(nq, 1))(*qs)
+        lens = (C.c_size_t * max(nq, 1))(*[len(q) for q in qs])
+        cap = max(1, nq * (self.total_counts if threshold <= 0 or num_results == 0 else
+                           min(num_results, self.total_counts)))
+        offs = (C.c_size_t * (nq + 1))()
+        bad = C.c_size_t(0)
+        while True:
+            hits = (Hit * cap)()
+            st = self._lib.cobs_gpu_search_batch(self._h, arr, lens, nq, float(threshold),
+                                                 int(num_results), hits, cap, offs, C.byref(bad))
+            if st == _capi.ERR_CAPACITY and offs[nq] > cap:
+                cap = int(offs[nq])
+                continue
+            check(st)
+            break
+        return [[(hits[i].file_no, hits[i].doc, hits[i].score) for i in range(offs[q], offs[q + 1])]
+                for q in range(nq)]
+
+    def search_batch(self, queries, threshold=0.0, num_results=0):
+        out = []
+        for per_query in self.search_hits(queries, threshold, num_results):
+            out.append([SearchResult(self.doc_name(f, d), s) for (f, d, s) in per_query])
+        return out
+
+    def counts(self, query):
+        """Raw per-document counts (incl. padding slots) over all files, uint32."""
+        q = _as_bytes(query)
+        out = np.zeros(self.total_counts, dtype=np.uint32)
+        check(self._lib.cobs_gpu_counts(self._h, q, len(q), out.ctypes.data, out.size))
+        return out
+
+    def timers(self, reset=False):
+        t = (C.c_double * 5)()
+        check(self._lib.cobs_gpu_timers(self._h, C.byref(t), 1 if reset else 0))
+        return dict(zip(["hashes", "h2d", "scan", "d2h", "rank"], list(t)))
+
+
+class _DevArray:
+    """__cuda_array_interface__ view of HBM owned by libcobs_gpu (zero copy into torch)."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False),
+                                         "version": 2, "strides": None}
+        self._owner = owner
+
+
+class Batch:
+    """Device-resident query batch (cobs_gpu_batch_*): inputs are copied to HBM
+    once, run() launches the hot path asynchronously, counts stay in HBM."""
+
+    def __init__(self, search, max_queries=0, max_query_len=0):
+        self._s = search
+        self._lib = search._lib
+        self._h = C.c_void_p()
+        check(self._lib.cobs_gpu_batch_create(search._h, max_queries, max_query_len, C.byref(self._h)))
+        self.nq = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cobs_gpu_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_queries(self, queries):
+        qs = [_as_bytes(q) for q in queries]
+        arr = (C.c_char_p * max(len(qs), 1))(*qs)
+        lens = (C.c_size_t * max(len(qs), 1))(*[len(q) for q in qs])
+        check(self._lib.cobs_gpu_batch_set_queries(self._h, arr, lens, len(qs)))
+        self.nq = len(qs)
+
+    def run(self, threshold=0.0, stream=0):
+        check(self._lib.cobs_gpu_batch_run(self._h, float(threshold), C.c_void_p(stream)))
+
+    def sync(self, stream=0):
+        bad = C.c_size_t(0)
+        check(self._lib.cobs_gpu_batch_sync(self._h, C.c_void_p(stream), C.byref(bad)))
+
+    def counts_device(self):
+        """-> (device pointer, element bytes, row stride bytes)"""
+        eb, rs = C.c_uint32(0), C.c_uint64(0)
+        p = self._lib.cobs_gpu_batch_counts_device(self._h, C.byref(eb), C.byref(rs))
+        return p, eb.value, rs.value
+
+    def counts_tensor(self):
+        """torch view [nq, local_counts] (int16 / int32 bit patterns of u16 / u32 scores)."""
+        import torch
+        p, eb, rs = self.counts_device()
+        n = self._s.local_counts
+        if self.nq == 0 or n == 0:
+            return torch.empty((self.nq, n), dtype=torch.int16 if eb == 2 else torch.int32, device="cuda")
+        return torch.as_tensor(_DevArray(p, (self.nq, n), "<i2" if eb == 2 else "<i4", self), device="cuda")
+
+    def counts_host(self, query_no):
+        out = np.zeros(self._s.total_counts, dtype=np.uint32)
+        check(self._lib.cobs_gpu_batch_counts_host(self._h, query_no, out.ctypes.data, out.size))
+        return out
+
+    def hits_host(self, query_no, num_results=0):
+        cap = max(1, self._s.total_counts if num_results == 0 else min(num_results, self._s.total_counts))
+        hits = (Hit * cap)()
+        n = C.c_size_t(0)
+        check(self._lib.cobs_gpu_batch_hits_host(self._h, query_no, int(num_results), hits, cap, C.byref(n)))
+        return [(hits[i].file_no, hits[i].doc, hits[i].score) for i in range(n.value)]
+
+    def stats(self):
+        s = (C.c_uint64 * 4)()
+        check(self._lib.cobs_gpu_batch_stats(self._h, C.byref(s)))
+        return {"algorithmic_bytes": int(s[0]), "scan_launches": int(s[1]), "kmer_lookups": int(s[2]),
+                "table_bytes": int(s[3])}
+
+    def kernel_ms(self):
+        a, b = C.c_float(0), C.c_float(0)
+        check(self._lib.cobs_gpu_batch_kernel_ms(self._h, C.byref(a), C.byref(b)))
+        return {"scan_ms": a.value, "hash_ms": b.value}
+
+
+__all__ = ["Search", "SearchResult", "Batch", "CobsGpuError"]

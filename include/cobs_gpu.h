@@ -1,0 +1,202 @@
+/*
+ * include/cobs_gpu.h -- C ABI of libcobs_gpu.so, the MI355X (gfx950) query
+ * engine for COBS bit-sliced signature indexes (.cobs_classic / .cobs_compact).
+ *
+ * This is the drop-in boundary for ONE path of bingmann/cobs:
+ * cobs::ClassicSearch::search (reference cobs/query/classic_search.cpp:403-505)
+ * and everything it calls.  Each entry point names the reference interface it
+ * replaces.  Plain pointers and sizes only; no C++ / torch types.  Functions
+ * return a cobs_gpu_status; they never abort or exit (the reference terminates
+ * the process on bad input, see INTEGRATION.md for the mapping).
+ *
+ * Threading: one handle / one batch = one in-flight call.  Different handles
+ * may be used from different threads.
+ */
+#ifndef COBS_GPU_H
+#define COBS_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COBS_GPU_ABI_VERSION 1
+
+typedef enum cobs_gpu_status {
+    COBS_GPU_OK = 0,
+    COBS_GPU_ERR_OPEN = 1,            /* index file cannot be opened / mapped   (util/query.cpp:24-31) */
+    COBS_GPU_ERR_FORMAT = 2,          /* neither classic nor compact header     (classic_search.cpp:61-63) */
+    COBS_GPU_ERR_QUERY_TOO_SHORT = 3, /* "query too short, needs to be at least k characters" (:431-433) */
+    COBS_GPU_ERR_INVALID_BASE = 4,    /* "Invalid DNA base pair in query string" (:93-96) */
+    COBS_GPU_ERR_QUERY_TOO_LONG = 5,  /* "query too long" (:323-327, :501-503) */
+    COBS_GPU_ERR_HIP = 6,             /* HIP runtime error, text in cobs_gpu_last_error() */
+    COBS_GPU_ERR_ARG = 7,             /* NULL / out-of-range argument */
+    COBS_GPU_ERR_UNSUPPORTED = 8,     /* legal index the engine cannot hold (e.g. signature_size >= 2^32) */
+    COBS_GPU_ERR_CAPACITY = 9,        /* caller buffer too small; *n_out holds the needed size */
+    COBS_GPU_ERR_NO_DEVICE = 10       /* no HIP device (the library has no CPU fallback) */
+} cobs_gpu_status;
+
+/* Opaque handles. */
+typedef struct cobs_gpu_index cobs_gpu_index;   /* >= 1 index files resident in HBM  (ClassicSearch::index_files_) */
+typedef struct cobs_gpu_batch cobs_gpu_batch;   /* device workspace of one query batch */
+
+typedef struct cobs_gpu_options {
+    uint32_t struct_size;     /* sizeof(cobs_gpu_options) */
+    int32_t device;           /* HIP device ordinal, -1 = current device */
+    /* Multi-GPU sharding by sub-index block: this process keeps the
+     * sub-indexes (compact) / row-byte columns (classic) of shard
+     * shard_rank out of shard_count; counts of other shards' documents are 0.  */
+    uint32_t shard_rank;
+    uint32_t shard_count;     /* 0 or 1 = unsharded */
+    uint32_t waves_per_group; /* 0 = default (4): waves that split one query's terms */
+    uint32_t reserved;
+} cobs_gpu_options;
+
+/* Geometry of one opened index file (IndexSearchFile getters, query/index_file.hpp:19-35). */
+typedef struct cobs_gpu_index_info {
+    uint32_t kind;            /* 0 classic, 1 compact */
+    uint32_t term_size;       /* k */
+    uint32_t canonicalize;
+    uint32_t num_pages;       /* sub-indexes; classic: 1 */
+    uint64_t num_hashes;
+    uint64_t page_size;       /* as IndexSearchFile::page_size(): classic reports 1 */
+    uint64_t row_size;        /* bytes per full row: classic ceil(D/8); compact page_size * P */
+    uint64_t counts_size;     /* 8 * row_size: score slots incl. padding documents */
+    uint64_t num_docs;        /* file_names().size() */
+    uint64_t doc_offset;      /* first score slot of this file in a concatenated count vector */
+    uint64_t hbm_bytes;       /* bytes this file occupies in HBM on this process */
+    uint32_t first_page;      /* sub-index range held by this shard: [first_page, end_page) */
+    uint32_t end_page;
+    uint64_t slot_begin;      /* score slots of this file computed by this shard: */
+    uint64_t slot_count;      /*   [slot_begin, slot_begin + slot_count), multiples of 8 */
+    uint64_t local_offset;    /* where those slots start in this process' local count vector */
+} cobs_gpu_index_info;
+
+/* One ranked hit (cobs::SearchResult, query/search.hpp:17-27, plus ids). */
+typedef struct cobs_gpu_hit {
+    uint32_t file_no;         /* which index file of the handle */
+    uint32_t doc;             /* document id inside that file */
+    uint32_t score;           /* number of matching k-mers */
+} cobs_gpu_hit;
+
+/* Parameters of a procedural (synthetic) index filled directly in HBM; the
+ * benchmark-sized stand-in for `cobs classic-construct-random`
+ * (construction/classic_index.cpp:661-725).  Bits are a pure function of
+ * (seed, page, row, byte) with density ~0.297 so that any row can be recomputed
+ * by a checker; documents >= num_docs have no bits. */
+typedef struct cobs_gpu_synth {
+    uint32_t kind;            /* 0 classic, 1 compact */
+    uint32_t term_size;
+    uint32_t canonicalize;
+    uint32_t num_pages;       /* classic: 1 */
+    uint64_t num_hashes;
+    uint64_t page_size;       /* compact only */
+    uint64_t num_docs;
+    uint64_t seed;
+    const uint64_t* signature_sizes;   /* num_pages entries */
+} cobs_gpu_synth;
+
+/* ---- library ----------------------------------------------------------- */
+uint32_t cobs_gpu_abi_version(void);
+/* thread-local text of the last error on this thread */
+const char* cobs_gpu_last_error(void);
+/* number of visible HIP devices (0 if none) */
+int cobs_gpu_device_count(void);
+
+/* ---- index ------------------------------------------------------------- */
+/* ClassicSearch(std::string path) / ClassicSearch(vector<IndexSearchFile>)
+ * (classic_search.cpp:41-64): sniff classic vs compact per file, stage every
+ * sub-index into HBM (replaces initialize_mmap, util/query.cpp:38-88).        */
+cobs_gpu_status cobs_gpu_open(const char* const* paths, size_t n_paths,
+                              const cobs_gpu_options* opts, cobs_gpu_index** out);
+cobs_gpu_status cobs_gpu_open_synthetic(const cobs_gpu_synth* desc,
+                                        const cobs_gpu_options* opts, cobs_gpu_index** out);
+void cobs_gpu_close(cobs_gpu_index* ix);
+
+size_t cobs_gpu_num_files(const cobs_gpu_index* ix);
+cobs_gpu_status cobs_gpu_info(const cobs_gpu_index* ix, size_t file_no, cobs_gpu_index_info* info);
+/* signature_size of sub-index `page` of file `file_no` (0 if out of range) */
+uint64_t cobs_gpu_signature_size(const cobs_gpu_index* ix, size_t file_no, uint32_t page);
+/* file_names()[doc].c_str(): owned by the handle, valid until cobs_gpu_close */
+const char* cobs_gpu_doc_name(const cobs_gpu_index* ix, size_t file_no, uint64_t doc);
+/* sum of counts_size over all files = length of one query's count vector */
+uint64_t cobs_gpu_total_counts(const cobs_gpu_index* ix);
+/* score slots per query held by THIS shard (== cobs_gpu_total_counts when
+ * unsharded); device count rows have this many elements */
+uint64_t cobs_gpu_local_counts(const cobs_gpu_index* ix);
+/* copy `n` bytes of row `row` of sub-index `page` back from HBM (diagnostics/tests) */
+cobs_gpu_status cobs_gpu_read_row(const cobs_gpu_index* ix, size_t file_no, uint32_t page,
+                                  uint64_t row, uint8_t* out, size_t n);
+
+/* ---- search (host buffers in, host buffers out) ------------------------ */
+/* ClassicSearch::search (classic_search.cpp:403-505): hits ordered by score
+ * descending, ties by (file_no, doc) ascending; no ordering when the query has a
+ * single hash in total (max_counts <= 1, :136,:179).  num_results == 0 = all.  */
+cobs_gpu_status cobs_gpu_search(cobs_gpu_index* ix, const char* query, size_t len,
+                                double threshold, size_t num_results,
+                                cobs_gpu_hit* hits, size_t cap, size_t* n_hits);
+
+/* The same for nq queries in one device pass.  hit_offsets has nq+1 entries;
+ * hits of query i are hits[hit_offsets[i] .. hit_offsets[i+1]).  A query with
+ * bad input fails the whole call; *bad_query (optional) receives its index.  */
+cobs_gpu_status cobs_gpu_search_batch(cobs_gpu_index* ix, const char* const* queries,
+                                      const size_t* lens, size_t nq,
+                                      double threshold, size_t num_results,
+                                      cobs_gpu_hit* hits, size_t cap, size_t* hit_offsets,
+                                      size_t* bad_query);
+
+/* Raw per-document counts of one query over all files (the reference's
+ * score_list before counts_to_result, classic_search.cpp:456-467), widened to
+ * u32; cap >= cobs_gpu_total_counts(). */
+cobs_gpu_status cobs_gpu_counts(cobs_gpu_index* ix, const char* query, size_t len,
+                                uint32_t* counts, size_t cap);
+
+/* ---- device-resident batches (benchmark / multi-GPU plumbing) ---------- */
+/* Workspace for up to max_queries queries of up to max_query_len characters. */
+cobs_gpu_status cobs_gpu_batch_create(cobs_gpu_index* ix, size_t max_queries,
+                                      size_t max_query_len, cobs_gpu_batch** out);
+void cobs_gpu_batch_destroy(cobs_gpu_batch* b);
+/* Copy query text to HBM (H2D) and validate lengths.  After this call the
+ * inputs of cobs_gpu_batch_run are resident in HBM. */
+cobs_gpu_status cobs_gpu_batch_set_queries(cobs_gpu_batch* b, const char* const* queries,
+                                           const size_t* lens, size_t nq);
+/* One pass of the hot path over the batch, asynchronously on `hip_stream`
+ * (a hipStream_t, NULL = default stream): K1 canonicalise + XXH64 + row index
+ * per sub-index (create_hashes, :66-107), K2 row gather + AND + bit-sliced
+ * per-document count (read_from_disk / aggregate_rows / compute_counts,
+ * :279-307, :643-1022), and, if threshold > 0, on-device selection of documents
+ * with count >= ceil(threshold * T) (:127-132).  Counts stay in HBM.          */
+cobs_gpu_status cobs_gpu_batch_run(cobs_gpu_batch* b, double threshold, void* hip_stream);
+/* wait for the stream and fetch device-side error flags (invalid bases, ...) */
+cobs_gpu_status cobs_gpu_batch_sync(cobs_gpu_batch* b, void* hip_stream, size_t* bad_query);
+/* Device pointer to the counts of the last run: row i (query i) starts at
+ * ptr + i * row_stride_bytes and holds cobs_gpu_local_counts() elements of
+ * elem_bytes (2 or 4) each.  Valid until the batch is destroyed. */
+void* cobs_gpu_batch_counts_device(cobs_gpu_batch* b, uint32_t* elem_bytes, uint64_t* row_stride_bytes);
+/* D2H of one query's counts widened to u32 */
+cobs_gpu_status cobs_gpu_batch_counts_host(cobs_gpu_batch* b, size_t query_no, uint32_t* counts, size_t cap);
+/* D2H + rank the hits of query `query_no` of the last run */
+cobs_gpu_status cobs_gpu_batch_hits_host(cobs_gpu_batch* b, size_t query_no, size_t num_results,
+                                         cobs_gpu_hit* hits, size_t cap, size_t* n_hits);
+
+/* Per-launch bookkeeping of the last cobs_gpu_batch_run (for rooflines):
+ * out[0] = algorithmic bytes of the scan kernel(s): sum over queries of
+ *          T * H * (row bytes gathered) + score bytes written
+ * out[1] = number of scan-kernel launches, out[2] = k-mer lookups (sum T),
+ * out[3] = bytes of row-index table written by K1 and read by K2.            */
+cobs_gpu_status cobs_gpu_batch_stats(const cobs_gpu_batch* b, uint64_t out[4]);
+/* HIP-event duration (ms) of the scan kernel(s) / hash kernel of the last run;
+ * events are recorded on the stream the kernels were launched on.  Call after
+ * cobs_gpu_batch_sync. */
+cobs_gpu_status cobs_gpu_batch_kernel_ms(cobs_gpu_batch* b, float* scan_ms, float* hash_ms);
+
+/* phase timers of the host-buffer search API since the last reset, seconds:
+ * out[0] hashes (K1), out[1] h2d, out[2] scan (K2), out[3] d2h, out[4] rank  */
+cobs_gpu_status cobs_gpu_timers(cobs_gpu_index* ix, double out[5], int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COBS_GPU_H */

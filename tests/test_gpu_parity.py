@@ -1,0 +1,237 @@
+"""GPU parity: libcobs_gpu.so (HIP, through the C ABI) against the oracle, bit-exact.
+
+Integer path: every per-document count and every ranked result must be
+identical (no tolerance).  Edge cases follow the reference's own tests
+(tests/classic_index_query.cpp, tests/compact_index_query.cpp) and SURVEY 8c.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+Q50 = b"AGTCAACGCTAAGGCATTTCCCCCCTGCCTCCTGCCTGCTGCCAAGCCCT"
+
+
+def _check_index(gpu, O, paths, queries, thresholds=(0.0, 0.3, 0.8, 1.0), limits=(0, 1, 5)):
+    paths = paths if isinstance(paths, list) else [paths]
+    s = gpu.Search(paths if len(paths) > 1 else paths[0])
+    ixs = [O.Index.open(p) for p in paths]
+    for q in queries:
+        want = np.concatenate([ix.counts(q) for ix in ixs])
+        got = s.counts(q)
+        assert got.dtype == np.uint32 and got.shape == want.shape
+        assert np.array_equal(got, want), "counts differ for query of %d chars" % len(q)
+    for t in thresholds:
+        for lim in limits:
+            got = s.search_hits(queries, t, lim)
+            for q, g in zip(queries, got):
+                assert g == cases.oracle_results(ixs, q, t, lim), (t, lim, len(q))
+    return s
+
+
+def test_c1_fixture_known_answers(gpu_lib, oracle, golden_dir):
+    """BASELINE config 1 / reference python/tests/test_cobs_index.py:22-61"""
+    for name in ("c1.cobs_classic", "c1.cobs_compact"):
+        s = gpu_lib.Search(os.path.join(golden_dir, name))
+        r = s.search(Q50.decode())
+        assert len(r) == 7
+        assert r[0].doc_name == "sample1" and r[0].score == 20
+        assert [(x.doc_name, x.score) for x in r] == [
+            ("sample1", 20), ("sample7", 3), ("sample2", 1), ("sample4", 1), ("sample6", 1),
+            ("sample3", 0), ("sample5", 0)]
+        assert list(s.counts(Q50)[:8]) == [20, 1, 0, 1, 0, 1, 3, 0]
+        # threshold = ceil(threshold * T) in double
+        assert len(s.search(Q50, 0.05)) == 5
+        assert len(s.search(Q50, 0.051)) == 2
+        assert [(x.doc_name, x.score) for x in s.search(Q50, 0.15)] == [("sample1", 20), ("sample7", 3)]
+        assert len(s.search(Q50, 0.1500001)) == 1
+        # single k-mer, one hash: no sorting, document order
+        assert [(x.doc_name, x.score) for x in s.search(Q50[5:36])] == [
+            ("sample1", 1), ("sample2", 0), ("sample3", 0), ("sample4", 0), ("sample5", 0),
+            ("sample6", 0), ("sample7", 1)]
+    _check_index(gpu_lib, oracle, os.path.join(golden_dir, "c1.cobs_classic"), [Q50, Q50[:31], Q50[3:40]])
+    _check_index(gpu_lib, oracle, os.path.join(golden_dir, "c1.cobs_compact"), [Q50, Q50[:31], Q50[3:40]])
+
+
+def test_c1_two_indexes_ordering(gpu_lib, oracle, golden_dir):
+    """several -i files: ties by (index number, document) (classic_search.cpp:158-201)"""
+    paths = [os.path.join(golden_dir, "c1.cobs_compact"), os.path.join(golden_dir, "c1.cobs_classic")]
+    s = _check_index(gpu_lib, oracle, paths, [Q50, Q50[:33]])
+    assert [(x.doc_name, x.score) for x in s.search(Q50)] == [
+        ("sample1", 20), ("sample1", 20), ("sample7", 3), ("sample7", 3), ("sample2", 1),
+        ("sample4", 1), ("sample6", 1), ("sample2", 1), ("sample4", 1), ("sample6", 1),
+        ("sample3", 0), ("sample5", 0), ("sample3", 0), ("sample5", 0)]
+
+
+@pytest.mark.parametrize("num_hashes", [1, 3])
+@pytest.mark.parametrize("canonicalize", [0, 1])
+def test_classic_random_bits(gpu_lib, oracle, tmp_path, num_hashes, canonicalize):
+    """hand-built classic indexes, D not a multiple of 8 / of 128, all plane widths"""
+    for D, S, seed in ((7, 997, 1), (130, 5003, 2), (1001, 4099, 3), (10007, 2053, 4)):
+        q_long = oracle.random_sequence(1030, 100 + seed)
+        p = cases.make_classic(cases.tmp(tmp_path, "r%d.cobs_classic" % D), D, S, num_hashes, 31,
+                               canonicalize, 0.3, seed,
+                               planted={0: 1.0, D // 2: 0.85, D - 1: 0.5}, query=q_long)
+        # T = 1, 8, 9, 20, 255, 256, 270, 1000 cross the u8/u16 boundary and the plane counts
+        queries = [q_long[:31], q_long[:38], q_long[:39], q_long[:50], q_long[:285], q_long[:286],
+                   q_long[:300], q_long]
+        _check_index(gpu_lib, oracle, p, queries)
+
+
+@pytest.mark.parametrize("page_size,pages", [(2, 5), (8, 3), (16, 4), (24, 3), (64, 2), (200, 3)])
+def test_compact_random_bits(gpu_lib, oracle, tmp_path, page_size, pages):
+    """variable signature size per sub-index, page sizes that are not multiples of 16"""
+    rng = np.random.default_rng(page_size)
+    sigs = [int(x) for x in rng.integers(300, 3000, size=pages)]
+    D = (pages - 1) * 8 * page_size + max(1, 8 * page_size - 3)
+    q_long = oracle.random_sequence(600, 7 + page_size)
+    planted = {0: 1.0, D - 1: 0.9, D // 2: 0.4}
+    for H in (1, 2):
+        p = cases.make_compact(cases.tmp(tmp_path, "c%d_%d.cobs_compact" % (page_size, H)), D, page_size,
+                               sigs, H, 31, 1, 0.3, page_size, planted=planted, query=q_long)
+        _check_index(gpu_lib, oracle, p, [q_long[:31], q_long[:131], q_long[:400], q_long])
+
+
+def test_other_term_sizes(gpu_lib, oracle, tmp_path):
+    """k below 8, even k, k >= 32 (XXH64 stripe loop), k = 64"""
+    for k in (3, 12, 20, 32, 33, 47, 64):
+        q = oracle.random_sequence(200, k)
+        p = cases.make_classic(cases.tmp(tmp_path, "k%d.cobs_classic" % k), 77, 1009, 2, k, 1, 0.3, k,
+                               planted={5: 1.0, 70: 0.7}, query=q)
+        _check_index(gpu_lib, oracle, p, [q[:k], q[:k + 1], q[:k + 30], q], thresholds=(0.0, 0.5),
+                     limits=(0, 3))
+
+
+def test_reference_corpora(gpu_lib, oracle, construct, tmp_path):
+    """the corpora of tests/classic_index_query.cpp:36-111 and
+    tests/compact_index_query.cpp:36-181, built by the construction restatement"""
+    query = oracle.random_sequence(21000, 1)
+    docs = construct.generate_documents_all(query)
+    pc = cases.tmp(tmp_path, "all.cobs_classic")
+    construct.classic_construct(docs, pc, num_hashes=3, false_positive_rate=0.1)
+    pk = cases.tmp(tmp_path, "all.cobs_compact")
+    construct.compact_construct(docs, pk, num_hashes=3, false_positive_rate=0.1, page_size=2)
+    for p in (pc, pk):
+        s = _check_index(gpu_lib, oracle, p, [query, query[:160]], thresholds=(0.0, 0.5), limits=(0, 4))
+        res = s.search(query.decode())
+        assert len(res) == len(docs)
+        for r in res:       # ASSERT_GE(r.score, documents[index].data().size())
+            assert r.score >= docs[int(r.doc_name[-2:])].num_terms
+    one = construct.generate_documents_one(query, 2000)
+    po = cases.tmp(tmp_path, "one.cobs_classic")
+    construct.classic_construct(one, po, num_hashes=3, false_positive_rate=0.1)
+    pko = cases.tmp(tmp_path, "one.cobs_compact")
+    construct.compact_construct(one, pko, num_hashes=3, false_positive_rate=0.1, page_size=2)
+    for p in (po, pko):
+        s = _check_index(gpu_lib, oracle, p, [query[:5000]], thresholds=(0.0,), limits=(0,))
+        res = s.search(query.decode())
+        assert len(res) == 2000 and all(r.score == 1 for r in res)
+
+
+def test_multi_index_one_included(gpu_lib, oracle, construct, tmp_path):
+    """tests/classic_index_query.cpp:156-197: 33 + 44 + 55 documents, all scores 1"""
+    query = oracle.random_sequence(5000, 2)
+    paths = []
+    for i, n in enumerate((33, 44, 55)):
+        p = cases.tmp(tmp_path, "m%d.cobs_classic" % i)
+        construct.classic_construct(construct.generate_documents_one(query, n), p, num_hashes=3,
+                                    false_positive_rate=0.1)
+        paths.append(p)
+    s = _check_index(gpu_lib, oracle, paths, [query], thresholds=(0.0, 0.0001), limits=(0, 40))
+    res = s.search(query.decode())
+    assert len(res) == 33 + 44 + 55 and all(r.score == 1 for r in res)
+
+
+def test_ragged_batch_and_device_selection(gpu_lib, oracle, tmp_path):
+    """one device pass over queries of different lengths; on-device threshold
+    selection (count >= ceil(t*T)) equals the oracle's filter + ranking"""
+    D, ps, sigs = 5000, 128, [1500, 2100, 2900, 4001, 5003]
+    q_long = oracle.random_sequence(1500, 9)
+    planted = {d: f for d, f in zip(range(0, D, 97), np.linspace(0.05, 1.0, 52))}
+    p = cases.make_compact(cases.tmp(tmp_path, "rag.cobs_compact"), D, ps, sigs, 1, 31, 1, 0.3, 5,
+                           planted=planted, query=q_long)
+    s = gpu_lib.Search(p)
+    ix = oracle.Index.open(p)
+    queries = [q_long[:31], q_long[:1030], q_long[:100], q_long, q_long[200:531], q_long[:255 + 30],
+               q_long[:256 + 30]] * 3
+    b = gpu_lib.Batch(s)
+    b.set_queries(queries)
+    for t in (0.0, 0.2, 0.7):
+        b.run(t)
+        b.sync()
+        for i, q in enumerate(queries):
+            assert np.array_equal(b.counts_host(i), ix.counts(q))
+            for lim in (0, 3):
+                assert b.hits_host(i, lim) == cases.oracle_results([ix], q, t, lim)
+    ms = b.kernel_ms()
+    assert ms["scan_ms"] > 0 and ms["hash_ms"] > 0
+    st = b.stats()
+    T = sum(len(q) - 30 for q in queries)
+    assert st["kmer_lookups"] == T
+    assert st["algorithmic_bytes"] == T * len(sigs) * ps + len(queries) * 8 * ps * len(sigs) * 2
+
+
+def test_errors_match_reference_conditions(gpu_lib, oracle, golden_dir):
+    from cobs_amd import _capi
+    s = gpu_lib.Search(os.path.join(golden_dir, "c1.cobs_classic"))
+    with pytest.raises(gpu_lib.CobsGpuError) as e:      # classic_search.cpp:431-433
+        s.search("ACGT" * 7)
+    assert e.value.status == _capi.ERR_QUERY_TOO_SHORT
+    with pytest.raises(gpu_lib.CobsGpuError) as e:      # classic_search.cpp:93-96
+        s.search(Q50[:20].decode() + "N" + Q50[21:].decode())
+    assert e.value.status == _capi.ERR_INVALID_BASE
+    with pytest.raises(gpu_lib.CobsGpuError) as e:      # lower case is not ACGT (util/query.cpp:104-141)
+        s.search(Q50.decode().lower())
+    assert e.value.status == _capi.ERR_INVALID_BASE
+    with pytest.raises(oracle.OracleError):
+        oracle.Index.open(os.path.join(golden_dir, "c1.cobs_classic")).counts(Q50[:20] + b"N" + Q50[21:])
+    with pytest.raises(gpu_lib.CobsGpuError) as e:
+        gpu_lib.Search(os.path.join(golden_dir, "fasta", "sample1.fasta"))
+    assert e.value.status == _capi.ERR_FORMAT
+    # the handle stays usable after an error
+    assert s.search(Q50.decode())[0].score == 20
+
+
+def test_synthetic_index_matches_generator(gpu_lib, oracle):
+    """procedural index: rows in HBM equal the checker's generator; counts equal"""
+    sigs = [1201, 1789, 2503]
+    ps, D = 112, 2 * 8 * 112 + 500
+    s = gpu_lib.Search.synthetic("compact", sigs, D, page_size=ps, seed=77)
+    ix = oracle.Index.synthetic(1, 31, 1, 1, ps, sigs, D, 77)
+    for page, row in ((0, 0), (0, 1200), (1, 17), (2, 2502), (2, 1000)):
+        assert np.array_equal(s.read_row(0, page, row, ps), oracle.synth_row(1, 77, ps, 3, D, page, row, ps))
+    assert not s.read_row(0, 1, sigs[1], ps).any()          # the zero row
+    got = s.read_row(0, 2, 5, ps)
+    assert not got[(D - 2 * 8 * ps + 7) // 8:].any()        # padding documents have no bits
+    for q in cases.queries_acgt(3, 1030, 40):
+        assert np.array_equal(s.counts(q), ix.counts(q))
+    s2 = gpu_lib.Search.synthetic("classic", [3001], 1000, seed=5)
+    ix2 = oracle.Index.synthetic(0, 31, 1, 1, 0, [3001], 1000, 5)
+    for q in cases.queries_acgt(2, 300, 50):
+        assert np.array_equal(s2.counts(q), ix2.counts(q))
+
+
+def test_sharded_counts_sum_to_whole(gpu_lib, oracle, tmp_path):
+    """shards hold disjoint sub-index blocks / column ranges; the sum
+    of the zero-padded shard vectors equals the unsharded result"""
+    q = oracle.random_sequence(500, 3)
+    pc = cases.make_compact(cases.tmp(tmp_path, "sh.cobs_compact"), 700, 16, [800, 900, 1000, 1100, 1200, 1300],
+                            2, 31, 1, 0.3, 8)
+    pk = cases.make_classic(cases.tmp(tmp_path, "sh.cobs_classic"), 3000, 1999, 1, 31, 1, 0.3, 9)
+    for p in (pc, pk):
+        want = oracle.Index.open(p).counts(q)
+        for n in (2, 3, 4):
+            total = np.zeros_like(want)
+            for r in range(n):
+                s = gpu_lib.Search(p, shard_rank=r, shard_count=n)
+                c = s.counts(q)
+                i = s.info(0)
+                outside = np.ones(len(c), dtype=bool)
+                outside[i.slot_begin:i.slot_begin + i.slot_count] = False
+                assert not c[outside].any()
+                total += c
+            assert np.array_equal(total, want)
