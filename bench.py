@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X COBS query engine.
+
+Metric (BASELINE.json): k-mer queries/s + achieved HBM GB/s on the synthetic
+100k-document compact index (8 sub-indexes, page_size 1568 B, S_p 250k..4M rows,
+18.4 GB in HBM), 1000-k-mer (1030-character) queries, batch of 10k queries --
+BASELINE configs[2], the configuration the metric is quoted on.
+
+A "step" is one pass of the hot path over the resident batch:
+  K1 canonicalise + XXH64 + row index per sub-index, K2 row gather + AND +
+  bit-sliced per-document count (+ on-device threshold selection if
+  --threshold > 0), counts written to HBM.  Query text and index are resident in
+  HBM before the timed region; nothing is copied to the host inside it.
+
+Usage:  python bench.py --gpus N --steps K --warmup W
+For N > 1 it is launched by torch.distributed.run, one rank per GPU (RCCL).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import cobs_amd  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def c3_config(scale=1.0):
+    """BASELINE configs[2] / SURVEY 8d: compact, D=100000, page_size 1568 -> P=8,
+    S_p geometric 250k..4M rows (ratio 16^(1/7))."""
+    ratio = 16.0 ** (1.0 / 7.0)
+    sigs = [max(64, int(round(250000 * scale * ratio ** p))) for p in range(8)]
+    return {"kind": "compact", "num_docs": 100000, "page_size": 1568, "signature_sizes": sigs,
+            "term_size": 31, "canonicalize": 1, "num_hashes": 1, "seed": 1}
+
+
+def c2_config(scale=1.0):
+    """BASELINE configs[1]: classic, 10k docs x 1M-row signatures"""
+    return {"kind": "classic", "num_docs": 10000, "page_size": 0,
+            "signature_sizes": [max(64, int(1000000 * scale))],
+            "term_size": 31, "canonicalize": 1, "num_hashes": 1, "seed": 1}
+
+
+def make_queries(n, kmers, seed=42):
+    """benchmark-fpr queries (reference src/cobs.cpp:709-720): one std::mt19937(seed),
+    rng() % 4 -> ACGT, kmers+30 characters each.  numpy's legacy RandomState uses the
+    same init_genrand seeding and emits the same raw 32-bit stream."""
+    rs = np.random.RandomState(seed)
+    raw = rs.randint(0, 2 ** 32, size=n * (kmers + 30), dtype=np.uint64)
+    text = np.frombuffer(b"ACGT", dtype=np.uint8)[(raw % 4).astype(np.int64)]
+    text = text.reshape(n, kmers + 30)
+    return [text[i].tobytes() for i in range(n)]
+
+
+def cpu_baseline(search, cfg, queries, seconds_target=12.0, check_queries=4, batch=None):
+    """Time the oracle (plain-C port of the reference algorithm: per-batch row
+    gather -> AND -> LUT/SSE2 expand-add -> threshold -> partial sort) on this
+    host's cores, on a bounded sample of the same workload, and compare its
+    counts with the GPU's on the same queries."""
+    from oracle import oracle as O
+    O.build(native=True, force=True)
+    info = search.info(0)
+    sigs = cfg["signature_sizes"]
+    index_bytes = sum(s * (info.page_size if info.kind else info.row_size) for s in sigs)
+    avail = 0
+    with open("/proc/meminfo") as f:
+        for ln in f:
+            if ln.startswith("MemAvailable"):
+                avail = int(ln.split()[1]) * 1024
+    kind = 1 if info.kind else 0
+    width = info.page_size if info.kind else info.row_size
+    sample = "same index, same queries"
+    if avail > 2.5 * index_bytes:
+        # host copy of the very index the GPU scans (the reference's --load-complete)
+        pages = [search.read_rows(0, p, 0, sigs[p]) for p in range(len(sigs))]
+        ix = O.Index.from_memory(kind, cfg["term_size"], cfg["canonicalize"], cfg["num_hashes"],
+                                 cfg["page_size"], sigs, cfg["num_docs"], pages)
+        exact_index = True
+    else:
+        # not enough host RAM: same geometry with every S_p divided by 16 (row gathers
+        # still miss all caches), bits from the same generator
+        small = [max(64, s // 16) for s in sigs]
+        pages = []
+        for p, s in enumerate(small):
+            m = np.empty((s, width), dtype=np.uint8)
+            for r in range(s):
+                m[r] = O.synth_row(kind, cfg["seed"], cfg["page_size"], len(sigs), cfg["num_docs"], p, r, width)
+            pages.append(m)
+        ix = O.Index.from_memory(kind, cfg["term_size"], cfg["canonicalize"], cfg["num_hashes"],
+                                 cfg["page_size"], small, cfg["num_docs"], pages)
+        exact_index = False
+        sample = "same geometry with S_p/16 (host RAM too small for the full index), same queries"
+    # bit-exactness of the GPU counts against the port on the same inputs
+    bit_exact = None
+    if exact_index and batch is not None:
+        bit_exact = True
+        for i in range(min(check_queries, len(queries))):
+            bit_exact = bit_exact and bool(np.array_equal(batch.counts_host(i), ix.counts(queries[i])))
+    out = {}
+    ncores = os.cpu_count() or 1
+    for threads in (1, min(ncores, 8)):
+        O.timers(reset=True)
+        t0 = time.perf_counter()
+        n = 0
+        while n < len(queries):
+            O.search(ix, queries[n], 0.0, 0, threads=threads)
+            n += 1
+            if time.perf_counter() - t0 > seconds_target / 2:
+                break
+        dt = time.perf_counter() - t0
+        out[threads] = (n / dt, n, dt, O.timers())
+    qps1, n1, dt1, tm1 = out[1]
+    tmax = max(out)
+    res = {"value": round(qps1, 2), "unit": "queries/s", "cores": 1, "kind": "port",
+           "sample": "%d of the batch's queries, 1 thread, %.1f s; %s; index resident in host RAM"
+                     % (n1, dt1, sample),
+           "kmer_lookups_per_s": round(qps1 * (len(queries[0]) - cfg["term_size"] + 1), 1),
+           "phase_seconds": {k: round(v, 3) for k, v in tm1.items()},
+           "host_cores": ncores,
+           "threads_%d" % tmax: {"value": round(out[tmax][0], 2), "queries": out[tmax][1]},
+           "bit_exact_vs_gpu": bit_exact}
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--queries", type=int, default=10000, help="queries per batch (whole job)")
+    ap.add_argument("--kmers", type=int, default=1000)
+    ap.add_argument("--config", choices=["c3", "c2"], default="c3")
+    ap.add_argument("--scale", type=float, default=1.0, help="scale signature sizes (smoke runs)")
+    ap.add_argument("--threshold", type=float, default=0.0,
+                    help="0 = benchmark-fpr semantics (all documents scored)")
+    ap.add_argument("--shard-mode", choices=["queries", "index"], default="queries",
+                    help="N>1: replicate the index and split the batch (no collective), or shard the "
+                         "index by sub-index block and all-gather the count slices over RCCL")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    n_gpus = world
+    dev = torch.cuda.current_device()
+
+    cfg = (c3_config if args.config == "c3" else c2_config)(args.scale)
+    shard_index = world > 1 and args.shard_mode == "index"
+    s = cobs_amd.Search.synthetic(cfg["kind"], cfg["signature_sizes"], cfg["num_docs"],
+                                  page_size=cfg["page_size"], term_size=cfg["term_size"],
+                                  canonicalize=cfg["canonicalize"], num_hashes=cfg["num_hashes"],
+                                  seed=cfg["seed"], device=dev,
+                                  shard_rank=rank if shard_index else 0,
+                                  shard_count=world if shard_index else 1)
+    all_queries = make_queries(args.queries, args.kmers)
+    if world > 1 and not shard_index:
+        mine = all_queries[rank::world]        # strong scaling: the batch is split over the ranks
+    else:
+        mine = all_queries
+    batch = cobs_amd.Batch(s)
+    batch.set_queries(mine)                    # H2D once; inputs now resident in HBM
+
+    gathered = None
+    if shard_index:
+        local = batch.counts_tensor()
+        gathered = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device="cuda")
+
+    def step():
+        batch.run(args.threshold, 0)
+        if shard_index:
+            # per-document hit counts of the disjoint sub-index blocks -> every rank (RCCL all-gather)
+            dist.all_gather_into_tensor(gathered, batch.counts_tensor())
+
+    for _ in range(args.warmup):
+        step()
+    batch.sync()
+    batch.kernel_ms()                          # drop warm-up events
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    batch.sync()                               # also raises on invalid bases
+    ms = batch.kernel_ms()                     # HIP events on the launch stream, averaged over the timed steps
+    st = batch.stats()
+
+    total_queries = args.queries               # whole job, both shard modes
+    ms_per_step = dt / args.steps * 1e3
+    qps = total_queries * args.steps / dt
+    algo = st["algorithmic_bytes"]
+    achieved = algo / (ms["scan_ms"] * 1e-3) / 1e9
+    traffic = None
+    tr_path = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tr_path) and n_gpus == 1 and args.scale == 1.0 and args.queries == 10000:
+        try:
+            with open(tr_path) as f:
+                tj = json.load(f)
+            if tj.get("config") == args.config:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "k-mer queries/sec (1000-k-mer queries, 100k-doc compact index)",
+        "value": round(qps, 1),
+        "unit": "queries/s",
+        "n_gpus": n_gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "u32 bit-planes (u16 scores)",
+        "data": "synthetic",
+        "config": {
+            "workload": ("BASELINE configs[2]: synthetic compact index, %d docs, %d sub-indexes, page_size %d B, "
+                         "S_p %d..%d rows (%.1f GB in HBM), batch of %d queries x %d k-mers, H=%d, threshold %g"
+                         % (cfg["num_docs"], len(cfg["signature_sizes"]), cfg["page_size"],
+                            cfg["signature_sizes"][0], cfg["signature_sizes"][-1],
+                            sum(cfg["signature_sizes"]) * max(cfg["page_size"], (cfg["num_docs"] + 7) // 8) / 1e9,
+                            args.queries, args.kmers, cfg["num_hashes"], args.threshold))
+            if args.config == "c3" else
+            ("BASELINE configs[1]: synthetic classic index, %d docs x %d rows, batch of %d queries x %d k-mers"
+             % (cfg["num_docs"], cfg["signature_sizes"][0], args.queries, args.kmers)),
+            "global_batch": args.queries,
+            "kmers_per_query": args.kmers,
+            "parallelism": ("1 gpu" if world == 1 else
+                            ("index sharded by sub-index block x%d + RCCL all-gather of counts" % world
+                             if shard_index else "index replicated, batch split x%d, no collective" % world)),
+        },
+        "kmer_lookups_per_s": round(qps * args.kmers, 1),
+        "roofline": {
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": traffic,
+            "kernel": "scan_kernel (gather + AND + bit-sliced count), rank 0",
+            "algorithmic_bytes_per_launch": algo,
+            "scan_ms_per_launch": round(ms["scan_ms"], 4),
+            "hash_ms_per_launch": round(ms["hash_ms"], 4),
+        },
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(s, cfg, mine, batch=batch)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

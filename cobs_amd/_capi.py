@@ -65,6 +65,7 @@ SYMBOLS = {
     "cobs_gpu_total_counts": (_u64, [_vp]),
     "cobs_gpu_local_counts": (_u64, [_vp]),
     "cobs_gpu_read_row": (_int, [_vp, _sz, _u32, _u64, _vp, _sz]),
+    "cobs_gpu_read_rows": (_int, [_vp, _sz, _u32, _u64, _u64, _vp, _sz]),
     "cobs_gpu_search": (_int, [_vp, _cp, _sz, _dbl, _sz, C.POINTER(Hit), _sz, C.POINTER(_sz)]),
     "cobs_gpu_search_batch": (_int, [_vp, C.POINTER(_cp), C.POINTER(_sz), _sz, _dbl, _sz,
                                      C.POINTER(Hit), _sz, C.POINTER(_sz), C.POINTER(_sz)]),
@@ -94,6 +95,14 @@ def load():
         raise ImportError(
             "cobs_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` or `make -C cobs_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 and, when
+    # it is going to be used in this process (device memory, streams,
+    # torch.distributed), it must be the copy that is loaded first so that
+    # libcobs_gpu binds to the same runtime instance (same device pointers).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)       # AttributeError if the library does not export it

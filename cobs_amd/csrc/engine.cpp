@@ -147,10 +147,13 @@ struct cobs_gpu_batch {
     std::vector<HitDev> h_hits;       // pool copy, sorted by query
     std::vector<size_t> h_hit_off;
     bool pool_fetched = false;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    // HIP events around K1 and K2 of the most recent runs (recorded on the launch stream)
+    static constexpr int kRing = 64;
+    hipEvent_t ev[kRing][3] = {};
+    uint64_t run_seq = 0, read_seq = 0;
     uint64_t stats[4] = {0, 0, 0, 0};
     ~cobs_gpu_batch() {
-        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        for (auto& r : ev) for (auto& e : r) if (e) (void)hipEventDestroy(e);
     }
 };
 
@@ -504,6 +507,20 @@ cobs_gpu_status cobs_gpu_read_row(const cobs_gpu_index* ix, size_t f, uint32_t p
     return COBS_GPU_OK;
 }
 
+cobs_gpu_status cobs_gpu_read_rows(const cobs_gpu_index* ix, size_t f, uint32_t page, uint64_t row0,
+                                   uint64_t nrows, uint8_t* out, size_t out_pitch) {
+    if (!ix || !out || f >= ix->parts.size()) return fail(COBS_GPU_ERR_ARG, "bad argument");
+    const Part& p = ix->parts[f];
+    if (page < p.first_page || page >= p.end_page) return fail(COBS_GPU_ERR_ARG, "sub-index not held by this shard");
+    const PageDev& pd = p.pages[page - p.first_page];
+    if (row0 + nrows > pd.sig + 1 || out_pitch < p.ncols) return fail(COBS_GPU_ERR_ARG, "rows or pitch out of range");
+    HIP_TRY(hipSetDevice(ix->device));
+    if (nrows)
+        HIP_TRY(hipMemcpy2D(out, out_pitch, p.d_blob + pd.base + row0 * (uint64_t)p.pitch, p.pitch,
+                            (size_t)p.ncols, (size_t)nrows, hipMemcpyDeviceToHost));
+    return COBS_GPU_OK;
+}
+
 // ---------------------------------------------------------------------------
 // batches
 
@@ -517,7 +534,7 @@ cobs_gpu_status cobs_gpu_batch_create(cobs_gpu_index* ix, size_t max_queries, si
     b->max_queries = max_queries;
     b->max_len = max_query_len;
     b->work.resize(ix->parts.size());
-    for (auto& e : b->ev) HIP_TRY(hipEventCreate(&e));
+    for (auto& r : b->ev) for (auto& e : r) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(b->flags.reserve(2));
     *out = b.release();
     return COBS_GPU_OK;
@@ -637,7 +654,8 @@ cobs_gpu_status cobs_gpu_batch_run(cobs_gpu_batch* b, double threshold, void* hi
             if (nq) HIP_TRY(hipMemcpyAsync(b->work[f].thr.p, stage, 4 * nq, hipMemcpyHostToDevice, st));
         }
     }
-    HIP_TRY(hipEventRecord(b->ev[0], st));
+    hipEvent_t* ev = b->ev[b->run_seq % cobs_gpu_batch::kRing];
+    HIP_TRY(hipEventRecord(ev[0], st));
     for (size_t f = 0; f < ix->parts.size(); ++f) {
         const Part& p = ix->parts[f];
         if (p.nlocal == 0 || nq == 0) continue;
@@ -656,7 +674,7 @@ cobs_gpu_status cobs_gpu_batch_run(cobs_gpu_batch* b, double threshold, void* hi
         ha.num_hashes = (uint32_t)p.meta.num_hashes;
         HIP_TRY(launch_hash(ha, b->span_off[nq], st));
     }
-    HIP_TRY(hipEventRecord(b->ev[1], st));
+    HIP_TRY(hipEventRecord(ev[1], st));
     uint64_t launches = 0;
     for (size_t f = 0; f < ix->parts.size(); ++f) {
         const Part& p = ix->parts[f];
@@ -688,7 +706,8 @@ cobs_gpu_status cobs_gpu_batch_run(cobs_gpu_batch* b, double threshold, void* hi
         HIP_TRY(launch_scan(sa, p.ntiles, b->planes, st));
         ++launches;
     }
-    HIP_TRY(hipEventRecord(b->ev[2], st));
+    HIP_TRY(hipEventRecord(ev[2], st));
+    b->run_seq++;
     b->stats[1] = launches;
     b->ran = true;
     return COBS_GPU_OK;
@@ -810,11 +829,23 @@ cobs_gpu_status cobs_gpu_batch_stats(const cobs_gpu_batch* b, uint64_t out[4]) {
 cobs_gpu_status cobs_gpu_batch_kernel_ms(cobs_gpu_batch* b, float* scan_ms, float* hash_ms) {
     if (!b) return fail(COBS_GPU_ERR_ARG, "NULL batch");
     if (!b->ran || !b->synced) return fail(COBS_GPU_ERR_ARG, "run and sync the batch first");
-    float h = 0, s = 0;
-    HIP_TRY(hipEventElapsedTime(&h, b->ev[0], b->ev[1]));
-    HIP_TRY(hipEventElapsedTime(&s, b->ev[1], b->ev[2]));
-    if (hash_ms) *hash_ms = h;
-    if (scan_ms) *scan_ms = s;
+    // average over the runs since the previous call (at most the last kRing runs)
+    uint64_t first = b->read_seq;
+    if (b->run_seq - first > (uint64_t)cobs_gpu_batch::kRing) first = b->run_seq - cobs_gpu_batch::kRing;
+    if (first == b->run_seq) first = b->run_seq - 1;       // nothing new: report the last run again
+    double h = 0, s = 0;
+    for (uint64_t r = first; r < b->run_seq; ++r) {
+        hipEvent_t* ev = b->ev[r % cobs_gpu_batch::kRing];
+        float a = 0, c = 0;
+        HIP_TRY(hipEventElapsedTime(&a, ev[0], ev[1]));
+        HIP_TRY(hipEventElapsedTime(&c, ev[1], ev[2]));
+        h += a;
+        s += c;
+    }
+    const double n = (double)(b->run_seq - first);
+    b->read_seq = b->run_seq;
+    if (hash_ms) *hash_ms = (float)(h / n);
+    if (scan_ms) *scan_ms = (float)(s / n);
     return COBS_GPU_OK;
 }
 

@@ -118,6 +118,15 @@ class Search:
         check(self._lib.cobs_gpu_read_row(self._h, file_no, page, row, out.ctypes.data, nbytes))
         return out
 
+    def read_rows(self, file_no, page, row0, nrows, out=None):
+        """bulk D2H of whole rows of one held sub-index -> uint8 [nrows, valid bytes]"""
+        i = self.info(file_no)
+        width = i.slot_count // 8 if i.kind == 0 else i.page_size
+        if out is None:
+            out = np.empty((nrows, width), dtype=np.uint8)
+        check(self._lib.cobs_gpu_read_rows(self._h, file_no, page, row0, nrows, out.ctypes.data, width))
+        return out
+
     # -- queries -------------------------------------------------------------
     def search(self, query, threshold=0.0, num_results=0):
         """Same contract as cobs_index.Search.search (python/module.cpp:372-386)."""

@@ -130,6 +130,10 @@ uint64_t cobs_gpu_local_counts(const cobs_gpu_index* ix);
 cobs_gpu_status cobs_gpu_read_row(const cobs_gpu_index* ix, size_t file_no, uint32_t page,
                                   uint64_t row, uint8_t* out, size_t n);
 
+/* the valid bytes of rows [row0, row0+nrows) of a held sub-index, out_pitch bytes apart */
+cobs_gpu_status cobs_gpu_read_rows(const cobs_gpu_index* ix, size_t file_no, uint32_t page,
+                                   uint64_t row0, uint64_t nrows, uint8_t* out, size_t out_pitch);
+
 /* ---- search (host buffers in, host buffers out) ------------------------ */
 /* ClassicSearch::search (classic_search.cpp:403-505): hits ordered by score
  * descending, ties by (file_no, doc) ascending; no ordering when the query has a
@@ -187,9 +191,9 @@ cobs_gpu_status cobs_gpu_batch_hits_host(cobs_gpu_batch* b, size_t query_no, siz
  * out[1] = number of scan-kernel launches, out[2] = k-mer lookups (sum T),
  * out[3] = bytes of row-index table written by K1 and read by K2.            */
 cobs_gpu_status cobs_gpu_batch_stats(const cobs_gpu_batch* b, uint64_t out[4]);
-/* HIP-event duration (ms) of the scan kernel(s) / hash kernel of the last run;
- * events are recorded on the stream the kernels were launched on.  Call after
- * cobs_gpu_batch_sync. */
+/* HIP-event duration (ms) of the scan kernel(s) / hash kernel, averaged over the
+ * runs since the previous call (at most the last 64); events are recorded on the
+ * stream the kernels were launched on.  Call after cobs_gpu_batch_sync. */
 cobs_gpu_status cobs_gpu_batch_kernel_ms(cobs_gpu_batch* b, float* scan_ms, float* hash_ms);
 
 /* phase timers of the host-buffer search API since the last reset, seconds:
