@@ -832,3 +832,34 @@ int oracle_search(oracle_index* const* ixs, size_t n, const char* query, size_t 
     free(hits); free(scores); free(sum); free(thr);
     return ORACLE_OK;
 }
+
+/* ------------------------------------------------------------------------ */
+/* timing loop for the CPU baseline: runs oracle_search over queries
+ * 0, 1, ... until `seconds` have elapsed (at least one query), entirely in C
+ * so that no marshalling cost is included.  Returns the number of queries run. */
+size_t oracle_search_many(oracle_index* const* ixs, size_t n, const char* text,
+                          const uint64_t* offsets, size_t nq, double threshold,
+                          size_t num_results, int threads, double seconds,
+                          double* elapsed_out, uint64_t* checksum_out) {
+    size_t cap = 0;
+    for (size_t i = 0; i < n; ++i) cap += oracle_counts_size(ixs[i]);
+    uint32_t* oi = (uint32_t*)malloc(4 * (cap ? cap : 1));
+    uint32_t* od = (uint32_t*)malloc(4 * (cap ? cap : 1));
+    uint32_t* os = (uint32_t*)malloc(4 * (cap ? cap : 1));
+    uint64_t sum = 0;
+    size_t done = 0;
+    double t0 = now_s();
+    while (done < nq) {
+        size_t nout = 0;
+        int rc = oracle_search(ixs, n, text + offsets[done], (size_t)(offsets[done + 1] - offsets[done]),
+                               threshold, num_results, threads, oi, od, os, cap, &nout);
+        if (rc != ORACLE_OK) break;
+        for (size_t k = 0; k < nout && k < 4; ++k) sum += (uint64_t)os[k] * 31 + od[k];
+        done++;
+        if (now_s() - t0 >= seconds) break;
+    }
+    if (elapsed_out) *elapsed_out = now_s() - t0;
+    if (checksum_out) *checksum_out = sum;
+    free(oi); free(od); free(os);
+    return done;
+}

@@ -82,6 +82,9 @@ def lib():
     L.oracle_counts.argtypes = [vp, cp, sz, C.c_int, vp, C.POINTER(C.c_int)]
     L.oracle_search.restype = C.c_int
     L.oracle_search.argtypes = [vp, sz, cp, sz, C.c_double, sz, C.c_int, vp, vp, vp, sz, C.POINTER(sz)]
+    L.oracle_search_many.restype = sz
+    L.oracle_search_many.argtypes = [vp, sz, cp, vp, sz, C.c_double, sz, C.c_int, C.c_double,
+                                     C.POINTER(C.c_double), C.POINTER(u64)]
     L.oracle_timers.restype = None
     L.oracle_timers.argtypes = [vp, C.c_int]
     L.oracle_last_error.restype = cp
@@ -228,6 +231,20 @@ def search(indexes, query: bytes, threshold=0.0, num_results=0, threads=1):
                                threads, oi.ctypes.data, od.ctypes.data, os_.ctypes.data, cap, C.byref(n)))
     return [(int(oi[i]), int(od[i]), indexes[int(oi[i])].doc_name(int(od[i])), int(os_[i]))
             for i in range(n.value)]
+
+
+def search_many(indexes, queries, threshold=0.0, num_results=0, threads=1, seconds=5.0):
+    """time ClassicSearch::search over `queries` inside C -> (queries done, seconds)"""
+    if isinstance(indexes, Index):
+        indexes = [indexes]
+    hs = (C.c_void_p * len(indexes))(*[ix._h for ix in indexes])
+    text = b"".join(queries)
+    offs = np.zeros(len(queries) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(q) for q in queries])
+    el, ck = C.c_double(0), C.c_uint64(0)
+    n = lib().oracle_search_many(hs, len(indexes), text, offs.ctypes.data, len(queries), float(threshold),
+                                 int(num_results), threads, float(seconds), C.byref(el), C.byref(ck))
+    return int(n), el.value
 
 
 def timers(reset=False):

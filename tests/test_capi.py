@@ -1,0 +1,112 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads, exports every
+symbol include/cobs_gpu.h declares, parses index headers without a device and
+fails loudly (no CPU fallback) when a compute entry point is used without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "cobs_gpu.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cobs_gpu_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from cobs_amd import _capi
+    lib = _capi.load()
+    names = _declared_symbols()
+    assert len(names) >= 28
+    for n in names:
+        assert hasattr(lib, n), "libcobs_gpu.so does not export " + n
+        assert n in _capi.SYMBOLS, "cobs_amd/_capi.py does not bind " + n
+    assert sorted(_capi.SYMBOLS) == names
+    assert lib.cobs_gpu_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    from cobs_amd import _capi
+    assert C.sizeof(_capi.Options) == 24
+    assert C.sizeof(_capi.Hit) == 12
+    assert C.sizeof(_capi.IndexInfo) == 16 + 7 * 8 + 8 + 3 * 8
+    assert C.sizeof(_capi.Synth) == 16 + 4 * 8 + 8
+
+
+def test_no_oracle_in_product():
+    """the product path must not import, link or call anything under oracle/"""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "cobs_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or fn == "Makefile":
+                txt = open(os.path.join(dirpath, fn), errors="replace").read()
+                assert "oracle" not in txt.lower(), (fn, "mentions the oracle")
+    out = os.popen("ldd %s" % os.path.join(ROOT, "cobs_amd", "libcobs_gpu.so")).read()
+    assert "oracle" not in out
+
+
+def test_errors_without_a_device(golden_dir, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; the no-device path is exercised on CPU-only hosts")
+    import cobs_amd
+    from cobs_amd import _capi
+    with pytest.raises(cobs_amd.CobsGpuError) as e:
+        cobs_amd.Search(os.path.join(golden_dir, "c1.cobs_classic"))
+    assert e.value.status == _capi.ERR_NO_DEVICE and "no CPU fallback" in str(e.value)
+    with pytest.raises(cobs_amd.CobsGpuError) as e:
+        cobs_amd.Search.synthetic("compact", [100, 200], 100, page_size=16)
+    assert e.value.status == _capi.ERR_NO_DEVICE
+
+
+def test_open_errors_are_reported_before_any_device_work(golden_dir, tmp_path):
+    import cobs_amd
+    from cobs_amd import _capi
+    with pytest.raises(cobs_amd.CobsGpuError) as e:
+        cobs_amd.Search(str(tmp_path / "missing.cobs_classic"))
+    assert e.value.status == _capi.ERR_OPEN
+    with pytest.raises(cobs_amd.CobsGpuError) as e:
+        cobs_amd.Search(os.path.join(golden_dir, "expected.json"))
+    assert e.value.status == _capi.ERR_FORMAT
+    # truncated matrix
+    raw = open(os.path.join(golden_dir, "c1.cobs_classic"), "rb").read()
+    p = tmp_path / "short.cobs_classic"
+    p.write_bytes(raw[:4000])
+    with pytest.raises(cobs_amd.CobsGpuError) as e:
+        cobs_amd.Search(str(p))
+    assert e.value.status == _capi.ERR_FORMAT
+    # wrong version
+    p2 = tmp_path / "v2.cobs_classic"
+    p2.write_bytes(raw[:18] + b"\x02\x00\x00\x00" + raw[22:])
+    with pytest.raises(cobs_amd.CobsGpuError) as e:
+        cobs_amd.Search(str(p2))
+    assert e.value.status == _capi.ERR_FORMAT
+    with pytest.raises(cobs_amd.CobsGpuError) as e:
+        cobs_amd.Search(os.path.join(golden_dir, "c1.cobs_classic"), shard_rank=3, shard_count=2)
+    assert e.value.status in (_capi.ERR_ARG, _capi.ERR_NO_DEVICE)
+
+
+def test_python_mirror_surface():
+    """names and defaults of python/module.cpp:351-386"""
+    import inspect
+
+    import cobs_amd
+    r = cobs_amd.SearchResult()
+    assert r.doc_name == "" and r.score == 0
+    sig = inspect.signature(cobs_amd.Search.search)
+    assert list(sig.parameters) == ["self", "query", "threshold", "num_results"]
+    assert sig.parameters["threshold"].default == 0.0 and sig.parameters["num_results"].default == 0
+    assert isinstance(cobs_amd.__version__, str)
+
+
+def test_bench_query_stream_is_the_reference_benchmark_stream(oracle):
+    """bench.make_queries == std::mt19937(42) % 4 (reference src/cobs.cpp:709-720)"""
+    import bench
+    qs = bench.make_queries(3, 1000, seed=42)
+    g = oracle.Mt19937Queries(42)
+    assert [g.next(1030) for _ in range(3)] == qs
+    cfg = bench.c3_config()
+    assert cfg["signature_sizes"][0] == 250000 and cfg["signature_sizes"][-1] == 4000000
+    assert len(cfg["signature_sizes"]) == 8 and cfg["page_size"] * 8 * 8 >= cfg["num_docs"]

@@ -1,0 +1,84 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU exchange: count slices of
+disjoint sub-index blocks are gathered and assembled into the global vector, hit
+lists are merged into the reference's result order.  The per-rank count slices
+are produced here by the oracle restricted to the rank's documents (on a GPU box
+they come from libcobs_gpu with shard_rank/shard_count; see
+tests/test_gpu_parity.py::test_sharded_counts_sum_to_whole)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests import cases
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, path, queries, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cobs_amd import distributed as D
+        from oracle import oracle as O
+        ix = O.Index.open(path)
+        P, ps = ix.num_pages, ix.page_size
+        first, end = P * rank // world, P * (rank + 1) // world          # engine's block split
+        begin, count = first * 8 * ps, (end - first) * 8 * ps
+        full = np.stack([ix.counts(q) for q in queries]).astype(np.uint16)
+        local = torch.from_numpy(full[:, begin:begin + count].astype(np.int16))
+        layouts = [None] * world
+        dist.all_gather_object(layouts, [(begin, count, 0)])
+        gathered = D.all_gather_counts(local)
+        assert [g.shape[1] for g in gathered] == [l[0][1] for l in layouts]
+        whole = D.assemble_counts(gathered, layouts, ix.counts_size)
+        assert np.array_equal(whole.numpy().astype(np.uint16), full)
+        # hits mode: per-shard ranked lists -> global order
+        for t, lim in ((0.0, 0), (0.3, 0), (0.3, 3), (0.9, 0)):
+            for qi, q in enumerate(queries):
+                T = len(q) - 30
+                thr = int(np.ceil(t * T))
+                mine = [(0, d, int(full[qi, d])) for d in range(begin, min(begin + count, ix.num_docs))
+                        if full[qi, d] >= thr]
+                mine.sort(key=lambda h: (-h[2], h[1]))
+                if lim:
+                    mine = mine[:lim]
+                everyone = [None] * world
+                dist.all_gather_object(everyone, mine)
+                merged = D.merge_hits(everyone, lim, T * ix.num_hashes, ix.counts_size)
+                assert merged == cases.oracle_results([ix], q, t, lim), (t, lim, qi)
+        open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_shard_exchange_gloo(oracle, tmp_path, world):
+    q_long = oracle.random_sequence(400, 21)
+    planted = {3: 1.0, 200: 0.8, 777: 0.5, 1100: 0.95}
+    path = cases.make_compact(cases.tmp(tmp_path, "d.cobs_compact"), 1200, 32, [600, 700, 800, 900, 1000], 1, 31, 1,
+                              0.3, 4, planted=planted, query=q_long)
+    queries = [q_long, q_long[:31], q_long[:200]]
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, path, queries, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert os.path.exists(os.path.join(str(tmp_path), "ok%d" % r))
+
+
+def test_merge_hits_order():
+    from cobs_amd.distributed import merge_hits
+    a = [(0, 5, 9), (0, 1, 3)]
+    b = [(0, 9, 9), (1, 0, 9), (0, 7, 1)]
+    assert merge_hits([a, b]) == [(0, 5, 9), (0, 9, 9), (1, 0, 9), (0, 1, 3), (0, 7, 1)]
+    assert merge_hits([a, b], 2) == [(0, 5, 9), (0, 9, 9)]
+    assert merge_hits([a, b], 0, total_hashes=1) == [(0, 1, 3), (0, 5, 9), (0, 7, 1), (0, 9, 9), (1, 0, 9)]

@@ -1,0 +1,260 @@
+"""Pins of the oracle (oracle/cobs_oracle.c, the CPU restatement) against every
+known answer the reference's own tests hold for this path, plus the
+facts recorded from a run of the real reference during the survey.  CPU only."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import cases
+
+Q50 = b"AGTCAACGCTAAGGCATTTCCCCCCTGCCTCCTGCCTGCTGCCAAGCCCT"
+
+
+# --- XXH64: third-party xxHash (extlib/xxhash, un-vendored); call sites
+# classic_search.cpp:84,99, util/misc.hpp:69 --------------------------------------
+
+def test_xxh64_known_answers(oracle):
+    assert oracle.xxh64(b"", 0) == 0xEF46DB3751D8E999            # published XXH64 test vector
+    kmer = b"AGGAAAGTCTTTTACGCTGGGGTAAGAGTGA"
+    assert oracle.xxh64(kmer, 0) == 0xC8D2277D16E89C15
+    assert oracle.xxh64(kmer, 1) == 0x5121D4E40ED1BE5B
+    assert oracle.xxh64(kmer, 2) == 0x5DCEECCDAD06CA97
+
+
+def test_xxh64_against_python_xxhash(oracle):
+    xxhash = pytest.importorskip("xxhash")       # python-xxhash 3.8.1 / libxxhash 0.8.2 in this image
+    rng = np.random.default_rng(0)
+    for n in list(range(0, 100)) + [127, 128, 129, 1000]:
+        data = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+        for seed in (0, 1, 2, 7, 2 ** 63 + 5):
+            assert oracle.xxh64(data, seed) == xxhash.xxh64_intdigest(data, seed=seed)
+
+
+# --- canonicalize_kmer: reference tests/util.cpp:38-60 (all seven vectors) ------------
+
+KATS = [
+    (b"AGGAAAGTCTTTTACGCTGGGGTAAGAGTGA", b"AGGAAAGTCTTTTACGCTGGGGTAAGAGTGA", True),
+    (b"TGGAAAGTCTTTTACGCTGGGGTAAGAGTGA", b"TCACTCTTACCCCAGCGTAAAAGACTTTCCA", True),
+    (b"TTTTTTGTCTTTTACGCTGGGGTTTAAAAAA", b"TTTTTTAAACCCCAGCGTAAAAGACAAAAAA", True),
+    (b"AAAAAAAAAAAAAAAATTTTTTTTTTTTTTT", b"AAAAAAAAAAAAAAAATTTTTTTTTTTTTTT", True),
+    (b"AGGAAAGTCTTTTACGCTGGGXXXAGAGTGA", b"AGGAAAGTCTTTTACGCTGGG\0\0\0AGAGTGA", False),
+    (b"TGGAAAGTCTTTTACGCTGGGXXXAGAGTGA", b"TCACTCT\0\0\0CCCAGCGTAAAAGACTTTCCA", False),
+    (b"AAAAAAAAAAAAAAAXTTTTTTTTTTTTTTT", b"AAAAAAAAAAAAAAA\0TTTTTTTTTTTTTTT", False),
+]
+
+
+def test_canonicalize_reference_kats(oracle):
+    for inp, want, good in KATS:
+        got, g = oracle.canonicalize_kmer(inp)
+        assert got == want and g == good
+
+
+def test_canonicalize_tie_rule(oracle):
+    """the middle base of an odd k is never compared"""
+    for kmer in (b"AAAAAAAAAAAAAAATTTTTTTTTTTTTTTT", b"AAAAAAAAAAAAAAAGTTTTTTTTTTTTTTT", b"CTG", b"AGT"):
+        assert oracle.canonicalize_kmer(kmer) == (kmer, True)
+
+
+def test_canonicalize_is_min_of_kmer_and_revcomp(oracle):
+    """reference tests/parameters.cpp:107-122 on random 31-mers"""
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    seq = oracle.random_sequence(10000, 1)
+    for i in range(len(seq) - 31):
+        k = seq[i:i + 31]
+        rc = k.translate(comp)[::-1]
+        assert oracle.canonicalize_kmer(k)[0] == min(k, rc)
+
+
+# --- file formats: reference tests/file.cpp:37-142 ---------------------------------
+
+def test_golden_files_are_reproducible(golden_dir, tmp_path):
+    """tests/golden/make_golden.py regenerates the committed fixtures byte for byte"""
+    import shutil
+    work = tmp_path / "golden"
+    shutil.copytree(golden_dir, work)
+    for n in ("c1.cobs_classic", "c1.cobs_compact", "expected.json"):
+        os.remove(work / n)
+    root = os.path.dirname(os.path.dirname(golden_dir))
+    env = dict(os.environ, PYTHONPATH=root)
+    subprocess.check_call([sys.executable, str(work / "make_golden.py")], env=env, cwd=root)
+    for n in ("c1.cobs_classic", "c1.cobs_compact", "expected.json"):
+        assert (work / n).read_bytes() == open(os.path.join(golden_dir, n), "rb").read(), n
+
+
+def test_header_geometry(oracle, golden_dir):
+    c = oracle.Index.open(os.path.join(golden_dir, "c1.cobs_classic"))
+    assert (c.term_size, c.canonicalize, c.num_hashes, c.num_docs) == (31, 1, 1, 7)
+    assert c.signature_size(0) == 8748 and c.data_offset == 116          # survey-probed reference build
+    assert c.page_size == 1 and c.row_size == 1 and c.counts_size == 8    # classic_index/search_file.hpp:26
+    assert os.path.getsize(os.path.join(golden_dir, "c1.cobs_classic")) == 116 + 8748
+    k = oracle.Index.open(os.path.join(golden_dir, "c1.cobs_compact"))
+    assert (k.page_size, k.num_pages, k.data_offset, k.counts_size) == (8, 1, 128, 64)
+    assert k.data_offset % k.page_size == 0                               # tests/file.cpp:122-142
+    assert [k.doc_name(i) for i in range(7)] == ["sample%d" % i for i in range(1, 8)]
+
+
+def test_compact_data_is_page_aligned(oracle, tmp_path):
+    for ps, ndocs in ((2, 33), (16, 200), (24, 500), (4096, 40000)):
+        pages = (ndocs + 8 * ps - 1) // (8 * ps)
+        p = cases.make_compact(cases.tmp(tmp_path, "a%d.cobs_compact" % ps), ndocs, ps, [50 + i for i in range(pages)])
+        ix = oracle.Index.open(p)
+        assert ix.data_offset % ps == 0 and ix.num_pages == pages
+        assert os.path.getsize(p) == ix.data_offset + sum((50 + i) * ps for i in range(pages))
+
+
+def test_not_an_index(oracle, golden_dir):
+    with pytest.raises(oracle.OracleError):
+        oracle.Index.open(os.path.join(golden_dir, "fasta", "sample1.fasta"))
+
+
+# --- exact scores: python/tests/test_cobs_index.py:22-61 + survey-probed outputs -----
+
+def test_python_test_known_answer(oracle, golden_dir):
+    exp = json.load(open(os.path.join(golden_dir, "expected.json")))
+    for key, name in (("classic", "c1.cobs_classic"), ("compact", "c1.cobs_compact")):
+        ix = oracle.Index.open(os.path.join(golden_dir, name))
+        r = oracle.search(ix, Q50)
+        assert len(r) == 7 and r[0][2] == "sample1" and r[0][3] == 20      # the reference's assertions
+        # full vector recorded from the real reference
+        assert [(n, s) for (_, _, n, s) in r] == [("sample1", 20), ("sample7", 3), ("sample2", 1),
+                                                   ("sample4", 1), ("sample6", 1), ("sample3", 0), ("sample5", 0)]
+        assert list(ix.counts(Q50)[:8]) == [20, 1, 0, 1, 0, 1, 3, 0]
+        assert [int(x) for x in ix.counts(Q50)] == exp[key]["counts"]
+        # threshold = ceil(threshold * T) in double (SURVEY App. D, T = 20)
+        assert len(oracle.search(ix, Q50, 0.05)) == 5
+        assert len(oracle.search(ix, Q50, 0.051)) == 2
+        assert [(n, s) for (_, _, n, s) in oracle.search(ix, Q50, 0.15)] == [("sample1", 20), ("sample7", 3)]
+        assert len(oracle.search(ix, Q50, 0.1500001)) == 1
+        # max_counts <= 1: unsorted, document order (App. D)
+        assert [(n, s) for (_, _, n, s) in oracle.search(ix, Q50[5:36])] == [
+            ("sample1", 1), ("sample2", 0), ("sample3", 0), ("sample4", 0), ("sample5", 0),
+            ("sample6", 0), ("sample7", 1)]
+        # num_results truncation keeps the best
+        assert [(n, s) for (_, _, n, s) in oracle.search(ix, Q50, 0.0, 2)] == [("sample1", 20), ("sample7", 3)]
+    a = oracle.Index.open(os.path.join(golden_dir, "c1.cobs_compact"))
+    b = oracle.Index.open(os.path.join(golden_dir, "c1.cobs_classic"))
+    assert [(n, s) for (_, _, n, s) in oracle.search([a, b], Q50)] == [
+        ("sample1", 20), ("sample1", 20), ("sample7", 3), ("sample7", 3), ("sample2", 1), ("sample4", 1),
+        ("sample6", 1), ("sample2", 1), ("sample4", 1), ("sample6", 1), ("sample3", 0), ("sample5", 0),
+        ("sample3", 0), ("sample5", 0)]
+
+
+def test_every_document_kmer_is_found(oracle, construct, golden_dir, tmp_path):
+    """reference tests/fasta_file.cpp:55-94: index with canonicalize=0, 3 hashes, fpr 0.1;
+    every 31-mer of a document (protein letters and N included) scores >= 1 in it"""
+    fasta = os.path.join(golden_dir, "fasta")
+    docs = construct.fasta_dir_docs(fasta, 31, 0, 3)
+    assert len(docs) == 7
+    p = cases.tmp(tmp_path, "raw.cobs_classic")
+    construct.classic_construct(docs, p, canonicalize=0, num_hashes=3, false_positive_rate=0.1)
+    ix = oracle.Index.open(p)
+    assert ix.canonicalize == 0 and ix.num_hashes == 3
+    for d, fn in enumerate(sorted(os.listdir(fasta))):
+        for seq in construct.fasta_sequences(os.path.join(fasta, fn)):
+            if len(seq) >= 31:
+                assert ix.counts(seq)[d] == len(seq) - 30
+                res = oracle.search(ix, seq[:31])
+                assert len(res) == 7
+
+
+# --- the reference's synthetic-corpus tests, run through the restatement -----------
+
+def test_classic_index_query_suite(oracle, construct, tmp_path):
+    """tests/classic_index_query.cpp:36-154 (query shortened from 50000 to 8000 characters)"""
+    query = oracle.random_sequence(8000, 2)
+    docs = construct.generate_documents_all(query)
+    p = cases.tmp(tmp_path, "all.cobs_classic")
+    construct.classic_construct(docs, p, num_hashes=3, false_positive_rate=0.1)
+    ix = oracle.Index.open(p)
+    res = oracle.search(ix, query)
+    assert len(res) == len(docs)
+    for (_, d, name, score) in res:
+        assert score >= docs[int(name[-2:])].num_terms         # all_included: lower bound
+    # false_positive: random 31-mers score 0 or 1, per-document total bounded (scaled from 10000 queries)
+    totals = np.zeros(ix.counts_size, dtype=np.int64)
+    n = 2000
+    for i in range(n):
+        c = ix.counts(oracle.random_sequence(31, i))
+        assert c.max() <= 1
+        totals += c
+    assert totals.max() <= 1070 * n / 10000 * 1.25
+    for ndocs in (33, 2000):
+        one = construct.generate_documents_one(query, ndocs)
+        po = cases.tmp(tmp_path, "one%d.cobs_classic" % ndocs)
+        construct.classic_construct(one, po, num_hashes=3, false_positive_rate=0.1)
+        res = oracle.search(oracle.Index.open(po), query)
+        assert len(res) == ndocs and all(r[3] == 1 for r in res)
+
+
+def test_compact_index_query_suite_all_score_widths(oracle, construct, tmp_path):
+    """tests/compact_index_query.cpp:36-181: u8 path (160 chars) and u16 path agree with truth"""
+    for length in (160, 6000):
+        query = oracle.random_sequence(length, 1)
+        docs = construct.generate_documents_all(query)
+        p = cases.tmp(tmp_path, "all%d.cobs_compact" % length)
+        construct.compact_construct(docs, p, num_hashes=3, false_positive_rate=0.1, page_size=2)
+        ix = oracle.Index.open(p)
+        assert ix.page_size == 2 and ix.num_pages == 3
+        c, width = ix.counts(query, want_width=True)
+        assert width == (1 if length == 160 else 2)
+        res = oracle.search(ix, query)
+        assert len(res) == len(docs)
+        for (_, d, name, score) in res:
+            assert score >= docs[int(name[-2:])].num_terms
+    one = construct.generate_documents_one(query, 2000)
+    po = cases.tmp(tmp_path, "one.cobs_compact")
+    construct.compact_construct(one, po, num_hashes=3, false_positive_rate=0.1, page_size=2)
+    ix = oracle.Index.open(po)
+    assert ix.num_pages == 125
+    res = oracle.search(ix, query)
+    assert len(res) == 2000 and all(r[3] == 1 for r in res)
+
+
+def test_score_width_paths_agree(oracle, tmp_path):
+    """u8 (T<=255), u16, and multi-threaded batches give the same counts as a direct bit count"""
+    q = oracle.random_sequence(400, 5)
+    p = cases.make_compact(cases.tmp(tmp_path, "w.cobs_compact"), 500, 16, [700, 900, 1100, 1300], 2, 31, 1, 0.3, 3)
+    ix = oracle.Index.open(p)
+    raw = open(p, "rb").read()
+    off = ix.data_offset
+    mats = []
+    for s in (700, 900, 1100, 1300):
+        mats.append(np.frombuffer(raw, dtype=np.uint8, count=s * 16, offset=off).reshape(s, 16))
+        off += s * 16
+    for length in (31, 200, 285, 286, 400):
+        qq = q[:length]
+        hashes, _ = oracle.term_hashes(qq, 31, 1, 2)
+        want = np.zeros(ix.counts_size, dtype=np.uint32)
+        for pg, (s, m) in enumerate(zip((700, 900, 1100, 1300), mats)):
+            rows = m[(hashes % np.uint64(s)).astype(np.int64)]          # [T, H, 16]
+            anded = np.bitwise_and.reduce(rows, axis=1)
+            bits = np.unpackbits(anded, axis=1, bitorder="little")       # [T, 128]
+            want[pg * 128:(pg + 1) * 128] = bits.sum(axis=0)
+        for threads in (1, 3):
+            assert np.array_equal(ix.counts(qq, threads=threads), want)
+
+
+def test_error_conditions(oracle, golden_dir):
+    ix = oracle.Index.open(os.path.join(golden_dir, "c1.cobs_classic"))
+    with pytest.raises(oracle.OracleError) as e:
+        ix.counts(b"ACGT" * 7)
+    assert e.value.code == 3
+    with pytest.raises(oracle.OracleError) as e:
+        ix.counts(Q50[:20] + b"N" + Q50[21:])
+    assert e.value.code == 4
+
+
+def test_query_generators(oracle):
+    """cobs::random_sequence = minstd_rand0 % 4; benchmark queries = one mt19937 stream"""
+    s = oracle.random_sequence(12, 1)
+    x, want = 1, []
+    for _ in range(12):
+        x = x * 16807 % 2147483647
+        want.append(b"ACGT"[x % 4])
+    assert s == bytes(want)
+    g = oracle.Mt19937Queries(5489)               # default std::mt19937 seed: first output 3499211612
+    assert g.next(1) == b"ACGT"[3499211612 % 4:3499211612 % 4 + 1]
