@@ -1,0 +1,116 @@
+// include/cobs_gpu_search.hpp -- C++17 host-side mirror of the reference's operator
+// API for the query path, implemented over the C ABI of cobs_gpu.h (header only).
+//
+// Reference interface being mirrored:
+//   struct cobs::SearchResult { const char* doc_name; uint32_t score; }   (cobs/query/search.hpp:17-27)
+//   class  cobs::Search { virtual void search(const std::string& query,
+//                std::vector<SearchResult>& result, double threshold = 0.0,
+//                size_t num_results = 0) = 0; }                            (cobs/query/search.hpp:29-47)
+//   class  cobs::ClassicSearch : Search { ClassicSearch(std::string path); ... } (classic_search.hpp:19-37)
+//
+// Same names, argument meaning and defaults.  Differences, all at the error
+// boundary: where the reference terminates the process (exit/abort on a short
+// query, a non-ACGT base, an unreadable index: classic_search.cpp:431-433, :93-96,
+// :61-63) this class throws cobs_gpu::Error carrying the C-ABI status.
+// `result` is caller-owned, resized and overwritten (classic_search.cpp:147,190);
+// SearchResult::doc_name points into strings owned by the Search object.
+#pragma once
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "cobs_gpu.h"
+
+namespace cobs_gpu {
+
+struct SearchResult {
+    //! string reference to document name (owned by the index handle)
+    const char* doc_name = nullptr;
+    //! score (number of matched k-mers)
+    uint32_t score = 0;
+    SearchResult() = default;
+    SearchResult(const char* name, uint32_t s) : doc_name(name), score(s) {}
+};
+
+class Error : public std::runtime_error {
+public:
+    Error(cobs_gpu_status st, const std::string& msg) : std::runtime_error(msg), status(st) {}
+    cobs_gpu_status status;
+};
+
+class Search {
+public:
+    virtual ~Search() = default;
+    virtual void search(const std::string& query, std::vector<SearchResult>& result,
+                        double threshold = 0.0, size_t num_results = 0) = 0;
+};
+
+class ClassicSearch : public Search {
+public:
+    //! auto-detect classic / compact and stage the index into HBM
+    explicit ClassicSearch(const std::string& path, int device = -1)
+        : ClassicSearch(std::vector<std::string>{path}, device) {}
+
+    //! several index files searched together (reference: vector<shared_ptr<IndexSearchFile>>)
+    explicit ClassicSearch(const std::vector<std::string>& paths, int device = -1) {
+        std::vector<const char*> cp;
+        for (const auto& p : paths) cp.push_back(p.c_str());
+        cobs_gpu_options o{};
+        o.struct_size = sizeof o;
+        o.device = device;
+        check(cobs_gpu_open(cp.data(), cp.size(), &o, &ix_));
+    }
+
+    ~ClassicSearch() override { cobs_gpu_close(ix_); }
+    ClassicSearch(const ClassicSearch&) = delete;
+    ClassicSearch& operator=(const ClassicSearch&) = delete;
+
+    void search(const std::string& query, std::vector<SearchResult>& result,
+                double threshold = 0.0, size_t num_results = 0) final {
+        size_t n = 0;
+        const size_t total = (size_t)cobs_gpu_total_counts(ix_);
+        hits_.resize(num_results == 0 || num_results > total ? total : num_results);
+        check(cobs_gpu_search(ix_, query.data(), query.size(), threshold, num_results,
+                              hits_.data(), hits_.size(), &n));
+        result.resize(n);
+        for (size_t i = 0; i < n; ++i)
+            result[i] = SearchResult(cobs_gpu_doc_name(ix_, hits_[i].file_no, hits_[i].doc), hits_[i].score);
+    }
+
+    //! many queries in one device pass (the performance path; the reference loops serially)
+    void search_batch(const std::vector<std::string>& queries,
+                      std::vector<std::vector<SearchResult>>& results,
+                      double threshold = 0.0, size_t num_results = 0) {
+        std::vector<const char*> qp;
+        std::vector<size_t> ql;
+        for (const auto& q : queries) { qp.push_back(q.data()); ql.push_back(q.size()); }
+        std::vector<size_t> offs(queries.size() + 1, 0);
+        const size_t total = (size_t)cobs_gpu_total_counts(ix_);
+        size_t per = num_results == 0 || num_results > total ? total : num_results;
+        hits_.resize(per * queries.size() + 1);
+        size_t bad = 0;
+        cobs_gpu_status st = cobs_gpu_search_batch(ix_, qp.data(), ql.data(), queries.size(), threshold,
+                                                   num_results, hits_.data(), hits_.size(), offs.data(), &bad);
+        check(st);
+        results.resize(queries.size());
+        for (size_t q = 0; q < queries.size(); ++q) {
+            results[q].resize(offs[q + 1] - offs[q]);
+            for (size_t i = offs[q]; i < offs[q + 1]; ++i)
+                results[q][i - offs[q]] =
+                    SearchResult(cobs_gpu_doc_name(ix_, hits_[i].file_no, hits_[i].doc), hits_[i].score);
+        }
+    }
+
+    cobs_gpu_index* handle() const { return ix_; }
+
+private:
+    static void check(cobs_gpu_status st) {
+        if (st != COBS_GPU_OK) throw Error(st, cobs_gpu_last_error());
+    }
+    cobs_gpu_index* ix_ = nullptr;
+    std::vector<cobs_gpu_hit> hits_;
+};
+
+}  // namespace cobs_gpu

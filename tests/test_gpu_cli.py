@@ -1,0 +1,57 @@
+"""GPU: the C++17 host class (include/cobs_gpu_search.hpp) through the `cobs query`
+style command line tool, against the oracle (output format of reference
+src/cobs.cpp:410-469)."""
+import os
+import subprocess
+
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "cobs_amd", "cobs_gpu_query")
+Q50 = "AGTCAACGCTAAGGCATTTCCCCCCTGCCTCCTGCCTGCTGCCAAGCCCT"
+
+
+def _run(*args):
+    assert os.path.exists(TOOL), "build cobs_amd/cobs_gpu_query first (make -C cobs_amd/csrc)"
+    return subprocess.run([TOOL] + list(args), capture_output=True, text=True, timeout=300)
+
+
+def test_single_query_default_threshold(gpu_lib, oracle, golden_dir):
+    idx = os.path.join(golden_dir, "c1.cobs_classic")
+    r = _run("-i", idx, Q50)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == "sample1\t20\n"                       # default threshold 0.8 (src/cobs.cpp:481-484)
+    r = _run("-i", idx, "-t", "0", Q50)
+    want = "".join("%s\t%d\n" % (n, s) for (_, _, n, s) in oracle.search(oracle.Index.open(idx), Q50.encode()))
+    assert r.stdout == want
+    r = _run("-i", idx, "-t", "0", "-l", "2", Q50)
+    assert r.stdout == "sample1\t20\nsample7\t3\n"
+
+
+def test_query_file_and_two_indexes(gpu_lib, oracle, golden_dir, tmp_path):
+    a = os.path.join(golden_dir, "c1.cobs_compact")
+    b = os.path.join(golden_dir, "c1.cobs_classic")
+    qf = tmp_path / "q.fa"
+    qf.write_text(">first query\n%s\n%s\n\n;second\n%s\n" % (Q50[:25], Q50[25:], Q50[3:40]))
+    r = _run("-i", a, "-i", b, "-t", "0.05", "-f", str(qf))
+    assert r.returncode == 0, r.stderr
+    ixs = [oracle.Index.open(a), oracle.Index.open(b)]
+    want = ""
+    for comment, q in (("*first query", Q50), ("*second", Q50[3:40])):
+        res = oracle.search(ixs, q.encode(), 0.05)
+        want += "%s\t%d\n" % (comment, len(res)) + "".join("%s\t%d\n" % (n, s) for (_, _, n, s) in res)
+    assert r.stdout == want
+
+
+def test_bad_input_is_an_error_exit(gpu_lib, golden_dir):
+    idx = os.path.join(golden_dir, "c1.cobs_classic")
+    r = _run("-i", idx, "ACGT")
+    assert r.returncode != 0 and "query too short" in r.stderr
+    r = _run("-i", idx, Q50.replace("G", "N", 1))
+    assert r.returncode != 0 and "Invalid DNA base pair" in r.stderr
+    r = _run("-i", os.path.join(golden_dir, "expected.json"), Q50)
+    assert r.returncode != 0 and "Could not open index path" in r.stderr
