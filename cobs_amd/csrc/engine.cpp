@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -224,7 +225,19 @@ cobs_gpu_status plan_part(Part& pt, uint32_t rank, uint32_t count) {
     }
     pt.nlocal = pt.end_page - pt.first_page;
     if (pt.ncols > 0xFFFFFFF0ull / 16) return fail(COBS_GPU_ERR_UNSUPPORTED, "row too wide");
-    pt.pitch = (uint32_t)round_up(pt.ncols, 16);
+    // Rows are made of 16-byte chunks.  Starting every row on a 128-byte cache-line
+    // boundary removes the partial lines at both ends of a gathered row (measured on
+    // MI355X: 1568-byte rows, 1664-byte pitch: -8.5 % scan time); it is applied when
+    // it costs at most 12.5 % more HBM.  COBS_GPU_ROW_ALIGN overrides (tuning hook).
+    uint64_t align = 16;
+    for (uint64_t a : {128ull, 64ull, 32ull}) {
+        if (round_up(pt.ncols, a) * 8 <= pt.ncols * 9) { align = a; break; }
+    }
+    if (const char* e = getenv("COBS_GPU_ROW_ALIGN")) {
+        const uint64_t v = std::strtoull(e, nullptr, 10);
+        if (v >= 16 && v <= 4096 && v % 16 == 0) align = v;
+    }
+    pt.pitch = (uint32_t)round_up(pt.ncols, align);
     pt.cpp = pt.pitch / 16;
     pt.total_chunks = pt.nlocal * pt.cpp;
     pt.ntiles = (pt.total_chunks + 63) / 64;

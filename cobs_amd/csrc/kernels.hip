@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "device_types.hpp"
 #include "kernels.hpp"
@@ -268,20 +269,26 @@ __device__ __forceinline__ void retire_pair(uint32_t (&pl)[4][NP], const uint32_
     }
 }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool NT>
 __device__ __forceinline__ uint4 load_row(const uint8_t* lane_base, uint32_t row, uint32_t pitch) {
-    return *reinterpret_cast<const uint4*>(lane_base + (uint64_t)row * pitch);
+    const u32x4* p = reinterpret_cast<const u32x4*>(lane_base + (uint64_t)row * pitch);
+    const u32x4 v = NT ? __builtin_nontemporal_load(p) : *p;
+    return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+template <bool NT>
 __device__ __forceinline__ void issue_rows(uint4 (&X)[8], const uint8_t* lane_base, uint32_t pitch,
                                            const uint4& i0, const uint4& i1) {
-    X[0] = load_row(lane_base, i0.x, pitch);
-    X[1] = load_row(lane_base, i0.y, pitch);
-    X[2] = load_row(lane_base, i0.z, pitch);
-    X[3] = load_row(lane_base, i0.w, pitch);
-    X[4] = load_row(lane_base, i1.x, pitch);
-    X[5] = load_row(lane_base, i1.y, pitch);
-    X[6] = load_row(lane_base, i1.z, pitch);
-    X[7] = load_row(lane_base, i1.w, pitch);
+    X[0] = load_row<NT>(lane_base, i0.x, pitch);
+    X[1] = load_row<NT>(lane_base, i0.y, pitch);
+    X[2] = load_row<NT>(lane_base, i0.z, pitch);
+    X[3] = load_row<NT>(lane_base, i0.w, pitch);
+    X[4] = load_row<NT>(lane_base, i1.x, pitch);
+    X[5] = load_row<NT>(lane_base, i1.y, pitch);
+    X[6] = load_row<NT>(lane_base, i1.z, pitch);
+    X[7] = load_row<NT>(lane_base, i1.w, pitch);
 }
 
 __device__ __forceinline__ void and_rows(uint4 (&X)[8], const uint4 (&Y)[8]) {
@@ -291,16 +298,25 @@ __device__ __forceinline__ void and_rows(uint4 (&X)[8], const uint4 (&Y)[8]) {
     }
 }
 
-template <int NP, int NW, bool H1, typename OutT>
-__global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
+// VAR bit 0: non-temporal row loads; bit 1: query-major instead of tile-major group order
+template <int NP, int NW, bool H1, typename OutT, int VAR = 0, int MINW = 1>
+__global__ __launch_bounds__(NW * 64, MINW) void scan_kernel(ScanArgs a) {
+    constexpr bool NT = (VAR & 1) != 0;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // merge buffers: [NW/2 (min 1)][NP][64 lanes] of uint4
     uint4* mbuf = reinterpret_cast<uint4*>(smem);
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
-    const uint32_t tile = blockIdx.x / a.nq;         // tile-major: co-resident groups share a sub-index
-    const uint32_t q = blockIdx.x - tile * a.nq;
+    uint32_t tile, q;
+    if constexpr ((VAR & 2) != 0) {
+        const uint32_t ntiles = (a.total_chunks + 63u) / 64u;
+        q = blockIdx.x / ntiles;
+        tile = blockIdx.x - q * ntiles;
+    } else {
+        tile = blockIdx.x / a.nq;                    // tile-major: co-resident groups share a sub-index
+        q = blockIdx.x - tile * a.nq;
+    }
 
     const uint32_t g = tile * 64u + lane;
     const uint32_t gc = g < a.total_chunks ? g : a.total_chunks - 1u;
@@ -335,7 +351,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
             const uint32_t last = nw - 1;
             const uint4* t0 = reinterpret_cast<const uint4*>(tw);
             uint4 i0a = t0[0], i0b = t0[1];
-            issue_rows(XA, lane_base, pitch, i0a, i0b);
+            issue_rows<NT>(XA, lane_base, pitch, i0a, i0b);
             const uint4* t1 = reinterpret_cast<const uint4*>(tw + step * (last < 1u ? last : 1u));
             uint4 i1a = t1[0], i1b = t1[1];
             uint32_t i = 0;
@@ -343,18 +359,18 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
                 // XA in flight = block i, (i1a,i1b) = indices of block i+1
                 const uint4* tn = reinterpret_cast<const uint4*>(tw + step * (i + 2));
                 i0a = tn[0]; i0b = tn[1];
-                issue_rows(XB, lane_base, pitch, i1a, i1b);
+                issue_rows<NT>(XB, lane_base, pitch, i1a, i1b);
                 absorb_block<NP>(pl, XA, ea);
                 const uint32_t nx = i + 3 < last ? i + 3 : last;
                 const uint4* tm = reinterpret_cast<const uint4*>(tw + step * nx);
                 i1a = tm[0]; i1b = tm[1];
-                issue_rows(XA, lane_base, pitch, i0a, i0b);
+                issue_rows<NT>(XA, lane_base, pitch, i0a, i0b);
                 absorb_block<NP>(pl, XB, eb);
                 retire_pair<NP>(pl, ea, eb);
             }
             // XA in flight = block i; one or two blocks left
             if (i + 1 < nw) {
-                issue_rows(XB, lane_base, pitch, i1a, i1b);
+                issue_rows<NT>(XB, lane_base, pitch, i1a, i1b);
                 absorb_block<NP>(pl, XA, ea);
                 absorb_block<NP>(pl, XB, eb);
                 retire_pair<NP>(pl, ea, eb);
@@ -369,9 +385,9 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
         for (uint32_t i = 0; i < nw; ++i) {
             const uint32_t blk = wave + i * NW;
             const uint4* t = reinterpret_cast<const uint4*>(tab + (uint64_t)blk * 8u * H);
-            issue_rows(X, lane_base, pitch, t[0], t[1]);
+            issue_rows<NT>(X, lane_base, pitch, t[0], t[1]);
             for (uint32_t j = 1; j < H; ++j) {
-                issue_rows(Y, lane_base, pitch, t[2 * j], t[2 * j + 1]);
+                issue_rows<NT>(Y, lane_base, pitch, t[2 * j], t[2 * j + 1]);
                 and_rows(X, Y);
             }
             absorb_block<NP>(pl, X, ea);
@@ -570,13 +586,13 @@ hipError_t launch_hash(const HashArgs& a, uint64_t total_threads, hipStream_t st
     return hipGetLastError();
 }
 
-template <int NP, int NW, bool H1, typename OutT>
+template <int NP, int NW, bool H1, typename OutT, int VAR = 0, int MINW = 1>
 static hipError_t launch_scan_inst(const ScanArgs& a, uint32_t ntiles, hipStream_t stream) {
     const uint64_t groups = (uint64_t)ntiles * a.nq;
     if (groups == 0) return hipSuccess;
     if (groups > 0x7FFFFFFFull) return hipErrorInvalidValue;
     constexpr size_t lds = (size_t)(NW >= 2 ? NW / 2 : 1) * NP * 64 * sizeof(uint4);
-    auto kern = scan_kernel<NP, NW, H1, OutT>;
+    auto kern = scan_kernel<NP, NW, H1, OutT, VAR, MINW>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -601,8 +617,31 @@ int scan_planes_for(uint64_t max_terms) {
     return -1;
 }
 
+// Tuning hook for kernel experiments (not part of the C ABI): COBS_GPU_SCAN_VARIANT=<n>
+// selects an alternative instantiation of the 10-plane single-hash kernel.
+static int scan_variant() {
+    static const int v = [] {
+        const char* e = getenv("COBS_GPU_SCAN_VARIANT");
+        return e ? atoi(e) : 0;
+    }();
+    return v;
+}
+
 hipError_t launch_scan(const ScanArgs& a, uint32_t ntiles, int planes, hipStream_t stream) {
     const bool h1 = a.num_hashes == 1;
+    if (planes == 10 && h1) {
+        switch (scan_variant()) {
+        case 1: return launch_scan_inst<10, 4, true, uint16_t, 1>(a, ntiles, stream);       // nt loads
+        case 2: return launch_scan_inst<10, 4, true, uint16_t, 2>(a, ntiles, stream);       // query-major
+        case 3: return launch_scan_inst<10, 4, true, uint16_t, 0, 4>(a, ntiles, stream);    // <=128 VGPRs
+        case 4: return launch_scan_inst<10, 2, true, uint16_t, 0>(a, ntiles, stream);       // 2 waves/group
+        case 5: return launch_scan_inst<10, 8, true, uint16_t, 0>(a, ntiles, stream);       // 8 waves/group
+        case 6: return launch_scan_inst<10, 8, true, uint16_t, 0, 4>(a, ntiles, stream);    // 8 waves, <=128 VGPRs
+        case 7: return launch_scan_inst<10, 4, true, uint16_t, 1, 4>(a, ntiles, stream);    // nt + <=128
+        case 8: return launch_scan_inst<10, 1, true, uint16_t, 0>(a, ntiles, stream);       // 1 wave/group
+        default: break;
+        }
+    }
     switch (planes) {
     case 4: return launch_scan_np<4, uint16_t>(a, ntiles, h1, stream);
     case 8: return launch_scan_np<8, uint16_t>(a, ntiles, h1, stream);
