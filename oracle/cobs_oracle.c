@@ -851,10 +851,23 @@ size_t oracle_search_many(oracle_index* const* ixs, size_t n, const char* text,
     double t0 = now_s();
     while (done < nq) {
         size_t nout = 0;
-        int rc = oracle_search(ixs, n, text + offsets[done], (size_t)(offsets[done + 1] - offsets[done]),
+        int rc;
+        if (threshold < 0) {
+            /* counts only: the score_list of classic_search.cpp:456-467, no counts_to_result */
+            size_t off = 0;
+            rc = ORACLE_OK;
+            for (size_t i = 0; i < n && rc == ORACLE_OK; ++i) {
+                rc = oracle_counts(ixs[i], text + offsets[done], (size_t)(offsets[done + 1] - offsets[done]),
+                                   threads, os + off, NULL);
+                off += oracle_counts_size(ixs[i]);
+            }
+            nout = cap < 4 ? cap : 4;
+        } else {
+            rc = oracle_search(ixs, n, text + offsets[done], (size_t)(offsets[done + 1] - offsets[done]),
                                threshold, num_results, threads, oi, od, os, cap, &nout);
+        }
         if (rc != ORACLE_OK) break;
-        for (size_t k = 0; k < nout && k < 4; ++k) sum += (uint64_t)os[k] * 31 + od[k];
+        for (size_t k = 0; k < nout && k < 4; ++k) sum += (uint64_t)os[k] * 31;
         done++;
         if (now_s() - t0 >= seconds) break;
     }

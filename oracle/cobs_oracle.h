@@ -103,7 +103,8 @@ int oracle_search(oracle_index* const* ixs, size_t n, const char* query, size_t 
                   uint32_t* out_index, uint32_t* out_doc, uint32_t* out_score,
                   size_t cap, size_t* n_out);
 
-/* CPU-baseline timing loop (all in C): queries q at text[offsets[q]..offsets[q+1]) */
+/* CPU-baseline timing loop (all in C): queries q at text[offsets[q]..offsets[q+1]);
+ * threshold < 0 = per-document counts only (no threshold filter / ranking) */
 size_t oracle_search_many(oracle_index* const* ixs, size_t n, const char* text,
                           const uint64_t* offsets, size_t nq, double threshold,
                           size_t num_results, int threads, double seconds,
