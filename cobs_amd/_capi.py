@@ -25,7 +25,8 @@ STATUS_NAMES = {
 class Options(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32),
                 ("shard_rank", C.c_uint32), ("shard_count", C.c_uint32),
-                ("waves_per_group", C.c_uint32), ("reserved", C.c_uint32)]
+                ("waves_per_group", C.c_uint32), ("reserved", C.c_uint32),
+                ("hbm_budget_bytes", C.c_uint64)]
 
 
 class IndexInfo(C.Structure):

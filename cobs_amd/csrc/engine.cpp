@@ -58,6 +58,10 @@ template <typename T>
 struct DevBuf {     // grow-only device allocation
     T* p = nullptr;
     size_t cap = 0;   // elements
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
     ~DevBuf() { if (p) (void)hipFree(p); }
     hipError_t reserve(size_t n) {
         if (n <= cap) return hipSuccess;
@@ -72,6 +76,10 @@ template <typename T>
 struct PinnedBuf {  // grow-only pinned host staging
     T* p = nullptr;
     size_t cap = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    PinnedBuf(PinnedBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
     ~PinnedBuf() { if (p) (void)hipHostFree(p); }
     hipError_t reserve(size_t n) {
         if (n <= cap) return hipSuccess;
@@ -82,20 +90,67 @@ struct PinnedBuf {  // grow-only pinned host staging
     }
 };
 
-// One index file as resident on this device (possibly only a shard of it).
+// A slice of one file-level sub-index: all of its rows, row bytes [col0, col0+ncols).
+struct VPage {
+    uint32_t fp = 0;
+    uint64_t col0 = 0, ncols = 0;
+};
+
+// A group of slices (equal width) that is in HBM at the same time.  A resident
+// index is one chunk; an index larger than the HBM budget is cut into chunks that
+// are streamed through two device buffers, one scan pass per chunk (documents of
+// different sub-indexes / column ranges never combine, so every chunk is an
+// independent scan that fills its own score slots).
+struct Chunk {
+    std::vector<VPage> vp;
+    std::vector<PageDev> pages;      // bases relative to the chunk's buffer
+    PageDev* d_pages = nullptr;
+    uint32_t pitch = 0, cpp = 0, total_chunks = 0, ntiles = 0;
+    size_t bytes = 0;                // device bytes incl. zero rows
+    size_t stage_bytes = 0;          // packed host bytes (rows x ncols)
+    uint8_t* d_data = nullptr;       // resident chunk only
+};
+
+// One index file as held by this device (possibly only a shard of it).
 struct Part {
     IndexMeta meta;
     uint32_t first_page = 0, end_page = 0;   // file-level sub-indexes held here
     uint64_t col0 = 0, ncols = 0;            // row bytes [col0, col0+ncols) of each held sub-index
-    uint32_t pitch = 0, cpp = 0, nlocal = 0, total_chunks = 0, ntiles = 0;
-    uint8_t* d_blob = nullptr;
-    size_t blob_bytes = 0;
-    PageDev* d_pages = nullptr;
-    std::vector<PageDev> pages;
+    std::vector<Chunk> chunks;
+    bool streamed = false;
+    size_t hbm_bytes = 0;
+    uint32_t max_chunk_pages = 0;
+    // streaming state (BASELINE config 5: index larger than the HBM budget)
+    std::unique_ptr<MappedFile> file;        // source of the chunks
+    bool synthetic = false;
+    uint64_t synth_seed = 0;
+    DevBuf<uint8_t> sbuf[2];
+    PinnedBuf<uint8_t> stage[2];
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copied[2] = {nullptr, nullptr}, scanned[2] = {nullptr, nullptr};
+    bool buf_used[2] = {false, false};
     uint64_t doc_offset = 0;      // first global score slot of this file
     uint64_t slot_begin = 0;      // file-level score slots computed here
     uint64_t slot_count = 0;
     uint64_t local_offset = 0;    // position of those slots in a local count row
+
+    uint32_t num_vpages() const {
+        uint32_t n = 0;
+        for (const Chunk& c : chunks) n += (uint32_t)c.vp.size();
+        return n;
+    }
+    Part() = default;
+    Part(Part&&) = default;
+    Part(const Part&) = delete;
+    ~Part() {
+        for (Chunk& c : chunks) {
+            if (c.d_data) (void)hipFree(c.d_data);
+            if (c.d_pages) (void)hipFree(c.d_pages);
+        }
+        for (auto& e : copied) if (e) (void)hipEventDestroy(e);
+        for (auto& e : scanned) if (e) (void)hipEventDestroy(e);
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    }
 };
 
 }  // namespace
@@ -103,6 +158,7 @@ struct Part {
 struct cobs_gpu_index {
     int device = 0;
     uint32_t shard_rank = 0, shard_count = 1;
+    uint64_t hbm_budget = 0;      // 0 = everything resident
     std::vector<Part> parts;
     uint64_t total_counts = 0, local_counts = 0;
     double timers[5] = {0, 0, 0, 0, 0};
@@ -158,13 +214,7 @@ struct cobs_gpu_batch {
     }
 };
 
-cobs_gpu_index::~cobs_gpu_index() {
-    delete scratch;
-    for (auto& p : parts) {
-        if (p.d_blob) (void)hipFree(p.d_blob);
-        if (p.d_pages) (void)hipFree(p.d_pages);
-    }
-}
+cobs_gpu_index::~cobs_gpu_index() { delete scratch; }
 
 namespace {
 
@@ -191,8 +241,59 @@ cobs_gpu_status select_device(const cobs_gpu_options* o, int* device) {
     return COBS_GPU_OK;
 }
 
-// Decide which slice of the file this shard holds and lay out its pages.
-cobs_gpu_status plan_part(Part& pt, uint32_t rank, uint32_t count) {
+// Rows are made of 16-byte chunks.  Starting every row on a 128-byte cache-line
+// boundary removes the partial lines at both ends of a gathered row (measured on
+// MI355X: 1568-byte rows, 1664-byte pitch: -8.5 % scan time); it is applied when
+// it costs at most 12.5 % more HBM.  COBS_GPU_ROW_ALIGN overrides (tuning hook).
+uint32_t pitch_for(uint64_t ncols) {
+    uint64_t align = 16;
+    for (uint64_t a : {128ull, 64ull, 32ull}) {
+        if (round_up(ncols, a) * 8 <= ncols * 9) { align = a; break; }
+    }
+    if (const char* e = getenv("COBS_GPU_ROW_ALIGN")) {
+        const uint64_t v = std::strtoull(e, nullptr, 10);
+        if (v >= 16 && v <= 4096 && v % 16 == 0) align = v;
+    }
+    return (uint32_t)round_up(ncols, align);
+}
+
+uint64_t slice_bytes(uint64_t sig, uint64_t ncols) {
+    return round_up((sig + 1) * (uint64_t)pitch_for(ncols), 256);     // +1: the all-zero row
+}
+
+// fill pages / geometry of a chunk whose slices (equal ncols) are already listed
+void layout_chunk(const Part& pt, Chunk& c) {
+    const IndexMeta& m = pt.meta;
+    const uint64_t prb = m.page_row_bytes();
+    const uint64_t ncols = c.vp.empty() ? 0 : c.vp[0].ncols;
+    c.pitch = pitch_for(ncols);
+    c.cpp = c.pitch / 16;
+    c.total_chunks = (uint32_t)c.vp.size() * c.cpp;
+    c.ntiles = (c.total_chunks + 63) / 64;
+    c.pages.resize(c.vp.size());
+    uint64_t off = 0, packed = 0;
+    for (size_t i = 0; i < c.vp.size(); ++i) {
+        const VPage& v = c.vp[i];
+        PageDev& pd = c.pages[i];
+        const uint64_t file_slot = ((m.kind == IndexKind::Compact ? (uint64_t)v.fp * prb : 0) + v.col0) * 8;
+        pd.base = off;
+        pd.sig = m.signature_sizes[v.fp];
+        pd.magic = ~0ull / pd.sig;
+        pd.slot0 = (uint32_t)(file_slot - pt.slot_begin);
+        pd.doc0 = (uint32_t)file_slot;
+        pd.valid_bytes = (uint32_t)v.ncols;
+        pd.reserved = 0;
+        off += round_up((pd.sig + 1) * (uint64_t)c.pitch, 256);
+        packed += pd.sig * v.ncols;
+    }
+    c.bytes = off;
+    c.stage_bytes = packed;
+}
+
+// Decide which slice of the file this shard holds and cut it into chunks:
+// one resident chunk if it fits `budget` (0 = unlimited), else streamed chunks of at
+// most budget/2 bytes each (two device buffers).
+cobs_gpu_status plan_part(Part& pt, uint32_t rank, uint32_t count, uint64_t* budget_left) {
     const IndexMeta& m = pt.meta;
     if (m.term_size == 0) return fail(COBS_GPU_ERR_FORMAT, "term_size is zero");
     if (m.num_hashes == 0 || m.num_hashes > 64)
@@ -223,61 +324,102 @@ cobs_gpu_status plan_part(Part& pt, uint32_t rank, uint32_t count) {
         pt.slot_begin = pt.col0 * 8;
         pt.slot_count = pt.ncols * 8;
     }
-    pt.nlocal = pt.end_page - pt.first_page;
     if (pt.ncols > 0xFFFFFFF0ull / 16) return fail(COBS_GPU_ERR_UNSUPPORTED, "row too wide");
-    // Rows are made of 16-byte chunks.  Starting every row on a 128-byte cache-line
-    // boundary removes the partial lines at both ends of a gathered row (measured on
-    // MI355X: 1568-byte rows, 1664-byte pitch: -8.5 % scan time); it is applied when
-    // it costs at most 12.5 % more HBM.  COBS_GPU_ROW_ALIGN overrides (tuning hook).
-    uint64_t align = 16;
-    for (uint64_t a : {128ull, 64ull, 32ull}) {
-        if (round_up(pt.ncols, a) * 8 <= pt.ncols * 9) { align = a; break; }
+    pt.chunks.clear();
+    const uint32_t nlocal = pt.end_page - pt.first_page;
+    if (nlocal == 0) return COBS_GPU_OK;
+    uint64_t resident = 0;
+    for (uint32_t fp = pt.first_page; fp < pt.end_page; ++fp) resident += slice_bytes(m.signature_sizes[fp], pt.ncols);
+    const bool unlimited = budget_left == nullptr;
+    if (unlimited || resident <= *budget_left) {
+        Chunk c;
+        for (uint32_t fp = pt.first_page; fp < pt.end_page; ++fp) c.vp.push_back(VPage{fp, pt.col0, pt.ncols});
+        layout_chunk(pt, c);
+        pt.chunks.push_back(std::move(c));
+        pt.streamed = false;
+        pt.hbm_bytes = resident;
+        if (!unlimited) *budget_left -= resident;
+    } else {
+        const uint64_t cap = *budget_left / 2;
+        *budget_left = 0;
+        Chunk cur;
+        uint64_t cur_bytes = 0;
+        auto flush = [&]() {
+            if (!cur.vp.empty()) {
+                layout_chunk(pt, cur);
+                pt.chunks.push_back(std::move(cur));
+                cur = Chunk();
+                cur_bytes = 0;
+            }
+        };
+        for (uint32_t fp = pt.first_page; fp < pt.end_page; ++fp) {
+            const uint64_t sig = m.signature_sizes[fp];
+            const uint64_t full = slice_bytes(sig, pt.ncols);
+            if (full <= cap) {
+                if (cur_bytes + full > cap) flush();
+                cur.vp.push_back(VPage{fp, pt.col0, pt.ncols});
+                cur_bytes += full;
+                continue;
+            }
+            flush();
+            // a single sub-index exceeds a buffer: cut it by columns (all rows, fewer documents)
+            uint64_t w = cap / (sig + 1);
+            w = w >= 128 ? w / 128 * 128 : w / 16 * 16;
+            while (w >= 16 && slice_bytes(sig, w) > cap) w -= 16;
+            if (w < 16)
+                return fail(COBS_GPU_ERR_CAPACITY,
+                            "hbm budget too small: a 16-byte column slice of the largest sub-index needs " +
+                            std::to_string(2 * slice_bytes(sig, 16)) + " bytes");
+            for (uint64_t c0 = 0; c0 < pt.ncols; c0 += w) {
+                cur.vp.push_back(VPage{fp, pt.col0 + c0, std::min<uint64_t>(w, pt.ncols - c0)});
+                flush();
+            }
+        }
+        flush();
+        pt.streamed = true;
+        pt.hbm_bytes = 2 * cap;
     }
-    if (const char* e = getenv("COBS_GPU_ROW_ALIGN")) {
-        const uint64_t v = std::strtoull(e, nullptr, 10);
-        if (v >= 16 && v <= 4096 && v % 16 == 0) align = v;
-    }
-    pt.pitch = (uint32_t)round_up(pt.ncols, align);
-    pt.cpp = pt.pitch / 16;
-    pt.total_chunks = pt.nlocal * pt.cpp;
-    pt.ntiles = (pt.total_chunks + 63) / 64;
-    pt.pages.resize(pt.nlocal);
-    uint64_t off = 0;
-    for (uint32_t lp = 0; lp < pt.nlocal; ++lp) {
-        const uint32_t fp = pt.first_page + lp;
-        PageDev& pd = pt.pages[lp];
-        pd.base = off;
-        pd.sig = m.signature_sizes[fp];
-        pd.magic = ~0ull / pd.sig;
-        pd.slot0 = (uint32_t)(lp * pt.ncols * 8);
-        pd.doc0 = (uint32_t)((m.kind == IndexKind::Compact ? (uint64_t)fp * 8 * prb : 0) + pt.col0 * 8);
-        pd.valid_bytes = (uint32_t)pt.ncols;
-        pd.reserved = 0;
-        off += round_up((pd.sig + 1) * (uint64_t)pt.pitch, 256);     // +1: the all-zero row
-    }
-    pt.blob_bytes = off;
+    pt.max_chunk_pages = 0;
+    for (const Chunk& c : pt.chunks) pt.max_chunk_pages = std::max<uint32_t>(pt.max_chunk_pages, (uint32_t)c.vp.size());
     return COBS_GPU_OK;
 }
 
 cobs_gpu_status alloc_part(Part& pt) {
-    if (pt.nlocal == 0) return COBS_GPU_OK;
-    HIP_TRY(hipMalloc((void**)&pt.d_blob, pt.blob_bytes));
-    HIP_TRY(hipMalloc((void**)&pt.d_pages, sizeof(PageDev) * pt.nlocal));
-    HIP_TRY(hipMemcpy(pt.d_pages, pt.pages.data(), sizeof(PageDev) * pt.nlocal, hipMemcpyHostToDevice));
+    for (Chunk& c : pt.chunks) {
+        HIP_TRY(hipMalloc((void**)&c.d_pages, sizeof(PageDev) * c.pages.size()));
+        HIP_TRY(hipMemcpy(c.d_pages, c.pages.data(), sizeof(PageDev) * c.pages.size(), hipMemcpyHostToDevice));
+    }
+    if (pt.chunks.empty()) return COBS_GPU_OK;
+    if (!pt.streamed) {
+        HIP_TRY(hipMalloc((void**)&pt.chunks[0].d_data, pt.chunks[0].bytes));
+    } else {
+        size_t dev = 0, host = 0;
+        for (const Chunk& c : pt.chunks) { dev = std::max(dev, c.bytes); host = std::max(host, c.stage_bytes); }
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(pt.sbuf[i].reserve(dev));
+            if (!pt.synthetic) HIP_TRY(pt.stage[i].reserve(host));
+            HIP_TRY(hipEventCreateWithFlags(&pt.copied[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&pt.scanned[i], hipEventDisableTiming));
+        }
+        HIP_TRY(hipStreamCreateWithFlags(&pt.copy_stream, hipStreamNonBlocking));
+    }
     return COBS_GPU_OK;
 }
 
-// Copy the held columns of every held sub-index from the mapped file into HBM.
-cobs_gpu_status upload_part(Part& pt, const uint8_t* file) {
+// Resident chunk: copy the held columns of every held sub-index from the mapped file into HBM.
+cobs_gpu_status upload_resident(Part& pt, const uint8_t* file) {
+    if (pt.chunks.empty()) return COBS_GPU_OK;
     const IndexMeta& m = pt.meta;
+    Chunk& c = pt.chunks[0];
     const uint64_t src_pitch = m.page_row_bytes();
     DevBuf<uint8_t> stage;
-    for (uint32_t lp = 0; lp < pt.nlocal; ++lp) {
-        const PageDev& pd = pt.pages[lp];
-        const uint8_t* src = file + m.page_offset(pt.first_page + lp);
-        uint8_t* dst = pt.d_blob + pd.base;
-        if (src_pitch == pt.pitch && pt.col0 == 0) {
-            // rows are already 16-byte pitched: one straight copy
+    for (size_t lp = 0; lp < c.vp.size(); ++lp) {
+        const PageDev& pd = c.pages[lp];
+        const VPage& v = c.vp[lp];
+        const uint8_t* src = file + m.page_offset(v.fp);
+        uint8_t* dst = c.d_data + pd.base;
+        if (src_pitch == c.pitch && v.col0 == 0) {
+            // rows already have the device pitch: one straight copy
             const uint64_t total = pd.sig * src_pitch;
             const uint64_t step = 1ull << 30;
             for (uint64_t o = 0; o < total; o += step)
@@ -291,17 +433,67 @@ cobs_gpu_status upload_part(Part& pt, const uint8_t* file) {
                 HIP_TRY(hipMemcpy(stage.p, src + r * src_pitch, (size_t)(n * src_pitch), hipMemcpyHostToDevice));
                 RepitchArgs ra;
                 ra.src = stage.p;
-                ra.dst = dst + r * pt.pitch;
+                ra.dst = dst + r * c.pitch;
                 ra.rows = n;
                 ra.src_pitch = (uint32_t)src_pitch;
-                ra.dst_pitch = pt.pitch;
-                ra.copy_bytes = (uint32_t)pt.ncols;
-                ra.src_col0 = (uint32_t)pt.col0;
+                ra.dst_pitch = c.pitch;
+                ra.copy_bytes = (uint32_t)v.ncols;
+                ra.src_col0 = (uint32_t)v.col0;
                 HIP_TRY(launch_repitch(ra, nullptr));
                 HIP_TRY(hipDeviceSynchronize());
             }
         }
-        HIP_TRY(hipMemset(dst + pd.sig * (uint64_t)pt.pitch, 0, pt.pitch));   // zero row
+        HIP_TRY(hipMemset(dst + pd.sig * (uint64_t)c.pitch, 0, c.pitch));   // zero row
+    }
+    return COBS_GPU_OK;
+}
+
+SynthArgs synth_args(const Part& pt, const Chunk& c, uint8_t* data) {
+    SynthArgs sa;
+    sa.blob = data;
+    sa.pages = c.d_pages;
+    sa.seed = pt.synth_seed;
+    sa.row_bytes = pt.meta.page_row_bytes();
+    sa.col0 = c.vp[0].col0;
+    sa.num_docs = pt.meta.doc_names.size();
+    sa.page_docs = pt.meta.kind == IndexKind::Compact ? 8 * pt.meta.header_page_size : 0;
+    sa.npages = (uint32_t)c.vp.size();
+    sa.first_page = c.vp[0].fp;
+    sa.pitch = c.pitch;
+    return sa;
+}
+
+// Streamed chunk: bring it into device buffer `buf` on the copy stream (file-backed:
+// pack the needed columns into pinned staging, async H2D; procedural: regenerate).
+cobs_gpu_status stream_chunk_in(Part& pt, const Chunk& c, int buf) {
+    uint8_t* dev = pt.sbuf[buf].p;
+    if (pt.synthetic) {
+        HIP_TRY(launch_synth(synth_args(pt, c, dev), pt.copy_stream));
+        return COBS_GPU_OK;
+    }
+    const IndexMeta& m = pt.meta;
+    const uint64_t prb = m.page_row_bytes();
+    uint8_t* host = pt.stage[buf].p;
+    uint64_t hoff = 0;
+    for (size_t i = 0; i < c.vp.size(); ++i) {
+        const VPage& v = c.vp[i];
+        const PageDev& pd = c.pages[i];
+        const uint8_t* src = pt.file->data() + m.page_offset(v.fp);
+        uint8_t* hp = host + hoff;
+        if (v.ncols == prb) {
+            std::memcpy(hp, src, (size_t)(pd.sig * prb));
+        } else {
+            for (uint64_t r = 0; r < pd.sig; ++r)
+                std::memcpy(hp + r * v.ncols, src + r * prb + v.col0, (size_t)v.ncols);
+        }
+        uint8_t* dst = dev + pd.base;
+        if (c.pitch == v.ncols)
+            HIP_TRY(hipMemcpyAsync(dst, hp, (size_t)(pd.sig * v.ncols), hipMemcpyHostToDevice, pt.copy_stream));
+        else
+            HIP_TRY(hipMemcpy2DAsync(dst, c.pitch, hp, (size_t)v.ncols, (size_t)v.ncols, (size_t)pd.sig,
+                                     hipMemcpyHostToDevice, pt.copy_stream));
+        HIP_TRY(hipMemsetAsync(dst + pd.sig * (uint64_t)c.pitch, 0, c.pitch, pt.copy_stream));
+        hoff += pd.sig * v.ncols;
     }
     return COBS_GPU_OK;
 }
@@ -316,6 +508,12 @@ void finish_layout(cobs_gpu_index* ix) {
     }
     ix->total_counts = g;
     ix->local_counts = l;
+}
+
+uint64_t budget_of(const cobs_gpu_options* o) {
+    // hbm_budget_bytes was appended to the options struct: honour it only if the caller's struct has it
+    if (o && o->struct_size >= sizeof(cobs_gpu_options)) return o->hbm_budget_bytes;
+    return 0;
 }
 
 cobs_gpu_status shard_of(const cobs_gpu_options* o, uint32_t* rank, uint32_t* count) {
@@ -341,6 +539,14 @@ bool hit_before(const cobs_gpu_hit& a, const cobs_gpu_hit& b) {
 bool doc_before(const cobs_gpu_hit& a, const cobs_gpu_hit& b) {
     if (a.file_no != b.file_no) return a.file_no < b.file_no;
     return a.doc < b.doc;
+}
+
+// row bytes one hash lookup gathers from this part (all held slices)
+uint64_t gathered_row_bytes(const Part& p) {
+    uint64_t n = 0;
+    for (const Chunk& c : p.chunks)
+        for (const VPage& v : c.vp) n += v.ncols;
+    return n;
 }
 
 // total number of hashes of query `q` over all files: the reference's max_counts
@@ -396,18 +602,25 @@ cobs_gpu_status cobs_gpu_open(const char* const* paths, size_t n_paths,
     }
     cobs_gpu_status st = shard_of(opts, &ix->shard_rank, &ix->shard_count);
     if (st != COBS_GPU_OK) return st;
+    ix->hbm_budget = budget_of(opts);
+    uint64_t left = ix->hbm_budget;
     for (auto& pt : ix->parts) {
-        st = plan_part(pt, ix->shard_rank, ix->shard_count);
+        st = plan_part(pt, ix->shard_rank, ix->shard_count, ix->hbm_budget ? &left : nullptr);
         if (st != COBS_GPU_OK) return st;
     }
     finish_layout(ix.get());
     st = select_device(opts, &ix->device);
     if (st != COBS_GPU_OK) return st;
     for (size_t i = 0; i < ix->parts.size(); ++i) {
-        st = alloc_part(ix->parts[i]);
+        Part& pt = ix->parts[i];
+        st = alloc_part(pt);
         if (st != COBS_GPU_OK) return st;
-        st = upload_part(ix->parts[i], files[i]->data());
-        if (st != COBS_GPU_OK) return st;
+        if (pt.streamed) {
+            pt.file = std::move(files[i]);       // chunks are read from the mapping at every pass
+        } else {
+            st = upload_resident(pt, files[i]->data());
+            if (st != COBS_GPU_OK) return st;
+        }
     }
     *out = ix.release();
     return COBS_GPU_OK;
@@ -438,10 +651,14 @@ cobs_gpu_status cobs_gpu_open_synthetic(const cobs_gpu_synth* d, const cobs_gpu_
         std::snprintf(nm, sizeof nm, "file_%06u", (unsigned)i);
         pt.meta.doc_names[i] = nm;
     }
+    pt.synthetic = true;
+    pt.synth_seed = d->seed;
     ix->parts.push_back(std::move(pt));
     cobs_gpu_status st = shard_of(opts, &ix->shard_rank, &ix->shard_count);
     if (st != COBS_GPU_OK) return st;
-    st = plan_part(ix->parts[0], ix->shard_rank, ix->shard_count);
+    ix->hbm_budget = budget_of(opts);
+    uint64_t left = ix->hbm_budget;
+    st = plan_part(ix->parts[0], ix->shard_rank, ix->shard_count, ix->hbm_budget ? &left : nullptr);
     if (st != COBS_GPU_OK) return st;
     finish_layout(ix.get());
     st = select_device(opts, &ix->device);
@@ -449,19 +666,8 @@ cobs_gpu_status cobs_gpu_open_synthetic(const cobs_gpu_synth* d, const cobs_gpu_
     Part& p = ix->parts[0];
     st = alloc_part(p);
     if (st != COBS_GPU_OK) return st;
-    if (p.nlocal) {
-        SynthArgs sa;
-        sa.blob = p.d_blob;
-        sa.pages = p.d_pages;
-        sa.seed = d->seed;
-        sa.row_bytes = p.meta.page_row_bytes();
-        sa.col0 = p.col0;
-        sa.num_docs = d->num_docs;
-        sa.page_docs = d->kind ? 8 * d->page_size : 0;
-        sa.npages = p.nlocal;
-        sa.first_page = p.first_page;
-        sa.pitch = p.pitch;
-        HIP_TRY(launch_synth(sa, nullptr));
+    if (!p.streamed && !p.chunks.empty()) {
+        HIP_TRY(launch_synth(synth_args(p, p.chunks[0], p.chunks[0].d_data), nullptr));
         HIP_TRY(hipDeviceSynchronize());
     }
     *out = ix.release();
@@ -486,7 +692,7 @@ cobs_gpu_status cobs_gpu_info(const cobs_gpu_index* ix, size_t f, cobs_gpu_index
     o->counts_size = p.meta.counts_size();
     o->num_docs = p.meta.doc_names.size();
     o->doc_offset = p.doc_offset;
-    o->hbm_bytes = p.blob_bytes;
+    o->hbm_bytes = p.hbm_bytes;
     o->first_page = p.first_page;
     o->end_page = p.end_page;
     o->slot_begin = p.slot_begin;
@@ -508,29 +714,43 @@ const char* cobs_gpu_doc_name(const cobs_gpu_index* ix, size_t f, uint64_t doc) 
 uint64_t cobs_gpu_total_counts(const cobs_gpu_index* ix) { return ix ? ix->total_counts : 0; }
 uint64_t cobs_gpu_local_counts(const cobs_gpu_index* ix) { return ix ? ix->local_counts : 0; }
 
-cobs_gpu_status cobs_gpu_read_row(const cobs_gpu_index* ix, size_t f, uint32_t page, uint64_t row,
-                                  uint8_t* out, size_t n) {
-    if (!ix || !out || f >= ix->parts.size()) return fail(COBS_GPU_ERR_ARG, "bad argument");
+// resident slice of file-level sub-index `page` (only resident, un-split pages can be read back)
+static cobs_gpu_status find_resident(const cobs_gpu_index* ix, size_t f, uint32_t page, const Chunk** c,
+                                     const PageDev** pd) {
+    if (!ix || f >= ix->parts.size()) return fail(COBS_GPU_ERR_ARG, "bad argument");
     const Part& p = ix->parts[f];
     if (page < p.first_page || page >= p.end_page) return fail(COBS_GPU_ERR_ARG, "sub-index not held by this shard");
-    const PageDev& pd = p.pages[page - p.first_page];
-    if (row > pd.sig || n > p.pitch) return fail(COBS_GPU_ERR_ARG, "row or length out of range");
+    if (p.streamed) return fail(COBS_GPU_ERR_UNSUPPORTED, "index is streamed, rows are not resident");
+    *c = &p.chunks[0];
+    *pd = &p.chunks[0].pages[page - p.first_page];
+    return COBS_GPU_OK;
+}
+
+cobs_gpu_status cobs_gpu_read_row(const cobs_gpu_index* ix, size_t f, uint32_t page, uint64_t row,
+                                  uint8_t* out, size_t n) {
+    const Chunk* c = nullptr;
+    const PageDev* pd = nullptr;
+    if (!out) return fail(COBS_GPU_ERR_ARG, "bad argument");
+    cobs_gpu_status st = find_resident(ix, f, page, &c, &pd);
+    if (st != COBS_GPU_OK) return st;
+    if (row > pd->sig || n > c->pitch) return fail(COBS_GPU_ERR_ARG, "row or length out of range");
     HIP_TRY(hipSetDevice(ix->device));
-    HIP_TRY(hipMemcpy(out, p.d_blob + pd.base + row * (uint64_t)p.pitch, n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, c->d_data + pd->base + row * (uint64_t)c->pitch, n, hipMemcpyDeviceToHost));
     return COBS_GPU_OK;
 }
 
 cobs_gpu_status cobs_gpu_read_rows(const cobs_gpu_index* ix, size_t f, uint32_t page, uint64_t row0,
                                    uint64_t nrows, uint8_t* out, size_t out_pitch) {
-    if (!ix || !out || f >= ix->parts.size()) return fail(COBS_GPU_ERR_ARG, "bad argument");
-    const Part& p = ix->parts[f];
-    if (page < p.first_page || page >= p.end_page) return fail(COBS_GPU_ERR_ARG, "sub-index not held by this shard");
-    const PageDev& pd = p.pages[page - p.first_page];
-    if (row0 + nrows > pd.sig + 1 || out_pitch < p.ncols) return fail(COBS_GPU_ERR_ARG, "rows or pitch out of range");
+    const Chunk* c = nullptr;
+    const PageDev* pd = nullptr;
+    if (!out) return fail(COBS_GPU_ERR_ARG, "bad argument");
+    cobs_gpu_status st = find_resident(ix, f, page, &c, &pd);
+    if (st != COBS_GPU_OK) return st;
+    if (row0 + nrows > pd->sig + 1 || out_pitch < pd->valid_bytes) return fail(COBS_GPU_ERR_ARG, "rows or pitch out of range");
     HIP_TRY(hipSetDevice(ix->device));
     if (nrows)
-        HIP_TRY(hipMemcpy2D(out, out_pitch, p.d_blob + pd.base + row0 * (uint64_t)p.pitch, p.pitch,
-                            (size_t)p.ncols, (size_t)nrows, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy2D(out, out_pitch, c->d_data + pd->base + row0 * (uint64_t)c->pitch, c->pitch,
+                            (size_t)pd->valid_bytes, (size_t)nrows, hipMemcpyDeviceToHost));
     return COBS_GPU_OK;
 }
 
@@ -619,12 +839,12 @@ cobs_gpu_status cobs_gpu_batch_set_queries(cobs_gpu_batch* b, const char* const*
             blk += (T + 7) / 8;
             lookups += T;
             // T * H * (row bytes gathered) + score bytes written
-            algo_bytes += T * p.meta.num_hashes * (uint64_t)p.nlocal * p.ncols;
+            algo_bytes += T * p.meta.num_hashes * gathered_row_bytes(p);
         }
         w.h_blk_off[nq] = blk;
-        w.table_entries = blk * 8 * p.meta.num_hashes * p.nlocal;
+        w.table_entries = blk * 8 * p.meta.num_hashes * p.max_chunk_pages;
+        table_bytes += (blk * 8 * p.meta.num_hashes * p.num_vpages()) * 4;
         if (w.table_entries >= (1ull << 40)) return fail(COBS_GPU_ERR_CAPACITY, "batch too large");
-        table_bytes += w.table_entries * 4;
         HIP_TRY(w.blk_off.reserve(nq + 1));
         HIP_TRY(w.table.reserve((size_t)w.table_entries));
         HIP_TRY(w.thr.reserve(nq));
@@ -669,56 +889,76 @@ cobs_gpu_status cobs_gpu_batch_run(cobs_gpu_batch* b, double threshold, void* hi
     }
     hipEvent_t* ev = b->ev[b->run_seq % cobs_gpu_batch::kRing];
     HIP_TRY(hipEventRecord(ev[0], st));
-    for (size_t f = 0; f < ix->parts.size(); ++f) {
-        const Part& p = ix->parts[f];
-        if (p.nlocal == 0 || nq == 0) continue;
-        HashArgs ha;
-        ha.text = b->text.p;
-        ha.span_off = b->d_span_off.p;
-        ha.q_len = b->d_qlen.p;
-        ha.blk_off = b->work[f].blk_off.p;
-        ha.pages = p.d_pages;
-        ha.table = b->work[f].table.p;
-        ha.err_query = b->flags.p;
-        ha.nq = (uint32_t)nq;
-        ha.npages = p.nlocal;
-        ha.term_size = p.meta.term_size;
-        ha.canonicalize = p.meta.canonicalize;
-        ha.num_hashes = (uint32_t)p.meta.num_hashes;
-        HIP_TRY(launch_hash(ha, b->span_off[nq], st));
-    }
-    HIP_TRY(hipEventRecord(ev[1], st));
+    bool hash_marked = false;
     uint64_t launches = 0;
     for (size_t f = 0; f < ix->parts.size(); ++f) {
-        const Part& p = ix->parts[f];
-        if (p.nlocal == 0 || nq == 0) continue;
-        ScanArgs sa;
-        sa.blob = p.d_blob;
-        sa.pages = p.d_pages;
-        sa.table = b->work[f].table.p;
-        sa.blk_off = b->work[f].blk_off.p;
-        sa.counts = b->counts.p;
-        sa.thresholds = b->selected ? b->work[f].thr.p : nullptr;
-        sa.hits = b->hits.p;
-        sa.hit_count = b->flags.p + 1;
-        sa.counts_stride = ix->local_counts;
-        sa.counts_offset = p.local_offset;
-        sa.hit_cap = b->hit_cap;
-        sa.nq = (uint32_t)nq;
-        sa.npages = p.nlocal;
-        sa.pitch = p.pitch;
-        sa.cpp = p.cpp;
-        sa.total_chunks = p.total_chunks;
-        sa.num_hashes = (uint32_t)p.meta.num_hashes;
-        sa.num_docs = (uint32_t)p.meta.doc_names.size();
-        sa.part = (uint32_t)f;
-        sa.write_counts = 1;
-        // one launch covers at most 2^31-1 work-groups: split the queries if needed
-        const uint64_t per = std::max<uint64_t>(1, 0x7FFFFFFFull / std::max<uint32_t>(p.ntiles, 1));
-        if (nq > per) return fail(COBS_GPU_ERR_CAPACITY, "batch too large for one scan launch; use fewer queries");
-        HIP_TRY(launch_scan(sa, p.ntiles, b->planes, st));
-        ++launches;
+        Part& p = ix->parts[f];
+        if (nq == 0) continue;
+        for (size_t ci = 0; ci < p.chunks.size(); ++ci) {
+            const Chunk& c = p.chunks[ci];
+            const uint8_t* data = c.d_data;
+            int buf = 0;
+            if (p.streamed) {
+                // double buffer: chunk ci goes to buffer ci % 2 once the scan that last used it is done
+                buf = (int)(ci & 1);
+                if (p.buf_used[buf]) HIP_TRY(hipEventSynchronize(p.scanned[buf]));
+                cobs_gpu_status cs = stream_chunk_in(p, c, buf);
+                if (cs != COBS_GPU_OK) return cs;
+                HIP_TRY(hipEventRecord(p.copied[buf], p.copy_stream));
+                HIP_TRY(hipStreamWaitEvent(st, p.copied[buf], 0));
+                data = p.sbuf[buf].p;
+            }
+            HashArgs ha;
+            ha.text = b->text.p;
+            ha.span_off = b->d_span_off.p;
+            ha.q_len = b->d_qlen.p;
+            ha.blk_off = b->work[f].blk_off.p;
+            ha.pages = c.d_pages;
+            ha.table = b->work[f].table.p;
+            ha.err_query = b->flags.p;
+            ha.nq = (uint32_t)nq;
+            ha.npages = (uint32_t)c.vp.size();
+            ha.term_size = p.meta.term_size;
+            ha.canonicalize = p.meta.canonicalize;
+            ha.num_hashes = (uint32_t)p.meta.num_hashes;
+            HIP_TRY(launch_hash(ha, b->span_off[nq], st));
+            if (!hash_marked) {      // K1 / K2 split of the timing events: first chunk only
+                HIP_TRY(hipEventRecord(ev[1], st));
+                hash_marked = true;
+            }
+            ScanArgs sa;
+            sa.blob = data;
+            sa.pages = c.d_pages;
+            sa.table = b->work[f].table.p;
+            sa.blk_off = b->work[f].blk_off.p;
+            sa.counts = b->counts.p;
+            sa.thresholds = b->selected ? b->work[f].thr.p : nullptr;
+            sa.hits = b->hits.p;
+            sa.hit_count = b->flags.p + 1;
+            sa.counts_stride = ix->local_counts;
+            sa.counts_offset = p.local_offset;
+            sa.hit_cap = b->hit_cap;
+            sa.nq = (uint32_t)nq;
+            sa.npages = (uint32_t)c.vp.size();
+            sa.pitch = c.pitch;
+            sa.cpp = c.cpp;
+            sa.total_chunks = c.total_chunks;
+            sa.num_hashes = (uint32_t)p.meta.num_hashes;
+            sa.num_docs = (uint32_t)p.meta.doc_names.size();
+            sa.part = (uint32_t)f;
+            sa.write_counts = 1;
+            // one launch covers at most 2^31-1 work-groups
+            const uint64_t per = std::max<uint64_t>(1, 0x7FFFFFFFull / std::max<uint32_t>(c.ntiles, 1));
+            if (nq > per) return fail(COBS_GPU_ERR_CAPACITY, "batch too large for one scan launch; use fewer queries");
+            HIP_TRY(launch_scan(sa, c.ntiles, b->planes, st));
+            ++launches;
+            if (p.streamed) {
+                HIP_TRY(hipEventRecord(p.scanned[buf], st));
+                p.buf_used[buf] = true;
+            }
+        }
     }
+    if (!hash_marked) HIP_TRY(hipEventRecord(ev[1], st));
     HIP_TRY(hipEventRecord(ev[2], st));
     b->run_seq++;
     b->stats[1] = launches;

@@ -38,12 +38,13 @@ def _as_bytes(q):
     return q.encode("latin-1") if isinstance(q, str) else bytes(q)
 
 
-def _options(device, shard_rank, shard_count):
+def _options(device, shard_rank, shard_count, hbm_budget=0):
     o = Options()
     o.struct_size = C.sizeof(Options)
     o.device = device
     o.shard_rank = shard_rank
     o.shard_count = shard_count
+    o.hbm_budget_bytes = int(hbm_budget)
     return o
 
 
@@ -51,7 +52,7 @@ class Search:
     """cobs_index.Search: open one or several index files (classic or compact,
     auto-detected per file) and query them on the GPU."""
 
-    def __init__(self, path, device=-1, shard_rank=0, shard_count=1, _handle=None):
+    def __init__(self, path, device=-1, shard_rank=0, shard_count=1, hbm_budget=0, _handle=None):
         self._lib = _capi.load()
         self._h = C.c_void_p()
         if _handle is not None:
@@ -59,12 +60,12 @@ class Search:
             return
         paths = [path] if isinstance(path, (str, bytes, os.PathLike)) else list(path)
         arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
-        opts = _options(device, shard_rank, shard_count)
+        opts = _options(device, shard_rank, shard_count, hbm_budget)
         check(self._lib.cobs_gpu_open(arr, len(paths), C.byref(opts), C.byref(self._h)))
 
     @classmethod
     def synthetic(cls, kind, signature_sizes, num_docs, page_size=0, term_size=31, canonicalize=1,
-                  num_hashes=1, seed=1, device=-1, shard_rank=0, shard_count=1):
+                  num_hashes=1, seed=1, device=-1, shard_rank=0, shard_count=1, hbm_budget=0):
         """Procedural index generated directly in HBM (benchmark / large parity runs)."""
         lib = _capi.load()
         sigs = (C.c_uint64 * len(signature_sizes))(*[int(s) for s in signature_sizes])
@@ -74,7 +75,7 @@ class Search:
         d.num_hashes, d.page_size, d.num_docs, d.seed = num_hashes, page_size, num_docs, seed
         d.signature_sizes = C.cast(sigs, C.POINTER(C.c_uint64))
         h = C.c_void_p()
-        opts = _options(device, shard_rank, shard_count)
+        opts = _options(device, shard_rank, shard_count, hbm_budget)
         check(lib.cobs_gpu_open_synthetic(C.byref(d), C.byref(opts), C.byref(h)))
         return cls(None, _handle=h)
 

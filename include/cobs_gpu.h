@@ -52,6 +52,13 @@ typedef struct cobs_gpu_options {
     uint32_t shard_count;     /* 0 or 1 = unsharded */
     uint32_t waves_per_group; /* 0 = default (4): waves that split one query's terms */
     uint32_t reserved;
+    /* 0 = stage the whole (shard of the) index into HBM.  Otherwise the index may
+     * use at most this many bytes of HBM: files that do not fit are cut into chunks
+     * (whole sub-indexes, or column ranges of one sub-index) that are streamed from
+     * the mapped file through two device buffers with hipMemcpyAsync, one scan pass
+     * per chunk overlapping the next chunk's copy (the successor of the reference's
+     * mmap / AIO back-ends, util/query.cpp:38-88, compact_index/aio_search_file.cpp). */
+    uint64_t hbm_budget_bytes;
 } cobs_gpu_options;
 
 /* Geometry of one opened index file (IndexSearchFile getters, query/index_file.hpp:19-35). */

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     from cobs_amd import _capi
-    assert C.sizeof(_capi.Options) == 24
+    assert C.sizeof(_capi.Options) == 32
     assert C.sizeof(_capi.Hit) == 12
     assert C.sizeof(_capi.IndexInfo) == 16 + 7 * 8 + 8 + 3 * 8
     assert C.sizeof(_capi.Synth) == 16 + 4 * 8 + 8

@@ -1,0 +1,79 @@
+"""GPU: indexes larger than the HBM budget are streamed chunk by chunk (BASELINE
+config 5) and give bit-identical results to the resident path
+and to the oracle."""
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(gpu, oracle, path, budget, queries):
+    ix = oracle.Index.open(path)
+    s = gpu.Search(path, hbm_budget=budget)
+    info = s.info(0)
+    assert info.hbm_bytes <= budget
+    for q in queries:
+        assert np.array_equal(s.counts(q), ix.counts(q))
+    for t, lim in ((0.0, 0), (0.4, 0), (0.4, 3), (0.9, 0)):
+        got = s.search_hits(queries, t, lim)
+        for q, g in zip(queries, got):
+            assert g == cases.oracle_results([ix], q, t, lim)
+    return s
+
+
+def test_streamed_compact_whole_pages_and_column_slices(gpu_lib, oracle, tmp_path):
+    ps, D = 96, 5 * 8 * 96 - 11
+    sigs = [700, 1500, 5000, 900, 2600]           # 67 KB .. 480 KB per sub-index
+    q_long = oracle.random_sequence(700, 31)
+    planted = {0: 1.0, D - 1: 0.95, 1000: 0.6, 2500: 0.85}
+    p = cases.make_compact(cases.tmp(tmp_path, "st.cobs_compact"), D, ps, sigs, 2, 31, 1, 0.3, 6,
+                           planted=planted, query=q_long)
+    queries = [q_long, q_long[:31], q_long[:300]]
+    # 400 KB budget -> 200 KB buffers: small sub-indexes travel whole (some share a chunk), the
+    # 5000-row sub-index (480 KB) is cut into column slices
+    _compare(gpu_lib, oracle, p, 400 * 1024, queries)
+    # 2 MB budget: everything resident
+    s = _compare(gpu_lib, oracle, p, 2 * 1024 * 1024, queries)
+    assert s.read_row(0, 2, 17, ps).shape == (ps,)
+    # a budget below one 16-byte column slice of the largest sub-index is refused
+    from cobs_amd import _capi
+    with pytest.raises(gpu_lib.CobsGpuError) as e:
+        gpu_lib.Search(p, hbm_budget=64 * 1024)
+    assert e.value.status == _capi.ERR_CAPACITY
+
+
+def test_streamed_classic_and_second_pass(gpu_lib, oracle, tmp_path):
+    D, S = 4000, 3001                                # 500-byte rows, 1.5 MB
+    q_long = oracle.random_sequence(1030, 8)
+    p = cases.make_classic(cases.tmp(tmp_path, "st.cobs_classic"), D, S, 1, 31, 1, 0.3, 7,
+                           planted={5: 1.0, 3999: 0.9}, query=q_long)
+    s = _compare(gpu_lib, oracle, p, 600 * 1024, [q_long, q_long[:100]])
+    # the same handle again (buffers are reused across passes)
+    ix = oracle.Index.open(p)
+    for q in cases.queries_acgt(3, 400, 77):
+        assert np.array_equal(s.counts(q), ix.counts(q))
+
+
+def test_streamed_synthetic_equals_resident(gpu_lib, oracle):
+    sigs = [4001, 6007, 9001, 12007]
+    ps, D = 256, 4 * 8 * 256 - 100
+    a = gpu_lib.Search.synthetic("compact", sigs, D, page_size=ps, seed=9)
+    b = gpu_lib.Search.synthetic("compact", sigs, D, page_size=ps, seed=9, hbm_budget=5 * 1024 * 1024)
+    assert b.info(0).hbm_bytes <= 5 * 1024 * 1024 < a.info(0).hbm_bytes
+    qs = cases.queries_acgt(6, 1030, 5)
+    ba, bb = gpu_lib.Batch(a), gpu_lib.Batch(b)
+    ba.set_queries(qs)
+    bb.set_queries(qs)
+    for t in (0.0, 0.28):
+        ba.run(t)
+        bb.run(t)
+        ba.sync()
+        bb.sync()
+        for i in range(len(qs)):
+            assert np.array_equal(ba.counts_host(i), bb.counts_host(i))
+            assert ba.hits_host(i, 10) == bb.hits_host(i, 10)
+    assert bb.stats()["scan_launches"] > 1 and ba.stats()["scan_launches"] == 1
+    ix = oracle.Index.synthetic(1, 31, 1, 1, ps, sigs, D, 9)
+    assert np.array_equal(bb.counts_host(0), ix.counts(qs[0]))
