@@ -150,6 +150,8 @@ def main():
                     help="N>1: replicate the index and split the batch (no collective), or shard the "
                          "index by sub-index block and all-gather the count slices over RCCL")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real multi-GPU runs; gloo only "
+                    "for smoke-testing the launch path with several ranks on one GPU")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -158,8 +160,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.dist_backend)
     else:
         torch.cuda.set_device(0)
     n_gpus = world
@@ -183,14 +189,15 @@ def main():
 
     gathered = None
     if shard_index:
-        local = batch.counts_tensor()
-        gathered = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device="cuda")
+        # RCCL has no 16-bit integer type: the u16 count slices travel as bytes
+        local = batch.counts_tensor().view(torch.uint8).reshape(-1)
+        gathered = torch.empty((world * local.numel(),), dtype=torch.uint8, device="cuda")
 
     def step():
         batch.run(args.threshold, 0)
         if shard_index:
-            # per-document hit counts of the disjoint sub-index blocks -> every rank (RCCL all-gather)
-            dist.all_gather_into_tensor(gathered, batch.counts_tensor())
+            # per-document hit counts of the disjoint sub-index blocks -> every rank (all-gather over xGMI)
+            dist.all_gather_into_tensor(gathered, batch.counts_tensor().view(torch.uint8).reshape(-1))
 
     for _ in range(args.warmup):
         step()
@@ -207,7 +214,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     batch.sync()                               # also raises on invalid bases

@@ -66,6 +66,21 @@ struct ScanArgs {
     uint32_t write_counts;      // 0: selection only
 };
 
+// Arguments of the top-k selection kernel K3 for one index file (u16 scores).
+struct TopkArgs {
+    const uint16_t* counts;      // [nq][counts_stride]
+    const uint32_t* thresholds;  // per query or nullptr (= 0)
+    uint2* out;                  // [nq][k] (doc, score), unordered within a query
+    uint32_t* out_count;         // [nq] entries written (<= k)
+    uint64_t counts_stride;
+    uint64_t counts_offset;      // first local slot of this file in a row
+    uint32_t nslots;             // local slots of this file
+    uint32_t doc_base;           // file-level document id of local slot 0
+    uint32_t num_docs;           // real documents of the file
+    uint32_t k;
+    uint32_t nq;
+};
+
 // procedural index fill
 struct SynthArgs {
     uint8_t* blob;

@@ -195,6 +195,12 @@ struct cobs_gpu_batch {
     uint32_t elem_bytes = 2;
     int planes = 0;
     DevBuf<HitDev> hits;
+    DevBuf<uint2> topk_out;           // K3 output [file][query][k]
+    DevBuf<uint32_t> topk_cnt;        // [file][query]
+    std::vector<uint2> h_topk;
+    std::vector<uint32_t> h_topk_cnt;
+    uint32_t topk_k = 0;              // k of the last run (0 = K3 not run)
+    bool topk_fetched = false;
     DevBuf<uint32_t> flags;           // [0] first invalid query, [1] selected hits
     uint32_t hit_cap = 0;
     // last run
@@ -865,7 +871,7 @@ cobs_gpu_status cobs_gpu_batch_set_queries(cobs_gpu_batch* b, const char* const*
     return COBS_GPU_OK;
 }
 
-cobs_gpu_status cobs_gpu_batch_run(cobs_gpu_batch* b, double threshold, void* hip_stream) {
+static cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk, void* hip_stream) {
     if (!b) return fail(COBS_GPU_ERR_ARG, "NULL batch");
     cobs_gpu_index* ix = b->ix;
     hipStream_t st = (hipStream_t)hip_stream;
@@ -873,13 +879,24 @@ cobs_gpu_status cobs_gpu_batch_run(cobs_gpu_batch* b, double threshold, void* hi
     b->ran = false;
     b->synced = false;
     b->pool_fetched = false;
+    b->topk_fetched = false;
     b->threshold = threshold;
-    b->selected = threshold > 0.0;
     const size_t nq = b->nq;
+    // K3 (exact top-k on the device) needs u16 scores and a bounded k
+    const bool use_topk = topk > 0 && b->elem_bytes == 2 && topk <= 65536 &&
+                          (uint64_t)topk * std::max<size_t>(nq, 1) * ix->parts.size() <= (1ull << 27);
+    b->topk_k = use_topk ? (uint32_t)topk : 0;
+    // with K3 the threshold is applied there; otherwise K2 selects into the hit pool
+    b->selected = threshold > 0.0 && !use_topk;
+    const bool need_thr = threshold > 0.0;
+    if (use_topk) {
+        HIP_TRY(b->topk_out.reserve((size_t)topk * std::max<size_t>(nq, 1) * ix->parts.size()));
+        HIP_TRY(b->topk_cnt.reserve(std::max<size_t>(nq, 1) * ix->parts.size()));
+    }
     // device flags: first invalid query = none, selected hits = 0
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)b->flags.p, (int)0xFFFFFFFFu, 1, st));
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(b->flags.p + 1), 0, 1, st));
-    if (b->selected) {
+    if (need_thr) {
         for (size_t f = 0; f < ix->parts.size(); ++f) {
             uint32_t* stage = b->h_thr_stage.p + f * nq;
             for (size_t q = 0; q < nq; ++q)
@@ -960,10 +977,37 @@ cobs_gpu_status cobs_gpu_batch_run(cobs_gpu_batch* b, double threshold, void* hi
     }
     if (!hash_marked) HIP_TRY(hipEventRecord(ev[1], st));
     HIP_TRY(hipEventRecord(ev[2], st));
+    if (use_topk && nq) {
+        for (size_t f = 0; f < ix->parts.size(); ++f) {
+            const Part& p = ix->parts[f];
+            TopkArgs ta;
+            ta.counts = reinterpret_cast<const uint16_t*>(b->counts.p);
+            ta.thresholds = need_thr ? b->work[f].thr.p : nullptr;
+            ta.out = b->topk_out.p + (uint64_t)f * nq * topk;
+            ta.out_count = b->topk_cnt.p + f * nq;
+            ta.counts_stride = ix->local_counts;
+            ta.counts_offset = p.local_offset;
+            ta.nslots = (uint32_t)p.slot_count;
+            ta.doc_base = (uint32_t)p.slot_begin;
+            ta.num_docs = (uint32_t)p.meta.doc_names.size();
+            ta.k = (uint32_t)topk;
+            ta.nq = (uint32_t)nq;
+            HIP_TRY(launch_topk(ta, st));
+        }
+    }
     b->run_seq++;
     b->stats[1] = launches;
     b->ran = true;
     return COBS_GPU_OK;
+}
+
+cobs_gpu_status cobs_gpu_batch_run(cobs_gpu_batch* b, double threshold, void* hip_stream) {
+    return run_impl(b, threshold, 0, hip_stream);
+}
+
+cobs_gpu_status cobs_gpu_batch_run_topk(cobs_gpu_batch* b, double threshold, size_t num_results,
+                                        void* hip_stream) {
+    return run_impl(b, threshold, num_results, hip_stream);
 }
 
 cobs_gpu_status cobs_gpu_batch_sync(cobs_gpu_batch* b, void* hip_stream, size_t* bad_query) {
@@ -1028,7 +1072,23 @@ cobs_gpu_status cobs_gpu_batch_hits_host(cobs_gpu_batch* b, size_t q, size_t num
     HIP_TRY(hipSetDevice(ix->device));
     std::vector<cobs_gpu_hit> sel;
     const bool pool_ok = b->selected && b->h_flags[1] <= b->hit_cap;
-    if (pool_ok) {
+    const bool topk_ok = b->topk_k > 0 && num_results > 0 && num_results <= b->topk_k && total_hashes(b, q) > 1;
+    if (topk_ok) {
+        // K3 left the k best documents of every file on the device: fetch once, merge per query
+        const size_t k = b->topk_k, nparts = ix->parts.size();
+        if (!b->topk_fetched) {
+            b->h_topk.resize(k * b->nq * nparts);
+            b->h_topk_cnt.resize(b->nq * nparts);
+            HIP_TRY(hipMemcpy(b->h_topk.data(), b->topk_out.p, sizeof(uint2) * b->h_topk.size(), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(b->h_topk_cnt.data(), b->topk_cnt.p, 4 * b->h_topk_cnt.size(), hipMemcpyDeviceToHost));
+            b->topk_fetched = true;
+        }
+        for (size_t f = 0; f < nparts; ++f) {
+            const uint2* e = b->h_topk.data() + (f * b->nq + q) * k;
+            const uint32_t cnt = b->h_topk_cnt[f * b->nq + q];
+            for (uint32_t i = 0; i < cnt; ++i) sel.push_back(cobs_gpu_hit{(uint32_t)f, e[i].x, e[i].y});
+        }
+    } else if (pool_ok) {
         if (!b->pool_fetched) {
             b->h_hits.resize(b->h_flags[1]);
             if (b->h_flags[1])
@@ -1106,7 +1166,7 @@ cobs_gpu_status cobs_gpu_batch_kernel_ms(cobs_gpu_batch* b, float* scan_ms, floa
 // host-buffer search API
 
 static cobs_gpu_status run_host_batch(cobs_gpu_index* ix, const char* const* queries, const size_t* lens,
-                                      size_t nq, double threshold, size_t* bad_query) {
+                                      size_t nq, double threshold, size_t* bad_query, size_t topk = 0) {
     if (!ix->scratch) {
         cobs_gpu_status st = cobs_gpu_batch_create(ix, 0, 0, &ix->scratch);
         if (st != COBS_GPU_OK) return st;
@@ -1117,7 +1177,7 @@ static cobs_gpu_status run_host_batch(cobs_gpu_index* ix, const char* const* que
     if (st != COBS_GPU_OK) return st;
     double t1 = now_s();
     ix->timers[1] += t1 - t0;
-    st = cobs_gpu_batch_run(b, threshold, nullptr);
+    st = run_impl(b, threshold, topk, nullptr);
     if (st != COBS_GPU_OK) return st;
     st = cobs_gpu_batch_sync(b, nullptr, bad_query);
     double t2 = now_s();
@@ -1137,7 +1197,9 @@ cobs_gpu_status cobs_gpu_search_batch(cobs_gpu_index* ix, const char* const* que
                                       cobs_gpu_hit* hits, size_t cap, size_t* hit_offsets,
                                       size_t* bad_query) {
     if (!ix || !hit_offsets) return fail(COBS_GPU_ERR_ARG, "NULL argument");
-    cobs_gpu_status st = run_host_batch(ix, queries, lens, nq, threshold, bad_query);
+    // a bounded num_results is selected on the device (K3), nothing but the k best travel back
+    cobs_gpu_status st = run_host_batch(ix, queries, lens, nq, threshold, bad_query,
+                                        num_results < ix->total_counts ? num_results : 0);
     if (st != COBS_GPU_OK) return st;
     size_t used = 0;
     hit_offsets[0] = 0;

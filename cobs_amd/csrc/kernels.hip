@@ -500,6 +500,130 @@ __global__ __launch_bounds__(NW * 64, MINW) void scan_kernel(ScanArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// K3: exact top-k selection per query (the device side of counts_to_result's
+// partial_sort, reference classic_search.cpp:127-145): find the score s* of the
+// k-th best document with a two-level radix histogram, emit every document with
+// score > s* and, in ascending document order, as many documents with score == s*
+// as are still needed.  The host only has to order the k survivors.
+// One work-group (4 waves) per query; wave w owns the contiguous quarter w of the
+// documents so that ballot prefixes keep document order.
+
+__device__ __forceinline__ uint32_t wave_prefix(unsigned long long mask, uint32_t lane) {
+    return (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+__global__ __launch_bounds__(256) void topk_kernel(TopkArgs a) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t sh[16];
+    const uint32_t q = blockIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint16_t* row = a.counts + (uint64_t)q * a.counts_stride + a.counts_offset;
+    const uint32_t thr = a.thresholds ? a.thresholds[q] : 0u;
+    // real documents among the local slots
+    uint32_t n = a.nslots;
+    if (a.doc_base >= a.num_docs) n = 0;
+    else if (a.num_docs - a.doc_base < n) n = a.num_docs - a.doc_base;
+    const uint32_t k = a.k;
+
+    // ---- level 1: histogram of the high byte over passing documents
+    hist[tid] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += 256) {
+        const uint32_t s = row[i];
+        if (s >= thr) atomicAdd(&hist[s >> 8], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t above = 0;
+        int b = 255;
+        for (; b >= 0; --b) {
+            if (above + hist[b] >= k) break;
+            above += hist[b];
+        }
+        sh[0] = (uint32_t)(b < 0 ? 0 : b);     // bucket of the k-th best (0 if fewer than k pass)
+        sh[1] = above;                          // passing documents in higher buckets
+        sh[2] = b < 0 ? 1u : 0u;                // fewer than k passing documents: take them all
+    }
+    __syncthreads();
+    const uint32_t hb = sh[0], above1 = sh[1], take_all = sh[2];
+    __syncthreads();
+    // ---- level 2: histogram of the low byte inside that bucket
+    hist[tid] = 0;
+    __syncthreads();
+    if (!take_all) {
+        for (uint32_t i = tid; i < n; i += 256) {
+            const uint32_t s = row[i];
+            if (s >= thr && (s >> 8) == hb) atomicAdd(&hist[s & 255u], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t above = above1, cut = thr;
+        if (!take_all) {
+            int b = 255;
+            for (; b >= 0; --b) {
+                if (above + hist[b] >= k) break;
+                above += hist[b];
+            }
+            cut = (hb << 8) | (uint32_t)b;
+        }
+        sh[3] = cut;                            // s*: score of the k-th best
+        sh[4] = above;                          // documents with score > s*
+        sh[5] = 0;                              // emission cursor for those
+    }
+    __syncthreads();
+    const uint32_t cut = sh[3], n_above = sh[4];
+    const uint32_t need_eq = take_all ? 0xFFFFFFFFu : k - n_above;
+    // ---- ties: per-wave counts of score == s* so that each wave knows its rank base
+    const uint32_t per = (n + 3u) / 4u;
+    const uint32_t w0 = wave * per, w1 = (w0 + per < n) ? w0 + per : n;
+    uint32_t eq_wave = 0;
+    if (!take_all) {
+        for (uint32_t i0 = w0; i0 < w1; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const bool eq = i < w1 && (uint32_t)row[i] == cut && cut >= thr;
+            eq_wave += (uint32_t)__popcll(__ballot(eq));
+        }
+    }
+    if (lane == 0) sh[8 + wave] = eq_wave;
+    __syncthreads();
+    uint32_t eq_base = 0;
+    for (uint32_t w = 0; w < wave; ++w) eq_base += sh[8 + w];
+    // ---- emission
+    uint2* out = a.out + (uint64_t)q * k;
+    for (uint32_t i0 = w0; i0 < w1; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        const uint32_t s = i < w1 ? (uint32_t)row[i] : 0u;
+        const bool pass = i < w1 && s >= thr;
+        const bool gt = pass && (take_all || s > cut);
+        const bool eq = pass && !take_all && s == cut;
+        const unsigned long long mg = __ballot(gt), me = __ballot(eq);
+        if (mg) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&sh[5], (uint32_t)__popcll(mg));
+            base = __shfl(base, 0);
+            if (gt) out[base + wave_prefix(mg, lane)] = make_uint2(a.doc_base + i, s);
+        }
+        if (me) {
+            const uint32_t r = eq_base + wave_prefix(me, lane);
+            if (eq && r < need_eq) out[n_above + r] = make_uint2(a.doc_base + i, s);
+            eq_base += (uint32_t)__popcll(me);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t total;
+        if (take_all) total = sh[5];
+        else {
+            uint32_t eq_total = sh[8] + sh[9] + sh[10] + sh[11];
+            total = n_above + (eq_total < need_eq ? eq_total : need_eq);
+        }
+        a.out_count[q] = total;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // procedural index bits (same definition as the checker's generator)
 
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
@@ -653,6 +777,12 @@ hipError_t launch_scan(const ScanArgs& a, uint32_t ntiles, int planes, hipStream
     case 32: return launch_scan_np<32, uint32_t>(a, ntiles, h1, stream);
     default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_topk(const TopkArgs& a, hipStream_t stream) {
+    if (a.nq == 0 || a.k == 0) return hipSuccess;
+    hipLaunchKernelGGL(topk_kernel, dim3(a.nq), dim3(256), 0, stream, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_synth(const SynthArgs& a, hipStream_t stream) {

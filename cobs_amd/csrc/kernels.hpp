@@ -19,6 +19,9 @@ inline uint32_t scan_score_bytes(int planes) { return planes <= 16 ? 2u : 4u; }
 // K2: ntiles * nq work-groups of 4 waves.
 hipError_t launch_scan(const ScanArgs& a, uint32_t ntiles, int planes, hipStream_t stream);
 
+// K3: per query the k best (score desc, doc asc) documents with score >= threshold.
+hipError_t launch_topk(const TopkArgs& a, hipStream_t stream);
+
 hipError_t launch_synth(const SynthArgs& a, hipStream_t stream);
 hipError_t launch_repitch(const RepitchArgs& a, hipStream_t stream);
 

@@ -180,6 +180,13 @@ cobs_gpu_status cobs_gpu_batch_set_queries(cobs_gpu_batch* b, const char* const*
  * :279-307, :643-1022), and, if threshold > 0, on-device selection of documents
  * with count >= ceil(threshold * T) (:127-132).  Counts stay in HBM.          */
 cobs_gpu_status cobs_gpu_batch_run(cobs_gpu_batch* b, double threshold, void* hip_stream);
+/* The same pass followed by K3: on-device selection of the num_results best
+ * documents per query (score descending, ties by document ascending -- the set
+ * std::partial_sort keeps, classic_search.cpp:134-145) among those with
+ * count >= ceil(threshold * T); cobs_gpu_batch_hits_host then moves only those.
+ * Falls back to the plain pass when scores are 32-bit (T >= 65535).            */
+cobs_gpu_status cobs_gpu_batch_run_topk(cobs_gpu_batch* b, double threshold, size_t num_results,
+                                        void* hip_stream);
 /* wait for the stream and fetch device-side error flags (invalid bases, ...) */
 cobs_gpu_status cobs_gpu_batch_sync(cobs_gpu_batch* b, void* hip_stream, size_t* bad_query);
 /* Device pointer to the counts of the last run: row i (query i) starts at

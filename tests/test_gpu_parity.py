@@ -235,3 +235,30 @@ def test_sharded_counts_sum_to_whole(gpu_lib, oracle, tmp_path):
                 assert not c[outside].any()
                 total += c
             assert np.array_equal(total, want)
+
+
+def test_device_topk_matches_partial_sort(gpu_lib, oracle, tmp_path):
+    """K3: the k best documents per query (score desc, document asc) selected on the
+    device equal the oracle's partial_sort, with many ties (short queries) and
+    thresholds, over two files"""
+    q_long = oracle.random_sequence(700, 13)
+    D = 9000
+    planted = {d: f for d, f in zip(range(5, D, 211), np.linspace(0.1, 1.0, 43))}
+    pa = cases.make_compact(cases.tmp(tmp_path, "tk.cobs_compact"), D, 160, [900, 1100, 1300, 1500, 1700, 1900, 2100, 2300],
+                            1, 31, 1, 0.3, 21, planted=planted, query=q_long)
+    pb = cases.make_classic(cases.tmp(tmp_path, "tk.cobs_classic"), 333, 1201, 1, 31, 1, 0.3, 22,
+                            planted={7: 1.0, 300: 0.97}, query=q_long)
+    s = gpu_lib.Search([pa, pb])
+    ixs = [oracle.Index.open(pa), oracle.Index.open(pb)]
+    queries = [q_long, q_long[:36], q_long[:50], q_long[100:400], q_long[:31]]
+    b = gpu_lib.Batch(s)
+    b.set_queries(queries)
+    for t in (0.0, 0.31, 0.9):
+        for k in (1, 7, 100, 5000):
+            b.run_topk(t, k)
+            b.sync()
+            for i, q in enumerate(queries):
+                for lim in sorted({1, min(k, 3), k}):
+                    assert b.hits_host(i, lim) == cases.oracle_results(ixs, q, t, lim), (t, k, lim, i)
+                # num_results = 0 after a top-k pass still returns everything
+                assert b.hits_host(i, 0) == cases.oracle_results(ixs, q, t, 0)
