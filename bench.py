@@ -149,6 +149,8 @@ def main():
     ap.add_argument("--shard-mode", choices=["queries", "index"], default="queries",
                     help="N>1: replicate the index and split the batch (no collective), or shard the "
                          "index by sub-index block and all-gather the count slices over RCCL")
+    ap.add_argument("--num-results", type=int, default=0,
+                    help="k > 0: the step also selects the k best documents per query on the device (K3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real multi-GPU runs; gloo only "
                     "for smoke-testing the launch path with several ranks on one GPU")
@@ -194,7 +196,10 @@ def main():
         gathered = torch.empty((world * local.numel(),), dtype=torch.uint8, device="cuda")
 
     def step():
-        batch.run(args.threshold, 0)
+        if args.num_results > 0:
+            batch.run_topk(args.threshold, args.num_results, 0)
+        else:
+            batch.run(args.threshold, 0)
         if shard_index:
             # per-document hit counts of the disjoint sub-index blocks -> every rank (all-gather over xGMI)
             dist.all_gather_into_tensor(gathered, batch.counts_tensor().view(torch.uint8).reshape(-1))
@@ -255,7 +260,8 @@ def main():
                          % (cfg["num_docs"], len(cfg["signature_sizes"]), cfg["page_size"],
                             cfg["signature_sizes"][0], cfg["signature_sizes"][-1],
                             sum(cfg["signature_sizes"]) * cfg["page_size"] / 1e9,
-                            args.queries, args.kmers, cfg["num_hashes"], args.threshold))
+                            args.queries, args.kmers, cfg["num_hashes"], args.threshold)
+                         + (", top-%d selected on device" % args.num_results if args.num_results else ""))
             if args.config == "c3" else
             ("BASELINE configs[1]: synthetic classic index, %d docs x %d rows, batch of %d queries x %d k-mers"
              % (cfg["num_docs"], cfg["signature_sizes"][0], args.queries, args.kmers)),

@@ -79,6 +79,8 @@ struct TopkArgs {
     uint32_t num_docs;           // real documents of the file
     uint32_t k;
     uint32_t nq;
+    uint32_t score_bits;         // scores are < 2^score_bits (the scan kernel's plane count, <= 16)
+    uint32_t shift1;             // level 1 bins = score >> shift1 (at most 4096), level 2 = the low shift1 bits
 };
 
 // procedural index fill

@@ -992,6 +992,8 @@ static cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk
             ta.num_docs = (uint32_t)p.meta.doc_names.size();
             ta.k = (uint32_t)topk;
             ta.nq = (uint32_t)nq;
+            ta.score_bits = (uint32_t)b->planes;
+            ta.shift1 = b->planes > 12 ? (uint32_t)(b->planes - 12) : 0u;
             HIP_TRY(launch_topk(ta, st));
         }
     }

@@ -512,115 +512,179 @@ __device__ __forceinline__ uint32_t wave_prefix(unsigned long long mask, uint32_
     return (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane, uint32_t* total) {
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off);
+        if (lane >= (uint32_t)off) incl += t;
+    }
+    *total = __shfl(incl, 63);
+    return incl - v;
+}
+
+// Dynamic LDS: hist1[4][NB1] | hist2[4][NB2] | partial[256] | sh[16]; one histogram
+// copy per wave (fewer same-address atomics, and the per-wave tie counts fall out).
 __global__ __launch_bounds__(256) void topk_kernel(TopkArgs a) {
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t sh[16];
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t sh1 = a.shift1;
+    const uint32_t NB1 = 1u << (a.score_bits - sh1), NB2 = 1u << sh1, lomask = NB2 - 1u;
+    uint32_t* hist1 = reinterpret_cast<uint32_t*>(smem);
+    uint32_t* hist2 = hist1 + 4u * NB1;
+    uint32_t* partial = hist2 + 4u * NB2;
+    uint32_t* sh = partial + 256;
     const uint32_t q = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint16_t* row = a.counts + (uint64_t)q * a.counts_stride + a.counts_offset;
     const uint32_t thr = a.thresholds ? a.thresholds[q] : 0u;
-    // real documents among the local slots
-    uint32_t n = a.nslots;
+    uint32_t n = a.nslots;                       // real documents among the local slots
     if (a.doc_base >= a.num_docs) n = 0;
     else if (a.num_docs - a.doc_base < n) n = a.num_docs - a.doc_base;
     const uint32_t k = a.k;
+    // wave w owns the contiguous document range [w0, w1); 512 documents per iteration
+    const uint32_t per = ((n + 3u) / 4u + 511u) / 512u * 512u;
+    const uint32_t w0 = wave * per < n ? wave * per : n;
+    const uint32_t w1 = w0 + per < n ? w0 + per : n;
 
-    // ---- level 1: histogram of the high byte over passing documents
-    hist[tid] = 0;
+    for (uint32_t i = tid; i < 4u * NB1 + 4u * NB2; i += 256) hist1[i] = 0;
     __syncthreads();
-    for (uint32_t i = tid; i < n; i += 256) {
-        const uint32_t s = row[i];
-        if (s >= thr) atomicAdd(&hist[s >> 8], 1u);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t above = 0;
-        int b = 255;
-        for (; b >= 0; --b) {
-            if (above + hist[b] >= k) break;
-            above += hist[b];
-        }
-        sh[0] = (uint32_t)(b < 0 ? 0 : b);     // bucket of the k-th best (0 if fewer than k pass)
-        sh[1] = above;                          // passing documents in higher buckets
-        sh[2] = b < 0 ? 1u : 0u;                // fewer than k passing documents: take them all
-    }
-    __syncthreads();
-    const uint32_t hb = sh[0], above1 = sh[1], take_all = sh[2];
-    __syncthreads();
-    // ---- level 2: histogram of the low byte inside that bucket
-    hist[tid] = 0;
-    __syncthreads();
-    if (!take_all) {
-        for (uint32_t i = tid; i < n; i += 256) {
-            const uint32_t s = row[i];
-            if (s >= thr && (s >> 8) == hb) atomicAdd(&hist[s & 255u], 1u);
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t above = above1, cut = thr;
-        if (!take_all) {
-            int b = 255;
-            for (; b >= 0; --b) {
-                if (above + hist[b] >= k) break;
-                above += hist[b];
+    // ---- level 1 histogram (score >> shift1) over passing documents
+    uint32_t* myh1 = hist1 + wave * NB1;
+    for (uint32_t i0 = w0; i0 < w1; i0 += 512) {
+        const uint32_t i = i0 + lane * 8u;
+        if (i < w1) {
+            const uint4 v = *reinterpret_cast<const uint4*>(row + i);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t s = (w[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                if (i + j < w1 && s >= thr) atomicAdd(&myh1[s >> sh1], 1u);
             }
-            cut = (hb << 8) | (uint32_t)b;
         }
-        sh[3] = cut;                            // s*: score of the k-th best
-        sh[4] = above;                          // documents with score > s*
-        sh[5] = 0;                              // emission cursor for those
     }
     __syncthreads();
-    const uint32_t cut = sh[3], n_above = sh[4];
-    const uint32_t need_eq = take_all ? 0xFFFFFFFFu : k - n_above;
-    // ---- ties: per-wave counts of score == s* so that each wave knows its rank base
-    const uint32_t per = (n + 3u) / 4u;
-    const uint32_t w0 = wave * per, w1 = (w0 + per < n) ? w0 + per : n;
-    uint32_t eq_wave = 0;
+    {   // parallel search of the bin holding the k-th best: per-thread segment sums, then thread 0
+        const uint32_t seg = (NB1 + 255u) / 256u;
+        uint32_t sum = 0;
+        for (uint32_t b = tid * seg; b < (tid + 1) * seg && b < NB1; ++b)
+            sum += hist1[b] + hist1[NB1 + b] + hist1[2 * NB1 + b] + hist1[3 * NB1 + b];
+        partial[tid] = sum;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t above = 0;
+            int t = 255;
+            for (; t >= 0; --t) {
+                if (above + partial[t] >= k) break;
+                above += partial[t];
+            }
+            int hb = -1;
+            if (t >= 0) {
+                int b = (int)((uint32_t)(t + 1) * seg) - 1;
+                if (b >= (int)NB1) b = (int)NB1 - 1;
+                for (; b >= (int)((uint32_t)t * seg); --b) {
+                    const uint32_t c = hist1[b] + hist1[NB1 + b] + hist1[2 * NB1 + b] + hist1[3 * NB1 + b];
+                    if (above + c >= k) { hb = b; break; }
+                    above += c;
+                }
+            }
+            sh[0] = hb < 0 ? 0u : (uint32_t)hb;
+            sh[1] = above;
+            sh[2] = hb < 0 ? 1u : 0u;            // fewer than k passing documents: take them all
+        }
+        __syncthreads();
+    }
+    const uint32_t hb = sh[0], take_all = sh[2];
+    uint32_t n_above = sh[1], cut = hb << sh1;
+    // ---- level 2 (only for scores wider than 12 bits): low bits inside bin hb
+    if (sh1 > 0 && !take_all) {
+        uint32_t* myh2 = hist2 + wave * NB2;
+        for (uint32_t i0 = w0; i0 < w1; i0 += 512) {
+            const uint32_t i = i0 + lane * 8u;
+            if (i < w1) {
+                const uint4 v = *reinterpret_cast<const uint4*>(row + i);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t s = (w[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                    if (i + j < w1 && s >= thr && (s >> sh1) == hb) atomicAdd(&myh2[s & lomask], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t above = n_above;
+            int b = (int)NB2 - 1;
+            for (; b > 0; --b) {
+                const uint32_t c = hist2[b] + hist2[NB2 + b] + hist2[2 * NB2 + b] + hist2[3 * NB2 + b];
+                if (above + c >= k) break;
+                above += c;
+            }
+            sh[3] = (uint32_t)b;
+            sh[4] = above;
+        }
+        __syncthreads();
+        cut = (hb << sh1) | sh[3];
+        n_above = sh[4];
+    }
+    if (take_all) cut = thr;
+    // ties: documents with score == cut, per wave (falls out of the per-wave histograms)
+    uint32_t eq_base = 0, eq_total = 0;
     if (!take_all) {
-        for (uint32_t i0 = w0; i0 < w1; i0 += 64) {
-            const uint32_t i = i0 + lane;
-            const bool eq = i < w1 && (uint32_t)row[i] == cut && cut >= thr;
-            eq_wave += (uint32_t)__popcll(__ballot(eq));
+        for (uint32_t w = 0; w < 4; ++w) {
+            const uint32_t c = sh1 > 0 ? hist2[w * NB2 + (cut & lomask)] : hist1[w * NB1 + hb];
+            if (w < wave) eq_base += c;
+            eq_total += c;
         }
     }
-    if (lane == 0) sh[8 + wave] = eq_wave;
+    const uint32_t need_eq = take_all ? 0u : k - n_above;
+    if (tid == 0) sh[5] = 0;                      // emission cursor of the documents above the cut
     __syncthreads();
-    uint32_t eq_base = 0;
-    for (uint32_t w = 0; w < wave; ++w) eq_base += sh[8 + w];
     // ---- emission
     uint2* out = a.out + (uint64_t)q * k;
-    for (uint32_t i0 = w0; i0 < w1; i0 += 64) {
-        const uint32_t i = i0 + lane;
-        const uint32_t s = i < w1 ? (uint32_t)row[i] : 0u;
-        const bool pass = i < w1 && s >= thr;
-        const bool gt = pass && (take_all || s > cut);
-        const bool eq = pass && !take_all && s == cut;
-        const unsigned long long mg = __ballot(gt), me = __ballot(eq);
-        if (mg) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&sh[5], (uint32_t)__popcll(mg));
-            base = __shfl(base, 0);
-            if (gt) out[base + wave_prefix(mg, lane)] = make_uint2(a.doc_base + i, s);
+    for (uint32_t i0 = w0; i0 < w1; i0 += 512) {
+        const uint32_t i = i0 + lane * 8u;
+        uint32_t s8[8];
+        uint32_t gt = 0, eq = 0;
+        if (i < w1) {
+            const uint4 v = *reinterpret_cast<const uint4*>(row + i);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t s = (w[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                s8[j] = s;
+                const bool pass = i + j < w1 && s >= thr;
+                if (pass && (take_all || s > cut)) gt |= 1u << j;
+                if (pass && !take_all && s == cut) eq |= 1u << j;
+            }
         }
-        if (me) {
-            const uint32_t r = eq_base + wave_prefix(me, lane);
-            if (eq && r < need_eq) out[n_above + r] = make_uint2(a.doc_base + i, s);
-            eq_base += (uint32_t)__popcll(me);
+        if (__any(gt != 0u)) {
+            uint32_t total;
+            const uint32_t excl = wave_excl_scan((uint32_t)__popc(gt), lane, &total);
+            uint32_t base = 0;
+            if (lane == 63u) base = atomicAdd(&sh[5], total);
+            base = __shfl(base, 63);
+            uint32_t pos = base + excl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (gt & (1u << j)) out[pos++] = make_uint2(a.doc_base + i + j, s8[j]);
+        }
+        if (__any(eq != 0u)) {
+            uint32_t total;
+            const uint32_t excl = wave_excl_scan((uint32_t)__popc(eq), lane, &total);
+            uint32_t r = eq_base + excl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (eq & (1u << j)) {
+                    if (r < need_eq) out[n_above + r] = make_uint2(a.doc_base + i + j, s8[j]);
+                    ++r;
+                }
+            eq_base += total;
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        uint32_t total;
-        if (take_all) total = sh[5];
-        else {
-            uint32_t eq_total = sh[8] + sh[9] + sh[10] + sh[11];
-            total = n_above + (eq_total < need_eq ? eq_total : need_eq);
-        }
-        a.out_count[q] = total;
-    }
+    if (tid == 0)
+        a.out_count[q] = take_all ? sh[5] : n_above + (eq_total < need_eq ? eq_total : need_eq);
 }
 
 // ---------------------------------------------------------------------------
@@ -781,7 +845,14 @@ hipError_t launch_scan(const ScanArgs& a, uint32_t ntiles, int planes, hipStream
 
 hipError_t launch_topk(const TopkArgs& a, hipStream_t stream) {
     if (a.nq == 0 || a.k == 0) return hipSuccess;
-    hipLaunchKernelGGL(topk_kernel, dim3(a.nq), dim3(256), 0, stream, a);
+    const uint32_t nb1 = 1u << (a.score_bits - a.shift1), nb2 = 1u << a.shift1;
+    const size_t lds = (size_t)(4 * nb1 + 4 * nb2 + 256 + 16) * sizeof(uint32_t);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(topk_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(topk_kernel, dim3(a.nq), dim3(256), lds, stream, a);
     return hipGetLastError();
 }
 
