@@ -25,7 +25,7 @@ struct HashArgs {
     const uint32_t* q_len;      // characters per query
     const uint64_t* blk_off;    // nq + 1 prefix sums of 8-term blocks per query
     const PageDev* pages;       // local sub-indexes
-    uint32_t* table;            // row indices: [q][page][block][hash][8]
+    uint32_t* table;            // row indices: [q][page][block (nblk + 1 padding block)][hash][8]
     uint32_t* err_query;        // atomicMin of queries holding a non-ACGT base
     uint32_t nq;
     uint32_t npages;
@@ -64,6 +64,9 @@ struct ScanArgs {
     uint32_t num_docs;          // documents of the file (ids >= this are padding)
     uint32_t part;              // file number
     uint32_t write_counts;      // 0: selection only
+    uint32_t tile_w;            // 16-byte chunks per tile: 4, 8, 16, 32 or 64
+    uint32_t chunk_begin;       // this launch covers column chunks [chunk_begin, chunk_end)
+    uint32_t chunk_end;
 };
 
 // Arguments of the top-k selection kernel K3 for one index file (u16 scores).

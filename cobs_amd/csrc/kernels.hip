@@ -157,15 +157,18 @@ __global__ __launch_bounds__(256) void hash_kernel(HashArgs a, uint64_t total_th
     const uint64_t b0 = a.blk_off[q];
     const uint32_t nblk = (uint32_t)(a.blk_off[q + 1] - b0);
     const uint32_t T = len - k + 1;
-    if (i >= nblk * 8u) return;
+    // every (query, sub-index) table has nblk blocks of 8 terms plus one all-padding
+    // block that lanes without work in a trip of K2 point at
+    const uint32_t tblk = nblk + 1u;
+    if (i >= tblk * 8u) return;
     const uint32_t H = a.num_hashes;
     const uint32_t blk = i >> 3, sub = i & 7u;
-    uint32_t* out = a.table + (b0 * a.npages) * (8ull * H);
+    uint32_t* out = a.table + ((b0 + q) * a.npages) * (8ull * H);
 
     if (i >= T) {       // padding term: the all-zero row of every sub-index
         for (uint32_t p = 0; p < a.npages; ++p) {
             const uint32_t zr = (uint32_t)a.pages[p].sig;
-            uint32_t* o = out + ((uint64_t)p * nblk + blk) * (8ull * H) + sub;
+            uint32_t* o = out + ((uint64_t)p * tblk + blk) * (8ull * H) + sub;
             for (uint32_t j = 0; j < H; ++j) o[j * 8] = zr;
         }
         return;
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(256) void hash_kernel(HashArgs a, uint64_t total_th
         const uint64_t h = xxh64_view(kv, (uint64_t)j);
         for (uint32_t p = 0; p < a.npages; ++p) {
             const PageDev pg = a.pages[p];
-            out[((uint64_t)p * nblk + blk) * (8ull * H) + j * 8 + sub] = fast_mod(h, pg.sig, pg.magic);
+            out[((uint64_t)p * tblk + blk) * (8ull * H) + j * 8 + sub] = fast_mod(h, pg.sig, pg.magic);
         }
     }
 }
@@ -308,18 +311,26 @@ __global__ __launch_bounds__(NW * 64, MINW) void scan_kernel(ScanArgs a) {
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
+    // A tile is W (power of two, <= 64) sixteen-byte column chunks of the chunk range
+    // [chunk_begin, chunk_end).  With W < 64 one wave-load fetches G = 64 / W different
+    // rows (terms): lane group g of wave w acts as "virtual wave" w*G + g with its own
+    // stream of 8-term blocks.  Narrow tiles keep the slice of a small sub-index that
+    // all queries of the batch hammer (rows x W*16 bytes) inside the 256 MB Infinity
+    // Cache, and they fill the lanes when the whole index is narrower than a wave.
+    const uint32_t W = a.tile_w;
+    const uint32_t G = 64u / W;
+    const uint32_t ntiles = (a.chunk_end - a.chunk_begin + W - 1u) / W;
     uint32_t tile, q;
     if constexpr ((VAR & 2) != 0) {
-        const uint32_t ntiles = (a.total_chunks + 63u) / 64u;
         q = blockIdx.x / ntiles;
         tile = blockIdx.x - q * ntiles;
     } else {
         tile = blockIdx.x / a.nq;                    // tile-major: co-resident groups share a sub-index
         q = blockIdx.x - tile * a.nq;
     }
-
-    const uint32_t g = tile * 64u + lane;
-    const uint32_t gc = g < a.total_chunks ? g : a.total_chunks - 1u;
+    const uint32_t grp = lane / W, col = lane & (W - 1u);
+    const uint32_t g = a.chunk_begin + tile * W + col;
+    const uint32_t gc = g < a.chunk_end ? g : a.chunk_end - 1u;     // dead lanes duplicate a live one
     const uint32_t pg = gc / a.cpp;
     const uint32_t ch = gc - pg * a.cpp;
     const uint8_t* lane_base = a.blob + a.pages[pg].base + (uint64_t)ch * 16u;
@@ -328,8 +339,15 @@ __global__ __launch_bounds__(NW * 64, MINW) void scan_kernel(ScanArgs a) {
     const uint64_t b0 = a.blk_off[q];
     const uint32_t nblk = (uint32_t)(a.blk_off[q + 1] - b0);
     const uint32_t H = H1 ? 1u : a.num_hashes;
-    // row indices of this lane's sub-index: [block][hash][8]
-    const uint32_t* tab = a.table + (b0 * a.npages + (uint64_t)pg * nblk) * (8ull * H);
+    // row indices of this lane's sub-index: [nblk + 1 blocks][hash][8]; block nblk is all padding
+    const uint32_t* tab = a.table + ((b0 + q) * a.npages + (uint64_t)pg * (nblk + 1u)) * (8ull * H);
+    const uint32_t vw = wave * G + grp;              // virtual wave of this lane
+    const uint32_t NV = NW * G;
+    // block of this lane in trip i: vw + i * NV, or the padding block when it has run out
+    auto blk_of = [&](uint32_t i) -> uint64_t {
+        const uint32_t bidx = vw + i * NV;
+        return (uint64_t)(bidx < nblk ? bidx : nblk) * 8u * H;
+    };
 
     uint32_t pl[4][NP];
 #pragma unroll
@@ -337,38 +355,35 @@ __global__ __launch_bounds__(NW * 64, MINW) void scan_kernel(ScanArgs a) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) pl[w][k] = 0u;
 
-    // this wave's blocks are wave, wave + NW, ...: nw of them (wave-uniform)
-    const uint32_t nw = nblk > wave ? (nblk - wave + NW - 1) / NW : 0u;
+    // trips of this wave (wave-uniform): as many as its first lane group needs
+    const uint32_t first = wave * G;
+    const uint32_t nw = nblk > first ? (nblk - first + NV - 1u) / NV : 0u;
     uint32_t ea[4], eb[4];
     if constexpr (H1) {
         // Three-stage software pipeline, branch-free in the steady state:
-        //   row indices of block i+2 | row loads of block i+1 | CSA of block i
+        //   row indices of trip i+2 | row loads of trip i+1 | CSA of trip i
         // so that 8..16 row loads (8..16 KiB per wave) are always in flight.
         if (nw > 0) {
             uint4 XA[8], XB[8];
-            const uint32_t* tw = tab + (uint64_t)wave * 8u;
-            const uint64_t step = (uint64_t)NW * 8u;            // u32 entries between this wave's blocks
-            const uint32_t last = nw - 1;
-            const uint4* t0 = reinterpret_cast<const uint4*>(tw);
+            const uint4* t0 = reinterpret_cast<const uint4*>(tab + blk_of(0));
             uint4 i0a = t0[0], i0b = t0[1];
             issue_rows<NT>(XA, lane_base, pitch, i0a, i0b);
-            const uint4* t1 = reinterpret_cast<const uint4*>(tw + step * (last < 1u ? last : 1u));
+            const uint4* t1 = reinterpret_cast<const uint4*>(tab + blk_of(1));
             uint4 i1a = t1[0], i1b = t1[1];
             uint32_t i = 0;
             for (; i + 2 < nw; i += 2) {
-                // XA in flight = block i, (i1a,i1b) = indices of block i+1
-                const uint4* tn = reinterpret_cast<const uint4*>(tw + step * (i + 2));
+                // XA in flight = trip i, (i1a,i1b) = indices of trip i+1
+                const uint4* tn = reinterpret_cast<const uint4*>(tab + blk_of(i + 2));
                 i0a = tn[0]; i0b = tn[1];
                 issue_rows<NT>(XB, lane_base, pitch, i1a, i1b);
                 absorb_block<NP>(pl, XA, ea);
-                const uint32_t nx = i + 3 < last ? i + 3 : last;
-                const uint4* tm = reinterpret_cast<const uint4*>(tw + step * nx);
+                const uint4* tm = reinterpret_cast<const uint4*>(tab + blk_of(i + 3));
                 i1a = tm[0]; i1b = tm[1];
                 issue_rows<NT>(XA, lane_base, pitch, i0a, i0b);
                 absorb_block<NP>(pl, XB, eb);
                 retire_pair<NP>(pl, ea, eb);
             }
-            // XA in flight = block i; one or two blocks left
+            // XA in flight = trip i; one or two trips left
             if (i + 1 < nw) {
                 issue_rows<NT>(XB, lane_base, pitch, i1a, i1b);
                 absorb_block<NP>(pl, XA, ea);
@@ -383,8 +398,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void scan_kernel(ScanArgs a) {
         // general H: AND the H hash rows of each term first (aggregate_rows)
         uint4 X[8], Y[8];
         for (uint32_t i = 0; i < nw; ++i) {
-            const uint32_t blk = wave + i * NW;
-            const uint4* t = reinterpret_cast<const uint4*>(tab + (uint64_t)blk * 8u * H);
+            const uint4* t = reinterpret_cast<const uint4*>(tab + blk_of(i));
             issue_rows<NT>(X, lane_base, pitch, t[0], t[1]);
             for (uint32_t j = 1; j < H; ++j) {
                 issue_rows<NT>(Y, lane_base, pitch, t[2 * j], t[2 * j + 1]);
@@ -392,6 +406,21 @@ __global__ __launch_bounds__(NW * 64, MINW) void scan_kernel(ScanArgs a) {
             }
             absorb_block<NP>(pl, X, ea);
             retire_single<NP>(pl, ea);
+        }
+    }
+
+    // ---- merge the G lane groups of this wave (bit-sliced adds across lanes)
+    for (uint32_t s = W; s < 64u; s <<= 1) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            uint32_t carry = 0u;
+#pragma unroll
+            for (int kk = 0; kk < NP; ++kk) {
+                const uint32_t o = __shfl_down(pl[w][kk], s);
+                uint32_t h;
+                csa(h, pl[w][kk], pl[w][kk], o, carry);
+                carry = h;
+            }
         }
     }
 
@@ -430,14 +459,12 @@ __global__ __launch_bounds__(NW * 64, MINW) void scan_kernel(ScanArgs a) {
     const uint32_t* planes = reinterpret_cast<const uint32_t*>(mbuf);   // [NP][64*4 words]
     const uint32_t thr = a.thresholds ? a.thresholds[q] : 0u;
     OutT* crow = reinterpret_cast<OutT*>(a.counts) + (uint64_t)q * a.counts_stride + a.counts_offset;
-    constexpr int BYTES_PER_THREAD = 1024 / (NW * 64);
 #pragma unroll 1
-    for (int it = 0; it < BYTES_PER_THREAD; ++it) {
-        const uint32_t b = threadIdx.x + it * (NW * 64);      // row byte inside the tile
+    for (uint32_t b = threadIdx.x; b < W * 16u; b += NW * 64) {      // row byte inside the tile
         const uint32_t chunk = b >> 4, cb = b & 15u;
-        const uint32_t gch = tile * 64u + chunk;
-        bool valid = gch < a.total_chunks;
-        const uint32_t gcc = valid ? gch : 0u;
+        const uint32_t gch = a.chunk_begin + tile * W + chunk;
+        bool valid = gch < a.chunk_end;
+        const uint32_t gcc = valid ? gch : a.chunk_begin;
         const uint32_t p2 = gcc / a.cpp;
         const uint32_t byte_in_page = (gcc - p2 * a.cpp) * 16u + cb;
         const PageDev pd = a.pages[p2];
@@ -776,7 +803,8 @@ hipError_t launch_hash(const HashArgs& a, uint64_t total_threads, hipStream_t st
 
 template <int NP, int NW, bool H1, typename OutT, int VAR = 0, int MINW = 1>
 static hipError_t launch_scan_inst(const ScanArgs& a, uint32_t ntiles, hipStream_t stream) {
-    const uint64_t groups = (uint64_t)ntiles * a.nq;
+    (void)ntiles;
+    const uint64_t groups = (uint64_t)((a.chunk_end - a.chunk_begin + a.tile_w - 1) / a.tile_w) * a.nq;
     if (groups == 0) return hipSuccess;
     if (groups > 0x7FFFFFFFull) return hipErrorInvalidValue;
     constexpr size_t lds = (size_t)(NW >= 2 ? NW / 2 : 1) * NP * 64 * sizeof(uint4);

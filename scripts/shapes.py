@@ -66,3 +66,6 @@ if __name__ == "__main__":
         run("C3 T=100 Q20k", "compact", bench.c3_config()["signature_sizes"], 100000, 1568, 20000, 100)
         run("C3 T=20 Q20k", "compact", bench.c3_config()["signature_sizes"], 100000, 1568, 20000, 20)
         run("C3 T=5000 Q2k", "compact", bench.c3_config()["signature_sizes"], 100000, 1568, 2000, 5000)
+    if on("huge"):
+        run("compact 25k docs ps1568 P2 S=30M Q2k", "compact", [30000000, 30000000], 25000, 1568, 2000, 1000)
+        run("compact 100k docs ps512 P25 S=6M Q2k", "compact", [6000000] * 25, 100000, 512, 2000, 1000)
