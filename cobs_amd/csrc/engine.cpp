@@ -853,13 +853,14 @@ cobs_gpu_status cobs_gpu_batch_set_queries(cobs_gpu_batch* b, const char* const*
         off += round_up(span, 8);
     }
     b->span_off[nq] = off;
-    HIP_TRY(b->h_text.reserve((size_t)off));
-    std::memset(b->h_text.p, 0, (size_t)off);
+    // + 64: K1 reads whole dwords around a k-mer
+    HIP_TRY(b->h_text.reserve((size_t)off + 64));
+    std::memset(b->h_text.p, 0, (size_t)off + 64);
     for (size_t q = 0; q < nq; ++q) std::memcpy(b->h_text.p + b->span_off[q], queries[q], lens[q]);
-    HIP_TRY(b->text.reserve((size_t)off));
+    HIP_TRY(b->text.reserve((size_t)off + 64));
     HIP_TRY(b->d_span_off.reserve(nq + 1));
     HIP_TRY(b->d_qlen.reserve(nq));
-    if (off) HIP_TRY(hipMemcpy(b->text.p, b->h_text.p, (size_t)off, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->text.p, b->h_text.p, (size_t)off + 64, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->d_span_off.p, b->span_off.data(), 8 * (nq + 1), hipMemcpyHostToDevice));
     if (nq) HIP_TRY(hipMemcpy(b->d_qlen.p, b->lens.data(), 4 * nq, hipMemcpyHostToDevice));
 

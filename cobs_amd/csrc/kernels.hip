@@ -197,6 +197,117 @@ __global__ __launch_bounds__(256) void hash_kernel(HashArgs a, uint64_t total_th
     }
 }
 
+// K1 specialised for k = 31 (the COBS default): the 31-mer lives in eight 32-bit
+// registers, complement and reversal are done four bases at a time, and the
+// reference's comparison of the first 15 positions (util/query.cpp:155-190) becomes
+// a big-endian integer comparison of forward vs reverse complement.
+__device__ __forceinline__ uint32_t comp4(uint32_t w) {
+    // A(0x41)<->T(0x54): xor 0x15, C(0x43)<->G(0x47): xor 0x04; C and G have bit 1 set
+    const uint32_t m = (w >> 1) & 0x01010101u;
+    return w ^ 0x15151515u ^ (m | (m << 4));
+}
+
+__device__ __forceinline__ uint64_t xxh64_31(const uint32_t (&c)[8], uint64_t seed) {
+    // public XXH64 spec for len = 31 < 32: 3 x 8 bytes, 1 x 4 bytes, 3 x 1 byte
+    uint64_t h = seed + XP5 + 31ull;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const uint64_t v = (uint64_t)c[2 * i] | ((uint64_t)c[2 * i + 1] << 32);
+        h ^= xround(0, v);
+        h = rotl64(h, 27) * XP1 + XP4;
+    }
+    h ^= (uint64_t)c[6] * XP1;
+    h = rotl64(h, 23) * XP2 + XP3;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        h ^= (uint64_t)((c[7] >> (8 * i)) & 0xFFu) * XP5;
+        h = rotl64(h, 11) * XP1;
+    }
+    h ^= h >> 33; h *= XP2; h ^= h >> 29; h *= XP3; h ^= h >> 32;
+    return h;
+}
+
+__global__ __launch_bounds__(256) void hash_kernel_k31(HashArgs a, uint64_t total_threads) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total_threads) return;
+    uint32_t lo = 0, hi = a.nq;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a.span_off[mid] <= gid) lo = mid; else hi = mid;
+    }
+    const uint32_t q = lo;
+    const uint64_t qbase = a.span_off[q];
+    const uint32_t i = (uint32_t)(gid - qbase);
+    const uint32_t len = a.q_len[q];
+    const uint8_t* text = a.text + qbase;
+    if (a.canonicalize != 0 && i < len) {
+        if (fwd_base(text[i]) == 0) atomicMin(a.err_query, q);
+    }
+    const uint64_t b0 = a.blk_off[q];
+    const uint32_t nblk = (uint32_t)(a.blk_off[q + 1] - b0);
+    const uint32_t T = len - 31u + 1u;
+    const uint32_t tblk = nblk + 1u;
+    if (i >= tblk * 8u) return;
+    const uint32_t H = a.num_hashes;
+    const uint32_t blk = i >> 3, sub = i & 7u;
+    uint32_t* out = a.table + ((b0 + q) * a.npages) * (8ull * H);
+    if (i >= T) {
+        for (uint32_t p = 0; p < a.npages; ++p) {
+            const uint32_t zr = (uint32_t)a.pages[p].sig;
+            uint32_t* o = out + ((uint64_t)p * tblk + blk) * (8ull * H) + sub;
+            for (uint32_t j = 0; j < H; ++j) o[j * 8] = zr;
+        }
+        return;
+    }
+    // the k-mer and one following byte as 8 (unaligned) dwords; the text buffer is padded
+    uint32_t f[8];
+    {
+        const uint8_t* p = text + i;
+        const uint32_t mis = (uint32_t)((uintptr_t)p & 3u);
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(p - mis);
+        uint32_t r[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) r[j] = w[j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            f[j] = mis == 0 ? r[j] : (uint32_t)(((uint64_t)r[j] | ((uint64_t)r[j + 1] << 32)) >> (8 * mis));
+    }
+    f[7] &= 0x00FFFFFFu;                          // byte 31 is not part of the 31-mer
+    uint32_t c[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c[j] = f[j];
+    if (a.canonicalize != 0) {
+        // reverse complement: B[j] = comp(raw[31 - j]) for the 32-byte block, then drop B[0]
+        uint32_t rv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rv[j] = __builtin_bswap32(comp4(f[7 - j]));
+        uint32_t rc[8];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) rc[j] = (rv[j] >> 8) | (rv[j + 1] << 24);
+        rc[7] = rv[7] >> 8;
+        // first strict difference among positions 0..14 decides (big-endian compare);
+        // the middle base (position 15) is never compared; ties keep the forward k-mer
+        bool use_rc = false, decided = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t x = __builtin_bswap32(f[j]), y = __builtin_bswap32(rc[j]);
+            if (j == 3) { x >>= 8; y >>= 8; }
+            if (!decided && x != y) { use_rc = x > y; decided = true; }
+        }
+        if (use_rc) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) c[j] = rc[j];
+        }
+    }
+    for (uint32_t j = 0; j < H; ++j) {
+        const uint64_t h = xxh64_31(c, (uint64_t)j);
+        for (uint32_t p = 0; p < a.npages; ++p) {
+            const PageDev pg = a.pages[p];
+            out[((uint64_t)p * tblk + blk) * (8ull * H) + j * 8 + sub] = fast_mod(h, pg.sig, pg.magic);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // K2: gather + AND + bit-sliced count.
 //
@@ -797,7 +908,10 @@ hipError_t launch_hash(const HashArgs& a, uint64_t total_threads, hipStream_t st
     if (total_threads == 0) return hipSuccess;
     const uint64_t blocks = (total_threads + 255) / 256;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(hash_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, a, total_threads);
+    if (a.term_size == 31)
+        hipLaunchKernelGGL(hash_kernel_k31, dim3((uint32_t)blocks), dim3(256), 0, stream, a, total_threads);
+    else
+        hipLaunchKernelGGL(hash_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, a, total_threads);
     return hipGetLastError();
 }
 
