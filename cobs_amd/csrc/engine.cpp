@@ -280,13 +280,13 @@ uint64_t slice_bytes(uint64_t sig, uint64_t ncols) {
 // tiles: every lane group should get about three blocks.  Indexes narrower than a
 // wave get the smallest tile that covers them so that no lanes idle.
 // Tuning hook: COBS_GPU_TILE_W forces one width.
-uint32_t tile_width_for(const Chunk& c, uint64_t mean_blocks, uint64_t num_hashes) {
+uint32_t tile_width_for(const Chunk& c, uint64_t mean_blocks, uint64_t num_hashes, int nwaves) {
     if (const char* e = getenv("COBS_GPU_TILE_W")) {
         const int v = atoi(e);
         if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) return (uint32_t)v;
     }
     uint32_t groups = 1;                       // lane groups per wave the queries can feed
-    while (groups < 8 && (uint64_t)groups * 2 * 4 * 3 <= mean_blocks) groups <<= 1;
+    while (groups < 8 && (uint64_t)groups * 2 * nwaves * 3 <= mean_blocks) groups <<= 1;
     uint32_t w = 64 / groups;
     if (num_hashes > 1 && w < 16) w = 16;      // generic-H kernel: 16 measured best
     if (c.total_chunks < w) {                  // index narrower than the tile
@@ -996,14 +996,21 @@ static cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk
             sa.num_docs = (uint32_t)p.meta.doc_names.size();
             sa.part = (uint32_t)f;
             sa.write_counts = 1;
-            sa.tile_w = tile_width_for(c, b->work[f].h_blk_off[nq] / nq, p.meta.num_hashes);
+            const uint64_t mean_blocks = b->work[f].h_blk_off[nq] / nq;
+            // waves that split one query's blocks: short queries get fewer (less merging, more groups per CU)
+            int nwaves = mean_blocks <= 4 ? 1 : mean_blocks <= 16 ? 2 : 4;
+            if (const char* e = getenv("COBS_GPU_WAVES")) {
+                const int v = atoi(e);
+                if (v == 1 || v == 2 || v == 4) nwaves = v;
+            }
+            sa.tile_w = tile_width_for(c, mean_blocks, p.meta.num_hashes, nwaves);
             sa.chunk_begin = 0;
             sa.chunk_end = c.total_chunks;
             // one launch covers at most 2^31-1 work-groups
             const uint32_t ntiles = (c.total_chunks + sa.tile_w - 1) / sa.tile_w;
             if ((uint64_t)ntiles * nq > 0x7FFFFFFFull)
                 return fail(COBS_GPU_ERR_CAPACITY, "batch too large for one scan launch; use fewer queries");
-            HIP_TRY(launch_scan(sa, ntiles, b->planes, st));
+            HIP_TRY(launch_scan(sa, ntiles, b->planes, nwaves, st));
             ++launches;
             if (p.streamed) {
                 HIP_TRY(hipEventRecord(p.scanned[buf], st));

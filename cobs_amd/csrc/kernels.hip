@@ -417,8 +417,17 @@ template <int NP, int NW, bool H1, typename OutT, int VAR = 0, int MINW = 1>
 __global__ __launch_bounds__(NW * 64, MINW) void scan_kernel(ScanArgs a) {
     constexpr bool NT = (VAR & 1) != 0;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    // merge buffers: [NW/2 (min 1)][NP][64 lanes] of uint4
+    // merge buffers: [NW/2 (min 1)][NP][64 lanes] of uint4, then the 256-entry expansion table
     uint4* mbuf = reinterpret_cast<uint4*>(smem);
+    uint4* lut = mbuf + (size_t)(NW >= 2 ? NW / 2 : 1) * NP * 64;
+    for (uint32_t v = threadIdx.x; v < 256u; v += NW * 64) {
+        uint4 e;
+        e.x = (v & 1u) | ((v & 2u) << 15);
+        e.y = ((v >> 2) & 1u) | ((v & 8u) << 13);
+        e.z = ((v >> 4) & 1u) | ((v & 32u) << 11);
+        e.w = ((v >> 6) & 1u) | ((v & 128u) << 9);
+        lut[v] = e;
+    }
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
@@ -581,23 +590,32 @@ __global__ __launch_bounds__(NW * 64, MINW) void scan_kernel(ScanArgs a) {
         const PageDev pd = a.pages[p2];
         valid = valid && byte_in_page < pd.valid_bytes;
 
-        uint32_t cnt[8];
-#pragma unroll
-        for (int d = 0; d < 8; ++d) cnt[d] = 0u;
+        // one LDS lookup spreads the 8 document bits of a plane byte into 8 sixteen-bit
+        // fields (4 dwords); shifting the dwords by the plane number adds that plane to all
+        // 8 counters at once.  Planes 16.. go to a second accumulator (32-bit scores).
+        uint32_t lo[4] = {0u, 0u, 0u, 0u}, hi[4] = {0u, 0u, 0u, 0u};
         const uint32_t sh = (cb & 3u) * 8u;
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const uint32_t v = (planes[(k * 64 + chunk) * 4 + (cb >> 2)] >> sh) & 0xFFu;
+            const uint4 e = lut[v];
+            if (k < 16) {
+                lo[0] |= e.x << k; lo[1] |= e.y << k; lo[2] |= e.z << k; lo[3] |= e.w << k;
+            } else {
+                hi[0] |= e.x << (k - 16); hi[1] |= e.y << (k - 16);
+                hi[2] |= e.z << (k - 16); hi[3] |= e.w << (k - 16);
+            }
+        }
+        uint32_t cnt[8];
 #pragma unroll
-            for (int d = 0; d < 8; ++d) cnt[d] |= ((v >> d) & 1u) << k;
+        for (int m = 0; m < 4; ++m) {
+            cnt[2 * m] = (lo[m] & 0xFFFFu) | ((hi[m] & 0xFFFFu) << 16);
+            cnt[2 * m + 1] = (lo[m] >> 16) | (hi[m] & 0xFFFF0000u);
         }
         const uint32_t slot = pd.slot0 + byte_in_page * 8u;
         if (valid && a.write_counts) {
             if constexpr (sizeof(OutT) == 2) {
-                uint4 o;
-                o.x = cnt[0] | (cnt[1] << 16); o.y = cnt[2] | (cnt[3] << 16);
-                o.z = cnt[4] | (cnt[5] << 16); o.w = cnt[6] | (cnt[7] << 16);
-                *reinterpret_cast<uint4*>(crow + slot) = o;
+                *reinterpret_cast<uint4*>(crow + slot) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
             } else {
                 *reinterpret_cast<uint4*>(crow + slot) = make_uint4(cnt[0], cnt[1], cnt[2], cnt[3]);
                 *reinterpret_cast<uint4*>(crow + slot + 4) = make_uint4(cnt[4], cnt[5], cnt[6], cnt[7]);
@@ -921,7 +939,7 @@ static hipError_t launch_scan_inst(const ScanArgs& a, uint32_t ntiles, hipStream
     const uint64_t groups = (uint64_t)((a.chunk_end - a.chunk_begin + a.tile_w - 1) / a.tile_w) * a.nq;
     if (groups == 0) return hipSuccess;
     if (groups > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    constexpr size_t lds = (size_t)(NW >= 2 ? NW / 2 : 1) * NP * 64 * sizeof(uint4);
+    constexpr size_t lds = ((size_t)(NW >= 2 ? NW / 2 : 1) * NP * 64 + 256) * sizeof(uint4);
     auto kern = scan_kernel<NP, NW, H1, OutT, VAR, MINW>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -933,7 +951,13 @@ static hipError_t launch_scan_inst(const ScanArgs& a, uint32_t ntiles, hipStream
 }
 
 template <int NP, typename OutT>
-static hipError_t launch_scan_np(const ScanArgs& a, uint32_t ntiles, bool h1, hipStream_t stream) {
+static hipError_t launch_scan_np(const ScanArgs& a, uint32_t ntiles, bool h1, int nw, hipStream_t stream) {
+    if (nw == 1)
+        return h1 ? launch_scan_inst<NP, 1, true, OutT>(a, ntiles, stream)
+                  : launch_scan_inst<NP, 1, false, OutT>(a, ntiles, stream);
+    if (nw == 2)
+        return h1 ? launch_scan_inst<NP, 2, true, OutT>(a, ntiles, stream)
+                  : launch_scan_inst<NP, 2, false, OutT>(a, ntiles, stream);
     return h1 ? launch_scan_inst<NP, 4, true, OutT>(a, ntiles, stream)
               : launch_scan_inst<NP, 4, false, OutT>(a, ntiles, stream);
 }
@@ -957,9 +981,9 @@ static int scan_variant() {
     return v;
 }
 
-hipError_t launch_scan(const ScanArgs& a, uint32_t ntiles, int planes, hipStream_t stream) {
+hipError_t launch_scan(const ScanArgs& a, uint32_t ntiles, int planes, int nw, hipStream_t stream) {
     const bool h1 = a.num_hashes == 1;
-    if (planes == 10 && h1) {
+    if (planes == 10 && h1 && scan_variant() != 0) {
         switch (scan_variant()) {
         case 1: return launch_scan_inst<10, 4, true, uint16_t, 1>(a, ntiles, stream);       // nt loads
         case 2: return launch_scan_inst<10, 4, true, uint16_t, 2>(a, ntiles, stream);       // query-major
@@ -973,14 +997,14 @@ hipError_t launch_scan(const ScanArgs& a, uint32_t ntiles, int planes, hipStream
         }
     }
     switch (planes) {
-    case 4: return launch_scan_np<4, uint16_t>(a, ntiles, h1, stream);
-    case 8: return launch_scan_np<8, uint16_t>(a, ntiles, h1, stream);
-    case 10: return launch_scan_np<10, uint16_t>(a, ntiles, h1, stream);
-    case 12: return launch_scan_np<12, uint16_t>(a, ntiles, h1, stream);
-    case 16: return launch_scan_np<16, uint16_t>(a, ntiles, h1, stream);
-    case 20: return launch_scan_np<20, uint32_t>(a, ntiles, h1, stream);
-    case 24: return launch_scan_np<24, uint32_t>(a, ntiles, h1, stream);
-    case 32: return launch_scan_np<32, uint32_t>(a, ntiles, h1, stream);
+    case 4: return launch_scan_np<4, uint16_t>(a, ntiles, h1, nw, stream);
+    case 8: return launch_scan_np<8, uint16_t>(a, ntiles, h1, nw, stream);
+    case 10: return launch_scan_np<10, uint16_t>(a, ntiles, h1, nw, stream);
+    case 12: return launch_scan_np<12, uint16_t>(a, ntiles, h1, nw, stream);
+    case 16: return launch_scan_np<16, uint16_t>(a, ntiles, h1, nw, stream);
+    case 20: return launch_scan_np<20, uint32_t>(a, ntiles, h1, nw, stream);
+    case 24: return launch_scan_np<24, uint32_t>(a, ntiles, h1, nw, stream);
+    case 32: return launch_scan_np<32, uint32_t>(a, ntiles, h1, nw, stream);
     default: return hipErrorInvalidValue;
     }
 }
