@@ -262,3 +262,37 @@ def test_device_topk_matches_partial_sort(gpu_lib, oracle, tmp_path):
                     assert b.hits_host(i, lim) == cases.oracle_results(ixs, q, t, lim), (t, k, lim, i)
                 # num_results = 0 after a top-k pass still returns everything
                 assert b.hits_host(i, 0) == cases.oracle_results(ixs, q, t, 0)
+
+
+def test_long_queries_u32_scores(gpu_lib, oracle, tmp_path):
+    """queries long enough for 12, 16, 20, 24 and 32 bit planes (u32 scores from T >= 65536,
+    the reference's uint32_t Score path, classic_search.cpp:485-500)"""
+    D = 70
+    p = cases.make_classic(cases.tmp(tmp_path, "long.cobs_classic"), D, 1201, 1, 31, 1, 0.3, 3)
+    pk = cases.make_compact(cases.tmp(tmp_path, "long.cobs_compact"), 150, 8, [257, 509, 1021], 2, 31, 1, 0.3, 4)
+    s, sk = gpu_lib.Search(p), gpu_lib.Search(pk)
+    ix, ixk = oracle.Index.open(p), oracle.Index.open(pk)
+    for length in (2000 + 30, 40000 + 30, 70000 + 30, 1100000 + 30):
+        q = oracle.random_sequence(length, length)
+        got = s.counts(q)
+        want, width = ix.counts(q, want_width=True)
+        assert width == (2 if length < 65565 else 4)
+        assert np.array_equal(got, want)
+        assert np.array_equal(sk.counts(q), ixk.counts(q))
+        assert s.search_hits([q], 0.29, 5)[0] == cases.oracle_results([ix], q, 0.29, 5)
+        assert s.search_hits([q], 0.0, 0)[0] == cases.oracle_results([ix], q, 0.0, 0)
+    q = oracle.random_sequence(17000000, 99)          # T > 2^24: 32 planes
+    assert np.array_equal(s.counts(q), ix.counts(q))
+
+
+def test_empty_and_minimal_batches(gpu_lib, oracle, golden_dir):
+    s = gpu_lib.Search(os.path.join(golden_dir, "c1.cobs_compact"))
+    assert s.search_hits([], 0.0, 0) == []
+    b = gpu_lib.Batch(s)
+    b.set_queries([])
+    b.run(0.5)
+    b.sync()
+    ix = oracle.Index.open(os.path.join(golden_dir, "c1.cobs_compact"))
+    q = Q50[:31]                                         # exactly one term
+    assert np.array_equal(s.counts(q), ix.counts(q))
+    assert s.search_hits([q], 1.0, 0)[0] == cases.oracle_results([ix], q, 1.0, 0)
