@@ -1242,23 +1242,48 @@ cobs_gpu_status cobs_gpu_search_batch(cobs_gpu_index* ix, const char* const* que
                                       cobs_gpu_hit* hits, size_t cap, size_t* hit_offsets,
                                       size_t* bad_query) {
     if (!ix || !hit_offsets) return fail(COBS_GPU_ERR_ARG, "NULL argument");
-    // a bounded num_results is selected on the device (K3), nothing but the k best travel back
-    cobs_gpu_status st = run_host_batch(ix, queries, lens, nq, threshold, bad_query,
-                                        num_results < ix->total_counts ? num_results : 0);
-    if (st != COBS_GPU_OK) return st;
+    if (nq && (!queries || !lens)) return fail(COBS_GPU_ERR_ARG, "NULL argument");
     size_t used = 0;
     hit_offsets[0] = 0;
     bool overflow = false;
-    for (size_t q = 0; q < nq; ++q) {
-        double t0 = now_s();
-        size_t n = 0;
-        st = cobs_gpu_batch_hits_host(ix->scratch, q, num_results, overflow ? nullptr : hits + used,
-                                      overflow ? 0 : cap - used, &n);
-        ix->timers[4] += now_s() - t0;
-        if (st == COBS_GPU_ERR_CAPACITY || (overflow && st == COBS_GPU_ERR_ARG)) overflow = true;
-        else if (st != COBS_GPU_OK) return st;
-        used += n;
-        hit_offsets[q + 1] = used;
+    // Large batches are cut into device passes whose score rows and row-index tables stay
+    // below ~4 GiB each (the caller sees one call; results are concatenated).
+    uint64_t kLimit = 4ull << 30;
+    if (const char* e = getenv("COBS_GPU_PASS_BYTES")) kLimit = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
+    uint64_t terms_per_char = 0;                      // table bytes per query character, all files
+    for (const auto& p : ix->parts) terms_per_char += 4ull * p.meta.num_hashes * std::max<uint32_t>(p.max_chunk_pages, 1);
+    size_t g0 = 0;
+    while (g0 < nq || (nq == 0 && g0 == 0)) {
+        size_t g1 = g0;
+        uint64_t score_bytes = 0, table_bytes = 0;
+        while (g1 < nq) {
+            const uint64_t sb = ix->local_counts * 4ull, tb = (uint64_t)(lens[g1] + 16) * terms_per_char;
+            if (g1 > g0 && (score_bytes + sb > kLimit || table_bytes + tb > kLimit)) break;
+            score_bytes += sb;
+            table_bytes += tb;
+            ++g1;
+        }
+        size_t bad = 0;
+        // a bounded num_results is selected on the device (K3), nothing but the k best travel back
+        cobs_gpu_status st = run_host_batch(ix, queries + g0, lens + g0, g1 - g0, threshold, &bad,
+                                            num_results < ix->total_counts ? num_results : 0);
+        if (st != COBS_GPU_OK) {
+            if (bad_query) *bad_query = g0 + bad;
+            return st;
+        }
+        for (size_t q = g0; q < g1; ++q) {
+            double t0 = now_s();
+            size_t n = 0;
+            st = cobs_gpu_batch_hits_host(ix->scratch, q - g0, num_results, overflow ? nullptr : hits + used,
+                                          overflow ? 0 : cap - used, &n);
+            ix->timers[4] += now_s() - t0;
+            if (st == COBS_GPU_ERR_CAPACITY || (overflow && st == COBS_GPU_ERR_ARG)) overflow = true;
+            else if (st != COBS_GPU_OK) return st;
+            used += n;
+            hit_offsets[q + 1] = used;
+        }
+        if (nq == 0) break;
+        g0 = g1;
     }
     if (overflow) return fail(COBS_GPU_ERR_CAPACITY, "hit buffer too small; hit_offsets[nq] holds the needed size");
     return COBS_GPU_OK;

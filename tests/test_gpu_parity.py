@@ -296,3 +296,28 @@ def test_empty_and_minimal_batches(gpu_lib, oracle, golden_dir):
     q = Q50[:31]                                         # exactly one term
     assert np.array_equal(s.counts(q), ix.counts(q))
     assert s.search_hits([q], 1.0, 0)[0] == cases.oracle_results([ix], q, 1.0, 0)
+
+
+def test_large_host_batch_is_cut_into_passes(gpu_lib, oracle, tmp_path, monkeypatch):
+    """cobs_gpu_search_batch splits a batch whose score rows / tables exceed the pass limit;
+    results and the index of a bad query are those of one big batch"""
+    from cobs_amd import _capi
+    q_long = oracle.random_sequence(300, 44)
+    p = cases.make_compact(cases.tmp(tmp_path, "pass.cobs_compact"), 900, 16, [401, 503, 601, 701, 809, 907, 1009, 1103],
+                           1, 31, 1, 0.3, 5, planted={3: 1.0, 500: 0.8}, query=q_long)
+    s = gpu_lib.Search(p)
+    ix = oracle.Index.open(p)
+    queries = [q_long[i:i + 60 + 7 * (i % 5)] for i in range(40)]
+    monkeypatch.setenv("COBS_GPU_PASS_BYTES", str(5 * s.local_counts * 4))       # 5 queries per pass
+    for t, lim in ((0.0, 0), (0.3, 4), (0.0, 3)):
+        got = s.search_hits(queries, t, lim)
+        assert got == [cases.oracle_results([ix], q, t, lim) for q in queries]
+    bad = list(queries)
+    bad[23] = bad[23][:10] + b"N" + bad[23][11:]
+    arr = (_capi.C.c_char_p * len(bad))(*bad)
+    lens = (_capi.C.c_size_t * len(bad))(*[len(q) for q in bad])
+    offs = (_capi.C.c_size_t * (len(bad) + 1))()
+    hits = (_capi.Hit * (len(bad) * s.total_counts))()
+    badq = _capi.C.c_size_t(999)
+    st = s._lib.cobs_gpu_search_batch(s._h, arr, lens, len(bad), 0.0, 0, hits, len(hits), offs, _capi.C.byref(badq))
+    assert st == _capi.ERR_INVALID_BASE and badq.value == 23
