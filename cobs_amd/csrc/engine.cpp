@@ -12,6 +12,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/cobs_gpu.h"
@@ -122,6 +123,7 @@ struct Part {
     uint32_t max_chunk_pages = 0;
     // streaming state (BASELINE config 5: index larger than the HBM budget)
     std::unique_ptr<MappedFile> file;        // source of the chunks
+    bool file_pinned = false;                // the mapping is registered with HIP: DMA straight from it
     bool synthetic = false;
     uint64_t synth_seed = 0;
     DevBuf<uint8_t> sbuf[2];
@@ -129,6 +131,7 @@ struct Part {
     hipStream_t copy_stream = nullptr;
     hipEvent_t copied[2] = {nullptr, nullptr}, scanned[2] = {nullptr, nullptr};
     bool buf_used[2] = {false, false};
+    size_t stage_need = 0;
     uint64_t doc_offset = 0;      // first global score slot of this file
     uint64_t slot_begin = 0;      // file-level score slots computed here
     uint64_t slot_count = 0;
@@ -147,6 +150,7 @@ struct Part {
             if (c.d_data) (void)hipFree(c.d_data);
             if (c.d_pages) (void)hipFree(c.d_pages);
         }
+        if (file_pinned && file) (void)hipHostUnregister(const_cast<uint8_t*>(file->data()));
         for (auto& e : copied) if (e) (void)hipEventDestroy(e);
         for (auto& e : scanned) if (e) (void)hipEventDestroy(e);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
@@ -433,7 +437,7 @@ cobs_gpu_status alloc_part(Part& pt) {
         for (const Chunk& c : pt.chunks) { dev = std::max(dev, c.bytes); host = std::max(host, c.stage_bytes); }
         for (int i = 0; i < 2; ++i) {
             HIP_TRY(pt.sbuf[i].reserve(dev));
-            if (!pt.synthetic) HIP_TRY(pt.stage[i].reserve(host));
+            pt.stage_need = host;
             HIP_TRY(hipEventCreateWithFlags(&pt.copied[i], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&pt.scanned[i], hipEventDisableTiming));
         }
@@ -509,20 +513,37 @@ cobs_gpu_status stream_chunk_in(Part& pt, const Chunk& c, int buf) {
     }
     const IndexMeta& m = pt.meta;
     const uint64_t prb = m.page_row_bytes();
+    if (!pt.file_pinned) HIP_TRY(pt.stage[buf].reserve(pt.stage_need));
     uint8_t* host = pt.stage[buf].p;
     uint64_t hoff = 0;
     for (size_t i = 0; i < c.vp.size(); ++i) {
         const VPage& v = c.vp[i];
         const PageDev& pd = c.pages[i];
         const uint8_t* src = pt.file->data() + m.page_offset(v.fp);
-        uint8_t* hp = host + hoff;
-        if (v.ncols == prb) {
-            std::memcpy(hp, src, (size_t)(pd.sig * prb));
-        } else {
-            for (uint64_t r = 0; r < pd.sig; ++r)
-                std::memcpy(hp + r * v.ncols, src + r * prb + v.col0, (size_t)v.ncols);
-        }
         uint8_t* dst = dev + pd.base;
+        if (pt.file_pinned) {
+            HIP_TRY(hipMemcpy2DAsync(dst, c.pitch, src + v.col0, (size_t)prb, (size_t)v.ncols, (size_t)pd.sig,
+                                     hipMemcpyHostToDevice, pt.copy_stream));
+            HIP_TRY(hipMemsetAsync(dst + pd.sig * (uint64_t)c.pitch, 0, c.pitch, pt.copy_stream));
+            continue;
+        }
+        uint8_t* hp = host + hoff;
+        {   // pack the needed columns into pinned staging with a few host threads
+            const unsigned nthr = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(8, pd.sig * v.ncols >> 24));
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < nthr; ++t) {
+                const uint64_t r0 = pd.sig * t / nthr, r1 = pd.sig * (t + 1) / nthr;
+                pool.emplace_back([=]() {
+                    if (v.ncols == prb) {
+                        std::memcpy(hp + r0 * prb, src + r0 * prb, (size_t)((r1 - r0) * prb));
+                    } else {
+                        for (uint64_t r = r0; r < r1; ++r)
+                            std::memcpy(hp + r * v.ncols, src + r * prb + v.col0, (size_t)v.ncols);
+                    }
+                });
+            }
+            for (auto& th : pool) th.join();
+        }
         if (c.pitch == v.ncols)
             HIP_TRY(hipMemcpyAsync(dst, hp, (size_t)(pd.sig * v.ncols), hipMemcpyHostToDevice, pt.copy_stream));
         else
@@ -653,6 +674,19 @@ cobs_gpu_status cobs_gpu_open(const char* const* paths, size_t n_paths,
         if (st != COBS_GPU_OK) return st;
         if (pt.streamed) {
             pt.file = std::move(files[i]);       // chunks are read from the mapping at every pass
+            // Pin the read-only mapping so that the copy engine reads it directly (no packing
+            // through staging buffers).  Not every kernel/driver allows pinning file pages;
+            // if it fails the staged path is used.
+            if (!getenv("COBS_GPU_NO_PIN")) {
+                hipError_t pe = hipHostRegister(const_cast<uint8_t*>(pt.file->data()), pt.file->size(),
+                                                hipHostRegisterReadOnly);
+                if (pe != hipSuccess) {
+                    (void)hipGetLastError();
+                    pe = hipHostRegister(const_cast<uint8_t*>(pt.file->data()), pt.file->size(), hipHostRegisterDefault);
+                }
+                if (pe == hipSuccess) pt.file_pinned = true;
+                else (void)hipGetLastError();
+            }
         } else {
             st = upload_resident(pt, files[i]->data());
             if (st != COBS_GPU_OK) return st;
