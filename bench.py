@@ -135,6 +135,34 @@ def cpu_baseline(search, cfg, queries, seconds_target=12.0, check_queries=4, bat
     return res
 
 
+def end_to_end(search, batch, queries):
+    """PCIe-inclusive rates of the host-buffer API on the same batch (never `value`):
+    query text H2D + K1 + K2 (+ selection) + D2H of the results + host ordering."""
+    res = {}
+    nq = len(queries)
+    for name, thr, k in (("threshold_0.8_all_hits", 0.8, 0), ("threshold_0_top10", 0.0, 10)):
+        search.search_hits(queries, thr, k)                      # sizes the scratch workspace
+        t0 = time.perf_counter()
+        hits = search.search_hits(queries, thr, k)
+        dt = time.perf_counter() - t0
+        res[name] = {"queries_per_s": round(nq / dt, 1), "seconds": round(dt, 4),
+                     "hits": sum(len(h) for h in hits)}
+    # threshold 0, every document scored: the scores themselves have to cross PCIe
+    t = batch.counts_tensor()
+    host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    batch.run(0.0, 0)
+    host.copy_(t, non_blocking=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    batch.sync()
+    res["threshold_0_all_scores_to_pinned_host"] = {
+        "queries_per_s": round(nq / dt, 1), "seconds": round(dt, 4),
+        "d2h_GB": round(t.numel() * t.element_size() / 1e9, 3)}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -286,6 +314,7 @@ def main():
         },
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["end_to_end"] = end_to_end(s, batch, mine)
         out["cpu_baseline"] = cpu_baseline(s, cfg, mine, batch=batch)
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -139,8 +139,13 @@ class Search:
         nq = len(qs)
         arr = (C.c_char_p * max(nq, 1))(*qs)
         lens = (C.c_size_t * max(nq, 1))(*[len(q) for q in qs])
-        cap = max(1, nq * (self.total_counts if threshold <= 0 or num_results == 0 else
-                           min(num_results, self.total_counts)))
+        if num_results > 0:
+            cap = nq * min(num_results, self.total_counts)
+        elif threshold <= 0:
+            cap = nq * self.total_counts          # every document is a result
+        else:
+            cap = 16 * nq + 1024                  # grown on demand (ERR_CAPACITY reports the size)
+        cap = max(1, cap)
         offs = (C.c_size_t * (nq + 1))()
         bad = C.c_size_t(0)
         while True:
