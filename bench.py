@@ -209,11 +209,11 @@ def main():
                                   seed=cfg["seed"], device=dev,
                                   shard_rank=rank if shard_index else 0,
                                   shard_count=world if shard_index else 1)
-    all_queries = make_queries(args.queries, args.kmers)
     if world > 1 and not shard_index:
-        mine = all_queries[rank::world]        # strong scaling: the batch is split over the ranks
+        # weak scaling: every rank serves its own batch of --queries queries against its replica
+        mine = make_queries(args.queries, args.kmers, seed=42 + rank)
     else:
-        mine = all_queries
+        mine = make_queries(args.queries, args.kmers)
     batch = cobs_amd.Batch(s)
     batch.set_queries(mine)                    # H2D once; inputs now resident in HBM
 
@@ -254,7 +254,8 @@ def main():
     ms = batch.kernel_ms()                     # HIP events on the launch stream, averaged over the timed steps
     st = batch.stats()
 
-    total_queries = args.queries               # whole job, both shard modes
+    # whole job: replicated index -> N independent batches; sharded index -> one batch on all ranks
+    total_queries = args.queries * (world if not shard_index else 1)
     ms_per_step = dt / args.steps * 1e3
     qps = total_queries * args.steps / dt
     algo = st["algorithmic_bytes"]
@@ -278,7 +279,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": "strong" if shard_index else "weak",
         "vs_baseline": None,
         "dtype": "u32 bit-planes (u16 scores)",
         "data": "synthetic",
@@ -293,11 +294,13 @@ def main():
             if args.config == "c3" else
             ("BASELINE configs[1]: synthetic classic index, %d docs x %d rows, batch of %d queries x %d k-mers"
              % (cfg["num_docs"], cfg["signature_sizes"][0], args.queries, args.kmers)),
-            "global_batch": args.queries,
+            "global_batch": total_queries,
+            "queries_per_gpu_batch": args.queries,
             "kmers_per_query": args.kmers,
             "parallelism": ("1 gpu" if world == 1 else
                             ("index sharded by sub-index block x%d + RCCL all-gather of counts" % world
-                             if shard_index else "index replicated, batch split x%d, no collective" % world)),
+                             if shard_index else "index replicated on %d GPUs, one %d-query batch per GPU, no data-path collective"
+                             % (world, args.queries))),
         },
         "kmer_lookups_per_s": round(qps * args.kmers, 1),
         "roofline": {
