@@ -163,6 +163,7 @@ struct cobs_gpu_index {
     int device = 0;
     uint32_t shard_rank = 0, shard_count = 1;
     uint64_t hbm_budget = 0;      // 0 = everything resident
+    uint32_t waves_per_group = 0; // 0 = by query length
     std::vector<Part> parts;
     uint64_t total_counts = 0, local_counts = 0;
     double timers[5] = {0, 0, 0, 0, 0};
@@ -660,6 +661,8 @@ cobs_gpu_status cobs_gpu_open(const char* const* paths, size_t n_paths,
     cobs_gpu_status st = shard_of(opts, &ix->shard_rank, &ix->shard_count);
     if (st != COBS_GPU_OK) return st;
     ix->hbm_budget = budget_of(opts);
+    if (opts && (opts->waves_per_group == 1 || opts->waves_per_group == 2 || opts->waves_per_group == 4))
+        ix->waves_per_group = opts->waves_per_group;
     uint64_t left = ix->hbm_budget;
     for (auto& pt : ix->parts) {
         st = plan_part(pt, ix->shard_rank, ix->shard_count, ix->hbm_budget ? &left : nullptr);
@@ -1033,7 +1036,8 @@ static cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk
             const uint64_t mean_blocks = b->work[f].h_blk_off[nq] / nq;
             // waves that split one query's blocks: short queries get fewer (less merging, more groups per CU)
             int nwaves = mean_blocks <= 4 ? 1 : mean_blocks <= 16 ? 2 : 4;
-            if (const char* e = getenv("COBS_GPU_WAVES")) {
+            if (ix->waves_per_group) nwaves = (int)ix->waves_per_group;
+            if (const char* e = getenv("COBS_GPU_WAVES")) {     // tuning hook
                 const int v = atoi(e);
                 if (v == 1 || v == 2 || v == 4) nwaves = v;
             }

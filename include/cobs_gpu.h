@@ -50,7 +50,7 @@ typedef struct cobs_gpu_options {
      * shard_rank out of shard_count; counts of other shards' documents are 0.  */
     uint32_t shard_rank;
     uint32_t shard_count;     /* 0 or 1 = unsharded */
-    uint32_t waves_per_group; /* 0 = default (4): waves that split one query's terms */
+    uint32_t waves_per_group; /* waves that split one query's terms: 1, 2 or 4; 0 = chosen by query length */
     uint32_t reserved;
     /* 0 = stage the whole (shard of the) index into HBM.  Otherwise the index may
      * use at most this many bytes of HBM: files that do not fit are cut into chunks
