@@ -12,8 +12,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <fstream>
 #include <iostream>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -22,7 +24,42 @@
 static void usage() {
     std::fprintf(stderr,
                  "usage: cobs_gpu_query -i INDEX [-i INDEX ...] [-t THRESHOLD] [-l LIMIT] "
-                 "[-d DEVICE] (QUERY | -f QUERY_FILE)\n");
+                 "[-d DEVICE] (QUERY | -f QUERY_FILE)\n"
+                 "       cobs_gpu_query --benchmark -i INDEX [-k KMERS] [-q QUERIES] [-w WARMUP] [--seed S]\n");
+}
+
+// `cobs benchmark-fpr` (reference src/cobs.cpp:605-730): random ACGT queries of
+// num_kmers + 30 characters from one std::mt19937(seed), default threshold 0 and
+// num_results 0, one RESULT line.  Here the queries run as one device batch; the
+// reference's t_io / t_and / t_add phases are one scan kernel (t_scan).
+static int benchmark(cobs_gpu::ClassicSearch& s, const std::string& index, unsigned num_kmers,
+                     unsigned num_queries, unsigned num_warmup, size_t seed) {
+    static const char basepairs[4] = {'A', 'C', 'G', 'T'};
+    std::mt19937 rng(seed);
+    auto make = [&](unsigned n) {
+        std::vector<std::string> v(n);
+        for (auto& q : v) {
+            q.resize(num_kmers + 30);
+            for (auto& c : q) c = basepairs[rng() % 4];
+        }
+        return v;
+    };
+    std::vector<std::string> warm = make(num_warmup), queries = make(num_queries);
+    std::vector<std::vector<cobs_gpu::SearchResult>> results;
+    if (!warm.empty()) s.search_batch(warm, results);
+    double t[5];
+    cobs_gpu_timers(s.handle(), t, 1);
+    const auto t0 = std::chrono::steady_clock::now();
+    s.search_batch(queries, results);
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    cobs_gpu_timers(s.handle(), t, 0);
+    std::cout << "RESULT name=benchmark  index=" << index << " kmer_queries=" << num_kmers
+              << " queries=" << num_queries << " warmup=" << num_warmup
+              << " results=" << (results.empty() ? 0 : results.back().size()) << " backend=gpu"
+              << " t_hashes=" << t[0] << " t_scan=" << t[2] << " t_h2d=" << t[1] << " t_d2h=" << t[3]
+              << " t_sort=" << t[4] << " t_total=" << wall << " queries_per_s=" << num_queries / wall
+              << std::endl;
+    return 0;
 }
 
 int main(int argc, char** argv) {
@@ -31,6 +68,9 @@ int main(int argc, char** argv) {
     double threshold = 0.8;
     size_t num_results = 0;
     int device = -1;
+    bool bench = false;
+    unsigned num_kmers = 1000, num_queries = 10000, num_warmup = 100;
+    size_t seed = std::random_device{}();
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto need = [&](const char* what) -> const char* {
@@ -42,9 +82,23 @@ int main(int argc, char** argv) {
         else if (a == "-t" || a == "--threshold") threshold = std::atof(need("-t"));
         else if (a == "-l" || a == "--limit") num_results = (size_t)std::strtoull(need("-l"), nullptr, 10);
         else if (a == "-d" || a == "--device") device = std::atoi(need("-d"));
+        else if (a == "--benchmark") bench = true;
+        else if (a == "-k" || a == "--num-kmers") num_kmers = (unsigned)std::atoi(need("-k"));
+        else if (a == "-q" || a == "--queries") num_queries = (unsigned)std::atoi(need("-q"));
+        else if (a == "-w" || a == "--warmup") num_warmup = (unsigned)std::atoi(need("-w"));
+        else if (a == "--seed") seed = (size_t)std::strtoull(need("--seed"), nullptr, 10);
         else if (a == "-h" || a == "--help") { usage(); return 0; }
         else if (!a.empty() && a[0] == '-') { std::fprintf(stderr, "unknown flag %s\n", a.c_str()); usage(); return 1; }
         else query_line = a;
+    }
+    if (bench && !index_paths.empty()) {
+        try {
+            cobs_gpu::ClassicSearch s(index_paths, device);
+            return benchmark(s, index_paths[0], num_kmers, num_queries, num_warmup, seed);
+        } catch (const cobs_gpu::Error& e) {
+            std::fprintf(stderr, "EXCEPTION: %s\n", e.what());
+            return 1;
+        }
     }
     if (index_paths.empty() || (query_line.empty() && query_file.empty())) {
         if (!index_paths.empty()) std::fprintf(stderr, "Pass a verbatim query or a query file.\n");

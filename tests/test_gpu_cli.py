@@ -55,3 +55,16 @@ def test_bad_input_is_an_error_exit(gpu_lib, golden_dir):
     assert r.returncode != 0 and "Invalid DNA base pair" in r.stderr
     r = _run("-i", os.path.join(golden_dir, "expected.json"), Q50)
     assert r.returncode != 0 and "Could not open index path" in r.stderr
+
+
+def test_benchmark_result_line(gpu_lib, oracle, tmp_path):
+    """`cobs benchmark-fpr` harness (reference src/cobs.cpp:605-730): RESULT line, mt19937 queries"""
+    p = cases.make_classic(cases.tmp(tmp_path, "b.cobs_classic"), 500, 4001, 1, 31, 1, 0.3, 1)
+    r = _run("--benchmark", "-i", p, "-k", "200", "-q", "50", "-w", "5", "--seed", "7")
+    assert r.returncode == 0, r.stderr
+    line = r.stdout.strip().splitlines()[-1]
+    assert line.startswith("RESULT name=benchmark ")
+    kv = dict(f.split("=", 1) for f in line.split()[1:])
+    assert kv["kmer_queries"] == "200" and kv["queries"] == "50" and kv["warmup"] == "5"
+    assert kv["results"] == "500"                       # threshold 0: every document is returned
+    assert float(kv["t_scan"]) > 0 and float(kv["queries_per_s"]) > 0
