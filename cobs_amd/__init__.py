@@ -6,7 +6,10 @@ threshold, num_results)` (reference python/module.cpp:367-386) /
 All compute happens in libcobs_gpu.so (HIP, C ABI in include/cobs_gpu.h).
 """
 from ._capi import CobsGpuError  # noqa: F401
+from .construct import (ClassicIndexParameters, CompactIndexParameters, DocumentList,  # noqa: F401
+                        classic_construct, compact_construct, disable_cache)
 from .search import Batch, Search, SearchResult  # noqa: F401
 
 __version__ = "0.1.0"
-__all__ = ["Search", "SearchResult", "Batch", "CobsGpuError", "__version__"]
+__all__ = ["Search", "SearchResult", "Batch", "CobsGpuError", "DocumentList", "ClassicIndexParameters",
+           "CompactIndexParameters", "classic_construct", "compact_construct", "disable_cache", "__version__"]

@@ -42,6 +42,13 @@ class Hit(C.Structure):
     _fields_ = [("file_no", C.c_uint32), ("doc", C.c_uint32), ("score", C.c_uint32)]
 
 
+class BuildParams(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("term_size", C.c_uint32), ("canonicalize", C.c_uint32),
+                ("num_hashes", C.c_uint32), ("false_positive_rate", C.c_double),
+                ("signature_size", C.c_uint64), ("page_size", C.c_uint64),
+                ("device", C.c_int32), ("reserved", C.c_uint32)]
+
+
 class Synth(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("term_size", C.c_uint32), ("canonicalize", C.c_uint32),
                 ("num_pages", C.c_uint32), ("num_hashes", C.c_uint64), ("page_size", C.c_uint64),
@@ -67,6 +74,10 @@ SYMBOLS = {
     "cobs_gpu_local_counts": (_u64, [_vp]),
     "cobs_gpu_read_row": (_int, [_vp, _sz, _u32, _u64, _vp, _sz]),
     "cobs_gpu_read_rows": (_int, [_vp, _sz, _u32, _u64, _u64, _vp, _sz]),
+    "cobs_gpu_build_classic": (_int, [C.POINTER(_cp), C.POINTER(_cp), C.POINTER(_sz), _sz,
+                                      C.POINTER(BuildParams), _cp]),
+    "cobs_gpu_build_compact": (_int, [C.POINTER(_cp), C.POINTER(_cp), C.POINTER(_sz), _sz,
+                                      C.POINTER(BuildParams), _cp]),
     "cobs_gpu_search": (_int, [_vp, _cp, _sz, _dbl, _sz, C.POINTER(Hit), _sz, C.POINTER(_sz)]),
     "cobs_gpu_search_batch": (_int, [_vp, C.POINTER(_cp), C.POINTER(_sz), _sz, _dbl, _sz,
                                      C.POINTER(Hit), _sz, C.POINTER(_sz), C.POINTER(_sz)]),

@@ -86,6 +86,22 @@ struct TopkArgs {
     uint32_t shift1;             // level 1 bins = score >> shift1 (at most 4096), level 2 = the low shift1 bits
 };
 
+// Arguments of the construction kernel: set the signature bits of documents.
+struct BuildArgs {
+    const uint8_t* text;        // documents back to back, each followed by '\n'; sequences inside a
+                                // document are separated by '\n' too (terms never span a separator)
+    const uint64_t* doc_off;    // ndocs + 1 offsets into text (incl. the trailing separator)
+    uint32_t* matrix;           // signature_size rows of row_bytes (multiple of 4) bytes, as words
+    uint64_t signature_size;
+    uint64_t magic;             // floor((2^64-1) / signature_size)
+    uint64_t row_bytes;
+    uint32_t ndocs;
+    uint32_t doc_bit0;          // column (document slot) of document 0 of this launch
+    uint32_t term_size;
+    uint32_t canonicalize;
+    uint32_t num_hashes;
+};
+
 // procedural index fill
 struct SynthArgs {
     uint8_t* blob;

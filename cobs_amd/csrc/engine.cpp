@@ -625,6 +625,9 @@ uint32_t threshold_for(double threshold, uint64_t terms) {
 
 }  // namespace
 
+// shared with build.cpp
+__attribute__((visibility("hidden"))) cobs_gpu_status cobs_gpu_set_error(cobs_gpu_status st, const char* msg) { return fail(st, msg ? msg : ""); }
+
 // ===========================================================================
 // C ABI
 

@@ -840,6 +840,46 @@ __global__ __launch_bounds__(256) void topk_kernel(TopkArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// Construction: the reference sets bit (doc % 8) of byte doc / 8
+// of row XXH64(canon(term), seed j) % signature_size for every term of every document
+// (cobs/construction/classic_index.cpp:40-73).  One thread per text position; a
+// position starts a term if the next k characters hold no separator.  With
+// canonicalize = 1 the reference hashes the canonicalised buffer even when it holds
+// invalid characters (mapped to 0), which the generic byte view reproduces.
+__global__ __launch_bounds__(256) void build_kernel(BuildArgs a, uint64_t total_bytes) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total_bytes) return;
+    const uint32_t k = a.term_size;
+    if (gid + k > total_bytes) return;
+    const uint8_t* p = a.text + gid;
+    for (uint32_t i = 0; i < k; ++i)
+        if (p[i] == '\n') return;                     // term would span a sequence / document boundary
+    uint32_t lo = 0, hi = a.ndocs;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a.doc_off[mid] <= gid) lo = mid; else hi = mid;
+    }
+    const uint32_t doc = a.doc_bit0 + lo;
+    KmerView kv{p, k, 0u};
+    if (a.canonicalize != 0) {
+        uint32_t mode = 1;
+        for (uint32_t s = 0; s < k / 2; ++s) {
+            const int f = (int)fwd_base(p[s]);
+            const int r = (int)rev_base(p[k - 1 - s]);
+            if (f < r) break;
+            if (f > r) { mode = 2; break; }
+        }
+        kv.mode = mode;
+    }
+    const uint64_t byte_in_row = doc >> 3;
+    const uint32_t bit = 1u << ((uint32_t)(byte_in_row & 3u) * 8u + (doc & 7u));
+    for (uint32_t j = 0; j < a.num_hashes; ++j) {
+        const uint64_t row = fast_mod(xxh64_view(kv, (uint64_t)j), a.signature_size, a.magic);
+        atomicOr(a.matrix + (row * a.row_bytes + byte_in_row) / 4u, bit);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // procedural index bits (same definition as the checker's generator)
 
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
@@ -992,6 +1032,14 @@ hipError_t launch_topk(const TopkArgs& a, hipStream_t stream) {
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(topk_kernel, dim3(a.nq), dim3(256), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_build(const BuildArgs& a, uint64_t total_bytes, hipStream_t stream) {
+    if (total_bytes == 0) return hipSuccess;
+    const uint64_t blocks = (total_bytes + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(build_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, a, total_bytes);
     return hipGetLastError();
 }
 

@@ -22,6 +22,9 @@ hipError_t launch_scan(const ScanArgs& a, uint32_t ntiles, int planes, int nw, h
 // K3: per query the k best (score desc, doc asc) documents with score >= threshold.
 hipError_t launch_topk(const TopkArgs& a, hipStream_t stream);
 
+// Index construction: one thread per text position hashes its term and sets the bits.
+hipError_t launch_build(const BuildArgs& a, uint64_t total_bytes, hipStream_t stream);
+
 hipError_t launch_synth(const SynthArgs& a, hipStream_t stream);
 hipError_t launch_repitch(const RepitchArgs& a, hipStream_t stream);
 

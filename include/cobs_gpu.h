@@ -141,6 +141,33 @@ cobs_gpu_status cobs_gpu_read_row(const cobs_gpu_index* ix, size_t file_no, uint
 cobs_gpu_status cobs_gpu_read_rows(const cobs_gpu_index* ix, size_t file_no, uint32_t page,
                                    uint64_t row0, uint64_t nrows, uint8_t* out, size_t out_pitch);
 
+/* ---- construction (the step in front of the query path) ------ */
+typedef struct cobs_gpu_build_params {
+    uint32_t struct_size;        /* sizeof(cobs_gpu_build_params) */
+    uint32_t term_size;          /* ClassicIndexParameters::term_size, default 31 */
+    uint32_t canonicalize;       /* 1 */
+    uint32_t num_hashes;         /* 1 */
+    double false_positive_rate;  /* 0.3 */
+    uint64_t signature_size;     /* 0 = calc_signature_size(largest document, num_hashes, fpr) */
+    uint64_t page_size;          /* compact: 0 = reference heuristic (compact_index.cpp:184-189) */
+    int32_t device;              /* -1 = current */
+    uint32_t reserved;
+} cobs_gpu_build_params;
+
+/* classic_construct (construction/classic_index.cpp:565-659) for documents that are already
+ * parsed: texts[d] holds the sequences of document d joined by '\n' (terms do not span a
+ * separator), names[d] its name; documents are written in the given order.  Term hashing and
+ * bit setting run on the GPU; the file is byte-for-byte what the reference writes. */
+cobs_gpu_status cobs_gpu_build_classic(const char* const* names, const char* const* texts,
+                                       const size_t* lens, size_t ndocs,
+                                       const cobs_gpu_build_params* params, const char* out_path);
+/* compact_construct (construction/compact_index.cpp:171-340): the documents must already be in
+ * their final order (sorted by size, by path inside every group of 8*page_size); each group
+ * becomes one sub-index with its own signature size. */
+cobs_gpu_status cobs_gpu_build_compact(const char* const* names, const char* const* texts,
+                                       const size_t* lens, size_t ndocs,
+                                       const cobs_gpu_build_params* params, const char* out_path);
+
 /* ---- search (host buffers in, host buffers out) ------------------------ */
 /* ClassicSearch::search (classic_search.cpp:403-505): hits ordered by score
  * descending, ties by (file_no, doc) ascending; no ordering when the query has a

@@ -1,0 +1,93 @@
+"""GPU index construction: files written by cobs_gpu_build_* are
+byte-identical to the golden fixtures / to the numpy construction restatement, and the
+reference's own Python test (python/tests/test_cobs_index.py) passes against the mirror."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+Q50 = "AGTCAACGCTAAGGCATTTCCCCCCTGCCTCCTGCCTGCTGCCAAGCCCT"
+
+
+def test_reference_python_test_flow(gpu_lib, golden_dir, tmp_path):
+    """python/tests/test_cobs_index.py:13-61 with `import cobs_amd as cobs`"""
+    cobs = gpu_lib
+    datadir = os.path.join(golden_dir, "fasta")
+    cobs.disable_cache()
+    l1 = cobs.DocumentList(datadir)
+    assert l1.size() == 7
+    l2 = cobs.DocumentList()
+    l2.add_recursive(datadir)
+    assert l2.size() == 7
+    index_file = str(tmp_path / "python_test.cobs_classic")
+    p = cobs.ClassicIndexParameters()
+    p.clobber = True
+    cobs.classic_construct(input=datadir, out_file=index_file, index_params=p)
+    assert os.path.isfile(index_file)
+    r = cobs.Search(index_file).search(Q50)
+    assert len(r) == 7 and r[0].doc_name == "sample1" and r[0].score == 20
+    index_file = str(tmp_path / "python_test.cobs_compact")
+    p = cobs.CompactIndexParameters()
+    p.clobber = True
+    cobs.compact_construct(input=datadir, out_file=index_file, index_params=p)
+    r = cobs.Search(index_file).search(Q50)
+    assert len(r) == 7 and r[0].doc_name == "sample1" and r[0].score == 20
+
+
+def test_files_equal_golden_fixtures(gpu_lib, golden_dir, tmp_path):
+    for name, fn, params in (("c1.cobs_classic", gpu_lib.classic_construct, gpu_lib.ClassicIndexParameters()),
+                             ("c1.cobs_compact", gpu_lib.compact_construct, gpu_lib.CompactIndexParameters())):
+        out = str(tmp_path / name)
+        fn(input=os.path.join(golden_dir, "fasta"), out_file=out, index_params=params)
+        assert open(out, "rb").read() == open(os.path.join(golden_dir, name), "rb").read(), name
+
+
+def _random_docs(oracle, n, seed):
+    rng = np.random.default_rng(seed)
+    docs = []
+    for d in range(n):
+        seqs = []
+        for s in range(int(rng.integers(1, 4))):
+            q = bytearray(oracle.random_sequence(int(rng.integers(5, 400)), seed * 1000 + d * 10 + s))
+            if rng.random() < 0.3 and len(q) > 40:
+                q[int(rng.integers(0, len(q)))] = ord("N")           # invalid base inside a document
+            seqs.append(bytes(q))
+        docs.append(("doc_%04d" % d, seqs))
+    return docs
+
+
+@pytest.mark.parametrize("canonicalize,num_hashes,k", [(1, 1, 31), (1, 3, 31), (0, 2, 31), (1, 2, 20), (0, 1, 40)])
+def test_in_memory_documents_vs_restatement(gpu_lib, oracle, construct, tmp_path, canonicalize, num_hashes, k):
+    docs = _random_docs(oracle, 75, 7 + k)
+    dl = gpu_lib.DocumentList()
+    kdocs = []
+    for name, seqs in docs:
+        dl.add_document(name, seqs)
+        hs = [oracle.term_hashes(s, k, canonicalize, num_hashes)[0] for s in seqs if len(s) >= k]
+        hashes = np.concatenate(hs) if hs else np.zeros((0, num_hashes), dtype=np.uint64)
+        text_len = len(b"\n".join(seqs)) + 1
+        kdocs.append(construct.Doc(name, name, text_len, sum(max(len(s) - k + 1, 0) for s in seqs), hashes))
+    pc = gpu_lib.ClassicIndexParameters()
+    pc.term_size, pc.canonicalize, pc.num_hashes, pc.false_positive_rate = k, canonicalize, num_hashes, 0.1
+    got, want = str(tmp_path / "g.cobs_classic"), str(tmp_path / "w.cobs_classic")
+    gpu_lib.classic_construct(list=dl, out_file=got, index_params=pc)
+    construct.classic_construct(kdocs, want, term_size=k, canonicalize=canonicalize, num_hashes=num_hashes,
+                                false_positive_rate=0.1)
+    assert open(got, "rb").read() == open(want, "rb").read()
+    pk = gpu_lib.CompactIndexParameters()
+    pk.term_size, pk.canonicalize, pk.num_hashes, pk.false_positive_rate, pk.page_size = k, canonicalize, num_hashes, 0.1, 2
+    got, want = str(tmp_path / "g.cobs_compact"), str(tmp_path / "w.cobs_compact")
+    gpu_lib.compact_construct(list=dl, out_file=got, index_params=pk)
+    construct.compact_construct(kdocs, want, term_size=k, canonicalize=canonicalize, num_hashes=num_hashes,
+                                false_positive_rate=0.1, page_size=2)
+    assert open(got, "rb").read() == open(want, "rb").read()
+    # and the built index answers like the oracle
+    s = gpu_lib.Search(got)
+    ix = oracle.Index.open(got)
+    q = docs[3][1][0] if len(docs[3][1][0]) >= k and b"N" not in docs[3][1][0] else oracle.random_sequence(100, 1)
+    if canonicalize == 0 or b"N" not in q:
+        assert np.array_equal(s.counts(q), ix.counts(q))
