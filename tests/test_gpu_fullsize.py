@@ -86,3 +86,33 @@ def test_full_size_config(gpu_lib, oracle, name):
     order = sorted([(int(sc), d) for d, sc in enumerate(c0[:cfg["num_docs"]]) if sc >= thr],
                    key=lambda x: (-x[0], x[1]))[:50]
     assert [(sc, d) for (_, d, sc) in hits] == order
+
+
+def test_large_files_cross_staging_boundaries(gpu_lib, oracle, construct, tmp_path):
+    """file-backed indexes big enough to cross the 64 MiB re-pitch chunks and the 1 GiB
+    straight-copy steps of the upload path"""
+    rng = np.random.default_rng(5)
+
+    def random_rows(rows, width):
+        raw = rng.integers(0, 2 ** 63, size=(rows * width + 7) // 8, dtype=np.int64)
+        a = raw & rng.integers(0, 2 ** 63, size=raw.shape, dtype=np.int64)       # density 0.25
+        return a.view(np.uint8)[:rows * width].reshape(rows, width)
+
+    queries = [oracle.random_sequence(1030, 60 + i) for i in range(3)]
+    # classic: 10 000 docs -> 1250-byte rows (re-pitched to 1280), 230 MB
+    D, S = 10000, 184321
+    pc = str(tmp_path / "big.cobs_classic")
+    construct.write_classic(pc, 31, 1, ["d%05d" % i for i in range(D)], S, 1, random_rows(S, 1250))
+    # compact: 512-byte pages (copied straight), 1.28 GB -> crosses the 1 GiB copy step
+    ps, sigs = 512, [1300003, 1200007]
+    pk = str(tmp_path / "big.cobs_compact")
+    mats = [random_rows(s, ps) for s in sigs]
+    construct.write_compact(pk, 31, 1, ps, [(s, 1) for s in sigs], ["d%05d" % i for i in range(2 * 8 * ps)], mats)
+    for p in (pc, pk):
+        s = gpu_lib.Search(p)
+        ix = oracle.Index.open(p)
+        for q in queries:
+            assert np.array_equal(s.counts(q), ix.counts(q))
+        assert s.search_hits(queries, 0.26, 20) == [
+            [(f, d, sc) for (f, d, _n, sc) in oracle.search(ix, q, 0.26, 20)] for q in queries]
+        del s
