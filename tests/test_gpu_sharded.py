@@ -1,0 +1,63 @@
+"""GPU: the sharded engine end to end -- several processes (all on GPU 0, gloo for the exchange;
+on a multi-GPU node the same code runs one rank per GPU over RCCL) each stage and scan their
+sub-index block, exchange count slices / hit lists, and every rank gets the oracle's result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, paths, queries, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cobs_amd.distributed import ShardedSearch
+        from oracle import oracle as O
+        ixs = [O.Index.open(p) for p in paths]
+        ss = ShardedSearch(paths if len(paths) > 1 else paths[0], device=0)
+        assert ss.search_local.info(0).slot_count < ixs[0].counts_size or world == 1
+        got = ss.counts(queries).cpu().numpy().astype(np.int64) & 0xFFFF
+        want = np.stack([np.concatenate([ix.counts(q) for ix in ixs]) for q in queries])
+        assert np.array_equal(got, want)
+        for t, lim in ((0.0, 0), (0.3, 0), (0.3, 4), (0.0, 6), (0.95, 0)):
+            res = ss.search_hits(queries, t, lim)
+            for q, r in zip(queries, res):
+                assert [tuple(x) for x in r] == cases.oracle_results(ixs, q, t, lim), (t, lim)
+        r = ss.search(queries[0].decode(), 0.3, 2)
+        assert [(x.doc_name, x.score) for x in r] == [(n, s) for (_, _, n, s) in O.search(ixs, queries[0], 0.3, 2)]
+        open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_search_processes(gpu_lib, oracle, tmp_path, world):
+    q_long = oracle.random_sequence(500, 17)
+    planted = {5: 1.0, 700: 0.9, 1500: 0.6, 2300: 0.97}
+    pa = cases.make_compact(cases.tmp(tmp_path, "s.cobs_compact"), 2400, 64, [900, 1000, 1100, 1200, 1300], 1, 31, 1,
+                            0.3, 3, planted=planted, query=q_long)
+    pb = cases.make_classic(cases.tmp(tmp_path, "s.cobs_classic"), 1000, 1501, 2, 31, 1, 0.3, 4,
+                            planted={9: 1.0, 990: 0.8}, query=q_long)
+    queries = [q_long, q_long[:31], q_long[:250], q_long[100:340]]
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, [pa, pb], queries, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert os.path.exists(os.path.join(str(tmp_path), "ok%d" % r))
