@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""scripts/latency.py -- small-batch behaviour of the host API on the C3 index."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+import cobs_amd  # noqa: E402
+
+cfg = bench.c3_config()
+s = cobs_amd.Search.synthetic("compact", cfg["signature_sizes"], cfg["num_docs"], page_size=cfg["page_size"], seed=1)
+qs = bench.make_queries(4096, 1000)
+b = cobs_amd.Batch(s)
+for n in (1, 4, 16, 64, 256, 1024, 4096):
+    b.set_queries(qs[:n])
+    for _ in range(3):
+        b.run_topk(0.0, 10)
+    b.sync()
+    b.kernel_ms()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 20
+    for _ in range(reps):
+        b.run_topk(0.0, 10)
+    torch.cuda.synchronize()
+    dev = (time.perf_counter() - t0) / reps
+    b.sync()
+    ms = b.kernel_ms()
+    # host API: text H2D + K1 + K2 + K3 + D2H of the top-10 + ordering
+    s.search_hits(qs[:n], 0.0, 10)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        s.search_hits(qs[:n], 0.0, 10)
+    host = (time.perf_counter() - t0) / 5
+    print("nq=%5d  device pass %8.3f ms (scan %7.3f hash %6.3f)  %9.0f q/s   host API top-10 %8.3f ms  %9.0f q/s"
+          % (n, dev * 1e3, ms["scan_ms"], ms["hash_ms"], n / dev, host * 1e3, n / host), flush=True)
