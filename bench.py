@@ -180,6 +180,8 @@ def main():
     ap.add_argument("--num-results", type=int, default=0,
                     help="k > 0: the step also selects the k best documents per query on the device (K3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange-chunks", type=int, default=4,
+                    help="--shard-mode index: sub-batches whose all-gather overlaps the next scan")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real multi-GPU runs; gloo only "
                     "for smoke-testing the launch path with several ranks on one GPU")
     args = ap.parse_args()
@@ -217,25 +219,43 @@ def main():
     batch = cobs_amd.Batch(s)
     batch.set_queries(mine)                    # H2D once; inputs now resident in HBM
 
-    gathered = None
+    sub, gathered = [], []
     if shard_index:
-        # RCCL has no 16-bit integer type: the u16 count slices travel as bytes
-        local = batch.counts_tensor().view(torch.uint8).reshape(-1)
-        gathered = torch.empty((world * local.numel(),), dtype=torch.uint8, device="cuda")
+        # The batch is cut into sub-batches so that the all-gather of sub-batch i (RCCL's own
+        # stream, xGMI) overlaps the scan of sub-batch i+1 (the stream the kernels are on).
+        # RCCL has no 16-bit integer type: the u16 count slices travel as bytes.
+        nsub = max(1, min(args.exchange_chunks, len(mine)))
+        for i in range(nsub):
+            bi = cobs_amd.Batch(s)
+            bi.set_queries(mine[i * len(mine) // nsub:(i + 1) * len(mine) // nsub])
+            sub.append(bi)
+            local = bi.counts_tensor().view(torch.uint8).reshape(-1)
+            gathered.append(torch.empty((world * local.numel(),), dtype=torch.uint8, device="cuda"))
 
     def step():
-        if args.num_results > 0:
-            batch.run_topk(args.threshold, args.num_results, 0)
-        else:
-            batch.run(args.threshold, 0)
-        if shard_index:
-            # per-document hit counts of the disjoint sub-index blocks -> every rank (all-gather over xGMI)
-            dist.all_gather_into_tensor(gathered, batch.counts_tensor().view(torch.uint8).reshape(-1))
+        if not shard_index:
+            if args.num_results > 0:
+                batch.run_topk(args.threshold, args.num_results, 0)
+            else:
+                batch.run(args.threshold, 0)
+            return
+        works = []
+        for bi, out in zip(sub, gathered):
+            bi.run(args.threshold, 0)
+            # per-document hit counts of the disjoint sub-index blocks -> every rank
+            works.append(dist.all_gather_into_tensor(out, bi.counts_tensor().view(torch.uint8).reshape(-1),
+                                                     async_op=True))
+        for w in works:
+            w.wait()
 
     for _ in range(args.warmup):
         step()
-    batch.sync()
-    batch.kernel_ms()                          # drop warm-up events
+    if not shard_index:
+        batch.sync()
+        batch.kernel_ms()                      # drop warm-up events
+    for bi in sub:
+        bi.sync()
+        bi.kernel_ms()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -250,9 +270,16 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    batch.sync()                               # also raises on invalid bases
-    ms = batch.kernel_ms()                     # HIP events on the launch stream, averaged over the timed steps
-    st = batch.stats()
+    if shard_index:
+        for bi in sub:
+            bi.sync()
+        parts = [bi.kernel_ms() for bi in sub]  # one launch per sub-batch: a step's scan time is their sum
+        ms = {"scan_ms": sum(p["scan_ms"] for p in parts), "hash_ms": sum(p["hash_ms"] for p in parts)}
+        st = {"algorithmic_bytes": sum(bi.stats()["algorithmic_bytes"] for bi in sub)}
+    else:
+        batch.sync()                           # also raises on invalid bases
+        ms = batch.kernel_ms()                 # HIP events on the launch stream, averaged over the timed steps
+        st = batch.stats()
 
     # whole job: replicated index -> N independent batches; sharded index -> one batch on all ranks
     total_queries = args.queries * (world if not shard_index else 1)
