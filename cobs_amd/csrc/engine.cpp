@@ -272,42 +272,62 @@ uint64_t slice_bytes(uint64_t sig, uint64_t ncols) {
     return round_up((sig + 1) * (uint64_t)pitch_for(ncols), 256);     // +1: the all-zero row
 }
 
-// Tile width of a scan launch (16-byte column chunks per tile: 64, 32, 16, 8 or 4).
-// With W < 64 one wave-load fetches 64/W different rows, and a tile of one
-// sub-index is signature_size x W*16 bytes.  All queries of a batch work on the
-// same tile before the grid moves on (tile-major order), so narrow tiles turn the
-// repeated lookups of a batch into Infinity-Cache hits, and W = 8 makes every row
-// slice exactly one 128-byte line.  Measured on MI355X (10k x 1000-k-mer queries):
-// W = 8 beats W = 64 on every wide shape (C3 -10 % scan time, C4 512-byte pages
-// 85.7 -> 94.5 % of HBM peak, 30 M-row sub-indexes that cannot be cached +3 %);
-// W = 4 (64-byte slices) halves throughput.  Narrow tiles multiply the number of
-// lane groups that split a query's 8-term blocks, so short queries keep wide
-// tiles: every lane group should get about three blocks.  Indexes narrower than a
-// wave get the smallest tile that covers them so that no lanes idle.
-// Tuning hook: COBS_GPU_TILE_W forces one width.
-uint32_t tile_width_for(const Chunk& c, uint64_t mean_blocks, uint64_t num_hashes, int nwaves) {
-    if (const char* e = getenv("COBS_GPU_TILE_W")) {
-        const int v = atoi(e);
-        if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) return (uint32_t)v;
+// Geometry of a scan launch: tile width W (16-byte column chunks per tile: 64, 32, 16, 8 or 4)
+// and waves per work-group NW (1, 2 or 4).  A query's 8-term blocks are split over
+// NV = NW * (64 / W) "virtual waves" (lane groups).
+// * Narrow tiles: with W < 64 one wave-load fetches 64/W different rows, and a tile of one
+//   sub-index is signature_size x W*16 bytes.  All queries of a batch work on the same tile
+//   before the grid moves on (tile-major order), so narrow tiles turn the repeated lookups of
+//   a batch into Infinity-Cache hits, and W = 8 makes every row slice exactly one 128-byte
+//   line.  Interleaved A/B on MI355X, 10k x 1000-k-mer queries: W = 8 vs 64: C3 -7 % scan
+//   time, 512-byte pages -9 %, 128-byte pages -12 %, 30 M-row sub-indexes that cannot be
+//   cached -3 %; W = 4 (64-byte slices) halves throughput.
+// * Every virtual wave should keep about two to four blocks (merging and expansion cost per
+//   tile is fixed): NV = largest power of two <= blocks / 1.75, at most 32.  Measured optimum
+//   for 100/150/250-bp reads (9/15/28 blocks): (NW 2, W 32), (NW 2, W 16), (NW 2, W 8).
+// * Indexes narrower than a wave get the smallest tile that covers them (no idle lanes).
+// Tuning hooks: COBS_GPU_TILE_W, COBS_GPU_WAVES force a value.
+struct ScanGeom { uint32_t tile_w; int nwaves; };
+
+ScanGeom scan_geometry(const Chunk& c, uint64_t mean_blocks, uint64_t num_hashes, uint32_t forced_waves) {
+    uint32_t nv = 1;
+    while (nv < 32 && (uint64_t)nv * 2 * 7 <= mean_blocks * 4) nv <<= 1;     // blocks / NV >= 1.75
+    ScanGeom g;
+    if (nv >= 16) { g.nwaves = (int)(nv / 8); g.tile_w = 8; }
+    else if (nv == 8) {
+        if (mean_blocks >= 24) { g.nwaves = 1; g.tile_w = 8; }
+        else { g.nwaves = 2; g.tile_w = 16; }
     }
-    uint32_t groups = 1;                       // lane groups per wave the queries can feed
-    while (groups < 8 && (uint64_t)groups * 2 * nwaves * 3 <= mean_blocks) groups <<= 1;
-    uint32_t w = 64 / groups;
-    if (num_hashes > 1 && w < 16) w = 16;      // generic-H kernel: 16 measured best
-    if (w < 16) {
+    else if (nv == 4) { g.nwaves = 2; g.tile_w = 32; }
+    else if (nv == 2) { g.nwaves = 2; g.tile_w = 64; }
+    else { g.nwaves = 1; g.tile_w = 64; }
+    if (num_hashes > 1 && g.tile_w < 16) {     // generic-H kernel: 16 measured best
+        g.tile_w = 16;
+        g.nwaves = std::min(4, g.nwaves * 2);
+    }
+    if (g.tile_w < 16) {
         // when even the largest sub-index fits the Infinity Cache with 256-byte slices, 16-chunk
         // tiles win (half the merge/expand work; C2: 7.3 vs 6.8 TB/s); otherwise 128-byte slices
         uint64_t max_sig = 0;
         for (const PageDev& pd : c.pages) max_sig = std::max<uint64_t>(max_sig, pd.sig);
-        if (max_sig * 256ull <= (256ull << 20)) w = 16;
+        if (max_sig * 256ull <= (256ull << 20) && g.nwaves >= 2) { g.tile_w = 16; }
     }
-    if (c.total_chunks < w) {                  // index narrower than the tile
+    if (forced_waves) g.nwaves = (int)forced_waves;
+    if (const char* e = getenv("COBS_GPU_WAVES")) {
+        const int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4) g.nwaves = v;
+    }
+    if (c.total_chunks < g.tile_w) {           // index narrower than the tile
         uint32_t cover = 4;
         while (cover < c.total_chunks) cover <<= 1;
-        w = std::max<uint32_t>(cover, 64 / groups);
-        if (w > 64) w = 64;
+        g.tile_w = std::min<uint32_t>(g.tile_w, std::max<uint32_t>(cover, 8));
+        if (c.total_chunks <= 4) g.tile_w = 4;
     }
-    return w;
+    if (const char* e = getenv("COBS_GPU_TILE_W")) {
+        const int v = atoi(e);
+        if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) g.tile_w = (uint32_t)v;
+    }
+    return g;
 }
 
 // fill pages / geometry of a chunk whose slices (equal ncols) are already listed
@@ -1043,15 +1063,9 @@ static cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk
             sa.num_docs = (uint32_t)p.meta.doc_names.size();
             sa.part = (uint32_t)f;
             sa.write_counts = 1;
-            const uint64_t mean_blocks = b->work[f].h_blk_off[nq] / nq;
-            // waves that split one query's blocks: short queries get fewer (less merging, more groups per CU)
-            int nwaves = mean_blocks <= 4 ? 1 : mean_blocks <= 16 ? 2 : 4;
-            if (ix->waves_per_group) nwaves = (int)ix->waves_per_group;
-            if (const char* e = getenv("COBS_GPU_WAVES")) {     // tuning hook
-                const int v = atoi(e);
-                if (v == 1 || v == 2 || v == 4) nwaves = v;
-            }
-            sa.tile_w = tile_width_for(c, mean_blocks, p.meta.num_hashes, nwaves);
+            const ScanGeom geom = scan_geometry(c, b->work[f].h_blk_off[nq] / nq, p.meta.num_hashes, ix->waves_per_group);
+            const int nwaves = geom.nwaves;
+            sa.tile_w = geom.tile_w;
             sa.chunk_begin = 0;
             sa.chunk_end = c.total_chunks;
             // one launch covers at most 2^31-1 work-groups

@@ -19,6 +19,9 @@ def main():
         cfg, nq, kmers = bench.c3_config(), 10000, 1000
     elif shape == "c3short":
         cfg, nq, kmers = bench.c3_config(), 20000, 100
+    elif shape.startswith("reads"):
+        bp = int(shape[5:])
+        cfg, nq, kmers = bench.c3_config(), 40000, bp - 30
     elif shape == "c2":
         cfg, nq, kmers = bench.c2_config(), 10000, 1000
     elif shape == "c4":

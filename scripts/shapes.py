@@ -69,3 +69,6 @@ if __name__ == "__main__":
     if on("huge"):
         run("compact 25k docs ps1568 P2 S=30M Q2k", "compact", [30000000, 30000000], 25000, 1568, 2000, 1000)
         run("compact 100k docs ps512 P25 S=6M Q2k", "compact", [6000000] * 25, 100000, 512, 2000, 1000)
+    if on("reads"):
+        for bp in (100, 150, 250):
+            run("C3 %d-bp reads Q40k" % bp, "compact", bench.c3_config()["signature_sizes"], 100000, 1568, 40000, bp - 30)
