@@ -133,8 +133,11 @@ class Search:
         """Same contract as cobs_index.Search.search (python/module.cpp:372-386)."""
         return self.search_batch([query], threshold, num_results)[0]
 
-    def search_hits(self, queries, threshold=0.0, num_results=0):
-        """-> per query: list of (file_no, doc, score) in result order."""
+    HIT_DTYPE = np.dtype([("file_no", "<u4"), ("doc", "<u4"), ("score", "<u4")])
+
+    def search_arrays(self, queries, threshold=0.0, num_results=0):
+        """-> (offsets uint64 [nq + 1], hits structured array of (file_no, doc, score)):
+        the hits of query i are hits[offsets[i]:offsets[i + 1]], in result order."""
         qs = [_as_bytes(q) for q in queries]
         nq = len(qs)
         arr = (C.c_char_p * max(nq, 1))(*qs)
@@ -146,19 +149,26 @@ class Search:
         else:
             cap = 16 * nq + 1024                  # grown on demand (ERR_CAPACITY reports the size)
         cap = max(1, cap)
-        offs = (C.c_size_t * (nq + 1))()
+        offs = np.zeros(nq + 1, dtype=np.uint64)
         bad = C.c_size_t(0)
         while True:
-            hits = (Hit * cap)()
-            st = self._lib.cobs_gpu_search_batch(self._h, arr, lens, nq, float(threshold),
-                                                 int(num_results), hits, cap, offs, C.byref(bad))
-            if st == _capi.ERR_CAPACITY and offs[nq] > cap:
+            hits = np.empty(cap, dtype=self.HIT_DTYPE)
+            st = self._lib.cobs_gpu_search_batch(
+                self._h, arr, lens, nq, float(threshold), int(num_results),
+                C.cast(hits.ctypes.data, C.POINTER(Hit)), cap,
+                C.cast(offs.ctypes.data, C.POINTER(C.c_size_t)), C.byref(bad))
+            if st == _capi.ERR_CAPACITY and int(offs[nq]) > cap:
                 cap = int(offs[nq])
                 continue
             check(st)
             break
-        return [[(hits[i].file_no, hits[i].doc, hits[i].score) for i in range(offs[q], offs[q + 1])]
-                for q in range(nq)]
+        return offs, hits[:int(offs[nq])]
+
+    def search_hits(self, queries, threshold=0.0, num_results=0):
+        """-> per query: list of (file_no, doc, score) in result order."""
+        offs, hits = self.search_arrays(queries, threshold, num_results)
+        rows = hits.tolist()
+        return [rows[int(offs[q]):int(offs[q + 1])] for q in range(len(queries))]
 
     def search_batch(self, queries, threshold=0.0, num_results=0):
         out = []
