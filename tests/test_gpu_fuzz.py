@@ -1,0 +1,64 @@
+"""GPU: randomised geometry sweep (fixed seeds) against the oracle -- random document counts,
+page sizes, sub-index counts, signature sizes, hash counts, k, canonicalisation, ragged query
+batches, thresholds and limits, under every tile width / wave count of the scan kernel."""
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_case(rng, oracle, tmp_path, idx):
+    k = int(rng.choice([15, 21, 31, 31, 31, 33]))
+    H = int(rng.choice([1, 1, 2, 3]))
+    canon = int(rng.integers(0, 2))
+    qlen = int(rng.choice([k, k + 7, 100, 300, 1030, 2100]))
+    q_long = oracle.random_sequence(max(qlen, 400) + 50, 1000 + idx)
+    if rng.random() < 0.5:
+        D = int(rng.integers(1, 3000))
+        S = int(rng.integers(50, 4000))
+        planted = {int(d): float(rng.random()) for d in rng.integers(0, D, size=min(D, 6))}
+        path = cases.make_classic(cases.tmp(tmp_path, "f%d.cobs_classic" % idx), D, S, H, k, canon, 0.3, idx,
+                                  planted=planted, query=q_long[:qlen])
+    else:
+        ps = int(rng.choice([1, 2, 4, 8, 16, 24, 40, 64, 128, 136, 256]))   # what the reference's batching accepts (App. A)
+        P = int(rng.integers(1, 7))
+        D = (P - 1) * 8 * ps + int(rng.integers(1, 8 * ps + 1))
+        sigs = [int(x) for x in rng.integers(40, 3000, size=P)]
+        planted = {int(d): float(rng.random()) for d in rng.integers(0, D, size=min(D, 6))}
+        path = cases.make_compact(cases.tmp(tmp_path, "f%d.cobs_compact" % idx), D, ps, sigs, H, k, canon, 0.3, idx,
+                                  planted=planted, query=q_long[:qlen])
+    nq = int(rng.integers(1, 6))
+    queries = []
+    for _ in range(nq):
+        ln = int(rng.integers(k, len(q_long)))
+        st = int(rng.integers(0, len(q_long) - ln + 1))
+        queries.append(q_long[st:st + ln])
+    queries.append(q_long[:qlen])
+    return path, queries
+
+
+@pytest.mark.parametrize("tile_w,waves", [(None, None), ("4", "1"), ("8", "4"), ("16", "2"), ("32", "1"), ("64", "4"),
+                                          ("8", "1"), ("64", "2")])
+def test_random_geometries(gpu_lib, oracle, tmp_path, monkeypatch, tile_w, waves):
+    if tile_w:
+        monkeypatch.setenv("COBS_GPU_TILE_W", tile_w)
+        monkeypatch.setenv("COBS_GPU_WAVES", waves)
+    rng = np.random.default_rng(20260928 + (int(tile_w) if tile_w else 0) + (int(waves) if waves else 0))
+    for idx in range(40):
+        path, queries = _random_case(rng, oracle, tmp_path, idx)
+        ix = oracle.Index.open(path)
+        s = gpu_lib.Search(path)
+        b = gpu_lib.Batch(s)
+        b.set_queries(queries)
+        t = float(rng.choice([0.0, 0.0, 0.25, 0.5, 0.9]))
+        lim = int(rng.choice([0, 0, 1, 3, 50]))
+        if lim:
+            b.run_topk(t, lim)
+        else:
+            b.run(t)
+        b.sync()
+        for i, q in enumerate(queries):
+            assert np.array_equal(b.counts_host(i), ix.counts(q)), (path, i, len(q))
+            assert b.hits_host(i, lim) == cases.oracle_results([ix], q, t, lim), (path, i, t, lim)
