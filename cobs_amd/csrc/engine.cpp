@@ -199,6 +199,7 @@ struct cobs_gpu_batch {
     DevBuf<uint8_t> counts;
     uint32_t elem_bytes = 2;
     int planes = 0;
+    uint64_t max_terms = 0;              // longest query of the batch, in terms
     DevBuf<HitDev> hits;
     DevBuf<uint2> topk_out;           // K3 output [file][query][k]
     DevBuf<uint32_t> topk_cnt;        // [file][query]
@@ -287,9 +288,10 @@ uint64_t slice_bytes(uint64_t sig, uint64_t ncols) {
 //   for 100/150/250-bp reads (9/15/28 blocks): (NW 2, W 32), (NW 2, W 16), (NW 2, W 8).
 // * Indexes narrower than a wave get the smallest tile that covers them (no idle lanes).
 // Tuning hooks: COBS_GPU_TILE_W, COBS_GPU_WAVES force a value.
-struct ScanGeom { uint32_t tile_w; int nwaves; };
+struct ScanGeom { uint32_t tile_w; int nwaves; bool multi_query; };
 
-ScanGeom scan_geometry(const Chunk& c, uint64_t mean_blocks, uint64_t num_hashes, uint32_t forced_waves) {
+ScanGeom scan_geometry(const Chunk& c, uint64_t mean_blocks, uint64_t max_blocks, uint64_t num_hashes,
+                       uint32_t forced_waves, int planes) {
     uint32_t nv = 1;
     while (nv < 32 && (uint64_t)nv * 2 * 7 <= mean_blocks * 4) nv <<= 1;     // blocks / NV >= 1.75
     ScanGeom g;
@@ -327,6 +329,29 @@ ScanGeom scan_geometry(const Chunk& c, uint64_t mean_blocks, uint64_t num_hashes
         const int v = atoi(e);
         if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) g.tile_w = (uint32_t)v;
     }
+    // Very short queries (<= 10 blocks: reads up to ~110 bp): the lane groups of a wave serve 8
+    // different queries instead of splitting one query's few blocks.  Interleaved A/B on the C3
+    // index: 50-bp reads -7.4 % scan time with (W 8, NW 2), 100-bp reads -4 % with (W 8, NW 1);
+    // from 150 bp on the one-query geometry above is faster (+2.4 %, 250 bp: equal, C3: +1.5 %).
+    g.multi_query = false;
+    int mq_env = -1;                           // tuning hook: COBS_GPU_MQ=0/1 forces the variant
+    if (const char* e = getenv("COBS_GPU_MQ")) mq_env = atoi(e) != 0;
+    if (mq_env != 0 && forced_waves == 0 && mean_blocks <= 10 && max_blocks <= 20 && c.total_chunks >= 8 &&
+        scan_has_multi_query(planes, (uint32_t)num_hashes, 8)) {
+        g.multi_query = true;
+        g.tile_w = 8;
+        g.nwaves = mean_blocks <= 5 ? 2 : 1;
+        if (const char* e = getenv("COBS_GPU_WAVES")) {
+            const int v = atoi(e);
+            if (v == 1 || v == 2 || v == 4) g.nwaves = v;
+        }
+        if (const char* e = getenv("COBS_GPU_TILE_W")) {
+            const int v = atoi(e);
+            if (v == 4 || v == 8 || v == 16 || v == 32) g.tile_w = (uint32_t)v;
+        }
+    }
+    if (mq_env == 1) g.multi_query = true;
+    if (g.multi_query && !scan_has_multi_query(planes, (uint32_t)num_hashes, g.tile_w)) g.multi_query = false;
     return g;
 }
 
@@ -905,6 +930,7 @@ cobs_gpu_status cobs_gpu_batch_set_queries(cobs_gpu_batch* b, const char* const*
     const int planes = scan_planes_for(max_terms);
     if (planes < 0) return fail(COBS_GPU_ERR_QUERY_TOO_LONG, "query too long");
     b->planes = planes;
+    b->max_terms = max_terms;
     b->elem_bytes = scan_score_bytes(planes);
 
     // thread spans of K1: every character and every (padded) term of every file
@@ -1063,7 +1089,8 @@ static cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk
             sa.num_docs = (uint32_t)p.meta.doc_names.size();
             sa.part = (uint32_t)f;
             sa.write_counts = 1;
-            const ScanGeom geom = scan_geometry(c, b->work[f].h_blk_off[nq] / nq, p.meta.num_hashes, ix->waves_per_group);
+            const ScanGeom geom = scan_geometry(c, b->work[f].h_blk_off[nq] / nq, (b->max_terms + 7) / 8,
+                                                 p.meta.num_hashes, ix->waves_per_group, b->planes);
             const int nwaves = geom.nwaves;
             sa.tile_w = geom.tile_w;
             sa.chunk_begin = 0;
@@ -1072,7 +1099,7 @@ static cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk
             const uint32_t ntiles = (c.total_chunks + sa.tile_w - 1) / sa.tile_w;
             if ((uint64_t)ntiles * nq > 0x7FFFFFFFull)
                 return fail(COBS_GPU_ERR_CAPACITY, "batch too large for one scan launch; use fewer queries");
-            HIP_TRY(launch_scan(sa, ntiles, b->planes, nwaves, st));
+            HIP_TRY(launch_scan(sa, ntiles, b->planes, nwaves, geom.multi_query, st));
             ++launches;
             if (p.streamed) {
                 HIP_TRY(hipEventRecord(p.scanned[buf], st));

@@ -412,7 +412,12 @@ __device__ __forceinline__ void and_rows(uint4 (&X)[8], const uint4 (&Y)[8]) {
     }
 }
 
-template <int NP, int NW, bool H1, typename OutT>
+// MQ ("multi-query", short queries): the G = 64 / W lane groups of a wave belong to G
+// DIFFERENT queries (q = qi*G + grp) instead of splitting one query's blocks.  Every lane
+// group then walks all blocks of its own query (divided over the NW waves only): G times
+// more trips per wave, so the load pipeline reaches its steady state even for 100-bp reads,
+// and the cross-lane merge disappears.
+template <int NP, int NW, bool H1, typename OutT, bool MQ>
 __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     // row loads stay temporal: non-temporal loads measured 18 % slower (they bypass the Infinity Cache)
     constexpr bool NT = false;
@@ -442,9 +447,14 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     const uint32_t ntiles = (a.chunk_end - a.chunk_begin + W - 1u) / W;
     (void)ntiles;
     // tile-major order: co-resident groups read the same sub-index columns (query-major: 13 % slower)
-    const uint32_t tile = blockIdx.x / a.nq;
-    const uint32_t q = blockIdx.x - tile * a.nq;
+    const uint32_t nqg = MQ ? (a.nq + G - 1u) / G : a.nq;         // query groups per tile
+    const uint32_t tile = blockIdx.x / nqg;
+    const uint32_t qi = blockIdx.x - tile * nqg;
     const uint32_t grp = lane / W, col = lane & (W - 1u);
+    // MQ: per-lane query (groups past the end of the batch idle on the padding block)
+    const uint32_t qraw = MQ ? qi * G + grp : qi;
+    const bool qlive = qraw < a.nq;
+    const uint32_t q = qlive ? qraw : a.nq - 1u;
     const uint32_t g = a.chunk_begin + tile * W + col;
     const uint32_t gc = g < a.chunk_end ? g : a.chunk_end - 1u;     // dead lanes duplicate a live one
     const uint32_t pg = gc / a.cpp;
@@ -453,16 +463,17 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     const uint32_t pitch = a.pitch;
 
     const uint64_t b0 = a.blk_off[q];
-    const uint32_t nblk = (uint32_t)(a.blk_off[q + 1] - b0);
+    const uint32_t nblk_q = (uint32_t)(a.blk_off[q + 1] - b0);   // table stride of query q
+    const uint32_t nblk = qlive ? nblk_q : 0u;
     const uint32_t H = H1 ? 1u : a.num_hashes;
     // row indices of this lane's sub-index: [nblk + 1 blocks][hash][8]; block nblk is all padding
-    const uint32_t* tab = a.table + ((b0 + q) * a.npages + (uint64_t)pg * (nblk + 1u)) * (8ull * H);
-    const uint32_t vw = wave * G + grp;              // virtual wave of this lane
-    const uint32_t NV = NW * G;
+    const uint32_t* tab = a.table + ((b0 + q) * a.npages + (uint64_t)pg * (nblk_q + 1u)) * (8ull * H);
+    const uint32_t vw = MQ ? wave : wave * G + grp;  // virtual wave of this lane
+    const uint32_t NV = MQ ? (uint32_t)NW : NW * G;
     // block of this lane in trip i: vw + i * NV, or the padding block when it has run out
     auto blk_of = [&](uint32_t i) -> uint64_t {
         const uint32_t bidx = vw + i * NV;
-        return (uint64_t)(bidx < nblk ? bidx : nblk) * 8u * H;
+        return (uint64_t)(bidx < nblk ? bidx : nblk_q) * 8u * H;
     };
 
     uint32_t pl[4][NP];
@@ -472,8 +483,17 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
         for (int k = 0; k < NP; ++k) pl[w][k] = 0u;
 
     // trips of this wave (wave-uniform): as many as its first lane group needs
-    const uint32_t first = wave * G;
-    const uint32_t nw = nblk > first ? (nblk - first + NV - 1u) / NV : 0u;
+    uint32_t nw;
+    if constexpr (MQ) {
+        // the longest query among the wave's lane groups sets the trip count
+        uint32_t need = nblk > wave ? (nblk - wave + NW - 1u) / NW : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) need = max(need, (uint32_t)__shfl_xor(need, off));
+        nw = __builtin_amdgcn_readfirstlane(need);
+    } else {
+        const uint32_t first = wave * G;
+        nw = nblk > first ? (nblk - first + NV - 1u) / NV : 0u;
+    }
     uint32_t ea[4], eb[4];
     if constexpr (H1) {
         // Three-stage software pipeline, branch-free in the steady state:
@@ -526,7 +546,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     }
 
     // ---- merge the G lane groups of this wave (bit-sliced adds across lanes)
-    for (uint32_t s = W; s < 64u; s <<= 1) {
+    for (uint32_t s = MQ ? 64u : W; s < 64u; s <<= 1) {
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             uint32_t carry = 0u;
@@ -573,13 +593,17 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
 
     // ---- expand planes -> per-document counts; every thread handles row bytes ----
     const uint32_t* planes = reinterpret_cast<const uint32_t*>(mbuf);   // [NP][64*4 words]
-    const uint32_t thr = a.thresholds ? a.thresholds[q] : 0u;
-    OutT* crow = reinterpret_cast<OutT*>(a.counts) + (uint64_t)q * a.counts_stride + a.counts_offset;
+    const uint32_t nbytes = MQ ? 1024u : W * 16u;    // MQ: every lane group holds a query's tile
 #pragma unroll 1
-    for (uint32_t b = threadIdx.x; b < W * 16u; b += NW * 64) {      // row byte inside the tile
-        const uint32_t chunk = b >> 4, cb = b & 15u;
+    for (uint32_t b = threadIdx.x; b < nbytes; b += NW * 64) {       // row byte inside the tile
+        const uint32_t pl_lane = b >> 4, cb = b & 15u;               // lane that held the planes
+        const uint32_t chunk = MQ ? (pl_lane & (W - 1u)) : pl_lane;
+        const uint32_t q2raw = MQ ? qi * G + pl_lane / W : qi;
+        const uint32_t q2 = q2raw < a.nq ? q2raw : a.nq - 1u;
+        const uint32_t thr = a.thresholds ? a.thresholds[q2] : 0u;
+        OutT* crow = reinterpret_cast<OutT*>(a.counts) + (uint64_t)q2 * a.counts_stride + a.counts_offset;
         const uint32_t gch = a.chunk_begin + tile * W + chunk;
-        bool valid = gch < a.chunk_end;
+        bool valid = gch < a.chunk_end && q2raw < a.nq;
         const uint32_t gcc = valid ? gch : a.chunk_begin;
         const uint32_t p2 = gcc / a.cpp;
         const uint32_t byte_in_page = (gcc - p2 * a.cpp) * 16u + cb;
@@ -593,7 +617,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
         const uint32_t sh = (cb & 3u) * 8u;
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-            const uint32_t v = (planes[(k * 64 + chunk) * 4 + (cb >> 2)] >> sh) & 0xFFu;
+            const uint32_t v = (planes[(k * 64 + pl_lane) * 4 + (cb >> 2)] >> sh) & 0xFFu;
             const uint4 e = lut[v];
             if (k < 16) {
                 lo[0] |= e.x << k; lo[1] |= e.y << k; lo[2] |= e.z << k; lo[3] |= e.w << k;
@@ -642,7 +666,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
 #pragma unroll
                 for (int d = 0; d < 8; ++d) {
                     if (mask & (1u << d)) {
-                        if (pos < a.hit_cap) a.hits[pos] = HitDev{q, a.part, doc + d, cnt[d]};
+                        if (pos < a.hit_cap) a.hits[pos] = HitDev{q2, a.part, doc + d, cnt[d]};
                         ++pos;
                     }
                 }
@@ -969,14 +993,16 @@ hipError_t launch_hash(const HashArgs& a, uint64_t total_threads, hipStream_t st
     return hipGetLastError();
 }
 
-template <int NP, int NW, bool H1, typename OutT>
+template <int NP, int NW, bool H1, typename OutT, bool MQ = false>
 static hipError_t launch_scan_inst(const ScanArgs& a, uint32_t ntiles, hipStream_t stream) {
     (void)ntiles;
-    const uint64_t groups = (uint64_t)((a.chunk_end - a.chunk_begin + a.tile_w - 1) / a.tile_w) * a.nq;
+    const uint32_t per_group = MQ ? 64u / a.tile_w : 1u;
+    const uint64_t groups = (uint64_t)((a.chunk_end - a.chunk_begin + a.tile_w - 1) / a.tile_w) *
+                            ((a.nq + per_group - 1u) / per_group);
     if (groups == 0) return hipSuccess;
     if (groups > 0x7FFFFFFFull) return hipErrorInvalidValue;
     constexpr size_t lds = ((size_t)(NW >= 2 ? NW / 2 : 1) * NP * 64 + 256) * sizeof(uint4);
-    auto kern = scan_kernel<NP, NW, H1, OutT>;
+    auto kern = scan_kernel<NP, NW, H1, OutT, MQ>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -984,6 +1010,14 @@ static hipError_t launch_scan_inst(const ScanArgs& a, uint32_t ntiles, hipStream
     }
     hipLaunchKernelGGL(kern, dim3((uint32_t)groups), dim3(NW * 64), lds, stream, a);
     return hipGetLastError();
+}
+
+// multi-query variant: H = 1, u16 scores (short queries)
+template <int NP>
+static hipError_t launch_scan_mq(const ScanArgs& a, uint32_t ntiles, int nw, hipStream_t stream) {
+    if (nw == 1) return launch_scan_inst<NP, 1, true, uint16_t, true>(a, ntiles, stream);
+    if (nw == 2) return launch_scan_inst<NP, 2, true, uint16_t, true>(a, ntiles, stream);
+    return launch_scan_inst<NP, 4, true, uint16_t, true>(a, ntiles, stream);
 }
 
 template <int NP, typename OutT>
@@ -1007,8 +1041,22 @@ int scan_planes_for(uint64_t max_terms) {
     return -1;
 }
 
-hipError_t launch_scan(const ScanArgs& a, uint32_t ntiles, int planes, int nw, hipStream_t stream) {
+bool scan_has_multi_query(int planes, uint32_t num_hashes, uint32_t tile_w) {
+    return num_hashes == 1 && tile_w < 64 && (planes == 4 || planes == 8 || planes == 10 || planes == 12);
+}
+
+hipError_t launch_scan(const ScanArgs& a, uint32_t ntiles, int planes, int nw, bool multi_query,
+                       hipStream_t stream) {
     const bool h1 = a.num_hashes == 1;
+    if (multi_query) {
+        if (!scan_has_multi_query(planes, a.num_hashes, a.tile_w)) return hipErrorInvalidValue;
+        switch (planes) {
+        case 4: return launch_scan_mq<4>(a, ntiles, nw, stream);
+        case 8: return launch_scan_mq<8>(a, ntiles, nw, stream);
+        case 10: return launch_scan_mq<10>(a, ntiles, nw, stream);
+        default: return launch_scan_mq<12>(a, ntiles, nw, stream);
+        }
+    }
     switch (planes) {
     case 4: return launch_scan_np<4, uint16_t>(a, ntiles, h1, nw, stream);
     case 8: return launch_scan_np<8, uint16_t>(a, ntiles, h1, nw, stream);

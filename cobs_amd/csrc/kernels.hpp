@@ -16,8 +16,11 @@ hipError_t launch_hash(const HashArgs& a, uint64_t total_threads, hipStream_t st
 int scan_planes_for(uint64_t max_terms);
 inline uint32_t scan_score_bytes(int planes) { return planes <= 16 ? 2u : 4u; }
 
-// K2: ntiles * nq work-groups of nw (1, 2 or 4) waves.
-hipError_t launch_scan(const ScanArgs& a, uint32_t ntiles, int planes, int nw, hipStream_t stream);
+// K2: ntiles * nq work-groups of nw (1, 2 or 4) waves; multi_query: ntiles * ceil(nq / (64 / tile_w))
+// work-groups whose lane groups serve different queries (short queries; see scan_has_multi_query).
+hipError_t launch_scan(const ScanArgs& a, uint32_t ntiles, int planes, int nw, bool multi_query,
+                       hipStream_t stream);
+bool scan_has_multi_query(int planes, uint32_t num_hashes, uint32_t tile_w);
 
 // K3: per query the k best (score desc, doc asc) documents with score >= threshold.
 hipError_t launch_topk(const TopkArgs& a, hipStream_t stream);

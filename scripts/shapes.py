@@ -72,3 +72,21 @@ if __name__ == "__main__":
     if on("reads"):
         for bp in (100, 150, 250):
             run("C3 %d-bp reads Q40k" % bp, "compact", bench.c3_config()["signature_sizes"], 100000, 1568, 40000, bp - 30)
+    if on("vpage"):
+        # emulation of a row-range split of a 4M-row sub-index into R passes: same lookups and
+        # gathered bytes, R x fewer rows per scanned slice, R x fewer terms per work-group
+        for R in (1, 2, 4, 8, 16):
+            run("8 x S=%dk T=%d Q=%dk (R=%d)" % (4000 // R, 1000 // R, 10 * R, R), "compact",
+                [4000000 // R] * 8, 100000, 1568, 10000 * R, 1000 // R)
+    if on("mq"):
+        # multi-query work-groups vs the default geometry (COBS_GPU_MQ / _TILE_W / _WAVES are read per run)
+        c3 = bench.c3_config()["signature_sizes"]
+        for T, nq in ((20, 40000), (70, 40000), (120, 40000), (220, 40000), (500, 20000), (1000, 10000)):
+            for mq, w, nw in ((0, 0, 0), (1, 8, 1), (1, 8, 2), (1, 8, 4), (1, 16, 1), (1, 16, 2), (1, 16, 4), (1, 32, 2)):
+                os.environ["COBS_GPU_MQ"] = str(mq)
+                for k, v in (("COBS_GPU_TILE_W", w), ("COBS_GPU_WAVES", nw)):
+                    if v:
+                        os.environ[k] = str(v)
+                    else:
+                        os.environ.pop(k, None)
+                run("C3 T=%d Q=%dk mq=%d W=%d NW=%d" % (T, nq // 1000, mq, w, nw), "compact", c3, 100000, 1568, nq, T, steps=3)

@@ -29,7 +29,7 @@ def _random_case(rng, oracle, tmp_path, idx):
         planted = {int(d): float(rng.random()) for d in rng.integers(0, D, size=min(D, 6))}
         path = cases.make_compact(cases.tmp(tmp_path, "f%d.cobs_compact" % idx), D, ps, sigs, H, k, canon, 0.3, idx,
                                   planted=planted, query=q_long[:qlen])
-    nq = int(rng.integers(1, 6))
+    nq = int(rng.integers(1, 20))
     queries = []
     for _ in range(nq):
         ln = int(rng.integers(k, len(q_long)))
@@ -39,13 +39,18 @@ def _random_case(rng, oracle, tmp_path, idx):
     return path, queries
 
 
-@pytest.mark.parametrize("tile_w,waves", [(None, None), ("4", "1"), ("8", "4"), ("16", "2"), ("32", "1"), ("64", "4"),
-                                          ("8", "1"), ("64", "2")])
-def test_random_geometries(gpu_lib, oracle, tmp_path, monkeypatch, tile_w, waves):
+@pytest.mark.parametrize("tile_w,waves,mq", [
+    (None, None, "0"), ("4", "1", "0"), ("8", "4", "0"), ("16", "2", "0"), ("32", "1", "0"), ("64", "4", "0"),
+    ("8", "1", "0"), ("64", "2", "0"),
+    # multi-query work-groups (lane groups = different queries of the batch)
+    (None, None, "1"), ("4", "1", "1"), ("8", "4", "1"), ("16", "2", "1"), ("32", "1", "1"), ("8", "1", "1"),
+    ("16", "4", "1")])
+def test_random_geometries(gpu_lib, oracle, tmp_path, monkeypatch, tile_w, waves, mq):
+    monkeypatch.setenv("COBS_GPU_MQ", mq)
     if tile_w:
         monkeypatch.setenv("COBS_GPU_TILE_W", tile_w)
         monkeypatch.setenv("COBS_GPU_WAVES", waves)
-    rng = np.random.default_rng(20260928 + (int(tile_w) if tile_w else 0) + (int(waves) if waves else 0))
+    rng = np.random.default_rng(20260928 + (int(tile_w) if tile_w else 0) + (int(waves) if waves else 0) + 977 * int(mq))
     for idx in range(40):
         path, queries = _random_case(rng, oracle, tmp_path, idx)
         ix = oracle.Index.open(path)
