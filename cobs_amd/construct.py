@@ -213,5 +213,16 @@ def compact_construct(input=None, out_file=None, index_params=None, file_type="a
     _build("cobs_gpu_build_compact", final, fixed, out_file, device)
 
 
+def classic_construct_list(list, out_file, index_params=None, tmp_path="", device=-1):
+    """cobs_index.classic_construct_list (module.cpp:253-268): same, from a populated DocumentList"""
+    classic_construct(None, out_file, index_params, "any", tmp_path, list=list, device=device)
+
+
+def compact_construct_list(list, out_file, index_params=None, tmp_path="", device=-1):
+    """cobs_index.compact_construct_list (module.cpp:332-347)"""
+    compact_construct(None, out_file, index_params, "any", tmp_path, list=list, device=device)
+
+
 __all__ = ["DocumentList", "DocumentEntry", "ClassicIndexParameters", "CompactIndexParameters",
-           "classic_construct", "compact_construct", "disable_cache"]
+           "classic_construct", "classic_construct_list", "compact_construct", "compact_construct_list",
+           "disable_cache"]

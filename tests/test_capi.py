@@ -99,6 +99,18 @@ def test_python_mirror_surface():
     assert list(sig.parameters) == ["self", "query", "threshold", "num_results"]
     assert sig.parameters["threshold"].default == 0.0 and sig.parameters["num_results"].default == 0
     assert isinstance(cobs_amd.__version__, str)
+    # every name the reference module exports (python/module.cpp:100-386)
+    for name in ("disable_cache", "DocumentList", "ClassicIndexParameters", "classic_construct",
+                 "classic_construct_list", "CompactIndexParameters", "compact_construct",
+                 "compact_construct_list", "SearchResult", "Search"):
+        assert hasattr(cobs_amd, name), name
+    for fn, first in ((cobs_amd.classic_construct, "input"), (cobs_amd.compact_construct, "input"),
+                      (cobs_amd.classic_construct_list, "list"), (cobs_amd.compact_construct_list, "list")):
+        ps = list(inspect.signature(fn).parameters)
+        assert ps[:3] == [first, "out_file", "index_params"], ps
+    p = cobs_amd.ClassicIndexParameters()
+    assert (p.term_size, p.canonicalize, p.num_hashes, p.false_positive_rate) == (31, True, 1, 0.3)
+    assert cobs_amd.CompactIndexParameters().page_size == 0
 
 
 def test_bench_query_stream_is_the_reference_benchmark_stream(oracle):

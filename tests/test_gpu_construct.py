@@ -44,6 +44,16 @@ def test_files_equal_golden_fixtures(gpu_lib, golden_dir, tmp_path):
         out = str(tmp_path / name)
         fn(input=os.path.join(golden_dir, "fasta"), out_file=out, index_params=params)
         assert open(out, "rb").read() == open(os.path.join(golden_dir, name), "rb").read(), name
+    # the *_construct_list variants (python/module.cpp:253-268, :332-347) on a populated DocumentList
+    for name, fn, params in (("c1.cobs_classic", gpu_lib.classic_construct_list, gpu_lib.ClassicIndexParameters()),
+                             ("c1.cobs_compact", gpu_lib.compact_construct_list, gpu_lib.CompactIndexParameters())):
+        dl = gpu_lib.DocumentList()
+        dl.add_recursive(os.path.join(golden_dir, "fasta"))
+        assert dl.size() == 7
+        params.clobber = True
+        out = str(tmp_path / name)
+        fn(dl, out, params)
+        assert open(out, "rb").read() == open(os.path.join(golden_dir, name), "rb").read(), name
 
 
 def _random_docs(oracle, n, seed):
