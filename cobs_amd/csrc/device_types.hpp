@@ -71,7 +71,7 @@ struct ScanArgs {
 
 // Arguments of the top-k selection kernel K3 for one index file (u16 scores).
 struct TopkArgs {
-    const uint16_t* counts;      // [nq][counts_stride]
+    const void* counts;          // [nq][counts_stride] scores of score_bytes (1 or 2) bytes
     const uint32_t* thresholds;  // per query or nullptr (= 0)
     uint2* out;                  // [nq][k] (doc, score), unordered within a query
     uint32_t* out_count;         // [nq] entries written (<= k)
@@ -84,6 +84,7 @@ struct TopkArgs {
     uint32_t nq;
     uint32_t score_bits;         // scores are < 2^score_bits (the scan kernel's plane count, <= 16)
     uint32_t shift1;             // level 1 bins = score >> shift1 (at most 4096), level 2 = the low shift1 bits
+    uint32_t score_bytes;        // 1 (planes <= 8) or 2
 };
 
 // Arguments of the construction kernel: set the signature bits of documents.

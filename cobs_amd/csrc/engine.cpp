@@ -1008,7 +1008,7 @@ static cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk
     b->threshold = threshold;
     const size_t nq = b->nq;
     // K3 (exact top-k on the device) needs u16 scores and a bounded k
-    const bool use_topk = topk > 0 && b->elem_bytes == 2 && topk <= 65536 &&
+    const bool use_topk = topk > 0 && b->elem_bytes <= 2 && topk <= 65536 &&
                           (uint64_t)topk * std::max<size_t>(nq, 1) * ix->parts.size() <= (1ull << 27);
     b->topk_k = use_topk ? (uint32_t)topk : 0;
     // with K3 the threshold is applied there; otherwise K2 selects into the hit pool
@@ -1113,7 +1113,8 @@ static cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk
         for (size_t f = 0; f < ix->parts.size(); ++f) {
             const Part& p = ix->parts[f];
             TopkArgs ta;
-            ta.counts = reinterpret_cast<const uint16_t*>(b->counts.p);
+            ta.counts = b->counts.p;
+            ta.score_bytes = b->elem_bytes;
             ta.thresholds = need_thr ? b->work[f].thr.p : nullptr;
             ta.out = b->topk_out.p + (uint64_t)f * nq * topk;
             ta.out_count = b->topk_cnt.p + f * nq;
@@ -1177,7 +1178,10 @@ static cobs_gpu_status fetch_counts(cobs_gpu_batch* b, size_t q, uint32_t* count
     std::fill(counts, counts + ix->total_counts, 0u);
     for (const Part& p : ix->parts) {
         uint32_t* dst = counts + p.doc_offset + p.slot_begin;
-        if (b->elem_bytes == 2) {
+        if (b->elem_bytes == 1) {
+            const uint8_t* s = raw.data() + p.local_offset;
+            for (uint64_t i = 0; i < p.slot_count; ++i) dst[i] = s[i];
+        } else if (b->elem_bytes == 2) {
             const uint16_t* s = reinterpret_cast<const uint16_t*>(raw.data()) + p.local_offset;
             for (uint64_t i = 0; i < p.slot_count; ++i) dst[i] = s[i];
         } else {

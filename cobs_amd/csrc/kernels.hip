@@ -427,11 +427,19 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     uint4* lut = mbuf + (size_t)(NW >= 2 ? NW / 2 : 1) * NP * 64;
     for (uint32_t v = threadIdx.x; v < 256u; v += NW * 64) {
         uint4 e;
-        e.x = (v & 1u) | ((v & 2u) << 15);
-        e.y = ((v >> 2) & 1u) | ((v & 8u) << 13);
-        e.z = ((v >> 4) & 1u) | ((v & 32u) << 11);
-        e.w = ((v >> 6) & 1u) | ((v & 128u) << 9);
-        lut[v] = e;
+        if constexpr (sizeof(OutT) == 1) {
+            // 8-bit scores (T <= 255, the reference's uint8_t path): bit j -> byte j, 8 bytes
+            e.x = (v & 1u) | ((v & 2u) << 7) | ((v & 4u) << 14) | ((v & 8u) << 21);
+            e.y = ((v >> 4) & 1u) | ((v & 32u) << 3) | ((v & 64u) << 10) | ((v & 128u) << 17);
+            e.z = 0u; e.w = 0u;
+            reinterpret_cast<uint2*>(lut)[v] = make_uint2(e.x, e.y);
+        } else {
+            e.x = (v & 1u) | ((v & 2u) << 15);
+            e.y = ((v >> 2) & 1u) | ((v & 8u) << 13);
+            e.z = ((v >> 4) & 1u) | ((v & 32u) << 11);
+            e.w = ((v >> 6) & 1u) | ((v & 128u) << 9);
+            lut[v] = e;
+        }
     }
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -615,26 +623,41 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
         // 8 counters at once.  Planes 16.. go to a second accumulator (32-bit scores).
         uint32_t lo[4] = {0u, 0u, 0u, 0u}, hi[4] = {0u, 0u, 0u, 0u};
         const uint32_t sh = (cb & 3u) * 8u;
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            const uint32_t v = (planes[(k * 64 + pl_lane) * 4 + (cb >> 2)] >> sh) & 0xFFu;
-            const uint4 e = lut[v];
-            if (k < 16) {
-                lo[0] |= e.x << k; lo[1] |= e.y << k; lo[2] |= e.z << k; lo[3] |= e.w << k;
-            } else {
-                hi[0] |= e.x << (k - 16); hi[1] |= e.y << (k - 16);
-                hi[2] |= e.z << (k - 16); hi[3] |= e.w << (k - 16);
-            }
-        }
         uint32_t cnt[8];
+        if constexpr (sizeof(OutT) == 1) {
+            static_assert(sizeof(OutT) != 1 || NP <= 8, "8-bit scores hold at most 8 planes");
+            const uint2* lut8 = reinterpret_cast<const uint2*>(lut);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            cnt[2 * m] = (lo[m] & 0xFFFFu) | ((hi[m] & 0xFFFFu) << 16);
-            cnt[2 * m + 1] = (lo[m] >> 16) | (hi[m] & 0xFFFF0000u);
+            for (int k = 0; k < NP; ++k) {
+                const uint32_t v = (planes[(k * 64 + pl_lane) * 4 + (cb >> 2)] >> sh) & 0xFFu;
+                const uint2 e = lut8[v];
+                lo[0] |= e.x << k; lo[1] |= e.y << k;
+            }
+#pragma unroll
+            for (int d = 0; d < 8; ++d) cnt[d] = (lo[d >> 2] >> ((d & 3) * 8)) & 0xFFu;
+        } else {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const uint32_t v = (planes[(k * 64 + pl_lane) * 4 + (cb >> 2)] >> sh) & 0xFFu;
+                const uint4 e = lut[v];
+                if (k < 16) {
+                    lo[0] |= e.x << k; lo[1] |= e.y << k; lo[2] |= e.z << k; lo[3] |= e.w << k;
+                } else {
+                    hi[0] |= e.x << (k - 16); hi[1] |= e.y << (k - 16);
+                    hi[2] |= e.z << (k - 16); hi[3] |= e.w << (k - 16);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                cnt[2 * m] = (lo[m] & 0xFFFFu) | ((hi[m] & 0xFFFFu) << 16);
+                cnt[2 * m + 1] = (lo[m] >> 16) | (hi[m] & 0xFFFF0000u);
+            }
         }
         const uint32_t slot = pd.slot0 + byte_in_page * 8u;
         if (valid && a.write_counts) {
-            if constexpr (sizeof(OutT) == 2) {
+            if constexpr (sizeof(OutT) == 1) {
+                *reinterpret_cast<uint2*>(crow + slot) = make_uint2(lo[0], lo[1]);
+            } else if constexpr (sizeof(OutT) == 2) {
                 *reinterpret_cast<uint4*>(crow + slot) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
             } else {
                 *reinterpret_cast<uint4*>(crow + slot) = make_uint4(cnt[0], cnt[1], cnt[2], cnt[3]);
@@ -701,6 +724,22 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane, ui
 
 // Dynamic LDS: hist1[4][NB1] | hist2[4][NB2] | partial[256] | sh[16]; one histogram
 // copy per wave (fewer same-address atomics, and the per-wave tie counts fall out).
+// eight consecutive scores (u8 or u16) starting at document i (a multiple of 8)
+template <typename ST>
+__device__ __forceinline__ void load_scores8(const ST* row, uint32_t i, uint32_t (&s)[8]) {
+    if constexpr (sizeof(ST) == 1) {
+        const uint2 v = *reinterpret_cast<const uint2*>(row + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = ((j < 4 ? v.x : v.y) >> ((j & 3) * 8)) & 0xFFu;
+    } else {
+        const uint4 v = *reinterpret_cast<const uint4*>(row + i);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = (w[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+    }
+}
+
+template <typename ST>
 __global__ __launch_bounds__(256) void topk_kernel(TopkArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t sh1 = a.shift1;
@@ -712,7 +751,7 @@ __global__ __launch_bounds__(256) void topk_kernel(TopkArgs a) {
     const uint32_t q = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint16_t* row = a.counts + (uint64_t)q * a.counts_stride + a.counts_offset;
+    const ST* row = reinterpret_cast<const ST*>(a.counts) + (uint64_t)q * a.counts_stride + a.counts_offset;
     const uint32_t thr = a.thresholds ? a.thresholds[q] : 0u;
     uint32_t n = a.nslots;                       // real documents among the local slots
     if (a.doc_base >= a.num_docs) n = 0;
@@ -730,11 +769,11 @@ __global__ __launch_bounds__(256) void topk_kernel(TopkArgs a) {
     for (uint32_t i0 = w0; i0 < w1; i0 += 512) {
         const uint32_t i = i0 + lane * 8u;
         if (i < w1) {
-            const uint4 v = *reinterpret_cast<const uint4*>(row + i);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            uint32_t sc[8];
+            load_scores8<ST>(row, i, sc);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const uint32_t s = (w[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                const uint32_t s = sc[j];
                 if (i + j < w1 && s >= thr) atomicAdd(&myh1[s >> sh1], 1u);
             }
         }
@@ -778,11 +817,11 @@ __global__ __launch_bounds__(256) void topk_kernel(TopkArgs a) {
         for (uint32_t i0 = w0; i0 < w1; i0 += 512) {
             const uint32_t i = i0 + lane * 8u;
             if (i < w1) {
-                const uint4 v = *reinterpret_cast<const uint4*>(row + i);
-                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                uint32_t sc[8];
+                load_scores8<ST>(row, i, sc);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const uint32_t s = (w[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                    const uint32_t s = sc[j];
                     if (i + j < w1 && s >= thr && (s >> sh1) == hb) atomicAdd(&myh2[s & lomask], 1u);
                 }
             }
@@ -823,12 +862,10 @@ __global__ __launch_bounds__(256) void topk_kernel(TopkArgs a) {
         uint32_t s8[8];
         uint32_t gt = 0, eq = 0;
         if (i < w1) {
-            const uint4 v = *reinterpret_cast<const uint4*>(row + i);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            load_scores8<ST>(row, i, s8);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const uint32_t s = (w[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
-                s8[j] = s;
+                const uint32_t s = s8[j];
                 const bool pass = i + j < w1 && s >= thr;
                 if (pass && (take_all || s > cut)) gt |= 1u << j;
                 if (pass && !take_all && s == cut) eq |= 1u << j;
@@ -1013,11 +1050,11 @@ static hipError_t launch_scan_inst(const ScanArgs& a, uint32_t ntiles, hipStream
 }
 
 // multi-query variant: H = 1, u16 scores (short queries)
-template <int NP>
+template <int NP, typename OutT>
 static hipError_t launch_scan_mq(const ScanArgs& a, uint32_t ntiles, int nw, hipStream_t stream) {
-    if (nw == 1) return launch_scan_inst<NP, 1, true, uint16_t, true>(a, ntiles, stream);
-    if (nw == 2) return launch_scan_inst<NP, 2, true, uint16_t, true>(a, ntiles, stream);
-    return launch_scan_inst<NP, 4, true, uint16_t, true>(a, ntiles, stream);
+    if (nw == 1) return launch_scan_inst<NP, 1, true, OutT, true>(a, ntiles, stream);
+    if (nw == 2) return launch_scan_inst<NP, 2, true, OutT, true>(a, ntiles, stream);
+    return launch_scan_inst<NP, 4, true, OutT, true>(a, ntiles, stream);
 }
 
 template <int NP, typename OutT>
@@ -1051,15 +1088,15 @@ hipError_t launch_scan(const ScanArgs& a, uint32_t ntiles, int planes, int nw, b
     if (multi_query) {
         if (!scan_has_multi_query(planes, a.num_hashes, a.tile_w)) return hipErrorInvalidValue;
         switch (planes) {
-        case 4: return launch_scan_mq<4>(a, ntiles, nw, stream);
-        case 8: return launch_scan_mq<8>(a, ntiles, nw, stream);
-        case 10: return launch_scan_mq<10>(a, ntiles, nw, stream);
-        default: return launch_scan_mq<12>(a, ntiles, nw, stream);
+        case 4: return launch_scan_mq<4, uint8_t>(a, ntiles, nw, stream);
+        case 8: return launch_scan_mq<8, uint8_t>(a, ntiles, nw, stream);
+        case 10: return launch_scan_mq<10, uint16_t>(a, ntiles, nw, stream);
+        default: return launch_scan_mq<12, uint16_t>(a, ntiles, nw, stream);
         }
     }
     switch (planes) {
-    case 4: return launch_scan_np<4, uint16_t>(a, ntiles, h1, nw, stream);
-    case 8: return launch_scan_np<8, uint16_t>(a, ntiles, h1, nw, stream);
+    case 4: return launch_scan_np<4, uint8_t>(a, ntiles, h1, nw, stream);
+    case 8: return launch_scan_np<8, uint8_t>(a, ntiles, h1, nw, stream);
     case 10: return launch_scan_np<10, uint16_t>(a, ntiles, h1, nw, stream);
     case 12: return launch_scan_np<12, uint16_t>(a, ntiles, h1, nw, stream);
     case 16: return launch_scan_np<16, uint16_t>(a, ntiles, h1, nw, stream);
@@ -1074,12 +1111,14 @@ hipError_t launch_topk(const TopkArgs& a, hipStream_t stream) {
     if (a.nq == 0 || a.k == 0) return hipSuccess;
     const uint32_t nb1 = 1u << (a.score_bits - a.shift1), nb2 = 1u << a.shift1;
     const size_t lds = (size_t)(4 * nb1 + 4 * nb2 + 256 + 16) * sizeof(uint32_t);
+    auto kern = a.score_bytes == 1 ? topk_kernel<uint8_t> : topk_kernel<uint16_t>;
+    if (a.score_bytes != 1 && a.score_bytes != 2) return hipErrorInvalidValue;
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(topk_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(topk_kernel, dim3(a.nq), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(a.nq), dim3(256), lds, stream, a);
     return hipGetLastError();
 }
 

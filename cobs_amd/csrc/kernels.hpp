@@ -12,9 +12,9 @@ namespace cobs_amd {
 hipError_t launch_hash(const HashArgs& a, uint64_t total_threads, hipStream_t stream);
 
 // Smallest instantiated plane count that can hold counts up to max_terms
-// (4, 8, 10, 12, 16 -> u16 scores; 20, 24, 32 -> u32 scores); -1 if none.
+// (4, 8 -> u8 scores as the reference's T < 255 path; 10, 12, 16 -> u16; 20, 24, 32 -> u32); -1 if none.
 int scan_planes_for(uint64_t max_terms);
-inline uint32_t scan_score_bytes(int planes) { return planes <= 16 ? 2u : 4u; }
+inline uint32_t scan_score_bytes(int planes) { return planes <= 8 ? 1u : planes <= 16 ? 2u : 4u; }
 
 // K2: ntiles * nq work-groups of nw (1, 2 or 4) waves; multi_query: ntiles * ceil(nq / (64 / tile_w))
 // work-groups whose lane groups serve different queries (short queries; see scan_has_multi_query).

@@ -245,13 +245,15 @@ class Batch:
         return p, eb.value, rs.value
 
     def counts_tensor(self):
-        """torch view [nq, local_counts] (int16 / int32 bit patterns of u16 / u32 scores)."""
+        """torch view [nq, local_counts]: uint8 scores when no query of the batch has more than 255
+        terms (the reference's uint8_t path), else int16 / int32 bit patterns of u16 / u32 scores."""
         import torch
         p, eb, rs = self.counts_device()
         n = self._s.local_counts
         if self.nq == 0 or n == 0:
-            return torch.empty((self.nq, n), dtype=torch.int16 if eb == 2 else torch.int32, device="cuda")
-        return torch.as_tensor(_DevArray(p, (self.nq, n), "<i2" if eb == 2 else "<i4", self), device="cuda")
+            return torch.empty((self.nq, n), dtype={1: torch.uint8, 2: torch.int16}.get(eb, torch.int32),
+                               device="cuda")
+        return torch.as_tensor(_DevArray(p, (self.nq, n), {1: "|u1", 2: "<i2"}.get(eb, "<i4"), self), device="cuda")
 
     def counts_host(self, query_no):
         out = np.zeros(self._s.total_counts, dtype=np.uint32)

@@ -218,7 +218,9 @@ cobs_gpu_status cobs_gpu_batch_run_topk(cobs_gpu_batch* b, double threshold, siz
 cobs_gpu_status cobs_gpu_batch_sync(cobs_gpu_batch* b, void* hip_stream, size_t* bad_query);
 /* Device pointer to the counts of the last run: row i (query i) starts at
  * ptr + i * row_stride_bytes and holds cobs_gpu_local_counts() elements of
- * elem_bytes (2 or 4) each.  Valid until the batch is destroyed. */
+ * elem_bytes each: 1 when no query of the batch has more than 255 terms, 2 up to
+ * 65535, else 4 -- the Score widths of classic_search.cpp:453-504.  Valid until the
+ * batch is destroyed. */
 void* cobs_gpu_batch_counts_device(cobs_gpu_batch* b, uint32_t* elem_bytes, uint64_t* row_stride_bytes);
 /* D2H of one query's counts widened to u32 */
 cobs_gpu_status cobs_gpu_batch_counts_host(cobs_gpu_batch* b, size_t query_no, uint32_t* counts, size_t cap);

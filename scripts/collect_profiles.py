@@ -30,6 +30,14 @@ def main():
     os.makedirs(dst, exist_ok=True)
     shutil.copy(os.path.join(src, "trace", "bench_kernel_stats.csv"),
                 os.path.join(dst, tag + "_kernel_stats.csv"))
+    # the bench line printed by the profiled process itself: its HIP-event duration of the
+    # scan kernel is the one to compare with the AverageNs of the kernel-stats table
+    log = os.path.join(src, "trace.log")
+    if os.path.exists(log):
+        lines = [ln for ln in open(log, errors="replace") if ln.startswith('{"metric"')]
+        if lines:
+            with open(os.path.join(dst, tag + "_bench_profiled.json"), "w") as f:
+                f.write(lines[-1])
     summary = {"tag": tag, "command": "python bench.py --no-cpu-baseline (see scripts/profile.sh)",
                "kernel": "scan_kernel", "counters": {}}
     for d in sorted(os.listdir(src)):
