@@ -216,6 +216,10 @@ struct cobs_gpu_batch {
     std::vector<HitDev> h_hits;       // pool copy, sorted by query
     std::vector<size_t> h_hit_off;
     bool pool_fetched = false;
+    // host copy of a window of score rows [rows_q0, rows_q1) of the last run (raw elem_bytes)
+    PinnedBuf<uint8_t> h_rows;
+    size_t rows_q0 = 0, rows_q1 = 0;
+    std::vector<uint32_t> rank_hist;  // scratch of the counting sort in hits_host
     // HIP events around K1 and K2 of the most recent runs (recorded on the launch stream)
     static constexpr int kRing = 64;
     hipEvent_t ev[kRing][3] = {};
@@ -1005,6 +1009,7 @@ static cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk
     b->synced = false;
     b->pool_fetched = false;
     b->topk_fetched = false;
+    b->rows_q0 = b->rows_q1 = 0;
     b->threshold = threshold;
     const size_t nq = b->nq;
     // K3 (exact top-k on the device) needs u16 scores and a bounded k
@@ -1169,24 +1174,106 @@ void* cobs_gpu_batch_counts_device(cobs_gpu_batch* b, uint32_t* elem_bytes, uint
     return b->counts.p;
 }
 
+// Raw local score row of query q of the last run, through a pinned host window of up to 64 MiB
+// of consecutive rows (callers walk the queries in order: one DMA per window, not per query).
+static cobs_gpu_status fetch_row(cobs_gpu_batch* b, size_t q, const uint8_t** row) {
+    const size_t row_bytes = (size_t)(b->ix->local_counts * b->elem_bytes);
+    if (q < b->rows_q0 || q >= b->rows_q1) {
+        const size_t per = std::max<size_t>(1, (64u << 20) / std::max<size_t>(row_bytes, 1));
+        const size_t q1 = std::min(b->nq, q + per);
+        HIP_TRY(b->h_rows.reserve(std::max<size_t>((q1 - q) * row_bytes, 1)));
+        if (row_bytes)
+            HIP_TRY(hipMemcpy(b->h_rows.p, b->counts.p + q * row_bytes, (q1 - q) * row_bytes, hipMemcpyDeviceToHost));
+        b->rows_q0 = q;
+        b->rows_q1 = q1;
+    }
+    *row = b->h_rows.p + (q - b->rows_q0) * row_bytes;
+    return COBS_GPU_OK;
+}
+
+static inline uint32_t score_at(const uint8_t* row, uint32_t elem_bytes, uint64_t i) {
+    if (elem_bytes == 1) return row[i];
+    if (elem_bytes == 2) return reinterpret_cast<const uint16_t*>(row)[i];
+    return reinterpret_cast<const uint32_t*>(row)[i];
+}
+
 // local count row of query q, widened to u32, scattered into a global-layout vector
 static cobs_gpu_status fetch_counts(cobs_gpu_batch* b, size_t q, uint32_t* counts) {
     cobs_gpu_index* ix = b->ix;
-    const uint64_t n = ix->local_counts;
-    std::vector<uint8_t> raw((size_t)(n * b->elem_bytes));
-    if (n) HIP_TRY(hipMemcpy(raw.data(), b->counts.p + q * n * b->elem_bytes, raw.size(), hipMemcpyDeviceToHost));
+    const uint8_t* raw = nullptr;
+    cobs_gpu_status st = fetch_row(b, q, &raw);
+    if (st != COBS_GPU_OK) return st;
     std::fill(counts, counts + ix->total_counts, 0u);
     for (const Part& p : ix->parts) {
         uint32_t* dst = counts + p.doc_offset + p.slot_begin;
         if (b->elem_bytes == 1) {
-            const uint8_t* s = raw.data() + p.local_offset;
+            const uint8_t* s = raw + p.local_offset;
             for (uint64_t i = 0; i < p.slot_count; ++i) dst[i] = s[i];
         } else if (b->elem_bytes == 2) {
-            const uint16_t* s = reinterpret_cast<const uint16_t*>(raw.data()) + p.local_offset;
+            const uint16_t* s = reinterpret_cast<const uint16_t*>(raw) + p.local_offset;
             for (uint64_t i = 0; i < p.slot_count; ++i) dst[i] = s[i];
         } else {
-            const uint32_t* s = reinterpret_cast<const uint32_t*>(raw.data()) + p.local_offset;
+            const uint32_t* s = reinterpret_cast<const uint32_t*>(raw) + p.local_offset;
             for (uint64_t i = 0; i < p.slot_count; ++i) dst[i] = s[i];
+        }
+    }
+    return COBS_GPU_OK;
+}
+
+// counts_to_result over a whole score row (threshold <= 0: every document is a result):
+// the result order (score desc, then (file, doc) asc; classic_search.cpp:134-145, :179-188) is a
+// stable counting sort by score of the documents taken in (file, doc) order -- O(documents),
+// where std::partial_sort of 100 000 documents costs ~9 ms per query.  Writes the first `want`
+// results straight into `hits` (when it is large enough) and returns their number.
+static cobs_gpu_status rank_row(cobs_gpu_batch* b, size_t q, size_t num_results, cobs_gpu_hit* hits, size_t cap,
+                                size_t* n_hits) {
+    cobs_gpu_index* ix = b->ix;
+    const uint8_t* raw = nullptr;
+    cobs_gpu_status st = fetch_row(b, q, &raw);
+    if (st != COBS_GPU_OK) return st;
+    const uint32_t eb = b->elem_bytes;
+    const bool by_score = total_hashes(b, q) > 1;       // max_counts <= 1: index order, no sort (:134, :177)
+    // pass 1: passing documents per score
+    uint64_t max_score = 0;
+    for (const Part& p : ix->parts)
+        max_score = std::max<uint64_t>(max_score, (uint64_t)b->lens[q] - p.meta.term_size + 1);
+    if (max_score > (1u << 24)) return COBS_GPU_ERR_UNSUPPORTED;      // caller falls back to the generic sort
+    std::vector<uint32_t>& hist = b->rank_hist;
+    hist.assign((size_t)max_score + 2, 0u);
+    size_t passing = 0;
+    for (size_t f = 0; f < ix->parts.size(); ++f) {
+        const Part& p = ix->parts[f];
+        const uint32_t thr = threshold_for(b->threshold, (uint64_t)b->lens[q] - p.meta.term_size + 1);
+        const uint64_t d0 = p.slot_begin;
+        const uint64_t d1 = std::min<uint64_t>(p.slot_begin + p.slot_count, p.meta.doc_names.size());
+        for (uint64_t d = d0; d < d1; ++d) {
+            const uint32_t s = score_at(raw, eb, p.local_offset + d - d0);
+            if (s >= thr) { ++hist[by_score ? std::min<uint64_t>(s, max_score) : 0]; ++passing; }
+        }
+    }
+    size_t want = num_results == 0 ? (size_t)ix->total_counts : std::min<size_t>(num_results, (size_t)ix->total_counts);
+    want = std::min(want, passing);
+    *n_hits = want;
+    if (want > cap) return fail(COBS_GPU_ERR_CAPACITY, "hit buffer too small");
+    if (want && !hits) return fail(COBS_GPU_ERR_ARG, "NULL hit buffer");
+    // start position of every score, highest first
+    uint32_t pos = 0;
+    for (size_t s = hist.size(); s-- > 0;) {
+        const uint32_t c = hist[s];
+        hist[s] = pos;
+        pos += c;
+    }
+    // pass 2: scatter in (file, doc) order; positions >= want are dropped
+    for (size_t f = 0; f < ix->parts.size(); ++f) {
+        const Part& p = ix->parts[f];
+        const uint32_t thr = threshold_for(b->threshold, (uint64_t)b->lens[q] - p.meta.term_size + 1);
+        const uint64_t d0 = p.slot_begin;
+        const uint64_t d1 = std::min<uint64_t>(p.slot_begin + p.slot_count, p.meta.doc_names.size());
+        for (uint64_t d = d0; d < d1; ++d) {
+            const uint32_t s = score_at(raw, eb, p.local_offset + d - d0);
+            if (s < thr) continue;
+            const uint32_t at = hist[by_score ? std::min<uint64_t>(s, max_score) : 0]++;
+            if (at < want) hits[at] = cobs_gpu_hit{(uint32_t)f, (uint32_t)d, s};
         }
     }
     return COBS_GPU_OK;
@@ -1241,7 +1328,10 @@ cobs_gpu_status cobs_gpu_batch_hits_host(cobs_gpu_batch* b, size_t q, size_t num
         for (size_t i = b->h_hit_off[q]; i < b->h_hit_off[q + 1]; ++i)
             sel.push_back(cobs_gpu_hit{b->h_hits[i].part, b->h_hits[i].doc, b->h_hits[i].score});
     } else {
-        // threshold <= 0 (every document is a hit) or pool overflow: filter the counts on the host
+        // threshold <= 0 (every document is a hit) or pool overflow: rank the score row on the host
+        cobs_gpu_status rs = rank_row(b, q, num_results, hits, cap, n_hits);
+        if (rs != COBS_GPU_ERR_UNSUPPORTED) return rs;
+        // scores too wide for a counting sort: generic path
         std::vector<uint32_t> counts((size_t)ix->total_counts);
         cobs_gpu_status st = fetch_counts(b, q, counts.data());
         if (st != COBS_GPU_OK) return st;

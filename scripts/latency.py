@@ -37,3 +37,15 @@ for n in (1, 4, 16, 64, 256, 1024, 4096):
     host = (time.perf_counter() - t0) / 5
     print("nq=%5d  device pass %8.3f ms (scan %7.3f hash %6.3f)  %9.0f q/s   host API top-10 %8.3f ms  %9.0f q/s"
           % (n, dev * 1e3, ms["scan_ms"], ms["hash_ms"], n / dev, host * 1e3, n / host), flush=True)
+
+# the reference's default call, search(query) = threshold 0, num_results 0: EVERY document ranked
+for n in (1, 16, 256):
+    s.search_arrays(qs[:n], 0.0, 0)
+    t0 = time.perf_counter()
+    reps = 5 if n < 256 else 2
+    for _ in range(reps):
+        offs, hits = s.search_arrays(qs[:n], 0.0, 0)
+    host = (time.perf_counter() - t0) / reps
+    tm = s.timers(reset=True)
+    print("nq=%5d  host API all %d documents ranked per query %9.3f ms  %8.0f q/s  (rank %.3f s)"
+          % (n, len(hits) // n, host * 1e3, n / host, tm["rank"] / (reps + 1)), flush=True)
