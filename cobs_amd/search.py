@@ -111,6 +111,15 @@ class Search:
     def doc_name(self, file_no, doc):
         return self._lib.cobs_gpu_doc_name(self._h, file_no, doc).decode()
 
+    def _names(self, file_no):
+        """document names of one file, fetched once (search() of a 100k-document index names
+        100k results per query)"""
+        cache = self.__dict__.setdefault("_name_cache", {})
+        if file_no not in cache:
+            fn, h = self._lib.cobs_gpu_doc_name, self._h
+            cache[file_no] = [fn(h, file_no, d).decode() for d in range(int(self.info(file_no).num_docs))]
+        return cache[file_no]
+
     def signature_size(self, file_no=0, page=0):
         return int(self._lib.cobs_gpu_signature_size(self._h, file_no, page))
 
@@ -171,9 +180,21 @@ class Search:
         return [rows[int(offs[q]):int(offs[q + 1])] for q in range(len(queries))]
 
     def search_batch(self, queries, threshold=0.0, num_results=0):
+        offs, hits = self.search_arrays(queries, threshold, num_results)
         out = []
-        for per_query in self.search_hits(queries, threshold, num_results):
-            out.append([SearchResult(self.doc_name(f, d), s) for (f, d, s) in per_query])
+        for q in range(len(queries)):
+            seg = hits[int(offs[q]):int(offs[q + 1])]
+            if len(seg) <= 64:
+                out.append([SearchResult(self.doc_name(f, d), s) for (f, d, s) in seg.tolist()])
+                continue
+            # many results (the default call ranks every document): column-wise, cached names
+            files = seg["file_no"]
+            names = [self._names(int(f)) for f in range(int(files.max()) + 1)]
+            if len(names) == 1:
+                picked = map(names[0].__getitem__, seg["doc"].tolist())
+            else:
+                picked = (names[f][d] for f, d in zip(files.tolist(), seg["doc"].tolist()))
+            out.append(list(map(SearchResult, picked, seg["score"].tolist())))
         return out
 
     def counts(self, query):

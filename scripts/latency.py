@@ -49,3 +49,10 @@ for n in (1, 16, 256):
     tm = s.timers(reset=True)
     print("nq=%5d  host API all %d documents ranked per query %9.3f ms  %8.0f q/s  (rank %.3f s)"
           % (n, len(hits) // n, host * 1e3, n / host, tm["rank"] / (reps + 1)), flush=True)
+
+# the Python mirror of that call: 100k SearchResult objects per query
+s.search(qs[0])
+t0 = time.perf_counter()
+for _ in range(5):
+    r = s.search(qs[0])
+print("python Search.search(query) -> %d SearchResult objects: %.2f ms" % (len(r), (time.perf_counter() - t0) / 5 * 1e3))

@@ -321,3 +321,22 @@ def test_large_host_batch_is_cut_into_passes(gpu_lib, oracle, tmp_path, monkeypa
     badq = _capi.C.c_size_t(999)
     st = s._lib.cobs_gpu_search_batch(s._h, arr, lens, len(bad), 0.0, 0, hits, len(hits), offs, _capi.C.byref(badq))
     assert st == _capi.ERR_INVALID_BASE and badq.value == 23
+
+
+def test_default_python_call_ranks_every_document(gpu_lib, oracle, tmp_path):
+    """cobs_index.Search.search(query) with its defaults (threshold 0, no limit): every
+    document, named, in the reference's order -- two files, several hundred documents, ties"""
+    q = oracle.random_sequence(331, 5)
+    pa = cases.make_classic(cases.tmp(tmp_path, "a.cobs_classic"), 611, 701, 1, 31, 1, 0.3, 3,
+                            planted={17: 1.0, 300: 0.5, 610: 0.5}, query=q)
+    pb = cases.make_compact(cases.tmp(tmp_path, "b.cobs_compact"), 333, 8, [509, 401, 307, 600, 450, 333], 1, 31, 1,
+                            0.3, 4, planted={0: 0.5, 332: 1.0}, query=q)
+    ixs = [oracle.Index.open(pa), oracle.Index.open(pb)]
+    s = gpu_lib.Search([pa, pb])
+    for query in (q, q[:40], q[:31]):
+        want = oracle.search(ixs, query, 0.0, 0)
+        got = s.search(query)
+        assert len(got) == 611 + 333
+        assert [(r.doc_name, r.score) for r in got] == [(n, sc) for (_, _, n, sc) in want]
+        got5 = s.search(query, 0.0, 5)
+        assert [(r.doc_name, r.score) for r in got5] == [(n, sc) for (_, _, n, sc) in want[:5]]
