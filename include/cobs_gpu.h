@@ -178,7 +178,9 @@ cobs_gpu_status cobs_gpu_search(cobs_gpu_index* ix, const char* query, size_t le
 
 /* The same for nq queries in one device pass.  hit_offsets has nq+1 entries;
  * hits of query i are hits[hit_offsets[i] .. hit_offsets[i+1]).  A query with
- * bad input fails the whole call; *bad_query (optional) receives its index.  */
+ * bad input fails the whole call; *bad_query (optional) receives its index.
+ * If cap is too small the call returns COBS_GPU_ERR_CAPACITY and hit_offsets[nq]
+ * holds the capacity a retry needs (hit_offsets stay valid, hits do not).      */
 cobs_gpu_status cobs_gpu_search_batch(cobs_gpu_index* ix, const char* const* queries,
                                       const size_t* lens, size_t nq,
                                       double threshold, size_t num_results,

@@ -88,11 +88,24 @@ public:
         for (const auto& q : queries) { qp.push_back(q.data()); ql.push_back(q.size()); }
         std::vector<size_t> offs(queries.size() + 1, 0);
         const size_t total = (size_t)cobs_gpu_total_counts(ix_);
-        size_t per = num_results == 0 || num_results > total ? total : num_results;
-        hits_.resize(per * queries.size() + 1);
+        // hit buffer: exact when the result count is known (a limit, or threshold 0 = every
+        // document); with a threshold start small and grow to the size the library reports
+        size_t cap;
+        if (num_results > 0) cap = (num_results > total ? total : num_results) * queries.size();
+        else if (threshold <= 0.0) cap = total * queries.size();
+        else cap = 16 * queries.size() + 1024;
         size_t bad = 0;
-        cobs_gpu_status st = cobs_gpu_search_batch(ix_, qp.data(), ql.data(), queries.size(), threshold,
-                                                   num_results, hits_.data(), hits_.size(), offs.data(), &bad);
+        cobs_gpu_status st;
+        for (;;) {
+            hits_.resize(cap + 1);
+            st = cobs_gpu_search_batch(ix_, qp.data(), ql.data(), queries.size(), threshold,
+                                       num_results, hits_.data(), hits_.size(), offs.data(), &bad);
+            if (st == COBS_GPU_ERR_CAPACITY && offs[queries.size()] > cap) {
+                cap = offs[queries.size()];        // needed size, as documented in cobs_gpu.h
+                continue;
+            }
+            break;
+        }
         check(st);
         results.resize(queries.size());
         for (size_t q = 0; q < queries.size(); ++q) {
