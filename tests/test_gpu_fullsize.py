@@ -88,6 +88,46 @@ def test_full_size_config(gpu_lib, oracle, name):
     assert [(sc, d) for (_, d, sc) in hits] == order
 
 
+@pytest.mark.parametrize("bp", [50, 100, 150, 250])
+def test_full_size_short_reads(gpu_lib, oracle, bp):
+    """sequencing reads against the full-size C3 index: 8-bit scores (T <= 255), the multi-query
+    work-groups (<= 10 blocks) and a ragged batch; sampled exact equality + properties"""
+    import torch
+    cfg = bench.c3_config()
+    s = _open(gpu_lib, cfg)
+    ix = _oracle_index(oracle, cfg)
+    k = cfg["term_size"]
+    nq = 4099                                       # not a multiple of the 8 queries of a work-group
+    queries = bench.make_queries(nq, bp - k + 1, seed=bp)
+    ragged = [q[:k + (i * 7) % (bp - k + 1)] for i, q in enumerate(queries)]     # 1 .. T terms
+    for qs in (queries, ragged):
+        b = gpu_lib.Batch(s)
+        b.set_queries(qs)
+        b.run(0.0)
+        b.sync()
+        t = b.counts_tensor()
+        assert t.dtype == torch.uint8 and tuple(t.shape) == (nq, s.local_counts)
+        for i in (0, 1, 7, 8, nq // 2, nq - 2, nq - 1):
+            assert np.array_equal(b.counts_host(i), ix.counts(qs[i])), (bp, i)
+        terms = torch.tensor([len(q) - k + 1 for q in qs], device=t.device)
+        assert bool((t.max(dim=1).values.to(torch.int64) <= terms).all())
+        assert not bool(t[:, cfg["num_docs"]:].any())            # padding documents never score
+        # batch-position independence: the same reads in reversed order, device-side row sums
+        b2 = gpu_lib.Batch(s)
+        b2.set_queries(qs[::-1])
+        b2.run(0.0)
+        b2.sync()
+        s1 = t.to(torch.int64).sum(dim=1).cpu().numpy()
+        s2 = b2.counts_tensor().to(torch.int64).sum(dim=1).cpu().numpy()
+        assert np.array_equal(s1, s2[::-1])
+        # exact top-5 on the device (K3 over 8-bit scores) vs the oracle's ranking
+        b.run_topk(0.0, 5)
+        b.sync()
+        for i in (0, 9, nq - 1):
+            want = [(f, d, sc) for (f, d, _n, sc) in oracle.search(ix, qs[i], 0.0, 5)]
+            assert b.hits_host(i, 5) == want, (bp, i)
+
+
 def test_large_files_cross_staging_boundaries(gpu_lib, oracle, construct, tmp_path):
     """file-backed indexes big enough to cross the 64 MiB re-pitch chunks and the 1 GiB
     straight-copy steps of the upload path"""
