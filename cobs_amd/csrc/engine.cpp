@@ -211,6 +211,7 @@ struct cobs_gpu_batch {
     uint32_t hit_cap = 0;
     // last run
     bool ran = false, selected = false, synced = false;
+    bool have_counts = false;         // the last run wrote the score rows
     double threshold = 0.0;
     uint32_t h_flags[2] = {0xFFFFFFFFu, 0};
     std::vector<HitDev> h_hits;       // pool copy, sorted by query
@@ -1000,7 +1001,10 @@ cobs_gpu_status cobs_gpu_batch_set_queries(cobs_gpu_batch* b, const char* const*
     return COBS_GPU_OK;
 }
 
-static cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk, void* hip_stream) {
+// want_counts = false: the caller only needs the selected hits (threshold > 0, no top-k), so the
+// scan does not write the score rows (for reads they are up to a third of the traffic).
+static cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk, void* hip_stream,
+                                bool want_counts = true) {
     if (!b) return fail(COBS_GPU_ERR_ARG, "NULL batch");
     cobs_gpu_index* ix = b->ix;
     hipStream_t st = (hipStream_t)hip_stream;
@@ -1018,6 +1022,7 @@ static cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk
     b->topk_k = use_topk ? (uint32_t)topk : 0;
     // with K3 the threshold is applied there; otherwise K2 selects into the hit pool
     b->selected = threshold > 0.0 && !use_topk;
+    b->have_counts = want_counts || !b->selected;
     const bool need_thr = threshold > 0.0;
     if (use_topk) {
         HIP_TRY(b->topk_out.reserve((size_t)topk * std::max<size_t>(nq, 1) * ix->parts.size()));
@@ -1093,7 +1098,7 @@ static cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk
             sa.num_hashes = (uint32_t)p.meta.num_hashes;
             sa.num_docs = (uint32_t)p.meta.doc_names.size();
             sa.part = (uint32_t)f;
-            sa.write_counts = 1;
+            sa.write_counts = b->have_counts ? 1 : 0;
             const ScanGeom geom = scan_geometry(c, b->work[f].h_blk_off[nq] / nq, (b->max_terms + 7) / 8,
                                                  p.meta.num_hashes, ix->waves_per_group, b->planes);
             const int nwaves = geom.nwaves;
@@ -1200,6 +1205,7 @@ static inline uint32_t score_at(const uint8_t* row, uint32_t elem_bytes, uint64_
 // local count row of query q, widened to u32, scattered into a global-layout vector
 static cobs_gpu_status fetch_counts(cobs_gpu_batch* b, size_t q, uint32_t* counts) {
     cobs_gpu_index* ix = b->ix;
+    if (!b->have_counts) return fail(COBS_GPU_ERR_ARG, "the last run did not keep the score rows");
     const uint8_t* raw = nullptr;
     cobs_gpu_status st = fetch_row(b, q, &raw);
     if (st != COBS_GPU_OK) return st;
@@ -1228,6 +1234,7 @@ static cobs_gpu_status fetch_counts(cobs_gpu_batch* b, size_t q, uint32_t* count
 static cobs_gpu_status rank_row(cobs_gpu_batch* b, size_t q, size_t num_results, cobs_gpu_hit* hits, size_t cap,
                                 size_t* n_hits) {
     cobs_gpu_index* ix = b->ix;
+    if (!b->have_counts) return fail(COBS_GPU_ERR_ARG, "the last run did not keep the score rows");
     const uint8_t* raw = nullptr;
     cobs_gpu_status st = fetch_row(b, q, &raw);
     if (st != COBS_GPU_OK) return st;
@@ -1405,9 +1412,17 @@ static cobs_gpu_status run_host_batch(cobs_gpu_index* ix, const char* const* que
     if (st != COBS_GPU_OK) return st;
     double t1 = now_s();
     ix->timers[1] += t1 - t0;
-    st = run_impl(b, threshold, topk, nullptr);
+    // with a threshold and no limit only the selected hits travel back: skip the score rows,
+    // unless the hit pool overflows (then the pass is repeated with them and ranked on the host)
+    const bool hits_only = threshold > 0.0 && topk == 0;
+    st = run_impl(b, threshold, topk, nullptr, !hits_only);
     if (st != COBS_GPU_OK) return st;
     st = cobs_gpu_batch_sync(b, nullptr, bad_query);
+    if (st == COBS_GPU_OK && !b->have_counts && b->h_flags[1] > b->hit_cap) {
+        st = run_impl(b, threshold, topk, nullptr, true);
+        if (st != COBS_GPU_OK) return st;
+        st = cobs_gpu_batch_sync(b, nullptr, bad_query);
+    }
     double t2 = now_s();
     if (st == COBS_GPU_OK || st == COBS_GPU_ERR_INVALID_BASE) {
         float sm = 0, hm = 0;

@@ -340,3 +340,26 @@ def test_default_python_call_ranks_every_document(gpu_lib, oracle, tmp_path):
         assert [(r.doc_name, r.score) for r in got] == [(n, sc) for (_, _, n, sc) in want]
         got5 = s.search(query, 0.0, 5)
         assert [(r.doc_name, r.score) for r in got5] == [(n, sc) for (_, _, n, sc) in want[:5]]
+
+
+def test_hit_pool_overflow_is_ranked_from_the_score_rows(gpu_lib, oracle, tmp_path):
+    """a low threshold on many queries selects more hits than the device pool holds (1 Mi):
+    the host API repeats the pass with score rows and ranks them; results unchanged"""
+    q = oracle.random_sequence(2000, 77)
+    D = 3100
+    p = cases.make_classic(cases.tmp(tmp_path, "pool.cobs_classic"), D, 1511, 1, 31, 1, 0.3, 9,
+                           planted={5: 1.0, 3000: 0.6}, query=q[:200])
+    ix = oracle.Index.open(p)
+    s = gpu_lib.Search(p)
+    queries = [q[i:i + 100 + (i % 50)] for i in range(420)]
+    offs, hits = s.search_arrays(queries, 0.05, 0)
+    assert int(offs[-1]) > (1 << 20)                 # more than the pool
+    for i in (0, 1, 200, 419):
+        want = [(f, d, sc) for (f, d, _n, sc) in oracle.search(ix, queries[i], 0.05, 0)]
+        got = hits[int(offs[i]):int(offs[i + 1])].tolist()
+        assert got == want, i
+    # and the common case right after it on the same handle: few hits, no score rows needed
+    offs2, hits2 = s.search_arrays(queries[:8], 0.9, 0)
+    for i in range(8):
+        want = [(f, d, sc) for (f, d, _n, sc) in oracle.search(ix, queries[i], 0.9, 0)]
+        assert hits2[int(offs2[i]):int(offs2[i + 1])].tolist() == want
