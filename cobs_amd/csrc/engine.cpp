@@ -1470,8 +1470,14 @@ cobs_gpu_status cobs_gpu_search_batch(cobs_gpu_index* ix, const char* const* que
             return st;
         }
         for (size_t q = g0; q < g1; ++q) {
-            double t0 = now_s();
             size_t n = 0;
+            const cobs_gpu_batch* sb = ix->scratch;
+            if (sb->selected && sb->pool_fetched && sb->h_flags[1] <= sb->hit_cap &&
+                sb->h_hit_off[q - g0] == sb->h_hit_off[q - g0 + 1]) {
+                hit_offsets[q + 1] = used;       // no document of this query reached the threshold
+                continue;
+            }
+            double t0 = now_s();
             st = cobs_gpu_batch_hits_host(ix->scratch, q - g0, num_results, overflow ? nullptr : hits + used,
                                           overflow ? 0 : cap - used, &n);
             ix->timers[4] += now_s() - t0;

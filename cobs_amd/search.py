@@ -147,10 +147,33 @@ class Search:
     def search_arrays(self, queries, threshold=0.0, num_results=0):
         """-> (offsets uint64 [nq + 1], hits structured array of (file_no, doc, score)):
         the hits of query i are hits[offsets[i]:offsets[i + 1]], in result order."""
-        qs = [_as_bytes(q) for q in queries]
-        nq = len(qs)
-        arr = (C.c_char_p * max(nq, 1))(*qs)
-        lens = (C.c_size_t * max(nq, 1))(*[len(q) for q in qs])
+        qs = [q if type(q) is bytes else _as_bytes(q) for q in queries]
+        offsets = np.zeros(len(qs) + 1, dtype=np.uint64)
+        np.cumsum(np.fromiter(map(len, qs), dtype=np.uint64, count=len(qs)), out=offsets[1:])
+        return self.search_packed(b"".join(qs), offsets, threshold, num_results)
+
+    def search_packed(self, text, offsets, threshold=0.0, num_results=0):
+        """The same for queries packed back to back: query i is text[offsets[i]:offsets[i + 1]]
+        (text: bytes or a uint8 array, e.g. the sequence lines of a FASTQ block; offsets: nq + 1
+        integers).  No per-query Python objects: the pointer array is built with numpy."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        nq = len(offsets) - 1
+        if nq < 0:
+            raise ValueError("offsets needs nq + 1 entries")
+        if isinstance(text, np.ndarray):
+            text = np.ascontiguousarray(text, dtype=np.uint8)
+            base, size = text.ctypes.data, text.size
+        else:
+            text = bytes(text) if not isinstance(text, bytes) else text
+            base, size = C.cast(C.c_char_p(text), C.c_void_p).value or 0, len(text)
+        if nq and (int(offsets[-1]) > size or np.any(offsets[1:] < offsets[:-1])):
+            raise ValueError("offsets are not ascending positions inside text")
+        ptrs_np = (offsets[:-1] + np.uint64(base)) if nq else np.zeros(1, dtype=np.uint64)
+        lens_np = (offsets[1:] - offsets[:-1]) if nq else np.zeros(1, dtype=np.uint64)
+        ptrs_np = np.ascontiguousarray(ptrs_np)
+        lens_np = np.ascontiguousarray(lens_np)
+        arr = C.cast(ptrs_np.ctypes.data, C.POINTER(C.c_char_p))
+        lens = C.cast(lens_np.ctypes.data, C.POINTER(C.c_size_t))
         if num_results > 0:
             cap = nq * min(num_results, self.total_counts)
         elif threshold <= 0:

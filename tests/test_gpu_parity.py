@@ -363,3 +363,27 @@ def test_hit_pool_overflow_is_ranked_from_the_score_rows(gpu_lib, oracle, tmp_pa
     for i in range(8):
         want = [(f, d, sc) for (f, d, _n, sc) in oracle.search(ix, queries[i], 0.9, 0)]
         assert hits2[int(offs2[i]):int(offs2[i + 1])].tolist() == want
+
+
+def test_packed_queries(gpu_lib, oracle, golden_dir):
+    """search_packed: queries back to back in one buffer (bytes or uint8 array) + offsets"""
+    import os
+    p = os.path.join(golden_dir, "c1.cobs_compact")
+    s = gpu_lib.Search(p)
+    ix = oracle.Index.open(p)
+    qs = [Q50, Q50[3:40], Q50[10:41], Q50[:31]]
+    text = b"".join(qs)
+    offs = np.cumsum([0] + [len(q) for q in qs])
+    for buf in (text, np.frombuffer(text, dtype=np.uint8), bytearray(text)):
+        o, h = s.search_packed(buf, offs, 0.0, 0)
+        for i, q in enumerate(qs):
+            want = [(f, d, sc) for (f, d, _n, sc) in oracle.search(ix, q, 0.0, 0)]
+            assert h[int(o[i]):int(o[i + 1])].tolist() == want
+    o, h = s.search_packed(b"", [0], 0.5, 0)
+    assert len(h) == 0 and list(o) == [0]
+    with pytest.raises(ValueError):
+        s.search_packed(text, [0, len(text) + 1])
+    with pytest.raises(ValueError):
+        s.search_packed(text, [0, 40, 35])
+    with pytest.raises(gpu_lib.CobsGpuError):        # a 30-character slice is shorter than k = 31
+        s.search_packed(text, [0, 30])
