@@ -97,8 +97,8 @@ def test_compact_random_bits(gpu_lib, oracle, tmp_path, page_size, pages):
 
 
 def test_other_term_sizes(gpu_lib, oracle, tmp_path):
-    """k below 8, even k, k >= 32 (XXH64 stripe loop), k = 64"""
-    for k in (3, 12, 20, 32, 33, 47, 64):
+    """k below 8, even k, k >= 32 (XXH64 stripe loop), k = 64 and beyond (term_size is a uint32 in the file format)"""
+    for k in (3, 12, 20, 32, 33, 47, 64, 65, 100, 131):
         q = oracle.random_sequence(200, k)
         p = cases.make_classic(cases.tmp(tmp_path, "k%d.cobs_classic" % k), 77, 1009, 2, k, 1, 0.3, k,
                                planted={5: 1.0, 70: 0.7}, query=q)
