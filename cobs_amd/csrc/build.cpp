@@ -116,7 +116,7 @@ cobs_gpu_status build_matrix(const char* const* texts, const size_t* lens, size_
         text[(size_t)(off[d - d0] + lens[d])] = '\n';
     }
     const uint64_t row_bytes = (row_size + 3) / 4 * 4;
-    if (sig >= 0xFFFFFFFFull) return cobs_gpu_set_error(COBS_GPU_ERR_UNSUPPORTED, "signature_size must be below 2^32-1");
+    if (sig > (1ull << 46)) return cobs_gpu_set_error(COBS_GPU_ERR_UNSUPPORTED, "signature_size must be at most 2^46");
     DevMem d_text, d_off, d_mat;
     BUILD_TRY(hipMalloc(&d_text.p, std::max<size_t>((size_t)total, 1)));
     BUILD_TRY(hipMalloc(&d_off.p, off.size() * 8));

@@ -10,7 +10,7 @@ namespace cobs_amd {
 // padded query terms point at.
 struct PageDev {
     uint64_t base;         // byte offset of row 0 from the file's HBM blob
-    uint64_t sig;          // signature_size S_p (row index = hash % S_p), < 2^32
+    uint64_t sig;          // signature_size S_p (row index = hash % S_p)
     uint64_t magic;        // floor((2^64 - 1) / S_p) for the exact fast modulo
     uint32_t slot0;        // first local score slot of this page (multiple of 8)
     uint32_t doc0;         // file-level document id of the page's first document
@@ -25,13 +25,14 @@ struct HashArgs {
     const uint32_t* q_len;      // characters per query
     const uint64_t* blk_off;    // nq + 1 prefix sums of 8-term blocks per query
     const PageDev* pages;       // local sub-indexes
-    uint32_t* table;            // row indices: [q][page][block (nblk + 1 padding block)][hash][8]
+    void* table;                // row indices (u32, or u64 when idx64): [q][page][block (nblk + 1 padding block)][hash][8]
     uint32_t* err_query;        // atomicMin of queries holding a non-ACGT base
     uint32_t nq;
     uint32_t npages;
     uint32_t term_size;
     uint32_t canonicalize;
     uint32_t num_hashes;
+    uint32_t idx64;             // some sub-index has >= 2^32 - 1 rows: 64-bit table entries
 };
 
 // One selected (query, document) pair of the on-device threshold pass.
@@ -46,7 +47,7 @@ struct HitDev {
 struct ScanArgs {
     const uint8_t* blob;        // HBM blob of the file
     const PageDev* pages;
-    const uint32_t* table;      // from K1
+    const void* table;          // from K1 (u32 entries, u64 when idx64)
     const uint64_t* blk_off;    // nq + 1
     void* counts;               // u16 or u32 [nq][counts_stride]
     const uint32_t* thresholds; // per query (this file) or nullptr = no selection
@@ -67,6 +68,7 @@ struct ScanArgs {
     uint32_t tile_w;            // 16-byte chunks per tile: 4, 8, 16, 32 or 64
     uint32_t chunk_begin;       // this launch covers column chunks [chunk_begin, chunk_end)
     uint32_t chunk_end;
+    uint32_t idx64;             // 64-bit row indices in the table
 };
 
 // Arguments of the top-k selection kernel K3 for one index file (u16 scores).

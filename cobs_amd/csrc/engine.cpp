@@ -119,6 +119,7 @@ struct Part {
     uint64_t col0 = 0, ncols = 0;            // row bytes [col0, col0+ncols) of each held sub-index
     std::vector<Chunk> chunks;
     bool streamed = false;
+    bool idx64 = false;                      // a sub-index has >= 2^32 - 1 rows: 64-bit row-index table
     size_t hbm_bytes = 0;
     uint32_t max_chunk_pages = 0;
     // streaming state (BASELINE config 5: index larger than the HBM budget)
@@ -296,7 +297,7 @@ uint64_t slice_bytes(uint64_t sig, uint64_t ncols) {
 struct ScanGeom { uint32_t tile_w; int nwaves; bool multi_query; };
 
 ScanGeom scan_geometry(const Chunk& c, uint64_t mean_blocks, uint64_t max_blocks, uint64_t num_hashes,
-                       uint32_t forced_waves, int planes) {
+                       uint32_t forced_waves, int planes, bool idx64) {
     uint32_t nv = 1;
     while (nv < 32 && (uint64_t)nv * 2 * 7 <= mean_blocks * 4) nv <<= 1;     // blocks / NV >= 1.75
     ScanGeom g;
@@ -341,7 +342,7 @@ ScanGeom scan_geometry(const Chunk& c, uint64_t mean_blocks, uint64_t max_blocks
     g.multi_query = false;
     int mq_env = -1;                           // tuning hook: COBS_GPU_MQ=0/1 forces the variant
     if (const char* e = getenv("COBS_GPU_MQ")) mq_env = atoi(e) != 0;
-    if (mq_env != 0 && forced_waves == 0 && mean_blocks <= 10 && max_blocks <= 20 && c.total_chunks >= 8 &&
+    if (mq_env != 0 && !idx64 && forced_waves == 0 && mean_blocks <= 10 && max_blocks <= 20 && c.total_chunks >= 8 &&
         scan_has_multi_query(planes, (uint32_t)num_hashes, 8)) {
         g.multi_query = true;
         g.tile_w = 8;
@@ -355,7 +356,7 @@ ScanGeom scan_geometry(const Chunk& c, uint64_t mean_blocks, uint64_t max_blocks
             if (v == 4 || v == 8 || v == 16 || v == 32) g.tile_w = (uint32_t)v;
         }
     }
-    if (mq_env == 1) g.multi_query = true;
+    if (mq_env == 1 && !idx64) g.multi_query = true;
     if (g.multi_query && !scan_has_multi_query(planes, (uint32_t)num_hashes, g.tile_w)) g.multi_query = false;
     return g;
 }
@@ -399,8 +400,12 @@ cobs_gpu_status plan_part(Part& pt, uint32_t rank, uint32_t count, uint64_t* bud
     if (m.canonicalize > 1)
         return fail(COBS_GPU_ERR_FORMAT, "Unknown canonicalize value " + std::to_string(m.canonicalize));
     for (uint64_t s : m.signature_sizes)
-        if (s == 0 || s >= 0xFFFFFFFFull)
-            return fail(COBS_GPU_ERR_UNSUPPORTED, "signature_size must be in 1..2^32-2");
+        if (s == 0 || s > (1ull << 46))
+            return fail(COBS_GPU_ERR_UNSUPPORTED, "signature_size must be in 1..2^46");
+    // row indices are 32-bit unless a sub-index (plus its zero row) does not fit them
+    pt.idx64 = false;
+    for (uint64_t s : m.signature_sizes)
+        if (s >= 0xFFFFFFFFull) pt.idx64 = true;
     if (m.counts_size() > 0xFFFFFFF0ull)
         return fail(COBS_GPU_ERR_UNSUPPORTED, "more than 2^32 score slots in one file");
     const uint64_t prb = m.page_row_bytes();
@@ -978,8 +983,9 @@ cobs_gpu_status cobs_gpu_batch_set_queries(cobs_gpu_batch* b, const char* const*
         }
         w.h_blk_off[nq] = blk;
         // per (query, sub-index): its 8-term blocks plus one padding block
-        w.table_entries = (blk + nq) * 8 * p.meta.num_hashes * p.max_chunk_pages;
-        table_bytes += ((blk + nq) * 8 * p.meta.num_hashes * p.num_vpages()) * 4;
+        const uint64_t idx_words = p.idx64 ? 2 : 1;      // u32 words per table entry
+        w.table_entries = (blk + nq) * 8 * p.meta.num_hashes * p.max_chunk_pages * idx_words;
+        table_bytes += ((blk + nq) * 8 * p.meta.num_hashes * p.num_vpages()) * 4 * idx_words;
         if (w.table_entries >= (1ull << 40)) return fail(COBS_GPU_ERR_CAPACITY, "batch too large");
         HIP_TRY(w.blk_off.reserve(nq + 1));
         HIP_TRY(w.table.reserve((size_t)w.table_entries));
@@ -1073,6 +1079,7 @@ static cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk
             ha.term_size = p.meta.term_size;
             ha.canonicalize = p.meta.canonicalize;
             ha.num_hashes = (uint32_t)p.meta.num_hashes;
+            ha.idx64 = p.idx64 ? 1u : 0u;
             HIP_TRY(launch_hash(ha, b->span_off[nq], st));
             if (!hash_marked) {      // K1 / K2 split of the timing events: first chunk only
                 HIP_TRY(hipEventRecord(ev[1], st));
@@ -1099,8 +1106,9 @@ static cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk
             sa.num_docs = (uint32_t)p.meta.doc_names.size();
             sa.part = (uint32_t)f;
             sa.write_counts = b->have_counts ? 1 : 0;
+            sa.idx64 = p.idx64 ? 1u : 0u;
             const ScanGeom geom = scan_geometry(c, b->work[f].h_blk_off[nq] / nq, (b->max_terms + 7) / 8,
-                                                 p.meta.num_hashes, ix->waves_per_group, b->planes);
+                                                 p.meta.num_hashes, ix->waves_per_group, b->planes, p.idx64);
             const int nwaves = geom.nwaves;
             sa.tile_w = geom.tile_w;
             sa.chunk_begin = 0;

@@ -36,12 +36,12 @@ __device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) 
 
 // exact n % d with the precomputed m = floor((2^64-1)/d); the estimate
 // q = hi64(n*m) is at most 2 below the true quotient.
-__device__ __forceinline__ uint32_t fast_mod(uint64_t n, uint64_t d, uint64_t m) {
+__device__ __forceinline__ uint64_t fast_mod(uint64_t n, uint64_t d, uint64_t m) {
     uint64_t q = __umul64hi(n, m);
     uint64_t r = n - q * d;
     if (r >= d) r -= d;
     if (r >= d) r -= d;
-    return (uint32_t)r;
+    return r;
 }
 
 __device__ __forceinline__ uint32_t fwd_base(uint32_t c) {
@@ -131,6 +131,7 @@ __device__ uint64_t xxh64_view(const KmerView& kv, uint64_t seed) {
     return h;
 }
 
+template <typename IdxT>
 __global__ __launch_bounds__(256) void hash_kernel(HashArgs a, uint64_t total_threads) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total_threads) return;
@@ -163,12 +164,12 @@ __global__ __launch_bounds__(256) void hash_kernel(HashArgs a, uint64_t total_th
     if (i >= tblk * 8u) return;
     const uint32_t H = a.num_hashes;
     const uint32_t blk = i >> 3, sub = i & 7u;
-    uint32_t* out = a.table + ((b0 + q) * a.npages) * (8ull * H);
+    IdxT* out = reinterpret_cast<IdxT*>(a.table) + ((b0 + q) * a.npages) * (8ull * H);
 
     if (i >= T) {       // padding term: the all-zero row of every sub-index
         for (uint32_t p = 0; p < a.npages; ++p) {
-            const uint32_t zr = (uint32_t)a.pages[p].sig;
-            uint32_t* o = out + ((uint64_t)p * tblk + blk) * (8ull * H) + sub;
+            const IdxT zr = (IdxT)a.pages[p].sig;
+            IdxT* o = out + ((uint64_t)p * tblk + blk) * (8ull * H) + sub;
             for (uint32_t j = 0; j < H; ++j) o[j * 8] = zr;
         }
         return;
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void hash_kernel(HashArgs a, uint64_t total_th
         const uint64_t h = xxh64_view(kv, (uint64_t)j);
         for (uint32_t p = 0; p < a.npages; ++p) {
             const PageDev pg = a.pages[p];
-            out[((uint64_t)p * tblk + blk) * (8ull * H) + j * 8 + sub] = fast_mod(h, pg.sig, pg.magic);
+            out[((uint64_t)p * tblk + blk) * (8ull * H) + j * 8 + sub] = (IdxT)fast_mod(h, pg.sig, pg.magic);
         }
     }
 }
@@ -227,6 +228,7 @@ __device__ __forceinline__ uint64_t xxh64_31(const uint32_t (&c)[8], uint64_t se
     return h;
 }
 
+template <typename IdxT>
 __global__ __launch_bounds__(256) void hash_kernel_k31(HashArgs a, uint64_t total_threads) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total_threads) return;
@@ -250,11 +252,11 @@ __global__ __launch_bounds__(256) void hash_kernel_k31(HashArgs a, uint64_t tota
     if (i >= tblk * 8u) return;
     const uint32_t H = a.num_hashes;
     const uint32_t blk = i >> 3, sub = i & 7u;
-    uint32_t* out = a.table + ((b0 + q) * a.npages) * (8ull * H);
+    IdxT* out = reinterpret_cast<IdxT*>(a.table) + ((b0 + q) * a.npages) * (8ull * H);
     if (i >= T) {
         for (uint32_t p = 0; p < a.npages; ++p) {
-            const uint32_t zr = (uint32_t)a.pages[p].sig;
-            uint32_t* o = out + ((uint64_t)p * tblk + blk) * (8ull * H) + sub;
+            const IdxT zr = (IdxT)a.pages[p].sig;
+            IdxT* o = out + ((uint64_t)p * tblk + blk) * (8ull * H) + sub;
             for (uint32_t j = 0; j < H; ++j) o[j * 8] = zr;
         }
         return;
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(256) void hash_kernel_k31(HashArgs a, uint64_t tota
         const uint64_t h = xxh64_31(c, (uint64_t)j);
         for (uint32_t p = 0; p < a.npages; ++p) {
             const PageDev pg = a.pages[p];
-            out[((uint64_t)p * tblk + blk) * (8ull * H) + j * 8 + sub] = fast_mod(h, pg.sig, pg.magic);
+            out[((uint64_t)p * tblk + blk) * (8ull * H) + j * 8 + sub] = (IdxT)fast_mod(h, pg.sig, pg.magic);
         }
     }
 }
@@ -386,23 +388,53 @@ __device__ __forceinline__ void retire_pair(uint32_t (&pl)[4][NP], const uint32_
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <bool NT>
-__device__ __forceinline__ uint4 load_row(const uint8_t* lane_base, uint32_t row, uint32_t pitch) {
-    const u32x4* p = reinterpret_cast<const u32x4*>(lane_base + (uint64_t)row * pitch);
+__device__ __forceinline__ uint4 load_row(const uint8_t* lane_base, uint64_t row, uint32_t pitch) {
+    const u32x4* p = reinterpret_cast<const u32x4*>(lane_base + row * pitch);
     const u32x4 v = NT ? __builtin_nontemporal_load(p) : *p;
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// Eight row indices of one (block, hash): 32-bit (two 16-byte loads) or, for sub-indexes with
+// 2^32 or more rows (signature sizes of human-sized documents), 64-bit (four loads).
+template <typename IdxT> struct Idx8;
+template <> struct Idx8<uint32_t> { uint4 a, b; };
+template <> struct Idx8<uint64_t> { uint4 a, b, c, d; };
+
+__device__ __forceinline__ Idx8<uint32_t> load_idx8(const uint32_t* p) {
+    const uint4* t = reinterpret_cast<const uint4*>(p);
+    return Idx8<uint32_t>{t[0], t[1]};
+}
+__device__ __forceinline__ Idx8<uint64_t> load_idx8(const uint64_t* p) {
+    const uint4* t = reinterpret_cast<const uint4*>(p);
+    return Idx8<uint64_t>{t[0], t[1], t[2], t[3]};
+}
+
 template <bool NT>
 __device__ __forceinline__ void issue_rows(uint4 (&X)[8], const uint8_t* lane_base, uint32_t pitch,
-                                           const uint4& i0, const uint4& i1) {
-    X[0] = load_row<NT>(lane_base, i0.x, pitch);
-    X[1] = load_row<NT>(lane_base, i0.y, pitch);
-    X[2] = load_row<NT>(lane_base, i0.z, pitch);
-    X[3] = load_row<NT>(lane_base, i0.w, pitch);
-    X[4] = load_row<NT>(lane_base, i1.x, pitch);
-    X[5] = load_row<NT>(lane_base, i1.y, pitch);
-    X[6] = load_row<NT>(lane_base, i1.z, pitch);
-    X[7] = load_row<NT>(lane_base, i1.w, pitch);
+                                           const Idx8<uint32_t>& i) {
+    X[0] = load_row<NT>(lane_base, i.a.x, pitch);
+    X[1] = load_row<NT>(lane_base, i.a.y, pitch);
+    X[2] = load_row<NT>(lane_base, i.a.z, pitch);
+    X[3] = load_row<NT>(lane_base, i.a.w, pitch);
+    X[4] = load_row<NT>(lane_base, i.b.x, pitch);
+    X[5] = load_row<NT>(lane_base, i.b.y, pitch);
+    X[6] = load_row<NT>(lane_base, i.b.z, pitch);
+    X[7] = load_row<NT>(lane_base, i.b.w, pitch);
+}
+
+__device__ __forceinline__ uint64_t u64_of(uint32_t lo, uint32_t hi) { return (uint64_t)hi << 32 | lo; }
+
+template <bool NT>
+__device__ __forceinline__ void issue_rows(uint4 (&X)[8], const uint8_t* lane_base, uint32_t pitch,
+                                           const Idx8<uint64_t>& i) {
+    X[0] = load_row<NT>(lane_base, u64_of(i.a.x, i.a.y), pitch);
+    X[1] = load_row<NT>(lane_base, u64_of(i.a.z, i.a.w), pitch);
+    X[2] = load_row<NT>(lane_base, u64_of(i.b.x, i.b.y), pitch);
+    X[3] = load_row<NT>(lane_base, u64_of(i.b.z, i.b.w), pitch);
+    X[4] = load_row<NT>(lane_base, u64_of(i.c.x, i.c.y), pitch);
+    X[5] = load_row<NT>(lane_base, u64_of(i.c.z, i.c.w), pitch);
+    X[6] = load_row<NT>(lane_base, u64_of(i.d.x, i.d.y), pitch);
+    X[7] = load_row<NT>(lane_base, u64_of(i.d.z, i.d.w), pitch);
 }
 
 __device__ __forceinline__ void and_rows(uint4 (&X)[8], const uint4 (&Y)[8]) {
@@ -417,7 +449,7 @@ __device__ __forceinline__ void and_rows(uint4 (&X)[8], const uint4 (&Y)[8]) {
 // group then walks all blocks of its own query (divided over the NW waves only): G times
 // more trips per wave, so the load pipeline reaches its steady state even for 100-bp reads,
 // and the cross-lane merge disappears.
-template <int NP, int NW, bool H1, typename OutT, bool MQ>
+template <int NP, int NW, bool H1, typename OutT, bool MQ, typename IdxT>
 __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     // row loads stay temporal: non-temporal loads measured 18 % slower (they bypass the Infinity Cache)
     constexpr bool NT = false;
@@ -475,7 +507,8 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     const uint32_t nblk = qlive ? nblk_q : 0u;
     const uint32_t H = H1 ? 1u : a.num_hashes;
     // row indices of this lane's sub-index: [nblk + 1 blocks][hash][8]; block nblk is all padding
-    const uint32_t* tab = a.table + ((b0 + q) * a.npages + (uint64_t)pg * (nblk_q + 1u)) * (8ull * H);
+    const IdxT* tab = reinterpret_cast<const IdxT*>(a.table) +
+                      ((b0 + q) * a.npages + (uint64_t)pg * (nblk_q + 1u)) * (8ull * H);
     const uint32_t vw = MQ ? wave : wave * G + grp;  // virtual wave of this lane
     const uint32_t NV = MQ ? (uint32_t)NW : NW * G;
     // block of this lane in trip i: vw + i * NV, or the padding block when it has run out
@@ -509,27 +542,23 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
         // so that 8..16 row loads (8..16 KiB per wave) are always in flight.
         if (nw > 0) {
             uint4 XA[8], XB[8];
-            const uint4* t0 = reinterpret_cast<const uint4*>(tab + blk_of(0));
-            uint4 i0a = t0[0], i0b = t0[1];
-            issue_rows<NT>(XA, lane_base, pitch, i0a, i0b);
-            const uint4* t1 = reinterpret_cast<const uint4*>(tab + blk_of(1));
-            uint4 i1a = t1[0], i1b = t1[1];
+            Idx8<IdxT> i0 = load_idx8(tab + blk_of(0));
+            issue_rows<NT>(XA, lane_base, pitch, i0);
+            Idx8<IdxT> i1 = load_idx8(tab + blk_of(1));
             uint32_t i = 0;
             for (; i + 2 < nw; i += 2) {
-                // XA in flight = trip i, (i1a,i1b) = indices of trip i+1
-                const uint4* tn = reinterpret_cast<const uint4*>(tab + blk_of(i + 2));
-                i0a = tn[0]; i0b = tn[1];
-                issue_rows<NT>(XB, lane_base, pitch, i1a, i1b);
+                // XA in flight = trip i, i1 = indices of trip i+1
+                i0 = load_idx8(tab + blk_of(i + 2));
+                issue_rows<NT>(XB, lane_base, pitch, i1);
                 absorb_block<NP>(pl, XA, ea);
-                const uint4* tm = reinterpret_cast<const uint4*>(tab + blk_of(i + 3));
-                i1a = tm[0]; i1b = tm[1];
-                issue_rows<NT>(XA, lane_base, pitch, i0a, i0b);
+                i1 = load_idx8(tab + blk_of(i + 3));
+                issue_rows<NT>(XA, lane_base, pitch, i0);
                 absorb_block<NP>(pl, XB, eb);
                 retire_pair<NP>(pl, ea, eb);
             }
             // XA in flight = trip i; one or two trips left
             if (i + 1 < nw) {
-                issue_rows<NT>(XB, lane_base, pitch, i1a, i1b);
+                issue_rows<NT>(XB, lane_base, pitch, i1);
                 absorb_block<NP>(pl, XA, ea);
                 absorb_block<NP>(pl, XB, eb);
                 retire_pair<NP>(pl, ea, eb);
@@ -542,10 +571,10 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
         // general H: AND the H hash rows of each term first (aggregate_rows)
         uint4 X[8], Y[8];
         for (uint32_t i = 0; i < nw; ++i) {
-            const uint4* t = reinterpret_cast<const uint4*>(tab + blk_of(i));
-            issue_rows<NT>(X, lane_base, pitch, t[0], t[1]);
+            const IdxT* t = tab + blk_of(i);
+            issue_rows<NT>(X, lane_base, pitch, load_idx8(t));
             for (uint32_t j = 1; j < H; ++j) {
-                issue_rows<NT>(Y, lane_base, pitch, t[2 * j], t[2 * j + 1]);
+                issue_rows<NT>(Y, lane_base, pitch, load_idx8(t + 8u * j));
                 and_rows(X, Y);
             }
             absorb_block<NP>(pl, X, ea);
@@ -1023,14 +1052,17 @@ hipError_t launch_hash(const HashArgs& a, uint64_t total_threads, hipStream_t st
     if (total_threads == 0) return hipSuccess;
     const uint64_t blocks = (total_threads + 255) / 256;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    if (a.term_size == 31)
-        hipLaunchKernelGGL(hash_kernel_k31, dim3((uint32_t)blocks), dim3(256), 0, stream, a, total_threads);
-    else
-        hipLaunchKernelGGL(hash_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, a, total_threads);
+    if (a.term_size == 31) {
+        if (a.idx64) hipLaunchKernelGGL(hash_kernel_k31<uint64_t>, dim3((uint32_t)blocks), dim3(256), 0, stream, a, total_threads);
+        else hipLaunchKernelGGL(hash_kernel_k31<uint32_t>, dim3((uint32_t)blocks), dim3(256), 0, stream, a, total_threads);
+    } else {
+        if (a.idx64) hipLaunchKernelGGL(hash_kernel<uint64_t>, dim3((uint32_t)blocks), dim3(256), 0, stream, a, total_threads);
+        else hipLaunchKernelGGL(hash_kernel<uint32_t>, dim3((uint32_t)blocks), dim3(256), 0, stream, a, total_threads);
+    }
     return hipGetLastError();
 }
 
-template <int NP, int NW, bool H1, typename OutT, bool MQ = false>
+template <int NP, int NW, bool H1, typename OutT, bool MQ = false, typename IdxT = uint32_t>
 static hipError_t launch_scan_inst(const ScanArgs& a, uint32_t ntiles, hipStream_t stream) {
     (void)ntiles;
     const uint32_t per_group = MQ ? 64u / a.tile_w : 1u;
@@ -1039,7 +1071,7 @@ static hipError_t launch_scan_inst(const ScanArgs& a, uint32_t ntiles, hipStream
     if (groups == 0) return hipSuccess;
     if (groups > 0x7FFFFFFFull) return hipErrorInvalidValue;
     constexpr size_t lds = ((size_t)(NW >= 2 ? NW / 2 : 1) * NP * 64 + 256) * sizeof(uint4);
-    auto kern = scan_kernel<NP, NW, H1, OutT, MQ>;
+    auto kern = scan_kernel<NP, NW, H1, OutT, MQ, IdxT>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1059,6 +1091,12 @@ static hipError_t launch_scan_mq(const ScanArgs& a, uint32_t ntiles, int nw, hip
 
 template <int NP, typename OutT>
 static hipError_t launch_scan_np(const ScanArgs& a, uint32_t ntiles, bool h1, int nw, hipStream_t stream) {
+    if (a.idx64) {
+        // sub-indexes with >= 2^32 rows: 64-bit row indices; two waves per group cover every
+        // query length well enough for this rare geometry (keeps the instantiation count down)
+        return h1 ? launch_scan_inst<NP, 2, true, OutT, false, uint64_t>(a, ntiles, stream)
+                  : launch_scan_inst<NP, 2, false, OutT, false, uint64_t>(a, ntiles, stream);
+    }
     if (nw == 1)
         return h1 ? launch_scan_inst<NP, 1, true, OutT>(a, ntiles, stream)
                   : launch_scan_inst<NP, 1, false, OutT>(a, ntiles, stream);
@@ -1086,7 +1124,7 @@ hipError_t launch_scan(const ScanArgs& a, uint32_t ntiles, int planes, int nw, b
                        hipStream_t stream) {
     const bool h1 = a.num_hashes == 1;
     if (multi_query) {
-        if (!scan_has_multi_query(planes, a.num_hashes, a.tile_w)) return hipErrorInvalidValue;
+        if (a.idx64 || !scan_has_multi_query(planes, a.num_hashes, a.tile_w)) return hipErrorInvalidValue;
         switch (planes) {
         case 4: return launch_scan_mq<4, uint8_t>(a, ntiles, nw, stream);
         case 8: return launch_scan_mq<8, uint8_t>(a, ntiles, nw, stream);

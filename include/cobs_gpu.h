@@ -33,7 +33,7 @@ typedef enum cobs_gpu_status {
     COBS_GPU_ERR_QUERY_TOO_LONG = 5,  /* "query too long" (:323-327, :501-503) */
     COBS_GPU_ERR_HIP = 6,             /* HIP runtime error, text in cobs_gpu_last_error() */
     COBS_GPU_ERR_ARG = 7,             /* NULL / out-of-range argument */
-    COBS_GPU_ERR_UNSUPPORTED = 8,     /* legal index the engine cannot hold (e.g. signature_size >= 2^32) */
+    COBS_GPU_ERR_UNSUPPORTED = 8,     /* legal index the engine cannot hold (e.g. more than 2^32 score slots in one file) */
     COBS_GPU_ERR_CAPACITY = 9,        /* caller buffer too small; *n_out holds the needed size */
     COBS_GPU_ERR_NO_DEVICE = 10       /* no HIP device (the library has no CPU fallback) */
 } cobs_gpu_status;

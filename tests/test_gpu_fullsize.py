@@ -128,6 +128,41 @@ def test_full_size_short_reads(gpu_lib, oracle, bp):
             assert b.hits_host(i, 5) == want, (bp, i)
 
 
+@pytest.mark.parametrize("kind", ["classic", "compact"])
+def test_signature_size_beyond_32_bits(gpu_lib, oracle, kind):
+    """sub-indexes with more than 2^32 rows (signature sizes of human-sized documents are ~10^10;
+    the reference's signature_size is a uint64): 64-bit row-index table, 69 GB of rows in HBM"""
+    S = (1 << 32) + 12345
+    if kind == "classic":
+        cfg = dict(kind="classic", signature_sizes=[S], num_docs=61, page_size=0, term_size=31,
+                   canonicalize=1, num_hashes=1, seed=11)
+    else:       # a small and a huge sub-index side by side share one table format
+        cfg = dict(kind="compact", signature_sizes=[1000003, S], num_docs=100, page_size=8, term_size=31,
+                   canonicalize=1, num_hashes=2, seed=12)
+    s = _open(gpu_lib, cfg)
+    ix = _oracle_index(oracle, cfg)
+    assert s.signature_size(0, len(cfg["signature_sizes"]) - 1) == S
+    queries = bench.make_queries(40, 300, seed=5) + bench.make_queries(3, 1, seed=6)
+    b = gpu_lib.Batch(s)
+    b.set_queries(queries)
+    b.run(0.0)
+    b.sync()
+    rows_beyond = 0
+    for i, q in enumerate(queries):
+        assert np.array_equal(b.counts_host(i), ix.counts(q)), (kind, i)
+    # the lookups really land beyond row 2^32 - 1 for a share of the terms
+    P = len(cfg["signature_sizes"])
+    width = cfg["page_size"] if kind == "compact" else (cfg["num_docs"] + 7) // 8
+    for row in (S - 1, (1 << 32) + 1, (1 << 32) - 1):
+        want = oracle.synth_row(1 if kind == "compact" else 0, cfg["seed"], cfg["page_size"], P,
+                                cfg["num_docs"], P - 1, row, width)
+        assert np.array_equal(s.read_row(0, P - 1, row, width), want)
+        rows_beyond += int(want.any())
+    assert rows_beyond > 0
+    got = s.search_hits(queries[:5], 0.3, 7)
+    assert got == [[(f, d, sc) for (f, d, _n, sc) in oracle.search(ix, q, 0.3, 7)] for q in queries[:5]]
+
+
 def test_large_files_cross_staging_boundaries(gpu_lib, oracle, construct, tmp_path):
     """file-backed indexes big enough to cross the 64 MiB re-pitch chunks and the 1 GiB
     straight-copy steps of the upload path"""
