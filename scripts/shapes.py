@@ -90,3 +90,7 @@ if __name__ == "__main__":
                     else:
                         os.environ.pop(k, None)
                 run("C3 T=%d Q=%dk mq=%d W=%d NW=%d" % (T, nq // 1000, mq, w, nw), "compact", c3, 100000, 1568, nq, T, steps=3)
+    if on("ssweep"):
+        # throughput vs slice working set at a fixed query length: 8 equal sub-indexes of S rows
+        for S in (8000000, 4000000, 2000000, 1000000, 500000, 250000, 125000, 62500):
+            run("8 x S=%dk T=1000 Q=10k" % (S // 1000), "compact", [S] * 8, 100000, 1568, 10000, 1000)
