@@ -122,3 +122,18 @@ def test_bench_query_stream_is_the_reference_benchmark_stream(oracle):
     cfg = bench.c3_config()
     assert cfg["signature_sizes"][0] == 250000 and cfg["signature_sizes"][-1] == 4000000
     assert len(cfg["signature_sizes"]) == 8 and cfg["page_size"] * 8 * 8 >= cfg["num_docs"]
+
+
+def test_header_is_plain_c_and_cpp(tmp_path):
+    """include/cobs_gpu.h is the FFI surface: it must compile as C99 (cgo / ctypes-style
+    consumers) and as C++17, and the C++ mirror must compile against it"""
+    import subprocess
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    c = tmp_path / "t.c"
+    c.write_text('#include "cobs_gpu.h"\nint main(void) { cobs_gpu_options o; o.struct_size = sizeof o; '
+                 'return (int)o.struct_size == 0; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc,
+                           "-fsyntax-only", str(c)])
+    cpp = tmp_path / "t.cpp"
+    cpp.write_text('#include "cobs_gpu_search.hpp"\nint main() { cobs_gpu::SearchResult r; return r.score != 0; }\n')
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", inc, "-fsyntax-only", str(cpp)])
