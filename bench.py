@@ -162,6 +162,87 @@ def end_to_end(search, batch, queries):
     return res
 
 
+def sharded_setup(s, queries, world, nsub, threshold):
+    """--shard-mode index: the batch is cut into sub-batches so that the all-gather of sub-batch i
+    (RCCL's own stream, xGMI) overlaps the scan of sub-batch i+1 (the stream the kernels are on).
+    RCCL has no 16-bit integer type: the count slices travel as bytes.  -> (step, sub-batches)"""
+    sub, gathered = [], []
+    nsub = max(1, min(nsub, len(queries)))
+    for i in range(nsub):
+        bi = cobs_amd.Batch(s)
+        bi.set_queries(queries[i * len(queries) // nsub:(i + 1) * len(queries) // nsub])
+        sub.append(bi)
+        local = bi.counts_tensor().view(torch.uint8).reshape(-1)
+        gathered.append(torch.empty((world * local.numel(),), dtype=torch.uint8, device="cuda"))
+
+    def step():
+        works = []
+        for bi, out in zip(sub, gathered):
+            bi.run(threshold, 0)
+            # per-document hit counts of the disjoint sub-index blocks -> every rank
+            works.append(dist.all_gather_into_tensor(out, bi.counts_tensor().view(torch.uint8).reshape(-1),
+                                                     async_op=True))
+        for w in works:
+            w.wait()
+    return step, sub, gathered
+
+
+def timed(step, steps, warmup, world, backend):
+    """the bench contract's timing: warm-up, barrier + synchronize on both sides, max over ranks"""
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def sharded_extra(args, cfg, world, rank, dev):
+    """N > 1, after the headline (replicated) measurement: the same 10k-query batch against the
+    index SHARDED by sub-index block over the ranks, per-document counts all-gathered over
+    RCCL/xGMI (north_star's multi-GPU layout; strong scaling).  Every rank must agree that its
+    set-up succeeded before the first collective, so a local failure cannot strand the others."""
+    ok, err, state = 1, "", None
+    try:
+        s = cobs_amd.Search.synthetic(cfg["kind"], cfg["signature_sizes"], cfg["num_docs"],
+                                      page_size=cfg["page_size"], term_size=cfg["term_size"],
+                                      canonicalize=cfg["canonicalize"], num_hashes=cfg["num_hashes"],
+                                      seed=cfg["seed"], device=dev, shard_rank=rank, shard_count=world)
+        queries = make_queries(args.queries, args.kmers)            # the same batch on every rank
+        step, sub, gathered = sharded_setup(s, queries, world, args.exchange_chunks, args.threshold)
+        state = (s, sub, gathered)
+    except Exception as e:                                          # noqa: BLE001
+        ok, err = 0, repr(e)
+    flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if args.dist_backend == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        return {"skipped": err or "set-up failed on another rank"}
+    steps = max(1, min(args.steps, 5))
+    dt = timed(step, steps, 1, world, args.dist_backend)
+    for bi in sub:
+        bi.sync()
+    scan_ms = sum(bi.kernel_ms()["scan_ms"] for bi in sub)
+    payload = sum(int(g.numel()) for g in gathered)
+    del state
+    return {"queries_per_s": round(args.queries * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
+            "steps": steps, "scaling": "strong", "scan_ms_per_step_rank0": round(scan_ms, 4),
+            "gathered_bytes_per_step": payload,
+            "parallelism": "index sharded by sub-index block x%d, %d sub-batches, async RCCL all-gather of the "
+                           "count slices overlapped with the next scan" % (world, len(sub))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,6 +262,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange-chunks", type=int, default=4,
                     help="--shard-mode index: sub-batches whose all-gather overlaps the next scan")
+    ap.add_argument("--no-sharded-extra", action="store_true",
+                    help="N>1, default mode: skip the additional index-sharded + RCCL all-gather measurement")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real multi-GPU runs; gloo only "
                     "for smoke-testing the launch path with several ranks on one GPU")
     args = ap.parse_args()
@@ -218,34 +301,17 @@ def main():
     batch = cobs_amd.Batch(s)
     batch.set_queries(mine)                    # H2D once; inputs now resident in HBM
 
-    sub, gathered = [], []
+    sub, gathered, sharded_step = [], [], None
     if shard_index:
-        # The batch is cut into sub-batches so that the all-gather of sub-batch i (RCCL's own
-        # stream, xGMI) overlaps the scan of sub-batch i+1 (the stream the kernels are on).
-        # RCCL has no 16-bit integer type: the u16 count slices travel as bytes.
-        nsub = max(1, min(args.exchange_chunks, len(mine)))
-        for i in range(nsub):
-            bi = cobs_amd.Batch(s)
-            bi.set_queries(mine[i * len(mine) // nsub:(i + 1) * len(mine) // nsub])
-            sub.append(bi)
-            local = bi.counts_tensor().view(torch.uint8).reshape(-1)
-            gathered.append(torch.empty((world * local.numel(),), dtype=torch.uint8, device="cuda"))
+        sharded_step, sub, gathered = sharded_setup(s, mine, world, args.exchange_chunks, args.threshold)
 
     def step():
-        if not shard_index:
-            if args.num_results > 0:
-                batch.run_topk(args.threshold, args.num_results, 0)
-            else:
-                batch.run(args.threshold, 0)
-            return
-        works = []
-        for bi, out in zip(sub, gathered):
-            bi.run(args.threshold, 0)
-            # per-document hit counts of the disjoint sub-index blocks -> every rank
-            works.append(dist.all_gather_into_tensor(out, bi.counts_tensor().view(torch.uint8).reshape(-1),
-                                                     async_op=True))
-        for w in works:
-            w.wait()
+        if shard_index:
+            sharded_step()
+        elif args.num_results > 0:
+            batch.run_topk(args.threshold, args.num_results, 0)
+        else:
+            batch.run(args.threshold, 0)
 
     for _ in range(args.warmup):
         step()
@@ -343,6 +409,10 @@ def main():
             "hash_ms_per_launch": round(ms["hash_ms"], 4),
         },
     }
+    if world > 1 and not shard_index and not args.no_sharded_extra:
+        del batch, s
+        extra = sharded_extra(args, cfg, world, rank, dev)
+        out["index_sharded"] = extra
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["end_to_end"] = end_to_end(s, batch, mine)
         out["cpu_baseline"] = cpu_baseline(s, cfg, mine, batch=batch)
