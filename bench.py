@@ -225,10 +225,15 @@ def sharded_extra(args, cfg, world, rank, dev):
         state = (s, sub, gathered)
     except Exception as e:                                          # noqa: BLE001
         ok, err = 0, repr(e)
-    flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if args.dist_backend == "nccl" else "cpu")
+    # all_gather_into_tensor needs equal slices: 8 sub-indexes over 2, 4 or 8 ranks are; anything else is skipped
+    n_local = int(state[2][0].numel()) // world if ok else 0
+    flag = torch.tensor([ok, n_local, -n_local], dtype=torch.int64,
+                        device="cuda" if args.dist_backend == "nccl" else "cpu")
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    if int(flag.item()) == 0:
+    if int(flag[0].item()) == 0:
         return {"skipped": err or "set-up failed on another rank"}
+    if int(flag[1].item()) != -int(flag[2].item()):
+        return {"skipped": "ranks hold count slices of different sizes"}
     steps = max(1, min(args.steps, 5))
     dt = timed(step, steps, 1, world, args.dist_backend)
     for bi in sub:
