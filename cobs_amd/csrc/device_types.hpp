@@ -49,7 +49,7 @@ struct ScanArgs {
     const PageDev* pages;
     const void* table;          // from K1 (u32 entries, u64 when idx64)
     const uint64_t* blk_off;    // nq + 1
-    void* counts;               // u16 or u32 [nq][counts_stride]
+    void* counts;               // u8, u16 or u32 [nq][counts_stride]
     const uint32_t* thresholds; // per query (this file) or nullptr = no selection
     HitDev* hits;               // selection pool
     uint32_t* hit_count;        // pool fill (may exceed hit_cap: overflow)
