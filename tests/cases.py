@@ -82,3 +82,27 @@ def oracle_results(ix_list, query, threshold, num_results):
 
 def tmp(tmp_path, name):
     return os.path.join(str(tmp_path), name)
+
+
+SURVEY_PROBE_SCORES = [270, 135, 90, 68, 54, 45, 39, 34, 30, 27, 25, 23, 21, 20, 18, 17, 16, 15, 15, 14]
+
+
+def survey_probe_files(oracle, construct, tmp_path):
+    """SURVEY 8c [probed]: the real reference, run during the survey on a hand-built 20-document
+    classic (S = 5003, H = 3) and compact (page_size 1, P = 3, S_p = {3001, 4001, 5003}) index,
+    returned SURVEY_PROBE_SCORES for random_sequence(300, 7) -- document j holds every (j+1)-th
+    term of the query.  -> (classic path, compact path, query, names, expected scores)"""
+    q = oracle.random_sequence(300, 7)
+    H, k = 3, 31
+    hashes, good = oracle.term_hashes(q, k, 1, H)
+    assert good.all() and len(hashes) == 270
+    names = ["doc_%02d" % j for j in range(20)]
+    docs = [construct.Doc(names[j], names[j], 0, len(range(0, 270, j + 1)), hashes[np.arange(0, 270, j + 1)])
+            for j in range(20)]
+    pc = tmp(tmp_path, "probe.cobs_classic")
+    construct.write_classic(pc, k, 1, names, 5003, H, construct.build_matrix(docs, 5003, 3))
+    pk = tmp(tmp_path, "probe.cobs_compact")
+    sigs = [3001, 4001, 5003]
+    mats = [construct.build_matrix(docs[8 * p:8 * p + 8], sigs[p], 1) for p in range(3)]
+    construct.write_compact(pk, k, 1, 1, [(s, H) for s in sigs], names, mats)
+    return pc, pk, q, names, SURVEY_PROBE_SCORES

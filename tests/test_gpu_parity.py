@@ -387,3 +387,14 @@ def test_packed_queries(gpu_lib, oracle, golden_dir):
         s.search_packed(text, [0, 40, 35])
     with pytest.raises(gpu_lib.CobsGpuError):        # a 30-character slice is shorter than k = 31
         s.search_packed(text, [0, 30])
+
+
+def test_survey_probe_known_answer(gpu_lib, oracle, construct, tmp_path):
+    """the scores the REAL reference returned during the survey (SURVEY 8c [probed]) through the
+    HIP path: classic H = 3 and compact with one-byte pages"""
+    pc, pk, q, names, want = cases.survey_probe_files(oracle, construct, tmp_path)
+    for p in (pc, pk):
+        s = gpu_lib.Search(p)
+        assert s.counts(q)[:20].tolist() == want
+        assert [(r.doc_name, r.score) for r in s.search(q)] == sorted(zip(names, want), key=lambda t: (-t[1], t[0]))
+        assert [(r.doc_name, r.score) for r in s.search(q, 0.25)] == [(n, sc) for n, sc in zip(names, want) if sc >= 68]

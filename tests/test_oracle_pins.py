@@ -258,3 +258,13 @@ def test_query_generators(oracle):
     assert s == bytes(want)
     g = oracle.Mt19937Queries(5489)               # default std::mt19937 seed: first output 3499211612
     assert g.next(1) == b"ACGT"[3499211612 % 4:3499211612 % 4 + 1]
+
+
+def test_survey_probe_hand_built_20_documents(oracle, construct, tmp_path):
+    """SURVEY 8c [probed]: known answer of the REAL reference (see cases.survey_probe_files)"""
+    pc, pk, q, names, want = cases.survey_probe_files(oracle, construct, tmp_path)
+    for p in (pc, pk):
+        ix = oracle.Index.open(p)
+        res = oracle.search(ix, q)
+        assert [(n, s) for (_, _, n, s) in res] == sorted(zip(names, want), key=lambda t: (-t[1], t[0]))
+        assert ix.counts(q)[:20].tolist() == want
