@@ -630,6 +630,69 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
 
     // ---- expand planes -> per-document counts; every thread handles row bytes ----
     const uint32_t* planes = reinterpret_cast<const uint32_t*>(mbuf);   // [NP][64*4 words]
+    if (!a.write_counts && a.thresholds) {
+        // Hits only (threshold > 0, the scores themselves are not wanted): compare in bit-sliced
+        // form -- one 32-bit word = 32 documents, count >= threshold in NP boolean ops -- and
+        // expand nothing unless a document passes.  With the usual thresholds hardly any word
+        // holds a hit, so this replaces the whole LUT expansion (short reads: a third of the kernel).
+        const uint32_t nwords = MQ ? 256u : W * 4u;
+#pragma unroll 1
+        for (uint32_t w0 = wave * 64u; w0 < nwords; w0 += NW * 64) {     // wave-uniform bounds
+            const uint32_t w = w0 + lane;
+            const bool act = w < nwords;
+            const uint32_t pl_lane = act ? w >> 2 : 0u, comp = w & 3u;
+            const uint32_t chunk = MQ ? (pl_lane & (W - 1u)) : pl_lane;
+            const uint32_t q2raw = MQ ? qi * G + pl_lane / W : qi;
+            const uint32_t q2 = q2raw < a.nq ? q2raw : a.nq - 1u;
+            const uint32_t thr = a.thresholds[q2];
+            const uint32_t gch = a.chunk_begin + tile * W + chunk;
+            const bool valid = act && gch < a.chunk_end && q2raw < a.nq;
+            const uint32_t gcc = valid ? gch : a.chunk_begin;
+            const uint32_t p2 = gcc / a.cpp;
+            const uint32_t byte0 = (gcc - p2 * a.cpp) * 16u + comp * 4u;     // first row byte of this word
+            const PageDev pd = a.pages[p2];
+            // ge bit d = (count of document d >= thr), from the lowest plane up:
+            //   threshold bit 1: ge &= plane, threshold bit 0: ge |= plane
+            uint32_t ge = (NP < 32 && (thr >> (NP < 32 ? NP : 0)) != 0u) ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const uint32_t pk = planes[(k * 64 + pl_lane) * 4 + comp];
+                ge = ((thr >> k) & 1u) ? (ge & pk) : (ge | pk);
+            }
+            // real documents only: row bytes inside the page, document ids below num_docs
+            const uint32_t vb = pd.valid_bytes > byte0 ? pd.valid_bytes - byte0 : 0u;        // valid bytes of the word
+            if (vb < 4u) ge &= vb == 0u ? 0u : (1u << (vb * 8u)) - 1u;
+            const uint32_t doc0 = pd.doc0 + byte0 * 8u;
+            const uint32_t nd = a.num_docs > doc0 ? a.num_docs - doc0 : 0u;
+            if (nd < 32u) ge &= nd == 0u ? 0u : (1u << nd) - 1u;
+            if (!valid) ge = 0u;
+            if (__any(ge != 0u)) {
+                const uint32_t n = __popc(ge);
+                uint32_t incl = n;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t t = __shfl_up(incl, off);
+                    if (lane >= (uint32_t)off) incl += t;
+                }
+                const uint32_t total = __shfl(incl, 63);
+                uint32_t base = 0u;
+                if (lane == 63u) base = atomicAdd(a.hit_count, total);
+                base = __shfl(base, 63);
+                uint32_t pos = base + incl - n;
+                while (ge != 0u) {
+                    const uint32_t d = (uint32_t)__ffs((int)ge) - 1u;
+                    ge &= ge - 1u;
+                    uint32_t score = 0u;
+#pragma unroll
+                    for (int k = 0; k < NP; ++k)
+                        score |= ((planes[(k * 64 + pl_lane) * 4 + comp] >> d) & 1u) << k;
+                    if (pos < a.hit_cap) a.hits[pos] = HitDev{q2, a.part, doc0 + d, score};
+                    ++pos;
+                }
+            }
+        }
+        return;
+    }
     const uint32_t nbytes = MQ ? 1024u : W * 16u;    // MQ: every lane group holds a query's tile
 #pragma unroll 1
     for (uint32_t b = threadIdx.x; b < nbytes; b += NW * 64) {       // row byte inside the tile

@@ -67,3 +67,7 @@ def test_random_geometries(gpu_lib, oracle, tmp_path, monkeypatch, tile_w, waves
         for i, q in enumerate(queries):
             assert np.array_equal(b.counts_host(i), ix.counts(q)), (path, i, len(q))
             assert b.hits_host(i, lim) == cases.oracle_results([ix], q, t, lim), (path, i, t, lim)
+        # host-buffer API with a threshold and no limit: the scan runs hits-only (bit-sliced
+        # threshold compare, no score rows)
+        tt = t if t > 0 else 0.3
+        assert s.search_hits(queries, tt, 0) == [cases.oracle_results([ix], q, tt, 0) for q in queries], (path, tt)
