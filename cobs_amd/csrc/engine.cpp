@@ -1453,19 +1453,27 @@ cobs_gpu_status cobs_gpu_search_batch(cobs_gpu_index* ix, const char* const* que
     hit_offsets[0] = 0;
     bool overflow = false;
     // Large batches are cut into device passes whose score rows and row-index tables stay
-    // below ~4 GiB each (the caller sees one call; results are concatenated).
-    uint64_t kLimit = 4ull << 30;
+    // below a limit each (the caller sees one call; results are concatenated).
+    // (16 GiB: a small part of 288 GB of HBM, and large passes keep more lookups per cached line.)
+    uint64_t kLimit = 16ull << 30;
     if (const char* e = getenv("COBS_GPU_PASS_BYTES")) kLimit = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
+    uint32_t min_term = 0xFFFFFFFFu;
+    for (const auto& p : ix->parts) min_term = std::min(min_term, p.meta.term_size);
     uint64_t terms_per_char = 0;                      // table bytes per query character, all files
     for (const auto& p : ix->parts) terms_per_char += 4ull * p.meta.num_hashes * std::max<uint32_t>(p.max_chunk_pages, 1);
     size_t g0 = 0;
     while (g0 < nq || (nq == 0 && g0 == 0)) {
         size_t g1 = g0;
-        uint64_t score_bytes = 0, table_bytes = 0;
+        uint64_t table_bytes = 0, max_terms = 1;
         while (g1 < nq) {
-            const uint64_t sb = ix->local_counts * 4ull, tb = (uint64_t)(lens[g1] + 16) * terms_per_char;
-            if (g1 > g0 && (score_bytes + sb > kLimit || table_bytes + tb > kLimit)) break;
-            score_bytes += sb;
+            // score rows of the pass: queries x slots x the score width its longest query needs
+            const uint64_t terms = lens[g1] >= min_term ? lens[g1] - min_term + 1 : 1;
+            const uint64_t mt = std::max(max_terms, terms);
+            const int planes = scan_planes_for(mt);
+            const uint64_t sb = (uint64_t)(g1 - g0 + 1) * ix->local_counts * (planes > 0 ? scan_score_bytes(planes) : 4u);
+            const uint64_t tb = (uint64_t)(lens[g1] + 16) * terms_per_char;
+            if (g1 > g0 && (sb > kLimit || table_bytes + tb > kLimit)) break;
+            max_terms = mt;
             table_bytes += tb;
             ++g1;
         }
