@@ -993,7 +993,6 @@ cobs_gpu_status cobs_gpu_batch_set_queries(cobs_gpu_batch* b, const char* const*
         HIP_TRY(hipMemcpy(w.blk_off.p, w.h_blk_off.data(), 8 * (nq + 1), hipMemcpyHostToDevice));
     }
     algo_bytes += (uint64_t)nq * ix->local_counts * b->elem_bytes;
-    HIP_TRY(b->counts.reserve((size_t)(nq * ix->local_counts * b->elem_bytes)));
     // selection pool: room for 1024 hits per query, at least 1 Mi entries
     const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(1u << 20, nq * 1024ull), 1ull << 26);
     HIP_TRY(b->hits.reserve((size_t)want));
@@ -1029,6 +1028,9 @@ static cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk
     // with K3 the threshold is applied there; otherwise K2 selects into the hit pool
     b->selected = threshold > 0.0 && !use_topk;
     b->have_counts = want_counts || !b->selected;
+    // score rows are allocated by the first run that writes them (a hits-only caller never pays
+    // for them: 100k reads x 100k documents would be 10 GB)
+    if (b->have_counts) HIP_TRY(b->counts.reserve((size_t)(nq * ix->local_counts * b->elem_bytes)));
     const bool need_thr = threshold > 0.0;
     if (use_topk) {
         HIP_TRY(b->topk_out.reserve((size_t)topk * std::max<size_t>(nq, 1) * ix->parts.size()));
@@ -1184,6 +1186,13 @@ void* cobs_gpu_batch_counts_device(cobs_gpu_batch* b, uint32_t* elem_bytes, uint
     if (!b) return nullptr;
     if (elem_bytes) *elem_bytes = b->elem_bytes;
     if (row_stride_bytes) *row_stride_bytes = b->ix->local_counts * b->elem_bytes;
+    // the rows are allocated lazily (see run_impl); a caller that asks for them before the first
+    // run (to size an exchange buffer, say) gets them now
+    if (hipSetDevice(b->ix->device) != hipSuccess ||
+        b->counts.reserve((size_t)(b->nq * b->ix->local_counts * b->elem_bytes)) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
     return b->counts.p;
 }
 
