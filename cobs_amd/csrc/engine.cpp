@@ -222,6 +222,7 @@ struct cobs_gpu_batch {
     PinnedBuf<uint8_t> h_rows;
     size_t rows_q0 = 0, rows_q1 = 0;
     std::vector<uint32_t> rank_hist;  // scratch of the counting sort in hits_host
+    std::vector<cobs_gpu_hit> sel_scratch;
     // HIP events around K1 and K2 of the most recent runs (recorded on the launch stream)
     static constexpr int kRing = 64;
     hipEvent_t ev[kRing][3] = {};
@@ -1319,7 +1320,8 @@ cobs_gpu_status cobs_gpu_batch_hits_host(cobs_gpu_batch* b, size_t q, size_t num
     if (q >= b->nq) return fail(COBS_GPU_ERR_ARG, "query number out of range");
     cobs_gpu_index* ix = b->ix;
     HIP_TRY(hipSetDevice(ix->device));
-    std::vector<cobs_gpu_hit> sel;
+    std::vector<cobs_gpu_hit>& sel = b->sel_scratch;     // reused: no allocation per query
+    sel.clear();
     const bool pool_ok = b->selected && b->h_flags[1] <= b->hit_cap;
     const bool topk_ok = b->topk_k > 0 && num_results > 0 && num_results <= b->topk_k && total_hashes(b, q) > 1;
     if (topk_ok) {
@@ -1339,14 +1341,16 @@ cobs_gpu_status cobs_gpu_batch_hits_host(cobs_gpu_batch* b, size_t q, size_t num
         }
     } else if (pool_ok) {
         if (!b->pool_fetched) {
-            b->h_hits.resize(b->h_flags[1]);
+            // the pool arrives in arbitrary order: bucket it by query with a counting scatter
+            std::vector<HitDev> raw(b->h_flags[1]);
             if (b->h_flags[1])
-                HIP_TRY(hipMemcpy(b->h_hits.data(), b->hits.p, sizeof(HitDev) * b->h_flags[1], hipMemcpyDeviceToHost));
-            std::stable_sort(b->h_hits.begin(), b->h_hits.end(),
-                             [](const HitDev& x, const HitDev& y) { return x.query < y.query; });
+                HIP_TRY(hipMemcpy(raw.data(), b->hits.p, sizeof(HitDev) * b->h_flags[1], hipMemcpyDeviceToHost));
             b->h_hit_off.assign(b->nq + 1, 0);
-            for (const HitDev& h : b->h_hits) b->h_hit_off[h.query + 1]++;
+            for (const HitDev& h : raw) b->h_hit_off[h.query + 1]++;
             for (size_t i = 0; i < b->nq; ++i) b->h_hit_off[i + 1] += b->h_hit_off[i];
+            b->h_hits.resize(raw.size());
+            std::vector<size_t> cur(b->h_hit_off.begin(), b->h_hit_off.end() - 1);
+            for (const HitDev& h : raw) b->h_hits[cur[h.query]++] = h;
             b->pool_fetched = true;
         }
         for (size_t i = b->h_hit_off[q]; i < b->h_hit_off[q + 1]; ++i)
