@@ -77,3 +77,48 @@ def test_streamed_synthetic_equals_resident(gpu_lib, oracle):
     assert bb.stats()["scan_launches"] > 1 and ba.stats()["scan_launches"] == 1
     ix = oracle.Index.synthetic(1, 31, 1, 1, ps, sigs, D, 9)
     assert np.array_equal(bb.counts_host(0), ix.counts(qs[0]))
+
+
+@pytest.mark.parametrize("no_pin", ["0", "1"])
+def test_random_budgets(gpu_lib, oracle, tmp_path, monkeypatch, no_pin):
+    """random geometries x random HBM budgets (chunks of whole sub-indexes, shared chunks, column
+    slices of a sub-index larger than a buffer; pinned-mapping DMA and the staged fallback):
+    streamed results equal the oracle's"""
+    import os
+    from cobs_amd import _capi
+    if no_pin == "1":
+        monkeypatch.setenv("COBS_GPU_NO_PIN", "1")
+    rng = np.random.default_rng(424242 + int(no_pin) + 100003 * int(os.environ.get("COBS_FUZZ_SEED", "0")))
+    done = 0
+    for idx in range(30):
+        H = int(rng.choice([1, 1, 2]))
+        q_long = oracle.random_sequence(500, 900 + idx)
+        if rng.random() < 0.4:
+            D, S = int(rng.integers(200, 6000)), int(rng.integers(300, 3000))
+            path = cases.make_classic(cases.tmp(tmp_path, "r%d.cobs_classic" % idx), D, S, H, 31, 1, 0.3, idx,
+                                      planted={0: 1.0, D - 1: 0.7}, query=q_long[:200])
+            file_bytes = S * ((D + 7) // 8)
+        else:
+            ps = int(rng.choice([8, 24, 64, 136, 256]))
+            P = int(rng.integers(1, 7))
+            D = (P - 1) * 8 * ps + int(rng.integers(1, 8 * ps + 1))
+            sigs = [int(x) for x in rng.integers(200, 4000, size=P)]
+            path = cases.make_compact(cases.tmp(tmp_path, "r%d.cobs_compact" % idx), D, ps, sigs, H, 31, 1, 0.3, idx,
+                                      planted={0: 1.0, D - 1: 0.7}, query=q_long[:200])
+            file_bytes = sum(sigs) * ps
+        budget = int(file_bytes * float(rng.choice([0.15, 0.3, 0.6, 0.9])))
+        queries = [q_long[:200], q_long[100:131], q_long[:31 + int(rng.integers(0, 400))]]
+        try:
+            s = gpu_lib.Search(path, hbm_budget=budget)
+        except gpu_lib.CobsGpuError as e:       # budget below two 16-byte column slices of the largest sub-index
+            assert e.status == _capi.ERR_CAPACITY
+            continue
+        assert s.info(0).hbm_bytes <= budget
+        ix = oracle.Index.open(path)
+        for q in queries:
+            assert np.array_equal(s.counts(q), ix.counts(q)), (path, budget)
+        t = float(rng.choice([0.0, 0.3, 0.8]))
+        lim = int(rng.choice([0, 0, 5]))
+        assert s.search_hits(queries, t, lim) == [cases.oracle_results([ix], q, t, lim) for q in queries], (path, budget, t, lim)
+        done += 1
+    assert done >= 15
