@@ -21,7 +21,7 @@ __device__ __forceinline__ uint64_t mix(uint64_t z) {
 }
 
 // lines: number of 128-byte lines of the buffer; trips: 8-line batches per lane group
-template <int DEPTH>
+template <int DEPTH, bool NT = false>
 __global__ __launch_bounds__(256) void gather(const uint8_t* buf, uint64_t lines, uint32_t trips, uint32_t* sink) {
     const uint32_t lane = threadIdx.x & 63u, grp = lane >> 3, col = lane & 7u;
     const uint64_t wid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256) void gather(const uint8_t* buf, uint64_t lines
         for (int j = 0; j < DEPTH; ++j) {
             state = state * 6364136223846793005ull + 1442695040888963407ull;
             const uint64_t line = (state >> 20) % lines;
-            v[j] = *reinterpret_cast<const u32x4*>(buf + line * 128 + col * 16);
+            const u32x4* p = reinterpret_cast<const u32x4*>(buf + line * 128 + col * 16);
+            v[j] = NT ? __builtin_nontemporal_load(p) : *p;
         }
 #pragma unroll
         for (int j = 0; j < DEPTH; ++j) acc ^= v[j];
@@ -74,6 +75,16 @@ int main(int argc, char** argv) {
             const double moved = (double)groups * 4 * 8 * trips * 8 * 128;   // waves x groups x trips x lines x bytes
             if (rep == 3) std::printf("random 128-byte lines over %.1f GB, %2d loads in flight per wave: %7.1f GB/s\n", gb, depth, moved / ms / 1e6);
         }
+    }
+    for (int rep = 0; rep < 4; ++rep) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL((gather<8, true>), dim3(groups), dim3(256), 0, 0, buf, lines, trips, sink);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        const double moved = (double)groups * 4 * 8 * trips * 8 * 128;
+        if (rep == 3) std::printf("random 128-byte lines over %.1f GB, non-temporal loads, 8 in flight:  %7.1f GB/s\n", gb, moved / ms / 1e6);
     }
     for (int rep = 0; rep < 4; ++rep) {
         CHECK(hipEventRecord(e0));
