@@ -24,7 +24,9 @@
 static void usage() {
     std::fprintf(stderr,
                  "usage: cobs_gpu_query -i INDEX [-i INDEX ...] [-t THRESHOLD] [-l LIMIT] "
-                 "[-d DEVICE] (QUERY | -f QUERY_FILE)\n"
+                 "[-d DEVICE] [--hbm-budget GIB] (QUERY | -f QUERY_FILE)\n"
+                 "       (--load-complete and -T/--threads of `cobs query` are accepted and ignored: the index\n"
+                 "        always lives in HBM, or is streamed through it under --hbm-budget)\n"
                  "       cobs_gpu_query --benchmark -i INDEX [-k KMERS] [-q QUERIES] [-w WARMUP] [--seed S]\n");
 }
 
@@ -68,6 +70,7 @@ int main(int argc, char** argv) {
     double threshold = 0.8;
     size_t num_results = 0;
     int device = -1;
+    uint64_t hbm_budget = 0;
     bool bench = false;
     unsigned num_kmers = 1000, num_queries = 10000, num_warmup = 100;
     size_t seed = std::random_device{}();
@@ -82,6 +85,9 @@ int main(int argc, char** argv) {
         else if (a == "-t" || a == "--threshold") threshold = std::atof(need("-t"));
         else if (a == "-l" || a == "--limit") num_results = (size_t)std::strtoull(need("-l"), nullptr, 10);
         else if (a == "-d" || a == "--device") device = std::atoi(need("-d"));
+        else if (a == "--hbm-budget") hbm_budget = (uint64_t)(std::atof(need("--hbm-budget")) * 1073741824.0);
+        else if (a == "--load-complete") {}                  // reference flags without a meaning here
+        else if (a == "-T" || a == "--threads") (void)need("-T");
         else if (a == "--benchmark") bench = true;
         else if (a == "-k" || a == "--num-kmers") num_kmers = (unsigned)std::atoi(need("-k"));
         else if (a == "-q" || a == "--queries") num_queries = (unsigned)std::atoi(need("-q"));
@@ -93,7 +99,7 @@ int main(int argc, char** argv) {
     }
     if (bench && !index_paths.empty()) {
         try {
-            cobs_gpu::ClassicSearch s(index_paths, device);
+            cobs_gpu::ClassicSearch s(index_paths, device, hbm_budget);
             return benchmark(s, index_paths[0], num_kmers, num_queries, num_warmup, seed);
         } catch (const cobs_gpu::Error& e) {
             std::fprintf(stderr, "EXCEPTION: %s\n", e.what());
@@ -106,7 +112,7 @@ int main(int argc, char** argv) {
         return 1;
     }
     try {
-        cobs_gpu::ClassicSearch s(index_paths, device);
+        cobs_gpu::ClassicSearch s(index_paths, device, hbm_budget);
         if (!query_line.empty()) {
             std::vector<cobs_gpu::SearchResult> result;
             s.search(query_line, result, threshold, num_results);

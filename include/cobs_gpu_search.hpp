@@ -50,16 +50,20 @@ public:
 class ClassicSearch : public Search {
 public:
     //! auto-detect classic / compact and stage the index into HBM
-    explicit ClassicSearch(const std::string& path, int device = -1)
-        : ClassicSearch(std::vector<std::string>{path}, device) {}
+    //! hbm_budget_bytes > 0: an index larger than the budget is streamed chunk-wise at every
+    //! search (the role of the reference's mmap / AIO back-ends for indexes beyond memory)
+    explicit ClassicSearch(const std::string& path, int device = -1, uint64_t hbm_budget_bytes = 0)
+        : ClassicSearch(std::vector<std::string>{path}, device, hbm_budget_bytes) {}
 
     //! several index files searched together (reference: vector<shared_ptr<IndexSearchFile>>)
-    explicit ClassicSearch(const std::vector<std::string>& paths, int device = -1) {
+    explicit ClassicSearch(const std::vector<std::string>& paths, int device = -1,
+                           uint64_t hbm_budget_bytes = 0) {
         std::vector<const char*> cp;
         for (const auto& p : paths) cp.push_back(p.c_str());
         cobs_gpu_options o{};
         o.struct_size = sizeof o;
         o.device = device;
+        o.hbm_budget_bytes = hbm_budget_bytes;
         check(cobs_gpu_open(cp.data(), cp.size(), &o, &ix_));
     }
 

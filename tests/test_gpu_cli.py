@@ -30,6 +30,10 @@ def test_single_query_default_threshold(gpu_lib, oracle, golden_dir):
     assert r.stdout == want
     r = _run("-i", idx, "-t", "0", "-l", "2", Q50)
     assert r.stdout == "sample1\t20\nsample7\t3\n"
+    # flags of `cobs query` that have no meaning on the GPU are accepted, so is an HBM budget (streaming itself: test_gpu_streaming.py)
+    r = _run("-i", idx, "--load-complete", "-T", "4", "-t", "0", "--hbm-budget", "0.001", Q50)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == want
 
 
 def test_query_file_and_two_indexes(gpu_lib, oracle, golden_dir, tmp_path):
