@@ -168,7 +168,8 @@ struct cobs_gpu_index {
     std::vector<Part> parts;
     uint64_t total_counts = 0, local_counts = 0;
     double timers[5] = {0, 0, 0, 0, 0};
-    cobs_gpu_batch* scratch = nullptr;    // workspace of the host-buffer search API
+    static constexpr int kScratch = 3;
+    cobs_gpu_batch* scratch[kScratch] = {nullptr, nullptr, nullptr};   // workspaces of the host-buffer search API
     ~cobs_gpu_index();
 };
 
@@ -228,12 +229,17 @@ struct cobs_gpu_batch {
     hipEvent_t ev[kRing][3] = {};
     uint64_t run_seq = 0, read_seq = 0;
     uint64_t stats[4] = {0, 0, 0, 0};
+    // host-buffer API only: the stream this scratch batch lives on and the event after its pass
+    hipStream_t own_stream = nullptr;
+    hipEvent_t done = nullptr;
     ~cobs_gpu_batch() {
         for (auto& r : ev) for (auto& e : r) if (e) (void)hipEventDestroy(e);
+        if (done) (void)hipEventDestroy(done);
+        if (own_stream) (void)hipStreamDestroy(own_stream);
     }
 };
 
-cobs_gpu_index::~cobs_gpu_index() { delete scratch; }
+cobs_gpu_index::~cobs_gpu_index() { for (auto* b : scratch) delete b; }
 
 namespace {
 
@@ -914,8 +920,10 @@ cobs_gpu_status cobs_gpu_batch_create(cobs_gpu_index* ix, size_t max_queries, si
 
 void cobs_gpu_batch_destroy(cobs_gpu_batch* b) { delete b; }
 
-cobs_gpu_status cobs_gpu_batch_set_queries(cobs_gpu_batch* b, const char* const* queries,
-                                           const size_t* lens, size_t nq) {
+// Uploads go through `up` (asynchronously where the source is pinned); wait = false leaves them
+// in flight: the caller orders its kernels after them on the same stream.
+static cobs_gpu_status set_queries_on(cobs_gpu_batch* b, const char* const* queries, const size_t* lens,
+                                      size_t nq, hipStream_t up, bool wait) {
     if (!b || (nq && (!queries || !lens))) return fail(COBS_GPU_ERR_ARG, "NULL argument");
     cobs_gpu_index* ix = b->ix;
     HIP_TRY(hipSetDevice(ix->device));
@@ -964,9 +972,9 @@ cobs_gpu_status cobs_gpu_batch_set_queries(cobs_gpu_batch* b, const char* const*
     HIP_TRY(b->text.reserve((size_t)off + 64));
     HIP_TRY(b->d_span_off.reserve(nq + 1));
     HIP_TRY(b->d_qlen.reserve(nq));
-    HIP_TRY(hipMemcpy(b->text.p, b->h_text.p, (size_t)off + 64, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(b->d_span_off.p, b->span_off.data(), 8 * (nq + 1), hipMemcpyHostToDevice));
-    if (nq) HIP_TRY(hipMemcpy(b->d_qlen.p, b->lens.data(), 4 * nq, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(b->text.p, b->h_text.p, (size_t)off + 64, hipMemcpyHostToDevice, up));
+    HIP_TRY(hipMemcpyAsync(b->d_span_off.p, b->span_off.data(), 8 * (nq + 1), hipMemcpyHostToDevice, up));
+    if (nq) HIP_TRY(hipMemcpyAsync(b->d_qlen.p, b->lens.data(), 4 * nq, hipMemcpyHostToDevice, up));
 
     uint64_t algo_bytes = 0, lookups = 0, table_bytes = 0;
     for (size_t f = 0; f < ix->parts.size(); ++f) {
@@ -991,7 +999,7 @@ cobs_gpu_status cobs_gpu_batch_set_queries(cobs_gpu_batch* b, const char* const*
         HIP_TRY(w.blk_off.reserve(nq + 1));
         HIP_TRY(w.table.reserve((size_t)w.table_entries));
         HIP_TRY(w.thr.reserve(nq));
-        HIP_TRY(hipMemcpy(w.blk_off.p, w.h_blk_off.data(), 8 * (nq + 1), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpyAsync(w.blk_off.p, w.h_blk_off.data(), 8 * (nq + 1), hipMemcpyHostToDevice, up));
     }
     algo_bytes += (uint64_t)nq * ix->local_counts * b->elem_bytes;
     // selection pool: room for 1024 hits per query, at least 1 Mi entries
@@ -1004,7 +1012,13 @@ cobs_gpu_status cobs_gpu_batch_set_queries(cobs_gpu_batch* b, const char* const*
     b->stats[2] = lookups;
     b->stats[3] = table_bytes;
     b->nq = nq;
+    if (wait) HIP_TRY(hipStreamSynchronize(up));
     return COBS_GPU_OK;
+}
+
+cobs_gpu_status cobs_gpu_batch_set_queries(cobs_gpu_batch* b, const char* const* queries,
+                                           const size_t* lens, size_t nq) {
+    return set_queries_on(b, queries, lens, nq, nullptr, true);
 }
 
 // want_counts = false: the caller only needs the selected hits (threshold > 0, no top-k), so the
@@ -1421,30 +1435,43 @@ cobs_gpu_status cobs_gpu_batch_kernel_ms(cobs_gpu_batch* b, float* scan_ms, floa
 // ---------------------------------------------------------------------------
 // host-buffer search API
 
-static cobs_gpu_status run_host_batch(cobs_gpu_index* ix, const char* const* queries, const size_t* lens,
-                                      size_t nq, double threshold, size_t* bad_query, size_t topk = 0) {
-    if (!ix->scratch) {
-        cobs_gpu_status st = cobs_gpu_batch_create(ix, 0, 0, &ix->scratch);
+// One pass of the host-buffer API on scratch batch `slot`, in two halves so that passes can
+// overlap: begin = stage the queries, upload them and launch K1/K2(/K3) on the slot's own stream
+// (asynchronous; the kernels are ordered after `after`, the previous pass), end = wait for it,
+// repeat it with score rows if the hit pool overflowed, book the timers.
+static cobs_gpu_status host_pass_begin(cobs_gpu_index* ix, int slot, const char* const* queries, const size_t* lens,
+                                       size_t nq, double threshold, size_t topk, hipEvent_t after) {
+    HIP_TRY(hipSetDevice(ix->device));
+    if (!ix->scratch[slot]) {
+        cobs_gpu_status st = cobs_gpu_batch_create(ix, 0, 0, &ix->scratch[slot]);
         if (st != COBS_GPU_OK) return st;
+        HIP_TRY(hipStreamCreateWithFlags(&ix->scratch[slot]->own_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ix->scratch[slot]->done, hipEventDisableTiming));
     }
-    cobs_gpu_batch* b = ix->scratch;
+    cobs_gpu_batch* b = ix->scratch[slot];
     double t0 = now_s();
-    cobs_gpu_status st = cobs_gpu_batch_set_queries(b, queries, lens, nq);
+    cobs_gpu_status st = set_queries_on(b, queries, lens, nq, b->own_stream, false);
     if (st != COBS_GPU_OK) return st;
-    double t1 = now_s();
-    ix->timers[1] += t1 - t0;
+    ix->timers[1] += now_s() - t0;
+    if (after) HIP_TRY(hipStreamWaitEvent(b->own_stream, after, 0));
     // with a threshold and no limit only the selected hits travel back: skip the score rows,
     // unless the hit pool overflows (then the pass is repeated with them and ranked on the host)
     const bool hits_only = threshold > 0.0 && topk == 0;
-    st = run_impl(b, threshold, topk, nullptr, !hits_only);
+    st = run_impl(b, threshold, topk, b->own_stream, !hits_only);
     if (st != COBS_GPU_OK) return st;
-    st = cobs_gpu_batch_sync(b, nullptr, bad_query);
+    HIP_TRY(hipEventRecord(b->done, b->own_stream));
+    return COBS_GPU_OK;
+}
+
+static cobs_gpu_status host_pass_end(cobs_gpu_index* ix, int slot, double threshold, size_t topk, size_t* bad_query) {
+    cobs_gpu_batch* b = ix->scratch[slot];
+    cobs_gpu_status st = cobs_gpu_batch_sync(b, b->own_stream, bad_query);
     if (st == COBS_GPU_OK && !b->have_counts && b->h_flags[1] > b->hit_cap) {
-        st = run_impl(b, threshold, topk, nullptr, true);
+        st = run_impl(b, threshold, topk, b->own_stream, true);
         if (st != COBS_GPU_OK) return st;
-        st = cobs_gpu_batch_sync(b, nullptr, bad_query);
+        HIP_TRY(hipEventRecord(b->done, b->own_stream));
+        st = cobs_gpu_batch_sync(b, b->own_stream, bad_query);
     }
-    double t2 = now_s();
     if (st == COBS_GPU_OK || st == COBS_GPU_ERR_INVALID_BASE) {
         float sm = 0, hm = 0;
         if (b->ran && cobs_gpu_batch_kernel_ms(b, &sm, &hm) == COBS_GPU_OK) {
@@ -1452,8 +1479,14 @@ static cobs_gpu_status run_host_batch(cobs_gpu_index* ix, const char* const* que
             ix->timers[2] += sm * 1e-3;
         }
     }
-    (void)t2;
     return st;
+}
+
+static cobs_gpu_status run_host_batch(cobs_gpu_index* ix, const char* const* queries, const size_t* lens,
+                                      size_t nq, double threshold, size_t* bad_query, size_t topk = 0) {
+    cobs_gpu_status st = host_pass_begin(ix, 0, queries, lens, nq, threshold, topk, nullptr);
+    if (st != COBS_GPU_OK) return st;
+    return host_pass_end(ix, 0, threshold, topk, bad_query);
 }
 
 cobs_gpu_status cobs_gpu_search_batch(cobs_gpu_index* ix, const char* const* queries, const size_t* lens,
@@ -1474,11 +1507,53 @@ cobs_gpu_status cobs_gpu_search_batch(cobs_gpu_index* ix, const char* const* que
     for (const auto& p : ix->parts) min_term = std::min(min_term, p.meta.term_size);
     uint64_t terms_per_char = 0;                      // table bytes per query character, all files
     for (const auto& p : ix->parts) terms_per_char += 4ull * p.meta.num_hashes * std::max<uint32_t>(p.max_chunk_pages, 1);
-    size_t g0 = 0;
+    // Passes are pipelined over up to three scratch batches: while the GPU scans pass i the host
+    // stages and uploads pass i+1 and ranks pass i-1 (kernels of consecutive passes are chained by
+    // events, so they never share the GPU).  A batch of 64 Ki queries or more is cut into at least
+    // four passes for that.  Streamed (out-of-core) files share their chunk buffers: one pass at a time.
+    bool any_streamed = false;
+    for (const auto& p : ix->parts) any_streamed = any_streamed || p.streamed;
+    const size_t depth = any_streamed ? 1 : (size_t)cobs_gpu_index::kScratch;
+    const size_t max_pass = (!any_streamed && nq >= 65536) ? (nq + 3) / 4 : std::max<size_t>(nq, 1);
+    const size_t topk = num_results < ix->total_counts ? num_results : 0;   // bounded: K3 selects on the device
+    struct Pass { size_t g0, g1; int slot; };
+    std::vector<Pass> inflight;                        // FIFO, at most `depth` entries
+    auto drain = [&]() {                               // error paths: nothing may still use the scratch batches
+        for (const Pass& ps : inflight) (void)hipStreamSynchronize(ix->scratch[ps.slot]->own_stream);
+        inflight.clear();
+    };
+    auto collect = [&](const Pass& ps) -> cobs_gpu_status {
+        size_t bad = 0;
+        cobs_gpu_status st = host_pass_end(ix, ps.slot, threshold, topk, &bad);
+        if (st != COBS_GPU_OK) {
+            if (bad_query) *bad_query = ps.g0 + bad;
+            return st;
+        }
+        cobs_gpu_batch* sb = ix->scratch[ps.slot];
+        for (size_t q = ps.g0; q < ps.g1; ++q) {
+            size_t n = 0;
+            if (sb->selected && sb->pool_fetched && sb->h_flags[1] <= sb->hit_cap &&
+                sb->h_hit_off[q - ps.g0] == sb->h_hit_off[q - ps.g0 + 1]) {
+                hit_offsets[q + 1] = used;       // no document of this query reached the threshold
+                continue;
+            }
+            double t0 = now_s();
+            st = cobs_gpu_batch_hits_host(sb, q - ps.g0, num_results, overflow ? nullptr : hits + used,
+                                          overflow ? 0 : cap - used, &n);
+            ix->timers[4] += now_s() - t0;
+            if (st == COBS_GPU_ERR_CAPACITY || (overflow && st == COBS_GPU_ERR_ARG)) overflow = true;
+            else if (st != COBS_GPU_OK) return st;
+            used += n;
+            hit_offsets[q + 1] = used;
+        }
+        return COBS_GPU_OK;
+    };
+    size_t g0 = 0, pass_no = 0;
+    hipEvent_t prev_done = nullptr;
     while (g0 < nq || (nq == 0 && g0 == 0)) {
         size_t g1 = g0;
         uint64_t table_bytes = 0, max_terms = 1;
-        while (g1 < nq) {
+        while (g1 < nq && g1 - g0 < max_pass) {
             // score rows of the pass: queries x slots x the score width its longest query needs
             const uint64_t terms = lens[g1] >= min_term ? lens[g1] - min_term + 1 : 1;
             const uint64_t mt = std::max(max_terms, terms);
@@ -1490,33 +1565,41 @@ cobs_gpu_status cobs_gpu_search_batch(cobs_gpu_index* ix, const char* const* que
             table_bytes += tb;
             ++g1;
         }
-        size_t bad = 0;
-        // a bounded num_results is selected on the device (K3), nothing but the k best travel back
-        cobs_gpu_status st = run_host_batch(ix, queries + g0, lens + g0, g1 - g0, threshold, &bad,
-                                            num_results < ix->total_counts ? num_results : 0);
+        if (inflight.size() == depth) {                // the slot about to be reused must be collected first
+            const Pass oldest = inflight.front();
+            inflight.erase(inflight.begin());
+            cobs_gpu_status st = collect(oldest);
+            if (st != COBS_GPU_OK) { drain(); return st; }
+        }
+        const int slot = (int)(pass_no % depth);
+        cobs_gpu_status st = host_pass_begin(ix, slot, queries + g0, lens + g0, g1 - g0, threshold, topk, prev_done);
         if (st != COBS_GPU_OK) {
-            if (bad_query) *bad_query = g0 + bad;
+            // passes before this one come first in the caller's order: report their error if they have one
+            size_t first_bad = g0;
+            cobs_gpu_status earlier = COBS_GPU_OK;
+            while (!inflight.empty() && earlier == COBS_GPU_OK) {
+                const Pass ps = inflight.front();
+                inflight.erase(inflight.begin());
+                const std::string keep = g_last_error;
+                earlier = collect(ps);
+                if (earlier == COBS_GPU_OK) g_last_error = keep;
+            }
+            drain();
+            if (earlier != COBS_GPU_OK) return earlier;
+            if (bad_query) *bad_query = first_bad;
             return st;
         }
-        for (size_t q = g0; q < g1; ++q) {
-            size_t n = 0;
-            const cobs_gpu_batch* sb = ix->scratch;
-            if (sb->selected && sb->pool_fetched && sb->h_flags[1] <= sb->hit_cap &&
-                sb->h_hit_off[q - g0] == sb->h_hit_off[q - g0 + 1]) {
-                hit_offsets[q + 1] = used;       // no document of this query reached the threshold
-                continue;
-            }
-            double t0 = now_s();
-            st = cobs_gpu_batch_hits_host(ix->scratch, q - g0, num_results, overflow ? nullptr : hits + used,
-                                          overflow ? 0 : cap - used, &n);
-            ix->timers[4] += now_s() - t0;
-            if (st == COBS_GPU_ERR_CAPACITY || (overflow && st == COBS_GPU_ERR_ARG)) overflow = true;
-            else if (st != COBS_GPU_OK) return st;
-            used += n;
-            hit_offsets[q + 1] = used;
-        }
+        prev_done = ix->scratch[slot]->done;
+        inflight.push_back(Pass{g0, g1, slot});
+        ++pass_no;
         if (nq == 0) break;
         g0 = g1;
+    }
+    while (!inflight.empty()) {
+        const Pass ps = inflight.front();
+        inflight.erase(inflight.begin());
+        cobs_gpu_status st = collect(ps);
+        if (st != COBS_GPU_OK) { drain(); return st; }
     }
     if (overflow) return fail(COBS_GPU_ERR_CAPACITY, "hit buffer too small; hit_offsets[nq] holds the needed size");
     return COBS_GPU_OK;
@@ -1537,7 +1620,7 @@ cobs_gpu_status cobs_gpu_counts(cobs_gpu_index* ix, const char* query, size_t le
     cobs_gpu_status st = run_host_batch(ix, &query, &len, 1, 0.0, nullptr);
     if (st != COBS_GPU_OK) return st;
     double t0 = now_s();
-    st = fetch_counts(ix->scratch, 0, counts);
+    st = fetch_counts(ix->scratch[0], 0, counts);
     ix->timers[3] += now_s() - t0;
     return st;
 }
