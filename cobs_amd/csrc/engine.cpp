@@ -1527,6 +1527,9 @@ cobs_gpu_status cobs_gpu_search_batch(cobs_gpu_index* ix, const char* const* que
         cobs_gpu_status st = host_pass_end(ix, ps.slot, threshold, topk, &bad);
         if (st != COBS_GPU_OK) {
             if (bad_query) *bad_query = ps.g0 + bad;
+            if (st == COBS_GPU_ERR_INVALID_BASE)          // the message names the query by its index in the call
+                return fail(st, "Invalid DNA base pair in query string. Only ACGT are allowed. (query " +
+                                std::to_string(ps.g0 + bad) + ")");
             return st;
         }
         cobs_gpu_batch* sb = ix->scratch[ps.slot];

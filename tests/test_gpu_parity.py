@@ -398,3 +398,32 @@ def test_survey_probe_known_answer(gpu_lib, oracle, construct, tmp_path):
         assert s.counts(q)[:20].tolist() == want
         assert [(r.doc_name, r.score) for r in s.search(q)] == sorted(zip(names, want), key=lambda t: (-t[1], t[0]))
         assert [(r.doc_name, r.score) for r in s.search(q, 0.25)] == [(n, sc) for n, sc in zip(names, want) if sc >= 68]
+
+
+def test_pipelined_passes_of_a_large_call(gpu_lib, oracle, tmp_path):
+    """a call of >= 64 Ki queries is cut into >= 4 passes pipelined over three scratch batches:
+    results are in caller order, and a bad query deep inside is reported by its caller index"""
+    q_long = oracle.random_sequence(4000, 91)
+    p = cases.make_classic(cases.tmp(tmp_path, "pipe.cobs_classic"), 203, 1201, 1, 31, 1, 0.3, 13,
+                           planted={7: 1.0, 150: 0.7}, query=q_long[:120])
+    ix = oracle.Index.open(p)
+    s = gpu_lib.Search(p)
+    rng = np.random.default_rng(17)
+    starts = rng.integers(0, 3900, size=70001)
+    lens = rng.integers(31, 90, size=70001)
+    queries = [q_long[int(a):int(a) + int(n)] for a, n in zip(starts, lens)]
+    queries[0] = q_long[:120]
+    for t, lim in ((0.5, 0), (0.0, 3)):
+        offs, hits = s.search_arrays(queries, t, lim)
+        assert len(offs) == 70002
+        for i in [0, 1, 17499, 17500, 17501, 35000, 52501, 69999, 70000] + [int(x) for x in rng.integers(0, 70001, size=40)]:
+            want = [(f, d, sc) for (f, d, _n, sc) in oracle.search(ix, queries[i], t, lim)]
+            assert hits[int(offs[i]):int(offs[i + 1])].tolist() == want, (t, lim, i)
+    bad = list(queries)
+    bad[61234] = bad[61234][:5] + b"N" + bad[61234][6:]
+    with pytest.raises(gpu_lib.CobsGpuError) as e:
+        s.search_arrays(bad, 0.5, 0)
+    assert "(query 61234)" in str(e.value)                # named by its index in the call, not in its pass
+    # the handle is usable afterwards
+    offs, hits = s.search_arrays(queries[:3], 0.5, 0)
+    assert hits[int(offs[0]):int(offs[1])].tolist() == [(f, d, sc) for (f, d, _n, sc) in oracle.search(ix, queries[0], 0.5, 0)]
