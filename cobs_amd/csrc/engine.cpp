@@ -1509,12 +1509,17 @@ cobs_gpu_status cobs_gpu_search_batch(cobs_gpu_index* ix, const char* const* que
     for (const auto& p : ix->parts) terms_per_char += 4ull * p.meta.num_hashes * std::max<uint32_t>(p.max_chunk_pages, 1);
     // Passes are pipelined over up to three scratch batches: while the GPU scans pass i the host
     // stages and uploads pass i+1 and ranks pass i-1 (kernels of consecutive passes are chained by
-    // events, so they never share the GPU).  A batch of 64 Ki queries or more is cut into at least
-    // four passes for that.  Streamed (out-of-core) files share their chunk buffers: one pass at a time.
+    // events, so they never share the GPU).  A call with 4 MiB of query text or more is cut into at
+    // least four passes for that.  Streamed (out-of-core) files share their chunk buffers: one pass at a time.
     bool any_streamed = false;
     for (const auto& p : ix->parts) any_streamed = any_streamed || p.streamed;
     const size_t depth = any_streamed ? 1 : (size_t)cobs_gpu_index::kScratch;
-    const size_t max_pass = (!any_streamed && nq >= 65536) ? (nq + 3) / 4 : std::max<size_t>(nq, 1);
+    uint64_t total_chars = 0;
+    for (size_t q = 0; q < nq; ++q) total_chars += lens[q];
+    uint64_t pipe_chars = 4ull << 20;                  // tuning hook: COBS_GPU_PIPE_CHARS (0 = never cut for pipelining)
+    if (const char* e = getenv("COBS_GPU_PIPE_CHARS")) pipe_chars = std::strtoull(e, nullptr, 10);
+    const size_t max_pass = (!any_streamed && pipe_chars && total_chars >= pipe_chars && nq >= 64)
+                                ? (nq + 3) / 4 : std::max<size_t>(nq, 1);
     const size_t topk = num_results < ix->total_counts ? num_results : 0;   // bounded: K3 selects on the device
     struct Pass { size_t g0, g1; int slot; };
     std::vector<Pass> inflight;                        // FIFO, at most `depth` entries
