@@ -247,10 +247,27 @@ def sharded_extra(args, cfg, world, rank, dev):
         bi.sync()
     scan_ms = sum(bi.kernel_ms()["scan_ms"] for bi in sub)
     payload = sum(int(g.numel()) for g in gathered)
-    del state
+    # the production form of the same layout: with a threshold only hits leave a shard, so the
+    # exchange shrinks to the hit lists (none on random data at 0.8, like the reference's own
+    # benchmark); what remains is every rank scanning its sub-index block for the whole batch
+    whole = cobs_amd.Batch(s)
+    whole.set_queries(queries)
+    token = torch.zeros(1, dtype=torch.int64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+
+    def hits_step():
+        whole.run(0.8, 0)
+        dist.all_reduce(token, op=dist.ReduceOp.SUM)         # stands for the (empty) hit-list exchange
+
+    dth = timed(hits_step, steps, 1, world, args.dist_backend)
+    whole.sync()
+    hits_scan_ms = whole.kernel_ms()["scan_ms"]
+    del whole, state
     return {"queries_per_s": round(args.queries * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
             "steps": steps, "scaling": "strong", "scan_ms_per_step_rank0": round(scan_ms, 4),
             "gathered_bytes_per_step": payload,
+            "hits_mode_threshold_0.8": {"queries_per_s": round(args.queries * steps / dth, 1),
+                                        "ms_per_step": round(dth / steps * 1e3, 3),
+                                        "scan_ms_per_step_rank0": round(hits_scan_ms, 4)},
             "parallelism": "index sharded by sub-index block x%d, %d sub-batches, async RCCL all-gather of the "
                            "count slices overlapped with the next scan" % (world, len(sub))}
 
