@@ -427,3 +427,38 @@ def test_pipelined_passes_of_a_large_call(gpu_lib, oracle, tmp_path):
     # the handle is usable afterwards
     offs, hits = s.search_arrays(queries[:3], 0.5, 0)
     assert hits[int(offs[0]):int(offs[1])].tolist() == [(f, d, sc) for (f, d, _n, sc) in oracle.search(ix, queries[0], 0.5, 0)]
+
+
+def test_two_handles_from_two_threads(gpu_lib, oracle, tmp_path):
+    """INTEGRATION.md, threading: one handle = one in-flight call, different handles may be driven
+    from different threads at the same time (ctypes releases the GIL inside the library)"""
+    import threading
+    q_long = oracle.random_sequence(3000, 23)
+    pa = cases.make_classic(cases.tmp(tmp_path, "ta.cobs_classic"), 500, 1999, 1, 31, 1, 0.3, 21,
+                            planted={3: 1.0}, query=q_long[:200])
+    pb = cases.make_compact(cases.tmp(tmp_path, "tb.cobs_compact"), 700, 16, [801, 907, 1009, 1103, 1201, 1301], 2, 31, 1,
+                            0.3, 22, planted={650: 0.9}, query=q_long[:200])
+    rng = np.random.default_rng(3)
+    queries = [q_long[int(a):int(a) + int(n)] for a, n in zip(rng.integers(0, 2800, 400), rng.integers(31, 200, 400))]
+    want = {}
+    for p in (pa, pb):
+        ix = oracle.Index.open(p)
+        want[p] = [[(f, d, sc) for (f, d, _n, sc) in oracle.search(ix, q, 0.3, 5)] for q in queries]
+    errors = []
+
+    def worker(path):
+        try:
+            s = gpu_lib.Search(path)
+            for _ in range(6):
+                if s.search_hits(queries, 0.3, 5) != want[path]:
+                    errors.append("mismatch " + path)
+                    return
+        except Exception as e:                      # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(p,)) for p in (pa, pb, pa)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
