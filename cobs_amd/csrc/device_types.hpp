@@ -26,7 +26,7 @@ struct HashArgs {
     const uint64_t* blk_off;    // nq + 1 prefix sums of 8-term blocks per query
     const PageDev* pages;       // local sub-indexes
     void* table;                // row indices (u32, or u64 when idx64): [q][page][block (nblk + 1 padding block)][hash][8]
-    uint32_t* err_query;        // atomicMin of queries holding a non-ACGT base
+    uint32_t* err_query;        // atomicMax of (2^32-1 - q) over queries q holding a non-ACGT base; 0 = none
     uint32_t nq;
     uint32_t npages;
     uint32_t term_size;

@@ -176,7 +176,7 @@ struct cobs_gpu_index {
 namespace {
 
 struct PartWork {    // per-file device workspace of a batch
-    DevBuf<uint64_t> blk_off;
+    const uint64_t* blk_off = nullptr;   // inside the batch's upload buffer
     DevBuf<uint32_t> table;
     DevBuf<uint32_t> thr;
     std::vector<uint64_t> h_blk_off;
@@ -193,8 +193,10 @@ struct cobs_gpu_batch {
     std::vector<uint32_t> lens;
     std::vector<uint64_t> span_off;
     DevBuf<uint8_t> text;
-    DevBuf<uint64_t> d_span_off;
-    DevBuf<uint32_t> d_qlen;
+    // query text, span offsets, query lengths and the per-file block offsets live in ONE pinned
+    // staging buffer / ONE device buffer (`text`): a batch is uploaded with a single async copy
+    const uint64_t* d_span_off = nullptr;
+    const uint32_t* d_qlen = nullptr;
     PinnedBuf<uint8_t> h_text;
     PinnedBuf<uint32_t> h_thr_stage;
     std::vector<PartWork> work;
@@ -215,7 +217,7 @@ struct cobs_gpu_batch {
     bool ran = false, selected = false, synced = false;
     bool have_counts = false;         // the last run wrote the score rows
     double threshold = 0.0;
-    uint32_t h_flags[2] = {0xFFFFFFFFu, 0};
+    uint32_t h_flags[2] = {0, 0};
     std::vector<HitDev> h_hits;       // pool copy, sorted by query
     std::vector<size_t> h_hit_off;
     bool pool_fetched = false;
@@ -965,16 +967,20 @@ static cobs_gpu_status set_queries_on(cobs_gpu_batch* b, const char* const* quer
         off += round_up(span, 8);
     }
     b->span_off[nq] = off;
-    // + 64: K1 reads whole dwords around a k-mer
-    HIP_TRY(b->h_text.reserve((size_t)off + 64));
-    std::memset(b->h_text.p, 0, (size_t)off + 64);
+    // upload layout: text (+ 64: K1 reads whole dwords around a k-mer) | span_off | q_len | blk_off per file
+    const size_t o_span = (size_t)round_up(off + 64, 16);
+    const size_t o_qlen = o_span + (size_t)round_up(8 * (nq + 1), 16);
+    const size_t o_blk = o_qlen + (size_t)round_up(4 * std::max<size_t>(nq, 1), 16);
+    const size_t blk_stride = (size_t)round_up(8 * (nq + 1), 16);
+    const size_t upload_bytes = o_blk + blk_stride * ix->parts.size();
+    HIP_TRY(b->h_text.reserve(upload_bytes));
+    HIP_TRY(b->text.reserve(upload_bytes));
+    std::memset(b->h_text.p, 0, o_span);
     for (size_t q = 0; q < nq; ++q) std::memcpy(b->h_text.p + b->span_off[q], queries[q], lens[q]);
-    HIP_TRY(b->text.reserve((size_t)off + 64));
-    HIP_TRY(b->d_span_off.reserve(nq + 1));
-    HIP_TRY(b->d_qlen.reserve(nq));
-    HIP_TRY(hipMemcpyAsync(b->text.p, b->h_text.p, (size_t)off + 64, hipMemcpyHostToDevice, up));
-    HIP_TRY(hipMemcpyAsync(b->d_span_off.p, b->span_off.data(), 8 * (nq + 1), hipMemcpyHostToDevice, up));
-    if (nq) HIP_TRY(hipMemcpyAsync(b->d_qlen.p, b->lens.data(), 4 * nq, hipMemcpyHostToDevice, up));
+    std::memcpy(b->h_text.p + o_span, b->span_off.data(), 8 * (nq + 1));
+    if (nq) std::memcpy(b->h_text.p + o_qlen, b->lens.data(), 4 * nq);
+    b->d_span_off = reinterpret_cast<const uint64_t*>(b->text.p + o_span);
+    b->d_qlen = reinterpret_cast<const uint32_t*>(b->text.p + o_qlen);
 
     uint64_t algo_bytes = 0, lookups = 0, table_bytes = 0;
     for (size_t f = 0; f < ix->parts.size(); ++f) {
@@ -996,11 +1002,12 @@ static cobs_gpu_status set_queries_on(cobs_gpu_batch* b, const char* const* quer
         w.table_entries = (blk + nq) * 8 * p.meta.num_hashes * p.max_chunk_pages * idx_words;
         table_bytes += ((blk + nq) * 8 * p.meta.num_hashes * p.num_vpages()) * 4 * idx_words;
         if (w.table_entries >= (1ull << 40)) return fail(COBS_GPU_ERR_CAPACITY, "batch too large");
-        HIP_TRY(w.blk_off.reserve(nq + 1));
         HIP_TRY(w.table.reserve((size_t)w.table_entries));
         HIP_TRY(w.thr.reserve(nq));
-        HIP_TRY(hipMemcpyAsync(w.blk_off.p, w.h_blk_off.data(), 8 * (nq + 1), hipMemcpyHostToDevice, up));
+        std::memcpy(b->h_text.p + o_blk + f * blk_stride, w.h_blk_off.data(), 8 * (nq + 1));
+        w.blk_off = reinterpret_cast<const uint64_t*>(b->text.p + o_blk + f * blk_stride);
     }
+    HIP_TRY(hipMemcpyAsync(b->text.p, b->h_text.p, upload_bytes, hipMemcpyHostToDevice, up));
     algo_bytes += (uint64_t)nq * ix->local_counts * b->elem_bytes;
     // selection pool: room for 1024 hits per query, at least 1 Mi entries
     const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(1u << 20, nq * 1024ull), 1ull << 26);
@@ -1052,8 +1059,7 @@ static cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk
         HIP_TRY(b->topk_cnt.reserve(std::max<size_t>(nq, 1) * ix->parts.size()));
     }
     // device flags: first invalid query = none, selected hits = 0
-    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)b->flags.p, (int)0xFFFFFFFFu, 1, st));
-    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(b->flags.p + 1), 0, 1, st));
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)b->flags.p, 0, 2, st));      // both zero: one fill
     if (need_thr) {
         for (size_t f = 0; f < ix->parts.size(); ++f) {
             uint32_t* stage = b->h_thr_stage.p + f * nq;
@@ -1085,9 +1091,9 @@ static cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk
             }
             HashArgs ha;
             ha.text = b->text.p;
-            ha.span_off = b->d_span_off.p;
-            ha.q_len = b->d_qlen.p;
-            ha.blk_off = b->work[f].blk_off.p;
+            ha.span_off = b->d_span_off;
+            ha.q_len = b->d_qlen;
+            ha.blk_off = b->work[f].blk_off;
             ha.pages = c.d_pages;
             ha.table = b->work[f].table.p;
             ha.err_query = b->flags.p;
@@ -1106,7 +1112,7 @@ static cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk
             sa.blob = data;
             sa.pages = c.d_pages;
             sa.table = b->work[f].table.p;
-            sa.blk_off = b->work[f].blk_off.p;
+            sa.blk_off = b->work[f].blk_off;
             sa.counts = b->counts.p;
             sa.thresholds = b->selected ? b->work[f].thr.p : nullptr;
             sa.hits = b->hits.p;
@@ -1188,11 +1194,12 @@ cobs_gpu_status cobs_gpu_batch_sync(cobs_gpu_batch* b, void* hip_stream, size_t*
     HIP_TRY(hipMemcpyAsync(b->h_flags, b->flags.p, sizeof b->h_flags, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     b->synced = true;
-    if (b->h_flags[0] != 0xFFFFFFFFu) {
-        if (bad_query) *bad_query = b->h_flags[0];
+    if (b->h_flags[0] != 0u) {           // K1 keeps 2^32-1 - (first query with a non-ACGT character)
+        const uint32_t bad = 0xFFFFFFFFu - b->h_flags[0];
+        if (bad_query) *bad_query = bad;
         return fail(COBS_GPU_ERR_INVALID_BASE,
                     "Invalid DNA base pair in query string. Only ACGT are allowed. (query " +
-                    std::to_string(b->h_flags[0]) + ")");
+                    std::to_string(bad) + ")");
     }
     return COBS_GPU_OK;
 }

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void hash_kernel(HashArgs a, uint64_t total_th
     // (the reference dies, classic_search.cpp:93-96).  Every character of a
     // query of length >= k lies in some k-mer.
     if (a.canonicalize != 0 && i < len) {
-        if (fwd_base(text[i]) == 0) atomicMin(a.err_query, q);
+        if (fwd_base(text[i]) == 0) atomicMax(a.err_query, 0xFFFFFFFFu - q);   // first bad query wins
     }
 
     const uint64_t b0 = a.blk_off[q];
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void hash_kernel_k31(HashArgs a, uint64_t tota
     const uint32_t len = a.q_len[q];
     const uint8_t* text = a.text + qbase;
     if (a.canonicalize != 0 && i < len) {
-        if (fwd_base(text[i]) == 0) atomicMin(a.err_query, q);
+        if (fwd_base(text[i]) == 0) atomicMax(a.err_query, 0xFFFFFFFFu - q);   // first bad query wins
     }
     const uint64_t b0 = a.blk_off[q];
     const uint32_t nblk = (uint32_t)(a.blk_off[q + 1] - b0);
