@@ -1,6 +1,13 @@
-import os, sys, time
-sys.path.insert(0, "/root/repo")
-import bench, cobs_amd
+#!/usr/bin/env python3
+"""scripts/e2e_pipe.py -- host-buffer API on the C3 batch with and without pipelined passes
+(COBS_GPU_PIPE_CHARS = 0 disables the cut into four passes)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+import cobs_amd  # noqa: E402
 cfg = bench.c3_config()
 s = cobs_amd.Search.synthetic("compact", cfg["signature_sizes"], cfg["num_docs"], page_size=cfg["page_size"], seed=1)
 qs = bench.make_queries(10000, 1000)
