@@ -18,6 +18,8 @@
 //                     (+ optional threshold selection)
 //                     (read_from_disk, aggregate_rows :279-307, compute_counts
 //                      :643-1022, threshold filter of counts_to_result :127-132)
+//   K3 topk_kernel    exact top-k per query (partial_sort of counts_to_result, :134-145)
+//   build_kernel      index construction (classic_index.cpp:40-73): hash terms, set document bits
 //   synth_kernel / repitch_kernel   index staging helpers.
 #include <hip/hip_runtime.h>
 
@@ -313,10 +315,10 @@ __global__ __launch_bounds__(256) void hash_kernel_k31(HashArgs a, uint64_t tota
 // ---------------------------------------------------------------------------
 // K2: gather + AND + bit-sliced count.
 //
-// Work-group = (query q, tile of 64 sixteen-byte column chunks); its NW waves
-// split the query's 8-term blocks round-robin and merge their partial plane
-// counters through LDS at the end.  Lane l of every wave owns chunk
-// tile*64 + l: 128 documents, held as 4 column words x NP bit planes.
+// Work-group = (query q, tile of W sixteen-byte column chunks, W = 4..64); its NW
+// waves x 64/W lane groups split the query's 8-term blocks round-robin and merge
+// their partial plane counters (shuffles inside a wave, LDS across waves) at the
+// end.  A lane owns one chunk: 128 documents, held as 4 column words x NP bit planes.
 
 // carry-save adder: (h, l) = a + b + c per bit position.  gfx950 has a
 // three-input boolean op (v_bitop3_b32, 8-bit truth table), so majority (0xE8)
