@@ -121,15 +121,23 @@ def cpu_baseline(search, cfg, queries, seconds_target=12.0, check_queries=4, bat
     tmax = max(out)
     T = len(queries[0]) - cfg["term_size"] + 1
     gathered = T * cfg["num_hashes"] * width * (len(sigs) if kind else 1)
-    res = {"value": round(qps1, 2), "unit": "queries/s", "cores": 1, "kind": "port",
+    # `value` is the faster of the two: the reference parallelises a query over its document
+    # batches (8 sub-index batches at C3, classic_search.cpp:338-341), so its own default is the
+    # threaded run; the single-thread figure is kept next to it.
+    qpsm, nm, dtm, _ = out[tmax]
+    best_threads = tmax if qpsm >= qps1 else 1
+    qpsb, nb, dtb = (qpsm, nm, dtm) if best_threads == tmax else (qps1, n1, dt1)
+    res = {"value": round(qpsb, 2), "unit": "queries/s", "cores": best_threads, "kind": "port",
            "sample": "%d of the batch's queries, per-document counts (same step as the GPU: hash + "
-                     "gather + AND + expand-add), 1 thread, %.1f s; %s; index resident in host RAM"
-                     % (n1, dt1, sample),
-           "kmer_lookups_per_s": round(qps1 * T, 1),
-           "gathered_GBps": round(qps1 * gathered / 1e9, 3),
-           "phase_seconds": {k: round(v, 3) for k, v in tm1.items()},
+                     "gather + AND + expand-add), %d thread(s) over document batches as the reference "
+                     "does, %.1f s; %s; index resident in host RAM"
+                     % (nb, best_threads, dtb, sample),
+           "kmer_lookups_per_s": round(qpsb * T, 1),
+           "gathered_GBps": round(qpsb * gathered / 1e9, 3),
+           "phase_seconds_1thread": {k: round(v, 3) for k, v in tm1.items()},
            "host_cores": ncores,
-           "threads_%d" % tmax: {"value": round(out[tmax][0], 2), "queries": out[tmax][1]},
+           "threads_1": {"value": round(qps1, 2), "queries": n1},
+           "threads_%d" % tmax: {"value": round(qpsm, 2), "queries": nm},
            "full_search_with_ranking_1thread": {"value": round(n_full / dt_full, 2), "queries": n_full},
            "bit_exact_vs_gpu": bit_exact}
     return res
