@@ -462,3 +462,39 @@ def test_two_handles_from_two_threads(gpu_lib, oracle, tmp_path):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_no_device_memory_leak(gpu_lib, oracle, tmp_path):
+    """open / search (every mode) / close in a loop: device memory returns to where it was"""
+    import gc
+
+    import torch
+    q_long = oracle.random_sequence(600, 3)
+    p = cases.make_compact(cases.tmp(tmp_path, "leak.cobs_compact"), 3000, 64, [5001, 7001, 9001, 11003, 13001, 6007], 1,
+                           31, 1, 0.3, 8, planted={1: 1.0}, query=q_long[:200])
+    queries = [q_long[i:i + 100 + i] for i in range(60)]
+
+    def cycle(budget):
+        s = gpu_lib.Search(p, hbm_budget=budget)
+        s.search_hits(queries, 0.5, 0)
+        s.search_hits(queries, 0.0, 3)
+        s.search_hits(queries[:2], 0.0, 0)
+        b = gpu_lib.Batch(s)
+        b.set_queries(queries)
+        b.run_topk(0.2, 4)
+        b.sync()
+        b.hits_host(0, 4)
+        b.close()
+        s.close()
+
+    for budget in (0, 1 << 20):
+        cycle(budget)
+        gc.collect()
+        torch.cuda.synchronize()
+        free0, _ = torch.cuda.mem_get_info()
+        for _ in range(40):
+            cycle(budget)
+        gc.collect()
+        torch.cuda.synchronize()
+        free1, _ = torch.cuda.mem_get_info()
+        assert free0 - free1 < (32 << 20), (budget, free0, free1)
