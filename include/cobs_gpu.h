@@ -176,8 +176,12 @@ cobs_gpu_status cobs_gpu_search(cobs_gpu_index* ix, const char* query, size_t le
                                 double threshold, size_t num_results,
                                 cobs_gpu_hit* hits, size_t cap, size_t* n_hits);
 
-/* The same for nq queries in one device pass.  hit_offsets has nq+1 entries;
- * hits of query i are hits[hit_offsets[i] .. hit_offsets[i+1]).  A query with
+/* The same for nq queries (src/cobs.cpp:424-465 loops them one by one).  The call is
+ * one device pass, or -- for 4 MiB of query text and more, or when the workspaces
+ * would exceed 16 GiB -- several passes whose staging, upload and ranking overlap
+ * the scans; the caller sees one call.  With threshold > 0 and num_results == 0 the
+ * scan selects hits on the device and writes no score rows.  hit_offsets has nq+1
+ * entries; hits of query i are hits[hit_offsets[i] .. hit_offsets[i+1]).  A query with
  * bad input fails the whole call; *bad_query (optional) receives its index.
  * If cap is too small the call returns COBS_GPU_ERR_CAPACITY and hit_offsets[nq]
  * holds the capacity a retry needs (hit_offsets stay valid, hits do not).      */
@@ -198,8 +202,9 @@ cobs_gpu_status cobs_gpu_counts(cobs_gpu_index* ix, const char* query, size_t le
 cobs_gpu_status cobs_gpu_batch_create(cobs_gpu_index* ix, size_t max_queries,
                                       size_t max_query_len, cobs_gpu_batch** out);
 void cobs_gpu_batch_destroy(cobs_gpu_batch* b);
-/* Copy query text to HBM (H2D) and validate lengths.  After this call the
- * inputs of cobs_gpu_batch_run are resident in HBM. */
+/* Copy query text to HBM (one H2D) and validate lengths.  After this call the
+ * inputs of cobs_gpu_batch_run are resident in HBM.  Runs of the batch that are
+ * still in flight must have been waited for (cobs_gpu_batch_sync) before. */
 cobs_gpu_status cobs_gpu_batch_set_queries(cobs_gpu_batch* b, const char* const* queries,
                                            const size_t* lens, size_t nq);
 /* One pass of the hot path over the batch, asynchronously on `hip_stream`
