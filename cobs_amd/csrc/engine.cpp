@@ -929,6 +929,8 @@ static cobs_gpu_status set_queries_on(cobs_gpu_batch* b, const char* const* quer
     if (!b || (nq && (!queries || !lens))) return fail(COBS_GPU_ERR_ARG, "NULL argument");
     cobs_gpu_index* ix = b->ix;
     HIP_TRY(hipSetDevice(ix->device));
+    // the upload overwrites buffers a run still in flight would read: wait for a run nobody synced
+    if (b->ran && !b->synced) HIP_TRY(hipDeviceSynchronize());
     b->ran = false;
     b->nq = 0;
     if (nq >= 0xFFFFFFFEull) return fail(COBS_GPU_ERR_ARG, "too many queries");

@@ -203,8 +203,8 @@ cobs_gpu_status cobs_gpu_batch_create(cobs_gpu_index* ix, size_t max_queries,
                                       size_t max_query_len, cobs_gpu_batch** out);
 void cobs_gpu_batch_destroy(cobs_gpu_batch* b);
 /* Copy query text to HBM (one H2D) and validate lengths.  After this call the
- * inputs of cobs_gpu_batch_run are resident in HBM.  Runs of the batch that are
- * still in flight must have been waited for (cobs_gpu_batch_sync) before. */
+ * inputs of cobs_gpu_batch_run are resident in HBM.  A run of the batch that is
+ * still in flight and was never synced is waited for first. */
 cobs_gpu_status cobs_gpu_batch_set_queries(cobs_gpu_batch* b, const char* const* queries,
                                            const size_t* lens, size_t nq);
 /* One pass of the hot path over the batch, asynchronously on `hip_stream`
