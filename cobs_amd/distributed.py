@@ -9,7 +9,7 @@ produces the counts of its own documents.  One exchange per batch brings the
 disjoint slices together:
 
   * counts mode (threshold 0, every document is a result): all-gather of the
-    u16/u32 count slices (as bytes -- RCCL has no 16-bit integer type);
+    u8/u16/u32 count slices (as bytes -- RCCL has no 16-bit integer type);
   * hits mode (threshold > 0): each rank selects its hits on the device; the
     small (file, doc, score) lists are gathered and merged by
     (score desc, file asc, doc asc), the reference's result order
@@ -119,7 +119,10 @@ class ShardedSearch:
     def search_hits(self, queries, threshold=0.0, num_results=0):
         s = self.search_local
         self.batch.set_queries(queries)
-        self.batch.run(threshold)
+        if num_results > 0:
+            self.batch.run_topk(threshold, num_results)      # K3: only the k best of the shard leave the device
+        else:
+            self.batch.run(threshold)
         self.batch.sync()
         # local ranked hits of the held documents; truncation to num_results per shard is safe
         # because the global top-k is a subset of the union of the per-shard top-k
