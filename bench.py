@@ -49,6 +49,15 @@ def c2_config(scale=1.0):
             "term_size": 31, "canonicalize": 1, "num_hashes": 1, "seed": 1}
 
 
+def c4_config(scale=1.0):
+    """BASELINE configs[3]: compact, 1M docs, default page size 512 B -> 245 sub-indexes (the index
+    that is sharded by sub-index block over 8 GPUs; 68 GB, it also fits one MI355X)"""
+    r = (1600000 / 100000) ** (1.0 / 244)
+    return {"kind": "compact", "num_docs": 1000000, "page_size": 512,
+            "signature_sizes": [max(64, int(100000 * r ** i * scale)) for i in range(245)],
+            "term_size": 31, "canonicalize": 1, "num_hashes": 1, "seed": 1}
+
+
 def make_queries(n, kmers, seed=42):
     """benchmark-fpr queries (reference src/cobs.cpp:709-720): one std::mt19937(seed),
     rng() % 4 -> ACGT, kmers+30 characters each.  numpy's legacy RandomState uses the
@@ -287,7 +296,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--queries", type=int, default=10000, help="queries per batch (whole job)")
     ap.add_argument("--kmers", type=int, default=1000)
-    ap.add_argument("--config", choices=["c3", "c2"], default="c3")
+    ap.add_argument("--config", choices=["c3", "c2", "c4"], default="c3")
     ap.add_argument("--scale", type=float, default=1.0, help="scale signature sizes (smoke runs)")
     ap.add_argument("--threshold", type=float, default=0.0,
                     help="0 = benchmark-fpr semantics (all documents scored)")
@@ -322,7 +331,7 @@ def main():
     n_gpus = world
     dev = torch.cuda.current_device()
 
-    cfg = (c3_config if args.config == "c3" else c2_config)(args.scale)
+    cfg = {"c3": c3_config, "c2": c2_config, "c4": c4_config}[args.config](args.scale)
     shard_index = world > 1 and args.shard_mode == "index"
     s = cobs_amd.Search.synthetic(cfg["kind"], cfg["signature_sizes"], cfg["num_docs"],
                                   page_size=cfg["page_size"], term_size=cfg["term_size"],
@@ -414,14 +423,15 @@ def main():
         "dtype": "u32",        # bitwise ops on 32-bit column words (bit-sliced counters); scores leave as u16
         "data": "synthetic",
         "config": {
-            "workload": ("BASELINE configs[2]: synthetic compact index, %d docs, %d sub-indexes, page_size %d B, "
-                         "S_p %d..%d rows (%.1f GB in HBM), batch of %d queries x %d k-mers, H=%d, threshold %g"
+            "workload": ("BASELINE configs[%d]: synthetic compact index, %%d docs, %%d sub-indexes, page_size %%d B, "
+                         "S_p %%d..%%d rows (%%.1f GB in HBM), batch of %%d queries x %%d k-mers, H=%%d, threshold %%g"
+                         % (2 if args.config == "c3" else 3)
                          % (cfg["num_docs"], len(cfg["signature_sizes"]), cfg["page_size"],
                             cfg["signature_sizes"][0], cfg["signature_sizes"][-1],
                             sum(cfg["signature_sizes"]) * cfg["page_size"] / 1e9,
                             args.queries, args.kmers, cfg["num_hashes"], args.threshold)
                          + (", top-%d selected on device" % args.num_results if args.num_results else ""))
-            if args.config == "c3" else
+            if args.config != "c2" else
             ("BASELINE configs[1]: synthetic classic index, %d docs x %d rows, batch of %d queries x %d k-mers"
              % (cfg["num_docs"], cfg["signature_sizes"][0], args.queries, args.kmers)),
             "global_batch": total_queries,

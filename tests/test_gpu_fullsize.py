@@ -24,12 +24,12 @@ def _oracle_index(O, cfg):
                              cfg["seed"])
 
 
-@pytest.mark.parametrize("name", ["c3", "c2"])
+@pytest.mark.parametrize("name", ["c3", "c2", "c4"])
 def test_full_size_config(gpu_lib, oracle, name):
-    cfg = bench.c3_config() if name == "c3" else bench.c2_config()
+    cfg = {"c3": bench.c3_config, "c2": bench.c2_config, "c4": bench.c4_config}[name]()
     s = _open(gpu_lib, cfg)
     ix = _oracle_index(oracle, cfg)
-    nq = 256
+    nq = 256 if name != "c4" else 64              # C4: 1M documents, 245 sub-indexes, 68 GB
     queries = bench.make_queries(nq, 1000)
     b = gpu_lib.Batch(s)
     b.set_queries(queries)
