@@ -289,6 +289,44 @@ def sharded_extra(args, cfg, world, rank, dev):
                            "count slices overlapped with the next scan" % (world, len(sub))}
 
 
+def sharded_c4_extra(args, world, rank, dev):
+    """N > 1: BASELINE configs[3] -- the 1M-document compact index (245 sub-indexes) sharded by
+    sub-index block over the ranks, one 1000-query batch, per-document counts of the (unequal)
+    blocks all-gathered over RCCL/xGMI (padded to the largest block)."""
+    from cobs_amd.distributed import all_gather_counts
+    cfg = c4_config(args.scale)
+    nq = 1000
+    ok, err, b = 1, "", None
+    try:
+        s = cobs_amd.Search.synthetic(cfg["kind"], cfg["signature_sizes"], cfg["num_docs"],
+                                      page_size=cfg["page_size"], term_size=cfg["term_size"],
+                                      canonicalize=cfg["canonicalize"], num_hashes=cfg["num_hashes"],
+                                      seed=cfg["seed"], device=dev, shard_rank=rank, shard_count=world)
+        b = cobs_amd.Batch(s)
+        b.set_queries(make_queries(nq, args.kmers))
+    except Exception as e:                                          # noqa: BLE001
+        ok, err = 0, repr(e)
+    flag = torch.tensor([ok], dtype=torch.int64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        return {"skipped": err or "set-up failed on another rank"}
+    sizes = {}
+
+    def step():
+        b.run(args.threshold, 0)
+        parts = all_gather_counts(b.counts_tensor(), None)
+        sizes["bytes"] = sum(int(t.numel()) * t.element_size() for t in parts)
+
+    steps = max(1, min(args.steps, 3))
+    dt = timed(step, steps, 1, world, args.dist_backend)
+    b.sync()
+    scan_ms = b.kernel_ms()["scan_ms"]
+    return {"workload": "BASELINE configs[3]: compact index, 1000000 docs, 245 sub-indexes sharded over %d ranks, "
+                        "batch of %d queries x %d k-mers" % (world, nq, args.kmers),
+            "queries_per_s": round(nq * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+            "scan_ms_per_step_rank0": round(scan_ms, 4), "gathered_bytes_per_step": sizes.get("bytes", 0)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -459,6 +497,8 @@ def main():
     if world > 1 and not shard_index and not args.no_sharded_extra:
         del batch, s
         extra = sharded_extra(args, cfg, world, rank, dev)
+        if args.config == "c3":
+            extra["c4_1M_docs"] = sharded_c4_extra(args, world, rank, dev)
         out["index_sharded"] = extra
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["end_to_end"] = end_to_end(s, batch, mine)
