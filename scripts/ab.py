@@ -29,6 +29,11 @@ def main():
         cfg = {"kind": "compact", "num_docs": 1000000, "page_size": 512,
                "signature_sizes": [int(100000 * r ** i) for i in range(245)]}
         nq, kmers = 1000, 1000
+    elif shape == "c4big":      # C4 geometry with a 10x larger batch (more lookups per cached line)
+        r = (1600000 / 100000) ** (1.0 / 244)
+        cfg = {"kind": "compact", "num_docs": 1000000, "page_size": 512,
+               "signature_sizes": [int(100000 * r ** i) for i in range(245)]}
+        nq, kmers = 6000, 1000
     elif shape == "ps128":
         r = 16 ** (1.0 / 97)
         cfg = {"kind": "compact", "num_docs": 100000, "page_size": 128,
