@@ -22,6 +22,8 @@ def main():
     elif shape.startswith("reads"):
         bp = int(shape[5:])
         cfg, nq, kmers = bench.c3_config(), 40000, bp - 30
+    elif shape in ("c3h2", "c3h3"):     # several hash functions: the AND (aggregate_rows) variant of the scan
+        cfg, nq, kmers = dict(bench.c3_config(), num_hashes=int(shape[-1])), 4000, 1000
     elif shape == "c2":
         cfg, nq, kmers = bench.c2_config(), 10000, 1000
     elif shape == "c4":
@@ -41,7 +43,8 @@ def main():
         nq, kmers = 4000, 1000
     else:
         raise SystemExit("unknown shape")
-    s = cobs_amd.Search.synthetic(cfg["kind"], cfg["signature_sizes"], cfg["num_docs"], page_size=cfg["page_size"], seed=1)
+    s = cobs_amd.Search.synthetic(cfg["kind"], cfg["signature_sizes"], cfg["num_docs"], page_size=cfg["page_size"], seed=1,
+                                  num_hashes=cfg.get("num_hashes", 1))
     b = cobs_amd.Batch(s)
     b.set_queries(bench.make_queries(nq, kmers))
     keys = sorted({k for c in configs for k in c})
