@@ -14,6 +14,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _native_code_is_built():
+    """A fresh checkout has no binaries (they are git-ignored): build libcobs_gpu.so with hipcc
+    (cross-compiles for gfx950 without a GPU) before the first test.  A tree that already holds
+    the library -- e.g. the snapshot on the GPU box -- is left alone."""
+    import subprocess
+    lib = os.path.join(ROOT, "cobs_amd", "libcobs_gpu.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "cobs_amd", "csrc"), "-j8"],
+                              stdout=subprocess.DEVNULL)
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
