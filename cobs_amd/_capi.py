@@ -12,20 +12,23 @@ LIB_PATH = os.path.join(_HERE, "libcobs_gpu.so")
 
 OK = 0
 ERR_OPEN, ERR_FORMAT, ERR_QUERY_TOO_SHORT, ERR_INVALID_BASE, ERR_QUERY_TOO_LONG = 1, 2, 3, 4, 5
-ERR_HIP, ERR_ARG, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_NO_DEVICE = 6, 7, 8, 9, 10
+ERR_HIP, ERR_ARG, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_NO_DEVICE, ERR_RCCL = 6, 7, 8, 9, 10, 11
+XCHG_ALLGATHER, XCHG_ALLTOALL = 0, 1
+UNIQUE_ID_BYTES = 128
 
 STATUS_NAMES = {
     0: "COBS_GPU_OK", 1: "COBS_GPU_ERR_OPEN", 2: "COBS_GPU_ERR_FORMAT",
     3: "COBS_GPU_ERR_QUERY_TOO_SHORT", 4: "COBS_GPU_ERR_INVALID_BASE",
     5: "COBS_GPU_ERR_QUERY_TOO_LONG", 6: "COBS_GPU_ERR_HIP", 7: "COBS_GPU_ERR_ARG",
     8: "COBS_GPU_ERR_UNSUPPORTED", 9: "COBS_GPU_ERR_CAPACITY", 10: "COBS_GPU_ERR_NO_DEVICE",
+    11: "COBS_GPU_ERR_RCCL",
 }
 
 
 class Options(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32),
                 ("shard_rank", C.c_uint32), ("shard_count", C.c_uint32),
-                ("waves_per_group", C.c_uint32), ("reserved", C.c_uint32),
+                ("waves_per_group", C.c_uint32), ("shard_mode", C.c_uint32),
                 ("hbm_budget_bytes", C.c_uint64)]
 
 
@@ -59,6 +62,7 @@ class Synth(C.Structure):
 # name -> (restype, argtypes): every symbol include/cobs_gpu.h declares
 _vp, _sz, _u32, _u64, _cp, _dbl, _int = (C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64,
                                         C.c_char_p, C.c_double, C.c_int)
+_pu64 = C.POINTER(C.c_uint64)
 SYMBOLS = {
     "cobs_gpu_abi_version": (_u32, []),
     "cobs_gpu_last_error": (_cp, []),
@@ -66,6 +70,9 @@ SYMBOLS = {
     "cobs_gpu_open": (_int, [C.POINTER(_cp), _sz, C.POINTER(Options), C.POINTER(_vp)]),
     "cobs_gpu_open_synthetic": (_int, [C.POINTER(Synth), C.POINTER(Options), C.POINTER(_vp)]),
     "cobs_gpu_close": (None, [_vp]),
+    "cobs_gpu_set_tuning": (_int, [_vp, _cp, C.c_int64]),
+    "cobs_gpu_plan_shards": (_int, [_cp, _u32, _u32, _pu64, _pu64, _pu64]),
+    "cobs_gpu_page_columns": (_int, [_vp, _sz, _u32, _pu64, _pu64]),
     "cobs_gpu_num_files": (_sz, [_vp]),
     "cobs_gpu_info": (_int, [_vp, _sz, C.POINTER(IndexInfo)]),
     "cobs_gpu_signature_size": (_u64, [_vp, _sz, _u32]),
@@ -94,6 +101,18 @@ SYMBOLS = {
     "cobs_gpu_batch_stats": (_int, [_vp, C.POINTER(_u64 * 4)]),
     "cobs_gpu_batch_kernel_ms": (_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "cobs_gpu_timers": (_int, [_vp, C.POINTER(C.c_double * 5), _int]),
+    "cobs_gpu_comm_unique_id": (_int, [_vp]),
+    "cobs_gpu_comm_create": (_int, [_vp, _int, _int, _int, C.POINTER(_vp)]),
+    "cobs_gpu_comm_destroy": (None, [_vp]),
+    "cobs_gpu_comm_rank": (_int, [_vp]),
+    "cobs_gpu_comm_size": (_int, [_vp]),
+    "cobs_gpu_batch_exchange_counts": (_int, [_vp, _vp, _u32, _vp]),
+    "cobs_gpu_batch_global_counts_device": (_vp, [_vp, _pu64, _pu64, C.POINTER(_u32), _pu64]),
+    "cobs_gpu_batch_exchange_bytes": (_u64, [_vp]),
+    "cobs_gpu_batch_exchange_hits": (_int, [_vp, _vp, _vp, C.POINTER(_int)]),
+    "cobs_gpu_batch_exchange_topk": (_int, [_vp, _vp, _vp]),
+    "cobs_gpu_sharded_search_batch": (_int, [_vp, _vp, C.POINTER(_cp), C.POINTER(_sz), _sz, _dbl, _sz,
+                                             C.POINTER(Hit), _sz, C.POINTER(_sz), C.POINTER(_sz)]),
 }
 
 _lib = None
@@ -121,7 +140,7 @@ def load():
         fn = getattr(lib, name)       # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.cobs_gpu_abi_version() != 1:
+    if lib.cobs_gpu_abi_version() != 2:
         raise ImportError("cobs_amd: libcobs_gpu.so has an unexpected ABI version")
     _lib = lib
     return lib

@@ -1,0 +1,468 @@
+// cobs_amd/csrc/comm.cpp -- the multi-GPU half of libcobs_gpu.so: RCCL communicators and the
+// one exchange step of the sub-index-sharded layout.
+//
+// The reference has no distributed code.  What makes the path shardable is its own data
+// layout: a compact index is a concatenation of sub-indexes over disjoint, contiguous
+// document ranges (reference cobs/query/compact_index/mmap_search_file.cpp:22-27,
+// search_file.cpp:30-32), and per-document counts never combine across sub-indexes or row-byte
+// columns.  Every GPU stages and scans only its slice for the whole query batch
+// (cobs_gpu_options.shard_rank / shard_count) and ends with the counts of ITS documents;
+// one exchange per batch then brings the disjoint slices together:
+//
+//   counts, ALLTOALL  rank j owns the queries [nq*j/N, nq*(j+1)/N): every rank sends it the rows
+//                     of those queries (grouped ncclSend/ncclRecv, the slices travel as bytes --
+//                     RCCL has no 16-bit integer type).  Each count crosses xGMI once, to one
+//                     GPU: (N-1)/N of the score matrix in total, spread over all N*(N-1) links.
+//   counts, ALLGATHER every rank receives every slice (ncclAllGather when the slices have the
+//                     same size, else grouped ncclSend/ncclRecv): N-1 times the traffic; the
+//                     parity / "every rank ranks everything" mode.
+//   hit lists         with a threshold only (query, file, doc, score) records leave a shard:
+//                     sizes first (ncclAllGather of the pool fills), then the records.
+//   top-k             the k best of every shard (K3 output, same size on every rank):
+//                     one ncclAllGather; the global top-k is a subset of their union.
+//
+// The received slices are assembled into rows in global document order with strided
+// device-to-device copies, so that everything downstream (K3, ranking, D2H) sees the same
+// layout as on one GPU.  All calls are collective: every rank of the communicator makes the
+// same call with the same batch contents.
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "engine.hpp"
+
+using namespace cobs_amd;
+
+struct cobs_gpu_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1, device = 0;
+};
+
+namespace cobs_amd {
+
+// per-batch exchange workspace
+struct Exchange {
+    const cobs_gpu_comm* bound = nullptr;        // communicator the layout below was gathered on
+    size_t nparts = 0;
+    std::vector<uint64_t> layout;                // [rank][part][2] = slot_begin, slot_count
+    std::vector<uint64_t> local_n;               // [rank] score slots per query on that rank
+    DevBuf<uint8_t> staging;                     // received slices, rank after rank
+    DevBuf<uint8_t> global;                      // assembled rows
+    DevBuf<uint64_t> d_meta;                     // small device scratch for size exchanges
+    DevBuf<HitDev> hits_all;                     // gathered hit pools
+    DevBuf<uint2> topk_all;
+    DevBuf<uint32_t> topk_cnt_all;
+    uint64_t bytes_moved = 0;                    // bytes this rank received over the fabric in the last exchange
+};
+
+void destroy_exchange(Exchange* x) { delete x; }
+
+}  // namespace cobs_amd
+
+namespace {
+
+cobs_gpu_status nccl_fail(ncclResult_t r, const char* what) {
+    return fail(COBS_GPU_ERR_RCCL, std::string(what) + ": " + ncclGetErrorString(r));
+}
+
+#define NCCL_TRY(expr)                                         \
+    do {                                                       \
+        ncclResult_t _r = (expr);                              \
+        if (_r != ncclSuccess) return nccl_fail(_r, #expr);    \
+    } while (0)
+
+// every rank's score-slot layout, gathered once per (batch, communicator)
+cobs_gpu_status bind_layout(cobs_gpu_batch* b, const cobs_gpu_comm* c, hipStream_t st) {
+    if (!b->xchg) b->xchg = new Exchange;
+    Exchange& x = *b->xchg;
+    if (x.bound == c) return COBS_GPU_OK;
+    const cobs_gpu_index* ix = b->ix;
+    const size_t np = ix->parts.size(), per = 2 * np + 2, N = (size_t)c->nranks;
+    std::vector<uint64_t> mine(per);
+    mine[0] = np;
+    mine[1] = ix->total_counts;
+    for (size_t f = 0; f < np; ++f) {
+        mine[2 + 2 * f] = ix->parts[f].slot_begin;
+        mine[3 + 2 * f] = ix->parts[f].slot_count;
+    }
+    HIP_TRY(x.d_meta.reserve(per * (N + 1)));
+    HIP_TRY(hipMemcpyAsync(x.d_meta.p, mine.data(), per * 8, hipMemcpyHostToDevice, st));
+    NCCL_TRY(ncclAllGather(x.d_meta.p, x.d_meta.p + per, per * 8, ncclUint8, c->comm, st));
+    std::vector<uint64_t> all(per * N);
+    HIP_TRY(hipMemcpyAsync(all.data(), x.d_meta.p + per, per * N * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    x.layout.assign(N * np * 2, 0);
+    x.local_n.assign(N, 0);
+    for (size_t r = 0; r < N; ++r) {
+        const uint64_t* m = all.data() + r * per;
+        if (m[0] != np || m[1] != ix->total_counts)
+            return fail(COBS_GPU_ERR_ARG, "the ranks of the communicator did not open the same index files");
+        for (size_t f = 0; f < np; ++f) {
+            x.layout[(r * np + f) * 2] = m[2 + 2 * f];
+            x.layout[(r * np + f) * 2 + 1] = m[3 + 2 * f];
+            x.local_n[r] += m[3 + 2 * f];
+        }
+    }
+    x.nparts = np;
+    x.bound = c;
+    return COBS_GPU_OK;
+}
+
+// strided copy of one rank's slice block [nrows][n_r] into global rows [nrows][total]
+cobs_gpu_status assemble(const cobs_gpu_batch* b, const Exchange& x, size_t r, const uint8_t* src, uint8_t* dst,
+                         size_t nrows, hipStream_t st) {
+    if (nrows == 0) return COBS_GPU_OK;
+    const cobs_gpu_index* ix = b->ix;
+    const size_t eb = b->elem_bytes, np = x.nparts;
+    uint64_t local_off = 0;
+    for (size_t f = 0; f < np; ++f) {
+        const uint64_t begin = x.layout[(r * np + f) * 2], count = x.layout[(r * np + f) * 2 + 1];
+        if (count)
+            HIP_TRY(hipMemcpy2DAsync(dst + (ix->parts[f].doc_offset + begin) * eb, ix->total_counts * eb,
+                                     src + local_off * eb, x.local_n[r] * eb, count * eb, nrows,
+                                     hipMemcpyDeviceToDevice, st));
+        local_off += count;
+    }
+    return COBS_GPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+cobs_gpu_status cobs_gpu_comm_unique_id(uint8_t id[COBS_GPU_UNIQUE_ID_BYTES]) {
+    if (!id) return fail(COBS_GPU_ERR_ARG, "NULL argument");
+    static_assert(sizeof(ncclUniqueId) == COBS_GPU_UNIQUE_ID_BYTES, "unique id size");
+    ncclUniqueId u;
+    NCCL_TRY(ncclGetUniqueId(&u));
+    std::memcpy(id, &u, sizeof u);
+    return COBS_GPU_OK;
+}
+
+cobs_gpu_status cobs_gpu_comm_create(const uint8_t id[COBS_GPU_UNIQUE_ID_BYTES], int rank, int nranks, int device,
+                                     cobs_gpu_comm** out) {
+    if (!out) return fail(COBS_GPU_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!id || nranks <= 0 || rank < 0 || rank >= nranks) return fail(COBS_GPU_ERR_ARG, "bad rank / nranks / id");
+    return guarded([&]() -> cobs_gpu_status {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+            (void)hipGetLastError();
+            return fail(COBS_GPU_ERR_NO_DEVICE, "no HIP device visible; libcobs_gpu has no CPU fallback");
+        }
+        if (device < 0) HIP_TRY(hipGetDevice(&device));
+        if (device >= ndev) return fail(COBS_GPU_ERR_ARG, "device ordinal out of range");
+        HIP_TRY(hipSetDevice(device));
+        std::unique_ptr<cobs_gpu_comm> c(new cobs_gpu_comm);
+        c->rank = rank;
+        c->nranks = nranks;
+        c->device = device;
+        ncclUniqueId u;
+        std::memcpy(&u, id, sizeof u);
+        NCCL_TRY(ncclCommInitRank(&c->comm, nranks, u, rank));
+        *out = c.release();
+        return COBS_GPU_OK;
+    });
+}
+
+void cobs_gpu_comm_destroy(cobs_gpu_comm* c) {
+    if (!c) return;
+    if (c->comm) {
+        (void)hipSetDevice(c->device);
+        (void)ncclCommDestroy(c->comm);
+    }
+    delete c;
+}
+
+int cobs_gpu_comm_rank(const cobs_gpu_comm* c) {
+    int r = -1;
+    if (c && c->comm && ncclCommUserRank(c->comm, &r) == ncclSuccess) return r;
+    return -1;
+}
+
+int cobs_gpu_comm_size(const cobs_gpu_comm* c) {
+    int n = 0;
+    if (c && c->comm && ncclCommCount(c->comm, &n) == ncclSuccess) return n;
+    return 0;
+}
+
+cobs_gpu_status cobs_gpu_batch_exchange_counts(cobs_gpu_batch* b, cobs_gpu_comm* c, uint32_t mode, void* hip_stream) {
+    if (!b || !c) return fail(COBS_GPU_ERR_ARG, "NULL argument");
+    if (!b->ran || !b->have_counts) return fail(COBS_GPU_ERR_ARG, "run the batch with score rows first");
+    if (mode > COBS_GPU_XCHG_ALLTOALL) return fail(COBS_GPU_ERR_ARG, "unknown exchange mode");
+    return guarded([&]() -> cobs_gpu_status {
+        hipStream_t st = (hipStream_t)hip_stream;
+        const cobs_gpu_index* ix = b->ix;
+        HIP_TRY(hipSetDevice(ix->device));
+        cobs_gpu_status s = bind_layout(b, c, st);
+        if (s != COBS_GPU_OK) return s;
+        Exchange& x = *b->xchg;
+        const size_t N = (size_t)c->nranks, me = (size_t)c->rank, eb = b->elem_bytes, nq = b->nq;
+        // query group of rank j (ALLTOALL); ALLGATHER: every rank takes all queries
+        auto q0_of = [&](size_t j) { return mode == COBS_GPU_XCHG_ALLTOALL ? nq * j / N : (size_t)0; };
+        auto q1_of = [&](size_t j) { return mode == COBS_GPU_XCHG_ALLTOALL ? nq * (j + 1) / N : nq; };
+        const size_t my_q0 = q0_of(me), my_nq = q1_of(me) - my_q0;
+        // staging: the block of rank r is [my_nq][n_r]
+        std::vector<size_t> off(N + 1, 0);
+        for (size_t r = 0; r < N; ++r) off[r + 1] = off[r] + (r == me ? 0 : my_nq * x.local_n[r] * eb);
+        const uint8_t* mine = b->counts.p;
+        const size_t my_row = (size_t)(x.local_n[me] * eb);
+        // same-size slices (always so on one rank): the library collective, ncclAllGather
+        bool equal = mode == COBS_GPU_XCHG_ALLGATHER;
+        for (size_t r = 0; r < N; ++r) equal = equal && x.local_n[r] == x.local_n[me];
+        HIP_TRY(x.staging.reserve(std::max<size_t>(equal ? N * nq * my_row : off[N], 1)));
+        HIP_TRY(x.global.reserve(std::max<size_t>(my_nq * ix->total_counts * eb, 1)));
+        x.bytes_moved = equal ? (N - 1) * nq * my_row : off[N];
+        if (equal) {
+            // staging = [rank][nq][n] incl. our own block
+            NCCL_TRY(ncclAllGather(mine, x.staging.p, nq * my_row, ncclUint8, c->comm, st));
+            for (size_t r = 0; r < N; ++r) {
+                s = assemble(b, x, r, x.staging.p + r * nq * my_row, x.global.p, nq, st);
+                if (s != COBS_GPU_OK) return s;
+            }
+        } else {
+            if (N > 1) {
+                NCCL_TRY(ncclGroupStart());
+                for (size_t j = 0; j < N; ++j) {
+                    if (j == me) continue;
+                    const size_t sq0 = q0_of(j), snq = q1_of(j) - sq0;
+                    if (snq && my_row) NCCL_TRY(ncclSend(mine + sq0 * my_row, snq * my_row, ncclUint8, (int)j, c->comm, st));
+                    if (off[j + 1] > off[j]) NCCL_TRY(ncclRecv(x.staging.p + off[j], off[j + 1] - off[j], ncclUint8, (int)j, c->comm, st));
+                }
+                NCCL_TRY(ncclGroupEnd());
+            }
+            for (size_t r = 0; r < N; ++r) {
+                const uint8_t* src = r == me ? mine + my_q0 * my_row : x.staging.p + off[r];
+                s = assemble(b, x, r, src, x.global.p, my_nq, st);
+                if (s != COBS_GPU_OK) return s;
+            }
+        }
+        b->g_rows = x.global.p;
+        b->g_q0 = my_q0;
+        b->g_qn = my_nq;
+        b->view_global = true;
+        b->rows_q0 = b->rows_q1 = 0;
+        HIP_TRY(hipEventRecord(b->run_done, st));
+        return COBS_GPU_OK;
+    });
+}
+
+void* cobs_gpu_batch_global_counts_device(cobs_gpu_batch* b, uint64_t* q_begin, uint64_t* q_count,
+                                          uint32_t* elem_bytes, uint64_t* row_stride_bytes) {
+    if (!b || !b->view_global) return nullptr;
+    if (q_begin) *q_begin = b->g_q0;
+    if (q_count) *q_count = b->g_qn;
+    if (elem_bytes) *elem_bytes = b->elem_bytes;
+    if (row_stride_bytes) *row_stride_bytes = b->ix->total_counts * b->elem_bytes;
+    return const_cast<uint8_t*>(b->g_rows);
+}
+
+uint64_t cobs_gpu_batch_exchange_bytes(const cobs_gpu_batch* b) { return b && b->xchg ? b->xchg->bytes_moved : 0; }
+
+// Hit lists: call after cobs_gpu_batch_sync of a run with a threshold.  *overflow (optional) is
+// set when some rank's pool overflowed -- the lists are then incomplete everywhere and the caller
+// repeats the pass with score rows (every rank sees the same flag).
+cobs_gpu_status cobs_gpu_batch_exchange_hits(cobs_gpu_batch* b, cobs_gpu_comm* c, void* hip_stream, int* overflow) {
+    if (!b || !c) return fail(COBS_GPU_ERR_ARG, "NULL argument");
+    if (!b->ran || !b->synced || !b->selected)
+        return fail(COBS_GPU_ERR_ARG, "run the batch with a threshold and sync it first");
+    return guarded([&]() -> cobs_gpu_status {
+        hipStream_t st = (hipStream_t)hip_stream;
+        HIP_TRY(hipSetDevice(b->ix->device));
+        if (!b->xchg) b->xchg = new Exchange;
+        Exchange& x = *b->xchg;
+        const size_t N = (size_t)c->nranks, me = (size_t)c->rank;
+        // sizes first
+        const uint64_t mine = b->h_nhits();
+        HIP_TRY(x.d_meta.reserve(N + 1 + 64));
+        HIP_TRY(hipMemcpyAsync(x.d_meta.p, &mine, 8, hipMemcpyHostToDevice, st));
+        NCCL_TRY(ncclAllGather(x.d_meta.p, x.d_meta.p + 1, 8, ncclUint8, c->comm, st));
+        std::vector<uint64_t> n(N);
+        HIP_TRY(hipMemcpyAsync(n.data(), x.d_meta.p + 1, 8 * N, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        bool over = false;
+        uint64_t total = 0;
+        std::vector<uint64_t> off(N + 1, 0);
+        for (size_t r = 0; r < N; ++r) {
+            over = over || n[r] > b->hit_cap;       // the pool capacity is a function of the batch: equal on all ranks
+            off[r + 1] = off[r] + n[r];
+            total += n[r];
+        }
+        if (overflow) *overflow = over ? 1 : 0;
+        if (over) return COBS_GPU_OK;
+        HIP_TRY(x.hits_all.reserve(std::max<size_t>((size_t)total, 1)));
+        if (N > 1) {
+            NCCL_TRY(ncclGroupStart());
+            for (size_t j = 0; j < N; ++j) {
+                if (j == me) continue;
+                if (mine) NCCL_TRY(ncclSend(b->hits.p, mine * sizeof(HitDev), ncclUint8, (int)j, c->comm, st));
+                if (n[j]) NCCL_TRY(ncclRecv(x.hits_all.p + off[j], n[j] * sizeof(HitDev), ncclUint8, (int)j, c->comm, st));
+            }
+            NCCL_TRY(ncclGroupEnd());
+        }
+        if (mine)
+            HIP_TRY(hipMemcpyAsync(x.hits_all.p + off[me], b->hits.p, mine * sizeof(HitDev), hipMemcpyDeviceToDevice, st));
+        std::vector<HitDev> raw((size_t)total);
+        if (total)
+            HIP_TRY(hipMemcpyAsync(raw.data(), x.hits_all.p, total * sizeof(HitDev), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        x.bytes_moved = (total - mine) * sizeof(HitDev);
+        // bucket by query (the order inside a bucket is fixed later by the ranking sort)
+        b->h_hit_off.assign(b->nq + 1, 0);
+        for (const HitDev& h : raw)
+            if (h.query < b->nq) b->h_hit_off[h.query + 1]++;
+        for (size_t i = 0; i < b->nq; ++i) b->h_hit_off[i + 1] += b->h_hit_off[i];
+        b->h_hits.resize(raw.size());
+        std::vector<size_t> cur(b->h_hit_off.begin(), b->h_hit_off.end() - 1);
+        for (const HitDev& h : raw)
+            if (h.query < b->nq) b->h_hits[cur[h.query]++] = h;
+        b->pool_fetched = true;
+        b->pool_global = true;
+        return COBS_GPU_OK;
+    });
+}
+
+// Top-k candidates: call after a run with num_results > 0 (K3 ran).  Every rank ends up with the
+// k best documents of every shard; cobs_gpu_batch_hits_host then merges them per query.
+cobs_gpu_status cobs_gpu_batch_exchange_topk(cobs_gpu_batch* b, cobs_gpu_comm* c, void* hip_stream) {
+    if (!b || !c) return fail(COBS_GPU_ERR_ARG, "NULL argument");
+    if (!b->ran || b->topk_k == 0) return fail(COBS_GPU_ERR_ARG, "run the batch with num_results > 0 first");
+    return guarded([&]() -> cobs_gpu_status {
+        hipStream_t st = (hipStream_t)hip_stream;
+        HIP_TRY(hipSetDevice(b->ix->device));
+        if (!b->xchg) b->xchg = new Exchange;
+        Exchange& x = *b->xchg;
+        const size_t N = (size_t)c->nranks, k = b->topk_k, nq = b->nq, np = b->ix->parts.size();
+        const size_t ne = k * nq * np, nc = nq * np;
+        HIP_TRY(x.topk_all.reserve(std::max<size_t>(N * ne, 1)));
+        HIP_TRY(x.topk_cnt_all.reserve(std::max<size_t>(N * nc, 1)));
+        if (ne) NCCL_TRY(ncclAllGather(b->topk_out.p, x.topk_all.p, ne * sizeof(uint2), ncclUint8, c->comm, st));
+        if (nc) NCCL_TRY(ncclAllGather(b->topk_cnt.p, x.topk_cnt_all.p, nc * 4, ncclUint8, c->comm, st));
+        std::vector<uint2> all(N * ne);
+        std::vector<uint32_t> cnt(N * nc);
+        if (ne) HIP_TRY(hipMemcpyAsync(all.data(), x.topk_all.p, N * ne * sizeof(uint2), hipMemcpyDeviceToHost, st));
+        if (nc) HIP_TRY(hipMemcpyAsync(cnt.data(), x.topk_cnt_all.p, N * nc * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        x.bytes_moved = (N - 1) * (ne * sizeof(uint2) + nc * 4);
+        // [file][query][rank * k]: the candidates of all ranks side by side, packed to the front
+        b->h_topk.assign(N * ne, make_uint2(0, 0));
+        b->h_topk_cnt.assign(nc, 0);
+        for (size_t f = 0; f < np; ++f)
+            for (size_t q = 0; q < nq; ++q) {
+                uint2* dst = b->h_topk.data() + (f * nq + q) * (N * k);
+                uint32_t m = 0;
+                for (size_t r = 0; r < N; ++r) {
+                    const uint2* src = all.data() + r * ne + (f * nq + q) * k;
+                    const uint32_t cr = std::min<uint32_t>(cnt[r * nc + f * nq + q], (uint32_t)k);
+                    for (uint32_t i = 0; i < cr; ++i) dst[m++] = src[i];
+                }
+                b->h_topk_cnt[f * nq + q] = m;
+            }
+        b->topk_stride = (uint32_t)(N * k);
+        b->topk_fetched = true;
+        return COBS_GPU_OK;
+    });
+}
+
+// ClassicSearch::search over the sharded index: every rank calls this with the same queries and
+// gets the same, global, result (hits ordered as cobs_gpu_search_batch orders them).
+cobs_gpu_status cobs_gpu_sharded_search_batch(cobs_gpu_index* ix, cobs_gpu_comm* c, const char* const* queries,
+                                              const size_t* lens, size_t nq, double threshold, size_t num_results,
+                                              cobs_gpu_hit* hits, size_t cap, size_t* hit_offsets, size_t* bad_query) {
+    if (!ix || !c || !hit_offsets) return fail(COBS_GPU_ERR_ARG, "NULL argument");
+    if (nq && (!queries || !lens)) return fail(COBS_GPU_ERR_ARG, "NULL argument");
+    return guarded([&]() -> cobs_gpu_status {
+        HIP_TRY(hipSetDevice(ix->device));
+        if (!ix->scratch[0]) {
+            cobs_gpu_status cs = cobs_gpu_batch_create(ix, 0, 0, &ix->scratch[0]);
+            if (cs != COBS_GPU_OK) return cs;
+            HIP_TRY(hipStreamCreateWithFlags(&ix->scratch[0]->own_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&ix->scratch[0]->done, hipEventDisableTiming));
+        }
+        cobs_gpu_batch* b = ix->scratch[0];
+        hipStream_t st = b->own_stream;
+        hit_offsets[0] = 0;
+        size_t used = 0;
+        bool overflow = false;
+        // passes bounded like the single-GPU API (score rows / tables below the workspace limit)
+        uint32_t min_term = 0xFFFFFFFFu;
+        uint64_t table_per_char = 0;
+        for (const auto& p : ix->parts) {
+            min_term = std::min(min_term, p.meta.term_size);
+            table_per_char += 4ull * p.meta.num_hashes * std::max<uint32_t>(p.num_tpages(), 1) * (p.idx64 ? 2 : 1);
+        }
+        const size_t topk = num_results < ix->total_counts ? num_results : 0;
+        const bool all_docs = threshold <= 0.0 && topk == 0;
+        size_t g0 = 0;
+        do {
+            size_t g1 = g0;
+            uint64_t tb = 0, max_terms = 1;
+            while (g1 < nq) {
+                const uint64_t terms = lens[g1] >= min_term ? lens[g1] - min_term + 1 : 1;
+                const uint64_t mt = std::max(max_terms, terms);
+                const int planes = scan_planes_for(mt);
+                const uint64_t eb = planes > 0 ? scan_score_bytes(planes) : 4u;
+                // local rows, plus the assembled global rows of the all-documents mode
+                const uint64_t sb = (uint64_t)(g1 - g0 + 1) * (ix->local_counts + (all_docs ? ix->total_counts : 0)) * eb;
+                const uint64_t t = (uint64_t)(lens[g1] + 16) * table_per_char;
+                if (g1 > g0 && (sb > ix->tune.pass_bytes || tb + t > ix->tune.pass_bytes)) break;
+                max_terms = mt;
+                tb += t;
+                ++g1;
+            }
+            size_t bad = 0;
+            cobs_gpu_status s = set_queries_on(b, queries + g0, lens + g0, g1 - g0, st, false, &bad);
+            if (s != COBS_GPU_OK) {
+                if (bad_query) *bad_query = g0 + bad;
+                return s;
+            }
+            const bool hits_only = threshold > 0.0 && topk == 0;
+            s = run_impl(b, threshold, topk, st, !hits_only);
+            if (s != COBS_GPU_OK) return s;
+            s = cobs_gpu_batch_sync(b, st, &bad);
+            if (s != COBS_GPU_OK) {
+                if (bad_query) *bad_query = g0 + bad;
+                return s;
+            }
+            bool need_rows = !hits_only && b->topk_k == 0;
+            if (b->topk_k) {
+                s = cobs_gpu_batch_exchange_topk(b, c, st);
+                if (s != COBS_GPU_OK) return s;
+            } else if (b->selected) {
+                int over = 0;
+                s = cobs_gpu_batch_exchange_hits(b, c, st, &over);
+                if (s != COBS_GPU_OK) return s;
+                if (over) {     // some shard selected more hits than the pool holds: score rows instead
+                    s = run_impl(b, threshold, topk, st, true);
+                    if (s != COBS_GPU_OK) return s;
+                    s = cobs_gpu_batch_sync(b, st, &bad);
+                    if (s != COBS_GPU_OK) return s;
+                    b->selected = false;
+                    need_rows = true;
+                }
+            }
+            if (need_rows) {
+                // every rank ranks every query (the contract of this call): all slices to all ranks
+                s = cobs_gpu_batch_exchange_counts(b, c, COBS_GPU_XCHG_ALLGATHER, st);
+                if (s != COBS_GPU_OK) return s;
+                HIP_TRY(hipStreamSynchronize(st));
+            }
+            for (size_t q = g0; q < g1; ++q) {
+                size_t n = 0;
+                s = cobs_gpu_batch_hits_host(b, q - g0, num_results, overflow ? nullptr : hits + used,
+                                             overflow ? 0 : cap - used, &n);
+                if (s == COBS_GPU_ERR_CAPACITY || (overflow && s == COBS_GPU_ERR_ARG)) overflow = true;
+                else if (s != COBS_GPU_OK) return s;
+                used += n;
+                hit_offsets[q + 1] = used;
+            }
+            g0 = g1;
+        } while (g0 < nq);
+        if (overflow) return fail(COBS_GPU_ERR_CAPACITY, "hit buffer too small; hit_offsets[nq] holds the needed size");
+        return COBS_GPU_OK;
+    });
+}
+
+}  // extern "C"

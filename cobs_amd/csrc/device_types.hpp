@@ -15,7 +15,7 @@ struct PageDev {
     uint32_t slot0;        // first local score slot of this page (multiple of 8)
     uint32_t doc0;         // file-level document id of the page's first document
     uint32_t valid_bytes;  // row bytes that map to score slots (<= pitch)
-    uint32_t reserved;
+    uint32_t tpage;        // index of this sub-index in the part-wide row-index table (K1 output)
 };
 
 // Arguments of the hashing kernel K1 for one index file.
@@ -24,7 +24,7 @@ struct HashArgs {
     const uint64_t* span_off;   // nq + 1 prefix sums of per-query thread spans
     const uint32_t* q_len;      // characters per query
     const uint64_t* blk_off;    // nq + 1 prefix sums of 8-term blocks per query
-    const PageDev* pages;       // local sub-indexes
+    const PageDev* pages;       // the file-level sub-indexes this part holds (table pages): sig / magic are used
     void* table;                // row indices (u32, or u64 when idx64): [q][page][block (nblk + 1 padding block)][hash][8]
     uint32_t* err_query;        // atomicMax of (2^32-1 - q) over queries q holding a non-ACGT base; 0 = none
     uint32_t nq;
@@ -52,12 +52,13 @@ struct ScanArgs {
     void* counts;               // u8, u16 or u32 [nq][counts_stride]
     const uint32_t* thresholds; // per query (this file) or nullptr = no selection
     HitDev* hits;               // selection pool
-    uint32_t* hit_count;        // pool fill (may exceed hit_cap: overflow)
+    unsigned long long* hit_count;   // pool fill (may exceed hit_cap: overflow; 64-bit so that it cannot wrap)
     uint64_t counts_stride;     // elements per query row
     uint64_t counts_offset;     // local slot offset of this file inside a row
     uint32_t hit_cap;
     uint32_t nq;
     uint32_t npages;
+    uint32_t table_npages;      // sub-indexes in the row-index table (its page stride); PageDev::tpage selects one
     uint32_t pitch;             // bytes between rows
     uint32_t cpp;               // 16-byte chunks per row (pitch / 16)
     uint32_t total_chunks;      // npages * cpp

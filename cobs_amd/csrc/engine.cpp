@@ -11,14 +11,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <numeric>
 #include <string>
 #include <thread>
 #include <vector>
 
-#include "../../include/cobs_gpu.h"
-#include "device_types.hpp"
-#include "index_file.hpp"
-#include "kernels.hpp"
+#include "engine.hpp"
 
 using namespace cobs_amd;
 
@@ -26,8 +24,10 @@ using namespace cobs_amd;
 // errors
 
 namespace {
-
 thread_local std::string g_last_error;
+}
+
+namespace cobs_amd {
 
 cobs_gpu_status fail(cobs_gpu_status st, const std::string& msg) {
     g_last_error = msg;
@@ -42,204 +42,59 @@ cobs_gpu_status hip_fail(hipError_t e, const char* what) {
     return fail(nodev ? COBS_GPU_ERR_NO_DEVICE : COBS_GPU_ERR_HIP, m);
 }
 
-#define HIP_TRY(expr)                                              \
-    do {                                                           \
-        hipError_t _e = (expr);                                    \
-        if (_e != hipSuccess) return hip_fail(_e, #expr);          \
-    } while (0)
-
 double now_s() {
     using namespace std::chrono;
     return duration<double>(steady_clock::now().time_since_epoch()).count();
 }
 
-uint64_t round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
-
-template <typename T>
-struct DevBuf {     // grow-only device allocation
-    T* p = nullptr;
-    size_t cap = 0;   // elements
-    DevBuf() = default;
-    DevBuf(const DevBuf&) = delete;
-    DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t reserve(size_t n) {
-        if (n <= cap) return hipSuccess;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        hipError_t e = hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T));
-        if (e == hipSuccess) cap = n;
-        return e;
+Tuning Tuning::from_env() {
+    Tuning t;
+    if (const char* e = getenv("COBS_GPU_ROW_ALIGN")) {
+        const uint64_t v = std::strtoull(e, nullptr, 10);
+        if (v >= 16 && v <= 4096 && v % 16 == 0) t.row_align = (uint32_t)v;
     }
-};
-
-template <typename T>
-struct PinnedBuf {  // grow-only pinned host staging
-    T* p = nullptr;
-    size_t cap = 0;
-    PinnedBuf() = default;
-    PinnedBuf(const PinnedBuf&) = delete;
-    PinnedBuf& operator=(const PinnedBuf&) = delete;
-    PinnedBuf(PinnedBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
-    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
-    hipError_t reserve(size_t n) {
-        if (n <= cap) return hipSuccess;
-        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
-        hipError_t e = hipHostMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T), hipHostMallocDefault);
-        if (e == hipSuccess) cap = n;
-        return e;
+    if (const char* e = getenv("COBS_GPU_WAVES")) {
+        const int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4) t.waves = (uint32_t)v;
     }
-};
-
-// A slice of one file-level sub-index: all of its rows, row bytes [col0, col0+ncols).
-struct VPage {
-    uint32_t fp = 0;
-    uint64_t col0 = 0, ncols = 0;
-};
-
-// A group of slices (equal width) that is in HBM at the same time.  A resident
-// index is one chunk; an index larger than the HBM budget is cut into chunks that
-// are streamed through two device buffers, one scan pass per chunk (documents of
-// different sub-indexes / column ranges never combine, so every chunk is an
-// independent scan that fills its own score slots).
-struct Chunk {
-    std::vector<VPage> vp;
-    std::vector<PageDev> pages;      // bases relative to the chunk's buffer
-    PageDev* d_pages = nullptr;
-    uint32_t pitch = 0, cpp = 0, total_chunks = 0;
-    size_t bytes = 0;                // device bytes incl. zero rows
-    size_t stage_bytes = 0;          // packed host bytes (rows x ncols)
-    uint8_t* d_data = nullptr;       // resident chunk only
-};
-
-// One index file as held by this device (possibly only a shard of it).
-struct Part {
-    IndexMeta meta;
-    uint32_t first_page = 0, end_page = 0;   // file-level sub-indexes held here
-    uint64_t col0 = 0, ncols = 0;            // row bytes [col0, col0+ncols) of each held sub-index
-    std::vector<Chunk> chunks;
-    bool streamed = false;
-    bool idx64 = false;                      // a sub-index has >= 2^32 - 1 rows: 64-bit row-index table
-    size_t hbm_bytes = 0;
-    uint32_t max_chunk_pages = 0;
-    // streaming state (BASELINE config 5: index larger than the HBM budget)
-    std::unique_ptr<MappedFile> file;        // source of the chunks
-    bool file_pinned = false;                // the mapping is registered with HIP: DMA straight from it
-    bool synthetic = false;
-    uint64_t synth_seed = 0;
-    DevBuf<uint8_t> sbuf[2];
-    PinnedBuf<uint8_t> stage[2];
-    hipStream_t copy_stream = nullptr;
-    hipEvent_t copied[2] = {nullptr, nullptr}, scanned[2] = {nullptr, nullptr};
-    bool buf_used[2] = {false, false};
-    size_t stage_need = 0;
-    uint64_t doc_offset = 0;      // first global score slot of this file
-    uint64_t slot_begin = 0;      // file-level score slots computed here
-    uint64_t slot_count = 0;
-    uint64_t local_offset = 0;    // position of those slots in a local count row
-
-    uint32_t num_vpages() const {
-        uint32_t n = 0;
-        for (const Chunk& c : chunks) n += (uint32_t)c.vp.size();
-        return n;
+    if (const char* e = getenv("COBS_GPU_TILE_W")) {
+        const int v = atoi(e);
+        if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) t.tile_w = (uint32_t)v;
     }
-    Part() = default;
-    Part(Part&&) = default;
-    Part(const Part&) = delete;
-    ~Part() {
-        for (Chunk& c : chunks) {
-            if (c.d_data) (void)hipFree(c.d_data);
-            if (c.d_pages) (void)hipFree(c.d_pages);
-        }
-        if (file_pinned && file) (void)hipHostUnregister(const_cast<uint8_t*>(file->data()));
-        for (auto& e : copied) if (e) (void)hipEventDestroy(e);
-        for (auto& e : scanned) if (e) (void)hipEventDestroy(e);
-        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    if (const char* e = getenv("COBS_GPU_MQ")) t.mq = atoi(e) != 0;
+    if (const char* e = getenv("COBS_GPU_PASS_BYTES")) t.pass_bytes = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
+    if (const char* e = getenv("COBS_GPU_PIPE_CHARS")) t.pipe_chars = std::strtoull(e, nullptr, 10);
+    if (getenv("COBS_GPU_NO_PIN")) t.no_pin = true;
+    if (const char* e = getenv("COBS_GPU_GRAPH")) t.graph = atoi(e) != 0;
+    return t;
+}
+
+Part::~Part() {
+    for (Chunk& c : chunks) {
+        if (c.d_data) (void)hipFree(c.d_data);
+        if (c.d_pages) (void)hipFree(c.d_pages);
     }
-};
+    if (d_tpages) (void)hipFree(d_tpages);
+    if (file_pinned && file) (void)hipHostUnregister(const_cast<uint8_t*>(file->data()));
+}
 
-}  // namespace
+StreamBufs::~StreamBufs() {
+    for (auto& e : copied) if (e) (void)hipEventDestroy(e);
+    for (auto& e : scanned) if (e) (void)hipEventDestroy(e);
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
+}
 
-struct cobs_gpu_index {
-    int device = 0;
-    uint32_t shard_rank = 0, shard_count = 1;
-    uint64_t hbm_budget = 0;      // 0 = everything resident
-    uint32_t waves_per_group = 0; // 0 = by query length
-    std::vector<Part> parts;
-    uint64_t total_counts = 0, local_counts = 0;
-    double timers[5] = {0, 0, 0, 0, 0};
-    static constexpr int kScratch = 3;
-    cobs_gpu_batch* scratch[kScratch] = {nullptr, nullptr, nullptr};   // workspaces of the host-buffer search API
-    ~cobs_gpu_index();
-};
+}  // namespace cobs_amd
 
-namespace {
-
-struct PartWork {    // per-file device workspace of a batch
-    const uint64_t* blk_off = nullptr;   // inside the batch's upload buffer
-    DevBuf<uint32_t> table;
-    DevBuf<uint32_t> thr;
-    std::vector<uint64_t> h_blk_off;
-    std::vector<uint32_t> h_thr;
-    uint64_t table_entries = 0;
-};
-
-}  // namespace
-
-struct cobs_gpu_batch {
-    cobs_gpu_index* ix = nullptr;
-    size_t max_queries = 0, max_len = 0;
-    size_t nq = 0;
-    std::vector<uint32_t> lens;
-    std::vector<uint64_t> span_off;
-    DevBuf<uint8_t> text;
-    // query text, span offsets, query lengths and the per-file block offsets live in ONE pinned
-    // staging buffer / ONE device buffer (`text`): a batch is uploaded with a single async copy
-    const uint64_t* d_span_off = nullptr;
-    const uint32_t* d_qlen = nullptr;
-    PinnedBuf<uint8_t> h_text;
-    PinnedBuf<uint32_t> h_thr_stage;
-    std::vector<PartWork> work;
-    DevBuf<uint8_t> counts;
-    uint32_t elem_bytes = 2;
-    int planes = 0;
-    uint64_t max_terms = 0;              // longest query of the batch, in terms
-    DevBuf<HitDev> hits;
-    DevBuf<uint2> topk_out;           // K3 output [file][query][k]
-    DevBuf<uint32_t> topk_cnt;        // [file][query]
-    std::vector<uint2> h_topk;
-    std::vector<uint32_t> h_topk_cnt;
-    uint32_t topk_k = 0;              // k of the last run (0 = K3 not run)
-    bool topk_fetched = false;
-    DevBuf<uint32_t> flags;           // [0] first invalid query, [1] selected hits
-    uint32_t hit_cap = 0;
-    // last run
-    bool ran = false, selected = false, synced = false;
-    bool have_counts = false;         // the last run wrote the score rows
-    double threshold = 0.0;
-    uint32_t h_flags[2] = {0, 0};
-    std::vector<HitDev> h_hits;       // pool copy, sorted by query
-    std::vector<size_t> h_hit_off;
-    bool pool_fetched = false;
-    // host copy of a window of score rows [rows_q0, rows_q1) of the last run (raw elem_bytes)
-    PinnedBuf<uint8_t> h_rows;
-    size_t rows_q0 = 0, rows_q1 = 0;
-    std::vector<uint32_t> rank_hist;  // scratch of the counting sort in hits_host
-    std::vector<cobs_gpu_hit> sel_scratch;
-    // HIP events around K1 and K2 of the most recent runs (recorded on the launch stream)
-    static constexpr int kRing = 64;
-    hipEvent_t ev[kRing][3] = {};
-    uint64_t run_seq = 0, read_seq = 0;
-    uint64_t stats[4] = {0, 0, 0, 0};
-    // host-buffer API only: the stream this scratch batch lives on and the event after its pass
-    hipStream_t own_stream = nullptr;
-    hipEvent_t done = nullptr;
-    ~cobs_gpu_batch() {
-        for (auto& r : ev) for (auto& e : r) if (e) (void)hipEventDestroy(e);
-        if (done) (void)hipEventDestroy(done);
-        if (own_stream) (void)hipStreamDestroy(own_stream);
-    }
-};
+cobs_gpu_batch::~cobs_gpu_batch() {
+    if (xchg) destroy_exchange(xchg);
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    if (graph_stream) (void)hipStreamDestroy(graph_stream);
+    for (auto& r : ev) for (auto& e : r) if (e) (void)hipEventDestroy(e);
+    if (run_done) (void)hipEventDestroy(run_done);
+    if (done) (void)hipEventDestroy(done);
+    if (own_stream) (void)hipStreamDestroy(own_stream);
+}
 
 cobs_gpu_index::~cobs_gpu_index() { for (auto* b : scratch) delete b; }
 
@@ -271,21 +126,18 @@ cobs_gpu_status select_device(const cobs_gpu_options* o, int* device) {
 // Rows are made of 16-byte chunks.  Starting every row on a 128-byte cache-line
 // boundary removes the partial lines at both ends of a gathered row (measured on
 // MI355X: 1568-byte rows, 1664-byte pitch: -8.5 % scan time); it is applied when
-// it costs at most 12.5 % more HBM.  COBS_GPU_ROW_ALIGN overrides (tuning hook).
-uint32_t pitch_for(uint64_t ncols) {
+// it costs at most 12.5 % more HBM.  Tuning::row_align overrides.
+uint32_t pitch_for(uint64_t ncols, const Tuning& tune) {
     uint64_t align = 16;
     for (uint64_t a : {128ull, 64ull, 32ull}) {
         if (round_up(ncols, a) * 8 <= ncols * 9) { align = a; break; }
     }
-    if (const char* e = getenv("COBS_GPU_ROW_ALIGN")) {
-        const uint64_t v = std::strtoull(e, nullptr, 10);
-        if (v >= 16 && v <= 4096 && v % 16 == 0) align = v;
-    }
+    if (tune.row_align) align = tune.row_align;
     return (uint32_t)round_up(ncols, align);
 }
 
-uint64_t slice_bytes(uint64_t sig, uint64_t ncols) {
-    return round_up((sig + 1) * (uint64_t)pitch_for(ncols), 256);     // +1: the all-zero row
+uint64_t slice_bytes(uint64_t sig, uint64_t ncols, const Tuning& tune) {
+    return round_up((sig + 1) * (uint64_t)pitch_for(ncols, tune), 256);     // +1: the all-zero row
 }
 
 // Geometry of a scan launch: tile width W (16-byte column chunks per tile: 64, 32, 16, 8 or 4)
@@ -302,11 +154,11 @@ uint64_t slice_bytes(uint64_t sig, uint64_t ncols) {
 //   tile is fixed): NV = largest power of two <= blocks / 1.75, at most 32.  Measured optimum
 //   for 100/150/250-bp reads (9/15/28 blocks): (NW 2, W 32), (NW 2, W 16), (NW 2, W 8).
 // * Indexes narrower than a wave get the smallest tile that covers them (no idle lanes).
-// Tuning hooks: COBS_GPU_TILE_W, COBS_GPU_WAVES force a value.
+// Tuning hooks (per handle): tile_w, waves, mq force a value.
 struct ScanGeom { uint32_t tile_w; int nwaves; bool multi_query; };
 
 ScanGeom scan_geometry(const Chunk& c, uint64_t mean_blocks, uint64_t max_blocks, uint64_t num_hashes,
-                       uint32_t forced_waves, int planes, bool idx64) {
+                       uint32_t forced_waves, int planes, bool idx64, const Tuning& tune) {
     uint32_t nv = 1;
     while (nv < 32 && (uint64_t)nv * 2 * 7 <= mean_blocks * 4) nv <<= 1;     // blocks / NV >= 1.75
     ScanGeom g;
@@ -330,52 +182,38 @@ ScanGeom scan_geometry(const Chunk& c, uint64_t mean_blocks, uint64_t max_blocks
         if (max_sig * 256ull <= (256ull << 20) && g.nwaves >= 2) { g.tile_w = 16; }
     }
     if (forced_waves) g.nwaves = (int)forced_waves;
-    if (const char* e = getenv("COBS_GPU_WAVES")) {
-        const int v = atoi(e);
-        if (v == 1 || v == 2 || v == 4) g.nwaves = v;
-    }
+    if (tune.waves) g.nwaves = (int)tune.waves;
     if (c.total_chunks < g.tile_w) {           // index narrower than the tile
         uint32_t cover = 4;
         while (cover < c.total_chunks) cover <<= 1;
         g.tile_w = std::min<uint32_t>(g.tile_w, std::max<uint32_t>(cover, 8));
         if (c.total_chunks <= 4) g.tile_w = 4;
     }
-    if (const char* e = getenv("COBS_GPU_TILE_W")) {
-        const int v = atoi(e);
-        if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) g.tile_w = (uint32_t)v;
-    }
+    if (tune.tile_w) g.tile_w = tune.tile_w;
     // Very short queries (<= 10 blocks: reads up to ~110 bp): the lane groups of a wave serve 8
     // different queries instead of splitting one query's few blocks.  Interleaved A/B on the C3
     // index: 50-bp reads -7.4 % scan time with (W 8, NW 2), 100-bp reads -4 % with (W 8, NW 1);
     // from 150 bp on the one-query geometry above is faster (+2.4 %, 250 bp: equal, C3: +1.5 %).
     g.multi_query = false;
-    int mq_env = -1;                           // tuning hook: COBS_GPU_MQ=0/1 forces the variant
-    if (const char* e = getenv("COBS_GPU_MQ")) mq_env = atoi(e) != 0;
-    if (mq_env != 0 && !idx64 && forced_waves == 0 && mean_blocks <= 10 && max_blocks <= 20 && c.total_chunks >= 8 &&
+    if (tune.mq != 0 && !idx64 && forced_waves == 0 && mean_blocks <= 10 && max_blocks <= 20 && c.total_chunks >= 8 &&
         scan_has_multi_query(planes, (uint32_t)num_hashes, 8)) {
         g.multi_query = true;
         g.tile_w = 8;
         g.nwaves = mean_blocks <= 5 ? 2 : 1;
-        if (const char* e = getenv("COBS_GPU_WAVES")) {
-            const int v = atoi(e);
-            if (v == 1 || v == 2 || v == 4) g.nwaves = v;
-        }
-        if (const char* e = getenv("COBS_GPU_TILE_W")) {
-            const int v = atoi(e);
-            if (v == 4 || v == 8 || v == 16 || v == 32) g.tile_w = (uint32_t)v;
-        }
+        if (tune.waves) g.nwaves = (int)tune.waves;
+        if (tune.tile_w && tune.tile_w < 64) g.tile_w = tune.tile_w;
     }
-    if (mq_env == 1 && !idx64) g.multi_query = true;
+    if (tune.mq == 1 && !idx64) g.multi_query = true;
     if (g.multi_query && !scan_has_multi_query(planes, (uint32_t)num_hashes, g.tile_w)) g.multi_query = false;
     return g;
 }
 
 // fill pages / geometry of a chunk whose slices (equal ncols) are already listed
-void layout_chunk(const Part& pt, Chunk& c) {
+void layout_chunk(const Part& pt, Chunk& c, const Tuning& tune) {
     const IndexMeta& m = pt.meta;
     const uint64_t prb = m.page_row_bytes();
     const uint64_t ncols = c.vp.empty() ? 0 : c.vp[0].ncols;
-    c.pitch = pitch_for(ncols);
+    c.pitch = pitch_for(ncols, tune);
     c.cpp = c.pitch / 16;
     c.total_chunks = (uint32_t)c.vp.size() * c.cpp;
     c.pages.resize(c.vp.size());
@@ -390,7 +228,7 @@ void layout_chunk(const Part& pt, Chunk& c) {
         pd.slot0 = (uint32_t)(file_slot - pt.slot_begin);
         pd.doc0 = (uint32_t)file_slot;
         pd.valid_bytes = (uint32_t)v.ncols;
-        pd.reserved = 0;
+        pd.tpage = v.fp - pt.first_page;
         off += round_up((pd.sig + 1) * (uint64_t)c.pitch, 256);
         packed += pd.sig * v.ncols;
     }
@@ -398,11 +236,7 @@ void layout_chunk(const Part& pt, Chunk& c) {
     c.stage_bytes = packed;
 }
 
-// Decide which slice of the file this shard holds and cut it into chunks:
-// one resident chunk if it fits `budget` (0 = unlimited), else streamed chunks of at
-// most budget/2 bytes each (two device buffers).
-cobs_gpu_status plan_part(Part& pt, uint32_t rank, uint32_t count, uint64_t* budget_left) {
-    const IndexMeta& m = pt.meta;
+cobs_gpu_status check_meta(const IndexMeta& m) {
     if (m.term_size == 0) return fail(COBS_GPU_ERR_FORMAT, "term_size is zero");
     if (m.num_hashes == 0 || m.num_hashes > 64)
         return fail(COBS_GPU_ERR_UNSUPPORTED, "num_hashes must be in 1..64");
@@ -411,151 +245,279 @@ cobs_gpu_status plan_part(Part& pt, uint32_t rank, uint32_t count, uint64_t* bud
     for (uint64_t s : m.signature_sizes)
         if (s == 0 || s > (1ull << 46))
             return fail(COBS_GPU_ERR_UNSUPPORTED, "signature_size must be in 1..2^46");
+    const uint64_t prb = m.page_row_bytes();
+    if (prb == 0 || prb > (1ull << 28)) return fail(COBS_GPU_ERR_UNSUPPORTED, "row too wide");
+    if (m.signature_sizes.empty()) return fail(COBS_GPU_ERR_FORMAT, "index holds no sub-index");
+    if ((uint64_t)m.num_pages() * prb > 0xFFFFFFF0ull / 8)
+        return fail(COBS_GPU_ERR_UNSUPPORTED, "more than 2^32 score slots in one file");
+    return COBS_GPU_OK;
+}
+
+}  // namespace
+
+namespace cobs_amd {
+
+// The slices of a file that shard `rank` of `count` holds (documents of different
+// sub-indexes / row-byte columns never combine, so any cut of the (sub-index, column) space
+// gives independent shards; reference compact_index/mmap_search_file.cpp:22-27,
+// search_file.cpp:30-32).  The unit is one 16-byte column chunk of one sub-index; its cost is
+// the sub-index's signature size (rows).
+//   mode 0 (default): equal BYTES per shard -- a cut may fall inside a sub-index (8 sub-indexes
+//     whose sizes differ 16x would otherwise give 8 GPUs a 3x speed-up at best); a cut within
+//     3 % of a shard's share of a sub-index boundary snaps to it.
+//   mode 1: whole sub-indexes, equal COUNT per shard (compact), 16-byte columns (classic).
+// The held slices are contiguous in score-slot order: [tail columns of the first sub-index]
+// [whole sub-indexes] [head columns of the last].
+std::vector<VPage> held_slices(const IndexMeta& m, uint32_t rank, uint32_t count, uint32_t mode) {
+    const uint64_t prb = m.page_row_bytes();
+    const uint32_t P = m.num_pages();
+    const uint64_t nch = (prb + 15) / 16;                       // 16-byte chunks per row
+    std::vector<VPage> out;
+    if (count <= 1) {
+        for (uint32_t p = 0; p < P; ++p) out.push_back(VPage{p, 0, prb});
+        return out;
+    }
+    // a cut is a global chunk position in [0, P * nch]
+    auto cut_of = [&](uint32_t r) -> uint64_t {
+        if (r == 0) return 0;
+        if (r >= count) return (uint64_t)P * nch;
+        if (mode == 1) {
+            if (m.kind == IndexKind::Compact) return (uint64_t)((uint64_t)P * r / count) * nch;
+            return nch * r / count;
+        }
+        long double total = 0;
+        for (uint32_t p = 0; p < P; ++p) total += (long double)m.signature_sizes[p] * nch;
+        const long double share = total / count, ideal = share * r;
+        long double acc = 0;
+        for (uint32_t p = 0; p < P; ++p) {
+            const long double w = (long double)m.signature_sizes[p] * nch;
+            if (acc + w < ideal) { acc += w; continue; }
+            // the cut falls into sub-index p
+            const long double tol = 0.03L * share;
+            if (ideal - acc <= tol) return (uint64_t)p * nch;
+            if (acc + w - ideal <= tol) return (uint64_t)(p + 1) * nch;
+            uint64_t c = (uint64_t)((ideal - acc) / (long double)m.signature_sizes[p] + 0.5L);
+            if (c > nch) c = nch;
+            return (uint64_t)p * nch + c;
+        }
+        return (uint64_t)P * nch;
+    };
+    const uint64_t c0 = cut_of(rank), c1 = std::max(cut_of(rank + 1), c0);
+    for (uint64_t c = c0; c < c1;) {
+        const uint32_t p = (uint32_t)(c / nch);
+        const uint64_t in = c - (uint64_t)p * nch;
+        const uint64_t end = std::min<uint64_t>(nch, in + (c1 - c));
+        const uint64_t b0 = in * 16, b1 = std::min<uint64_t>(prb, end * 16);
+        if (b1 > b0) out.push_back(VPage{p, b0, b1 - b0});
+        c += end - in;
+    }
+    return out;
+}
+
+}  // namespace cobs_amd
+
+namespace {
+
+// Which slices this shard holds, their score-slot range and what they need in HBM.
+cobs_gpu_status plan_part(Part& pt, const cobs_gpu_index* ix) {
+    const IndexMeta& m = pt.meta;
+    cobs_gpu_status st = check_meta(m);
+    if (st != COBS_GPU_OK) return st;
     // row indices are 32-bit unless a sub-index (plus its zero row) does not fit them
     pt.idx64 = false;
     for (uint64_t s : m.signature_sizes)
         if (s >= 0xFFFFFFFFull) pt.idx64 = true;
-    if (m.counts_size() > 0xFFFFFFF0ull)
-        return fail(COBS_GPU_ERR_UNSUPPORTED, "more than 2^32 score slots in one file");
     const uint64_t prb = m.page_row_bytes();
-    if (m.kind == IndexKind::Compact) {
-        const uint32_t P = m.num_pages();
-        pt.first_page = (uint32_t)((uint64_t)P * rank / count);
-        pt.end_page = (uint32_t)((uint64_t)P * (rank + 1) / count);
-        pt.col0 = 0;
-        pt.ncols = prb;
-        pt.slot_begin = (uint64_t)pt.first_page * 8 * prb;
-        pt.slot_count = (uint64_t)(pt.end_page - pt.first_page) * 8 * prb;
-    } else {
-        const uint64_t nch = (prb + 15) / 16;
-        const uint64_t c0 = nch * rank / count, c1 = nch * (rank + 1) / count;
-        pt.col0 = c0 * 16;
-        pt.ncols = std::min<uint64_t>(prb, c1 * 16) - std::min<uint64_t>(prb, pt.col0);
-        pt.first_page = 0;
-        pt.end_page = pt.ncols ? 1 : 0;
-        pt.slot_begin = pt.col0 * 8;
-        pt.slot_count = pt.ncols * 8;
-    }
-    if (pt.ncols > 0xFFFFFFF0ull / 16) return fail(COBS_GPU_ERR_UNSUPPORTED, "row too wide");
+    pt.held = held_slices(m, ix->shard_rank, ix->shard_count, ix->shard_mode);
     pt.chunks.clear();
-    const uint32_t nlocal = pt.end_page - pt.first_page;
-    if (nlocal == 0) return COBS_GPU_OK;
-    uint64_t resident = 0;
-    for (uint32_t fp = pt.first_page; fp < pt.end_page; ++fp) resident += slice_bytes(m.signature_sizes[fp], pt.ncols);
-    const bool unlimited = budget_left == nullptr;
-    if (unlimited || resident <= *budget_left) {
-        Chunk c;
-        for (uint32_t fp = pt.first_page; fp < pt.end_page; ++fp) c.vp.push_back(VPage{fp, pt.col0, pt.ncols});
-        layout_chunk(pt, c);
-        pt.chunks.push_back(std::move(c));
-        pt.streamed = false;
-        pt.hbm_bytes = resident;
-        if (!unlimited) *budget_left -= resident;
-    } else {
-        const uint64_t cap = *budget_left / 2;
-        *budget_left = 0;
-        Chunk cur;
-        uint64_t cur_bytes = 0;
-        auto flush = [&]() {
-            if (!cur.vp.empty()) {
-                layout_chunk(pt, cur);
-                pt.chunks.push_back(std::move(cur));
-                cur = Chunk();
-                cur_bytes = 0;
-            }
-        };
-        for (uint32_t fp = pt.first_page; fp < pt.end_page; ++fp) {
-            const uint64_t sig = m.signature_sizes[fp];
-            const uint64_t full = slice_bytes(sig, pt.ncols);
-            if (full <= cap) {
-                if (cur_bytes + full > cap) flush();
-                cur.vp.push_back(VPage{fp, pt.col0, pt.ncols});
-                cur_bytes += full;
-                continue;
-            }
-            flush();
-            // a single sub-index exceeds a buffer: cut it by columns (all rows, fewer documents)
-            uint64_t w = cap / (sig + 1);
-            w = w >= 128 ? w / 128 * 128 : w / 16 * 16;
-            while (w >= 16 && slice_bytes(sig, w) > cap) w -= 16;
-            if (w < 16)
-                return fail(COBS_GPU_ERR_CAPACITY,
-                            "hbm budget too small: a 16-byte column slice of the largest sub-index needs " +
-                            std::to_string(2 * slice_bytes(sig, 16)) + " bytes");
-            for (uint64_t c0 = 0; c0 < pt.ncols; c0 += w) {
-                cur.vp.push_back(VPage{fp, pt.col0 + c0, std::min<uint64_t>(w, pt.ncols - c0)});
-                flush();
-            }
-        }
-        flush();
-        pt.streamed = true;
-        pt.hbm_bytes = 2 * cap;
+    pt.resident_bytes = 0;
+    if (pt.held.empty()) {
+        pt.first_page = pt.end_page = 0;
+        pt.slot_begin = pt.slot_count = 0;
+        return COBS_GPU_OK;
     }
-    pt.max_chunk_pages = 0;
-    for (const Chunk& c : pt.chunks) pt.max_chunk_pages = std::max<uint32_t>(pt.max_chunk_pages, (uint32_t)c.vp.size());
+    pt.first_page = pt.held.front().fp;
+    pt.end_page = pt.held.back().fp + 1;
+    const uint64_t page_slots = m.kind == IndexKind::Compact ? 8 * prb : 0;
+    pt.slot_begin = (uint64_t)pt.held.front().fp * page_slots + pt.held.front().col0 * 8;
+    pt.slot_count = 0;
+    for (const VPage& v : pt.held) {
+        pt.slot_count += v.ncols * 8;
+        pt.resident_bytes += slice_bytes(m.signature_sizes[v.fp], v.ncols, ix->tune);
+    }
+    pt.tpages.assign(pt.end_page - pt.first_page, PageDev{});
+    for (uint32_t fp = pt.first_page; fp < pt.end_page; ++fp) {
+        PageDev& t = pt.tpages[fp - pt.first_page];
+        t.sig = m.signature_sizes[fp];
+        t.magic = ~0ull / t.sig;
+        t.tpage = fp - pt.first_page;
+    }
     return COBS_GPU_OK;
 }
 
-cobs_gpu_status alloc_part(Part& pt) {
+// Cut the held slices into chunks: resident (cap == 0) = one chunk per run of equal-width
+// slices; streamed = chunks of at most `cap` bytes each (two device buffers of `cap` bytes).
+cobs_gpu_status chunk_part(Part& pt, uint64_t cap, const Tuning& tune) {
+    const IndexMeta& m = pt.meta;
+    pt.chunks.clear();
+    pt.streamed = cap != 0;
+    Chunk cur;
+    uint64_t cur_bytes = 0;
+    auto flush = [&]() {
+        if (!cur.vp.empty()) {
+            layout_chunk(pt, cur, tune);
+            pt.chunks.push_back(std::move(cur));
+            cur = Chunk();
+            cur_bytes = 0;
+        }
+    };
+    for (const VPage& v : pt.held) {
+        const uint64_t sig = m.signature_sizes[v.fp];
+        const uint64_t full = slice_bytes(sig, v.ncols, tune);
+        if (!cur.vp.empty() && cur.vp[0].ncols != v.ncols) flush();
+        if (cap == 0 || full <= cap) {
+            if (cap != 0 && cur_bytes + full > cap) flush();
+            cur.vp.push_back(v);
+            cur_bytes += full;
+            continue;
+        }
+        flush();
+        // a single slice exceeds a buffer: cut it by columns (all rows, fewer documents)
+        uint64_t w = cap / (sig + 1);
+        w = w >= 128 ? w / 128 * 128 : w / 16 * 16;
+        while (w >= 16 && slice_bytes(sig, w, tune) > cap) w -= 16;
+        if (w < 16)
+            return fail(COBS_GPU_ERR_CAPACITY,
+                        "hbm budget too small: a 16-byte column slice of the largest sub-index needs " +
+                        std::to_string(2 * slice_bytes(sig, 16, tune)) + " bytes of streaming buffers");
+        for (uint64_t c0 = 0; c0 < v.ncols; c0 += w) {
+            cur.vp.push_back(VPage{v.fp, v.col0 + c0, std::min<uint64_t>(w, v.ncols - c0)});
+            flush();
+        }
+    }
+    flush();
+    return COBS_GPU_OK;
+}
+
+// Decide residency for all files of the handle together (the budget is one number for the
+// whole handle): everything resident if it fits; otherwise the smallest files stay resident
+// while they use at most half the budget and all other files are streamed through ONE pair of
+// device buffers sized from what is left.
+cobs_gpu_status plan_index(cobs_gpu_index* ix) {
+    for (auto& pt : ix->parts) {
+        cobs_gpu_status st = plan_part(pt, ix);
+        if (st != COBS_GPU_OK) return st;
+    }
+    uint64_t total = 0;
+    for (auto& pt : ix->parts) total += pt.resident_bytes;
+    std::vector<bool> resident(ix->parts.size(), true);
+    uint64_t cap = 0;
+    if (ix->hbm_budget && total > ix->hbm_budget) {
+        std::vector<size_t> order(ix->parts.size());
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+            return ix->parts[a].resident_bytes < ix->parts[b].resident_bytes;
+        });
+        uint64_t kept = 0;
+        std::fill(resident.begin(), resident.end(), false);
+        for (size_t i : order) {
+            if (kept + ix->parts[i].resident_bytes > ix->hbm_budget / 2) break;
+            kept += ix->parts[i].resident_bytes;
+            resident[i] = true;
+        }
+        cap = (ix->hbm_budget - kept) / 2;
+        if (cap == 0) return fail(COBS_GPU_ERR_CAPACITY, "hbm budget too small");
+    }
+    ix->stream.cap = 0;
+    for (size_t i = 0; i < ix->parts.size(); ++i) {
+        Part& pt = ix->parts[i];
+        const bool res = resident[i] || pt.held.empty();
+        cobs_gpu_status st = chunk_part(pt, res ? 0 : cap, ix->tune);
+        if (st != COBS_GPU_OK) return st;
+        pt.hbm_bytes = res ? pt.resident_bytes : 0;
+        if (!res) ix->stream.cap = cap;
+    }
+    // the shared buffers are accounted to the first streamed file
+    for (auto& pt : ix->parts)
+        if (pt.streamed) { pt.hbm_bytes = 2 * cap; break; }
+    uint64_t g = 0, l = 0;
+    for (auto& p : ix->parts) {
+        p.doc_offset = g;
+        p.local_offset = l;
+        g += p.meta.counts_size();
+        l += p.slot_count;
+    }
+    ix->total_counts = g;
+    ix->local_counts = l;
+    return COBS_GPU_OK;
+}
+
+cobs_gpu_status alloc_part(cobs_gpu_index* ix, Part& pt) {
     for (Chunk& c : pt.chunks) {
         HIP_TRY(hipMalloc((void**)&c.d_pages, sizeof(PageDev) * c.pages.size()));
         HIP_TRY(hipMemcpy(c.d_pages, c.pages.data(), sizeof(PageDev) * c.pages.size(), hipMemcpyHostToDevice));
     }
     if (pt.chunks.empty()) return COBS_GPU_OK;
+    HIP_TRY(hipMalloc((void**)&pt.d_tpages, sizeof(PageDev) * pt.tpages.size()));
+    HIP_TRY(hipMemcpy(pt.d_tpages, pt.tpages.data(), sizeof(PageDev) * pt.tpages.size(), hipMemcpyHostToDevice));
     if (!pt.streamed) {
-        HIP_TRY(hipMalloc((void**)&pt.chunks[0].d_data, pt.chunks[0].bytes));
-    } else {
-        size_t dev = 0, host = 0;
-        for (const Chunk& c : pt.chunks) { dev = std::max(dev, c.bytes); host = std::max(host, c.stage_bytes); }
-        for (int i = 0; i < 2; ++i) {
-            HIP_TRY(pt.sbuf[i].reserve(dev));
-            pt.stage_need = host;
-            HIP_TRY(hipEventCreateWithFlags(&pt.copied[i], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&pt.scanned[i], hipEventDisableTiming));
-        }
-        HIP_TRY(hipStreamCreateWithFlags(&pt.copy_stream, hipStreamNonBlocking));
+        for (Chunk& c : pt.chunks) HIP_TRY(hipMalloc((void**)&c.d_data, c.bytes));
+        return COBS_GPU_OK;
     }
+    StreamBufs& sb = ix->stream;
+    size_t dev = 0, host = 0;
+    for (const Chunk& c : pt.chunks) { dev = std::max(dev, c.bytes); host = std::max(host, c.stage_bytes); }
+    sb.stage_need = std::max(sb.stage_need, host);
+    for (int i = 0; i < 2; ++i) {
+        if (sb.sbuf[i].cap < dev) {
+            // grow keeping nothing: buffers are only (re)allocated while the index is opened
+            HIP_TRY(sb.sbuf[i].reserve(dev));
+        }
+        if (!sb.copied[i]) HIP_TRY(hipEventCreateWithFlags(&sb.copied[i], hipEventDisableTiming));
+        if (!sb.scanned[i]) HIP_TRY(hipEventCreateWithFlags(&sb.scanned[i], hipEventDisableTiming));
+    }
+    if (!sb.copy_stream) HIP_TRY(hipStreamCreateWithFlags(&sb.copy_stream, hipStreamNonBlocking));
     return COBS_GPU_OK;
 }
 
-// Resident chunk: copy the held columns of every held sub-index from the mapped file into HBM.
+// Resident chunks: copy the held columns of every held sub-index from the mapped file into HBM.
 cobs_gpu_status upload_resident(Part& pt, const uint8_t* file) {
-    if (pt.chunks.empty()) return COBS_GPU_OK;
     const IndexMeta& m = pt.meta;
-    Chunk& c = pt.chunks[0];
     const uint64_t src_pitch = m.page_row_bytes();
     DevBuf<uint8_t> stage;
-    for (size_t lp = 0; lp < c.vp.size(); ++lp) {
-        const PageDev& pd = c.pages[lp];
-        const VPage& v = c.vp[lp];
-        const uint8_t* src = file + m.page_offset(v.fp);
-        uint8_t* dst = c.d_data + pd.base;
-        if (src_pitch == c.pitch && v.col0 == 0) {
-            // rows already have the device pitch: one straight copy
-            const uint64_t total = pd.sig * src_pitch;
-            const uint64_t step = 1ull << 30;
-            for (uint64_t o = 0; o < total; o += step)
-                HIP_TRY(hipMemcpy(dst + o, src + o, (size_t)std::min(step, total - o), hipMemcpyHostToDevice));
-        } else {
-            // stage raw rows, re-pitch on the device
-            const uint64_t rows_per = std::max<uint64_t>(1, (64ull << 20) / src_pitch);
-            HIP_TRY(stage.reserve((size_t)(std::min(rows_per, pd.sig) * src_pitch)));
-            for (uint64_t r = 0; r < pd.sig; r += rows_per) {
-                const uint64_t n = std::min(rows_per, pd.sig - r);
-                HIP_TRY(hipMemcpy(stage.p, src + r * src_pitch, (size_t)(n * src_pitch), hipMemcpyHostToDevice));
-                RepitchArgs ra;
-                ra.src = stage.p;
-                ra.dst = dst + r * c.pitch;
-                ra.rows = n;
-                ra.src_pitch = (uint32_t)src_pitch;
-                ra.dst_pitch = c.pitch;
-                ra.copy_bytes = (uint32_t)v.ncols;
-                ra.src_col0 = (uint32_t)v.col0;
-                HIP_TRY(launch_repitch(ra, nullptr));
-                HIP_TRY(hipDeviceSynchronize());
+    for (Chunk& c : pt.chunks) {
+        for (size_t lp = 0; lp < c.vp.size(); ++lp) {
+            const PageDev& pd = c.pages[lp];
+            const VPage& v = c.vp[lp];
+            const uint8_t* src = file + m.page_offset(v.fp);
+            uint8_t* dst = c.d_data + pd.base;
+            if (src_pitch == c.pitch && v.col0 == 0) {
+                // rows already have the device pitch: one straight copy
+                const uint64_t total = pd.sig * src_pitch;
+                const uint64_t step = 1ull << 30;
+                for (uint64_t o = 0; o < total; o += step)
+                    HIP_TRY(hipMemcpy(dst + o, src + o, (size_t)std::min(step, total - o), hipMemcpyHostToDevice));
+            } else {
+                // stage raw rows, re-pitch on the device
+                const uint64_t rows_per = std::max<uint64_t>(1, (64ull << 20) / src_pitch);
+                HIP_TRY(stage.reserve((size_t)(std::min(rows_per, pd.sig) * src_pitch)));
+                for (uint64_t r = 0; r < pd.sig; r += rows_per) {
+                    const uint64_t n = std::min(rows_per, pd.sig - r);
+                    HIP_TRY(hipMemcpy(stage.p, src + r * src_pitch, (size_t)(n * src_pitch), hipMemcpyHostToDevice));
+                    RepitchArgs ra;
+                    ra.src = stage.p;
+                    ra.dst = dst + r * c.pitch;
+                    ra.rows = n;
+                    ra.src_pitch = (uint32_t)src_pitch;
+                    ra.dst_pitch = c.pitch;
+                    ra.copy_bytes = (uint32_t)v.ncols;
+                    ra.src_col0 = (uint32_t)v.col0;
+                    HIP_TRY(launch_repitch(ra, nullptr));
+                    HIP_TRY(hipStreamSynchronize(nullptr));
+                }
             }
+            HIP_TRY(hipMemset(dst + pd.sig * (uint64_t)c.pitch, 0, c.pitch));   // zero row
         }
-        HIP_TRY(hipMemset(dst + pd.sig * (uint64_t)c.pitch, 0, c.pitch));   // zero row
     }
     return COBS_GPU_OK;
 }
@@ -576,17 +538,19 @@ SynthArgs synth_args(const Part& pt, const Chunk& c, uint8_t* data) {
 }
 
 // Streamed chunk: bring it into device buffer `buf` on the copy stream (file-backed:
-// pack the needed columns into pinned staging, async H2D; procedural: regenerate).
-cobs_gpu_status stream_chunk_in(Part& pt, const Chunk& c, int buf) {
-    uint8_t* dev = pt.sbuf[buf].p;
+// DMA from the pinned mapping, or pack the needed columns into pinned staging first;
+// procedural: regenerate).
+cobs_gpu_status stream_chunk_in(cobs_gpu_index* ix, Part& pt, const Chunk& c, int buf) {
+    StreamBufs& sb = ix->stream;
+    uint8_t* dev = sb.sbuf[buf].p;
     if (pt.synthetic) {
-        HIP_TRY(launch_synth(synth_args(pt, c, dev), pt.copy_stream));
+        HIP_TRY(launch_synth(synth_args(pt, c, dev), sb.copy_stream));
         return COBS_GPU_OK;
     }
     const IndexMeta& m = pt.meta;
     const uint64_t prb = m.page_row_bytes();
-    if (!pt.file_pinned) HIP_TRY(pt.stage[buf].reserve(pt.stage_need));
-    uint8_t* host = pt.stage[buf].p;
+    if (!pt.file_pinned) HIP_TRY(sb.stage[buf].reserve(sb.stage_need));
+    uint8_t* host = sb.stage[buf].p;
     uint64_t hoff = 0;
     for (size_t i = 0; i < c.vp.size(); ++i) {
         const VPage& v = c.vp[i];
@@ -595,8 +559,8 @@ cobs_gpu_status stream_chunk_in(Part& pt, const Chunk& c, int buf) {
         uint8_t* dst = dev + pd.base;
         if (pt.file_pinned) {
             HIP_TRY(hipMemcpy2DAsync(dst, c.pitch, src + v.col0, (size_t)prb, (size_t)v.ncols, (size_t)pd.sig,
-                                     hipMemcpyHostToDevice, pt.copy_stream));
-            HIP_TRY(hipMemsetAsync(dst + pd.sig * (uint64_t)c.pitch, 0, c.pitch, pt.copy_stream));
+                                     hipMemcpyHostToDevice, sb.copy_stream));
+            HIP_TRY(hipMemsetAsync(dst + pd.sig * (uint64_t)c.pitch, 0, c.pitch, sb.copy_stream));
             continue;
         }
         uint8_t* hp = host + hoff;
@@ -617,44 +581,49 @@ cobs_gpu_status stream_chunk_in(Part& pt, const Chunk& c, int buf) {
             for (auto& th : pool) th.join();
         }
         if (c.pitch == v.ncols)
-            HIP_TRY(hipMemcpyAsync(dst, hp, (size_t)(pd.sig * v.ncols), hipMemcpyHostToDevice, pt.copy_stream));
+            HIP_TRY(hipMemcpyAsync(dst, hp, (size_t)(pd.sig * v.ncols), hipMemcpyHostToDevice, sb.copy_stream));
         else
             HIP_TRY(hipMemcpy2DAsync(dst, c.pitch, hp, (size_t)v.ncols, (size_t)v.ncols, (size_t)pd.sig,
-                                     hipMemcpyHostToDevice, pt.copy_stream));
-        HIP_TRY(hipMemsetAsync(dst + pd.sig * (uint64_t)c.pitch, 0, c.pitch, pt.copy_stream));
+                                     hipMemcpyHostToDevice, sb.copy_stream));
+        HIP_TRY(hipMemsetAsync(dst + pd.sig * (uint64_t)c.pitch, 0, c.pitch, sb.copy_stream));
         hoff += pd.sig * v.ncols;
     }
     return COBS_GPU_OK;
 }
 
-void finish_layout(cobs_gpu_index* ix) {
-    uint64_t g = 0, l = 0;
-    for (auto& p : ix->parts) {
-        p.doc_offset = g;
-        p.local_offset = l;
-        g += p.meta.counts_size();
-        l += p.slot_count;
-    }
-    ix->total_counts = g;
-    ix->local_counts = l;
-}
+// options fields appended after the first release are honoured only if the caller's struct has them
+bool has_field(const cobs_gpu_options* o, size_t end_offset) { return o && o->struct_size >= end_offset; }
 
-uint64_t budget_of(const cobs_gpu_options* o) {
-    // hbm_budget_bytes was appended to the options struct: honour it only if the caller's struct has it
-    if (o && o->struct_size >= sizeof(cobs_gpu_options)) return o->hbm_budget_bytes;
-    return 0;
-}
-
-cobs_gpu_status shard_of(const cobs_gpu_options* o, uint32_t* rank, uint32_t* count) {
-    *rank = 0;
-    *count = 1;
-    if (o && o->shard_count > 1) {
+cobs_gpu_status read_options(const cobs_gpu_options* o, cobs_gpu_index* ix) {
+    ix->tune = Tuning::from_env();
+    ix->shard_rank = 0;
+    ix->shard_count = 1;
+    ix->shard_mode = 0;
+    ix->hbm_budget = 0;
+    if (!o) return COBS_GPU_OK;
+    if (o->shard_count > 1) {
         if (o->shard_rank >= o->shard_count) return fail(COBS_GPU_ERR_ARG, "shard_rank >= shard_count");
-        *rank = o->shard_rank;
-        *count = o->shard_count;
+        ix->shard_rank = o->shard_rank;
+        ix->shard_count = o->shard_count;
     }
+    if (o->waves_per_group == 1 || o->waves_per_group == 2 || o->waves_per_group == 4)
+        ix->waves_per_group = o->waves_per_group;
+    if (o->shard_mode > 1) return fail(COBS_GPU_ERR_ARG, "unknown shard_mode");
+    ix->shard_mode = o->shard_mode;
+    if (has_field(o, offsetof(cobs_gpu_options, hbm_budget_bytes) + sizeof(uint64_t))) ix->hbm_budget = o->hbm_budget_bytes;
     return COBS_GPU_OK;
 }
+
+// row bytes one hash lookup gathers from this part (all held slices)
+uint64_t gathered_row_bytes(const Part& p) {
+    uint64_t n = 0;
+    for (const VPage& v : p.held) n += v.ncols;
+    return n;
+}
+
+}  // namespace
+
+namespace cobs_amd {
 
 // ---------------------------------------------------------------------------
 // ranking (counts_to_result, reference classic_search.cpp:109-202)
@@ -668,14 +637,6 @@ bool hit_before(const cobs_gpu_hit& a, const cobs_gpu_hit& b) {
 bool doc_before(const cobs_gpu_hit& a, const cobs_gpu_hit& b) {
     if (a.file_no != b.file_no) return a.file_no < b.file_no;
     return a.doc < b.doc;
-}
-
-// row bytes one hash lookup gathers from this part (all held slices)
-uint64_t gathered_row_bytes(const Part& p) {
-    uint64_t n = 0;
-    for (const Chunk& c : p.chunks)
-        for (const VPage& v : c.vp) n += v.ncols;
-    return n;
 }
 
 // total number of hashes of query `q` over all files: the reference's max_counts
@@ -694,11 +655,10 @@ uint32_t threshold_for(double threshold, uint64_t terms) {
     return (uint32_t)v;
 }
 
-}  // namespace
+}  // namespace cobs_amd
 
 // shared with build.cpp
 __attribute__((visibility("hidden"))) cobs_gpu_status cobs_gpu_set_error(cobs_gpu_status st, const char* msg) { return fail(st, msg ? msg : ""); }
-
 // ===========================================================================
 // C ABI
 
@@ -714,47 +674,27 @@ int cobs_gpu_device_count(void) {
     return n;
 }
 
-cobs_gpu_status cobs_gpu_open(const char* const* paths, size_t n_paths,
-                              const cobs_gpu_options* opts, cobs_gpu_index** out) {
-    if (!out) return fail(COBS_GPU_ERR_ARG, "out is NULL");
-    *out = nullptr;
-    if (!paths || n_paths == 0) return fail(COBS_GPU_ERR_ARG, "no index paths");
-    // parse all headers first: format errors are reported even without a device
-    std::vector<std::unique_ptr<MappedFile>> files;
-    std::unique_ptr<cobs_gpu_index> ix(new cobs_gpu_index);
-    for (size_t i = 0; i < n_paths; ++i) {
-        if (!paths[i]) return fail(COBS_GPU_ERR_ARG, "NULL path");
-        std::string err;
-        files.emplace_back(new MappedFile);
-        if (!files.back()->open(paths[i], err)) return fail(COBS_GPU_ERR_OPEN, err);
-        Part pt;
-        if (!parse_index_header(files.back()->data(), files.back()->size(), pt.meta, err))
-            return fail(COBS_GPU_ERR_FORMAT, std::string("Could not open index path \"") + paths[i] + "\": " + err);
-        ix->parts.push_back(std::move(pt));
-    }
-    cobs_gpu_status st = shard_of(opts, &ix->shard_rank, &ix->shard_count);
-    if (st != COBS_GPU_OK) return st;
-    ix->hbm_budget = budget_of(opts);
-    if (opts && (opts->waves_per_group == 1 || opts->waves_per_group == 2 || opts->waves_per_group == 4))
-        ix->waves_per_group = opts->waves_per_group;
-    uint64_t left = ix->hbm_budget;
-    for (auto& pt : ix->parts) {
-        st = plan_part(pt, ix->shard_rank, ix->shard_count, ix->hbm_budget ? &left : nullptr);
-        if (st != COBS_GPU_OK) return st;
-    }
-    finish_layout(ix.get());
-    st = select_device(opts, &ix->device);
-    if (st != COBS_GPU_OK) return st;
+// stage every part: resident chunks are uploaded (file) or generated (procedural), streamed
+// parts keep their source and get the handle's shared buffers
+static cobs_gpu_status stage_index(cobs_gpu_index* ix, std::vector<std::unique_ptr<MappedFile>>& files) {
     for (size_t i = 0; i < ix->parts.size(); ++i) {
         Part& pt = ix->parts[i];
-        st = alloc_part(pt);
+        cobs_gpu_status st = alloc_part(ix, pt);
         if (st != COBS_GPU_OK) return st;
+        if (pt.chunks.empty()) continue;
+        if (pt.synthetic) {
+            if (!pt.streamed) {
+                for (Chunk& c : pt.chunks) HIP_TRY(launch_synth(synth_args(pt, c, c.d_data), nullptr));
+                HIP_TRY(hipStreamSynchronize(nullptr));
+            }
+            continue;
+        }
         if (pt.streamed) {
             pt.file = std::move(files[i]);       // chunks are read from the mapping at every pass
             // Pin the read-only mapping so that the copy engine reads it directly (no packing
             // through staging buffers).  Not every kernel/driver allows pinning file pages;
             // if it fails the staged path is used.
-            if (!getenv("COBS_GPU_NO_PIN")) {
+            if (!ix->tune.no_pin) {
                 hipError_t pe = hipHostRegister(const_cast<uint8_t*>(pt.file->data()), pt.file->size(),
                                                 hipHostRegisterReadOnly);
                 if (pe != hipSuccess) {
@@ -769,8 +709,39 @@ cobs_gpu_status cobs_gpu_open(const char* const* paths, size_t n_paths,
             if (st != COBS_GPU_OK) return st;
         }
     }
-    *out = ix.release();
     return COBS_GPU_OK;
+}
+
+cobs_gpu_status cobs_gpu_open(const char* const* paths, size_t n_paths,
+                              const cobs_gpu_options* opts, cobs_gpu_index** out) {
+    if (!out) return fail(COBS_GPU_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!paths || n_paths == 0) return fail(COBS_GPU_ERR_ARG, "no index paths");
+    return guarded([&]() -> cobs_gpu_status {
+        // parse all headers first: format errors are reported even without a device
+        std::vector<std::unique_ptr<MappedFile>> files;
+        std::unique_ptr<cobs_gpu_index> ix(new cobs_gpu_index);
+        for (size_t i = 0; i < n_paths; ++i) {
+            if (!paths[i]) return fail(COBS_GPU_ERR_ARG, "NULL path");
+            std::string err;
+            files.emplace_back(new MappedFile);
+            if (!files.back()->open(paths[i], err)) return fail(COBS_GPU_ERR_OPEN, err);
+            Part pt;
+            if (!parse_index_header(files.back()->data(), files.back()->size(), pt.meta, err))
+                return fail(COBS_GPU_ERR_FORMAT, std::string("Could not open index path \"") + paths[i] + "\": " + err);
+            ix->parts.push_back(std::move(pt));
+        }
+        cobs_gpu_status st = read_options(opts, ix.get());
+        if (st != COBS_GPU_OK) return st;
+        st = plan_index(ix.get());
+        if (st != COBS_GPU_OK) return st;
+        st = select_device(opts, &ix->device);
+        if (st != COBS_GPU_OK) return st;
+        st = stage_index(ix.get(), files);
+        if (st != COBS_GPU_OK) return st;
+        *out = ix.release();
+        return COBS_GPU_OK;
+    });
 }
 
 cobs_gpu_status cobs_gpu_open_synthetic(const cobs_gpu_synth* d, const cobs_gpu_options* opts,
@@ -784,44 +755,91 @@ cobs_gpu_status cobs_gpu_open_synthetic(const cobs_gpu_synth* d, const cobs_gpu_
     if (d->kind == 1 && d->num_docs > (uint64_t)d->num_pages * 8 * d->page_size)
         return fail(COBS_GPU_ERR_ARG, "more documents than sub-index slots");
     if (d->num_docs == 0 || d->num_docs > 0xFFFFFFF0ull) return fail(COBS_GPU_ERR_ARG, "bad num_docs");
-    std::unique_ptr<cobs_gpu_index> ix(new cobs_gpu_index);
-    Part pt;
-    pt.meta.kind = d->kind ? IndexKind::Compact : IndexKind::Classic;
-    pt.meta.term_size = d->term_size;
-    pt.meta.canonicalize = (uint8_t)d->canonicalize;
-    pt.meta.num_hashes = d->num_hashes;
-    pt.meta.header_page_size = d->kind ? d->page_size : 0;
-    pt.meta.signature_sizes.assign(d->signature_sizes, d->signature_sizes + d->num_pages);
-    pt.meta.doc_names.resize(d->num_docs);
-    char nm[32];
-    for (uint64_t i = 0; i < d->num_docs; ++i) {      // names as classic_construct_random, classic_index.cpp:668-670
-        std::snprintf(nm, sizeof nm, "file_%06u", (unsigned)i);
-        pt.meta.doc_names[i] = nm;
-    }
-    pt.synthetic = true;
-    pt.synth_seed = d->seed;
-    ix->parts.push_back(std::move(pt));
-    cobs_gpu_status st = shard_of(opts, &ix->shard_rank, &ix->shard_count);
-    if (st != COBS_GPU_OK) return st;
-    ix->hbm_budget = budget_of(opts);
-    uint64_t left = ix->hbm_budget;
-    st = plan_part(ix->parts[0], ix->shard_rank, ix->shard_count, ix->hbm_budget ? &left : nullptr);
-    if (st != COBS_GPU_OK) return st;
-    finish_layout(ix.get());
-    st = select_device(opts, &ix->device);
-    if (st != COBS_GPU_OK) return st;
-    Part& p = ix->parts[0];
-    st = alloc_part(p);
-    if (st != COBS_GPU_OK) return st;
-    if (!p.streamed && !p.chunks.empty()) {
-        HIP_TRY(launch_synth(synth_args(p, p.chunks[0], p.chunks[0].d_data), nullptr));
-        HIP_TRY(hipDeviceSynchronize());
-    }
-    *out = ix.release();
-    return COBS_GPU_OK;
+    return guarded([&]() -> cobs_gpu_status {
+        std::unique_ptr<cobs_gpu_index> ix(new cobs_gpu_index);
+        Part pt;
+        pt.meta.kind = d->kind ? IndexKind::Compact : IndexKind::Classic;
+        pt.meta.term_size = d->term_size;
+        pt.meta.canonicalize = (uint8_t)d->canonicalize;
+        pt.meta.num_hashes = d->num_hashes;
+        pt.meta.header_page_size = d->kind ? d->page_size : 0;
+        pt.meta.signature_sizes.assign(d->signature_sizes, d->signature_sizes + d->num_pages);
+        pt.meta.doc_names.resize(d->num_docs);
+        char nm[32];
+        for (uint64_t i = 0; i < d->num_docs; ++i) {      // names as classic_construct_random, classic_index.cpp:668-670
+            std::snprintf(nm, sizeof nm, "file_%06u", (unsigned)i);
+            pt.meta.doc_names[i] = nm;
+        }
+        pt.synthetic = true;
+        pt.synth_seed = d->seed;
+        ix->parts.push_back(std::move(pt));
+        cobs_gpu_status st = read_options(opts, ix.get());
+        if (st != COBS_GPU_OK) return st;
+        st = plan_index(ix.get());
+        if (st != COBS_GPU_OK) return st;
+        st = select_device(opts, &ix->device);
+        if (st != COBS_GPU_OK) return st;
+        std::vector<std::unique_ptr<MappedFile>> none;
+        st = stage_index(ix.get(), none);
+        if (st != COBS_GPU_OK) return st;
+        *out = ix.release();
+        return COBS_GPU_OK;
+    });
 }
 
 void cobs_gpu_close(cobs_gpu_index* ix) { delete ix; }
+
+cobs_gpu_status cobs_gpu_plan_shards(const char* path, uint32_t shard_count, uint32_t shard_mode,
+                                     uint64_t* slot_begin, uint64_t* slot_count, uint64_t* bytes) {
+    if (!path || !slot_begin || !slot_count || shard_count == 0 || shard_mode > 1)
+        return fail(COBS_GPU_ERR_ARG, "bad argument");
+    return guarded([&]() -> cobs_gpu_status {
+        MappedFile file;
+        std::string err;
+        if (!file.open(path, err)) return fail(COBS_GPU_ERR_OPEN, err);
+        cobs_gpu_index ix;
+        ix.tune = Tuning::from_env();
+        ix.shard_count = shard_count;
+        ix.shard_mode = shard_mode;
+        for (uint32_t r = 0; r < shard_count; ++r) {
+            Part pt;
+            if (!parse_index_header(file.data(), file.size(), pt.meta, err))
+                return fail(COBS_GPU_ERR_FORMAT, std::string("Could not open index path \"") + path + "\": " + err);
+            ix.shard_rank = r;
+            cobs_gpu_status st = plan_part(pt, &ix);
+            if (st != COBS_GPU_OK) return st;
+            slot_begin[r] = pt.slot_begin;
+            slot_count[r] = pt.slot_count;
+            if (bytes) bytes[r] = pt.resident_bytes;
+        }
+        return COBS_GPU_OK;
+    });
+}
+
+cobs_gpu_status cobs_gpu_set_tuning(cobs_gpu_index* ix, const char* key, int64_t value) {
+    if (!ix || !key) return fail(COBS_GPU_ERR_ARG, "NULL argument");
+    const std::string k = key;
+    Tuning& t = ix->tune;
+    if (k == "waves") {
+        if (value != 0 && value != 1 && value != 2 && value != 4) return fail(COBS_GPU_ERR_ARG, "waves: 0, 1, 2 or 4");
+        t.waves = (uint32_t)value;
+    } else if (k == "tile_w") {
+        if (value != 0 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64)
+            return fail(COBS_GPU_ERR_ARG, "tile_w: 0, 4, 8, 16, 32 or 64");
+        t.tile_w = (uint32_t)value;
+    } else if (k == "mq") {
+        t.mq = value < 0 ? -1 : value != 0;
+    } else if (k == "pass_bytes") {
+        t.pass_bytes = value > 0 ? (uint64_t)value : 16ull << 30;
+    } else if (k == "pipe_chars") {
+        t.pipe_chars = value < 0 ? 4ull << 20 : (uint64_t)value;
+    } else if (k == "graph") {
+        t.graph = value < 0 ? -1 : value != 0;
+    } else {
+        return fail(COBS_GPU_ERR_ARG, "unknown tuning key (waves, tile_w, mq, pass_bytes, pipe_chars, graph)");
+    }
+    return COBS_GPU_OK;
+}
 
 size_t cobs_gpu_num_files(const cobs_gpu_index* ix) { return ix ? ix->parts.size() : 0; }
 
@@ -861,16 +879,33 @@ const char* cobs_gpu_doc_name(const cobs_gpu_index* ix, size_t f, uint64_t doc) 
 uint64_t cobs_gpu_total_counts(const cobs_gpu_index* ix) { return ix ? ix->total_counts : 0; }
 uint64_t cobs_gpu_local_counts(const cobs_gpu_index* ix) { return ix ? ix->local_counts : 0; }
 
-// resident slice of file-level sub-index `page` (only resident, un-split pages can be read back)
+// resident slice of file-level sub-index `page` (streamed chunks cannot be read back)
 static cobs_gpu_status find_resident(const cobs_gpu_index* ix, size_t f, uint32_t page, const Chunk** c,
                                      const PageDev** pd) {
     if (!ix || f >= ix->parts.size()) return fail(COBS_GPU_ERR_ARG, "bad argument");
     const Part& p = ix->parts[f];
-    if (page < p.first_page || page >= p.end_page) return fail(COBS_GPU_ERR_ARG, "sub-index not held by this shard");
     if (p.streamed) return fail(COBS_GPU_ERR_UNSUPPORTED, "index is streamed, rows are not resident");
-    *c = &p.chunks[0];
-    *pd = &p.chunks[0].pages[page - p.first_page];
-    return COBS_GPU_OK;
+    for (const Chunk& ch : p.chunks)
+        for (size_t i = 0; i < ch.vp.size(); ++i)
+            if (ch.vp[i].fp == page) {
+                *c = &ch;
+                *pd = &ch.pages[i];
+                return COBS_GPU_OK;
+            }
+    return fail(COBS_GPU_ERR_ARG, "sub-index not held by this shard");
+}
+
+cobs_gpu_status cobs_gpu_page_columns(const cobs_gpu_index* ix, size_t f, uint32_t page, uint64_t* col0,
+                                      uint64_t* ncols) {
+    if (!ix || f >= ix->parts.size() || !col0 || !ncols) return fail(COBS_GPU_ERR_ARG, "bad argument");
+    *col0 = *ncols = 0;
+    for (const VPage& v : ix->parts[f].held)
+        if (v.fp == page) {
+            *col0 = v.col0;
+            *ncols = v.ncols;
+            return COBS_GPU_OK;
+        }
+    return COBS_GPU_OK;      // not held: zero columns
 }
 
 cobs_gpu_status cobs_gpu_read_row(const cobs_gpu_index* ix, size_t f, uint32_t page, uint64_t row,
@@ -908,6 +943,7 @@ cobs_gpu_status cobs_gpu_batch_create(cobs_gpu_index* ix, size_t max_queries, si
                                       cobs_gpu_batch** out) {
     if (!ix || !out) return fail(COBS_GPU_ERR_ARG, "NULL argument");
     *out = nullptr;
+    return guarded([&]() -> cobs_gpu_status {
     HIP_TRY(hipSetDevice(ix->device));
     std::unique_ptr<cobs_gpu_batch> b(new cobs_gpu_batch);
     b->ix = ix;
@@ -915,22 +951,27 @@ cobs_gpu_status cobs_gpu_batch_create(cobs_gpu_index* ix, size_t max_queries, si
     b->max_len = max_query_len;
     b->work.resize(ix->parts.size());
     for (auto& r : b->ev) for (auto& e : r) HIP_TRY(hipEventCreate(&e));
-    HIP_TRY(b->flags.reserve(2));
+    HIP_TRY(hipEventCreateWithFlags(&b->run_done, hipEventDisableTiming));
+    HIP_TRY(b->flags.reserve(4));
     *out = b.release();
     return COBS_GPU_OK;
+    });
 }
 
 void cobs_gpu_batch_destroy(cobs_gpu_batch* b) { delete b; }
 
 // Uploads go through `up` (asynchronously where the source is pinned); wait = false leaves them
 // in flight: the caller orders its kernels after them on the same stream.
-static cobs_gpu_status set_queries_on(cobs_gpu_batch* b, const char* const* queries, const size_t* lens,
-                                      size_t nq, hipStream_t up, bool wait) {
+}  // extern "C"
+
+cobs_gpu_status cobs_amd::set_queries_on(cobs_gpu_batch* b, const char* const* queries, const size_t* lens,
+                                         size_t nq, hipStream_t up, bool wait, size_t* bad_query) {
     if (!b || (nq && (!queries || !lens))) return fail(COBS_GPU_ERR_ARG, "NULL argument");
     cobs_gpu_index* ix = b->ix;
     HIP_TRY(hipSetDevice(ix->device));
-    // the upload overwrites buffers a run still in flight would read: wait for a run nobody synced
-    if (b->ran && !b->synced) HIP_TRY(hipDeviceSynchronize());
+    // the upload overwrites buffers a run still in flight would read: wait for a run nobody
+    // synced -- on that run's own event, other handles' streams on the device keep going
+    if (b->ran && !b->synced) HIP_TRY(hipEventSynchronize(b->run_done));
     b->ran = false;
     b->nq = 0;
     if (nq >= 0xFFFFFFFEull) return fail(COBS_GPU_ERR_ARG, "too many queries");
@@ -942,14 +983,16 @@ static cobs_gpu_status set_queries_on(cobs_gpu_batch* b, const char* const* quer
     }
     uint64_t max_terms = 1;
     for (size_t q = 0; q < nq; ++q) {
-        if (!queries[q]) return fail(COBS_GPU_ERR_ARG, "NULL query");
+        if (bad_query) *bad_query = q;
+        if (!queries[q]) return fail(COBS_GPU_ERR_ARG, "NULL query (query " + std::to_string(q) + ")");
         if (lens[q] < max_term)
             return fail(COBS_GPU_ERR_QUERY_TOO_SHORT, "query too short, needs to be at least " +
-                        std::to_string(max_term) + " characters long");
+                        std::to_string(max_term) + " characters long (query " + std::to_string(q) + ")");
         if (lens[q] - max_term >= 0xFFFFFFFFull || lens[q] >= 0xFFFFFFF0ull)
-            return fail(COBS_GPU_ERR_QUERY_TOO_LONG, "query too long");
+            return fail(COBS_GPU_ERR_QUERY_TOO_LONG, "query too long (query " + std::to_string(q) + ")");
         max_terms = std::max<uint64_t>(max_terms, lens[q] - min_term + 1);
     }
+    if (bad_query) *bad_query = 0;
     const int planes = scan_planes_for(max_terms);
     if (planes < 0) return fail(COBS_GPU_ERR_QUERY_TOO_LONG, "query too long");
     b->planes = planes;
@@ -1001,8 +1044,8 @@ static cobs_gpu_status set_queries_on(cobs_gpu_batch* b, const char* const* quer
         w.h_blk_off[nq] = blk;
         // per (query, sub-index): its 8-term blocks plus one padding block
         const uint64_t idx_words = p.idx64 ? 2 : 1;      // u32 words per table entry
-        w.table_entries = (blk + nq) * 8 * p.meta.num_hashes * p.max_chunk_pages * idx_words;
-        table_bytes += ((blk + nq) * 8 * p.meta.num_hashes * p.num_vpages()) * 4 * idx_words;
+        w.table_entries = (blk + nq) * 8 * p.meta.num_hashes * p.num_tpages() * idx_words;
+        table_bytes += w.table_entries * 4;
         if (w.table_entries >= (1ull << 40)) return fail(COBS_GPU_ERR_CAPACITY, "batch too large");
         HIP_TRY(w.table.reserve((size_t)w.table_entries));
         HIP_TRY(w.thr.reserve(nq));
@@ -1025,15 +1068,15 @@ static cobs_gpu_status set_queries_on(cobs_gpu_batch* b, const char* const* quer
     return COBS_GPU_OK;
 }
 
-cobs_gpu_status cobs_gpu_batch_set_queries(cobs_gpu_batch* b, const char* const* queries,
-                                           const size_t* lens, size_t nq) {
-    return set_queries_on(b, queries, lens, nq, nullptr, true);
+extern "C" cobs_gpu_status cobs_gpu_batch_set_queries(cobs_gpu_batch* b, const char* const* queries,
+                                                      const size_t* lens, size_t nq) {
+    return guarded([&]() { return set_queries_on(b, queries, lens, nq, nullptr, true, nullptr); });
 }
 
 // want_counts = false: the caller only needs the selected hits (threshold > 0, no top-k), so the
 // scan does not write the score rows (for reads they are up to a third of the traffic).
-static cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk, void* hip_stream,
-                                bool want_counts = true) {
+cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t topk, void* hip_stream,
+                                   bool want_counts) {
     if (!b) return fail(COBS_GPU_ERR_ARG, "NULL batch");
     cobs_gpu_index* ix = b->ix;
     hipStream_t st = (hipStream_t)hip_stream;
@@ -1043,6 +1086,9 @@ static cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk
     b->pool_fetched = false;
     b->topk_fetched = false;
     b->rows_q0 = b->rows_q1 = 0;
+    b->view_global = false;
+    b->pool_global = false;
+    b->topk_stride = 0;
     b->threshold = threshold;
     const size_t nq = b->nq;
     // K3 (exact top-k on the device) needs u16 scores and a bounded k
@@ -1061,7 +1107,7 @@ static cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk
         HIP_TRY(b->topk_cnt.reserve(std::max<size_t>(nq, 1) * ix->parts.size()));
     }
     // device flags: first invalid query = none, selected hits = 0
-    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)b->flags.p, 0, 2, st));      // both zero: one fill
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)b->flags.p, 0, 4, st));      // all zero: one fill
     if (need_thr) {
         for (size_t f = 0; f < ix->parts.size(); ++f) {
             uint32_t* stage = b->h_thr_stage.p + f * nq;
@@ -1074,41 +1120,46 @@ static cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk
     HIP_TRY(hipEventRecord(ev[0], st));
     bool hash_marked = false;
     uint64_t launches = 0;
+    StreamBufs& sbufs = ix->stream;
     for (size_t f = 0; f < ix->parts.size(); ++f) {
         Part& p = ix->parts[f];
-        if (nq == 0) continue;
-        for (size_t ci = 0; ci < p.chunks.size(); ++ci) {
-            const Chunk& c = p.chunks[ci];
-            const uint8_t* data = c.d_data;
-            int buf = 0;
-            if (p.streamed) {
-                // double buffer: chunk ci goes to buffer ci % 2 once the scan that last used it is done
-                buf = (int)(ci & 1);
-                if (p.buf_used[buf]) HIP_TRY(hipEventSynchronize(p.scanned[buf]));
-                cobs_gpu_status cs = stream_chunk_in(p, c, buf);
-                if (cs != COBS_GPU_OK) return cs;
-                HIP_TRY(hipEventRecord(p.copied[buf], p.copy_stream));
-                HIP_TRY(hipStreamWaitEvent(st, p.copied[buf], 0));
-                data = p.sbuf[buf].p;
-            }
+        if (nq == 0 || p.chunks.empty()) continue;
+        {   // K1 once per file and pass: the row-index table covers every held sub-index,
+            // the chunks (launches) of the file pick their sub-indexes by PageDev::tpage
             HashArgs ha;
             ha.text = b->text.p;
             ha.span_off = b->d_span_off;
             ha.q_len = b->d_qlen;
             ha.blk_off = b->work[f].blk_off;
-            ha.pages = c.d_pages;
+            ha.pages = p.d_tpages;
             ha.table = b->work[f].table.p;
             ha.err_query = b->flags.p;
             ha.nq = (uint32_t)nq;
-            ha.npages = (uint32_t)c.vp.size();
+            ha.npages = p.num_tpages();
             ha.term_size = p.meta.term_size;
             ha.canonicalize = p.meta.canonicalize;
             ha.num_hashes = (uint32_t)p.meta.num_hashes;
             ha.idx64 = p.idx64 ? 1u : 0u;
             HIP_TRY(launch_hash(ha, b->span_off[nq], st));
-            if (!hash_marked) {      // K1 / K2 split of the timing events: first chunk only
+            if (!hash_marked) {      // K1 / K2 split of the timing events: first file only
                 HIP_TRY(hipEventRecord(ev[1], st));
                 hash_marked = true;
+            }
+        }
+        for (size_t ci = 0; ci < p.chunks.size(); ++ci) {
+            const Chunk& c = p.chunks[ci];
+            const uint8_t* data = c.d_data;
+            int buf = 0;
+            if (p.streamed) {
+                // double buffer shared by all streamed files: the next chunk goes to the buffer
+                // whose last scan is done
+                buf = (int)(sbufs.seq++ & 1);
+                if (sbufs.used[buf]) HIP_TRY(hipEventSynchronize(sbufs.scanned[buf]));
+                cobs_gpu_status cs = stream_chunk_in(ix, p, c, buf);
+                if (cs != COBS_GPU_OK) return cs;
+                HIP_TRY(hipEventRecord(sbufs.copied[buf], sbufs.copy_stream));
+                HIP_TRY(hipStreamWaitEvent(st, sbufs.copied[buf], 0));
+                data = sbufs.sbuf[buf].p;
             }
             ScanArgs sa;
             sa.blob = data;
@@ -1118,12 +1169,13 @@ static cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk
             sa.counts = b->counts.p;
             sa.thresholds = b->selected ? b->work[f].thr.p : nullptr;
             sa.hits = b->hits.p;
-            sa.hit_count = b->flags.p + 1;
+            sa.hit_count = reinterpret_cast<unsigned long long*>(b->flags.p + 2);
             sa.counts_stride = ix->local_counts;
             sa.counts_offset = p.local_offset;
             sa.hit_cap = b->hit_cap;
             sa.nq = (uint32_t)nq;
             sa.npages = (uint32_t)c.vp.size();
+            sa.table_npages = p.num_tpages();
             sa.pitch = c.pitch;
             sa.cpp = c.cpp;
             sa.total_chunks = c.total_chunks;
@@ -1133,7 +1185,7 @@ static cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk
             sa.write_counts = b->have_counts ? 1 : 0;
             sa.idx64 = p.idx64 ? 1u : 0u;
             const ScanGeom geom = scan_geometry(c, b->work[f].h_blk_off[nq] / nq, (b->max_terms + 7) / 8,
-                                                 p.meta.num_hashes, ix->waves_per_group, b->planes, p.idx64);
+                                                 p.meta.num_hashes, ix->waves_per_group, b->planes, p.idx64, ix->tune);
             const int nwaves = geom.nwaves;
             sa.tile_w = geom.tile_w;
             sa.chunk_begin = 0;
@@ -1145,8 +1197,8 @@ static cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk
             HIP_TRY(launch_scan(sa, ntiles, b->planes, nwaves, geom.multi_query, st));
             ++launches;
             if (p.streamed) {
-                HIP_TRY(hipEventRecord(p.scanned[buf], st));
-                p.buf_used[buf] = true;
+                HIP_TRY(hipEventRecord(sbufs.scanned[buf], st));
+                sbufs.used[buf] = true;
             }
         }
     }
@@ -1173,19 +1225,22 @@ static cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk
             HIP_TRY(launch_topk(ta, st));
         }
     }
+    HIP_TRY(hipEventRecord(b->run_done, st));
     b->run_seq++;
     b->stats[1] = launches;
     b->ran = true;
     return COBS_GPU_OK;
 }
 
+extern "C" {
+
 cobs_gpu_status cobs_gpu_batch_run(cobs_gpu_batch* b, double threshold, void* hip_stream) {
-    return run_impl(b, threshold, 0, hip_stream);
+    return guarded([&]() { return run_impl(b, threshold, 0, hip_stream); });
 }
 
 cobs_gpu_status cobs_gpu_batch_run_topk(cobs_gpu_batch* b, double threshold, size_t num_results,
                                         void* hip_stream) {
-    return run_impl(b, threshold, num_results, hip_stream);
+    return guarded([&]() { return run_impl(b, threshold, num_results, hip_stream); });
 }
 
 cobs_gpu_status cobs_gpu_batch_sync(cobs_gpu_batch* b, void* hip_stream, size_t* bad_query) {
@@ -1222,14 +1277,20 @@ void* cobs_gpu_batch_counts_device(cobs_gpu_batch* b, uint32_t* elem_bytes, uint
 
 // Raw local score row of query q of the last run, through a pinned host window of up to 64 MiB
 // of consecutive rows (callers walk the queries in order: one DMA per window, not per query).
+// After an exchange (comm.cpp) the batch may expose GLOBAL rows instead: queries
+// [g_q0, g_q0 + g_qn), every row total_counts elements in global document order.
 static cobs_gpu_status fetch_row(cobs_gpu_batch* b, size_t q, const uint8_t** row) {
-    const size_t row_bytes = (size_t)(b->ix->local_counts * b->elem_bytes);
+    const bool glob = b->view_global;
+    const size_t row_bytes = (size_t)((glob ? b->ix->total_counts : b->ix->local_counts) * b->elem_bytes);
+    if (glob && (q < b->g_q0 || q >= b->g_q0 + b->g_qn))
+        return fail(COBS_GPU_ERR_ARG, "this rank does not hold the exchanged row of that query");
     if (q < b->rows_q0 || q >= b->rows_q1) {
         const size_t per = std::max<size_t>(1, (64u << 20) / std::max<size_t>(row_bytes, 1));
-        const size_t q1 = std::min(b->nq, q + per);
+        const size_t q1 = std::min(glob ? (size_t)(b->g_q0 + b->g_qn) : b->nq, q + per);
         HIP_TRY(b->h_rows.reserve(std::max<size_t>((q1 - q) * row_bytes, 1)));
+        const uint8_t* src = glob ? b->g_rows + (q - b->g_q0) * row_bytes : b->counts.p + q * row_bytes;
         if (row_bytes)
-            HIP_TRY(hipMemcpy(b->h_rows.p, b->counts.p + q * row_bytes, (q1 - q) * row_bytes, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(b->h_rows.p, src, (q1 - q) * row_bytes, hipMemcpyDeviceToHost));
         b->rows_q0 = q;
         b->rows_q1 = q1;
     }
@@ -1250,6 +1311,10 @@ static cobs_gpu_status fetch_counts(cobs_gpu_batch* b, size_t q, uint32_t* count
     const uint8_t* raw = nullptr;
     cobs_gpu_status st = fetch_row(b, q, &raw);
     if (st != COBS_GPU_OK) return st;
+    if (b->view_global) {
+        for (uint64_t i = 0; i < ix->total_counts; ++i) counts[i] = score_at(raw, b->elem_bytes, i);
+        return COBS_GPU_OK;
+    }
     std::fill(counts, counts + ix->total_counts, 0u);
     for (const Part& p : ix->parts) {
         uint32_t* dst = counts + p.doc_offset + p.slot_begin;
@@ -1280,6 +1345,7 @@ static cobs_gpu_status rank_row(cobs_gpu_batch* b, size_t q, size_t num_results,
     cobs_gpu_status st = fetch_row(b, q, &raw);
     if (st != COBS_GPU_OK) return st;
     const uint32_t eb = b->elem_bytes;
+    const bool glob = b->view_global;
     const bool by_score = total_hashes(b, q) > 1;       // max_counts <= 1: index order, no sort (:134, :177)
     // pass 1: passing documents per score
     uint64_t max_score = 0;
@@ -1292,10 +1358,12 @@ static cobs_gpu_status rank_row(cobs_gpu_batch* b, size_t q, size_t num_results,
     for (size_t f = 0; f < ix->parts.size(); ++f) {
         const Part& p = ix->parts[f];
         const uint32_t thr = threshold_for(b->threshold, (uint64_t)b->lens[q] - p.meta.term_size + 1);
-        const uint64_t d0 = p.slot_begin;
-        const uint64_t d1 = std::min<uint64_t>(p.slot_begin + p.slot_count, p.meta.doc_names.size());
+        const uint64_t d0 = glob ? 0 : p.slot_begin;
+        const uint64_t d1 = glob ? p.meta.doc_names.size()
+                                 : std::min<uint64_t>(p.slot_begin + p.slot_count, p.meta.doc_names.size());
+        const uint64_t base = glob ? p.doc_offset : p.local_offset;
         for (uint64_t d = d0; d < d1; ++d) {
-            const uint32_t s = score_at(raw, eb, p.local_offset + d - d0);
+            const uint32_t s = score_at(raw, eb, base + d - d0);
             if (s >= thr) { ++hist[by_score ? std::min<uint64_t>(s, max_score) : 0]; ++passing; }
         }
     }
@@ -1315,10 +1383,12 @@ static cobs_gpu_status rank_row(cobs_gpu_batch* b, size_t q, size_t num_results,
     for (size_t f = 0; f < ix->parts.size(); ++f) {
         const Part& p = ix->parts[f];
         const uint32_t thr = threshold_for(b->threshold, (uint64_t)b->lens[q] - p.meta.term_size + 1);
-        const uint64_t d0 = p.slot_begin;
-        const uint64_t d1 = std::min<uint64_t>(p.slot_begin + p.slot_count, p.meta.doc_names.size());
+        const uint64_t d0 = glob ? 0 : p.slot_begin;
+        const uint64_t d1 = glob ? p.meta.doc_names.size()
+                                 : std::min<uint64_t>(p.slot_begin + p.slot_count, p.meta.doc_names.size());
+        const uint64_t base = glob ? p.doc_offset : p.local_offset;
         for (uint64_t d = d0; d < d1; ++d) {
-            const uint32_t s = score_at(raw, eb, p.local_offset + d - d0);
+            const uint32_t s = score_at(raw, eb, base + d - d0);
             if (s < thr) continue;
             const uint32_t at = hist[by_score ? std::min<uint64_t>(s, max_score) : 0]++;
             if (at < want) hits[at] = cobs_gpu_hit{(uint32_t)f, (uint32_t)d, s};
@@ -1336,8 +1406,16 @@ cobs_gpu_status cobs_gpu_batch_counts_host(cobs_gpu_batch* b, size_t q, uint32_t
     return fetch_counts(b, q, counts);
 }
 
+static cobs_gpu_status hits_host_impl(cobs_gpu_batch* b, size_t q, size_t num_results,
+                                      cobs_gpu_hit* hits, size_t cap, size_t* n_hits);
+
 cobs_gpu_status cobs_gpu_batch_hits_host(cobs_gpu_batch* b, size_t q, size_t num_results,
                                          cobs_gpu_hit* hits, size_t cap, size_t* n_hits) {
+    return guarded([&]() { return hits_host_impl(b, q, num_results, hits, cap, n_hits); });
+}
+
+static cobs_gpu_status hits_host_impl(cobs_gpu_batch* b, size_t q, size_t num_results,
+                                      cobs_gpu_hit* hits, size_t cap, size_t* n_hits) {
     if (!b || !n_hits) return fail(COBS_GPU_ERR_ARG, "NULL argument");
     if (!b->ran || !b->synced) return fail(COBS_GPU_ERR_ARG, "run and sync the batch first");
     if (q >= b->nq) return fail(COBS_GPU_ERR_ARG, "query number out of range");
@@ -1345,7 +1423,7 @@ cobs_gpu_status cobs_gpu_batch_hits_host(cobs_gpu_batch* b, size_t q, size_t num
     HIP_TRY(hipSetDevice(ix->device));
     std::vector<cobs_gpu_hit>& sel = b->sel_scratch;     // reused: no allocation per query
     sel.clear();
-    const bool pool_ok = b->selected && b->h_flags[1] <= b->hit_cap;
+    const bool pool_ok = b->selected && (b->pool_global || b->h_nhits() <= b->hit_cap);
     const bool topk_ok = b->topk_k > 0 && num_results > 0 && num_results <= b->topk_k && total_hashes(b, q) > 1;
     if (topk_ok) {
         // K3 left the k best documents of every file on the device: fetch once, merge per query
@@ -1357,17 +1435,18 @@ cobs_gpu_status cobs_gpu_batch_hits_host(cobs_gpu_batch* b, size_t q, size_t num
             HIP_TRY(hipMemcpy(b->h_topk_cnt.data(), b->topk_cnt.p, 4 * b->h_topk_cnt.size(), hipMemcpyDeviceToHost));
             b->topk_fetched = true;
         }
+        const size_t stride = b->topk_stride ? b->topk_stride : k;     // ranks * k after an exchange
         for (size_t f = 0; f < nparts; ++f) {
-            const uint2* e = b->h_topk.data() + (f * b->nq + q) * k;
+            const uint2* e = b->h_topk.data() + (f * b->nq + q) * stride;
             const uint32_t cnt = b->h_topk_cnt[f * b->nq + q];
             for (uint32_t i = 0; i < cnt; ++i) sel.push_back(cobs_gpu_hit{(uint32_t)f, e[i].x, e[i].y});
         }
     } else if (pool_ok) {
         if (!b->pool_fetched) {
             // the pool arrives in arbitrary order: bucket it by query with a counting scatter
-            std::vector<HitDev> raw(b->h_flags[1]);
-            if (b->h_flags[1])
-                HIP_TRY(hipMemcpy(raw.data(), b->hits.p, sizeof(HitDev) * b->h_flags[1], hipMemcpyDeviceToHost));
+            std::vector<HitDev> raw((size_t)b->h_nhits());
+            if (!raw.empty())
+                HIP_TRY(hipMemcpy(raw.data(), b->hits.p, sizeof(HitDev) * raw.size(), hipMemcpyDeviceToHost));
             b->h_hit_off.assign(b->nq + 1, 0);
             for (const HitDev& h : raw) b->h_hit_off[h.query + 1]++;
             for (size_t i = 0; i < b->nq; ++i) b->h_hit_off[i + 1] += b->h_hit_off[i];
@@ -1390,8 +1469,9 @@ cobs_gpu_status cobs_gpu_batch_hits_host(cobs_gpu_batch* b, size_t q, size_t num
             const Part& p = ix->parts[f];
             const uint32_t thr = threshold_for(b->threshold, (uint64_t)b->lens[q] - p.meta.term_size + 1);
             // only documents whose slots this shard computed
-            const uint64_t d0 = p.slot_begin;
-            const uint64_t d1 = std::min<uint64_t>(p.slot_begin + p.slot_count, p.meta.doc_names.size());
+            const uint64_t d0 = b->view_global ? 0 : p.slot_begin;
+            const uint64_t d1 = b->view_global ? p.meta.doc_names.size()
+                                               : std::min<uint64_t>(p.slot_begin + p.slot_count, p.meta.doc_names.size());
             for (uint64_t d = d0; d < d1; ++d) {
                 const uint32_t s = counts[p.doc_offset + d];
                 if (s >= thr) sel.push_back(cobs_gpu_hit{(uint32_t)f, (uint32_t)d, s});
@@ -1449,7 +1529,8 @@ cobs_gpu_status cobs_gpu_batch_kernel_ms(cobs_gpu_batch* b, float* scan_ms, floa
 // (asynchronous; the kernels are ordered after `after`, the previous pass), end = wait for it,
 // repeat it with score rows if the hit pool overflowed, book the timers.
 static cobs_gpu_status host_pass_begin(cobs_gpu_index* ix, int slot, const char* const* queries, const size_t* lens,
-                                       size_t nq, double threshold, size_t topk, hipEvent_t after) {
+                                       size_t nq, double threshold, size_t topk, hipEvent_t after,
+                                       size_t* bad_at = nullptr) {
     HIP_TRY(hipSetDevice(ix->device));
     if (!ix->scratch[slot]) {
         cobs_gpu_status st = cobs_gpu_batch_create(ix, 0, 0, &ix->scratch[slot]);
@@ -1459,7 +1540,9 @@ static cobs_gpu_status host_pass_begin(cobs_gpu_index* ix, int slot, const char*
     }
     cobs_gpu_batch* b = ix->scratch[slot];
     double t0 = now_s();
-    cobs_gpu_status st = set_queries_on(b, queries, lens, nq, b->own_stream, false);
+    size_t bad_local = 0;
+    cobs_gpu_status st = set_queries_on(b, queries, lens, nq, b->own_stream, false, &bad_local);
+    if (st != COBS_GPU_OK && bad_at) *bad_at = bad_local;
     if (st != COBS_GPU_OK) return st;
     ix->timers[1] += now_s() - t0;
     if (after) HIP_TRY(hipStreamWaitEvent(b->own_stream, after, 0));
@@ -1475,7 +1558,7 @@ static cobs_gpu_status host_pass_begin(cobs_gpu_index* ix, int slot, const char*
 static cobs_gpu_status host_pass_end(cobs_gpu_index* ix, int slot, double threshold, size_t topk, size_t* bad_query) {
     cobs_gpu_batch* b = ix->scratch[slot];
     cobs_gpu_status st = cobs_gpu_batch_sync(b, b->own_stream, bad_query);
-    if (st == COBS_GPU_OK && !b->have_counts && b->h_flags[1] > b->hit_cap) {
+    if (st == COBS_GPU_OK && !b->have_counts && b->h_nhits() > b->hit_cap) {
         st = run_impl(b, threshold, topk, b->own_stream, true);
         if (st != COBS_GPU_OK) return st;
         HIP_TRY(hipEventRecord(b->done, b->own_stream));
@@ -1498,10 +1581,10 @@ static cobs_gpu_status run_host_batch(cobs_gpu_index* ix, const char* const* que
     return host_pass_end(ix, 0, threshold, topk, bad_query);
 }
 
-cobs_gpu_status cobs_gpu_search_batch(cobs_gpu_index* ix, const char* const* queries, const size_t* lens,
-                                      size_t nq, double threshold, size_t num_results,
-                                      cobs_gpu_hit* hits, size_t cap, size_t* hit_offsets,
-                                      size_t* bad_query) {
+static cobs_gpu_status search_batch_impl(cobs_gpu_index* ix, const char* const* queries, const size_t* lens,
+                                         size_t nq, double threshold, size_t num_results,
+                                         cobs_gpu_hit* hits, size_t cap, size_t* hit_offsets,
+                                         size_t* bad_query) {
     if (!ix || !hit_offsets) return fail(COBS_GPU_ERR_ARG, "NULL argument");
     if (nq && (!queries || !lens)) return fail(COBS_GPU_ERR_ARG, "NULL argument");
     size_t used = 0;
@@ -1510,12 +1593,11 @@ cobs_gpu_status cobs_gpu_search_batch(cobs_gpu_index* ix, const char* const* que
     // Large batches are cut into device passes whose score rows and row-index tables stay
     // below a limit each (the caller sees one call; results are concatenated).
     // (16 GiB: a small part of 288 GB of HBM, and large passes keep more lookups per cached line.)
-    uint64_t kLimit = 16ull << 30;
-    if (const char* e = getenv("COBS_GPU_PASS_BYTES")) kLimit = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
+    const uint64_t kLimit = ix->tune.pass_bytes;
     uint32_t min_term = 0xFFFFFFFFu;
     for (const auto& p : ix->parts) min_term = std::min(min_term, p.meta.term_size);
     uint64_t terms_per_char = 0;                      // table bytes per query character, all files
-    for (const auto& p : ix->parts) terms_per_char += 4ull * p.meta.num_hashes * std::max<uint32_t>(p.max_chunk_pages, 1);
+    for (const auto& p : ix->parts) terms_per_char += 4ull * p.meta.num_hashes * std::max<uint32_t>(p.num_tpages(), 1) * (p.idx64 ? 2 : 1);
     // Passes are pipelined over up to three scratch batches: while the GPU scans pass i the host
     // stages and uploads pass i+1 and ranks pass i-1 (kernels of consecutive passes are chained by
     // events, so they never share the GPU).  A call with 4 MiB of query text or more is cut into at
@@ -1525,8 +1607,7 @@ cobs_gpu_status cobs_gpu_search_batch(cobs_gpu_index* ix, const char* const* que
     const size_t depth = any_streamed ? 1 : (size_t)cobs_gpu_index::kScratch;
     uint64_t total_chars = 0;
     for (size_t q = 0; q < nq; ++q) total_chars += lens[q];
-    uint64_t pipe_chars = 4ull << 20;                  // tuning hook: COBS_GPU_PIPE_CHARS (0 = never cut for pipelining)
-    if (const char* e = getenv("COBS_GPU_PIPE_CHARS")) pipe_chars = std::strtoull(e, nullptr, 10);
+    const uint64_t pipe_chars = ix->tune.pipe_chars;   // 0 = never cut for pipelining
     const size_t max_pass = (!any_streamed && pipe_chars && total_chars >= pipe_chars && nq >= 64)
                                 ? (nq + 3) / 4 : std::max<size_t>(nq, 1);
     const size_t topk = num_results < ix->total_counts ? num_results : 0;   // bounded: K3 selects on the device
@@ -1549,7 +1630,7 @@ cobs_gpu_status cobs_gpu_search_batch(cobs_gpu_index* ix, const char* const* que
         cobs_gpu_batch* sb = ix->scratch[ps.slot];
         for (size_t q = ps.g0; q < ps.g1; ++q) {
             size_t n = 0;
-            if (sb->selected && sb->pool_fetched && sb->h_flags[1] <= sb->hit_cap &&
+            if (sb->selected && sb->pool_fetched && sb->h_nhits() <= sb->hit_cap &&
                 sb->h_hit_off[q - ps.g0] == sb->h_hit_off[q - ps.g0 + 1]) {
                 hit_offsets[q + 1] = used;       // no document of this query reached the threshold
                 continue;
@@ -1589,10 +1670,12 @@ cobs_gpu_status cobs_gpu_search_batch(cobs_gpu_index* ix, const char* const* que
             if (st != COBS_GPU_OK) { drain(); return st; }
         }
         const int slot = (int)(pass_no % depth);
-        cobs_gpu_status st = host_pass_begin(ix, slot, queries + g0, lens + g0, g1 - g0, threshold, topk, prev_done);
+        size_t bad_local = 0;
+        cobs_gpu_status st = host_pass_begin(ix, slot, queries + g0, lens + g0, g1 - g0, threshold, topk, prev_done,
+                                             &bad_local);
         if (st != COBS_GPU_OK) {
             // passes before this one come first in the caller's order: report their error if they have one
-            size_t first_bad = g0;
+            const size_t first_bad = g0 + bad_local;
             cobs_gpu_status earlier = COBS_GPU_OK;
             while (!inflight.empty() && earlier == COBS_GPU_OK) {
                 const Pass ps = inflight.front();
@@ -1622,6 +1705,15 @@ cobs_gpu_status cobs_gpu_search_batch(cobs_gpu_index* ix, const char* const* que
     return COBS_GPU_OK;
 }
 
+cobs_gpu_status cobs_gpu_search_batch(cobs_gpu_index* ix, const char* const* queries, const size_t* lens,
+                                      size_t nq, double threshold, size_t num_results,
+                                      cobs_gpu_hit* hits, size_t cap, size_t* hit_offsets,
+                                      size_t* bad_query) {
+    return guarded([&]() {
+        return search_batch_impl(ix, queries, lens, nq, threshold, num_results, hits, cap, hit_offsets, bad_query);
+    });
+}
+
 cobs_gpu_status cobs_gpu_search(cobs_gpu_index* ix, const char* query, size_t len, double threshold,
                                 size_t num_results, cobs_gpu_hit* hits, size_t cap, size_t* n_hits) {
     if (!ix || !query || !n_hits) return fail(COBS_GPU_ERR_ARG, "NULL argument");
@@ -1634,12 +1726,14 @@ cobs_gpu_status cobs_gpu_search(cobs_gpu_index* ix, const char* query, size_t le
 cobs_gpu_status cobs_gpu_counts(cobs_gpu_index* ix, const char* query, size_t len, uint32_t* counts, size_t cap) {
     if (!ix || !query || !counts) return fail(COBS_GPU_ERR_ARG, "NULL argument");
     if (cap < ix->total_counts) return fail(COBS_GPU_ERR_CAPACITY, "counts buffer too small");
-    cobs_gpu_status st = run_host_batch(ix, &query, &len, 1, 0.0, nullptr);
-    if (st != COBS_GPU_OK) return st;
-    double t0 = now_s();
-    st = fetch_counts(ix->scratch[0], 0, counts);
-    ix->timers[3] += now_s() - t0;
-    return st;
+    return guarded([&]() -> cobs_gpu_status {
+        cobs_gpu_status st = run_host_batch(ix, &query, &len, 1, 0.0, nullptr);
+        if (st != COBS_GPU_OK) return st;
+        double t0 = now_s();
+        st = fetch_counts(ix->scratch[0], 0, counts);
+        ix->timers[3] += now_s() - t0;
+        return st;
+    });
 }
 
 cobs_gpu_status cobs_gpu_timers(cobs_gpu_index* ix, double out[5], int reset) {

@@ -1,0 +1,275 @@
+// cobs_amd/csrc/engine.hpp -- internal types of libcobs_gpu.so shared by engine.cpp (index
+// staging, batches, the search API), comm.cpp (RCCL exchange of the sharded layout) and
+// build.cpp.  Nothing here is part of the C ABI (include/cobs_gpu.h).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <exception>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/cobs_gpu.h"
+#include "device_types.hpp"
+#include "index_file.hpp"
+#include "kernels.hpp"
+
+namespace cobs_amd {
+
+// ---------------------------------------------------------------------------
+// errors (thread-local text behind cobs_gpu_last_error)
+
+cobs_gpu_status fail(cobs_gpu_status st, const std::string& msg);
+cobs_gpu_status hip_fail(hipError_t e, const char* what);
+
+#define HIP_TRY(expr)                                                  \
+    do {                                                               \
+        hipError_t _e = (expr);                                        \
+        if (_e != hipSuccess) return ::cobs_amd::hip_fail(_e, #expr);  \
+    } while (0)
+
+// No C++ exception may cross the C ABI (an untrusted header can make a std::vector throw):
+// every entry point that allocates runs its body through this.
+template <typename F>
+cobs_gpu_status guarded(F&& body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return fail(COBS_GPU_ERR_CAPACITY, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(COBS_GPU_ERR_ARG, std::string("unexpected exception: ") + e.what());
+    } catch (...) {
+        return fail(COBS_GPU_ERR_ARG, "unexpected exception");
+    }
+}
+
+inline uint64_t round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
+double now_s();
+
+template <typename T>
+struct DevBuf {     // grow-only device allocation
+    T* p = nullptr;
+    size_t cap = 0;   // elements
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T));
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+};
+
+template <typename T>
+struct PinnedBuf {  // grow-only pinned host staging
+    T* p = nullptr;
+    size_t cap = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    PinnedBuf(PinnedBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipHostMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+};
+
+// Tuning hooks.  The COBS_GPU_* environment variables are read ONCE, when an index is opened,
+// into the handle (never on the launch path); cobs_gpu_set_tuning changes them per handle
+// afterwards (the A/B scripts use that).  0 / -1 = automatic.
+struct Tuning {
+    uint32_t row_align = 0;     // COBS_GPU_ROW_ALIGN: row pitch alignment (16..4096, multiple of 16)
+    uint32_t waves = 0;         // COBS_GPU_WAVES: waves per work-group (1, 2, 4)
+    uint32_t tile_w = 0;        // COBS_GPU_TILE_W: 16-byte chunks per tile (4..64)
+    int mq = -1;                // COBS_GPU_MQ: force the multi-query scan variant off / on
+    uint64_t pass_bytes = 16ull << 30;   // COBS_GPU_PASS_BYTES: workspace limit of one device pass
+    uint64_t pipe_chars = 4ull << 20;    // COBS_GPU_PIPE_CHARS: query text from which a call is pipelined
+    bool no_pin = false;        // COBS_GPU_NO_PIN: never hipHostRegister the mapped file
+    int graph = -1;             // COBS_GPU_GRAPH: captured-graph path for small batches off / on
+    static Tuning from_env();
+};
+
+// A slice of one file-level sub-index: all of its rows, row bytes [col0, col0+ncols).
+struct VPage {
+    uint32_t fp = 0;
+    uint64_t col0 = 0, ncols = 0;
+};
+
+// A group of slices (equal width) that is in HBM at the same time and is scanned by one
+// launch.  A resident part is one chunk per slice width (a shard cut inside a sub-index holds
+// up to three: tail columns of its first sub-index, whole sub-indexes, head columns of its
+// last); a part larger than the HBM budget is cut into chunks that are streamed through two
+// device buffers, one scan pass per chunk (documents of different sub-indexes / column ranges
+// never combine, so every chunk is an independent scan that fills its own score slots).
+struct Chunk {
+    std::vector<VPage> vp;
+    std::vector<PageDev> pages;      // bases relative to the chunk's buffer
+    PageDev* d_pages = nullptr;
+    uint32_t pitch = 0, cpp = 0, total_chunks = 0;
+    size_t bytes = 0;                // device bytes incl. zero rows
+    size_t stage_bytes = 0;          // packed host bytes (rows x ncols)
+    uint8_t* d_data = nullptr;       // resident chunk only
+};
+
+// One index file as held by this device (possibly only a shard of it).
+struct Part {
+    IndexMeta meta;
+    uint32_t first_page = 0, end_page = 0;   // file-level sub-indexes (partly) held here
+    std::vector<VPage> held;                 // the slices of those sub-indexes this shard holds, in slot order
+    std::vector<Chunk> chunks;
+    std::vector<PageDev> tpages;             // sub-indexes [first_page, end_page): pages of the row-index table
+    PageDev* d_tpages = nullptr;
+    bool streamed = false;
+    bool idx64 = false;                      // a sub-index has >= 2^32 - 1 rows: 64-bit row-index table
+    size_t hbm_bytes = 0;
+    uint64_t resident_bytes = 0;             // what the held slices need when they stay in HBM
+    // streaming (BASELINE config 5: index larger than the HBM budget)
+    std::unique_ptr<MappedFile> file;        // source of the chunks
+    bool file_pinned = false;                // the mapping is registered with HIP: DMA straight from it
+    bool synthetic = false;
+    uint64_t synth_seed = 0;
+    uint64_t doc_offset = 0;      // first global score slot of this file
+    uint64_t slot_begin = 0;      // file-level score slots computed here
+    uint64_t slot_count = 0;
+    uint64_t local_offset = 0;    // position of those slots in a local count row
+
+    uint32_t num_tpages() const { return end_page - first_page; }
+    Part() = default;
+    Part(Part&&) = default;
+    Part(const Part&) = delete;
+    ~Part();
+};
+
+// The two device buffers all streamed parts of a handle share (one pass at a time walks the
+// parts in order, so the double buffering simply continues across files), with the copy
+// stream and the events that order copies against scans.
+struct StreamBufs {
+    DevBuf<uint8_t> sbuf[2];
+    PinnedBuf<uint8_t> stage[2];
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copied[2] = {nullptr, nullptr}, scanned[2] = {nullptr, nullptr};
+    bool used[2] = {false, false};
+    uint64_t cap = 0;             // bytes per buffer
+    size_t stage_need = 0;
+    uint64_t seq = 0;             // chunks streamed so far: chunk goes to buffer seq % 2
+    ~StreamBufs();
+};
+
+struct PartWork {    // per-file device workspace of a batch
+    const uint64_t* blk_off = nullptr;   // inside the batch's upload buffer
+    DevBuf<uint32_t> table;
+    DevBuf<uint32_t> thr;
+    std::vector<uint64_t> h_blk_off;
+    uint64_t table_entries = 0;
+};
+
+struct Exchange;     // comm.cpp: buffers of the RCCL exchange bound to a batch
+
+}  // namespace cobs_amd
+
+struct cobs_gpu_index {
+    int device = 0;
+    uint32_t shard_rank = 0, shard_count = 1, shard_mode = 0;
+    uint64_t hbm_budget = 0;      // 0 = everything resident
+    uint32_t waves_per_group = 0; // 0 = by query length
+    cobs_amd::Tuning tune;
+    std::vector<cobs_amd::Part> parts;
+    cobs_amd::StreamBufs stream;
+    uint64_t total_counts = 0, local_counts = 0;
+    double timers[5] = {0, 0, 0, 0, 0};
+    static constexpr int kScratch = 3;
+    cobs_gpu_batch* scratch[kScratch] = {nullptr, nullptr, nullptr};   // workspaces of the host-buffer search API
+    ~cobs_gpu_index();
+};
+
+struct cobs_gpu_batch {
+    cobs_gpu_index* ix = nullptr;
+    size_t max_queries = 0, max_len = 0;
+    size_t nq = 0;
+    std::vector<uint32_t> lens;
+    std::vector<uint64_t> span_off;
+    cobs_amd::DevBuf<uint8_t> text;
+    // query text, span offsets, query lengths and the per-file block offsets live in ONE pinned
+    // staging buffer / ONE device buffer (`text`): a batch is uploaded with a single async copy
+    const uint64_t* d_span_off = nullptr;
+    const uint32_t* d_qlen = nullptr;
+    cobs_amd::PinnedBuf<uint8_t> h_text;
+    cobs_amd::PinnedBuf<uint32_t> h_thr_stage;
+    std::vector<cobs_amd::PartWork> work;
+    cobs_amd::DevBuf<uint8_t> counts;
+    uint32_t elem_bytes = 2;
+    int planes = 0;
+    uint64_t max_terms = 0;              // longest query of the batch, in terms
+    cobs_amd::DevBuf<cobs_amd::HitDev> hits;
+    cobs_amd::DevBuf<uint2> topk_out;    // K3 output [file][query][k], ordered (score desc, doc asc)
+    cobs_amd::DevBuf<uint32_t> topk_cnt; // [file][query]
+    std::vector<uint2> h_topk;
+    std::vector<uint32_t> h_topk_cnt;
+    uint32_t topk_k = 0;              // k of the last run (0 = K3 not run)
+    bool topk_fetched = false;
+    // device flags: word 0 = first invalid query (2^32-1 - q, 0 = none), words 2..3 = 64-bit fill
+    // of the hit pool (may exceed hit_cap: overflow)
+    cobs_amd::DevBuf<uint32_t> flags;
+    uint32_t hit_cap = 0;
+    // last run
+    bool ran = false, selected = false, synced = false;
+    bool have_counts = false;         // the last run wrote the score rows
+    double threshold = 0.0;
+    uint32_t h_flags[4] = {0, 0, 0, 0};
+    uint64_t h_nhits() const { return (uint64_t)h_flags[3] << 32 | h_flags[2]; }
+    std::vector<cobs_amd::HitDev> h_hits;       // pool copy, sorted by query
+    std::vector<size_t> h_hit_off;
+    bool pool_fetched = false;
+    // host copy of a window of score rows [rows_q0, rows_q1) of the last run (raw elem_bytes)
+    cobs_amd::PinnedBuf<uint8_t> h_rows;
+    size_t rows_q0 = 0, rows_q1 = 0;
+    std::vector<uint32_t> rank_hist;  // scratch of the counting sort in hits_host
+    std::vector<cobs_gpu_hit> sel_scratch;
+    // HIP events around K1 and K2 of the most recent runs (recorded on the launch stream)
+    static constexpr int kRing = 64;
+    hipEvent_t ev[kRing][3] = {};
+    uint64_t run_seq = 0, read_seq = 0;
+    uint64_t stats[4] = {0, 0, 0, 0};
+    hipEvent_t run_done = nullptr;    // after the last kernel of the most recent run
+    // host-buffer API only: the stream this scratch batch lives on and the event after its pass
+    hipStream_t own_stream = nullptr;
+    hipEvent_t done = nullptr;
+    // captured graph of a small pass (single-query latency path)
+    hipGraphExec_t graph_exec = nullptr;
+    uint64_t graph_key = 0;
+    hipStream_t graph_stream = nullptr;
+    cobs_amd::Exchange* xchg = nullptr;       // comm.cpp
+    // set by an exchange, cleared by the next run: GLOBAL score rows (all shards' slices assembled
+    // in global document order) of queries [g_q0, g_q0 + g_qn), owned by xchg
+    const uint8_t* g_rows = nullptr;
+    uint64_t g_q0 = 0, g_qn = 0;
+    bool view_global = false;
+    bool pool_global = false;         // h_hits holds the hit pools of ALL shards
+    uint32_t topk_stride = 0;         // entries per (file, query) in h_topk (0 = topk_k; ranks * k after an exchange)
+    ~cobs_gpu_batch();
+};
+
+namespace cobs_amd {
+
+// engine.cpp internals used by comm.cpp
+cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk, void* hip_stream, bool want_counts = true);
+cobs_gpu_status set_queries_on(cobs_gpu_batch* b, const char* const* queries, const size_t* lens, size_t nq,
+                               hipStream_t up, bool wait, size_t* bad_query);
+uint32_t threshold_for(double threshold, uint64_t terms);
+uint64_t total_hashes(const cobs_gpu_batch* b, size_t q);
+bool hit_before(const cobs_gpu_hit& a, const cobs_gpu_hit& b);
+bool doc_before(const cobs_gpu_hit& a, const cobs_gpu_hit& b);
+void destroy_exchange(Exchange* x);       // comm.cpp
+
+}  // namespace cobs_amd

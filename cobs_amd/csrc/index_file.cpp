@@ -19,6 +19,7 @@ public:
     Cursor(const uint8_t* p, size_t n) : p_(p), n_(n) {}
     bool ok() const { return ok_; }
     size_t pos() const { return pos_; }
+    size_t left() const { return n_ - pos_; }
     void skip(size_t n) {
         if (!ok_ || n > n_ - pos_) { ok_ = false; return; }
         pos_ += n;
@@ -74,6 +75,7 @@ bool try_classic(const uint8_t* data, size_t len, IndexMeta& m) {
     const uint64_t sig = c.pod<uint64_t>();
     m.num_hashes = c.pod<uint64_t>();
     if (!c.ok()) return false;
+    if (ndocs > c.left()) return false;            // every name takes at least its '\n'
     m.signature_sizes.assign(1, sig);
     m.doc_names.reserve(ndocs);
     for (uint32_t i = 0; i < ndocs && c.ok(); ++i) m.doc_names.push_back(c.line());
@@ -94,6 +96,8 @@ bool try_compact(const uint8_t* data, size_t len, IndexMeta& m) {
     const uint32_t ndocs = c.pod<uint32_t>();
     m.header_page_size = c.pod<uint64_t>();
     if (!c.ok() || nparams == 0 || m.header_page_size == 0) return false;
+    if (nparams > c.left() / 16 || ndocs > c.left()) return false;     // 16 bytes per sub-index, >= 1 per name
+    if (m.header_page_size > (1ull << 28)) return false;                // also keeps the padding arithmetic small
     m.signature_sizes.reserve(nparams);
     for (uint32_t p = 0; p < nparams && c.ok(); ++p) {
         const uint64_t sig = c.pod<uint64_t>();
@@ -118,7 +122,17 @@ bool try_compact(const uint8_t* data, size_t len, IndexMeta& m) {
 
 bool parse_index_header(const uint8_t* data, size_t len, IndexMeta& meta, std::string& err) {
     if (try_classic(data, len, meta) || try_compact(data, len, meta)) {
-        if (meta.data_offset + meta.data_bytes() > len) {
+        // matrix bytes with checked arithmetic: a crafted signature_size must not wrap to a small number
+        uint64_t need = meta.data_offset;
+        const uint64_t prb = meta.page_row_bytes();
+        for (uint64_t sig : meta.signature_sizes) {
+            uint64_t bytes = 0;
+            if (__builtin_mul_overflow(prb, sig, &bytes) || __builtin_add_overflow(need, bytes, &need)) {
+                err = "index header describes a matrix larger than 2^64 bytes";
+                return false;
+            }
+        }
+        if (need > len) {
             err = "index file is shorter than its header promises";
             return false;
         }

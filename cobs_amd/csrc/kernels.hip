@@ -459,6 +459,11 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     // merge buffers: [NW/2 (min 1)][NP][64 lanes] of uint4, then the 256-entry expansion table
     uint4* mbuf = reinterpret_cast<uint4*>(smem);
     uint4* lut = mbuf + (size_t)(NW >= 2 ? NW / 2 : 1) * NP * 64;
+    // per-chunk metadata of this tile (first local score slot, valid row bytes left in the
+    // chunk, first document id) and per-lane-group thresholds: the epilogue reads them from
+    // LDS instead of chasing a.pages[] / a.thresholds[] through global memory per iteration
+    uint32_t* tmeta = reinterpret_cast<uint32_t*>(lut + 256);       // [64][3]
+    uint32_t* tthr = tmeta + 64 * 3;                                 // [64]
     for (uint32_t v = threadIdx.x; v < 256u; v += NW * 64) {
         uint4 e;
         if constexpr (sizeof(OutT) == 1) {
@@ -497,12 +502,20 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     const uint32_t qraw = MQ ? qi * G + grp : qi;
     const bool qlive = qraw < a.nq;
     const uint32_t q = qlive ? qraw : a.nq - 1u;
+    if (a.thresholds && wave == 0u && col == 0u) tthr[MQ ? grp : 0u] = a.thresholds[q];
     const uint32_t g = a.chunk_begin + tile * W + col;
     const uint32_t gc = g < a.chunk_end ? g : a.chunk_end - 1u;     // dead lanes duplicate a live one
     const uint32_t pg = gc / a.cpp;
     const uint32_t ch = gc - pg * a.cpp;
-    const uint8_t* lane_base = a.blob + a.pages[pg].base + (uint64_t)ch * 16u;
+    const PageDev pdl = a.pages[pg];
+    const uint8_t* lane_base = a.blob + pdl.base + (uint64_t)ch * 16u;
     const uint32_t pitch = a.pitch;
+    if (threadIdx.x < W) {        // wave 0, lane group 0: one lane per chunk of the tile
+        const uint32_t vb = (g < a.chunk_end && pdl.valid_bytes > ch * 16u) ? min(pdl.valid_bytes - ch * 16u, 16u) : 0u;
+        tmeta[col * 3 + 0] = pdl.slot0 + ch * 128u;
+        tmeta[col * 3 + 1] = vb;
+        tmeta[col * 3 + 2] = pdl.doc0 + ch * 128u;
+    }
 
     const uint64_t b0 = a.blk_off[q];
     const uint32_t nblk_q = (uint32_t)(a.blk_off[q + 1] - b0);   // table stride of query q
@@ -510,7 +523,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     const uint32_t H = H1 ? 1u : a.num_hashes;
     // row indices of this lane's sub-index: [nblk + 1 blocks][hash][8]; block nblk is all padding
     const IdxT* tab = reinterpret_cast<const IdxT*>(a.table) +
-                      ((b0 + q) * a.npages + (uint64_t)pg * (nblk_q + 1u)) * (8ull * H);
+                      ((b0 + q) * a.table_npages + (uint64_t)pdl.tpage * (nblk_q + 1u)) * (8ull * H);
     const uint32_t vw = MQ ? wave : wave * G + grp;  // virtual wave of this lane
     const uint32_t NV = MQ ? (uint32_t)NW : NW * G;
     // block of this lane in trip i: vw + i * NV, or the padding block when it has run out
@@ -646,13 +659,9 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
             const uint32_t chunk = MQ ? (pl_lane & (W - 1u)) : pl_lane;
             const uint32_t q2raw = MQ ? qi * G + pl_lane / W : qi;
             const uint32_t q2 = q2raw < a.nq ? q2raw : a.nq - 1u;
-            const uint32_t thr = a.thresholds[q2];
-            const uint32_t gch = a.chunk_begin + tile * W + chunk;
-            const bool valid = act && gch < a.chunk_end && q2raw < a.nq;
-            const uint32_t gcc = valid ? gch : a.chunk_begin;
-            const uint32_t p2 = gcc / a.cpp;
-            const uint32_t byte0 = (gcc - p2 * a.cpp) * 16u + comp * 4u;     // first row byte of this word
-            const PageDev pd = a.pages[p2];
+            const uint32_t thr = tthr[MQ ? pl_lane / W : 0u];
+            const uint32_t vbc = tmeta[chunk * 3 + 1];                       // valid row bytes of the chunk (0: dead)
+            const bool valid = act && vbc != 0u && q2raw < a.nq;
             // ge bit d = (count of document d >= thr), from the lowest plane up:
             //   threshold bit 1: ge &= plane, threshold bit 0: ge |= plane
             uint32_t ge = (NP < 32 && (thr >> (NP < 32 ? NP : 0)) != 0u) ? 0u : 0xFFFFFFFFu;
@@ -662,9 +671,9 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
                 ge = ((thr >> k) & 1u) ? (ge & pk) : (ge | pk);
             }
             // real documents only: row bytes inside the page, document ids below num_docs
-            const uint32_t vb = pd.valid_bytes > byte0 ? pd.valid_bytes - byte0 : 0u;        // valid bytes of the word
+            const uint32_t vb = vbc > comp * 4u ? vbc - comp * 4u : 0u;                       // valid bytes of the word
             if (vb < 4u) ge &= vb == 0u ? 0u : (1u << (vb * 8u)) - 1u;
-            const uint32_t doc0 = pd.doc0 + byte0 * 8u;
+            const uint32_t doc0 = tmeta[chunk * 3 + 2] + comp * 32u;
             const uint32_t nd = a.num_docs > doc0 ? a.num_docs - doc0 : 0u;
             if (nd < 32u) ge &= nd == 0u ? 0u : (1u << nd) - 1u;
             if (!valid) ge = 0u;
@@ -677,10 +686,10 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
                     if (lane >= (uint32_t)off) incl += t;
                 }
                 const uint32_t total = __shfl(incl, 63);
-                uint32_t base = 0u;
-                if (lane == 63u) base = atomicAdd(a.hit_count, total);
+                unsigned long long base = 0ull;
+                if (lane == 63u) base = atomicAdd(a.hit_count, (unsigned long long)total);
                 base = __shfl(base, 63);
-                uint32_t pos = base + incl - n;
+                unsigned long long pos = base + incl - n;
                 while (ge != 0u) {
                     const uint32_t d = (uint32_t)__ffs((int)ge) - 1u;
                     ge &= ge - 1u;
@@ -702,15 +711,9 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
         const uint32_t chunk = MQ ? (pl_lane & (W - 1u)) : pl_lane;
         const uint32_t q2raw = MQ ? qi * G + pl_lane / W : qi;
         const uint32_t q2 = q2raw < a.nq ? q2raw : a.nq - 1u;
-        const uint32_t thr = a.thresholds ? a.thresholds[q2] : 0u;
+        const uint32_t thr = a.thresholds ? tthr[MQ ? pl_lane / W : 0u] : 0u;
         OutT* crow = reinterpret_cast<OutT*>(a.counts) + (uint64_t)q2 * a.counts_stride + a.counts_offset;
-        const uint32_t gch = a.chunk_begin + tile * W + chunk;
-        bool valid = gch < a.chunk_end && q2raw < a.nq;
-        const uint32_t gcc = valid ? gch : a.chunk_begin;
-        const uint32_t p2 = gcc / a.cpp;
-        const uint32_t byte_in_page = (gcc - p2 * a.cpp) * 16u + cb;
-        const PageDev pd = a.pages[p2];
-        valid = valid && byte_in_page < pd.valid_bytes;
+        const bool valid = q2raw < a.nq && cb < tmeta[chunk * 3 + 1];
 
         // one LDS lookup spreads the 8 document bits of a plane byte into 8 sixteen-bit
         // fields (4 dwords); shifting the dwords by the plane number adds that plane to all
@@ -747,7 +750,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
                 cnt[2 * m + 1] = (lo[m] >> 16) | (hi[m] & 0xFFFF0000u);
             }
         }
-        const uint32_t slot = pd.slot0 + byte_in_page * 8u;
+        const uint32_t slot = tmeta[chunk * 3 + 0] + cb * 8u;
         if (valid && a.write_counts) {
             if constexpr (sizeof(OutT) == 1) {
                 *reinterpret_cast<uint2*>(crow + slot) = make_uint2(lo[0], lo[1]);
@@ -760,7 +763,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
         }
         if (a.thresholds) {
             // counts_to_result filter: score >= threshold over real documents only
-            const uint32_t doc = pd.doc0 + byte_in_page * 8u;
+            const uint32_t doc = tmeta[chunk * 3 + 2] + cb * 8u;
             uint32_t mask = 0u;
             if (valid) {
 #pragma unroll
@@ -776,10 +779,10 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
                     if (lane >= (uint32_t)off) incl += t;
                 }
                 const uint32_t total = __shfl(incl, 63);
-                uint32_t base = 0u;
-                if (lane == 63u) base = atomicAdd(a.hit_count, total);
+                unsigned long long base = 0ull;
+                if (lane == 63u) base = atomicAdd(a.hit_count, (unsigned long long)total);
                 base = __shfl(base, 63);
-                uint32_t pos = base + incl - n;
+                unsigned long long pos = base + incl - n;
 #pragma unroll
                 for (int d = 0; d < 8; ++d) {
                     if (mask & (1u << d)) {
@@ -1135,7 +1138,7 @@ static hipError_t launch_scan_inst(const ScanArgs& a, uint32_t ntiles, hipStream
                             ((a.nq + per_group - 1u) / per_group);
     if (groups == 0) return hipSuccess;
     if (groups > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    constexpr size_t lds = ((size_t)(NW >= 2 ? NW / 2 : 1) * NP * 64 + 256) * sizeof(uint4);
+    constexpr size_t lds = ((size_t)(NW >= 2 ? NW / 2 : 1) * NP * 64 + 256) * sizeof(uint4) + 64 * 4 * sizeof(uint32_t);
     auto kern = scan_kernel<NP, NW, H1, OutT, MQ, IdxT>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

@@ -1,5 +1,13 @@
-"""Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" is
-RCCL on ROCm, xGMI between the GPUs of a node).
+"""Multi-GPU plumbing: one process per GPU.
+
+The exchange itself is native: libcobs_gpu.so calls RCCL (ncclAllGather / grouped
+ncclSend + ncclRecv over xGMI) through the cobs_gpu_comm_* / cobs_gpu_batch_exchange_* entry
+points of include/cobs_gpu.h (cobs_amd/csrc/comm.cpp); `Comm` below binds them.
+torch.distributed is only the LAUNCHER there: it hands rank 0's unique id to the other
+ranks.  The torch-level functions further down (all_gather_counts, assemble_counts,
+merge_hits) are the same exchange written against torch.distributed; they run on any
+backend, which is what lets world_size-2 gloo tests cover the N > 1 logic on CPU and lets
+several ranks share one GPU in tests (RCCL refuses two ranks on one device).
 
 The reference has no distributed code; a compact index is a concatenation of
 sub-indexes over disjoint, contiguous document ranges (reference
@@ -18,9 +26,61 @@ disjoint slices together:
 All functions work on whatever device the tensors live on, so the exchange and
 merge logic is covered by world_size-2 gloo tests on CPU.
 """
+import ctypes as C
+
 import numpy as np
 import torch
 import torch.distributed as dist
+
+from . import _capi
+
+
+class Comm:
+    """One rank of a native RCCL communicator (cobs_gpu_comm, comm.cpp)."""
+
+    def __init__(self, unique_id, rank, nranks, device=-1):
+        self._lib = _capi.load()
+        self._h = C.c_void_p()
+        assert len(unique_id) == _capi.UNIQUE_ID_BYTES
+        buf = (C.c_uint8 * _capi.UNIQUE_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        _capi.check(self._lib.cobs_gpu_comm_create(buf, rank, nranks, device, C.byref(self._h)))
+
+    @staticmethod
+    def unique_id():
+        """ncclGetUniqueId: call on one rank, hand the 128 bytes to all ranks"""
+        lib = _capi.load()
+        buf = (C.c_uint8 * _capi.UNIQUE_ID_BYTES)()
+        _capi.check(lib.cobs_gpu_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def from_torch(cls, group=None, device=-1):
+        """torch.distributed as the launcher: broadcast rank 0's unique id, then ncclCommInitRank"""
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(box[0], rank, world, device)
+
+    @property
+    def rank(self):
+        return int(self._lib.cobs_gpu_comm_rank(self._h))
+
+    @property
+    def size(self):
+        """ncclCommCount of the communicator"""
+        return int(self._lib.cobs_gpu_comm_size(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cobs_gpu_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def shard_slots(search, group=None):
@@ -96,28 +156,44 @@ def merge_hits(per_rank_hits, num_results=0, total_hashes=2, total_documents=Non
 class ShardedSearch:
     """cobs_index.Search over an index sharded by sub-index block across the ranks
     of `group`.  Every rank calls the same methods with the same arguments and
-    gets the same (global) results."""
+    gets the same (global) results.
 
-    def __init__(self, path, group=None, device=-1):
+    transport "rccl": the native exchange of libcobs_gpu.so (one GPU per rank);
+    "torch": the torch.distributed restatement (any backend; several ranks may share a GPU);
+    "auto": rccl when the group's backend is nccl, else torch.
+    hbm_budget > 0: every rank streams what of its shard does not fit (BASELINE configs[4])."""
+
+    def __init__(self, path, group=None, device=-1, hbm_budget=0, transport="auto", shard_mode=0):
         from .search import Batch, Search
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
-        self.search_local = Search(path, device=device, shard_rank=self.rank, shard_count=self.world)
+        if transport == "auto":
+            transport = "rccl" if dist.get_backend(group) == "nccl" else "torch"
+        self.transport = transport
+        self.search_local = Search(path, device=device, shard_rank=self.rank, shard_count=self.world,
+                                   hbm_budget=hbm_budget, shard_mode=shard_mode)
         self.batch = Batch(self.search_local)
-        self.layouts = shard_slots(self.search_local, group)
         self.total_counts = self.search_local.total_counts
+        self.comm = Comm.from_torch(group, device) if transport == "rccl" else None
+        self.layouts = shard_slots(self.search_local, group) if transport == "torch" else None
 
     def counts(self, queries):
         """-> [Q, total_counts] tensor of per-document counts on every rank"""
         self.batch.set_queries(queries)
         self.batch.run(0.0)
+        if self.comm is not None:
+            self.batch.exchange_counts(self.comm, _capi.XCHG_ALLGATHER)
+            self.batch.sync()
+            return self.batch.global_counts_tensor()[2]
         self.batch.sync()
         gathered = all_gather_counts(self.batch.counts_tensor(), self.group)
         return assemble_counts(gathered, self.layouts, self.total_counts)
 
     def search_hits(self, queries, threshold=0.0, num_results=0):
         s = self.search_local
+        if self.comm is not None:
+            return s.sharded_search_hits(self.comm, queries, threshold, num_results)
         self.batch.set_queries(queries)
         if num_results > 0:
             self.batch.run_topk(threshold, num_results)      # K3: only the k best of the shard leave the device
@@ -142,4 +218,4 @@ class ShardedSearch:
         return [SearchResult(self.search_local.doc_name(f, d), sc) for (f, d, sc) in hits]
 
 
-__all__ = ["ShardedSearch", "shard_slots", "all_gather_counts", "assemble_counts", "merge_hits"]
+__all__ = ["Comm", "ShardedSearch", "shard_slots", "all_gather_counts", "assemble_counts", "merge_hits"]

@@ -38,12 +38,13 @@ def _as_bytes(q):
     return q.encode("latin-1") if isinstance(q, str) else bytes(q)
 
 
-def _options(device, shard_rank, shard_count, hbm_budget=0):
+def _options(device, shard_rank, shard_count, hbm_budget=0, shard_mode=0):
     o = Options()
     o.struct_size = C.sizeof(Options)
     o.device = device
     o.shard_rank = shard_rank
     o.shard_count = shard_count
+    o.shard_mode = shard_mode
     o.hbm_budget_bytes = int(hbm_budget)
     return o
 
@@ -52,7 +53,7 @@ class Search:
     """cobs_index.Search: open one or several index files (classic or compact,
     auto-detected per file) and query them on the GPU."""
 
-    def __init__(self, path, device=-1, shard_rank=0, shard_count=1, hbm_budget=0, _handle=None):
+    def __init__(self, path, device=-1, shard_rank=0, shard_count=1, hbm_budget=0, shard_mode=0, _handle=None):
         self._lib = _capi.load()
         self._h = C.c_void_p()
         if _handle is not None:
@@ -60,12 +61,12 @@ class Search:
             return
         paths = [path] if isinstance(path, (str, bytes, os.PathLike)) else list(path)
         arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
-        opts = _options(device, shard_rank, shard_count, hbm_budget)
+        opts = _options(device, shard_rank, shard_count, hbm_budget, shard_mode)
         check(self._lib.cobs_gpu_open(arr, len(paths), C.byref(opts), C.byref(self._h)))
 
     @classmethod
     def synthetic(cls, kind, signature_sizes, num_docs, page_size=0, term_size=31, canonicalize=1,
-                  num_hashes=1, seed=1, device=-1, shard_rank=0, shard_count=1, hbm_budget=0):
+                  num_hashes=1, seed=1, device=-1, shard_rank=0, shard_count=1, hbm_budget=0, shard_mode=0):
         """Procedural index generated directly in HBM (benchmark / large parity runs)."""
         lib = _capi.load()
         sigs = (C.c_uint64 * len(signature_sizes))(*[int(s) for s in signature_sizes])
@@ -75,7 +76,7 @@ class Search:
         d.num_hashes, d.page_size, d.num_docs, d.seed = num_hashes, page_size, num_docs, seed
         d.signature_sizes = C.cast(sigs, C.POINTER(C.c_uint64))
         h = C.c_void_p()
-        opts = _options(device, shard_rank, shard_count, hbm_budget)
+        opts = _options(device, shard_rank, shard_count, hbm_budget, shard_mode)
         check(lib.cobs_gpu_open_synthetic(C.byref(d), C.byref(opts), C.byref(h)))
         return cls(None, _handle=h)
 
@@ -128,10 +129,19 @@ class Search:
         check(self._lib.cobs_gpu_read_row(self._h, file_no, page, row, out.ctypes.data, nbytes))
         return out
 
+    def page_columns(self, file_no, page):
+        """-> (col0, ncols): the row bytes of sub-index `page` this shard holds"""
+        c0, n = C.c_uint64(0), C.c_uint64(0)
+        check(self._lib.cobs_gpu_page_columns(self._h, file_no, page, C.byref(c0), C.byref(n)))
+        return int(c0.value), int(n.value)
+
+    def set_tuning(self, key, value):
+        """per-handle tuning hook of the scan launch (see cobs_gpu_set_tuning)"""
+        check(self._lib.cobs_gpu_set_tuning(self._h, key.encode(), int(value)))
+
     def read_rows(self, file_no, page, row0, nrows, out=None):
-        """bulk D2H of whole rows of one held sub-index -> uint8 [nrows, valid bytes]"""
-        i = self.info(file_no)
-        width = i.slot_count // 8 if i.kind == 0 else i.page_size
+        """bulk D2H of whole rows of one held sub-index -> uint8 [nrows, held row bytes]"""
+        width = self.page_columns(file_no, page)[1]
         if out is None:
             out = np.empty((nrows, width), dtype=np.uint8)
         check(self._lib.cobs_gpu_read_rows(self._h, file_no, page, row0, nrows, out.ctypes.data, width))
@@ -195,6 +205,36 @@ class Search:
             check(st)
             break
         return offs, hits[:int(offs[nq])]
+
+    def sharded_search_hits(self, comm, queries, threshold=0.0, num_results=0):
+        """cobs_gpu_sharded_search_batch: collective over `comm` (every rank, same queries);
+        -> per query the GLOBAL list of (file_no, doc, score) in result order."""
+        qs = [q if type(q) is bytes else _as_bytes(q) for q in queries]
+        nq = len(qs)
+        arr = (C.c_char_p * max(nq, 1))(*qs)
+        lens = (C.c_size_t * max(nq, 1))(*[len(q) for q in qs])
+        if num_results > 0:
+            cap = nq * min(num_results, self.total_counts)
+        elif threshold <= 0:
+            cap = nq * self.total_counts
+        else:
+            cap = 16 * nq + 1024
+        cap = max(1, cap)
+        offs = np.zeros(nq + 1, dtype=np.uint64)
+        bad = C.c_size_t(0)
+        while True:
+            hits = np.empty(cap, dtype=self.HIT_DTYPE)
+            st = self._lib.cobs_gpu_sharded_search_batch(
+                self._h, comm._h, arr, lens, nq, float(threshold), int(num_results),
+                C.cast(hits.ctypes.data, C.POINTER(Hit)), cap,
+                C.cast(offs.ctypes.data, C.POINTER(C.c_size_t)), C.byref(bad))
+            if st == _capi.ERR_CAPACITY and int(offs[nq]) > cap:
+                cap = int(offs[nq])
+                continue
+            check(st)
+            break
+        rows = hits[:int(offs[nq])].tolist()
+        return [rows[int(offs[q]):int(offs[q + 1])] for q in range(nq)]
 
     def search_hits(self, queries, threshold=0.0, num_results=0):
         """-> per query: list of (file_no, doc, score) in result order."""
@@ -298,6 +338,36 @@ class Batch:
             return torch.empty((self.nq, n), dtype={1: torch.uint8, 2: torch.int16}.get(eb, torch.int32),
                                device="cuda")
         return torch.as_tensor(_DevArray(p, (self.nq, n), {1: "|u1", 2: "<i2"}.get(eb, "<i4"), self), device="cuda")
+
+    # -- multi-GPU exchange (native RCCL, comm.cpp) ---------------------------------------
+    def exchange_counts(self, comm, mode=_capi.XCHG_ALLTOALL, stream=0):
+        check(self._lib.cobs_gpu_batch_exchange_counts(self._h, comm._h, int(mode), C.c_void_p(stream)))
+
+    def exchange_hits(self, comm, stream=0):
+        """-> True if some shard's hit pool overflowed (lists incomplete)"""
+        over = C.c_int(0)
+        check(self._lib.cobs_gpu_batch_exchange_hits(self._h, comm._h, C.c_void_p(stream), C.byref(over)))
+        return bool(over.value)
+
+    def exchange_topk(self, comm, stream=0):
+        check(self._lib.cobs_gpu_batch_exchange_topk(self._h, comm._h, C.c_void_p(stream)))
+
+    def exchange_bytes(self):
+        return int(self._lib.cobs_gpu_batch_exchange_bytes(self._h))
+
+    def global_counts_tensor(self):
+        """after exchange_counts: (q_begin, q_count, torch view [q_count, total_counts]) of the
+        assembled rows this rank holds (global document order)"""
+        import torch
+        q0, qn, eb, rs = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0), C.c_uint64(0)
+        p = self._lib.cobs_gpu_batch_global_counts_device(self._h, C.byref(q0), C.byref(qn), C.byref(eb), C.byref(rs))
+        n = self._s.total_counts
+        dt = {1: torch.uint8, 2: torch.int16}.get(eb.value, torch.int32)
+        if not p or qn.value == 0 or n == 0:
+            return int(q0.value), int(qn.value), torch.empty((int(qn.value), n), dtype=dt, device="cuda")
+        t = torch.as_tensor(_DevArray(p, (int(qn.value), n), {1: "|u1", 2: "<i2"}.get(eb.value, "<i4"), self),
+                            device="cuda")
+        return int(q0.value), int(qn.value), t
 
     def counts_host(self, query_no):
         out = np.zeros(self._s.total_counts, dtype=np.uint32)

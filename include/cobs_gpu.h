@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define COBS_GPU_ABI_VERSION 1
+#define COBS_GPU_ABI_VERSION 2
 
 typedef enum cobs_gpu_status {
     COBS_GPU_OK = 0,
@@ -35,12 +35,14 @@ typedef enum cobs_gpu_status {
     COBS_GPU_ERR_ARG = 7,             /* NULL / out-of-range argument */
     COBS_GPU_ERR_UNSUPPORTED = 8,     /* legal index the engine cannot hold (e.g. more than 2^32 score slots in one file) */
     COBS_GPU_ERR_CAPACITY = 9,        /* caller buffer too small; *n_out holds the needed size */
-    COBS_GPU_ERR_NO_DEVICE = 10       /* no HIP device (the library has no CPU fallback) */
+    COBS_GPU_ERR_NO_DEVICE = 10,      /* no HIP device (the library has no CPU fallback) */
+    COBS_GPU_ERR_RCCL = 11            /* RCCL error in the multi-GPU exchange, text in cobs_gpu_last_error() */
 } cobs_gpu_status;
 
 /* Opaque handles. */
 typedef struct cobs_gpu_index cobs_gpu_index;   /* >= 1 index files resident in HBM  (ClassicSearch::index_files_) */
 typedef struct cobs_gpu_batch cobs_gpu_batch;   /* device workspace of one query batch */
+typedef struct cobs_gpu_comm cobs_gpu_comm;     /* one rank of an RCCL communicator (multi-GPU exchange) */
 
 typedef struct cobs_gpu_options {
     uint32_t struct_size;     /* sizeof(cobs_gpu_options) */
@@ -51,7 +53,11 @@ typedef struct cobs_gpu_options {
     uint32_t shard_rank;
     uint32_t shard_count;     /* 0 or 1 = unsharded */
     uint32_t waves_per_group; /* waves that split one query's terms: 1, 2 or 4; 0 = chosen by query length */
-    uint32_t reserved;
+    /* how a file is cut into shard_count shards (the unit is a 16-byte column chunk of one sub-index;
+     * every shard holds a contiguous range of score slots):
+     *   0 = equal bytes per shard; a cut may fall inside a sub-index (column range)
+     *   1 = whole sub-indexes, equal count per shard (classic: 16-byte columns)            */
+    uint32_t shard_mode;
     /* 0 = stage the whole (shard of the) index into HBM.  Otherwise the index may
      * use at most this many bytes of HBM: files that do not fit are cut into chunks
      * (whole sub-indexes, or column ranges of one sub-index) that are streamed from
@@ -121,6 +127,15 @@ cobs_gpu_status cobs_gpu_open(const char* const* paths, size_t n_paths,
 cobs_gpu_status cobs_gpu_open_synthetic(const cobs_gpu_synth* desc,
                                         const cobs_gpu_options* opts, cobs_gpu_index** out);
 void cobs_gpu_close(cobs_gpu_index* ix);
+/* Per-handle tuning hooks of the scan launch (the COBS_GPU_* environment variables are read once,
+ * by cobs_gpu_open*; this changes them afterwards).  key: "waves" (0, 1, 2, 4), "tile_w" (0, 4..64),
+ * "mq" (-1 auto, 0, 1), "pass_bytes", "pipe_chars", "graph" (-1 auto, 0, 1).  0 / -1 = automatic. */
+cobs_gpu_status cobs_gpu_set_tuning(cobs_gpu_index* ix, const char* key, int64_t value);
+/* Host only (no device needed): the score slots [slot_begin[r], slot_begin[r] + slot_count[r]) and
+ * the index bytes shard r of shard_count would hold of the file at `path` (arrays of shard_count
+ * entries; bytes may be NULL).  The slot ranges are disjoint, ascending and cover counts_size. */
+cobs_gpu_status cobs_gpu_plan_shards(const char* path, uint32_t shard_count, uint32_t shard_mode,
+                                     uint64_t* slot_begin, uint64_t* slot_count, uint64_t* bytes);
 
 size_t cobs_gpu_num_files(const cobs_gpu_index* ix);
 cobs_gpu_status cobs_gpu_info(const cobs_gpu_index* ix, size_t file_no, cobs_gpu_index_info* info);
@@ -137,6 +152,9 @@ uint64_t cobs_gpu_local_counts(const cobs_gpu_index* ix);
 cobs_gpu_status cobs_gpu_read_row(const cobs_gpu_index* ix, size_t file_no, uint32_t page,
                                   uint64_t row, uint8_t* out, size_t n);
 
+/* row bytes [*col0, *col0 + *ncols) of sub-index `page` that this shard holds (0, 0 if none) */
+cobs_gpu_status cobs_gpu_page_columns(const cobs_gpu_index* ix, size_t file_no, uint32_t page,
+                                      uint64_t* col0, uint64_t* ncols);
 /* the valid bytes of rows [row0, row0+nrows) of a held sub-index, out_pitch bytes apart */
 cobs_gpu_status cobs_gpu_read_rows(const cobs_gpu_index* ix, size_t file_no, uint32_t page,
                                    uint64_t row0, uint64_t nrows, uint8_t* out, size_t out_pitch);
@@ -245,6 +263,46 @@ cobs_gpu_status cobs_gpu_batch_stats(const cobs_gpu_batch* b, uint64_t out[4]);
  * runs since the previous call (at most the last 64); events are recorded on the
  * stream the kernels were launched on.  Call after cobs_gpu_batch_sync. */
 cobs_gpu_status cobs_gpu_batch_kernel_ms(cobs_gpu_batch* b, float* scan_ms, float* hash_ms);
+
+/* ---- multi-GPU: index sharded by sub-index block, one exchange per batch over RCCL / xGMI ----
+ * (the shard boundary is the reference's own: sub-indexes cover disjoint document
+ * ranges, compact_index/mmap_search_file.cpp:22-27, search_file.cpp:30-32.)  One rank = one GPU =
+ * one cobs_gpu_index opened with shard_rank / shard_count = its rank / the communicator size.
+ * The launcher (torch.distributed, MPI, threads of one process...) only has to hand the unique id
+ * from rank 0 to the others.  All calls below are collective: every rank makes the same call.  */
+#define COBS_GPU_UNIQUE_ID_BYTES 128
+cobs_gpu_status cobs_gpu_comm_unique_id(uint8_t id[COBS_GPU_UNIQUE_ID_BYTES]);          /* ncclGetUniqueId */
+cobs_gpu_status cobs_gpu_comm_create(const uint8_t id[COBS_GPU_UNIQUE_ID_BYTES], int rank, int nranks,
+                                     int device /* -1 = current */, cobs_gpu_comm** out);  /* ncclCommInitRank */
+void cobs_gpu_comm_destroy(cobs_gpu_comm* c);
+int cobs_gpu_comm_rank(const cobs_gpu_comm* c);     /* ncclCommUserRank, -1 on error */
+int cobs_gpu_comm_size(const cobs_gpu_comm* c);     /* ncclCommCount, 0 on error */
+
+typedef enum cobs_gpu_exchange_mode {
+    COBS_GPU_XCHG_ALLGATHER = 0,  /* every rank receives the count slices of all ranks for all queries
+                                     (ncclAllGather when the slices have one size, else grouped send/recv) */
+    COBS_GPU_XCHG_ALLTOALL = 1    /* rank j receives the slices of the queries [nq*j/N, nq*(j+1)/N) only:
+                                     every count crosses the fabric once (grouped ncclSend / ncclRecv)      */
+} cobs_gpu_exchange_mode;
+/* After cobs_gpu_batch_run on every rank: exchange the per-document counts of the shards on
+ * `hip_stream` (asynchronous, ordered after the scan) and assemble rows in global document order. */
+cobs_gpu_status cobs_gpu_batch_exchange_counts(cobs_gpu_batch* b, cobs_gpu_comm* c, uint32_t mode, void* hip_stream);
+/* The assembled rows of queries [*q_begin, *q_begin + *q_count): cobs_gpu_total_counts() elements of
+ * *elem_bytes each, *row_stride_bytes apart.  NULL before an exchange.  Valid until the next run. */
+void* cobs_gpu_batch_global_counts_device(cobs_gpu_batch* b, uint64_t* q_begin, uint64_t* q_count,
+                                          uint32_t* elem_bytes, uint64_t* row_stride_bytes);
+/* bytes this rank received from other ranks in the last exchange */
+uint64_t cobs_gpu_batch_exchange_bytes(const cobs_gpu_batch* b);
+/* After a synced run with a threshold: gather the selected (query, file, doc, score) records of all
+ * shards (sizes first, then the records); cobs_gpu_batch_hits_host then returns global results.
+ * *overflow = 1 if a shard's pool overflowed (lists incomplete on every rank: rerun with score rows). */
+cobs_gpu_status cobs_gpu_batch_exchange_hits(cobs_gpu_batch* b, cobs_gpu_comm* c, void* hip_stream, int* overflow);
+/* After a run with num_results > 0: all-gather the k best documents of every shard. */
+cobs_gpu_status cobs_gpu_batch_exchange_topk(cobs_gpu_batch* b, cobs_gpu_comm* c, void* hip_stream);
+/* cobs_gpu_search_batch over the sharded index: same arguments and result on every rank. */
+cobs_gpu_status cobs_gpu_sharded_search_batch(cobs_gpu_index* ix, cobs_gpu_comm* c, const char* const* queries,
+                                              const size_t* lens, size_t nq, double threshold, size_t num_results,
+                                              cobs_gpu_hit* hits, size_t cap, size_t* hit_offsets, size_t* bad_query);
 
 /* phase timers of the host-buffer search API since the last reset, seconds:
  * out[0] hashes (K1), out[1] h2d, out[2] scan (K2), out[3] d2h, out[4] rank  */

@@ -47,14 +47,18 @@ def main():
                                   num_hashes=cfg.get("num_hashes", 1))
     b = cobs_amd.Batch(s)
     b.set_queries(bench.make_queries(nq, kmers))
+    # a config is a comma-separated list of per-handle tuning keys: waves=2,tile_w=16,mq=1
+    # (the old COBS_GPU_* spellings are accepted too)
+    alias = {"COBS_GPU_WAVES": "waves", "COBS_GPU_TILE_W": "tile_w", "COBS_GPU_MQ": "mq"}
+    configs = [{alias.get(k, k): v for k, v in c.items()} for c in configs]
     keys = sorted({k for c in configs for k in c})
     times = [[] for _ in configs]
     for rnd in range(7):
         for ci, c in enumerate(configs):
             for k in keys:
-                os.environ.pop(k, None)
+                s.set_tuning(k, -1 if k == "mq" else 0)
             for k, v in c.items():
-                os.environ[k] = v
+                s.set_tuning(k, int(v))
             for _ in range(3):
                 b.run(0.0)
             b.sync()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """scripts/e2e_pipe.py -- host-buffer API on the C3 batch with and without pipelined passes
-(COBS_GPU_PIPE_CHARS = 0 disables the cut into four passes)."""
+(tuning key pipe_chars = 0 disables the cut into four passes)."""
 import os
 import sys
 import time
@@ -14,7 +14,7 @@ qs = bench.make_queries(10000, 1000)
 import numpy as np
 text = np.frombuffer(b"".join(qs), dtype=np.uint8); offs = np.arange(10001, dtype=np.uint64) * np.uint64(1030)
 for pc in ("0", "4194304"):
-    os.environ["COBS_GPU_PIPE_CHARS"] = pc
+    s.set_tuning("pipe_chars", int(pc))
     for t, lim in ((0.8, 0), (0.0, 10)):
         s.search_packed(text, offs, t, lim)
         ts = []

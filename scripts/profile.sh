@@ -4,11 +4,13 @@
 # judged get copied into profiles/ by scripts/collect_profiles.py.
 set -u
 TAG=${1:-r01}
+shift || true
+EXTRA="$*"     # extra bench.py arguments (shape under the profiler)
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --no-cpu-baseline --steps 5 --warmup 2"
+BENCH="python $REPO/bench.py --no-cpu-baseline --steps 5 --warmup 2 $EXTRA"
 cd /tmp
 # 1) kernel trace + stats (per-kernel durations)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- $BENCH > "$OUT/trace.log" 2>&1

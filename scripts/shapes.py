@@ -19,8 +19,10 @@ def geo(lo, hi, n):
     return [int(lo * r ** i) for i in range(n)]
 
 
-def run(name, kind, sigs, ndocs, page_size, nq, kmers, H=1, steps=5):
+def run(name, kind, sigs, ndocs, page_size, nq, kmers, H=1, steps=5, tuning=None):
     s = cobs_amd.Search.synthetic(kind, sigs, ndocs, page_size=page_size, num_hashes=H, seed=1)
+    for k, v in (tuning or {}).items():
+        s.set_tuning(k, v)
     qs = bench.make_queries(nq, kmers)
     b = cobs_amd.Batch(s)
     b.set_queries(qs)
@@ -79,17 +81,12 @@ if __name__ == "__main__":
             run("8 x S=%dk T=%d Q=%dk (R=%d)" % (4000 // R, 1000 // R, 10 * R, R), "compact",
                 [4000000 // R] * 8, 100000, 1568, 10000 * R, 1000 // R)
     if on("mq"):
-        # multi-query work-groups vs the default geometry (COBS_GPU_MQ / _TILE_W / _WAVES are read per run)
+        # multi-query work-groups vs the default geometry (per-handle tuning keys mq / tile_w / waves)
         c3 = bench.c3_config()["signature_sizes"]
         for T, nq in ((20, 40000), (70, 40000), (120, 40000), (220, 40000), (500, 20000), (1000, 10000)):
             for mq, w, nw in ((0, 0, 0), (1, 8, 1), (1, 8, 2), (1, 8, 4), (1, 16, 1), (1, 16, 2), (1, 16, 4), (1, 32, 2)):
-                os.environ["COBS_GPU_MQ"] = str(mq)
-                for k, v in (("COBS_GPU_TILE_W", w), ("COBS_GPU_WAVES", nw)):
-                    if v:
-                        os.environ[k] = str(v)
-                    else:
-                        os.environ.pop(k, None)
-                run("C3 T=%d Q=%dk mq=%d W=%d NW=%d" % (T, nq // 1000, mq, w, nw), "compact", c3, 100000, 1568, nq, T, steps=3)
+                run("C3 T=%d Q=%dk mq=%d W=%d NW=%d" % (T, nq // 1000, mq, w, nw), "compact", c3, 100000, 1568, nq, T, steps=3,
+                    tuning={"mq": mq, "tile_w": w, "waves": nw})
     if on("ssweep"):
         # throughput vs slice working set at a fixed query length: 8 equal sub-indexes of S rows
         for S in (8000000, 4000000, 2000000, 1000000, 500000, 250000, 125000, 62500):

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), "libcobs_gpu.so does not export " + n
         assert n in _capi.SYMBOLS, "cobs_amd/_capi.py does not bind " + n
     assert sorted(_capi.SYMBOLS) == names
-    assert lib.cobs_gpu_abi_version() == 1
+    assert lib.cobs_gpu_abi_version() == 2
 
 
 def test_struct_layouts_match_header():

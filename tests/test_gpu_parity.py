@@ -308,7 +308,7 @@ def test_large_host_batch_is_cut_into_passes(gpu_lib, oracle, tmp_path, monkeypa
     s = gpu_lib.Search(p)
     ix = oracle.Index.open(p)
     queries = [q_long[i:i + 60 + 7 * (i % 5)] for i in range(40)]
-    monkeypatch.setenv("COBS_GPU_PASS_BYTES", str(5 * s.local_counts))           # 5 queries (one-byte scores) per pass
+    s.set_tuning("pass_bytes", 5 * s.local_counts)           # 5 queries (one-byte scores) per pass
     for t, lim in ((0.0, 0), (0.3, 4), (0.0, 3)):
         got = s.search_hits(queries, t, lim)
         assert got == [cases.oracle_results([ix], q, t, lim) for q in queries]

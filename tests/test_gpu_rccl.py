@@ -1,0 +1,131 @@
+"""GPU: the native multi-GPU path of libcobs_gpu.so (cobs_amd/csrc/comm.cpp).
+
+A one-GPU box can only host a ONE-rank RCCL communicator (RCCL refuses two ranks on one
+device), but that runs the very code an 8-GPU node runs: ncclGetUniqueId / ncclCommInitRank,
+the layout all-gather, ncclAllGather of the count slices typed as bytes, the strided assembly
+into global rows, the sizes-first hit exchange, the top-k gather and
+cobs_gpu_sharded_search_batch.  The N > 1 arithmetic (slot layouts of byte-balanced shards,
+assembly, merge order) is covered on the same GPU by opening every shard in turn, and across
+processes by tests/test_gpu_sharded.py / tests/test_distributed_cpu.py."""
+import numpy as np
+import pytest
+import torch
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def comm(gpu_lib):
+    from cobs_amd.distributed import Comm
+    c = Comm(Comm.unique_id(), 0, 1, device=0)
+    assert c.size == 1 and c.rank == 0             # ncclCommCount / ncclCommUserRank
+    yield c
+    c.close()
+
+
+def _files(oracle, tmp_path):
+    q_long = oracle.random_sequence(500, 17)
+    pa = cases.make_compact(cases.tmp(tmp_path, "s.cobs_compact"), 2400, 64, [900, 1000, 1100, 1200, 1300], 1, 31, 1,
+                            0.3, 3, planted={5: 1.0, 700: 0.9, 1500: 0.6, 2300: 0.97}, query=q_long)
+    pb = cases.make_classic(cases.tmp(tmp_path, "s.cobs_classic"), 1000, 1501, 2, 31, 1, 0.3, 4,
+                            planted={9: 1.0, 990: 0.8}, query=q_long)
+    return [pa, pb], [q_long, q_long[:31], q_long[:250], q_long[100:340], q_long[7:60]]
+
+
+def test_one_rank_exchange_is_the_real_collective(gpu_lib, oracle, tmp_path, comm):
+    from cobs_amd import _capi
+    paths, queries = _files(oracle, tmp_path)
+    ixs = [oracle.Index.open(p) for p in paths]
+    want = np.stack([np.concatenate([ix.counts(q) for ix in ixs]) for q in queries])
+    s = gpu_lib.Search(paths, device=0, shard_rank=0, shard_count=1)
+    b = gpu_lib.Batch(s)
+    b.set_queries(queries)
+    for mode in (_capi.XCHG_ALLGATHER, _capi.XCHG_ALLTOALL):
+        b.run(0.0)
+        b.exchange_counts(comm, mode)
+        b.sync()
+        q0, qn, t = b.global_counts_tensor()
+        assert (q0, qn) == (0, len(queries))
+        assert np.array_equal(t.cpu().numpy().astype(np.int64) & 0xFFFF, want)
+        assert b.exchange_bytes() == 0               # nothing crosses the fabric on one rank
+        for i in range(len(queries)):                # host readers follow the global view
+            assert np.array_equal(b.counts_host(i), want[i])
+            assert b.hits_host(i, 4) == cases.oracle_results(ixs, queries[i], 0.0, 4)
+    # hit lists (sizes first) and top-k candidates
+    b.run(0.3)
+    b.sync()
+    assert b.exchange_hits(comm) is False
+    for i, q in enumerate(queries):
+        assert b.hits_host(i, 0) == cases.oracle_results(ixs, q, 0.3, 0)
+    b.run_topk(0.0, 6)
+    b.sync()
+    b.exchange_topk(comm)
+    for i, q in enumerate(queries):
+        assert b.hits_host(i, 6) == cases.oracle_results(ixs, q, 0.0, 6)
+
+
+def test_sharded_search_batch_one_rank(gpu_lib, oracle, tmp_path, comm):
+    paths, queries = _files(oracle, tmp_path)
+    ixs = [oracle.Index.open(p) for p in paths]
+    s = gpu_lib.Search(paths, device=0)
+    for t, lim in ((0.0, 0), (0.3, 0), (0.3, 4), (0.0, 6), (0.95, 0)):
+        got = s.sharded_search_hits(comm, queries, t, lim)
+        assert got == [cases.oracle_results(ixs, q, t, lim) for q in queries], (t, lim)
+    # bad input is reported with the query's index, as in the single-GPU call
+    from cobs_amd import _capi
+    bad = list(queries)
+    bad[2] = bad[2][:40] + b"N" + bad[2][41:]
+    with pytest.raises(gpu_lib.CobsGpuError) as e:
+        s.sharded_search_hits(comm, bad, 0.0, 3)
+    assert e.value.status == _capi.ERR_INVALID_BASE and "(query 2)" in str(e.value)
+    # pass cut by the workspace limit
+    s.set_tuning("pass_bytes", 2 * (s.local_counts + s.total_counts))
+    assert s.sharded_search_hits(comm, queries, 0.0, 0) == [cases.oracle_results(ixs, q, 0.0, 0) for q in queries]
+
+
+def test_streamed_shard_under_a_budget(gpu_lib, oracle, tmp_path, comm):
+    """BASELINE configs[4]: sharding x out-of-core streaming -- the shard does not fit its HBM
+    budget, chunks are streamed, the exchange sees the same slices"""
+    paths, queries = _files(oracle, tmp_path)
+    ixs = [oracle.Index.open(p) for p in paths]
+    s = gpu_lib.Search(paths, device=0, hbm_budget=260 * 1024)        # the 0.5 MB compact file is streamed
+    assert s.info(0).hbm_bytes <= 260 * 1024
+    for t, lim in ((0.0, 0), (0.3, 0), (0.0, 5)):
+        assert s.sharded_search_hits(comm, queries, t, lim) == [cases.oracle_results(ixs, q, t, lim) for q in queries]
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("budget", [0, 200 * 1024])
+def test_byte_balanced_shards_assemble_to_the_whole(gpu_lib, oracle, tmp_path, mode, budget):
+    """every shard of 2..5 (cuts inside sub-indexes in mode 0) computes exactly its slot range;
+    their concatenation is the oracle's vector.  With a budget every shard also streams."""
+    q = oracle.random_sequence(500, 3)
+    ratio = 16.0 ** (1.0 / 7.0)
+    pc = cases.make_compact(cases.tmp(tmp_path, "sh.cobs_compact"), 8 * 8 * 48 - 9, 48,
+                            [int(150 * ratio ** p) for p in range(8)], 2, 31, 1, 0.3, 8)
+    pk = cases.make_classic(cases.tmp(tmp_path, "sh.cobs_classic"), 3000, 1999, 1, 31, 1, 0.3, 9)
+    for p in (pc, pk):
+        want = oracle.Index.open(p).counts(q)
+        for n in (2, 3, 5):
+            total = np.zeros_like(want)
+            covered = 0
+            for r in range(n):
+                s = gpu_lib.Search(p, shard_rank=r, shard_count=n, shard_mode=mode, hbm_budget=budget)
+                c = s.counts(q)
+                i = s.info(0)
+                outside = np.ones(len(c), dtype=bool)
+                outside[i.slot_begin:i.slot_begin + i.slot_count] = False
+                assert not c[outside].any()
+                assert i.slot_begin == covered or i.slot_count == 0
+                covered += i.slot_count
+                total += c
+                # hits of the shard's own documents, selected on the device
+                if i.slot_count:
+                    got = s.search_hits([q], 0.31, 0)[0]
+                    ref = [h for h in cases.oracle_results([oracle.Index.open(p)], q, 0.31, 0)
+                           if i.slot_begin <= h[1] < i.slot_begin + i.slot_count]
+                    assert got == ref
+            assert covered == len(want)
+            assert np.array_equal(total, want)

@@ -1,0 +1,102 @@
+"""CPU: the shard planner of libcobs_gpu.so (cobs_gpu_plan_shards, host only) and the header
+parser's defences.  A compact index is a concatenation of sub-indexes over disjoint document
+ranges (reference cobs/query/compact_index/mmap_search_file.cpp:22-27, search_file.cpp:30-32);
+shards are contiguous score-slot ranges that are disjoint, ascending and cover counts_size --
+whatever the shard count and mode."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from tests import cases
+
+
+def _plan(path, n, mode=0):
+    from cobs_amd import _capi
+    lib = _capi.load()
+    b = (C.c_uint64 * n)()
+    c = (C.c_uint64 * n)()
+    by = (C.c_uint64 * n)()
+    _capi.check(lib.cobs_gpu_plan_shards(os.fsencode(path), n, mode, b, c, by))
+    return list(b), list(c), list(by)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_shards_are_a_partition_of_the_score_slots(oracle, tmp_path, golden_dir, mode):
+    pc = cases.make_compact(cases.tmp(tmp_path, "p.cobs_compact"), 700, 16, [800, 900, 1000, 1100, 1200, 1300], 2)
+    pk = cases.make_classic(cases.tmp(tmp_path, "p.cobs_classic"), 3000, 1999, 1)
+    pw = cases.make_compact(cases.tmp(tmp_path, "w.cobs_compact"), 5000, 200, [300, 5000, 700, 9000], 1)
+    for p in (pc, pk, pw, os.path.join(golden_dir, "c1.cobs_compact"), os.path.join(golden_dir, "c1.cobs_classic")):
+        ix = oracle.Index.open(p)
+        for n in (1, 2, 3, 4, 7, 8, 16, 61):
+            begin, count, _ = _plan(p, n, mode)
+            pos = 0
+            for r in range(n):
+                if count[r] == 0:
+                    continue
+                assert begin[r] == pos and begin[r] % 8 == 0 and count[r] % 8 == 0, (p, n, r)
+                pos += count[r]
+            assert pos == ix.counts_size, (p, n)
+
+
+def test_balanced_mode_equalises_bytes_not_sub_index_counts(oracle, tmp_path):
+    """sub-indexes whose sizes differ 16x (the shape of BASELINE configs[2]): whole sub-indexes
+    per shard leave the largest shard with a third of the bytes, byte-balanced cuts do not"""
+    ratio = 16.0 ** (1.0 / 7.0)
+    sigs = [int(300 * ratio ** p) for p in range(8)]
+    p = cases.make_compact(cases.tmp(tmp_path, "b.cobs_compact"), 8 * 8 * 160 - 5, 160, sigs, 1)
+    total = sum(s * 160 for s in sigs)
+    for n in (2, 4, 8):
+        _, _, by0 = _plan(p, n, 0)
+        _, _, by1 = _plan(p, n, 1)
+        assert max(by0) <= 1.25 * total / n + 4096 * n            # pitch padding and zero rows aside
+        if n == 8:
+            assert max(by1) >= 2.5 * total / n
+    # many small sub-indexes: cuts snap to sub-index boundaries (whole sub-indexes only)
+    p2 = cases.make_compact(cases.tmp(tmp_path, "m.cobs_compact"), 100 * 8 * 16 - 3, 16, [50 + 3 * i for i in range(100)], 1)
+    begin, count, _ = _plan(p2, 4, 0)
+    assert all(b % (8 * 16) == 0 for b in begin)
+
+
+def _classic_header(ndocs, sig, nh=1, names=None):
+    h = b"COBS:CLASSIC_INDEX" + struct.pack("<IIBIQQ", 1, 31, 1, ndocs, sig, nh)
+    for i in range(ndocs if names is None else names):
+        h += b"d%d\n" % i
+    return h + b"CLASSIC_INDEX"
+
+
+def _compact_header(ndocs, page_size, params, names=None):
+    h = b"COBS:COMPACT_INDEX" + struct.pack("<IIBIIQ", 1, 31, 1, len(params), ndocs, page_size)
+    for s, nh in params:
+        h += struct.pack("<QQ", s, nh)
+    for i in range(ndocs if names is None else names):
+        h += b"d%d\n" % i
+    pad = (page_size - ((len(h) + 13) % page_size)) % page_size if page_size < (1 << 20) else 0
+    return h + b"\0" * pad + b"COMPACT_INDEX"
+
+
+def test_crafted_headers_are_rejected_not_trusted(tmp_path):
+    """signature_size / page_size / document counts that wrap 64-bit arithmetic or promise more
+    than the file holds must be a format error at open, on the host, before any allocation
+    (reference headers are trusted PODs: cobs/file/compact_index_header.cpp:45-65)"""
+    import cobs_amd
+    from cobs_amd import _capi
+    bad = {
+        "wrap_mul": _compact_header(8, 1 << 20, [(1 << 44, 1)]),                  # page_size * signature_size = 2^64
+        "wrap_sum": _compact_header(8, 16, [((1 << 60) + 1, 1)] * 16),
+        "huge_sig": _classic_header(8, (1 << 63) + 5),
+        "ndocs_lie": _classic_header(0xFFFFFFF0, 100, names=3),
+        "nparams_lie": b"COBS:COMPACT_INDEX" + struct.pack("<IIBIIQ", 1, 31, 1, 0xFFFFFFF0, 8, 16),
+        "page_size_huge": _compact_header(8, 1 << 40, [(100, 1)]),
+    }
+    for name, raw in bad.items():
+        p = tmp_path / (name + ".cobs")
+        p.write_bytes(raw + b"\0" * 64)
+        with pytest.raises(cobs_amd.CobsGpuError) as e:
+            cobs_amd.Search(str(p))
+        assert e.value.status == _capi.ERR_FORMAT, (name, e.value)
+        b = (C.c_uint64 * 2)()
+        c = (C.c_uint64 * 2)()
+        assert _capi.load().cobs_gpu_plan_shards(os.fsencode(str(p)), 2, 0, b, c, None) == _capi.ERR_FORMAT, name
