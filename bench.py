@@ -120,12 +120,16 @@ def cpu_baseline(search, cfg, queries, seconds_target=12.0, check_queries=4, bat
     # documents) is reported next to it.
     out = {}
     ncores = os.cpu_count() or 1
-    share = seconds_target / 3
+    share = seconds_target / 4
     for threads in (1, min(ncores, 8)):
         O.timers(reset=True)
         n, dt = O.search_many(ix, queries, -1.0, 0, threads=threads, seconds=share)
         out[threads] = (n / dt, n, dt, O.timers())
     n_full, dt_full = O.search_many(ix, queries, 0.0, 0, threads=1, seconds=share)
+    # all cores, the way a throughput-oriented caller would use the reference's algorithm:
+    # independent queries on independent threads (each query single-threaded)
+    n_all, dt_all = O.search_many_parallel(ix, queries, ncores, -1.0, 0, seconds=share)
+    qps_all = n_all / dt_all
     qps1, n1, dt1, tm1 = out[1]
     tmax = max(out)
     T = len(queries[0]) - cfg["term_size"] + 1
@@ -136,17 +140,21 @@ def cpu_baseline(search, cfg, queries, seconds_target=12.0, check_queries=4, bat
     qpsm, nm, dtm, _ = out[tmax]
     best_threads = tmax if qpsm >= qps1 else 1
     qpsb, nb, dtb = (qpsm, nm, dtm) if best_threads == tmax else (qps1, n1, dt1)
+    how = "%d thread(s) over the document batches of one query, as the reference parallelises" % best_threads
+    if qps_all > qpsb:
+        qpsb, nb, dtb, best_threads = qps_all, n_all, dt_all, min(ncores, len(queries))
+        how = "%d threads, one query per thread (all host cores)" % best_threads
     res = {"value": round(qpsb, 2), "unit": "queries/s", "cores": best_threads, "kind": "port",
            "sample": "%d of the batch's queries, per-document counts (same step as the GPU: hash + "
-                     "gather + AND + expand-add), %d thread(s) over document batches as the reference "
-                     "does, %.1f s; %s; index resident in host RAM"
-                     % (nb, best_threads, dtb, sample),
+                     "gather + AND + expand-add), %s, %.1f s; %s; index resident in host RAM"
+                     % (nb, how, dtb, sample),
            "kmer_lookups_per_s": round(qpsb * T, 1),
            "gathered_GBps": round(qpsb * gathered / 1e9, 3),
            "phase_seconds_1thread": {k: round(v, 3) for k, v in tm1.items()},
            "host_cores": ncores,
            "threads_1": {"value": round(qps1, 2), "queries": n1},
-           "threads_%d" % tmax: {"value": round(qpsm, 2), "queries": nm},
+           "threads_%d_over_document_batches" % tmax: {"value": round(qpsm, 2), "queries": nm},
+           "all_cores_one_query_per_thread": {"value": round(qps_all, 2), "queries": n_all, "threads": min(ncores, len(queries))},
            "full_search_with_ranking_1thread": {"value": round(n_full / dt_full, 2), "queries": n_full},
            "bit_exact_vs_gpu": bit_exact}
     return res
@@ -186,36 +194,105 @@ def end_to_end(search, batch, queries):
     return res
 
 
-def sharded_setup(s, queries, world, nsub, threshold):
-    """--shard-mode index: the batch is cut into sub-batches so that the all-gather of sub-batch i
-    (RCCL's own stream, xGMI) overlaps the scan of sub-batch i+1 (the stream the kernels are on).
-    RCCL has no 16-bit integer type: the count slices travel as bytes.  -> (step, sub-batches)"""
-    sub, gathered = [], []
-    nsub = max(1, min(nsub, len(queries)))
-    for i in range(nsub):
-        bi = cobs_amd.Batch(s)
-        bi.set_queries(queries[i * len(queries) // nsub:(i + 1) * len(queries) // nsub])
-        sub.append(bi)
-        local = bi.counts_tensor().view(torch.uint8).reshape(-1)
-        gathered.append(torch.empty((world * local.numel(),), dtype=torch.uint8, device="cuda"))
-
-    def step():
-        works = []
-        for bi, out in zip(sub, gathered):
-            bi.run(threshold, 0)
-            # per-document hit counts of the disjoint sub-index blocks -> every rank
-            works.append(dist.all_gather_into_tensor(out, bi.counts_tensor().view(torch.uint8).reshape(-1),
-                                                     async_op=True))
-        for w in works:
-            w.wait()
-    return step, sub, gathered
+def kernels_hash():
+    """identifies the kernel source a profile belongs to (the GPU box has no .git)"""
+    import hashlib
+    h = hashlib.sha256()
+    for fn in ("kernels.hip", "engine.cpp"):
+        with open(os.path.join(ROOT, "cobs_amd", "csrc", fn), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
-def timed(step, steps, warmup, world, backend):
+def make_index(cfg, dev, rank=0, world=1, hbm_budget=0, path=None):
+    if path:
+        return cobs_amd.Search(path, device=dev, shard_rank=rank, shard_count=world, hbm_budget=hbm_budget)
+    return cobs_amd.Search.synthetic(cfg["kind"], cfg["signature_sizes"], cfg["num_docs"],
+                                     page_size=cfg["page_size"], term_size=cfg["term_size"],
+                                     canonicalize=cfg["canonicalize"], num_hashes=cfg["num_hashes"],
+                                     seed=cfg["seed"], device=dev, shard_rank=rank, shard_count=world,
+                                     hbm_budget=hbm_budget)
+
+
+class ShardedRun:
+    """north_star's multi-GPU layout: the index sharded by sub-index block over the ranks
+    (byte-balanced: a cut may fall inside a sub-index), ONE query batch shared by all ranks,
+    every rank scans its slice for the whole batch, then one exchange of the per-document counts
+    over RCCL / xGMI inside libcobs_gpu.so (comm.cpp).  mode ALLTOALL: rank j ends up with the
+    complete count rows (global document order) of the queries [nq*j/N, nq*(j+1)/N) -- every
+    count crosses the fabric once; ALLGATHER: every rank ends up with every row.
+    nsub > 1: the batch is cut into sub-batches, the exchange of sub-batch i (own stream)
+    overlaps the scan of sub-batch i+1.  --dist-backend gloo (several ranks on ONE GPU, smoke
+    tests only) uses the torch.distributed restatement of the same exchange."""
+
+    def __init__(self, cfg, queries, world, rank, dev, comm, nsub=1, threshold=0.0, mode=None, hbm_budget=0,
+                 path=None, backend="nccl"):
+        from cobs_amd import _capi
+        self.world, self.rank, self.comm, self.backend = world, rank, comm, backend
+        self.mode = _capi.XCHG_ALLTOALL if mode is None else mode
+        self.threshold = threshold
+        self.s = make_index(cfg, dev, rank, world, hbm_budget, path)
+        nsub = max(1, min(nsub, len(queries)))
+        self.sub = []
+        for i in range(nsub):
+            bi = cobs_amd.Batch(self.s)
+            bi.set_queries(queries[i * len(queries) // nsub:(i + 1) * len(queries) // nsub])
+            self.sub.append(bi)
+        self.overlap = nsub > 1 and comm is not None
+        if self.overlap:
+            self.scan_stream, self.x_stream = torch.cuda.Stream(), torch.cuda.Stream()
+            self.events = [torch.cuda.Event() for _ in self.sub]
+        self.moved = 0
+
+    def step(self):
+        if self.comm is None:                       # gloo smoke path
+            from cobs_amd.distributed import all_gather_counts
+            for bi in self.sub:
+                bi.run(self.threshold, 0)
+                parts = all_gather_counts(bi.counts_tensor(), None)
+                self.moved = sum(int(t.numel()) * t.element_size() for t in parts[:self.rank] + parts[self.rank + 1:])
+            return
+        if not self.overlap:
+            for bi in self.sub:
+                bi.run(self.threshold, 0)
+                bi.exchange_counts(self.comm, self.mode, 0)
+            return
+        cur = torch.cuda.current_stream()
+        self.scan_stream.wait_stream(cur)
+        self.x_stream.wait_stream(cur)
+        for bi, ev in zip(self.sub, self.events):
+            bi.run(self.threshold, self.scan_stream.cuda_stream)
+            ev.record(self.scan_stream)
+            self.x_stream.wait_event(ev)
+            bi.exchange_counts(self.comm, self.mode, self.x_stream.cuda_stream)
+        cur.wait_stream(self.scan_stream)
+        cur.wait_stream(self.x_stream)
+
+    def finish(self):
+        """-> per step on this rank: (scan ms, hash ms, algorithmic bytes, bytes received), summed over sub-batches"""
+        scan = hsh = algo = moved = 0
+        for bi in self.sub:
+            bi.sync(self.scan_stream.cuda_stream if self.overlap else 0)
+            ms = bi.kernel_ms()
+            scan += ms["scan_ms"]
+            hsh += ms["hash_ms"]
+            algo += bi.stats()["algorithmic_bytes"]
+            moved += bi.exchange_bytes() if self.comm is not None else self.moved
+        return scan, hsh, algo, moved
+
+    def drop_warmup_events(self):
+        for bi in self.sub:
+            bi.sync(self.scan_stream.cuda_stream if self.overlap else 0)
+            bi.kernel_ms()
+
+
+def timed(step, steps, warmup, world, backend, after_warmup=None):
     """the bench contract's timing: warm-up, barrier + synchronize on both sides, max over ranks"""
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
+    if after_warmup:
+        after_warmup()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -233,98 +310,113 @@ def timed(step, steps, warmup, world, backend):
     return dt
 
 
-def sharded_extra(args, cfg, world, rank, dev):
-    """N > 1, after the headline (replicated) measurement: the same 10k-query batch against the
-    index SHARDED by sub-index block over the ranks, per-document counts all-gathered over
-    RCCL/xGMI (north_star's multi-GPU layout; strong scaling).  Every rank must agree that its
-    set-up succeeded before the first collective, so a local failure cannot strand the others."""
-    ok, err, state = 1, "", None
-    try:
-        s = cobs_amd.Search.synthetic(cfg["kind"], cfg["signature_sizes"], cfg["num_docs"],
-                                      page_size=cfg["page_size"], term_size=cfg["term_size"],
-                                      canonicalize=cfg["canonicalize"], num_hashes=cfg["num_hashes"],
-                                      seed=cfg["seed"], device=dev, shard_rank=rank, shard_count=world)
-        queries = make_queries(args.queries, args.kmers)            # the same batch on every rank
-        step, sub, gathered = sharded_setup(s, queries, world, args.exchange_chunks, args.threshold)
-        state = (s, sub, gathered)
-    except Exception as e:                                          # noqa: BLE001
-        ok, err = 0, repr(e)
-    # all_gather_into_tensor needs equal slices: 8 sub-indexes over 2, 4 or 8 ranks are; anything else is skipped
-    n_local = int(state[2][0].numel()) // world if ok else 0
-    flag = torch.tensor([ok, n_local, -n_local], dtype=torch.int64,
-                        device="cuda" if args.dist_backend == "nccl" else "cpu")
+def all_ranks_ok(ok, backend):
+    """every rank must agree that its set-up succeeded before the next collective, so that a
+    local failure (out of memory, ...) cannot strand the others inside RCCL"""
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    if int(flag[0].item()) == 0:
-        return {"skipped": err or "set-up failed on another rank"}
-    if int(flag[1].item()) != -int(flag[2].item()):
-        return {"skipped": "ranks hold count slices of different sizes"}
-    steps = max(1, min(args.steps, 5))
-    dt = timed(step, steps, 1, world, args.dist_backend)
-    for bi in sub:
-        bi.sync()
-    scan_ms = sum(bi.kernel_ms()["scan_ms"] for bi in sub)
-    payload = sum(int(g.numel()) for g in gathered)
-    # the production form of the same layout: with a threshold only hits leave a shard, so the
-    # exchange shrinks to the hit lists (none on random data at 0.8, like the reference's own
-    # benchmark); what remains is every rank scanning its sub-index block for the whole batch
-    whole = cobs_amd.Batch(s)
-    whole.set_queries(queries)
-    token = torch.zeros(1, dtype=torch.int64, device="cuda" if args.dist_backend == "nccl" else "cpu")
-
-    def hits_step():
-        whole.run(0.8, 0)
-        dist.all_reduce(token, op=dist.ReduceOp.SUM)         # stands for the (empty) hit-list exchange
-
-    dth = timed(hits_step, steps, 1, world, args.dist_backend)
-    whole.sync()
-    hits_scan_ms = whole.kernel_ms()["scan_ms"]
-    del whole, state
-    return {"queries_per_s": round(args.queries * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
-            "steps": steps, "scaling": "strong", "scan_ms_per_step_rank0": round(scan_ms, 4),
-            "gathered_bytes_per_step": payload,
-            "hits_mode_threshold_0.8": {"queries_per_s": round(args.queries * steps / dth, 1),
-                                        "ms_per_step": round(dth / steps * 1e3, 3),
-                                        "scan_ms_per_step_rank0": round(hits_scan_ms, 4)},
-            "parallelism": "index sharded by sub-index block x%d, %d sub-batches, async RCCL all-gather of the "
-                           "count slices overlapped with the next scan" % (world, len(sub))}
+    return int(flag.item()) == 1
 
 
-def sharded_c4_extra(args, world, rank, dev):
-    """N > 1: BASELINE configs[3] -- the 1M-document compact index (245 sub-indexes) sharded by
-    sub-index block over the ranks, one 1000-query batch, per-document counts of the (unequal)
-    blocks all-gathered over RCCL/xGMI (padded to the largest block)."""
-    from cobs_amd.distributed import all_gather_counts
-    cfg = c4_config(args.scale)
-    nq = 1000
-    ok, err, b = 1, "", None
-    try:
-        s = cobs_amd.Search.synthetic(cfg["kind"], cfg["signature_sizes"], cfg["num_docs"],
-                                      page_size=cfg["page_size"], term_size=cfg["term_size"],
-                                      canonicalize=cfg["canonicalize"], num_hashes=cfg["num_hashes"],
-                                      seed=cfg["seed"], device=dev, shard_rank=rank, shard_count=world)
-        b = cobs_amd.Batch(s)
-        b.set_queries(make_queries(nq, args.kmers))
-    except Exception as e:                                          # noqa: BLE001
-        ok, err = 0, repr(e)
-    flag = torch.tensor([ok], dtype=torch.int64, device="cuda" if args.dist_backend == "nccl" else "cpu")
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    if int(flag.item()) == 0:
-        return {"skipped": err or "set-up failed on another rank"}
-    sizes = {}
-
-    def step():
-        b.run(args.threshold, 0)
-        parts = all_gather_counts(b.counts_tensor(), None)
-        sizes["bytes"] = sum(int(t.numel()) * t.element_size() for t in parts)
-
+def side_measurements(args, cfg, queries, world, rank, dev, comm):
+    """N > 1, after the headline: the same job in its other forms, a few steps each (never `value`)."""
+    from cobs_amd import _capi
+    out = {}
     steps = max(1, min(args.steps, 3))
-    dt = timed(step, steps, 1, world, args.dist_backend)
-    b.sync()
-    scan_ms = b.kernel_ms()["scan_ms"]
-    return {"workload": "BASELINE configs[3]: compact index, 1000000 docs, 245 sub-indexes sharded over %d ranks, "
-                        "batch of %d queries x %d k-mers" % (world, nq, args.kmers),
-            "queries_per_s": round(nq * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
-            "scan_ms_per_step_rank0": round(scan_ms, 4), "gathered_bytes_per_step": sizes.get("bytes", 0)}
+    backend = args.dist_backend
+
+    def measure(name, build, describe):
+        run, err = None, ""
+        try:
+            run = build()
+        except Exception as e:                                      # noqa: BLE001
+            err = repr(e)
+        if not all_ranks_ok(run is not None, backend):
+            out[name] = {"skipped": err or "set-up failed on another rank"}
+            return
+        dt = timed(run.step, steps, 1, world, backend, run.drop_warmup_events)
+        scan, _, _, moved = run.finish()
+        out[name] = dict(describe, queries_per_s=round(run.nq_total * steps / dt, 1),
+                         ms_per_step=round(dt / steps * 1e3, 3), steps=steps,
+                         scan_ms_per_step_rank0=round(scan, 4) if scan else None,
+                         received_bytes_per_step_rank0=moved)
+        del run
+        torch.cuda.empty_cache()
+
+    def sharded(nsub, mode, cfg_=cfg, queries_=queries):
+        r = ShardedRun(cfg_, queries_, world, rank, dev, comm, nsub, args.threshold, mode, backend=backend)
+        r.nq_total = len(queries_)
+        return r
+
+    measure("sharded_overlap_2_sub_batches", lambda: sharded(2, _capi.XCHG_ALLTOALL),
+            {"parallelism": "as the headline, batch cut in 2: exchange of sub-batch 1 overlaps the scan of sub-batch 2"})
+    measure("sharded_allgather", lambda: sharded(1, _capi.XCHG_ALLGATHER),
+            {"parallelism": "as the headline, but every rank receives every count row (N-1 times the traffic)"})
+
+    class Replicated:
+        """round 1's headline: index replicated, one batch per rank, no data-path collective (weak scaling)"""
+        def __init__(self):
+            self.s = make_index(cfg, dev)
+            self.b = cobs_amd.Batch(self.s)
+            self.b.set_queries(make_queries(args.queries, args.kmers, seed=42 + rank))
+            self.nq_total = args.queries * world
+        def step(self):
+            self.b.run(args.threshold, 0)
+        def drop_warmup_events(self):
+            self.b.sync()
+            self.b.kernel_ms()
+        def finish(self):
+            self.b.sync()
+            return self.b.kernel_ms()["scan_ms"], 0, 0, 0
+    measure("index_replicated_weak", Replicated,
+            {"parallelism": "index replicated on every GPU, one %d-query batch per GPU, no collective" % args.queries,
+             "scaling": "weak"})
+
+    class HitsMode:
+        """threshold 0.8: the scan keeps no score rows, only hit records leave a shard (sizes first)"""
+        def __init__(self):
+            self.s = make_index(cfg, dev, rank, world)
+            self.b = cobs_amd.Batch(self.s)
+            self.b.set_queries(queries)
+            self.nq_total = len(queries)
+        def step(self):
+            self.b.run_hits(0.8, 0)
+            self.b.sync()
+            if comm is not None:
+                self.b.exchange_hits(comm, 0)
+        def drop_warmup_events(self):
+            self.b.kernel_ms()
+        def finish(self):
+            return self.b.kernel_ms()["scan_ms"], 0, 0, self.b.exchange_bytes() if comm is not None else 0
+    measure("sharded_hits_threshold_0.8", HitsMode,
+            {"parallelism": "sharded as the headline; hits-only scan + sizes-first exchange of hit records"})
+
+    if args.config == "c3" and args.scale == 1.0:
+        c4 = c4_config(args.scale)
+        q4 = make_queries(1000, args.kmers)
+        measure("configs3_1M_docs_sharded", lambda: sharded(1, _capi.XCHG_ALLTOALL, c4, q4),
+                {"workload": "BASELINE configs[3]: compact index, 1000000 docs, 245 sub-indexes (68 GB) sharded over "
+                             "%d ranks, batch of 1000 queries x %d k-mers" % (world, args.kmers)})
+    return out
+
+
+def workload_text(args, cfg):
+    if args.config == "c2":
+        return ("BASELINE configs[1]: synthetic classic index, %d docs x %d rows, batch of %d queries x %d k-mers"
+                % (cfg["num_docs"], cfg["signature_sizes"][0], args.queries, args.kmers))
+    t = ("BASELINE configs[%d]: synthetic compact index, %d docs, %d sub-indexes, page_size %d B, "
+         "S_p %d..%d rows (%.1f GB in HBM), batch of %d queries x %d k-mers, H=%d, threshold %g"
+         % ({"c3": 2, "c4": 3, "c5": 4}[args.config], cfg["num_docs"], len(cfg["signature_sizes"]), cfg["page_size"],
+            cfg["signature_sizes"][0], cfg["signature_sizes"][-1],
+            sum(cfg["signature_sizes"]) * cfg["page_size"] / 1e9,
+            args.queries, args.kmers, cfg["num_hashes"], args.threshold))
+    if args.num_results:
+        t += ", top-%d selected on device" % args.num_results
+    if args.hits_only:
+        t += ", hits only (no score rows)"
+    if args.hbm_budget_gb:
+        t += ", streamed under an HBM budget of %g GB per GPU" % args.hbm_budget_gb
+    return t
 
 
 def main():
@@ -334,24 +426,32 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--queries", type=int, default=10000, help="queries per batch (whole job)")
     ap.add_argument("--kmers", type=int, default=1000)
-    ap.add_argument("--config", choices=["c3", "c2", "c4"], default="c3")
+    ap.add_argument("--config", choices=["c3", "c2", "c4", "c5"], default="c3",
+                    help="c5 = BASELINE configs[4]: the c3 index as a FILE, streamed under --hbm-budget-gb")
     ap.add_argument("--scale", type=float, default=1.0, help="scale signature sizes (smoke runs)")
+    ap.add_argument("--num-hashes", type=int, default=1)
     ap.add_argument("--threshold", type=float, default=0.0,
                     help="0 = benchmark-fpr semantics (all documents scored)")
-    ap.add_argument("--shard-mode", choices=["queries", "index"], default="queries",
-                    help="N>1: replicate the index and split the batch (no collective), or shard the "
-                         "index by sub-index block and all-gather the count slices over RCCL")
+    ap.add_argument("--hits-only", action="store_true",
+                    help="with --threshold > 0: the scan keeps no score rows, only hit records")
+    ap.add_argument("--shard-mode", choices=["index", "queries"], default="index",
+                    help="N>1: shard the index by sub-index block and exchange the counts over RCCL (north_star's "
+                         "layout, the default), or replicate the index and split the work (no collective)")
     ap.add_argument("--num-results", type=int, default=0,
                     help="k > 0: the step also selects the k best documents per query on the device (K3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--exchange-chunks", type=int, default=4,
-                    help="--shard-mode index: sub-batches whose all-gather overlaps the next scan")
-    ap.add_argument("--no-sharded-extra", action="store_true",
-                    help="N>1, default mode: skip the additional index-sharded + RCCL all-gather measurement")
+    ap.add_argument("--exchange-chunks", type=int, default=1,
+                    help="N>1: sub-batches; with more than one the exchange of sub-batch i overlaps the scan of i+1")
+    ap.add_argument("--exchange", choices=["alltoall", "allgather"], default="alltoall")
+    ap.add_argument("--no-extras", "--no-sharded-extra", dest="no_extras", action="store_true",
+                    help="N>1: skip the additional measurements (overlap, all-gather, replicated, hits, configs[3])")
+    ap.add_argument("--hbm-budget-gb", type=float, default=0.0, help="per-GPU HBM budget of the index (0 = resident)")
+    ap.add_argument("--index-file", default="", help="c5: path of the index file (written once if missing)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real multi-GPU runs; gloo only "
                     "for smoke-testing the launch path with several ranks on one GPU")
     args = ap.parse_args()
 
+    from cobs_amd import _capi
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -369,83 +469,108 @@ def main():
     n_gpus = world
     dev = torch.cuda.current_device()
 
-    cfg = {"c3": c3_config, "c2": c2_config, "c4": c4_config}[args.config](args.scale)
+    base = "c3" if args.config == "c5" else args.config
+    cfg = {"c3": c3_config, "c2": c2_config, "c4": c4_config}[base](args.scale)
+    cfg["num_hashes"] = args.num_hashes
+    budget = int(args.hbm_budget_gb * 1e9)
+    path = None
+    if args.config == "c5":
+        # BASELINE configs[4]: the index is a FILE larger than the HBM budget; written once
+        path = args.index_file or os.path.join(os.environ.get("TMPDIR", "/tmp"), "cobs_c5_%g.cobs_compact" % args.scale)
+        if rank == 0 and not os.path.exists(path):
+            cobs_amd.write_synthetic(path, cfg["kind"], cfg["signature_sizes"], cfg["num_docs"],
+                                     page_size=cfg["page_size"], num_hashes=cfg["num_hashes"], seed=cfg["seed"], device=dev)
+        if world > 1:
+            dist.barrier()
+        if not budget:
+            budget = int(6e9)
+            args.hbm_budget_gb = 6.0
     shard_index = world > 1 and args.shard_mode == "index"
-    s = cobs_amd.Search.synthetic(cfg["kind"], cfg["signature_sizes"], cfg["num_docs"],
-                                  page_size=cfg["page_size"], term_size=cfg["term_size"],
-                                  canonicalize=cfg["canonicalize"], num_hashes=cfg["num_hashes"],
-                                  seed=cfg["seed"], device=dev,
-                                  shard_rank=rank if shard_index else 0,
-                                  shard_count=world if shard_index else 1)
-    if world > 1 and not shard_index:
-        # weak scaling: every rank serves its own batch of --queries queries against its replica
-        mine = make_queries(args.queries, args.kmers, seed=42 + rank)
-    else:
-        mine = make_queries(args.queries, args.kmers)
-    batch = cobs_amd.Batch(s)
-    batch.set_queries(mine)                    # H2D once; inputs now resident in HBM
+    queries = make_queries(args.queries, args.kmers, seed=42 + (rank if world > 1 and not shard_index else 0))
 
-    sub, gathered, sharded_step = [], [], None
+    comm = None
+    run = None
     if shard_index:
-        sharded_step, sub, gathered = sharded_setup(s, mine, world, args.exchange_chunks, args.threshold)
+        # the native RCCL communicator; torch.distributed is only the launcher that passes the id
+        if args.dist_backend == "nccl":
+            from cobs_amd.distributed import Comm
+            comm = Comm.from_torch(None, dev)
+        ok, err = True, ""
+        try:
+            run = ShardedRun(cfg, queries, world, rank, dev, comm, args.exchange_chunks, args.threshold,
+                             _capi.XCHG_ALLGATHER if args.exchange == "allgather" else _capi.XCHG_ALLTOALL,
+                             hbm_budget=budget, path=path, backend=args.dist_backend)
+        except Exception as e:                                      # noqa: BLE001
+            ok, err = False, repr(e)
+        if not all_ranks_ok(ok, args.dist_backend):
+            raise SystemExit("set-up of the sharded index failed: " + (err or "on another rank"))
+        s, batch = run.s, run.sub[0]
+        step = run.step
+    else:
+        s = make_index(cfg, dev, hbm_budget=budget, path=path)
+        batch = cobs_amd.Batch(s)
+        batch.set_queries(queries)                 # H2D once; inputs now resident in HBM
 
-    def step():
-        if shard_index:
-            sharded_step()
-        elif args.num_results > 0:
-            batch.run_topk(args.threshold, args.num_results, 0)
+        def step():
+            if args.num_results > 0:
+                batch.run_topk(args.threshold, args.num_results, 0)
+            elif args.hits_only and args.threshold > 0:
+                batch.run_hits(args.threshold, 0)
+            else:
+                batch.run(args.threshold, 0)
+
+    def drop_warmup_events():
+        if run is not None:
+            run.drop_warmup_events()
         else:
-            batch.run(args.threshold, 0)
+            batch.sync()
+            batch.kernel_ms()
 
-    for _ in range(args.warmup):
-        step()
-    if not shard_index:
-        batch.sync()
-        batch.kernel_ms()                      # drop warm-up events
-    for bi in sub:
-        bi.sync()
-        bi.kernel_ms()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    if shard_index:
-        for bi in sub:
-            bi.sync()
-        parts = [bi.kernel_ms() for bi in sub]  # one launch per sub-batch: a step's scan time is their sum
-        ms = {"scan_ms": sum(p["scan_ms"] for p in parts), "hash_ms": sum(p["hash_ms"] for p in parts)}
-        st = {"algorithmic_bytes": sum(bi.stats()["algorithmic_bytes"] for bi in sub)}
+    dt = timed(step, args.steps, args.warmup, world, args.dist_backend, drop_warmup_events)
+    received = 0
+    if run is not None:
+        scan_ms, hash_ms, algo, received = run.finish()     # per step: summed over the sub-batches
     else:
-        batch.sync()                           # also raises on invalid bases
-        ms = batch.kernel_ms()                 # HIP events on the launch stream, averaged over the timed steps
-        st = batch.stats()
+        batch.sync()                               # also raises on invalid bases
+        ms = batch.kernel_ms()                     # HIP events on the launch stream, averaged over the timed steps
+        scan_ms, hash_ms, algo = ms["scan_ms"], ms["hash_ms"], batch.stats()["algorithmic_bytes"]
+    nlaunch = batch.stats()["scan_launches"] if run is None else sum(b.stats()["scan_launches"] for b in run.sub)
 
-    # whole job: replicated index -> N independent batches; sharded index -> one batch on all ranks
-    total_queries = args.queries * (world if not shard_index else 1)
+    # whole job: sharded index -> one batch on all ranks; replicated index -> N independent batches
+    total_queries = args.queries * (1 if shard_index or world == 1 else world)
     ms_per_step = dt / args.steps * 1e3
     qps = total_queries * args.steps / dt
-    algo = st["algorithmic_bytes"]
-    achieved = algo / (ms["scan_ms"] * 1e-3) / 1e9
-    traffic = None
+    achieved = algo / (scan_ms * 1e-3) / 1e9
+    # HBM traffic from the PMC counters is measured by scripts/profile_shapes.sh (separate
+    # rocprofv3 --pmc passes) and replayed here from profiles/traffic.json -- only for the same
+    # workload AND the same kernel source; it is not measured in this run
+    traffic, traffic_source = None, None
+    key = "%s_q%d_k%d_h%d%s%s" % (args.config, args.queries, args.kmers, args.num_hashes,
+                                  "_hits" if args.hits_only and args.threshold > 0 else "",
+                                  "_top%d" % args.num_results if args.num_results else "")
     tr_path = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tr_path) and n_gpus == 1 and args.scale == 1.0 and args.queries == 10000:
+    if os.path.exists(tr_path) and n_gpus == 1 and args.scale == 1.0 and not budget:
         try:
             with open(tr_path) as f:
-                tj = json.load(f)
-            if tj.get("config") == args.config:
-                traffic = tj.get("hbm_bytes_per_launch")
+                ent = json.load(f).get(key)
+            if ent and ent.get("kernels_hash") == kernels_hash():
+                traffic = ent.get("hbm_bytes_per_launch")
+                traffic_source = ("replayed from profiles/traffic.json[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                  "of this workload at %s, same kernel source); not measured in this run"
+                                  % (key, ent.get("git_head", "?")))
+            elif ent:
+                traffic_source = "profiles/traffic.json[%s] belongs to other kernel source (%s): dropped" % (key, ent.get("git_head", "?"))
         except Exception:
             traffic = None
+    if shard_index:
+        par = ("index sharded by sub-index block (byte-balanced) over %d GPUs, one shared batch, %s exchange of the "
+               "per-document counts over RCCL/xGMI inside libcobs_gpu.so%s"
+               % (world, "all-to-all (query-owner)" if args.exchange == "alltoall" else "all-gather",
+                  ", %d overlapped sub-batches" % len(run.sub) if len(run.sub) > 1 else ""))
+    elif world > 1:
+        par = "index replicated on %d GPUs, one %d-query batch per GPU, no data-path collective" % (world, args.queries)
+    else:
+        par = "1 gpu"
     out = {
         # BASELINE.json's metric, verbatim; `value` is the queries/s part, roofline.achieved the GB/s part
         "metric": "k-mer queries/sec + achieved HBM GB/s, 100k-doc compact index, 1000-kmer query",
@@ -456,31 +581,20 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True,
-        "scaling": "strong" if shard_index else "weak",
+        "scaling": "strong" if shard_index or world == 1 else "weak",
         "vs_baseline": None,
-        "dtype": "u32",        # bitwise ops on 32-bit column words (bit-sliced counters); scores leave as u16
+        "dtype": "u32",        # bitwise ops on 32-bit column words (bit-sliced counters); scores leave as u8/u16
         "data": "synthetic",
         "config": {
-            "workload": ("BASELINE configs[%d]: synthetic compact index, %%d docs, %%d sub-indexes, page_size %%d B, "
-                         "S_p %%d..%%d rows (%%.1f GB in HBM), batch of %%d queries x %%d k-mers, H=%%d, threshold %%g"
-                         % (2 if args.config == "c3" else 3)
-                         % (cfg["num_docs"], len(cfg["signature_sizes"]), cfg["page_size"],
-                            cfg["signature_sizes"][0], cfg["signature_sizes"][-1],
-                            sum(cfg["signature_sizes"]) * cfg["page_size"] / 1e9,
-                            args.queries, args.kmers, cfg["num_hashes"], args.threshold)
-                         + (", top-%d selected on device" % args.num_results if args.num_results else ""))
-            if args.config != "c2" else
-            ("BASELINE configs[1]: synthetic classic index, %d docs x %d rows, batch of %d queries x %d k-mers"
-             % (cfg["num_docs"], cfg["signature_sizes"][0], args.queries, args.kmers)),
+            "workload": workload_text(args, cfg),
             "global_batch": total_queries,
             "queries_per_gpu_batch": args.queries,
             "kmers_per_query": args.kmers,
-            "parallelism": ("1 gpu" if world == 1 else
-                            ("index sharded by sub-index block x%d + RCCL all-gather of counts" % world
-                             if shard_index else "index replicated on %d GPUs, one %d-query batch per GPU, no data-path collective"
-                             % (world, args.queries))),
+            "parallelism": par,
         },
         "kmer_lookups_per_s": round(qps * args.kmers, 1),
+        "workload_key": key,
+        "kernels_hash": kernels_hash(),
         "roofline": {
             "bound": "hbm",
             "achieved": round(achieved, 1),
@@ -488,21 +602,34 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic,
-            "kernel": "scan_kernel (gather + AND + bit-sliced count), rank 0",
+            "traffic_source": traffic_source,
+            "kernel": "scan_kernel (gather + AND + bit-sliced count), rank 0%s"
+                      % (", %d launches per step summed" % nlaunch if nlaunch > 1 else ""),
             "algorithmic_bytes_per_launch": algo,
-            "scan_ms_per_launch": round(ms["scan_ms"], 4),
-            "hash_ms_per_launch": round(ms["hash_ms"], 4),
+            "scan_ms_per_launch": round(scan_ms, 4),
+            "hash_ms_per_launch": round(hash_ms, 4),
         },
     }
-    if world > 1 and not shard_index and not args.no_sharded_extra:
-        del batch, s
-        extra = sharded_extra(args, cfg, world, rank, dev)
-        if args.config == "c3":
-            extra["c4_1M_docs"] = sharded_c4_extra(args, world, rank, dev)
-        out["index_sharded"] = extra
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["end_to_end"] = end_to_end(s, batch, mine)
-        out["cpu_baseline"] = cpu_baseline(s, cfg, mine, batch=batch)
+    if shard_index:
+        out["rccl_ranks"] = comm.size if comm is not None else None       # ncclCommCount
+        out["exchange"] = {"mode": args.exchange, "received_bytes_per_step_rank0": received,
+                           "transport": "RCCL in libcobs_gpu.so" if comm is not None else "torch.distributed/" + args.dist_backend}
+        info = s.info(0)
+        out["shard_rank0"] = {"hbm_bytes": int(info.hbm_bytes), "slot_begin": int(info.slot_begin),
+                              "slot_count": int(info.slot_count)}
+    if budget:
+        info = s.info(0)
+        index_bytes = sum(cfg["signature_sizes"]) * (cfg["page_size"] or (cfg["num_docs"] + 7) // 8)
+        out["streaming"] = {"hbm_budget_bytes": budget, "index_bytes": index_bytes, "file": path,
+                            "scan_launches_per_step": nlaunch,
+                            "pcie_GBps_rank0": round(index_bytes / max(world if shard_index else 1, 1) / (dt / args.steps) / 1e9, 2)}
+    if world > 1 and shard_index and not args.no_extras:
+        del run, batch, s
+        torch.cuda.empty_cache()
+        out["other_forms"] = side_measurements(args, cfg, queries, world, rank, dev, comm)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not budget:
+        out["end_to_end"] = end_to_end(s, batch, queries)
+        out["cpu_baseline"] = cpu_baseline(s, cfg, queries, batch=batch)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -85,6 +85,7 @@ SYMBOLS = {
                                       C.POINTER(BuildParams), _cp]),
     "cobs_gpu_build_compact": (_int, [C.POINTER(_cp), C.POINTER(_cp), C.POINTER(_sz), _sz,
                                       C.POINTER(BuildParams), _cp]),
+    "cobs_gpu_write_synthetic": (_int, [C.POINTER(Synth), _cp, _int]),
     "cobs_gpu_search": (_int, [_vp, _cp, _sz, _dbl, _sz, C.POINTER(Hit), _sz, C.POINTER(_sz)]),
     "cobs_gpu_search_batch": (_int, [_vp, C.POINTER(_cp), C.POINTER(_sz), _sz, _dbl, _sz,
                                      C.POINTER(Hit), _sz, C.POINTER(_sz), C.POINTER(_sz)]),
@@ -93,6 +94,7 @@ SYMBOLS = {
     "cobs_gpu_batch_destroy": (None, [_vp]),
     "cobs_gpu_batch_set_queries": (_int, [_vp, C.POINTER(_cp), C.POINTER(_sz), _sz]),
     "cobs_gpu_batch_run": (_int, [_vp, _dbl, _vp]),
+    "cobs_gpu_batch_run_hits": (_int, [_vp, _dbl, _vp]),
     "cobs_gpu_batch_run_topk": (_int, [_vp, _dbl, _sz, _vp]),
     "cobs_gpu_batch_sync": (_int, [_vp, _vp, C.POINTER(_sz)]),
     "cobs_gpu_batch_counts_device": (_vp, [_vp, C.POINTER(_u32), C.POINTER(_u64)]),

@@ -223,6 +223,21 @@ def compact_construct_list(list, out_file, index_params=None, tmp_path="", devic
     compact_construct(None, out_file, index_params, "any", tmp_path, list=list, device=device)
 
 
-__all__ = ["DocumentList", "DocumentEntry", "ClassicIndexParameters", "CompactIndexParameters",
+def write_synthetic(out_file, kind, signature_sizes, num_docs, page_size=0, term_size=31, canonicalize=1,
+                    num_hashes=1, seed=1, device=-1):
+    """The procedural benchmark index (Search.synthetic) as a .cobs_classic / .cobs_compact FILE:
+    the generator tool next to `cobs classic-construct-random` (reference src/cobs.cpp:243-291)."""
+    from ._capi import Synth
+    lib = _capi.load()
+    sigs = (C.c_uint64 * len(signature_sizes))(*[int(s) for s in signature_sizes])
+    d = Synth()
+    d.kind = 1 if kind in (1, "compact") else 0
+    d.term_size, d.canonicalize, d.num_pages = term_size, canonicalize, len(signature_sizes)
+    d.num_hashes, d.page_size, d.num_docs, d.seed = num_hashes, page_size, num_docs, seed
+    d.signature_sizes = C.cast(sigs, C.POINTER(C.c_uint64))
+    check(lib.cobs_gpu_write_synthetic(C.byref(d), os.fsencode(out_file), device))
+
+
+__all__ = ["write_synthetic", "DocumentList", "DocumentEntry", "ClassicIndexParameters", "CompactIndexParameters",
            "classic_construct", "classic_construct_list", "compact_construct", "compact_construct_list",
            "disable_cache"]

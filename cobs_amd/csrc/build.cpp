@@ -243,4 +243,94 @@ cobs_gpu_status cobs_gpu_build_compact(const char* const* names, const char* con
     return COBS_GPU_OK;
 }
 
+// The procedural index of cobs_gpu_open_synthetic as a FILE in the reference's format: the
+// stand-in for `cobs classic-construct-random` (src/cobs.cpp:243-291,
+// construction/classic_index.cpp:661-725) at sizes where hashing 10^10 random k-mers is not the
+// point -- same header (classic_index_header.cpp:26-37 / compact_index_header.cpp:20-43), document
+// names file_%06u (classic_index.cpp:668-670), bits of density ~0.3.  `cobs query`, the reference's
+// tools and this engine (resident or streamed) read it.  Rows are generated on the device in
+// chunks and streamed to the file: neither HBM nor host memory holds the matrix.
+cobs_gpu_status cobs_gpu_write_synthetic(const cobs_gpu_synth* d, const char* out_path, int device) {
+    if (!d || !d->signature_sizes || !out_path || d->num_pages == 0 || d->kind > 1)
+        return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "bad synthetic index description");
+    if ((d->kind == 1 && d->page_size == 0) || (d->kind == 0 && d->num_pages != 1) || d->num_docs == 0 ||
+        d->num_docs > 0xFFFFFFF0ull || (d->kind == 1 && d->num_docs > (uint64_t)d->num_pages * 8 * d->page_size))
+        return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "bad synthetic index geometry");
+    cobs_gpu_status st = pick_device(device);
+    if (st != COBS_GPU_OK) return st;
+    const uint64_t prb = d->kind ? d->page_size : (d->num_docs + 7) / 8;
+    std::string h;
+    char nm[32];
+    if (d->kind == 0) {
+        h = "COBS:CLASSIC_INDEX";
+        put<uint32_t>(h, 1);
+        put<uint32_t>(h, d->term_size);
+        put<uint8_t>(h, (uint8_t)d->canonicalize);
+        put<uint32_t>(h, (uint32_t)d->num_docs);
+        put<uint64_t>(h, d->signature_sizes[0]);
+        put<uint64_t>(h, d->num_hashes);
+        for (uint64_t i = 0; i < d->num_docs; ++i) { std::snprintf(nm, sizeof nm, "file_%06u\n", (unsigned)i); h += nm; }
+        h += "CLASSIC_INDEX";
+    } else {
+        h = "COBS:COMPACT_INDEX";
+        put<uint32_t>(h, 1);
+        put<uint32_t>(h, d->term_size);
+        put<uint8_t>(h, (uint8_t)d->canonicalize);
+        put<uint32_t>(h, d->num_pages);
+        put<uint32_t>(h, (uint32_t)d->num_docs);
+        put<uint64_t>(h, d->page_size);
+        for (uint32_t p = 0; p < d->num_pages; ++p) { put<uint64_t>(h, d->signature_sizes[p]); put<uint64_t>(h, d->num_hashes); }
+        for (uint64_t i = 0; i < d->num_docs; ++i) { std::snprintf(nm, sizeof nm, "file_%06u\n", (unsigned)i); h += nm; }
+        const uint64_t pad = (d->page_size - ((h.size() + 13) % d->page_size)) % d->page_size;
+        h.append((size_t)pad, '\0');
+        h += "COMPACT_INDEX";
+    }
+    FILE* f = std::fopen(out_path, "wb");
+    if (!f) return cobs_gpu_set_error(COBS_GPU_ERR_OPEN, (std::string("could not create ") + out_path).c_str());
+    struct Closer { FILE* f; ~Closer() { if (f) std::fclose(f); } } closer{f};
+    if (!write_all(f, h.data(), h.size())) return cobs_gpu_set_error(COBS_GPU_ERR_OPEN, "short write");
+    const uint32_t pitch = (uint32_t)((prb + 7) / 8 * 8);
+    const uint64_t rows_per = std::max<uint64_t>(1, (256ull << 20) / pitch);
+    DevMem d_rows;
+    BUILD_TRY(hipMalloc(&d_rows.p, (size_t)(rows_per * pitch)));
+    struct Pinned { void* p = nullptr; ~Pinned() { if (p) (void)hipHostFree(p); } } host[2];
+    hipStream_t stream = nullptr;
+    BUILD_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{stream};
+    for (auto& hb : host) BUILD_TRY(hipHostMalloc(&hb.p, (size_t)(rows_per * prb), hipHostMallocDefault));
+    int cur = 0;
+    uint64_t pending = 0;       // bytes of host[cur ^ 1] still to be written
+    for (uint32_t p = 0; p < d->num_pages; ++p) {
+        const uint64_t sig = d->signature_sizes[p];
+        const uint64_t first_doc = d->kind ? (uint64_t)p * 8 * d->page_size : 0;
+        const uint64_t live = d->num_docs > first_doc ? d->num_docs - first_doc : 0;
+        for (uint64_t r = 0; r < sig; r += rows_per) {
+            const uint64_t n = std::min(rows_per, sig - r);
+            SynthRowsArgs a;
+            a.dst = (uint8_t*)d_rows.p;
+            a.seed = d->seed;
+            a.row0 = r;
+            a.nrows = n;
+            a.row_bytes = prb;
+            a.live_docs = live;
+            a.page = p;
+            a.pitch = pitch;
+            BUILD_TRY(launch_synth_rows(a, stream));
+            BUILD_TRY(hipMemcpy2DAsync(host[cur].p, (size_t)prb, d_rows.p, pitch, (size_t)prb, (size_t)n,
+                                       hipMemcpyDeviceToHost, stream));
+            // while the device produces this chunk the host writes the previous one
+            if (pending && !write_all(f, host[cur ^ 1].p, (size_t)pending))
+                return cobs_gpu_set_error(COBS_GPU_ERR_OPEN, "short write");
+            BUILD_TRY(hipStreamSynchronize(stream));
+            pending = n * prb;
+            cur ^= 1;
+        }
+    }
+    if (pending && !write_all(f, host[cur ^ 1].p, (size_t)pending))
+        return cobs_gpu_set_error(COBS_GPU_ERR_OPEN, "short write");
+    closer.f = nullptr;
+    if (std::fclose(f) != 0) return cobs_gpu_set_error(COBS_GPU_ERR_OPEN, "short write");
+    return COBS_GPU_OK;
+}
+
 }  // extern "C"

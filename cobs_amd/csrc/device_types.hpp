@@ -120,6 +120,17 @@ struct SynthArgs {
     uint32_t pitch;
 };
 
+// rows of one sub-index of the procedural index, for the file writer
+struct SynthRowsArgs {
+    uint8_t* dst;               // row r at dst + r * pitch
+    uint64_t seed;
+    uint64_t row0, nrows;
+    uint64_t row_bytes;         // valid bytes per row (rest of the pitch is zero)
+    uint64_t live_docs;         // real documents of this sub-index (later bits are zero)
+    uint32_t page;              // file-level sub-index
+    uint32_t pitch;             // multiple of 8
+};
+
 struct RepitchArgs {
     const uint8_t* src;         // staged raw rows: row r at src + r * src_pitch
     uint8_t* dst;               // dst row r at dst + r * dst_pitch

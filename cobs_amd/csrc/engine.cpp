@@ -1238,6 +1238,11 @@ cobs_gpu_status cobs_gpu_batch_run(cobs_gpu_batch* b, double threshold, void* hi
     return guarded([&]() { return run_impl(b, threshold, 0, hip_stream); });
 }
 
+cobs_gpu_status cobs_gpu_batch_run_hits(cobs_gpu_batch* b, double threshold, void* hip_stream) {
+    if (!(threshold > 0.0)) return fail(COBS_GPU_ERR_ARG, "a hits-only pass needs a threshold > 0");
+    return guarded([&]() { return run_impl(b, threshold, 0, hip_stream, false); });
+}
+
 cobs_gpu_status cobs_gpu_batch_run_topk(cobs_gpu_batch* b, double threshold, size_t num_results,
                                         void* hip_stream) {
     return guarded([&]() { return run_impl(b, threshold, num_results, hip_stream); });

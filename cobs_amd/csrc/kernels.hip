@@ -1094,6 +1094,30 @@ __global__ __launch_bounds__(256) void synth_kernel(SynthArgs a) {
     }
 }
 
+// rows [row0, row0 + nrows) of one sub-index of the procedural index, packed `pitch` bytes apart
+// (the file writer: cobs_gpu_write_synthetic)
+__global__ __launch_bounds__(256) void synth_rows_kernel(SynthRowsArgs a) {
+    const uint32_t wpr = a.pitch / 8u;
+    const uint64_t nwords = a.nrows * (uint64_t)wpr;
+    uint64_t* dst = reinterpret_cast<uint64_t*>(a.dst);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / wpr;
+        const uint32_t w = (uint32_t)(i - r * wpr);
+        const uint64_t x = synth_word(a.seed, a.page, a.row0 + r, w);
+        uint64_t v = 0;
+#pragma unroll
+        for (uint32_t b = 0; b < 8; ++b) {
+            const uint64_t gb = (uint64_t)w * 8u + b;          // row byte
+            uint32_t byte = (uint32_t)(x >> (8 * b)) & 0xFFu;
+            if (gb >= a.row_bytes || gb * 8 >= a.live_docs) byte = 0;
+            else if (gb * 8 + 8 > a.live_docs) byte &= (1u << (uint32_t)(a.live_docs - gb * 8)) - 1u;
+            v |= (uint64_t)byte << (8 * b);
+        }
+        dst[i] = v;
+    }
+}
+
 // staged raw rows -> pitched rows (16 bytes per thread), zero padding to the pitch
 __global__ __launch_bounds__(256) void repitch_kernel(RepitchArgs a) {
     const uint32_t cpr = a.dst_pitch / 16u;
@@ -1239,6 +1263,12 @@ hipError_t launch_build(const BuildArgs& a, uint64_t total_bytes, hipStream_t st
 hipError_t launch_synth(const SynthArgs& a, hipStream_t stream) {
     if (a.npages == 0) return hipSuccess;
     hipLaunchKernelGGL(synth_kernel, dim3(2048, a.npages), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth_rows(const SynthRowsArgs& a, hipStream_t stream) {
+    if (a.nrows == 0) return hipSuccess;
+    hipLaunchKernelGGL(synth_rows_kernel, dim3(4096), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -29,6 +29,7 @@ hipError_t launch_topk(const TopkArgs& a, hipStream_t stream);
 hipError_t launch_build(const BuildArgs& a, uint64_t total_bytes, hipStream_t stream);
 
 hipError_t launch_synth(const SynthArgs& a, hipStream_t stream);
+hipError_t launch_synth_rows(const SynthRowsArgs& a, hipStream_t stream);
 hipError_t launch_repitch(const RepitchArgs& a, hipStream_t stream);
 
 }  // namespace cobs_amd

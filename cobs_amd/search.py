@@ -314,6 +314,10 @@ class Batch:
     def run(self, threshold=0.0, stream=0):
         check(self._lib.cobs_gpu_batch_run(self._h, float(threshold), C.c_void_p(stream)))
 
+    def run_hits(self, threshold, stream=0):
+        """hot path without score rows: only the documents reaching the threshold are recorded"""
+        check(self._lib.cobs_gpu_batch_run_hits(self._h, float(threshold), C.c_void_p(stream)))
+
     def run_topk(self, threshold=0.0, num_results=10, stream=0):
         """hot path + on-device selection of the num_results best documents per query"""
         check(self._lib.cobs_gpu_batch_run_topk(self._h, float(threshold), int(num_results), C.c_void_p(stream)))

@@ -186,6 +186,11 @@ cobs_gpu_status cobs_gpu_build_compact(const char* const* names, const char* con
                                        const size_t* lens, size_t ndocs,
                                        const cobs_gpu_build_params* params, const char* out_path);
 
+/* The procedural index of cobs_gpu_open_synthetic written as a .cobs_classic / .cobs_compact FILE
+ * (the generator tool of SURVEY 8f rank 2, cf. `cobs classic-construct-random`, src/cobs.cpp:243-291):
+ * rows are produced on the device chunk by chunk and streamed to the file. */
+cobs_gpu_status cobs_gpu_write_synthetic(const cobs_gpu_synth* desc, const char* out_path, int device);
+
 /* ---- search (host buffers in, host buffers out) ------------------------ */
 /* ClassicSearch::search (classic_search.cpp:403-505): hits ordered by score
  * descending, ties by (file_no, doc) ascending; no ordering when the query has a
@@ -232,6 +237,12 @@ cobs_gpu_status cobs_gpu_batch_set_queries(cobs_gpu_batch* b, const char* const*
  * :279-307, :643-1022), and, if threshold > 0, on-device selection of documents
  * with count >= ceil(threshold * T) (:127-132).  Counts stay in HBM.          */
 cobs_gpu_status cobs_gpu_batch_run(cobs_gpu_batch* b, double threshold, void* hip_stream);
+/* The same pass without score rows (threshold > 0 required): the comparison count >= ceil(threshold * T)
+ * is done on the bit-sliced counters, only the selected (query, file, doc, score) records are
+ * written.  cobs_gpu_batch_hits_host returns them; if the selection pool overflowed it fails
+ * with COBS_GPU_ERR_ARG ("did not keep the score rows"): rerun with cobs_gpu_batch_run, as
+ * cobs_gpu_search_batch does on its own. */
+cobs_gpu_status cobs_gpu_batch_run_hits(cobs_gpu_batch* b, double threshold, void* hip_stream);
 /* The same pass followed by K3: on-device selection of the num_results best
  * documents per query (score descending, ties by document ascending -- the set
  * std::partial_sort keeps, classic_search.cpp:134-145) among those with

@@ -247,6 +247,25 @@ def search_many(indexes, queries, threshold=0.0, num_results=0, threads=1, secon
     return int(n), el.value
 
 
+def search_many_parallel(indexes, queries, workers, threshold=-1.0, num_results=0, seconds=5.0):
+    """`workers` host threads, each running search_many (one thread per query) over its own
+    share of the queries at the same time -- the throughput a caller gets from the reference's
+    algorithm by serving independent queries on all cores.  -> (queries done, seconds)"""
+    import threading
+    workers = max(1, min(int(workers), len(queries)))
+    res = [None] * workers
+
+    def work(i):
+        res[i] = search_many(indexes, queries[i::workers], threshold, num_results, threads=1, seconds=seconds)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(workers)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    return sum(r[0] for r in res), max(r[1] for r in res)
+
+
 def timers(reset=False):
     t = (C.c_double * 5)()
     lib().oracle_timers(t, 1 if reset else 0)

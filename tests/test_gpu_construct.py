@@ -101,3 +101,36 @@ def test_in_memory_documents_vs_restatement(gpu_lib, oracle, construct, tmp_path
     q = docs[3][1][0] if len(docs[3][1][0]) >= k and b"N" not in docs[3][1][0] else oracle.random_sequence(100, 1)
     if canonicalize == 0 or b"N" not in q:
         assert np.array_equal(s.counts(q), ix.counts(q))
+
+
+def test_write_synthetic_file_is_the_procedural_index(gpu_lib, oracle, tmp_path):
+    """cobs_gpu_write_synthetic (the generator tool): the file it writes holds exactly the rows the
+    checker's generator defines, in the reference's header format (the oracle's reader opens it),
+    and the engine answers from the file -- resident or streamed -- as from the in-HBM original."""
+    import cobs_amd
+    from tests import cases
+    sigs = [1201, 1789, 2503]
+    ps, D = 112, 2 * 8 * 112 + 500
+    pc = str(tmp_path / "syn.cobs_compact")
+    cobs_amd.write_synthetic(pc, "compact", sigs, D, page_size=ps, seed=77)
+    ix = oracle.Index.open(pc)
+    assert (ix.num_pages, ix.page_size, ix.num_docs) == (3, ps, D)
+    assert ix.doc_name(0) == "file_000000" and ix.doc_name(D - 1) == "file_%06d" % (D - 1)
+    ref = oracle.Index.synthetic(1, 31, 1, 1, ps, sigs, D, 77)
+    s_file = gpu_lib.Search(pc)
+    s_stream = gpu_lib.Search(pc, hbm_budget=300 * 1024)
+    s_mem = gpu_lib.Search.synthetic("compact", sigs, D, page_size=ps, seed=77)
+    for page, row in ((0, 0), (0, 1200), (1, 17), (2, 2502)):
+        assert np.array_equal(s_file.read_row(0, page, row, ps), oracle.synth_row(1, 77, ps, 3, D, page, row, ps))
+    for q in cases.queries_acgt(3, 400, 40):
+        want = ref.counts(q)
+        assert np.array_equal(ix.counts(q), want)
+        for s in (s_file, s_stream, s_mem):
+            assert np.array_equal(s.counts(q), want)
+    pk = str(tmp_path / "syn.cobs_classic")
+    cobs_amd.write_synthetic(pk, "classic", [3001], 1003, seed=5)       # row bytes not a multiple of 8
+    ref2 = oracle.Index.synthetic(0, 31, 1, 1, 0, [3001], 1003, 5)
+    s2 = gpu_lib.Search(pk)
+    for q in cases.queries_acgt(2, 300, 50):
+        assert np.array_equal(oracle.Index.open(pk).counts(q), ref2.counts(q))
+        assert np.array_equal(s2.counts(q), ref2.counts(q))
