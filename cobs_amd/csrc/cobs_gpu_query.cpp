@@ -10,11 +10,13 @@
 // Unlike the reference, which runs the queries of a file one after the other, the
 // whole file is one device batch.
 #include <cstdio>
+#include <unistd.h>
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
 #include <fstream>
 #include <iostream>
+#include <memory>
 #include <random>
 #include <string>
 #include <vector>
@@ -24,17 +26,22 @@
 static void usage() {
     std::fprintf(stderr,
                  "usage: cobs_gpu_query -i INDEX [-i INDEX ...] [-t THRESHOLD] [-l LIMIT] "
-                 "[-d DEVICE] [--hbm-budget GIB] (QUERY | -f QUERY_FILE)\n"
+                 "[-d DEVICE[,DEVICE...]] [--hbm-budget GIB] (QUERY | -f QUERY_FILE)\n"
+                 "       -d 0,1,2,3: the index is sharded by sub-index block over the listed GPUs, every search is\n"
+                 "        one scan per GPU + one RCCL exchange (same results as on one GPU)\n"
                  "       (--load-complete and -T/--threads of `cobs query` are accepted and ignored: the index\n"
                  "        always lives in HBM, or is streamed through it under --hbm-budget)\n"
-                 "       cobs_gpu_query --benchmark -i INDEX [-k KMERS] [-q QUERIES] [-w WARMUP] [--seed S]\n");
+                 "       cobs_gpu_query --benchmark -i INDEX [-k KMERS] [-q QUERIES] [-w WARMUP] [--seed S]\n"
+                 "       cobs_gpu_query --write-synthetic OUT (--classic -n DOCS -s ROWS | --compact -n DOCS -p PAGE_SIZE\n"
+                 "                      -s ROWS_0,ROWS_1,...) [--num-hashes H] [--seed S] [-d DEVICE]\n"
+                 "        (the generator next to `cobs classic-construct-random`: a random-bit index file, density 0.3)\n");
 }
 
 // `cobs benchmark-fpr` (reference src/cobs.cpp:605-730): random ACGT queries of
 // num_kmers + 30 characters from one std::mt19937(seed), default threshold 0 and
 // num_results 0, one RESULT line.  Here the queries run as one device batch; the
 // reference's t_io / t_and / t_add phases are one scan kernel (t_scan).
-static int benchmark(cobs_gpu::ClassicSearch& s, const std::string& index, unsigned num_kmers,
+static int benchmark(cobs_gpu::BatchSearch& s, const std::string& index, unsigned num_kmers,
                      unsigned num_queries, unsigned num_warmup, size_t seed) {
     static const char basepairs[4] = {'A', 'C', 'G', 'T'};
     std::mt19937 rng(seed);
@@ -69,8 +76,11 @@ int main(int argc, char** argv) {
     std::string query_line, query_file;
     double threshold = 0.8;
     size_t num_results = 0;
-    int device = -1;
+    std::vector<int> devices;
     uint64_t hbm_budget = 0;
+    std::string synth_out, synth_rows;
+    bool synth_compact = false, force_sharded = false;
+    uint64_t synth_docs = 10000, synth_page = 0, synth_hashes = 1;
     bool bench = false;
     unsigned num_kmers = 1000, num_queries = 10000, num_warmup = 100;
     size_t seed = std::random_device{}();
@@ -84,7 +94,23 @@ int main(int argc, char** argv) {
         else if (a == "-f" || a == "--file") query_file = need("-f");
         else if (a == "-t" || a == "--threshold") threshold = std::atof(need("-t"));
         else if (a == "-l" || a == "--limit") num_results = (size_t)std::strtoull(need("-l"), nullptr, 10);
-        else if (a == "-d" || a == "--device") device = std::atoi(need("-d"));
+        else if (a == "-d" || a == "--device") {
+            const std::string v = need("-d");
+            for (size_t p = 0; p < v.size();) {
+                size_t e = v.find(',', p);
+                if (e == std::string::npos) e = v.size();
+                devices.push_back(std::atoi(v.substr(p, e - p).c_str()));
+                p = e + 1;
+            }
+        }
+        else if (a == "--sharded") force_sharded = true;        // the multi-GPU code path even for one device
+        else if (a == "--write-synthetic") synth_out = need("--write-synthetic");
+        else if (a == "--classic") synth_compact = false;
+        else if (a == "--compact") synth_compact = true;
+        else if (a == "-n" || a == "--num-documents") synth_docs = std::strtoull(need("-n"), nullptr, 10);
+        else if (a == "-s" || a == "--signature-size") synth_rows = need("-s");
+        else if (a == "-p" || a == "--page-size") synth_page = std::strtoull(need("-p"), nullptr, 10);
+        else if (a == "--num-hashes") synth_hashes = std::strtoull(need("--num-hashes"), nullptr, 10);
         else if (a == "--hbm-budget") hbm_budget = (uint64_t)(std::atof(need("--hbm-budget")) * 1073741824.0);
         else if (a == "--load-complete") {}                  // reference flags without a meaning here
         else if (a == "-T" || a == "--threads") (void)need("-T");
@@ -97,9 +123,50 @@ int main(int argc, char** argv) {
         else if (!a.empty() && a[0] == '-') { std::fprintf(stderr, "unknown flag %s\n", a.c_str()); usage(); return 1; }
         else query_line = a;
     }
+    const int device = devices.empty() ? -1 : devices[0];
+    auto open_index = [&]() -> std::unique_ptr<cobs_gpu::BatchSearch> {
+        // stdout carries the results in `cobs query` format and nothing else: RCCL prints a
+        // version banner there when a communicator is created, so stdout points at stderr
+        // while the index is opened
+        struct StdoutToStderr {
+            int saved;
+            StdoutToStderr() { std::fflush(stdout); saved = dup(1); dup2(2, 1); }
+            ~StdoutToStderr() { std::fflush(stdout); dup2(saved, 1); close(saved); }
+        } quiet;
+        if (devices.size() > 1 || force_sharded)
+            return std::unique_ptr<cobs_gpu::BatchSearch>(new cobs_gpu::ShardedClassicSearch(
+                index_paths, devices.empty() ? std::vector<int>{0} : devices, hbm_budget));
+        return std::unique_ptr<cobs_gpu::BatchSearch>(new cobs_gpu::ClassicSearch(index_paths, device, hbm_budget));
+    };
+    if (!synth_out.empty()) {
+        std::vector<uint64_t> sigs;
+        for (size_t p = 0; p < synth_rows.size();) {
+            size_t e = synth_rows.find(',', p);
+            if (e == std::string::npos) e = synth_rows.size();
+            sigs.push_back(std::strtoull(synth_rows.substr(p, e - p).c_str(), nullptr, 10));
+            p = e + 1;
+        }
+        if (sigs.empty()) sigs.push_back(2 * 1024 * 1024);      // default of `cobs classic-construct-random -s`
+        cobs_gpu_synth d{};
+        d.kind = synth_compact ? 1 : 0;
+        d.term_size = 31;
+        d.canonicalize = 1;
+        d.num_pages = (uint32_t)sigs.size();
+        d.num_hashes = synth_hashes;
+        d.page_size = synth_page;
+        d.num_docs = synth_docs;
+        d.seed = seed;
+        d.signature_sizes = sigs.data();
+        if (cobs_gpu_write_synthetic(&d, synth_out.c_str(), device) != COBS_GPU_OK) {
+            std::fprintf(stderr, "EXCEPTION: %s\n", cobs_gpu_last_error());
+            return 1;
+        }
+        return 0;
+    }
     if (bench && !index_paths.empty()) {
         try {
-            cobs_gpu::ClassicSearch s(index_paths, device, hbm_budget);
+            std::unique_ptr<cobs_gpu::BatchSearch> sp = open_index();
+            cobs_gpu::BatchSearch& s = *sp;
             return benchmark(s, index_paths[0], num_kmers, num_queries, num_warmup, seed);
         } catch (const cobs_gpu::Error& e) {
             std::fprintf(stderr, "EXCEPTION: %s\n", e.what());
@@ -112,7 +179,8 @@ int main(int argc, char** argv) {
         return 1;
     }
     try {
-        cobs_gpu::ClassicSearch s(index_paths, device, hbm_budget);
+        std::unique_ptr<cobs_gpu::BatchSearch> sp = open_index();
+        cobs_gpu::BatchSearch& s = *sp;
         if (!query_line.empty()) {
             std::vector<cobs_gpu::SearchResult> result;
             s.search(query_line, result, threshold, num_results);

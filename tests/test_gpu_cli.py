@@ -72,3 +72,40 @@ def test_benchmark_result_line(gpu_lib, oracle, tmp_path):
     assert kv["kmer_queries"] == "200" and kv["queries"] == "50" and kv["warmup"] == "5"
     assert kv["results"] == "500"                       # threshold 0: every document is returned
     assert float(kv["t_scan"]) > 0 and float(kv["queries_per_s"]) > 0
+
+
+def test_sharded_class_and_generator_tool(gpu_lib, oracle, golden_dir, tmp_path):
+    """cobs_gpu::ShardedClassicSearch (-d list / --sharded): worker thread per device, RCCL
+    communicator, cobs_gpu_sharded_search_batch -- on this box one rank, the same code path.
+    And --write-synthetic: the generator tool writes a file both readers open."""
+    a = os.path.join(golden_dir, "c1.cobs_compact")
+    b = os.path.join(golden_dir, "c1.cobs_classic")
+    qf = tmp_path / "q.fa"
+    qf.write_text(">first query\n%s\n%s\n\n;second\n%s\n" % (Q50[:25], Q50[25:], Q50[3:40]))
+    ixs = [oracle.Index.open(a), oracle.Index.open(b)]
+    for extra in (["-t", "0.05"], ["-t", "0"], ["-t", "0", "-l", "3"]):
+        r = _run("--sharded", "-d", "0", "-i", a, "-i", b, "-f", str(qf), *extra)
+        assert r.returncode == 0, r.stderr
+        t = float(extra[1])
+        lim = int(extra[3]) if len(extra) > 2 else 0
+        want = ""
+        for comment, q in (("*first query", Q50), ("*second", Q50[3:40])):
+            res = oracle.search(ixs, q.encode(), t, lim)
+            want += "%s\t%d\n" % (comment, len(res)) + "".join("%s\t%d\n" % (n, s) for (_, _, n, s) in res)
+        assert r.stdout == want, extra
+    r = _run("--sharded", "-i", b, Q50.replace("G", "N", 1))
+    assert r.returncode != 0 and "Invalid DNA base pair" in r.stderr
+    r = _run("--sharded", "-d", "0,7", "-i", b, Q50)               # a device that does not exist: error, no hang
+    assert r.returncode != 0 and "EXCEPTION" in r.stderr
+    out = str(tmp_path / "gen.cobs_compact")
+    r = _run("--write-synthetic", out, "--compact", "-n", "700", "-p", "16", "-s", "801,907,1009,1201,1301,1409",
+             "--seed", "9")
+    assert r.returncode == 0, r.stderr
+    ix = oracle.Index.open(out)
+    ref = oracle.Index.synthetic(1, 31, 1, 1, 16, [801, 907, 1009, 1201, 1301, 1409], 700, 9)
+    q = oracle.random_sequence(200, 5)
+    import numpy as np
+    assert np.array_equal(ix.counts(q), ref.counts(q))
+    r = _run("-i", out, "-t", "0.3", q.decode())
+    want = "".join("%s\t%d\n" % (n, s) for (_, _, n, s) in oracle.search(ix, q, 0.3))
+    assert r.returncode == 0 and r.stdout == want
