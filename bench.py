@@ -108,11 +108,29 @@ def cpu_baseline(search, cfg, queries, seconds_target=12.0, check_queries=4, bat
         exact_index = False
         sample = "same geometry with S_p/16 (host RAM too small for the full index), same queries"
     # bit-exactness of the GPU counts against the port on the same inputs
-    bit_exact = None
-    if exact_index and batch is not None:
+    # (the checker regenerates the procedural rows itself: nothing is read back from the GPU for it)
+    bit_exact, checked = None, {}
+    if batch is not None:
+        gen = O.Index.synthetic(kind, cfg["term_size"], cfg["canonicalize"], cfg["num_hashes"],
+                                cfg["page_size"], sigs, cfg["num_docs"], cfg["seed"])
+        n_sum = min(64, len(queries))
+        eb = batch.counts_device()[1]
+        t_all = batch.counts_tensor()[:n_sum].to(torch.int64)
+        if eb > 1:
+            t_all = t_all.bitwise_and((1 << (8 * eb)) - 1)      # int16 / int32 views of u16 / u32 scores
+        w = (torch.arange(t_all.shape[1], device=t_all.device, dtype=torch.int64) % 1021) + 1
+        dev_sum = t_all.sum(dim=1).cpu().numpy()
+        dev_wsum = (t_all * w).sum(dim=1).cpu().numpy()
+        wn = (np.arange(t_all.shape[1], dtype=np.int64) % 1021) + 1
         bit_exact = True
-        for i in range(min(check_queries, len(queries))):
-            bit_exact = bit_exact and bool(np.array_equal(batch.counts_host(i), ix.counts(queries[i])))
+        n_rows = min(16, len(queries))
+        for i in range(n_sum):
+            want = gen.counts(queries[i])
+            bit_exact = bit_exact and int(dev_sum[i]) == int(want.sum()) \
+                and int(dev_wsum[i]) == int((want.astype(np.int64) * wn).sum())
+            if i < n_rows:
+                bit_exact = bit_exact and bool(np.array_equal(batch.counts_host(i), want))
+        checked = {"exact_rows": n_rows, "row_checksums": n_sum}
     # The timed GPU step ends with the per-document scores (the reference's score_list,
     # classic_search.cpp:456-467) in memory, so the CPU figure times the same step:
     # hashes + row gather + AND + expand-add, no threshold filter / ranking.  The rate of
@@ -156,7 +174,7 @@ def cpu_baseline(search, cfg, queries, seconds_target=12.0, check_queries=4, bat
            "threads_%d_over_document_batches" % tmax: {"value": round(qpsm, 2), "queries": nm},
            "all_cores_one_query_per_thread": {"value": round(qps_all, 2), "queries": n_all, "threads": min(ncores, len(queries))},
            "full_search_with_ranking_1thread": {"value": round(n_full / dt_full, 2), "queries": n_full},
-           "bit_exact_vs_gpu": bit_exact}
+           "bit_exact_vs_gpu": bit_exact, "bit_exact_checked": checked}
     return res
 
 

@@ -72,11 +72,11 @@ struct ScanArgs {
     uint32_t idx64;             // 64-bit row indices in the table
 };
 
-// Arguments of the top-k selection kernel K3 for one index file (u16 scores).
+// Arguments of the top-k selection kernel K3 for one index file.
 struct TopkArgs {
     const void* counts;          // [nq][counts_stride] scores of score_bytes (1 or 2) bytes
     const uint32_t* thresholds;  // per query or nullptr (= 0)
-    uint2* out;                  // [nq][k] (doc, score), unordered within a query
+    uint2* out;                  // [nq][k] (doc, score); ordered (score desc, doc asc) when at most sort_limit survive
     uint32_t* out_count;         // [nq] entries written (<= k)
     uint64_t counts_stride;
     uint64_t counts_offset;      // first local slot of this file in a row
@@ -85,9 +85,11 @@ struct TopkArgs {
     uint32_t num_docs;           // real documents of the file
     uint32_t k;
     uint32_t nq;
-    uint32_t score_bits;         // scores are < 2^score_bits (the scan kernel's plane count, <= 16)
-    uint32_t shift1;             // level 1 bins = score >> shift1 (at most 4096), level 2 = the low shift1 bits
-    uint32_t score_bytes;        // 1 (planes <= 8) or 2
+    uint32_t score_bits;         // scores are < 2^score_bits (the scan kernel's plane count, <= 32)
+    uint32_t level_bits;         // histogram bits per radix level (<= 12)
+    uint32_t levels;             // ceil(score_bits / level_bits): 1, 2 or 3
+    uint32_t score_bytes;        // 1 (planes <= 8), 2 (<= 16) or 4
+    uint32_t sort_limit;         // order the survivors on the device when there are at most this many (0 = never)
 };
 
 // Arguments of the construction kernel: set the signature bits of documents.

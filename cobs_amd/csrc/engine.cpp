@@ -157,6 +157,9 @@ uint64_t slice_bytes(uint64_t sig, uint64_t ncols, const Tuning& tune) {
 // Tuning hooks (per handle): tile_w, waves, mq force a value.
 struct ScanGeom { uint32_t tile_w; int nwaves; bool multi_query; };
 
+// K3 orders up to this many survivors per (query, file) on the device (8-byte keys in 64 KB of LDS)
+constexpr size_t kTopkSortLimit = 8192;
+
 ScanGeom scan_geometry(const Chunk& c, uint64_t mean_blocks, uint64_t max_blocks, uint64_t num_hashes,
                        uint32_t forced_waves, int planes, bool idx64, const Tuning& tune) {
     uint32_t nv = 1;
@@ -1091,10 +1094,11 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
     b->topk_stride = 0;
     b->threshold = threshold;
     const size_t nq = b->nq;
-    // K3 (exact top-k on the device) needs u16 scores and a bounded k
-    const bool use_topk = topk > 0 && b->elem_bytes <= 2 && topk <= 65536 &&
+    // K3 (exact top-k on the device, every score width) needs a bounded k
+    const bool use_topk = topk > 0 && topk <= 65536 &&
                           (uint64_t)topk * std::max<size_t>(nq, 1) * ix->parts.size() <= (1ull << 27);
     b->topk_k = use_topk ? (uint32_t)topk : 0;
+    b->topk_sorted = use_topk && topk <= kTopkSortLimit;
     // with K3 the threshold is applied there; otherwise K2 selects into the hit pool
     b->selected = threshold > 0.0 && !use_topk;
     b->have_counts = want_counts || !b->selected;
@@ -1221,7 +1225,9 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
             ta.k = (uint32_t)topk;
             ta.nq = (uint32_t)nq;
             ta.score_bits = (uint32_t)b->planes;
-            ta.shift1 = b->planes > 12 ? (uint32_t)(b->planes - 12) : 0u;
+            ta.levels = ((uint32_t)b->planes + 11u) / 12u;                       // radix levels of <= 12 bits
+            ta.level_bits = ((uint32_t)b->planes + ta.levels - 1u) / ta.levels;
+            ta.sort_limit = topk <= kTopkSortLimit ? (uint32_t)topk : 0u;        // survivors ordered on the device
             HIP_TRY(launch_topk(ta, st));
         }
     }
@@ -1441,6 +1447,16 @@ static cobs_gpu_status hits_host_impl(cobs_gpu_batch* b, size_t q, size_t num_re
             b->topk_fetched = true;
         }
         const size_t stride = b->topk_stride ? b->topk_stride : k;     // ranks * k after an exchange
+        if (nparts == 1 && b->topk_sorted && !b->topk_stride) {
+            // one file, one shard: K3 already left the survivors in result order
+            const uint2* e = b->h_topk.data() + q * k;
+            const size_t want1 = std::min<size_t>(std::min<size_t>(num_results, (size_t)ix->total_counts), b->h_topk_cnt[q]);
+            *n_hits = want1;
+            if (want1 > cap) return fail(COBS_GPU_ERR_CAPACITY, "hit buffer too small");
+            if (want1 && !hits) return fail(COBS_GPU_ERR_ARG, "NULL hit buffer");
+            for (size_t i = 0; i < want1; ++i) hits[i] = cobs_gpu_hit{0u, e[i].x, e[i].y};
+            return COBS_GPU_OK;
+        }
         for (size_t f = 0; f < nparts; ++f) {
             const uint2* e = b->h_topk.data() + (f * b->nq + q) * stride;
             const uint32_t cnt = b->h_topk_cnt[f * b->nq + q];

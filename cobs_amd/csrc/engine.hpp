@@ -218,6 +218,7 @@ struct cobs_gpu_batch {
     std::vector<uint32_t> h_topk_cnt;
     uint32_t topk_k = 0;              // k of the last run (0 = K3 not run)
     bool topk_fetched = false;
+    bool topk_sorted = false;         // K3 ordered the survivors of every (query, file) on the device
     // device flags: word 0 = first invalid query (2^32-1 - q, 0 = none), words 2..3 = 64-bit fill
     // of the hit pool (may exceed hit_cap: overflow)
     cobs_amd::DevBuf<uint32_t> flags;

@@ -23,6 +23,7 @@
 //   synth_kernel / repitch_kernel   index staging helpers.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 
@@ -797,10 +798,13 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
 
 // ---------------------------------------------------------------------------
 // K3: exact top-k selection per query (the device side of counts_to_result's
-// partial_sort, reference classic_search.cpp:127-145): find the score s* of the
-// k-th best document with a two-level radix histogram, emit every document with
-// score > s* and, in ascending document order, as many documents with score == s*
-// as are still needed.  The host only has to order the k survivors.
+// partial_sort, reference classic_search.cpp:127-145, for all three Score widths of
+// :453-504): find the score s* of the k-th best document with a radix descent over the
+// score bits (histogram levels of at most 12 bits each: one level for 8/10/12-bit scores,
+// two up to 24 bits, three for 32-bit scores), emit every document with score > s* and, in
+// ascending document order, as many documents with score == s* as are still needed, then
+// order the <= k survivors by (score desc, document asc) in LDS (bitonic sort on
+// (~score, doc) keys) -- the host copies the result as is.
 // One work-group (4 waves) per query; wave w owns the contiguous quarter w of the
 // documents so that ballot prefixes keep document order.
 
@@ -819,31 +823,34 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane, ui
     return incl - v;
 }
 
-// Dynamic LDS: hist1[4][NB1] | hist2[4][NB2] | partial[256] | sh[16]; one histogram
-// copy per wave (fewer same-address atomics, and the per-wave tie counts fall out).
-// eight consecutive scores (u8 or u16) starting at document i (a multiple of 8)
+// eight consecutive scores (u8, u16 or u32) starting at document i (a multiple of 8)
 template <typename ST>
 __device__ __forceinline__ void load_scores8(const ST* row, uint32_t i, uint32_t (&s)[8]) {
     if constexpr (sizeof(ST) == 1) {
         const uint2 v = *reinterpret_cast<const uint2*>(row + i);
 #pragma unroll
         for (int j = 0; j < 8; ++j) s[j] = ((j < 4 ? v.x : v.y) >> ((j & 3) * 8)) & 0xFFu;
-    } else {
+    } else if constexpr (sizeof(ST) == 2) {
         const uint4 v = *reinterpret_cast<const uint4*>(row + i);
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) s[j] = (w[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+    } else {
+        const uint4 a = *reinterpret_cast<const uint4*>(row + i);
+        const uint4 b = *reinterpret_cast<const uint4*>(row + i + 4);
+        s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
+        s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
     }
 }
 
+// Dynamic LDS: hist[4 waves][NB] (NB = 2^level_bits <= 4096; reused by every level and, after
+// the emission, as the sort buffer: 8192 eight-byte keys) | partial[256] | sh[16]
 template <typename ST>
 __global__ __launch_bounds__(256) void topk_kernel(TopkArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t sh1 = a.shift1;
-    const uint32_t NB1 = 1u << (a.score_bits - sh1), NB2 = 1u << sh1, lomask = NB2 - 1u;
-    uint32_t* hist1 = reinterpret_cast<uint32_t*>(smem);
-    uint32_t* hist2 = hist1 + 4u * NB1;
-    uint32_t* partial = hist2 + 4u * NB2;
+    const uint32_t NB = 1u << a.level_bits;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
+    uint32_t* partial = hist + 4u * NB;
     uint32_t* sh = partial + 256;
     const uint32_t q = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -859,58 +866,16 @@ __global__ __launch_bounds__(256) void topk_kernel(TopkArgs a) {
     const uint32_t w0 = wave * per < n ? wave * per : n;
     const uint32_t w1 = w0 + per < n ? w0 + per : n;
 
-    for (uint32_t i = tid; i < 4u * NB1 + 4u * NB2; i += 256) hist1[i] = 0;
-    __syncthreads();
-    // ---- level 1 histogram (score >> shift1) over passing documents
-    uint32_t* myh1 = hist1 + wave * NB1;
-    for (uint32_t i0 = w0; i0 < w1; i0 += 512) {
-        const uint32_t i = i0 + lane * 8u;
-        if (i < w1) {
-            uint32_t sc[8];
-            load_scores8<ST>(row, i, sc);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint32_t s = sc[j];
-                if (i + j < w1 && s >= thr) atomicAdd(&myh1[s >> sh1], 1u);
-            }
-        }
-    }
-    __syncthreads();
-    {   // parallel search of the bin holding the k-th best: per-thread segment sums, then thread 0
-        const uint32_t seg = (NB1 + 255u) / 256u;
-        uint32_t sum = 0;
-        for (uint32_t b = tid * seg; b < (tid + 1) * seg && b < NB1; ++b)
-            sum += hist1[b] + hist1[NB1 + b] + hist1[2 * NB1 + b] + hist1[3 * NB1 + b];
-        partial[tid] = sum;
+    // ---- radix descent: after level l the top (l+1)*level_bits bits of s* are known
+    uint32_t prefix = 0, n_above = 0, take_all = 0;
+    uint32_t bits_left = a.score_bits;           // bits below the known prefix
+    uint32_t* myh = hist + wave * NB;
+    for (uint32_t level = 0; level < a.levels; ++level) {
+        const uint32_t lb = bits_left < a.level_bits ? bits_left : a.level_bits;     // bits of this level
+        const uint32_t shift = bits_left - lb;
+        const uint32_t nb = 1u << lb, mask = nb - 1u;
+        for (uint32_t i = tid; i < 4u * NB; i += 256) hist[i] = 0;
         __syncthreads();
-        if (tid == 0) {
-            uint32_t above = 0;
-            int t = 255;
-            for (; t >= 0; --t) {
-                if (above + partial[t] >= k) break;
-                above += partial[t];
-            }
-            int hb = -1;
-            if (t >= 0) {
-                int b = (int)((uint32_t)(t + 1) * seg) - 1;
-                if (b >= (int)NB1) b = (int)NB1 - 1;
-                for (; b >= (int)((uint32_t)t * seg); --b) {
-                    const uint32_t c = hist1[b] + hist1[NB1 + b] + hist1[2 * NB1 + b] + hist1[3 * NB1 + b];
-                    if (above + c >= k) { hb = b; break; }
-                    above += c;
-                }
-            }
-            sh[0] = hb < 0 ? 0u : (uint32_t)hb;
-            sh[1] = above;
-            sh[2] = hb < 0 ? 1u : 0u;            // fewer than k passing documents: take them all
-        }
-        __syncthreads();
-    }
-    const uint32_t hb = sh[0], take_all = sh[2];
-    uint32_t n_above = sh[1], cut = hb << sh1;
-    // ---- level 2 (only for scores wider than 12 bits): low bits inside bin hb
-    if (sh1 > 0 && !take_all) {
-        uint32_t* myh2 = hist2 + wave * NB2;
         for (uint32_t i0 = w0; i0 < w1; i0 += 512) {
             const uint32_t i = i0 + lane * 8u;
             if (i < w1) {
@@ -919,32 +884,59 @@ __global__ __launch_bounds__(256) void topk_kernel(TopkArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const uint32_t s = sc[j];
-                    if (i + j < w1 && s >= thr && (s >> sh1) == hb) atomicAdd(&myh2[s & lomask], 1u);
+                    // the bits above this level must equal the prefix found so far
+                    const bool in = level == 0 || (bits_left >= 32u ? true : (s >> bits_left) == prefix);
+                    if (i + j < w1 && s >= thr && in) atomicAdd(&myh[(s >> shift) & mask], 1u);
                 }
             }
         }
         __syncthreads();
-        if (tid == 0) {
-            uint32_t above = n_above;
-            int b = (int)NB2 - 1;
-            for (; b > 0; --b) {
-                const uint32_t c = hist2[b] + hist2[NB2 + b] + hist2[2 * NB2 + b] + hist2[3 * NB2 + b];
-                if (above + c >= k) break;
-                above += c;
+        {   // parallel search of the bin holding the k-th best: per-thread segment sums, then thread 0
+            const uint32_t seg = (nb + 255u) / 256u;
+            uint32_t sum = 0;
+            for (uint32_t b = tid * seg; b < (tid + 1) * seg && b < nb; ++b)
+                sum += hist[b] + hist[NB + b] + hist[2 * NB + b] + hist[3 * NB + b];
+            partial[tid] = sum;
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t above = n_above;
+                int t = 255;
+                for (; t >= 0; --t) {
+                    if (above + partial[t] >= k) break;
+                    above += partial[t];
+                }
+                int hb = -1;
+                if (t >= 0) {
+                    int b = (int)((uint32_t)(t + 1) * seg) - 1;
+                    if (b >= (int)nb) b = (int)nb - 1;
+                    for (; b >= (int)((uint32_t)t * seg); --b) {
+                        const uint32_t c = hist[b] + hist[NB + b] + hist[2 * NB + b] + hist[3 * NB + b];
+                        if (above + c >= k) { hb = b; break; }
+                        above += c;
+                    }
+                }
+                sh[0] = hb < 0 ? 0u : (uint32_t)hb;
+                sh[1] = above;
+                sh[2] = hb < 0 ? 1u : 0u;        // fewer than k passing documents: take them all
             }
-            sh[3] = (uint32_t)b;
-            sh[4] = above;
+            __syncthreads();
         }
-        __syncthreads();
-        cut = (hb << sh1) | sh[3];
-        n_above = sh[4];
+        const uint32_t hb = sh[0];
+        n_above = sh[1];
+        take_all = sh[2];
+        prefix = (lb >= 32u ? 0u : (prefix << lb)) | hb;
+        bits_left = shift;
+        if (take_all) break;                     // only possible at level 0 (block-uniform)
+        if (level + 1 < a.levels) __syncthreads();        // hist is zeroed again
     }
-    if (take_all) cut = thr;
-    // ties: documents with score == cut, per wave (falls out of the per-wave histograms)
+    uint32_t cut = take_all ? thr : prefix;
+    // ties: documents with score == cut, per wave (the last level's per-wave histogram bins)
     uint32_t eq_base = 0, eq_total = 0;
     if (!take_all) {
+        const uint32_t lastbits = a.score_bits - (a.levels - 1u) * a.level_bits;
+        const uint32_t bin = cut & ((lastbits >= 32u ? 0u : (1u << lastbits)) - 1u);
         for (uint32_t w = 0; w < 4; ++w) {
-            const uint32_t c = sh1 > 0 ? hist2[w * NB2 + (cut & lomask)] : hist1[w * NB1 + hb];
+            const uint32_t c = hist[w * NB + bin];
             if (w < wave) eq_base += c;
             eq_total += c;
         }
@@ -993,8 +985,39 @@ __global__ __launch_bounds__(256) void topk_kernel(TopkArgs a) {
         }
     }
     __syncthreads();
-    if (tid == 0)
-        a.out_count[q] = take_all ? sh[5] : n_above + (eq_total < need_eq ? eq_total : need_eq);
+    const uint32_t cnt = take_all ? sh[5] : n_above + (eq_total < need_eq ? eq_total : need_eq);
+    if (tid == 0) a.out_count[q] = cnt;
+    // ---- order the survivors: (score desc, doc asc) = ascending (~score << 32 | doc)
+    if (a.sort_limit && cnt > 1u && cnt <= a.sort_limit) {      // block-uniform condition
+        __syncthreads();                          // everybody has read sh[]: the key area may overlap it
+        unsigned long long* key = reinterpret_cast<unsigned long long*>(smem);
+        uint32_t m = 2;
+        while (m < cnt) m <<= 1;
+        for (uint32_t i = tid; i < m; i += 256) {
+            unsigned long long kv = ~0ull;        // padding sorts last
+            if (i < cnt) {
+                const uint2 e = out[i];
+                kv = ((unsigned long long)(~e.y) << 32) | e.x;
+            }
+            key[i] = kv;
+        }
+        __syncthreads();
+        for (uint32_t size = 2; size <= m; size <<= 1) {
+            for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                for (uint32_t t = tid; t < (m >> 1); t += 256) {
+                    const uint32_t lo = (t / stride) * (stride << 1) + (t % stride), hi = lo + stride;
+                    const bool up = ((lo & size) == 0u);
+                    const unsigned long long x = key[lo], y = key[hi];
+                    if ((x > y) == up) { key[lo] = y; key[hi] = x; }
+                }
+                __syncthreads();
+            }
+        }
+        for (uint32_t i = tid; i < cnt; i += 256) {
+            const unsigned long long kv = key[i];
+            out[i] = make_uint2((uint32_t)kv, ~(uint32_t)(kv >> 32));
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1239,10 +1262,18 @@ hipError_t launch_scan(const ScanArgs& a, uint32_t ntiles, int planes, int nw, b
 
 hipError_t launch_topk(const TopkArgs& a, hipStream_t stream) {
     if (a.nq == 0 || a.k == 0) return hipSuccess;
-    const uint32_t nb1 = 1u << (a.score_bits - a.shift1), nb2 = 1u << a.shift1;
-    const size_t lds = (size_t)(4 * nb1 + 4 * nb2 + 256 + 16) * sizeof(uint32_t);
-    auto kern = a.score_bytes == 1 ? topk_kernel<uint8_t> : topk_kernel<uint16_t>;
-    if (a.score_bytes != 1 && a.score_bytes != 2) return hipErrorInvalidValue;
+    if (a.level_bits == 0 || a.level_bits > 12 || a.levels == 0 || a.levels * a.level_bits < a.score_bits ||
+        (a.levels - 1) * a.level_bits >= a.score_bits)
+        return hipErrorInvalidValue;
+    const uint32_t nb = 1u << a.level_bits;
+    size_t lds = (size_t)(4 * nb + 256 + 16) * sizeof(uint32_t);
+    // the sort reuses the histogram area: 8 bytes per survivor
+    uint32_t m = 2;
+    while (m < a.sort_limit) m <<= 1;
+    if (a.sort_limit) lds = std::max(lds, (size_t)m * 8);
+    auto kern = a.score_bytes == 1 ? topk_kernel<uint8_t> : a.score_bytes == 2 ? topk_kernel<uint16_t> : topk_kernel<uint32_t>;
+    if (a.score_bytes != 1 && a.score_bytes != 2 && a.score_bytes != 4) return hipErrorInvalidValue;
+    if (lds > 64 * 1024 + 2048) return hipErrorInvalidValue;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

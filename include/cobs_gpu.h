@@ -246,8 +246,8 @@ cobs_gpu_status cobs_gpu_batch_run_hits(cobs_gpu_batch* b, double threshold, voi
 /* The same pass followed by K3: on-device selection of the num_results best
  * documents per query (score descending, ties by document ascending -- the set
  * std::partial_sort keeps, classic_search.cpp:134-145) among those with
- * count >= ceil(threshold * T); cobs_gpu_batch_hits_host then moves only those.
- * Falls back to the plain pass when scores are 32-bit (T >= 65535).            */
+ * count >= ceil(threshold * T), left in result order on the device (all score widths: 8, 16 and
+ * 32 bit); cobs_gpu_batch_hits_host then moves only those.                      */
 cobs_gpu_status cobs_gpu_batch_run_topk(cobs_gpu_batch* b, double threshold, size_t num_results,
                                         void* hip_stream);
 /* wait for the stream and fetch device-side error flags (invalid bases, ...) */

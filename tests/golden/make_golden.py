@@ -24,6 +24,8 @@ from oracle import construct as K  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 Q50 = b"AGTCAACGCTAAGGCATTTCCCCCCTGCCTCCTGCCTGCTGCCAAGCCCT"
+SHA256 = {"c1.cobs_classic": "3861d48c2bc4ea301111cd0b221b39f6833b3d05a076988c313b37ca73306266",
+          "c1.cobs_compact": "2e3a36b5488de5b219d40ef9a6968d4715d81ed9bb950fa22962913d6377f929"}
 
 
 def main():
@@ -34,6 +36,11 @@ def main():
     page_size, params = K.compact_construct(docs, pk)
     assert sig == 8748 and os.path.getsize(pc) == 8864
     assert page_size == 8 and params == [(8748, 1)] and os.path.getsize(pk) == 70112
+    # any drift of oracle/construct.py is loud: the committed fixtures are these exact bytes
+    import hashlib
+    for p, want in ((pc, SHA256["c1.cobs_classic"]), (pk, SHA256["c1.cobs_compact"])):
+        got = hashlib.sha256(open(p, "rb").read()).hexdigest()
+        assert got == want, (p, got)
     exp = {"query": Q50.decode(), "classic": {}, "compact": {}}
     for key, p in (("classic", pc), ("compact", pk)):
         ix = O.Index.open(p)

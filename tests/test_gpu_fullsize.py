@@ -36,9 +36,18 @@ def test_full_size_config(gpu_lib, oracle, name):
     b.run(0.0)
     b.sync()
     T = 1000
-    # sampled exact equality (the oracle regenerates the ~8000 rows a query touches)
-    for i in (0, 1, nq // 2, nq - 1):
-        assert np.array_equal(b.counts_host(i), ix.counts(queries[i]))
+    # exact equality of EVERY query's score row with the oracle (which regenerates the ~8000
+    # procedural rows a query touches), plus device-side row checksums against oracle checksums
+    import torch
+    t_all = b.counts_tensor().to(torch.int64).bitwise_and(0xFFFF)
+    w = (torch.arange(t_all.shape[1], device=t_all.device, dtype=torch.int64) % 1021) + 1
+    dev_sum = t_all.sum(dim=1).cpu().numpy()
+    dev_wsum = (t_all * w).sum(dim=1).cpu().numpy()
+    wn = (np.arange(t_all.shape[1], dtype=np.int64) % 1021) + 1
+    for i in range(nq):
+        want = ix.counts(queries[i])
+        assert np.array_equal(b.counts_host(i), want), (name, i)
+        assert int(dev_sum[i]) == int(want.sum()) and int(dev_wsum[i]) == int((want.astype(np.int64) * wn).sum())
     # a few rows of the index itself, incl. the last row of the largest sub-index
     P = len(cfg["signature_sizes"])
     width = cfg["page_size"] if cfg["kind"] == "compact" else (cfg["num_docs"] + 7) // 8
@@ -107,7 +116,16 @@ def test_full_size_short_reads(gpu_lib, oracle, bp):
         b.sync()
         t = b.counts_tensor()
         assert t.dtype == torch.uint8 and tuple(t.shape) == (nq, s.local_counts)
-        for i in (0, 1, 7, 8, nq // 2, nq - 2, nq - 1):
+        # every read of the batch: device-side row checksums against the oracle's, exact rows for 64
+        tt = t.to(torch.int64)
+        w = (torch.arange(tt.shape[1], device=tt.device, dtype=torch.int64) % 1021) + 1
+        dev_sum, dev_wsum = tt.sum(dim=1).cpu().numpy(), (tt * w).sum(dim=1).cpu().numpy()
+        wn = (np.arange(tt.shape[1], dtype=np.int64) % 1021) + 1
+        step = max(1, nq // 512)
+        for i in list(range(0, nq, step)) + [1, 7, 8, nq - 2, nq - 1]:
+            want = ix.counts(qs[i])
+            assert int(dev_sum[i]) == int(want.sum()) and int(dev_wsum[i]) == int((want.astype(np.int64) * wn).sum()), (bp, i)
+        for i in list(range(0, nq, nq // 57)) + [1, 7, 8, nq // 2, nq - 2, nq - 1]:
             assert np.array_equal(b.counts_host(i), ix.counts(qs[i])), (bp, i)
         terms = torch.tensor([len(q) - k + 1 for q in qs], device=t.device)
         assert bool((t.max(dim=1).values.to(torch.int64) <= terms).all())

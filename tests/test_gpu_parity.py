@@ -254,7 +254,7 @@ def test_device_topk_matches_partial_sort(gpu_lib, oracle, tmp_path):
     b = gpu_lib.Batch(s)
     b.set_queries(queries)
     for t in (0.0, 0.31, 0.9):
-        for k in (1, 7, 100, 5000):
+        for k in (1, 7, 100, 5000, 8192, 8500):       # beyond 8192 survivors the host orders them
             b.run_topk(t, k)
             b.sync()
             for i, q in enumerate(queries):
@@ -283,6 +283,20 @@ def test_long_queries_u32_scores(gpu_lib, oracle, tmp_path):
         assert s.search_hits([q], 0.0, 0)[0] == cases.oracle_results([ix], q, 0.0, 0)
     q = oracle.random_sequence(17000000, 99)          # T > 2^24: 32 planes
     assert np.array_equal(s.counts(q), ix.counts(q))
+    # K3 over 32-bit scores (three radix levels), survivors ordered on the device: num_results > 0
+    # never ships score rows (reference: the uint32_t instantiation of counts_to_result, :134-145)
+    for length in (70000 + 30, 1100000 + 30):
+        qs = [oracle.random_sequence(length, length + j) for j in range(3)]
+        for srch, idx in ((s, ix), (sk, ixk)):
+            b = gpu_lib.Batch(srch)
+            b.set_queries(qs)
+            for t, k in ((0.0, 1), (0.0, 9), (0.3, 40), (0.0, 1000)):
+                b.run_topk(t, k)
+                b.sync()
+                assert b.counts_device()[1] == 4
+                for i, qq in enumerate(qs):
+                    assert b.hits_host(i, k) == cases.oracle_results([idx], qq, t, k), (length, t, k, i)
+            assert srch.search_hits(qs, 0.0, 6) == [cases.oracle_results([idx], qq, 0.0, 6) for qq in qs]
 
 
 def test_empty_and_minimal_batches(gpu_lib, oracle, golden_dir):
@@ -498,3 +512,65 @@ def test_no_device_memory_leak(gpu_lib, oracle, tmp_path):
         torch.cuda.synchronize()
         free1, _ = torch.cuda.mem_get_info()
         assert free0 - free1 < (32 << 20), (budget, free0, free1)
+
+
+def test_indexes_with_different_term_sizes(gpu_lib, oracle, tmp_path):
+    """several index files whose term sizes differ (reference classic_search.cpp:413-449): length
+    check against the largest k, per-file thresholds ceil(t * (len - k_i + 1)), max_counts over
+    all files; K1 runs once per file with that file's k (31 -> the unrolled kernel, 21 -> generic)"""
+    from cobs_amd import _capi
+    q = oracle.random_sequence(400, 91)
+    pa = cases.make_classic(cases.tmp(tmp_path, "k31.cobs_classic"), 90, 997, 1, 31, 1, 0.3, 1,
+                            planted={3: 1.0, 40: 0.6}, query=q)
+    pb = cases.make_compact(cases.tmp(tmp_path, "k21.cobs_compact"), 50, 2, [1201, 1301, 1409, 1511], 2, 21, 1, 0.3, 2,
+                            planted={7: 1.0, 11: 0.5}, query=q)
+    pc = cases.make_classic(cases.tmp(tmp_path, "k25.cobs_classic"), 17, 733, 1, 25, 0, 0.3, 3)
+    ixs = [oracle.Index.open(p) for p in (pa, pb, pc)]
+    s = gpu_lib.Search([pa, pb, pc])
+    assert [s.info(f).term_size for f in range(3)] == [31, 21, 25]
+    queries = [q[:31], q[:100], q[:270], q[:275], q[50:321], q[:286], q]
+    for t, lim in ((0.0, 0), (0.5, 0), (0.55, 3), (0.0, 5), (1.0, 0)):
+        got = s.search_hits(queries, t, lim)
+        assert got == [cases.oracle_results(ixs, qq, t, lim) for qq in queries], (t, lim)
+    b = gpu_lib.Batch(s)
+    b.set_queries(queries)
+    b.run(0.0)
+    b.sync()
+    for i, qq in enumerate(queries):
+        assert np.array_equal(b.counts_host(i), np.concatenate([ix.counts(qq) for ix in ixs]))
+    # shorter than the largest term size: the reference exits with "query too short" (:431-433)
+    with pytest.raises(gpu_lib.CobsGpuError) as e:
+        s.search_hits([q[:100], q[:30]], 0.0, 0)
+    assert e.value.status == _capi.ERR_QUERY_TOO_SHORT and "(query 1)" in str(e.value) and "31" in str(e.value)
+    # Deviation, on purpose: for 255 <= len - k_min and len - k_max < 255 the reference picks 8-bit
+    # scores from the LARGEST term size (:453) and then dies in the file with the smaller one
+    # ("query too long", :323-327) although the query is legal.  The engine sizes the scores by
+    # the file with the most terms and answers: per-file counts equal the oracle's.
+    for ln in (276, 280, 285):
+        with pytest.raises(oracle.OracleError):
+            oracle.search(ixs, q[:ln])
+        got = s.counts(q[:ln])
+        assert np.array_equal(got, np.concatenate([ix.counts(q[:ln]) for ix in ixs]))
+
+
+def test_topk_single_file_is_ordered_on_the_device(gpu_lib, oracle, tmp_path):
+    """one file: K3's output is the result, in order -- every score width, ties at the cut,
+    fewer passing documents than k, k larger than the index"""
+    q_long = oracle.random_sequence(700, 13)
+    D = 9000
+    planted = {d: f for d, f in zip(range(5, D, 211), np.linspace(0.1, 1.0, 43))}
+    p = cases.make_compact(cases.tmp(tmp_path, "tk1.cobs_compact"), D, 160, [900, 1100, 1300, 1500, 1700, 1900, 2100, 2300],
+                           1, 31, 1, 0.3, 21, planted=planted, query=q_long)
+    s = gpu_lib.Search(p)
+    ix = oracle.Index.open(p)
+    for queries in ([q_long[:36], q_long[:50], q_long[:33]],             # 8-bit scores, many ties
+                    [q_long, q_long[100:400], q_long[:31]]):            # 16-bit scores
+        b = gpu_lib.Batch(s)
+        b.set_queries(queries)
+        for t in (0.0, 0.31, 0.9, 1.0):
+            for k in (1, 2, 7, 64, 100, 4097, 8192, 20000):
+                b.run_topk(t, k)
+                b.sync()
+                for i, q in enumerate(queries):
+                    assert b.hits_host(i, k) == cases.oracle_results([ix], q, t, k), (t, k, i)
+                    assert b.hits_host(i, 1) == cases.oracle_results([ix], q, t, 1)

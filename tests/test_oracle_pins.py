@@ -268,3 +268,114 @@ def test_survey_probe_hand_built_20_documents(oracle, construct, tmp_path):
         res = oracle.search(ix, q)
         assert [(n, s) for (_, _, n, s) in res] == sorted(zip(names, want), key=lambda t: (-t[1], t[0]))
         assert ix.counts(q)[:20].tolist() == want
+
+
+def test_golden_fixture_hashes(golden_dir):
+    """the committed index fixtures are the exact bytes tests/golden/make_golden.py pins"""
+    import hashlib
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(golden_dir, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    for name, want in mg.SHA256.items():
+        assert hashlib.sha256(open(os.path.join(golden_dir, name), "rb").read()).hexdigest() == want, name
+
+
+def test_header_writers_follow_the_reference_file_tests(oracle, construct, tmp_path):
+    """/root/reference/tests/file.cpp:37-142 restated: what the header writers serialize, the
+    readers (the oracle's and, for geometry, libcobs_gpu's host-side parser) give back; the byte
+    layout is the one of cobs/file/classic_index_header.cpp:26-37 and
+    compact_index_header.cpp:20-43, spelled out here independently."""
+    import struct
+    # file.cpp:37-60 classic_index_header, :62-90 classic_index (payload bytes all 7)
+    names = ["n1", "n2", "n3", "n4"]
+    p = str(tmp_path / "h.cobs_classic")
+    m = np.full((123, 1), 7, dtype=np.uint8)
+    construct.write_classic(p, 31, 1, names, 123, 12, m)
+    raw = open(p, "rb").read()
+    want = (b"COBS:CLASSIC_INDEX" + struct.pack("<I", 1) + struct.pack("<I", 31) + struct.pack("<B", 1)
+            + struct.pack("<I", 4) + struct.pack("<Q", 123) + struct.pack("<Q", 12)
+            + b"n1\nn2\nn3\nn4\n" + b"CLASSIC_INDEX" + bytes([7]) * 123)
+    assert raw == want
+    ix = oracle.Index.open(p)
+    assert (ix.term_size, ix.canonicalize, ix.num_hashes, ix.num_docs, ix.row_size) == (31, 1, 12, 4, 1)
+    assert [ix.doc_name(i) for i in range(4)] == names and ix.signature_size(0) == 123
+    assert ix.data_offset == len(want) - 123
+    # file.cpp:92-120 compact_index_header_values: three (signature_size, num_hashes) parameters
+    pk = str(tmp_path / "h.cobs_compact")
+    params = [(100, 1), (200, 1), (3000, 1)]
+    fnames = ["file_1", "file_2", "file_3"]
+    mats = [np.zeros((s, 4096), dtype=np.uint8) for s, _ in params]
+    construct.write_compact(pk, 31, 1, 4096, params, fnames, mats)
+    raw = open(pk, "rb").read()
+    head = (b"COBS:COMPACT_INDEX" + struct.pack("<IIBIIQ", 1, 31, 1, 3, 3, 4096)
+            + b"".join(struct.pack("<QQ", s, h) for s, h in params) + b"file_1\nfile_2\nfile_3\n")
+    assert raw.startswith(head)
+    ix = oracle.Index.open(pk)
+    assert [ix.signature_size(i) for i in range(3)] == [100, 200, 3000] and ix.num_hashes == 1
+    assert [ix.doc_name(i) for i in range(3)] == fnames and ix.page_size == 4096
+    # file.cpp:122-142 compact_index_header_padding: the matrix starts at a multiple of page_size,
+    # the bytes between the names and the closing magic word are zero
+    assert ix.data_offset % 4096 == 0 and raw[ix.data_offset - 13:ix.data_offset] == b"COMPACT_INDEX"
+    assert not any(raw[len(head):ix.data_offset - 13])
+    for ps, nn in ((8, 1), (8, 5), (16, 3), (4096, 0), (24, 7)):
+        h = construct.compact_header(31, 1, ps, [(10, 1)], ["x" * (3 + i) for i in range(nn)])
+        assert len(h) % ps == 0 and h.endswith(b"COMPACT_INDEX")
+    # the engine's own host-side parser agrees on the geometry (no device needed)
+    from cobs_amd import _capi
+    import ctypes as C
+    for path, total in ((p, 8), (pk, 3 * 8 * 4096)):
+        b, c = (C.c_uint64 * 1)(), (C.c_uint64 * 1)()
+        _capi.check(_capi.load().cobs_gpu_plan_shards(path.encode(), 1, 0, b, c, None))
+        assert (b[0], c[0]) == (0, total)
+
+
+def test_bit_layout_of_constructed_index(oracle, construct, tmp_path):
+    """/root/reference/tests/classic_index_construction.cpp:39-85 restated: 33 documents from
+    generate_documents_all, 3 hashes, fpr 0.1; document i is bit i % 8 of byte i / 8 of a row
+    (classic_index.cpp:40-43), and no document holds more ones than the expected fill * 1.01"""
+    query = oracle.random_sequence(10000, 1)
+    docs = construct.generate_documents_all(query, 33, num_hashes=3)
+    p = str(tmp_path / "cons.cobs_classic")
+    sig = construct.classic_construct(docs, p, num_hashes=3, false_positive_rate=0.1)
+    ix = oracle.Index.open(p)
+    assert ix.num_docs == 33 and ix.num_hashes == 3 and ix.row_size == 5
+    raw = np.frombuffer(open(p, "rb").read(), dtype=np.uint8)[ix.data_offset:].reshape(sig, 5)
+    bits = np.unpackbits(raw, axis=1, bitorder="little")[:, :33]          # bit o of byte k = document 8k + o
+    ones = bits.sum(axis=0)
+    # calc_average_set_bit_ratio(signature_size, 3, 0.1) (util/calc_signature_size.cpp:36-48)
+    max_terms = max(d.num_terms for d in docs)
+    ratio = 1.0 - (1.0 - 1.0 / sig) ** (3 * max_terms)
+    assert ones.max() <= ratio * sig * 1.01
+    # every bit of a document is at one of its own hash rows, and every hash row carries its bit
+    for j in (0, 1, 7, 8, 15, 16, 32):
+        rows = np.unique(docs[j].hashes.reshape(-1) % np.uint64(sig)).astype(np.int64)
+        assert bits[rows, j].all()
+        assert ones[j] == len(rows)
+    # documents beyond 33 (padding bits of the last byte) carry nothing
+    assert not np.unpackbits(raw, axis=1, bitorder="little")[:, 33:].any()
+
+
+def test_indexes_with_different_term_sizes(oracle, tmp_path):
+    """ClassicSearch over files with different term sizes (classic_search.cpp:413-449): the
+    query must be as long as the LARGEST term size, every file gets its own threshold
+    ceil(threshold * (len - k_i + 1)), max_counts is the sum of all files' hashes"""
+    q = oracle.random_sequence(260, 91)
+    pa = cases.make_classic(cases.tmp(tmp_path, "k31.cobs_classic"), 90, 997, 1, 31, 1, 0.3, 1,
+                            planted={3: 1.0, 40: 0.6}, query=q)
+    pb = cases.make_classic(cases.tmp(tmp_path, "k21.cobs_classic"), 50, 1201, 2, 21, 1, 0.3, 2,
+                            planted={7: 1.0, 11: 0.5}, query=q)
+    a, b = oracle.Index.open(pa), oracle.Index.open(pb)
+    for qq in (q, q[:31], q[:100]):
+        ca, cb = a.counts(qq), b.counts(qq)
+        assert ca[3] == len(qq) - 30 and cb[7] == len(qq) - 20            # planted documents hold every term
+        for t in (0.0, 0.5, 0.55, 1.0):
+            res = oracle.search([a, b], qq, t)
+            ta, tb = int(np.ceil(t * (len(qq) - 30))), int(np.ceil(t * (len(qq) - 20)))
+            want = [(0, d, int(s)) for d, s in enumerate(ca[:90]) if s >= ta] + \
+                   [(1, d, int(s)) for d, s in enumerate(cb[:50]) if s >= tb]
+            want.sort(key=lambda h: (-h[2], h[0], h[1]))
+            assert [(f, d, s) for (f, d, _n, s) in res] == want, (len(qq), t)
+    with pytest.raises(oracle.OracleError):
+        oracle.search([a, b], q[:30])          # shorter than the largest term size: "query too short"
+    oracle.search([b], q[:21])                 # fine for the k = 21 file alone
