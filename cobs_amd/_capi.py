@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcobs_gpu.so")
+# COBS_GPU_LIBRARY selects another build of the same library (the tuning build with phase stamps)
+LIB_PATH = os.environ.get("COBS_GPU_LIBRARY") or os.path.join(_HERE, "libcobs_gpu.so")
 
 OK = 0
 ERR_OPEN, ERR_FORMAT, ERR_QUERY_TOO_SHORT, ERR_INVALID_BASE, ERR_QUERY_TOO_LONG = 1, 2, 3, 4, 5
@@ -102,6 +103,7 @@ SYMBOLS = {
     "cobs_gpu_batch_hits_host": (_int, [_vp, _sz, _sz, C.POINTER(Hit), _sz, C.POINTER(_sz)]),
     "cobs_gpu_batch_stats": (_int, [_vp, C.POINTER(_u64 * 4)]),
     "cobs_gpu_batch_kernel_ms": (_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "cobs_gpu_batch_phase_stamps": (_int, [_vp, _pu64, _sz, C.POINTER(_sz)]),
     "cobs_gpu_timers": (_int, [_vp, C.POINTER(C.c_double * 5), _int]),
     "cobs_gpu_comm_unique_id": (_int, [_vp]),
     "cobs_gpu_comm_create": (_int, [_vp, _int, _int, _int, C.POINTER(_vp)]),

@@ -70,6 +70,10 @@ struct ScanArgs {
     uint32_t chunk_begin;       // this launch covers column chunks [chunk_begin, chunk_end)
     uint32_t chunk_end;
     uint32_t idx64;             // 64-bit row indices in the table
+    uint32_t lds_staged;        // measured variant: rows travel HBM -> LDS -> VGPR (global_load_lds)
+    // tuning builds (COBS_SCAN_TIMING) only: s_memtime stamps [slot][wave 0..3][8] of every dbg_every-th work-group
+    uint64_t* dbg;
+    uint32_t dbg_every, dbg_slots;
 };
 
 // Arguments of the top-k selection kernel K3 for one index file.

@@ -66,6 +66,7 @@ Tuning Tuning::from_env() {
     if (const char* e = getenv("COBS_GPU_PIPE_CHARS")) t.pipe_chars = std::strtoull(e, nullptr, 10);
     if (getenv("COBS_GPU_NO_PIN")) t.no_pin = true;
     if (const char* e = getenv("COBS_GPU_GRAPH")) t.graph = atoi(e) != 0;
+    if (const char* e = getenv("COBS_GPU_LDS_STAGED")) t.lds_staged = atoi(e) != 0;
     return t;
 }
 
@@ -838,8 +839,12 @@ cobs_gpu_status cobs_gpu_set_tuning(cobs_gpu_index* ix, const char* key, int64_t
         t.pipe_chars = value < 0 ? 4ull << 20 : (uint64_t)value;
     } else if (k == "graph") {
         t.graph = value < 0 ? -1 : value != 0;
+    } else if (k == "lds_staged") {
+        t.lds_staged = value > 0;
+    } else if (k == "phase_slots") {
+        t.phase_slots = value > 0 ? (uint32_t)std::min<int64_t>(value, 1 << 20) : 0;
     } else {
-        return fail(COBS_GPU_ERR_ARG, "unknown tuning key (waves, tile_w, mq, pass_bytes, pipe_chars, graph)");
+        return fail(COBS_GPU_ERR_ARG, "unknown tuning key (waves, tile_w, mq, pass_bytes, pipe_chars, graph, lds_staged)");
     }
     return COBS_GPU_OK;
 }
@@ -1192,12 +1197,29 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                                                  p.meta.num_hashes, ix->waves_per_group, b->planes, p.idx64, ix->tune);
             const int nwaves = geom.nwaves;
             sa.tile_w = geom.tile_w;
+            sa.dbg = nullptr;
+            sa.dbg_every = 1;
+            sa.dbg_slots = 0;
+            if (ix->tune.phase_slots) {          // tuning builds: phase stamps of sampled work-groups (last launch wins)
+                HIP_TRY(b->phase.reserve((size_t)ix->tune.phase_slots * 32));
+                HIP_TRY(hipMemsetAsync(b->phase.p, 0, (size_t)ix->tune.phase_slots * 32 * 8, st));
+                sa.dbg = b->phase.p;
+                sa.dbg_slots = ix->tune.phase_slots;
+            }
+            // measured variant (A/B only): rows staged through LDS, where that kernel exists
+            sa.lds_staged = ix->tune.lds_staged && !geom.multi_query && !p.idx64 &&
+                            scan_has_lds_staged(b->planes, (uint32_t)p.meta.num_hashes, nwaves) ? 1u : 0u;
             sa.chunk_begin = 0;
             sa.chunk_end = c.total_chunks;
             // one launch covers at most 2^31-1 work-groups
             const uint32_t ntiles = (c.total_chunks + sa.tile_w - 1) / sa.tile_w;
             if ((uint64_t)ntiles * nq > 0x7FFFFFFFull)
                 return fail(COBS_GPU_ERR_CAPACITY, "batch too large for one scan launch; use fewer queries");
+            if (sa.dbg) {
+                const uint64_t groups = geom.multi_query ? (uint64_t)ntiles * ((nq + 64 / sa.tile_w - 1) / (64 / sa.tile_w))
+                                                          : (uint64_t)ntiles * nq;
+                sa.dbg_every = (uint32_t)std::max<uint64_t>(1, groups / sa.dbg_slots);
+            }
             HIP_TRY(launch_scan(sa, ntiles, b->planes, nwaves, geom.multi_query, st));
             ++launches;
             if (p.streamed) {
@@ -1510,6 +1532,17 @@ static cobs_gpu_status hits_host_impl(cobs_gpu_batch* b, size_t q, size_t num_re
     if (want > cap) return fail(COBS_GPU_ERR_CAPACITY, "hit buffer too small");
     if (want && !hits) return fail(COBS_GPU_ERR_ARG, "NULL hit buffer");
     std::copy(sel.begin(), sel.begin() + want, hits);
+    return COBS_GPU_OK;
+}
+
+cobs_gpu_status cobs_gpu_batch_phase_stamps(cobs_gpu_batch* b, uint64_t* out, size_t cap_words, size_t* n_words) {
+    if (!b || !n_words) return fail(COBS_GPU_ERR_ARG, "NULL argument");
+    const size_t n = (size_t)b->ix->tune.phase_slots * 32;
+    *n_words = n;
+    if (!b->phase.p || n == 0) { *n_words = 0; return COBS_GPU_OK; }
+    if (cap_words < n || !out) return fail(COBS_GPU_ERR_CAPACITY, "stamp buffer too small");
+    HIP_TRY(hipSetDevice(b->ix->device));
+    HIP_TRY(hipMemcpy(out, b->phase.p, n * 8, hipMemcpyDeviceToHost));
     return COBS_GPU_OK;
 }
 

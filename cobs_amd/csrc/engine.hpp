@@ -97,6 +97,8 @@ struct Tuning {
     uint64_t pipe_chars = 4ull << 20;    // COBS_GPU_PIPE_CHARS: query text from which a call is pipelined
     bool no_pin = false;        // COBS_GPU_NO_PIN: never hipHostRegister the mapped file
     int graph = -1;             // COBS_GPU_GRAPH: captured-graph path for small batches off / on
+    bool lds_staged = false;    // COBS_GPU_LDS_STAGED: the LDS-staged scan variant (A/B measurements only)
+    uint32_t phase_slots = 0;   // tuning builds (make timing): work-groups of a scan launch that record phase stamps
     static Tuning from_env();
 };
 
@@ -250,6 +252,7 @@ struct cobs_gpu_batch {
     hipGraphExec_t graph_exec = nullptr;
     uint64_t graph_key = 0;
     hipStream_t graph_stream = nullptr;
+    cobs_amd::DevBuf<uint64_t> phase;          // phase stamps of the last scan launch (tuning builds)
     cobs_amd::Exchange* xchg = nullptr;       // comm.cpp
     // set by an exchange, cleared by the next run: GLOBAL score rows (all shards' slices assembled
     // in global document order) of queries [g_q0, g_q0 + g_qn), owned by xchg

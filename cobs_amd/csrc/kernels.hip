@@ -447,19 +447,70 @@ __device__ __forceinline__ void and_rows(uint4 (&X)[8], const uint4 (&Y)[8]) {
     }
 }
 
+// ---- LDS-staged variant of the row pipeline (LDSS): rows travel HBM -> LDS (direct-to-LDS DMA,
+// global_load_lds_dwordx4: 64 lanes x 16 B = 1 KiB per instruction) -> VGPR (ds_read_b128)
+// instead of HBM -> VGPR.  hipcc neither counts asm memory operations nor pipelines LDS-DMA
+// (it would drain it with vmcnt(0)), so the loop's VMEM operations are inline asm with counted
+// s_waitcnt vmcnt(N); the waits name the registers they make valid so that the compiler
+// cannot touch them earlier.  Kept as a measured A/B against the VGPR-direct pipeline
+// (scripts/ab.py ... lds=1; result in profiles/).
+__device__ __forceinline__ void asm_load_idx(u32x4& a, u32x4& b, const uint32_t* p) {
+    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
+                 : "=&v"(a), "=&v"(b) : "v"(p) : "memory");
+}
+// one row: the wave's 64 lanes x 16 bytes land at LDS address lds_dst + lane * 16
+__device__ __forceinline__ void asm_glds16(const uint8_t* gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds_rows(const uint8_t* lane_base, uint32_t pitch, const u32x4& a, const u32x4& b,
+                                          uint32_t lds_dst) {
+    asm_glds16(lane_base + (uint64_t)a.x * pitch, lds_dst);
+    asm_glds16(lane_base + (uint64_t)a.y * pitch, lds_dst + 1024u);
+    asm_glds16(lane_base + (uint64_t)a.z * pitch, lds_dst + 2048u);
+    asm_glds16(lane_base + (uint64_t)a.w * pitch, lds_dst + 3072u);
+    asm_glds16(lane_base + (uint64_t)b.x * pitch, lds_dst + 4096u);
+    asm_glds16(lane_base + (uint64_t)b.y * pitch, lds_dst + 5120u);
+    asm_glds16(lane_base + (uint64_t)b.z * pitch, lds_dst + 6144u);
+    asm_glds16(lane_base + (uint64_t)b.w * pitch, lds_dst + 7168u);
+}
+#define COBS_WAIT_VM_IDX(N, A, B) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(A), "+v"(B) : : "memory")
+#define COBS_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" : : : "memory")
+
+// Phase timestamps of sampled work-groups (tuning builds only: make -C cobs_amd/csrc timing;
+// scripts/phase_times.py).  COBS_STAMP(k) drains the memory queues first so that the time of a
+// phase includes the loads it issued.
+#ifdef COBS_SCAN_TIMING
+#define COBS_STAMP(K)                                                                           \
+    do {                                                                                        \
+        if (a.dbg && (blockIdx.x % a.dbg_every) == 0u && blockIdx.x / a.dbg_every < a.dbg_slots) { \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                         \
+            const uint64_t t_ = __builtin_amdgcn_s_memtime();                                   \
+            if (lane == 0u) a.dbg[((uint64_t)(blockIdx.x / a.dbg_every) * 4u + wave) * 8u + (K)] = t_; \
+        }                                                                                       \
+    } while (0)
+#else
+#define COBS_STAMP(K) do { } while (0)
+#endif
+
 // MQ ("multi-query", short queries): the G = 64 / W lane groups of a wave belong to G
 // DIFFERENT queries (q = qi*G + grp) instead of splitting one query's blocks.  Every lane
 // group then walks all blocks of its own query (divided over the NW waves only): G times
 // more trips per wave, so the load pipeline reaches its steady state even for 100-bp reads,
 // and the cross-lane merge disappears.
-template <int NP, int NW, bool H1, typename OutT, bool MQ, typename IdxT>
+template <int NP, int NW, bool H1, typename OutT, bool MQ, typename IdxT, bool LDSS = false>
 __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     // row loads stay temporal: non-temporal loads measured 18 % slower (they bypass the Infinity Cache)
     constexpr bool NT = false;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    // merge buffers: [NW/2 (min 1)][NP][64 lanes] of uint4, then the 256-entry expansion table
+    // merge buffers: [NW/2 (min 1)][NP][64 lanes] of uint4, then the 256-entry expansion table.
+    // LDSS: the front of the buffer is the row staging ring (2 x 8 KiB per wave); the merge
+    // buffers, needed only after the row loop, alias it.
+    constexpr size_t kFront = LDSS ? (size_t)NW * 16384 : (size_t)(NW >= 2 ? NW / 2 : 1) * NP * 64 * sizeof(uint4);
+    static_assert(!LDSS || kFront >= (size_t)(NW >= 2 ? NW / 2 : 1) * NP * 64 * sizeof(uint4), "ring holds the merge buffers");
     uint4* mbuf = reinterpret_cast<uint4*>(smem);
-    uint4* lut = mbuf + (size_t)(NW >= 2 ? NW / 2 : 1) * NP * 64;
+    uint4* lut = reinterpret_cast<uint4*>(smem + kFront);
     // per-chunk metadata of this tile (first local score slot, valid row bytes left in the
     // chunk, first document id) and per-lane-group thresholds: the epilogue reads them from
     // LDS instead of chasing a.pages[] / a.thresholds[] through global memory per iteration
@@ -484,6 +535,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
+    COBS_STAMP(0);
     // A tile is W (power of two, <= 64) sixteen-byte column chunks of the chunk range
     // [chunk_begin, chunk_end).  With W < 64 one wave-load fetches G = 64 / W different
     // rows (terms): lane group g of wave w acts as "virtual wave" w*G + g with its own
@@ -552,15 +604,74 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
         nw = nblk > first ? (nblk - first + NV - 1u) / NV : 0u;
     }
     uint32_t ea[4], eb[4];
-    if constexpr (H1) {
+    COBS_STAMP(1);                 // page / block-offset loads done, LUT written
+    if constexpr (LDSS) {
+        static_assert(!LDSS || (H1 && !MQ && sizeof(IdxT) == 4), "LDS-staged variant: H = 1, one query per group, 32-bit indices");
+        const uint32_t* tab32 = reinterpret_cast<const uint32_t*>(tab);
+        // LDS byte address of this wave's ring (wave-uniform: it goes into M0)
+        const uint32_t ring = __builtin_amdgcn_readfirstlane(
+            (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem + wave * 16384u);
+        const uint8_t* my = smem + wave * 16384u + lane * 16u;          // this lane's 16 bytes of row 0, buffer 0
+        auto read_rows = [&](uint4 (&X)[8], uint32_t buf) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) X[r] = *reinterpret_cast<const uint4*>(my + buf * 8192u + r * 1024u);
+        };
+        if (nw > 0) {
+            // VMEM queue, oldest first, at the top of step i: idx(i+1) [2 ops] | rows(i) [8 ops].
+            // A step loads idx(i+2), waits for idx(i+1), issues rows(i+1) into the other buffer, and
+            // only then waits for rows(i): two trips (16 KiB per wave) are in flight at every wait.
+            u32x4 pa, pb, qa, qb;              // two index register sets used alternately (no copies)
+            uint4 X[8];
+            asm_load_idx(pa, pb, tab32 + blk_of(0));
+            asm_load_idx(qa, qb, tab32 + blk_of(1));
+            COBS_WAIT_VM_IDX(2, pa, pb);
+            glds_rows(lane_base, pitch, pa, pb, ring);
+            uint32_t i = 0;
+            for (; i + 2 < nw; i += 2) {
+                asm_load_idx(pa, pb, tab32 + blk_of(i + 2));
+                COBS_WAIT_VM_IDX(10, qa, qb);
+                glds_rows(lane_base, pitch, qa, qb, ring + 8192u);
+                COBS_WAIT_VM(10);
+                read_rows(X, 0u);
+                absorb_block<NP>(pl, X, ea);
+                asm_load_idx(qa, qb, tab32 + blk_of(i + 3));
+                COBS_WAIT_VM_IDX(10, pa, pb);
+                glds_rows(lane_base, pitch, pa, pb, ring);
+                COBS_WAIT_VM(10);
+                read_rows(X, 1u);
+                absorb_block<NP>(pl, X, eb);
+                retire_pair<NP>(pl, ea, eb);
+            }
+            // queue: idx(i+1) in (qa, qb) | rows(i) in buffer 0; one or two trips left
+            if (i + 1 < nw) {
+                COBS_WAIT_VM_IDX(8, qa, qb);
+                glds_rows(lane_base, pitch, qa, qb, ring + 8192u);
+                COBS_WAIT_VM(8);
+                read_rows(X, 0u);
+                absorb_block<NP>(pl, X, ea);
+                COBS_WAIT_VM(0);
+                read_rows(X, 1u);
+                absorb_block<NP>(pl, X, eb);
+                retire_pair<NP>(pl, ea, eb);
+            } else {
+                COBS_WAIT_VM_IDX(0, qa, qb);
+                read_rows(X, 0u);
+                absorb_block<NP>(pl, X, ea);
+                retire_single<NP>(pl, ea);
+            }
+        }
+        __syncthreads();                   // the merge buffers alias the rings: every wave is done reading
+    } else if constexpr (H1) {
         // Three-stage software pipeline, branch-free in the steady state:
         //   row indices of trip i+2 | row loads of trip i+1 | CSA of trip i
         // so that 8..16 row loads (8..16 KiB per wave) are always in flight.
         if (nw > 0) {
             uint4 XA[8], XB[8];
             Idx8<IdxT> i0 = load_idx8(tab + blk_of(0));
+            COBS_STAMP(2);         // first row indices landed
             issue_rows<NT>(XA, lane_base, pitch, i0);
             Idx8<IdxT> i1 = load_idx8(tab + blk_of(1));
+            COBS_STAMP(3);         // first rows landed
             uint32_t i = 0;
             for (; i + 2 < nw; i += 2) {
                 // XA in flight = trip i, i1 = indices of trip i+1
@@ -598,6 +709,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
         }
     }
 
+    COBS_STAMP(4);                 // row loop done
     // ---- merge the G lane groups of this wave (bit-sliced adds across lanes)
     for (uint32_t s = MQ ? 64u : W; s < 64u; s <<= 1) {
 #pragma unroll
@@ -644,6 +756,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     }
     __syncthreads();
 
+    COBS_STAMP(5);                 // merged planes are in LDS
     // ---- expand planes -> per-document counts; every thread handles row bytes ----
     const uint32_t* planes = reinterpret_cast<const uint32_t*>(mbuf);   // [NP][64*4 words]
     if (!a.write_counts && a.thresholds) {
@@ -706,8 +819,17 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
         return;
     }
     const uint32_t nbytes = MQ ? 1024u : W * 16u;    // MQ: every lane group holds a query's tile
-#pragma unroll 1
-    for (uint32_t b = threadIdx.x; b < nbytes; b += NW * 64) {       // row byte inside the tile
+    // MQ: 1024 / (NW * 64) = 4..16 iterations per thread.  Unrolled by four so that the score stores
+    // of consecutive iterations use different registers: with one register set the next iteration's
+    // first write to the store's data registers waits (vmcnt) until the store has left the CU --
+    // measured 2 500 cycles per iteration, half of a short-read work-group's life.
+    // (A counted loop: with the thread-dependent start as induction variable the unroller gives up.)
+    constexpr int kUnroll = MQ ? 4 : 1;
+    const uint32_t niter = MQ ? 1024u / (NW * 64) : (nbytes + NW * 64 - 1u) / (NW * 64);
+#pragma unroll kUnroll
+    for (uint32_t it = 0; it < niter; ++it) {
+        const uint32_t b = threadIdx.x + it * (NW * 64);             // row byte inside the tile
+        if (!MQ && b >= nbytes) break;
         const uint32_t pl_lane = b >> 4, cb = b & 15u;               // lane that held the planes
         const uint32_t chunk = MQ ? (pl_lane & (W - 1u)) : pl_lane;
         const uint32_t q2raw = MQ ? qi * G + pl_lane / W : qi;
@@ -754,9 +876,14 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
         const uint32_t slot = tmeta[chunk * 3 + 0] + cb * 8u;
         if (valid && a.write_counts) {
             if constexpr (sizeof(OutT) == 1) {
-                *reinterpret_cast<uint2*>(crow + slot) = make_uint2(lo[0], lo[1]);
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                u32x2* dst = reinterpret_cast<u32x2*>(crow + slot);
+                const u32x2 v = {lo[0], lo[1]};
+                *dst = v;          // (non-temporal stores measured equal: scripts/ab.py, 50..150-bp reads, C2, C3)
             } else if constexpr (sizeof(OutT) == 2) {
-                *reinterpret_cast<uint4*>(crow + slot) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+                u32x4* dst = reinterpret_cast<u32x4*>(crow + slot);
+                const u32x4 v = {lo[0], lo[1], lo[2], lo[3]};
+                *dst = v;          // (non-temporal stores measured equal: scripts/ab.py, 50..150-bp reads, C2, C3)
             } else {
                 *reinterpret_cast<uint4*>(crow + slot) = make_uint4(cnt[0], cnt[1], cnt[2], cnt[3]);
                 *reinterpret_cast<uint4*>(crow + slot + 4) = make_uint4(cnt[4], cnt[5], cnt[6], cnt[7]);
@@ -794,6 +921,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
             }
         }
     }
+    COBS_STAMP(6);                 // scores stored
 }
 
 // ---------------------------------------------------------------------------
@@ -1177,7 +1305,7 @@ hipError_t launch_hash(const HashArgs& a, uint64_t total_threads, hipStream_t st
     return hipGetLastError();
 }
 
-template <int NP, int NW, bool H1, typename OutT, bool MQ = false, typename IdxT = uint32_t>
+template <int NP, int NW, bool H1, typename OutT, bool MQ = false, typename IdxT = uint32_t, bool LDSS = false>
 static hipError_t launch_scan_inst(const ScanArgs& a, uint32_t ntiles, hipStream_t stream) {
     (void)ntiles;
     const uint32_t per_group = MQ ? 64u / a.tile_w : 1u;
@@ -1185,8 +1313,9 @@ static hipError_t launch_scan_inst(const ScanArgs& a, uint32_t ntiles, hipStream
                             ((a.nq + per_group - 1u) / per_group);
     if (groups == 0) return hipSuccess;
     if (groups > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    constexpr size_t lds = ((size_t)(NW >= 2 ? NW / 2 : 1) * NP * 64 + 256) * sizeof(uint4) + 64 * 4 * sizeof(uint32_t);
-    auto kern = scan_kernel<NP, NW, H1, OutT, MQ, IdxT>;
+    constexpr size_t front = LDSS ? (size_t)NW * 16384 : (size_t)(NW >= 2 ? NW / 2 : 1) * NP * 64 * sizeof(uint4);
+    constexpr size_t lds = front + 256 * sizeof(uint4) + 64 * 4 * sizeof(uint32_t);
+    auto kern = scan_kernel<NP, NW, H1, OutT, MQ, IdxT, LDSS>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1235,9 +1364,18 @@ bool scan_has_multi_query(int planes, uint32_t num_hashes, uint32_t tile_w) {
     return num_hashes == 1 && tile_w < 64 && (planes == 4 || planes == 8 || planes == 10 || planes == 12);
 }
 
+bool scan_has_lds_staged(int planes, uint32_t num_hashes, int nw) {
+    return num_hashes == 1 && planes == 10 && (nw == 2 || nw == 4);
+}
+
 hipError_t launch_scan(const ScanArgs& a, uint32_t ntiles, int planes, int nw, bool multi_query,
                        hipStream_t stream) {
     const bool h1 = a.num_hashes == 1;
+    if (a.lds_staged) {     // measured variant (A/B): rows through LDS
+        if (multi_query || a.idx64 || !scan_has_lds_staged(planes, a.num_hashes, nw)) return hipErrorInvalidValue;
+        return nw == 2 ? launch_scan_inst<10, 2, true, uint16_t, false, uint32_t, true>(a, ntiles, stream)
+                       : launch_scan_inst<10, 4, true, uint16_t, false, uint32_t, true>(a, ntiles, stream);
+    }
     if (multi_query) {
         if (a.idx64 || !scan_has_multi_query(planes, a.num_hashes, a.tile_w)) return hipErrorInvalidValue;
         switch (planes) {

@@ -129,7 +129,8 @@ cobs_gpu_status cobs_gpu_open_synthetic(const cobs_gpu_synth* desc,
 void cobs_gpu_close(cobs_gpu_index* ix);
 /* Per-handle tuning hooks of the scan launch (the COBS_GPU_* environment variables are read once,
  * by cobs_gpu_open*; this changes them afterwards).  key: "waves" (0, 1, 2, 4), "tile_w" (0, 4..64),
- * "mq" (-1 auto, 0, 1), "pass_bytes", "pipe_chars", "graph" (-1 auto, 0, 1).  0 / -1 = automatic. */
+ * "mq" (-1 auto, 0, 1), "pass_bytes", "pipe_chars", "graph" (-1 auto, 0, 1), "lds_staged" (0, 1: the
+ * measured LDS-staged variant of the scan, headline shape only).  0 / -1 = automatic. */
 cobs_gpu_status cobs_gpu_set_tuning(cobs_gpu_index* ix, const char* key, int64_t value);
 /* Host only (no device needed): the score slots [slot_begin[r], slot_begin[r] + slot_count[r]) and
  * the index bytes shard r of shard_count would hold of the file at `path` (arrays of shard_count
@@ -314,6 +315,11 @@ cobs_gpu_status cobs_gpu_batch_exchange_topk(cobs_gpu_batch* b, cobs_gpu_comm* c
 cobs_gpu_status cobs_gpu_sharded_search_batch(cobs_gpu_index* ix, cobs_gpu_comm* c, const char* const* queries,
                                               const size_t* lens, size_t nq, double threshold, size_t num_results,
                                               cobs_gpu_hit* hits, size_t cap, size_t* hit_offsets, size_t* bad_query);
+
+/* Diagnostics of tuning builds (libcobs_gpu_timing.so, `make -C cobs_amd/csrc timing`): s_memtime stamps
+ * [work-group slot][wave 0..3][8 phases] of the work-groups sampled from the last scan launch after
+ * cobs_gpu_set_tuning(ix, "phase_slots", n).  The production library records nothing (*n_words = 0). */
+cobs_gpu_status cobs_gpu_batch_phase_stamps(cobs_gpu_batch* b, uint64_t* out, size_t cap_words, size_t* n_words);
 
 /* phase timers of the host-buffer search API since the last reset, seconds:
  * out[0] hashes (K1), out[1] h2d, out[2] scan (K2), out[3] d2h, out[4] rank  */

@@ -56,7 +56,7 @@ def main():
     for rnd in range(7):
         for ci, c in enumerate(configs):
             for k in keys:
-                s.set_tuning(k, -1 if k == "mq" else 0)
+                s.set_tuning(k, -1 if k in ("mq", "graph") else 0)
             for k, v in c.items():
                 s.set_tuning(k, int(v))
             for _ in range(3):

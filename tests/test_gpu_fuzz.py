@@ -75,3 +75,32 @@ def test_random_geometries(gpu_lib, oracle, tmp_path, monkeypatch, tile_w, waves
         # threshold compare, no score rows)
         tt = t if t > 0 else 0.3
         assert s.search_hits(queries, tt, 0) == [cases.oracle_results([ix], q, tt, 0) for q in queries], (path, tt)
+
+
+def test_lds_staged_variant_is_bit_exact(gpu_lib, oracle):
+    """the measured LDS-staged variant of the scan (rows HBM -> LDS via global_load_lds -> VGPR,
+    hand-counted vmcnt pipeline; tuning key lds_staged, profiles/r02_lds_staged_ab.txt) computes
+    the same counts as the VGPR-direct kernel and the oracle: every trip-count parity (1..6 trips
+    per wave), 2 and 4 waves, ragged lengths inside the 10-plane range"""
+    import bench
+    cfg = bench.c3_config(0.01)
+    s = gpu_lib.Search.synthetic("compact", cfg["signature_sizes"], cfg["num_docs"], page_size=cfg["page_size"], seed=1)
+    ix = oracle.Index.synthetic(1, 31, 1, 1, cfg["page_size"], cfg["signature_sizes"], cfg["num_docs"], 1)
+    base = bench.make_queries(48, 993, seed=3)
+    qs = [q[:286 + 15 * i] for i, q in enumerate(base)]            # 256 .. 961 terms: 32 .. 121 blocks
+    b = gpu_lib.Batch(s)
+    b.set_queries(qs)
+    want = [ix.counts(q) for q in qs]
+    for waves in (2, 4):
+        for tile_w in (0, 8, 16, 64):
+            s.set_tuning("lds_staged", 1)
+            s.set_tuning("waves", waves)
+            s.set_tuning("tile_w", tile_w)
+            b.run(0.0)
+            b.sync()
+            for i in range(len(qs)):
+                assert np.array_equal(b.counts_host(i), want[i]), (waves, tile_w, i)
+            b.run(0.3)                                             # selection epilogue after the staged loop
+            b.sync()
+            for i in (0, 17, 47):
+                assert b.hits_host(i, 0) == cases.oracle_results([ix], qs[i], 0.3, 0)
