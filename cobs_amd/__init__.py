@@ -8,10 +8,12 @@ All compute happens in libcobs_gpu.so (HIP, C ABI in include/cobs_gpu.h).
 from ._capi import CobsGpuError  # noqa: F401
 from .construct import (ClassicIndexParameters, CompactIndexParameters, DocumentList,  # noqa: F401
                         classic_construct, classic_construct_list, compact_construct,
-                        compact_construct_list, disable_cache, write_synthetic)
+                        compact_construct_list, disable_cache, write_synthetic, build_search,
+                        classic_combine, classic_construct_random)
 from .search import Batch, Search, SearchResult  # noqa: F401
 
 __version__ = "0.2.0"
 __all__ = ["Search", "SearchResult", "Batch", "CobsGpuError", "DocumentList", "ClassicIndexParameters",
            "CompactIndexParameters", "classic_construct", "classic_construct_list", "compact_construct",
-           "compact_construct_list", "disable_cache", "write_synthetic", "__version__"]
+           "compact_construct_list", "disable_cache", "write_synthetic", "build_search", "classic_combine",
+           "classic_construct_random", "__version__"]

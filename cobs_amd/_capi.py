@@ -50,7 +50,7 @@ class BuildParams(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("term_size", C.c_uint32), ("canonicalize", C.c_uint32),
                 ("num_hashes", C.c_uint32), ("false_positive_rate", C.c_double),
                 ("signature_size", C.c_uint64), ("page_size", C.c_uint64),
-                ("device", C.c_int32), ("reserved", C.c_uint32)]
+                ("device", C.c_int32), ("text_batch_bytes", C.c_uint32), ("doc_terms", C.POINTER(C.c_uint64))]
 
 
 class Synth(C.Structure):
@@ -87,6 +87,10 @@ SYMBOLS = {
     "cobs_gpu_build_compact": (_int, [C.POINTER(_cp), C.POINTER(_cp), C.POINTER(_sz), _sz,
                                       C.POINTER(BuildParams), _cp]),
     "cobs_gpu_write_synthetic": (_int, [C.POINTER(Synth), _cp, _int]),
+    "cobs_gpu_build_index": (_int, [_u32, C.POINTER(_cp), C.POINTER(_cp), C.POINTER(_sz), _sz,
+                                    C.POINTER(BuildParams), C.POINTER(Options), C.POINTER(_vp)]),
+    "cobs_gpu_combine_classic": (_int, [C.POINTER(_cp), _sz, _cp, _u64, _int]),
+    "cobs_gpu_construct_random": (_int, [_cp, _u64, _u64, _u64, _u64, _u64, _int]),
     "cobs_gpu_search": (_int, [_vp, _cp, _sz, _dbl, _sz, C.POINTER(Hit), _sz, C.POINTER(_sz)]),
     "cobs_gpu_search_batch": (_int, [_vp, C.POINTER(_cp), C.POINTER(_sz), _sz, _dbl, _sz,
                                      C.POINTER(Hit), _sz, C.POINTER(_sz), C.POINTER(_sz)]),

@@ -34,28 +34,64 @@ def _base_name(path):
     return os.path.basename(path).split(".")[0]
 
 
-def _read_fasta(path):
-    """-> (text with sequences joined by newlines, size).  Terms continue across line
-    breaks inside a sequence; comment ('>' ';') and empty lines end a sequence
-    (reference cobs/fasta_file.hpp:53-91,155-182).  size = FastaFile::size()."""
+def _fasta_runs(lines, k):
+    """The character runs whose k-grams FastaFile::process_terms hashes (reference
+    cobs/fasta_file.hpp:155-182), including what its line buffer does at the edges: a run ends at
+    a comment ('>' ';') or empty line -- but the test looks at index `pos` of the buffer, which is
+    0 while the run so far is shorter than k (then a comment line is swallowed INTO the run) and
+    keeps its old value k-1 after a clear (then a line of exactly k-1 characters counts as empty).
+    Reads past the end of the buffer (undefined in the reference) are taken as sequence."""
+    runs, cur = [], bytearray()
+    held, pos = 0, 0             # held = characters of the run the reference still has in its buffer
+    for ln in lines:
+        size = held + len(ln)
+        if size == pos:
+            comment = True
+        elif pos < size:
+            ch = cur[len(cur) - held + pos] if pos < held else ln[pos - held]
+            comment = ch in b">;"
+        else:
+            comment = False
+        if comment:
+            if cur:
+                runs.append(bytes(cur))
+            cur, held = bytearray(), 0
+            continue
+        cur += ln
+        if size > k - 1:
+            held, pos = k - 1, k - 1
+        else:
+            held, pos = size, 0
+    if cur:
+        runs.append(bytes(cur))
+    return runs
+
+
+def _fasta_lines(path):
     opener = gzip.open if path.endswith(".gz") else open
     with opener(path, "rb") as f:
         data = f.read()
     lines = data.split(b"\n")
     if lines and lines[-1] == b"":
         lines.pop()
+    return lines
+
+
+def _read_fasta(path, k=31):
+    """-> (runs joined by newlines, size, number of terms).  The bits of a document come from
+    process_terms (the runs above); size = FastaFile::size() and the term count that sizes a
+    signature come from the file's index (compute_index / num_terms, fasta_file.hpp:53-91,
+    147-153): maximal runs of non-comment, non-empty lines."""
+    lines = _fasta_lines(path)
     size = sum(len(ln) + 1 for ln in lines)
-    seqs, cur = [], []
-    for ln in lines:
+    num_terms, run = 0, 0
+    for ln in lines[1:] + [b""]:
         if len(ln) == 0 or ln[:1] in (b">", b";"):
-            if cur:
-                seqs.append(b"".join(cur))
-            cur = []
+            num_terms += max(run - k + 1, 0)
+            run = 0
         else:
-            cur.append(ln)
-    if cur:
-        seqs.append(b"".join(cur))
-    return b"\n".join(seqs), size
+            run += len(ln)
+    return b"\n".join(_fasta_runs(lines, k)), size, num_terms
 
 
 class DocumentEntry:
@@ -66,12 +102,24 @@ class DocumentEntry:
         self.name = name
         self.size = size
         self.type = "fasta"
-        self._text = text
+        self._text = text            # in-memory documents: sequences joined by newlines
+        self._by_k = {}
 
-    def text(self):
-        if self._text is None:
-            self._text = _read_fasta(self.path)[0]
-        return self._text
+    def text(self, k=31):
+        """the character runs whose k-grams are hashed, joined by newlines"""
+        if self._text is not None:
+            return self._text
+        if k not in self._by_k:
+            t, _, n = _read_fasta(self.path, k)
+            self._by_k[k] = (t, n)
+        return self._by_k[k][0]
+
+    def num_terms(self, k=31):
+        """FastaFile::num_terms(k): what sizes a signature (fasta_file.hpp:147-153)"""
+        if self._text is not None:
+            return sum(max(len(sq) - k + 1, 0) for sq in self._text.split(b"\n"))
+        self.text(k)
+        return self._by_k[k][1]
 
 
 class DocumentList:
@@ -94,8 +142,8 @@ class DocumentList:
         return iter(self._list)
 
     def add(self, path):
-        text, size = _read_fasta(path)
-        self._list.append(DocumentEntry(path, _base_name(path), size, text))
+        size = sum(len(ln) + 1 for ln in _fasta_lines(path))
+        self._list.append(DocumentEntry(path, _base_name(path), size))
 
     def add_document(self, name, sequences):
         """in-memory document: a name and its sequences (bytes)"""
@@ -151,6 +199,7 @@ def _params(p, device):
     b.signature_size = getattr(p, "signature_size", 0)
     b.page_size = getattr(p, "page_size", 0)
     b.device = device
+    b.text_batch_bytes = int(getattr(p, "text_batch_bytes", 0))
     return b
 
 
@@ -170,10 +219,15 @@ def _check_output(out_file, ext, params):
 def _build(fn, docs, params, out_file, device):
     lib = _capi.load()
     names = (C.c_char_p * len(docs))(*[d.name.encode() for d in docs])
-    texts = [d.text() for d in docs]
+    k = params.term_size
+    texts = [d.text(k) for d in docs]
     tarr = (C.c_char_p * len(docs))(*texts)
     lens = (C.c_size_t * len(docs))(*[len(t) for t in texts])
     b = _params(params, device)
+    # the term counts that size the signatures (the reference takes them from the documents'
+    # indexes, not from what process_terms later hashes)
+    terms = (C.c_uint64 * len(docs))(*[d.num_terms(k) for d in docs])
+    b.doc_terms = C.cast(terms, C.POINTER(C.c_uint64))
     check(getattr(lib, fn)(names, tarr, lens, len(docs), C.byref(b), os.fsencode(out_file)))
 
 
@@ -223,6 +277,66 @@ def compact_construct_list(list, out_file, index_params=None, tmp_path="", devic
     compact_construct(None, out_file, index_params, "any", tmp_path, list=list, device=device)
 
 
+def build_search(input=None, index_params=None, kind="classic", file_type="any", list=None, device=-1):
+    """classic_construct / compact_construct straight into a query handle (cobs_gpu_build_index):
+    the matrix is built in HBM at the engine's row pitch and searched where it lies -- no index
+    file in between.  -> cobs_amd.Search"""
+    from ._capi import Options
+    from .search import Search
+    compact = kind in (1, "compact")
+    params = index_params or (CompactIndexParameters() if compact else ClassicIndexParameters())
+    docs = _as_list(list if list is not None else input, file_type)
+    if compact:
+        ordered = sorted(docs, key=lambda d: (d.size, d.path))
+        page_size = getattr(params, "page_size", 0)
+        if page_size == 0:
+            v = int((len(ordered) // 8) ** 0.5)
+            p2 = 1
+            while p2 < v:
+                p2 *= 2
+            page_size = min(max(p2 if v else 0, 8), 4096)
+        final = []
+        for g in range(0, len(ordered), 8 * page_size):
+            final.extend(sorted(ordered[g:g + 8 * page_size], key=lambda d: d.path))
+        fixed = CompactIndexParameters()
+        fixed.__dict__.update(params.__dict__)
+        fixed.page_size = page_size
+        docs, params = final, fixed
+    else:
+        docs = sorted(docs, key=lambda d: d.path)
+    lib = _capi.load()
+    k = params.term_size
+    names = (C.c_char_p * len(docs))(*[d.name.encode() for d in docs])
+    texts = [d.text(k) for d in docs]
+    tarr = (C.c_char_p * len(docs))(*texts)
+    lens = (C.c_size_t * len(docs))(*[len(t) for t in texts])
+    b = _params(params, device)
+    terms = (C.c_uint64 * len(docs))(*[d.num_terms(k) for d in docs])
+    b.doc_terms = C.cast(terms, C.POINTER(C.c_uint64))
+    o = Options()
+    o.struct_size = C.sizeof(Options)
+    o.device = device
+    h = C.c_void_p()
+    check(lib.cobs_gpu_build_index(1 if compact else 0, names, tarr, lens, len(docs), C.byref(b), C.byref(o), C.byref(h)))
+    return Search(None, _handle=h)
+
+
+def classic_combine(in_files, out_file, mem_bytes=0, device=-1):
+    """classic_combine (construction/classic_index.cpp:195-327): several classic indexes with the
+    same parameters -> one, rows concatenated at bit granularity on the GPU"""
+    lib = _capi.load()
+    arr = (C.c_char_p * len(in_files))(*[os.fsencode(p) for p in in_files])
+    check(lib.cobs_gpu_combine_classic(arr, len(in_files), os.fsencode(out_file), int(mem_bytes), device))
+
+
+def classic_construct_random(out_file, signature_size=2 * 1024 * 1024, num_documents=10000, document_size=1000000,
+                             num_hashes=1, seed=1, device=-1):
+    """`cobs classic-construct-random` (src/cobs.cpp:243-291, classic_index.cpp:661-725), defaults
+    included: documents of random 31-mers hashed into a classic index on the GPU"""
+    check(_capi.load().cobs_gpu_construct_random(os.fsencode(out_file), int(signature_size), int(num_documents),
+                                                 int(document_size), int(num_hashes), int(seed), device))
+
+
 def write_synthetic(out_file, kind, signature_sizes, num_docs, page_size=0, term_size=31, canonicalize=1,
                     num_hashes=1, seed=1, device=-1):
     """The procedural benchmark index (Search.synthetic) as a .cobs_classic / .cobs_compact FILE:
@@ -238,6 +352,6 @@ def write_synthetic(out_file, kind, signature_sizes, num_docs, page_size=0, term
     check(lib.cobs_gpu_write_synthetic(C.byref(d), os.fsencode(out_file), device))
 
 
-__all__ = ["write_synthetic", "DocumentList", "DocumentEntry", "ClassicIndexParameters", "CompactIndexParameters",
+__all__ = ["write_synthetic", "build_search", "classic_combine", "classic_construct_random", "DocumentList", "DocumentEntry", "ClassicIndexParameters", "CompactIndexParameters",
            "classic_construct", "classic_construct_list", "compact_construct", "compact_construct_list",
            "disable_cache"]

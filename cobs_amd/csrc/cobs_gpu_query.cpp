@@ -34,7 +34,9 @@ static void usage() {
                  "       cobs_gpu_query --benchmark -i INDEX [-k KMERS] [-q QUERIES] [-w WARMUP] [--seed S]\n"
                  "       cobs_gpu_query --write-synthetic OUT (--classic -n DOCS -s ROWS | --compact -n DOCS -p PAGE_SIZE\n"
                  "                      -s ROWS_0,ROWS_1,...) [--num-hashes H] [--seed S] [-d DEVICE]\n"
-                 "        (the generator next to `cobs classic-construct-random`: a random-bit index file, density 0.3)\n");
+                 "        (a random-bit index file, density 0.3, for benchmarks of any size)\n"
+                 "       cobs_gpu_query --construct-random OUT [-s SIGNATURE_SIZE] [-n DOCS] [-m DOCUMENT_SIZE]\n"
+                 "                      [--num-hashes H] [--seed S]    (`cobs classic-construct-random`, same flags and defaults)\n");
 }
 
 // `cobs benchmark-fpr` (reference src/cobs.cpp:605-730): random ACGT queries of
@@ -78,7 +80,8 @@ int main(int argc, char** argv) {
     size_t num_results = 0;
     std::vector<int> devices;
     uint64_t hbm_budget = 0;
-    std::string synth_out, synth_rows;
+    std::string synth_out, synth_rows, random_out;
+    uint64_t document_size = 1000000;
     bool synth_compact = false, force_sharded = false;
     uint64_t synth_docs = 10000, synth_page = 0, synth_hashes = 1;
     bool bench = false;
@@ -105,6 +108,8 @@ int main(int argc, char** argv) {
         }
         else if (a == "--sharded") force_sharded = true;        // the multi-GPU code path even for one device
         else if (a == "--write-synthetic") synth_out = need("--write-synthetic");
+        else if (a == "--construct-random") random_out = need("--construct-random");
+        else if (a == "-m" || a == "--document-size") document_size = std::strtoull(need("-m"), nullptr, 10);
         else if (a == "--classic") synth_compact = false;
         else if (a == "--compact") synth_compact = true;
         else if (a == "-n" || a == "--num-documents") synth_docs = std::strtoull(need("-n"), nullptr, 10);
@@ -138,6 +143,15 @@ int main(int argc, char** argv) {
                 index_paths, devices.empty() ? std::vector<int>{0} : devices, hbm_budget));
         return std::unique_ptr<cobs_gpu::BatchSearch>(new cobs_gpu::ClassicSearch(index_paths, device, hbm_budget));
     };
+    if (!random_out.empty()) {
+        // `cobs classic-construct-random` (reference src/cobs.cpp:243-291): same flags and defaults
+        const uint64_t sig = synth_rows.empty() ? 2ull * 1024 * 1024 : std::strtoull(synth_rows.c_str(), nullptr, 10);
+        if (cobs_gpu_construct_random(random_out.c_str(), sig, synth_docs, document_size, synth_hashes, seed, device) != COBS_GPU_OK) {
+            std::fprintf(stderr, "EXCEPTION: %s\n", cobs_gpu_last_error());
+            return 1;
+        }
+        return 0;
+    }
     if (!synth_out.empty()) {
         std::vector<uint64_t> sigs;
         for (size_t p = 0; p < synth_rows.size();) {

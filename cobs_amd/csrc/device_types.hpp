@@ -112,6 +112,27 @@ struct BuildArgs {
     uint32_t num_hashes;
 };
 
+// classic_construct_random: documents of random 31-mers
+struct RandomBuildArgs {
+    uint32_t* matrix;           // signature_size rows of row_bytes (multiple of 4) bytes, as words
+    uint64_t signature_size, magic, row_bytes;
+    uint64_t doc0;              // first document (column) of this launch
+    uint64_t document_size;     // 31-mers per document
+    uint64_t seed;
+    uint32_t num_hashes;
+};
+
+// classic_combine: bit-level concatenation of the rows of several matrices
+struct CombineArgs {
+    const uint8_t* const* src;      // nsrc row blocks (device pointers, device array)
+    const uint64_t* src_row_bytes;  // nsrc
+    const uint64_t* bit_off;        // nsrc + 1 prefix sums of the inputs' document counts
+    uint8_t* dst;
+    uint64_t dst_row_bytes;
+    uint64_t rows;
+    uint32_t nsrc;
+};
+
 // procedural index fill
 struct SynthArgs {
     uint8_t* blob;

@@ -686,6 +686,10 @@ static cobs_gpu_status stage_index(cobs_gpu_index* ix, std::vector<std::unique_p
         cobs_gpu_status st = alloc_part(ix, pt);
         if (st != COBS_GPU_OK) return st;
         if (pt.chunks.empty()) continue;
+        if (pt.built) {          // rows are written by the caller (index construction straight into HBM)
+            for (Chunk& c : pt.chunks) HIP_TRY(hipMemset(c.d_data, 0, c.bytes));
+            continue;
+        }
         if (pt.synthetic) {
             if (!pt.streamed) {
                 for (Chunk& c : pt.chunks) HIP_TRY(launch_synth(synth_args(pt, c, c.d_data), nullptr));
@@ -792,6 +796,35 @@ cobs_gpu_status cobs_gpu_open_synthetic(const cobs_gpu_synth* d, const cobs_gpu_
 }
 
 void cobs_gpu_close(cobs_gpu_index* ix) { delete ix; }
+
+}  // extern "C"
+
+// An all-zero resident index of the given geometry (unsharded, no budget): index construction
+// fills its rows in place (build.cpp), so that build -> query needs no file.
+cobs_gpu_status cobs_amd::open_zeroed(IndexMeta&& meta, const cobs_gpu_options* opts, cobs_gpu_index** out) {
+    return guarded([&]() -> cobs_gpu_status {
+        std::unique_ptr<cobs_gpu_index> ix(new cobs_gpu_index);
+        Part pt;
+        pt.meta = std::move(meta);
+        pt.built = true;
+        ix->parts.push_back(std::move(pt));
+        cobs_gpu_status st = read_options(opts, ix.get());
+        if (st != COBS_GPU_OK) return st;
+        if (ix->shard_count > 1 || ix->hbm_budget)
+            return fail(COBS_GPU_ERR_UNSUPPORTED, "an index is built into HBM whole: no shard, no budget");
+        st = plan_index(ix.get());
+        if (st != COBS_GPU_OK) return st;
+        st = select_device(opts, &ix->device);
+        if (st != COBS_GPU_OK) return st;
+        std::vector<std::unique_ptr<MappedFile>> none;
+        st = stage_index(ix.get(), none);
+        if (st != COBS_GPU_OK) return st;
+        *out = ix.release();
+        return COBS_GPU_OK;
+    });
+}
+
+extern "C" {
 
 cobs_gpu_status cobs_gpu_plan_shards(const char* path, uint32_t shard_count, uint32_t shard_mode,
                                      uint64_t* slot_begin, uint64_t* slot_count, uint64_t* bytes) {

@@ -140,6 +140,7 @@ struct Part {
     std::unique_ptr<MappedFile> file;        // source of the chunks
     bool file_pinned = false;                // the mapping is registered with HIP: DMA straight from it
     bool synthetic = false;
+    bool built = false;                      // rows are produced in place by index construction
     uint64_t synth_seed = 0;
     uint64_t doc_offset = 0;      // first global score slot of this file
     uint64_t slot_begin = 0;      // file-level score slots computed here
@@ -275,5 +276,6 @@ uint64_t total_hashes(const cobs_gpu_batch* b, size_t q);
 bool hit_before(const cobs_gpu_hit& a, const cobs_gpu_hit& b);
 bool doc_before(const cobs_gpu_hit& a, const cobs_gpu_hit& b);
 void destroy_exchange(Exchange* x);       // comm.cpp
+cobs_gpu_status open_zeroed(IndexMeta&& meta, const cobs_gpu_options* opts, cobs_gpu_index** out);
 
 }  // namespace cobs_amd

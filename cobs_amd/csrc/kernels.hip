@@ -231,6 +231,32 @@ __device__ __forceinline__ uint64_t xxh64_31(const uint32_t (&c)[8], uint64_t se
     return h;
 }
 
+// canonical form of a 31-mer of valid bases held in eight dwords (byte 31 zero): c = f or its
+// reverse complement (util/query.cpp:143-199)
+__device__ __forceinline__ void canon31(const uint32_t (&f)[8], uint32_t (&c)[8]) {
+    // reverse complement: B[j] = comp(raw[31 - j]) for the 32-byte block, then drop B[0]
+    uint32_t rv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rv[j] = __builtin_bswap32(comp4(f[7 - j]));
+    uint32_t rc[8];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) rc[j] = (rv[j] >> 8) | (rv[j + 1] << 24);
+    rc[7] = rv[7] >> 8;
+    // first strict difference among positions 0..14 decides (big-endian compare);
+    // the middle base (position 15) is never compared; ties keep the forward k-mer
+    bool use_rc = false, decided = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t x = __builtin_bswap32(f[j]), y = __builtin_bswap32(rc[j]);
+        if (j == 3) { x >>= 8; y >>= 8; }
+        if (!decided && x != y) { use_rc = x > y; decided = true; }
+    }
+    if (use_rc) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[j] = rc[j];
+    }
+}
+
 template <typename IdxT>
 __global__ __launch_bounds__(256) void hash_kernel_k31(HashArgs a, uint64_t total_threads) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -281,29 +307,7 @@ __global__ __launch_bounds__(256) void hash_kernel_k31(HashArgs a, uint64_t tota
     uint32_t c[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) c[j] = f[j];
-    if (a.canonicalize != 0) {
-        // reverse complement: B[j] = comp(raw[31 - j]) for the 32-byte block, then drop B[0]
-        uint32_t rv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) rv[j] = __builtin_bswap32(comp4(f[7 - j]));
-        uint32_t rc[8];
-#pragma unroll
-        for (int j = 0; j < 7; ++j) rc[j] = (rv[j] >> 8) | (rv[j + 1] << 24);
-        rc[7] = rv[7] >> 8;
-        // first strict difference among positions 0..14 decides (big-endian compare);
-        // the middle base (position 15) is never compared; ties keep the forward k-mer
-        bool use_rc = false, decided = false;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            uint32_t x = __builtin_bswap32(f[j]), y = __builtin_bswap32(rc[j]);
-            if (j == 3) { x >>= 8; y >>= 8; }
-            if (!decided && x != y) { use_rc = x > y; decided = true; }
-        }
-        if (use_rc) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) c[j] = rc[j];
-        }
-    }
+    if (a.canonicalize != 0) canon31(f, c);
     for (uint32_t j = 0; j < H; ++j) {
         const uint64_t h = xxh64_31(c, (uint64_t)j);
         for (uint32_t p = 0; p < a.npages; ++p) {
@@ -1198,6 +1202,70 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 
+// classic_construct_random (construction/classic_index.cpp:661-725): every document is
+// document_size random 31-mers; each is canonicalised, hashed and its bit set.  One thread per
+// (document, k-mer); the 31 bases are the low 62 bits of mix64(mix64(seed ^ doc) + j), two bits
+// per base (A C G T), first base in the lowest bits.
+__global__ __launch_bounds__(256) void random_build_kernel(RandomBuildArgs a, uint64_t total) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const uint64_t doc = gid / a.document_size, j = gid - doc * a.document_size;
+    uint64_t bits = mix64(mix64(a.seed ^ (a.doc0 + doc)) + j);
+    uint32_t f[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t code = (uint32_t)(bits >> (2 * (4 * w + b))) & 3u;
+            // A 0x41, C 0x43, G 0x47, T 0x54
+            const uint32_t ch = code == 0 ? 0x41u : code == 1 ? 0x43u : code == 2 ? 0x47u : 0x54u;
+            v |= ch << (8 * b);
+        }
+        f[w] = v;
+    }
+    f[7] &= 0x00FFFFFFu;
+    uint32_t c[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) c[w] = f[w];
+    canon31(f, c);
+    const uint64_t col = a.doc0 + doc;
+    const uint64_t byte_in_row = col >> 3;
+    const uint32_t bit = 1u << ((uint32_t)(byte_in_row & 3u) * 8u + (uint32_t)(col & 7u));
+    for (uint32_t h = 0; h < a.num_hashes; ++h) {
+        const uint64_t row = fast_mod(xxh64_31(c, (uint64_t)h), a.signature_size, a.magic);
+        atomicOr(a.matrix + (row * a.row_bytes + byte_in_row) / 4u, bit);
+    }
+}
+
+// classic_combine (construction/classic_index.cpp:195-327): row r of the output is the rows r of
+// the inputs concatenated at BIT granularity (input i contributes its row_bits[i] documents).
+// One thread per output byte.
+__global__ __launch_bounds__(256) void combine_kernel(CombineArgs a) {
+    const uint64_t total = a.rows * a.dst_row_bytes;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t row = i / a.dst_row_bytes;
+        const uint64_t ob = i - row * a.dst_row_bytes;
+        uint64_t bit = ob * 8;                                  // first output document of this byte
+        // source holding document `bit`: last s with bit_off[s] <= bit
+        uint32_t lo = 0, hi = a.nsrc;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (a.bit_off[mid] <= bit) lo = mid; else hi = mid;
+        }
+        uint32_t sidx = lo, v = 0;
+#pragma unroll 1
+        for (uint32_t b = 0; b < 8 && bit < a.bit_off[a.nsrc]; ++b, ++bit) {
+            while (bit >= a.bit_off[sidx + 1]) ++sidx;          // sources without documents are skipped
+            const uint64_t sb = bit - a.bit_off[sidx];
+            const uint8_t byte = a.src[sidx][row * a.src_row_bytes[sidx] + (sb >> 3)];
+            v |= ((uint32_t)(byte >> (sb & 7u)) & 1u) << b;
+        }
+        a.dst[i] = (uint8_t)v;
+    }
+}
+
 __device__ __forceinline__ uint64_t synth_word(uint64_t seed, uint32_t page, uint64_t row, uint64_t w) {
     const uint64_t key = mix64(seed ^ mix64(((uint64_t)page << 40) ^ row));
     const uint64_t c = key + w * 6;
@@ -1426,6 +1494,21 @@ hipError_t launch_build(const BuildArgs& a, uint64_t total_bytes, hipStream_t st
     const uint64_t blocks = (total_bytes + 255) / 256;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(build_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, a, total_bytes);
+    return hipGetLastError();
+}
+
+hipError_t launch_random_build(const RandomBuildArgs& a, uint64_t ndocs, hipStream_t stream) {
+    const uint64_t total = ndocs * a.document_size;
+    if (total == 0) return hipSuccess;
+    const uint64_t blocks = (total + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(random_build_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, a, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_combine(const CombineArgs& a, hipStream_t stream) {
+    if (a.rows == 0 || a.dst_row_bytes == 0) return hipSuccess;
+    hipLaunchKernelGGL(combine_kernel, dim3(8192), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -170,7 +170,13 @@ typedef struct cobs_gpu_build_params {
     uint64_t signature_size;     /* 0 = calc_signature_size(largest document, num_hashes, fpr) */
     uint64_t page_size;          /* compact: 0 = reference heuristic (compact_index.cpp:184-189) */
     int32_t device;              /* -1 = current */
-    uint32_t reserved;
+    uint32_t text_batch_bytes;   /* documents are uploaded and hashed in batches of at most this much text
+                                    (0 = 256 MiB): the batching of classic_index.cpp:565-659 without the
+                                    per-batch index files -- every batch sets its bits in the one matrix in HBM */
+    /* optional, ndocs entries: the number of terms of every document as the reference's document
+     * index reports it (FastaFile::num_terms, fasta_file.hpp:147-153) -- what sizes a signature when
+     * signature_size is 0.  NULL = count the k-grams of the given text. */
+    const uint64_t* doc_terms;
 } cobs_gpu_build_params;
 
 /* classic_construct (construction/classic_index.cpp:565-659) for documents that are already
@@ -187,6 +193,25 @@ cobs_gpu_status cobs_gpu_build_compact(const char* const* names, const char* con
                                        const size_t* lens, size_t ndocs,
                                        const cobs_gpu_build_params* params, const char* out_path);
 
+/* classic_construct (kind 0) / compact_construct (kind 1) straight into a resident query handle:
+ * the bit matrix is built inside the handle's HBM blob at the engine's row pitch; no file, no host
+ * copy (the reference always goes through a file: classic_index.cpp:565-659).  Arguments as
+ * cobs_gpu_build_classic / _compact; opts may select the device (no shard, no budget). */
+cobs_gpu_status cobs_gpu_build_index(uint32_t kind, const char* const* names, const char* const* texts,
+                                     const size_t* lens, size_t ndocs, const cobs_gpu_build_params* params,
+                                     const cobs_gpu_options* opts, cobs_gpu_index** out);
+/* classic_combine (construction/classic_index.cpp:195-327): the rows of n classic indexes with equal
+ * term size / canonicalize / hashes / signature size concatenated at bit granularity into one
+ * index, document names in input order; row batches of at most mem_bytes (0 = 1 GiB) are
+ * interleaved on the device. */
+cobs_gpu_status cobs_gpu_combine_classic(const char* const* in_paths, size_t n, const char* out_path,
+                                         uint64_t mem_bytes, int device);
+/* classic_construct_random (classic_index.cpp:661-725; `cobs classic-construct-random`,
+ * src/cobs.cpp:243-291): num_documents documents of document_size random 31-mers, canonicalised,
+ * hashed num_hashes times into signature_size rows, written as a .cobs_classic file.  Same
+ * distribution as the reference, not the same random stream. */
+cobs_gpu_status cobs_gpu_construct_random(const char* out_path, uint64_t signature_size, uint64_t num_documents,
+                                          uint64_t document_size, uint64_t num_hashes, uint64_t seed, int device);
 /* The procedural index of cobs_gpu_open_synthetic written as a .cobs_classic / .cobs_compact FILE
  * (the generator tool of SURVEY 8f rank 2, cf. `cobs classic-construct-random`, src/cobs.cpp:243-291):
  * rows are produced on the device chunk by chunk and streamed to the file. */

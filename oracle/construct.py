@@ -79,11 +79,42 @@ def base_name(path):
     return os.path.basename(path).split(".")[0]
 
 
+def fasta_term_buffers(path, k):
+    """FastaFile::process_terms (fasta_file.hpp:155-182) followed literally, std::string and all:
+    yields every buffer whose k-windows the reference hands to the callback.  Its quirks are part
+    of what an index holds: after a run no longer than k-1 characters the buffer is kept and `pos`
+    is reset to 0, so a following '>' / ';' line is APPENDED and hashed as sequence; `pos` survives
+    a clear, so after a comment line the next line is tested at index k-1 instead of 0 (a line of
+    exactly k-1 characters is dropped as "empty").  Where the reference indexes past the end of
+    the string (undefined behaviour) the line is taken as sequence."""
+    line = bytearray()
+    pos = 0
+    for ln in _fasta_lines(path):
+        line += ln                                       # tlx::appendline
+        if len(line) == pos:
+            first = None                                 # "empty line"
+        elif pos < len(line):
+            first = line[pos:pos + 1]
+        else:
+            first = b"A"                                 # out-of-range read in the reference
+        if first is None or first in (b">", b";"):
+            line = bytearray()                           # line.clear(); pos keeps its value
+            continue
+        if len(line) >= k:
+            yield bytes(line)
+        if len(line) > k - 1:
+            line = line[len(line) - (k - 1):]
+            pos = len(line)
+        else:
+            pos = 0
+
+
 def fasta_doc(path, k, canonicalize, num_hashes, rel_path=None):
-    seqs = fasta_sequences(path)
-    hs = [_o.term_hashes(s, k, canonicalize, num_hashes)[0] for s in seqs if len(s) >= k]
+    # bits come from process_terms (the buffers above), the term COUNT that sizes the signature
+    # from the cached index (compute_index / num_terms, fasta_file.hpp:53-91,147-153)
+    hs = [_o.term_hashes(b, k, canonicalize, num_hashes)[0] for b in fasta_term_buffers(path, k)]
     hashes = np.concatenate(hs) if hs else np.zeros((0, num_hashes), dtype=np.uint64)
-    num_terms = sum(max(len(s) - k + 1, 0) for s in seqs)
+    num_terms = sum(max(len(s) - k + 1, 0) for s in fasta_sequences(path))
     return Doc(base_name(path), rel_path or path, fasta_size(path), num_terms, hashes)
 
 
@@ -233,3 +264,73 @@ def compact_construct(docs, out_path, term_size=31, canonicalize=1, num_hashes=1
         names.extend(d.name for d in part)
     write_compact(out_path, term_size, canonicalize, page_size, params, names, mats)
     return page_size, params
+
+
+# ---------------------------------------------------------------------------
+# classic_combine and classic_construct_random (restated; checkers of the GPU versions)
+
+
+def read_classic(path):
+    """-> (term_size, canonicalize, names, signature_size, num_hashes, matrix uint8 [S, ceil(D/8)])"""
+    raw = open(path, "rb").read()
+    assert raw[:18] == b"COBS:CLASSIC_INDEX"
+    ver, k, canon, ndocs, sig, nh = struct.unpack_from("<IIBIQQ", raw, 18)
+    pos = 18 + struct.calcsize("<IIBIQQ")
+    names = []
+    for _ in range(ndocs):
+        e = raw.index(b"\n", pos)
+        names.append(raw[pos:e].decode())
+        pos = e + 1
+    assert raw[pos:pos + 13] == b"CLASSIC_INDEX"
+    pos += 13
+    row = (ndocs + 7) // 8
+    m = np.frombuffer(raw, dtype=np.uint8, count=sig * row, offset=pos).reshape(sig, row)
+    return k, canon, names, sig, nh, m
+
+
+def classic_combine(in_paths, out_path):
+    """classic_combine_streams (classic_index.cpp:195-327): output row = the inputs' rows
+    concatenated at bit granularity (input i contributes its number of documents), names in order"""
+    parts, names, head = [], [], None
+    for p in in_paths:
+        k, canon, nm, sig, nh, m = read_classic(p)
+        assert head in (None, (k, canon, sig, nh))
+        head = (k, canon, sig, nh)
+        parts.append(np.unpackbits(m, axis=1, bitorder="little")[:, :len(nm)])
+        names += nm
+    bits = np.concatenate(parts, axis=1)
+    pad = (-bits.shape[1]) % 8
+    if pad:
+        bits = np.concatenate([bits, np.zeros((bits.shape[0], pad), dtype=np.uint8)], axis=1)
+    k, canon, sig, nh = head
+    write_classic(out_path, k, canon, names, sig, nh, np.packbits(bits, axis=1, bitorder="little"))
+
+
+def _mix64(z):
+    z = (z + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+    z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)).astype(np.uint64)
+    z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)).astype(np.uint64)
+    return z ^ (z >> np.uint64(31))
+
+
+def classic_construct_random(out_path, signature_size, num_documents, document_size, num_hashes, seed):
+    """classic_construct_random (classic_index.cpp:661-725) with the engine's counter generator:
+    k-mer j of document d = the low 62 bits of mix64(mix64(seed ^ d) + j), two bits per base
+    (A C G T), first base lowest; canonicalised, hashed, bit set"""
+    old = np.seterr(over="ignore")
+    try:
+        row = (num_documents + 7) // 8
+        m = np.zeros((signature_size, row), dtype=np.uint8)
+        base = np.frombuffer(b"ACGT", dtype=np.uint8)
+        for d in range(num_documents):
+            key = _mix64(np.array([np.uint64(seed) ^ np.uint64(d)], dtype=np.uint64))[0]
+            bits = _mix64((key + np.arange(document_size, dtype=np.uint64)).astype(np.uint64))
+            codes = (bits[:, None] >> (np.uint64(2) * np.arange(31, dtype=np.uint64))[None, :]) & np.uint64(3)
+            kmers = base[codes.astype(np.int64)]
+            for j in range(document_size):
+                hs, good = _o.term_hashes(kmers[j].tobytes(), 31, 1, num_hashes)
+                rows = (hs.reshape(-1) % np.uint64(signature_size)).astype(np.int64)
+                m[rows, d // 8] |= np.uint8(1 << (d % 8))
+    finally:
+        np.seterr(**old)
+    write_classic(out_path, 31, 1, ["file_%06d" % i for i in range(num_documents)], signature_size, num_hashes, m)

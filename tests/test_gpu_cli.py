@@ -109,3 +109,10 @@ def test_sharded_class_and_generator_tool(gpu_lib, oracle, golden_dir, tmp_path)
     r = _run("-i", out, "-t", "0.3", q.decode())
     want = "".join("%s\t%d\n" % (n, s) for (_, _, n, s) in oracle.search(ix, q, 0.3))
     assert r.returncode == 0 and r.stdout == want
+    # `cobs classic-construct-random` flags (src/cobs.cpp:243-291)
+    rnd = str(tmp_path / "rnd.cobs_classic")
+    r = _run("--construct-random", rnd, "-s", "5003", "-n", "40", "-m", "900", "--num-hashes", "2", "--seed", "3")
+    assert r.returncode == 0, r.stderr
+    ixr = oracle.Index.open(rnd)
+    assert (ixr.num_docs, ixr.num_hashes, ixr.term_size, ixr.signature_size(0)) == (40, 2, 31, 5003)
+    assert ixr.doc_name(39) == "file_000039"

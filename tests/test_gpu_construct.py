@@ -134,3 +134,100 @@ def test_write_synthetic_file_is_the_procedural_index(gpu_lib, oracle, tmp_path)
     for q in cases.queries_acgt(2, 300, 50):
         assert np.array_equal(oracle.Index.open(pk).counts(q), ref2.counts(q))
         assert np.array_equal(s2.counts(q), ref2.counts(q))
+
+
+def test_construct_follows_process_terms_on_odd_fasta(gpu_lib, oracle, construct, tmp_path):
+    """documents whose sequences are shorter than k, comment lines after sequences, CRLF: the GPU
+    builder's files equal the oracle's construction byte for byte (both follow the reference's
+    process_terms state machine, fasta_file.hpp:155-182; the signature size comes from num_terms)"""
+    import cobs_amd
+    from tests.test_oracle_pins import QUIRK_FASTAS
+    d = tmp_path / "odd"
+    d.mkdir()
+    for name, raw in QUIRK_FASTAS.items():
+        (d / (name + ".fasta")).write_bytes(raw)
+    for ext, build_gpu, build_ref in (
+            (".cobs_classic", cobs_amd.classic_construct, construct.classic_construct),
+            (".cobs_compact", cobs_amd.compact_construct, construct.compact_construct)):
+        pg, pr = str(tmp_path / ("g" + ext)), str(tmp_path / ("r" + ext))
+        params = cobs_amd.ClassicIndexParameters() if "classic" in ext else cobs_amd.CompactIndexParameters()
+        params.false_positive_rate = 0.1
+        params.num_hashes = 2
+        build_gpu(str(d), pg, params)
+        docs = construct.fasta_dir_docs(str(d), 31, 1, 2)
+        build_ref(docs, pr, num_hashes=2, false_positive_rate=0.1)
+        assert open(pg, "rb").read() == open(pr, "rb").read(), ext
+
+
+def test_combine_on_the_device(gpu_lib, oracle, construct, tmp_path):
+    """classic_combine (classic_index.cpp:195-327): byte-aligned and unaligned document counts,
+    one batch and several row batches; byte-identical to the numpy restatement; the combined
+    index answers like the union of its parts"""
+    import cobs_amd
+    q = oracle.random_sequence(200, 12)
+    for tag, counts in (("aligned", [16, 8, 24, 5]), ("unaligned", [5, 9, 3, 1, 14]), ("single", [11])):
+        parts = []
+        for i, n in enumerate(counts):
+            p = cases.make_classic(cases.tmp(tmp_path, "%s%d.cobs_classic" % (tag, i)), n, 977, 2, 31, 1, 0.3, 30 + i,
+                                   planted={0: 1.0}, query=q)
+            parts.append(p)
+        want = str(tmp_path / (tag + "_ref.cobs_classic"))
+        construct.classic_combine(parts, want)
+        for mem in (0, 300, 4096):                      # 0 = one batch; 300 bytes = a few rows per batch
+            got = str(tmp_path / ("%s_gpu_%d.cobs_classic" % (tag, mem)))
+            cobs_amd.classic_combine(parts, got, mem_bytes=mem)
+            assert open(got, "rb").read() == open(want, "rb").read(), (tag, mem)
+        s = gpu_lib.Search(want)
+        c = s.counts(q)
+        off = 0
+        for p, n in zip(parts, counts):
+            assert np.array_equal(c[off:off + n], oracle.Index.open(p).counts(q)[:n])
+            off += n
+    # mismatching parameters are refused
+    other = cases.make_classic(cases.tmp(tmp_path, "other.cobs_classic"), 8, 983, 2, 31, 1, 0.3, 77)
+    with pytest.raises(cobs_amd.CobsGpuError):
+        cobs_amd.classic_combine([parts[0], other], str(tmp_path / "bad.cobs_classic"))
+
+
+def test_construct_random_tool(gpu_lib, oracle, construct, tmp_path):
+    """classic_construct_random (classic_index.cpp:661-725): the file equals the numpy restatement of
+    the same generator byte for byte; fill ratio as the reference's "ratio of ones" (1 - e^(-mH/S))"""
+    import cobs_amd
+    got, want = str(tmp_path / "rg.cobs_classic"), str(tmp_path / "rr.cobs_classic")
+    cobs_amd.classic_construct_random(got, signature_size=1999, num_documents=21, document_size=150, num_hashes=2, seed=5)
+    construct.classic_construct_random(want, 1999, 21, 150, 2, 5)
+    assert open(got, "rb").read() == open(want, "rb").read()
+    big = str(tmp_path / "big.cobs_classic")
+    cobs_amd.classic_construct_random(big, signature_size=200003, num_documents=203, document_size=70000, num_hashes=1, seed=9)
+    k, canon, names, sig, nh, m = construct.read_classic(big)
+    assert (k, canon, sig, nh, len(names)) == (31, 1, 200003, 1, 203) and names[202] == "file_000202"
+    bits = np.unpackbits(m, axis=1, bitorder="little")[:, :203]
+    fill = bits.mean(axis=0)
+    expect = 1.0 - np.exp(-70000 / 200003)
+    assert np.all(np.abs(fill - expect) < 0.01)
+    assert not np.unpackbits(m, axis=1, bitorder="little")[:, 203:].any()
+    s = gpu_lib.Search(big)                                  # and the engine reads it
+    assert s.info(0).num_docs == 203
+
+
+def test_build_into_hbm_and_text_batches(gpu_lib, oracle, construct, golden_dir, tmp_path):
+    """cobs_gpu_build_index: construction straight into a resident query handle (no file) answers
+    exactly like the file-built index; tiny text batches (every document its own upload, the
+    batching of classic_index.cpp:565-659) give the same bytes"""
+    import cobs_amd
+    fasta = os.path.join(golden_dir, "fasta")
+    Q50 = b"AGTCAACGCTAAGGCATTTCCCCCCTGCCTCCTGCCTGCTGCCAAGCCCT"
+    for kind, golden in (("classic", "c1.cobs_classic"), ("compact", "c1.cobs_compact")):
+        ix = oracle.Index.open(os.path.join(golden_dir, golden))
+        s = cobs_amd.build_search(fasta, kind=kind)
+        assert s.info(0).num_docs == 7 and s.signature_size(0, 0) == 8748
+        assert np.array_equal(s.counts(Q50), ix.counts(Q50))
+        assert [(r.doc_name, r.score) for r in s.search(Q50.decode())] == \
+            [(n, sc) for (_, _, n, sc) in oracle.search(ix, Q50)]
+        qs = cases.queries_acgt(4, 120, 3)
+        assert s.search_hits(qs, 0.0, 3) == [cases.oracle_results([ix], q, 0.0, 3) for q in qs]
+        params = cobs_amd.ClassicIndexParameters() if kind == "classic" else cobs_amd.CompactIndexParameters()
+        params.text_batch_bytes = 700                            # smaller than any document: one document per batch
+        out = str(tmp_path / ("b." + ("cobs_" + kind)))
+        (cobs_amd.classic_construct if kind == "classic" else cobs_amd.compact_construct)(fasta, out, params)
+        assert open(out, "rb").read() == open(os.path.join(golden_dir, golden), "rb").read()

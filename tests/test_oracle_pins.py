@@ -379,3 +379,52 @@ def test_indexes_with_different_term_sizes(oracle, tmp_path):
     with pytest.raises(oracle.OracleError):
         oracle.search([a, b], q[:30])          # shorter than the largest term size: "query too short"
     oracle.search([b], q[:21])                 # fine for the k = 21 file alone
+
+
+QUIRK_FASTAS = {
+    # a sequence shorter than k before a header: the reference keeps the buffer and resets pos to
+    # 0, so the header line is appended and hashed as sequence (fasta_file.hpp:170-180)
+    "short_then_header": b">d\nACGTACGTAC\n>second header with some text\nACGTTGCAACGTTGCAACGTTGCAACGTTGCAACGTTGCAAC\n",
+    # after a run longer than k-1 the buffer holds k-1 characters and pos = k-1: a next line of
+    # exactly k-1 characters following a comment line counts as "empty" and is dropped
+    "line_of_k_minus_1": b">d\n" + b"ACGTTGCA" * 6 + b"\n>h2\n" + b"ACGTTGCAAC" * 3 + b"\n" + b"TTGACCAGTA" * 5 + b"\n",
+    # two comment lines in a row after a sequence: the second is tested at index k-1
+    "two_comments": b">d\n" + b"ACGTTGCA" * 6 + b"\n;first comment\n;a second comment line that is longer than thirty characters\n"
+                    + b"GGATCCAGTA" * 5 + b"\n",
+    "multi_line_sequence": b">d\n" + b"ACGTTGCAAC" * 4 + b"\n" + b"TGCATGCAAA" * 2 + b"\nACG\n\nACGTTGCAACGTTGCAACGTTGCAACGTTGCAACG\n",
+    "crlf": b">d\r\n" + b"ACGTTGCAAC" * 4 + b"\r\n" + b"TGCATGCAAA" * 4 + b"\r\n",
+    "only_short": b">d\nACGT\n>e\nTTTT\n",
+}
+
+
+def test_fasta_term_state_machine_restated_twice(oracle, construct, tmp_path):
+    """FastaFile::process_terms (/root/reference/cobs/fasta_file.hpp:155-182) has edge behaviour
+    that decides which bits an index holds (short sequences, comment lines after a sequence).
+    The oracle follows the reference's loop literally (std::string buffer + pos); the product's
+    host mirror (cobs_amd/construct.py) derives character runs.  Both must hash the same terms,
+    and on ordinary FASTA both equal the plain grammar."""
+    from cobs_amd import construct as mirror
+    k = 31
+    for name, raw in QUIRK_FASTAS.items():
+        p = tmp_path / (name + ".fasta")
+        p.write_bytes(raw)
+        bufs = list(construct.fasta_term_buffers(str(p), k))
+        terms_oracle = [b[i:i + k] for b in bufs for i in range(len(b) - k + 1)]
+        text, size, nterms = mirror._read_fasta(str(p), k)
+        terms_mirror = [r[i:i + k] for r in text.split(b"\n") for i in range(len(r) - k + 1)]
+        assert terms_mirror == terms_oracle, name
+        assert size == construct.fasta_size(str(p))
+        assert nterms == sum(max(len(s) - k + 1, 0) for s in construct.fasta_sequences(str(p))), name
+    # the quirks are real: header text is hashed / a line is dropped
+    p = tmp_path / "short_then_header.fasta"
+    bufs = list(construct.fasta_term_buffers(str(p), k))
+    assert any(b">second header" in b for b in bufs)
+    p = tmp_path / "line_of_k_minus_1.fasta"
+    assert not any(b"ACGTTGCAAC" * 3 in b for b in construct.fasta_term_buffers(str(p), k))
+    # ordinary FASTA (the reference's own corpus): identical to maximal runs of sequence lines
+    for i in range(1, 8):
+        f = os.path.join(os.path.dirname(__file__), "golden", "fasta", "sample%d.fasta" % i)
+        f = f if os.path.exists(f) else f + ".gz"
+        plain = [s[j:j + k] for s in construct.fasta_sequences(f) for j in range(len(s) - k + 1)]
+        got = [b[j:j + k] for b in construct.fasta_term_buffers(f, k) for j in range(len(b) - k + 1)]
+        assert got == plain
