@@ -108,6 +108,7 @@ SYMBOLS = {
     "cobs_gpu_batch_stats": (_int, [_vp, C.POINTER(_u64 * 4)]),
     "cobs_gpu_batch_kernel_ms": (_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "cobs_gpu_batch_phase_stamps": (_int, [_vp, _pu64, _sz, C.POINTER(_sz)]),
+    "cobs_gpu_graph_replays": (_u64, [_vp]),
     "cobs_gpu_timers": (_int, [_vp, C.POINTER(C.c_double * 5), _int]),
     "cobs_gpu_comm_unique_id": (_int, [_vp]),
     "cobs_gpu_comm_create": (_int, [_vp, _int, _int, _int, C.POINTER(_vp)]),

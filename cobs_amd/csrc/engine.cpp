@@ -158,6 +158,9 @@ uint64_t slice_bytes(uint64_t sig, uint64_t ncols, const Tuning& tune) {
 // Tuning hooks (per handle): tile_w, waves, mq force a value.
 struct ScanGeom { uint32_t tile_w; int nwaves; bool multi_query; };
 
+// a replayed small pass brings this many hit-pool entries home inside the graph
+constexpr size_t kGraphPoolPrefix = 2048;
+
 // K3 orders up to this many survivors per (query, file) on the device (8-byte keys in 64 KB of LDS)
 constexpr size_t kTopkSortLimit = 8192;
 
@@ -1116,12 +1119,9 @@ extern "C" cobs_gpu_status cobs_gpu_batch_set_queries(cobs_gpu_batch* b, const c
 
 // want_counts = false: the caller only needs the selected hits (threshold > 0, no top-k), so the
 // scan does not write the score rows (for reads they are up to a third of the traffic).
-cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t topk, void* hip_stream,
-                                   bool want_counts) {
-    if (!b) return fail(COBS_GPU_ERR_ARG, "NULL batch");
+// what a run leaves behind on the host side of the batch (a replayed graph sets the same)
+static void set_run_state(cobs_gpu_batch* b, double threshold, size_t topk, bool want_counts) {
     cobs_gpu_index* ix = b->ix;
-    hipStream_t st = (hipStream_t)hip_stream;
-    HIP_TRY(hipSetDevice(ix->device));
     b->ran = false;
     b->synced = false;
     b->pool_fetched = false;
@@ -1130,16 +1130,27 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
     b->view_global = false;
     b->pool_global = false;
     b->topk_stride = 0;
+    b->graph_run = false;
     b->threshold = threshold;
-    const size_t nq = b->nq;
     // K3 (exact top-k on the device, every score width) needs a bounded k
     const bool use_topk = topk > 0 && topk <= 65536 &&
-                          (uint64_t)topk * std::max<size_t>(nq, 1) * ix->parts.size() <= (1ull << 27);
+                          (uint64_t)topk * std::max<size_t>(b->nq, 1) * ix->parts.size() <= (1ull << 27);
     b->topk_k = use_topk ? (uint32_t)topk : 0;
     b->topk_sorted = use_topk && topk <= kTopkSortLimit;
     // with K3 the threshold is applied there; otherwise K2 selects into the hit pool
     b->selected = threshold > 0.0 && !use_topk;
     b->have_counts = want_counts || !b->selected;
+}
+
+cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t topk, void* hip_stream,
+                                   bool want_counts) {
+    if (!b) return fail(COBS_GPU_ERR_ARG, "NULL batch");
+    cobs_gpu_index* ix = b->ix;
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIP_TRY(hipSetDevice(ix->device));
+    set_run_state(b, threshold, topk, want_counts);
+    const size_t nq = b->nq;
+    const bool use_topk = b->topk_k != 0;
     // score rows are allocated by the first run that writes them (a hits-only caller never pays
     // for them: 100k reads x 100k documents would be 10 GB)
     if (b->have_counts) HIP_TRY(b->counts.reserve((size_t)(nq * ix->local_counts * b->elem_bytes)));
@@ -1314,8 +1325,13 @@ cobs_gpu_status cobs_gpu_batch_sync(cobs_gpu_batch* b, void* hip_stream, size_t*
     if (!b->ran) return fail(COBS_GPU_ERR_ARG, "batch has not been run");
     hipStream_t st = (hipStream_t)hip_stream;
     HIP_TRY(hipSetDevice(b->ix->device));
-    HIP_TRY(hipMemcpyAsync(b->h_flags, b->flags.p, sizeof b->h_flags, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    if (b->graph_run && b->h_res.p) {            // the graph already copied the flags (and the results) home
+        HIP_TRY(hipStreamSynchronize(st));
+        std::memcpy(b->h_flags, b->h_res.p, sizeof b->h_flags);
+    } else {
+        HIP_TRY(hipMemcpyAsync(b->h_flags, b->flags.p, sizeof b->h_flags, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     b->synced = true;
     if (b->h_flags[0] != 0u) {           // K1 keeps 2^32-1 - (first query with a non-ACGT character)
         const uint32_t bad = 0xFFFFFFFFu - b->h_flags[0];
@@ -1350,6 +1366,10 @@ static cobs_gpu_status fetch_row(cobs_gpu_batch* b, size_t q, const uint8_t** ro
     const size_t row_bytes = (size_t)((glob ? b->ix->total_counts : b->ix->local_counts) * b->elem_bytes);
     if (glob && (q < b->g_q0 || q >= b->g_q0 + b->g_qn))
         return fail(COBS_GPU_ERR_ARG, "this rank does not hold the exchanged row of that query");
+    if (!glob && b->graph_run && b->res_rows && b->rows_q1 == 0) {
+        b->rows_q0 = 0;                 // the replayed graph copied all rows of this small pass into the window
+        b->rows_q1 = b->nq;
+    }
     if (q < b->rows_q0 || q >= b->rows_q1) {
         const size_t per = std::max<size_t>(1, (64u << 20) / std::max<size_t>(row_bytes, 1));
         const size_t q1 = std::min(glob ? (size_t)(b->g_q0 + b->g_qn) : b->nq, q + per);
@@ -1497,8 +1517,13 @@ static cobs_gpu_status hits_host_impl(cobs_gpu_batch* b, size_t q, size_t num_re
         if (!b->topk_fetched) {
             b->h_topk.resize(k * b->nq * nparts);
             b->h_topk_cnt.resize(b->nq * nparts);
-            HIP_TRY(hipMemcpy(b->h_topk.data(), b->topk_out.p, sizeof(uint2) * b->h_topk.size(), hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(b->h_topk_cnt.data(), b->topk_cnt.p, 4 * b->h_topk_cnt.size(), hipMemcpyDeviceToHost));
+            if (b->graph_run && b->h_res.p) {
+                std::memcpy(b->h_topk_cnt.data(), b->h_res.p + 16, 4 * b->h_topk_cnt.size());
+                std::memcpy(b->h_topk.data(), b->h_res.p + b->res_topk, sizeof(uint2) * b->h_topk.size());
+            } else {
+                HIP_TRY(hipMemcpy(b->h_topk.data(), b->topk_out.p, sizeof(uint2) * b->h_topk.size(), hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(b->h_topk_cnt.data(), b->topk_cnt.p, 4 * b->h_topk_cnt.size(), hipMemcpyDeviceToHost));
+            }
             b->topk_fetched = true;
         }
         const size_t stride = b->topk_stride ? b->topk_stride : k;     // ranks * k after an exchange
@@ -1521,8 +1546,12 @@ static cobs_gpu_status hits_host_impl(cobs_gpu_batch* b, size_t q, size_t num_re
         if (!b->pool_fetched) {
             // the pool arrives in arbitrary order: bucket it by query with a counting scatter
             std::vector<HitDev> raw((size_t)b->h_nhits());
-            if (!raw.empty())
-                HIP_TRY(hipMemcpy(raw.data(), b->hits.p, sizeof(HitDev) * raw.size(), hipMemcpyDeviceToHost));
+            if (!raw.empty()) {
+                if (b->graph_run && b->h_res.p && raw.size() <= b->res_pool_n)
+                    std::memcpy(raw.data(), b->h_res.p + b->res_pool, sizeof(HitDev) * raw.size());
+                else
+                    HIP_TRY(hipMemcpy(raw.data(), b->hits.p, sizeof(HitDev) * raw.size(), hipMemcpyDeviceToHost));
+            }
             b->h_hit_off.assign(b->nq + 1, 0);
             for (const HitDev& h : raw) b->h_hit_off[h.query + 1]++;
             for (size_t i = 0; i < b->nq; ++i) b->h_hit_off[i + 1] += b->h_hit_off[i];
@@ -1636,6 +1665,99 @@ static cobs_gpu_status host_pass_begin(cobs_gpu_index* ix, int slot, const char*
     // with a threshold and no limit only the selected hits travel back: skip the score rows,
     // unless the hit pool overflows (then the pass is repeated with them and ranked on the host)
     const bool hits_only = threshold > 0.0 && topk == 0;
+    // Small calls (a single query is the reference's own entry point, search.hpp:39-42) are
+    // launch-bound: fill + K1 + K2 (+ K3) are four launches for ~15 us of work.  The second time
+    // the same shape comes along (same query lengths, parameters and buffers) the pass is captured
+    // into a hipGraph and from then on replayed with one launch.
+    bool any_streamed = false;
+    for (const auto& p : ix->parts) any_streamed = any_streamed || p.streamed;
+    if (nq > 0 && nq <= 16 && ix->tune.graph != 0 && !any_streamed && !ix->tune.phase_slots) {
+        // the shape of the pass and every address the captured nodes hold
+        auto make_key = [&]() {
+            uint64_t key = 1469598103934665603ull;
+            auto mixin = [&](uint64_t v) { key = (key ^ v) * 1099511628211ull; };
+            mixin(nq);
+            for (size_t q = 0; q < nq; ++q) mixin(lens[q]);
+            uint64_t tb;
+            std::memcpy(&tb, &threshold, 8);
+            mixin(tb); mixin(topk); mixin(hits_only);
+            mixin((uint64_t)(uintptr_t)b->text.p); mixin((uint64_t)(uintptr_t)b->counts.p); mixin((uint64_t)(uintptr_t)b->hits.p);
+            mixin((uint64_t)(uintptr_t)b->topk_out.p); mixin((uint64_t)(uintptr_t)b->topk_cnt.p);
+            for (auto& w : b->work) { mixin((uint64_t)(uintptr_t)w.table.p); mixin((uint64_t)(uintptr_t)w.thr.p); }
+            mixin((uint64_t)(uintptr_t)b->h_res.p); mixin((uint64_t)(uintptr_t)b->h_rows.p);      // the graph writes there
+            mixin((uint64_t)(uintptr_t)b->h_text.p); mixin((uint64_t)(uintptr_t)b->h_thr_stage.p);
+            mixin(ix->tune.waves); mixin(ix->tune.tile_w); mixin((uint64_t)(int64_t)ix->tune.mq); mixin(ix->tune.lds_staged);
+            return key;
+        };
+        const uint64_t key = make_key();
+        if (b->graph_exec && b->graph_key == key) {
+            set_run_state(b, threshold, topk, !hits_only);
+            HIP_TRY(hipGraphLaunch(b->graph_exec, b->own_stream));
+            b->graph_run = true;
+            b->run_seq++;
+            b->ran = true;
+            ix->graph_replays++;
+            HIP_TRY(hipEventRecord(b->done, b->own_stream));
+            return COBS_GPU_OK;
+        }
+        if (b->graph_candidate == key) {
+            // same shape twice in a row: every buffer already has its size (no allocation inside the capture)
+            hipGraph_t graph = nullptr;
+            // the results travel back inside the graph too (pinned buffers sized before the capture):
+            // flags | top-k counts and survivors | a prefix of the hit pool; score rows of an
+            // all-documents call go to the row window
+            const size_t np = ix->parts.size();
+            const bool will_topk = topk > 0 && topk <= 65536 && (uint64_t)topk * nq * np <= (1ull << 27);
+            const bool will_select = threshold > 0.0 && !will_topk;
+            const size_t res_topk_cnt = 16, res_topk = res_topk_cnt + (will_topk ? 4 * np * nq : 0);
+            const size_t res_pool = (res_topk + (will_topk ? 8 * np * nq * topk : 0) + 15) / 16 * 16;
+            const size_t pool_n = will_select ? std::min<size_t>(b->hit_cap, kGraphPoolPrefix) : 0;
+            const size_t row_bytes_all = (!will_topk && !will_select) ? (size_t)(nq * ix->local_counts * b->elem_bytes) : 0;
+            bool pre_ok = b->h_res.reserve(res_pool + pool_n * sizeof(HitDev) + 16) == hipSuccess;
+            if (row_bytes_all) pre_ok = pre_ok && row_bytes_all <= (64u << 20) && b->h_rows.reserve(row_bytes_all) == hipSuccess;
+            if (pre_ok && hipStreamBeginCapture(b->own_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                cobs_gpu_status cs = run_impl(b, threshold, topk, b->own_stream, !hits_only);
+                if (cs == COBS_GPU_OK) {
+                    hipError_t ce = hipMemcpyAsync(b->h_res.p, b->flags.p, 16, hipMemcpyDeviceToHost, b->own_stream);
+                    if (ce == hipSuccess && b->topk_k) {
+                        ce = hipMemcpyAsync(b->h_res.p + res_topk_cnt, b->topk_cnt.p, 4 * np * nq, hipMemcpyDeviceToHost, b->own_stream);
+                        if (ce == hipSuccess)
+                            ce = hipMemcpyAsync(b->h_res.p + res_topk, b->topk_out.p, 8 * np * nq * topk, hipMemcpyDeviceToHost, b->own_stream);
+                    }
+                    if (ce == hipSuccess && pool_n)
+                        ce = hipMemcpyAsync(b->h_res.p + res_pool, b->hits.p, pool_n * sizeof(HitDev), hipMemcpyDeviceToHost, b->own_stream);
+                    if (ce == hipSuccess && row_bytes_all && b->have_counts)
+                        ce = hipMemcpyAsync(b->h_rows.p, b->counts.p, row_bytes_all, hipMemcpyDeviceToHost, b->own_stream);
+                    if (ce != hipSuccess) cs = COBS_GPU_ERR_HIP;
+                }
+                const hipError_t ee = hipStreamEndCapture(b->own_stream, &graph);
+                hipGraphExec_t exec = nullptr;
+                if (cs == COBS_GPU_OK && ee == hipSuccess && graph &&
+                    hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                    if (b->graph_exec) (void)hipGraphExecDestroy(b->graph_exec);
+                    b->graph_exec = exec;
+                    b->graph_key = make_key();          // with the addresses as they are now
+                    b->res_topk = res_topk;
+                    b->res_pool = res_pool;
+                    b->res_pool_n = pool_n;
+                    b->res_rows = row_bytes_all != 0;
+                    (void)hipGraphDestroy(graph);
+                    HIP_TRY(hipGraphLaunch(b->graph_exec, b->own_stream));
+                    b->graph_run = true;
+                    HIP_TRY(hipEventRecord(b->done, b->own_stream));
+                    return COBS_GPU_OK;
+                }
+                if (graph) (void)hipGraphDestroy(graph);
+            }
+            (void)hipGetLastError();
+            ix->tune.graph = 0;              // capture is not possible here: never try again on this handle
+        }
+        st = run_impl(b, threshold, topk, b->own_stream, !hits_only);
+        if (st != COBS_GPU_OK) return st;
+        b->graph_candidate = make_key();                // buffers have their sizes (and addresses) now
+        HIP_TRY(hipEventRecord(b->done, b->own_stream));
+        return COBS_GPU_OK;
+    }
     st = run_impl(b, threshold, topk, b->own_stream, !hits_only);
     if (st != COBS_GPU_OK) return st;
     HIP_TRY(hipEventRecord(b->done, b->own_stream));
@@ -1653,7 +1775,8 @@ static cobs_gpu_status host_pass_end(cobs_gpu_index* ix, int slot, double thresh
     }
     if (st == COBS_GPU_OK || st == COBS_GPU_ERR_INVALID_BASE) {
         float sm = 0, hm = 0;
-        if (b->ran && cobs_gpu_batch_kernel_ms(b, &sm, &hm) == COBS_GPU_OK) {
+        // (a replayed graph re-records the events of the run it was captured from: no per-kernel split)
+        if (b->ran && !b->graph_run && cobs_gpu_batch_kernel_ms(b, &sm, &hm) == COBS_GPU_OK) {
             ix->timers[0] += hm * 1e-3;
             ix->timers[2] += sm * 1e-3;
         }
@@ -1822,6 +1945,8 @@ cobs_gpu_status cobs_gpu_counts(cobs_gpu_index* ix, const char* query, size_t le
         return st;
     });
 }
+
+uint64_t cobs_gpu_graph_replays(const cobs_gpu_index* ix) { return ix ? ix->graph_replays : 0; }
 
 cobs_gpu_status cobs_gpu_timers(cobs_gpu_index* ix, double out[5], int reset) {
     if (!ix) return fail(COBS_GPU_ERR_ARG, "NULL index");

@@ -191,6 +191,7 @@ struct cobs_gpu_index {
     cobs_amd::StreamBufs stream;
     uint64_t total_counts = 0, local_counts = 0;
     double timers[5] = {0, 0, 0, 0, 0};
+    uint64_t graph_replays = 0;   // small passes of the host API served by a captured hipGraph
     static constexpr int kScratch = 3;
     cobs_gpu_batch* scratch[kScratch] = {nullptr, nullptr, nullptr};   // workspaces of the host-buffer search API
     ~cobs_gpu_index();
@@ -251,7 +252,12 @@ struct cobs_gpu_batch {
     hipEvent_t done = nullptr;
     // captured graph of a small pass (single-query latency path)
     hipGraphExec_t graph_exec = nullptr;
-    uint64_t graph_key = 0;
+    uint64_t graph_key = 0, graph_candidate = 0;
+    bool graph_run = false;           // the last run was a graph replay
+    // results a replayed graph copies home by itself (pinned): flags | top-k counts | survivors | hit-pool prefix
+    cobs_amd::PinnedBuf<uint8_t> h_res;
+    size_t res_topk = 0, res_pool = 0, res_pool_n = 0;
+    bool res_rows = false;            // ... and the score rows of an all-documents pass, into h_rows
     hipStream_t graph_stream = nullptr;
     cobs_amd::DevBuf<uint64_t> phase;          // phase stamps of the last scan launch (tuning builds)
     cobs_amd::Exchange* xchg = nullptr;       // comm.cpp

@@ -267,6 +267,11 @@ class Search:
         check(self._lib.cobs_gpu_counts(self._h, q, len(q), out.ctypes.data, out.size))
         return out
 
+    @property
+    def graph_replays(self):
+        """small host-API passes served by a captured hipGraph so far"""
+        return int(self._lib.cobs_gpu_graph_replays(self._h))
+
     def timers(self, reset=False):
         t = (C.c_double * 5)()
         check(self._lib.cobs_gpu_timers(self._h, C.byref(t), 1 if reset else 0))

@@ -346,6 +346,11 @@ cobs_gpu_status cobs_gpu_sharded_search_batch(cobs_gpu_index* ix, cobs_gpu_comm*
  * cobs_gpu_set_tuning(ix, "phase_slots", n).  The production library records nothing (*n_words = 0). */
 cobs_gpu_status cobs_gpu_batch_phase_stamps(cobs_gpu_batch* b, uint64_t* out, size_t cap_words, size_t* n_words);
 
+/* Small calls of the host-buffer API (up to 16 queries) are captured into a hipGraph the second time
+ * the same shape (query lengths, parameters) comes along and replayed with one launch afterwards;
+ * this counts the replays (diagnostics; tuning key "graph" = 0 turns the path off). */
+uint64_t cobs_gpu_graph_replays(const cobs_gpu_index* ix);
+
 /* phase timers of the host-buffer search API since the last reset, seconds:
  * out[0] hashes (K1), out[1] h2d, out[2] scan (K2), out[3] d2h, out[4] rank  */
 cobs_gpu_status cobs_gpu_timers(cobs_gpu_index* ix, double out[5], int reset);

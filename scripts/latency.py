@@ -38,6 +38,19 @@ for n in (1, 4, 16, 64, 256, 1024, 4096):
     print("nq=%5d  device pass %8.3f ms (scan %7.3f hash %6.3f)  %9.0f q/s   host API top-10 %8.3f ms  %9.0f q/s"
           % (n, dev * 1e3, ms["scan_ms"], ms["hash_ms"], n / dev, host * 1e3, n / host), flush=True)
 
+# single-query latency of the host API with and without the captured graph (device pass replayed with one launch)
+for n in (1, 4, 16):
+    for g in (0, -1):
+        s.set_tuning("graph", g)
+        for _ in range(4):
+            s.search_hits(qs[:n], 0.0, 10)
+        t0 = time.perf_counter()
+        for i in range(200):
+            s.search_hits(qs[i % 64:i % 64 + n], 0.0, 10)
+        host = (time.perf_counter() - t0) / 200
+        print("nq=%5d  host API top-10, graph %s: %7.1f us per call (%d replays so far)"
+              % (n, "off" if g == 0 else "on ", host * 1e6, s.graph_replays), flush=True)
+
 # the reference's default call, search(query) = threshold 0, num_results 0: EVERY document ranked
 for n in (1, 16, 256):
     s.search_arrays(qs[:n], 0.0, 0)

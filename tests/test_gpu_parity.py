@@ -574,3 +574,40 @@ def test_topk_single_file_is_ordered_on_the_device(gpu_lib, oracle, tmp_path):
                 for i, q in enumerate(queries):
                     assert b.hits_host(i, k) == cases.oracle_results([ix], q, t, k), (t, k, i)
                     assert b.hits_host(i, 1) == cases.oracle_results([ix], q, t, 1)
+
+
+def test_small_calls_replay_a_captured_graph(gpu_lib, oracle, tmp_path):
+    """single queries / small batches of one shape: from the third call on the pass is a hipGraph
+    replay; results stay those of the oracle for DIFFERENT queries of the same lengths, and a
+    change of shape, threshold or limit falls back to plain launches"""
+    q_long = oracle.random_sequence(600, 77)
+    p = cases.make_compact(cases.tmp(tmp_path, "g.cobs_compact"), 3000, 64, [900, 1000, 1100, 1200, 1300, 1400], 1, 31, 1,
+                           0.3, 5, planted={5: 1.0, 700: 0.9, 2500: 0.6}, query=q_long)
+    ix = oracle.Index.open(p)
+    s = gpu_lib.Search(p)
+    before = s.graph_replays
+    for t, lim in ((0.0, 5), (0.5, 0), (0.0, 0)):
+        for i in range(6):
+            qs = [q_long[i * 7:i * 7 + 331]]                       # same length, different text
+            assert s.search_hits(qs, t, lim) == [cases.oracle_results([ix], qs[0], t, lim)], (t, lim, i)
+    assert s.graph_replays - before >= 9                            # 3 shapes x (6 calls - candidate - capture - ...)
+    mid = s.graph_replays
+    # a batch of four of mixed lengths, repeated; then other lengths
+    for i in range(4):
+        qs = [q_long[i:i + 100], q_long[i + 5:i + 5 + 31], q_long[i:i + 400], q_long[i + 9:i + 9 + 64]]
+        assert s.search_hits(qs, 0.3, 3) == [cases.oracle_results([ix], q, 0.3, 3) for q in qs]
+    assert s.graph_replays > mid
+    for n in (90, 91, 92, 93):
+        qs = [q_long[:n]]
+        assert s.search_hits(qs, 0.0, 2) == [cases.oracle_results([ix], qs[0], 0.0, 2)]
+    # bad input still reports, also on a replay
+    good = q_long[:200]
+    for _ in range(3):
+        s.search_hits([good], 0.0, 1)
+    with pytest.raises(gpu_lib.CobsGpuError):
+        s.search_hits([good[:50] + b"N" + good[51:]], 0.0, 1)
+    s.set_tuning("graph", 0)
+    r = s.graph_replays
+    for _ in range(4):
+        assert s.search_hits([good], 0.0, 1) == [cases.oracle_results([ix], good, 0.0, 1)]
+    assert s.graph_replays == r
