@@ -413,7 +413,7 @@ cobs_gpu_status cobs_gpu_sharded_search_batch(cobs_gpu_index* ix, cobs_gpu_comm*
                 ++g1;
             }
             size_t bad = 0;
-            cobs_gpu_status s = set_queries_on(b, queries + g0, lens + g0, g1 - g0, st, false, &bad);
+            cobs_gpu_status s = set_queries_on(b, queries + g0, lens + g0, g1 - g0, st, false, &bad, g0);
             if (s != COBS_GPU_OK) {
                 if (bad_query) *bad_query = g0 + bad;
                 return s;
@@ -424,6 +424,9 @@ cobs_gpu_status cobs_gpu_sharded_search_batch(cobs_gpu_index* ix, cobs_gpu_comm*
             s = cobs_gpu_batch_sync(b, st, &bad);
             if (s != COBS_GPU_OK) {
                 if (bad_query) *bad_query = g0 + bad;
+                if (s == COBS_GPU_ERR_INVALID_BASE)       // the message names the query by its index in the call
+                    return fail(s, "Invalid DNA base pair in query string. Only ACGT are allowed. (query " +
+                                   std::to_string(g0 + bad) + ")");
                 return s;
             }
             bool need_rows = !hits_only && b->topk_k == 0;

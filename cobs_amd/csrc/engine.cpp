@@ -1009,7 +1009,7 @@ void cobs_gpu_batch_destroy(cobs_gpu_batch* b) { delete b; }
 }  // extern "C"
 
 cobs_gpu_status cobs_amd::set_queries_on(cobs_gpu_batch* b, const char* const* queries, const size_t* lens,
-                                         size_t nq, hipStream_t up, bool wait, size_t* bad_query) {
+                                         size_t nq, hipStream_t up, bool wait, size_t* bad_query, size_t index_base) {
     if (!b || (nq && (!queries || !lens))) return fail(COBS_GPU_ERR_ARG, "NULL argument");
     cobs_gpu_index* ix = b->ix;
     HIP_TRY(hipSetDevice(ix->device));
@@ -1028,12 +1028,12 @@ cobs_gpu_status cobs_amd::set_queries_on(cobs_gpu_batch* b, const char* const* q
     uint64_t max_terms = 1;
     for (size_t q = 0; q < nq; ++q) {
         if (bad_query) *bad_query = q;
-        if (!queries[q]) return fail(COBS_GPU_ERR_ARG, "NULL query (query " + std::to_string(q) + ")");
+        if (!queries[q]) return fail(COBS_GPU_ERR_ARG, "NULL query (query " + std::to_string(index_base + q) + ")");
         if (lens[q] < max_term)
             return fail(COBS_GPU_ERR_QUERY_TOO_SHORT, "query too short, needs to be at least " +
-                        std::to_string(max_term) + " characters long (query " + std::to_string(q) + ")");
+                        std::to_string(max_term) + " characters long (query " + std::to_string(index_base + q) + ")");
         if (lens[q] - max_term >= 0xFFFFFFFFull || lens[q] >= 0xFFFFFFF0ull)
-            return fail(COBS_GPU_ERR_QUERY_TOO_LONG, "query too long (query " + std::to_string(q) + ")");
+            return fail(COBS_GPU_ERR_QUERY_TOO_LONG, "query too long (query " + std::to_string(index_base + q) + ")");
         max_terms = std::max<uint64_t>(max_terms, lens[q] - min_term + 1);
     }
     if (bad_query) *bad_query = 0;
@@ -1097,13 +1097,13 @@ cobs_gpu_status cobs_amd::set_queries_on(cobs_gpu_batch* b, const char* const* q
         w.blk_off = reinterpret_cast<const uint64_t*>(b->text.p + o_blk + f * blk_stride);
     }
     HIP_TRY(hipMemcpyAsync(b->text.p, b->h_text.p, upload_bytes, hipMemcpyHostToDevice, up));
-    algo_bytes += (uint64_t)nq * ix->local_counts * b->elem_bytes;
+    b->algo_row_bytes = algo_bytes;                          // the score bytes are added by the run that writes them
     // selection pool: room for 1024 hits per query, at least 1 Mi entries
     const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(1u << 20, nq * 1024ull), 1ull << 26);
     HIP_TRY(b->hits.reserve((size_t)want));
     b->hit_cap = (uint32_t)b->hits.cap;
     HIP_TRY(b->h_thr_stage.reserve(std::max<size_t>(nq * ix->parts.size(), 1)));
-    b->stats[0] = algo_bytes;
+    b->stats[0] = algo_bytes + (uint64_t)nq * ix->local_counts * b->elem_bytes;      // until a run says otherwise
     b->stats[1] = 0;
     b->stats[2] = lookups;
     b->stats[3] = table_bytes;
@@ -1300,6 +1300,8 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
     HIP_TRY(hipEventRecord(b->run_done, st));
     b->run_seq++;
     b->stats[1] = launches;
+    // T * H * (row bytes gathered) + score bytes WRITTEN (a hits-only pass writes none)
+    b->stats[0] = b->algo_row_bytes + (b->have_counts ? (uint64_t)nq * ix->local_counts * b->elem_bytes : 0);
     b->ran = true;
     return COBS_GPU_OK;
 }
@@ -1646,7 +1648,7 @@ cobs_gpu_status cobs_gpu_batch_kernel_ms(cobs_gpu_batch* b, float* scan_ms, floa
 // repeat it with score rows if the hit pool overflowed, book the timers.
 static cobs_gpu_status host_pass_begin(cobs_gpu_index* ix, int slot, const char* const* queries, const size_t* lens,
                                        size_t nq, double threshold, size_t topk, hipEvent_t after,
-                                       size_t* bad_at = nullptr) {
+                                       size_t* bad_at = nullptr, size_t index_base = 0) {
     HIP_TRY(hipSetDevice(ix->device));
     if (!ix->scratch[slot]) {
         cobs_gpu_status st = cobs_gpu_batch_create(ix, 0, 0, &ix->scratch[slot]);
@@ -1657,7 +1659,7 @@ static cobs_gpu_status host_pass_begin(cobs_gpu_index* ix, int slot, const char*
     cobs_gpu_batch* b = ix->scratch[slot];
     double t0 = now_s();
     size_t bad_local = 0;
-    cobs_gpu_status st = set_queries_on(b, queries, lens, nq, b->own_stream, false, &bad_local);
+    cobs_gpu_status st = set_queries_on(b, queries, lens, nq, b->own_stream, false, &bad_local, index_base);
     if (st != COBS_GPU_OK && bad_at) *bad_at = bad_local;
     if (st != COBS_GPU_OK) return st;
     ix->timers[1] += now_s() - t0;
@@ -1882,7 +1884,7 @@ static cobs_gpu_status search_batch_impl(cobs_gpu_index* ix, const char* const* 
         const int slot = (int)(pass_no % depth);
         size_t bad_local = 0;
         cobs_gpu_status st = host_pass_begin(ix, slot, queries + g0, lens + g0, g1 - g0, threshold, topk, prev_done,
-                                             &bad_local);
+                                             &bad_local, g0);
         if (st != COBS_GPU_OK) {
             // passes before this one come first in the caller's order: report their error if they have one
             const size_t first_bad = g0 + bad_local;

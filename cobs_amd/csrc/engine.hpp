@@ -246,6 +246,7 @@ struct cobs_gpu_batch {
     hipEvent_t ev[kRing][3] = {};
     uint64_t run_seq = 0, read_seq = 0;
     uint64_t stats[4] = {0, 0, 0, 0};
+    uint64_t algo_row_bytes = 0;      // gathered row bytes of the current queries (stats[0] adds the score bytes a run writes)
     hipEvent_t run_done = nullptr;    // after the last kernel of the most recent run
     // host-buffer API only: the stream this scratch batch lives on and the event after its pass
     hipStream_t own_stream = nullptr;
@@ -276,7 +277,7 @@ namespace cobs_amd {
 // engine.cpp internals used by comm.cpp
 cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk, void* hip_stream, bool want_counts = true);
 cobs_gpu_status set_queries_on(cobs_gpu_batch* b, const char* const* queries, const size_t* lens, size_t nq,
-                               hipStream_t up, bool wait, size_t* bad_query);
+                               hipStream_t up, bool wait, size_t* bad_query, size_t index_base = 0);
 uint32_t threshold_for(double threshold, uint64_t terms);
 uint64_t total_hashes(const cobs_gpu_batch* b, size_t q);
 bool hit_before(const cobs_gpu_hit& a, const cobs_gpu_hit& b);

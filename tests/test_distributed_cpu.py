@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, path, queries, out_dir):
+def _worker(rank, world, port, path, queries, out_dir, mode):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -32,9 +32,13 @@ def _worker(rank, world, port, path, queries, out_dir):
         from cobs_amd import distributed as D
         from oracle import oracle as O
         ix = O.Index.open(path)
-        P, ps = ix.num_pages, ix.page_size
-        first, end = P * rank // world, P * (rank + 1) // world          # engine's block split
-        begin, count = first * 8 * ps, (end - first) * 8 * ps
+        # the engine's own shard layout (host-side planner of libcobs_gpu.so, no device needed):
+        # byte-balanced cuts (mode 0) may fall inside a sub-index
+        import ctypes as C
+        from cobs_amd import _capi
+        b_, c_ = (C.c_uint64 * world)(), (C.c_uint64 * world)()
+        _capi.check(_capi.load().cobs_gpu_plan_shards(path.encode(), world, mode, b_, c_, None))
+        begin, count = int(b_[rank]), int(c_[rank])
         full = np.stack([ix.counts(q) for q in queries]).astype(np.uint16)
         local = torch.from_numpy(full[:, begin:begin + count].astype(np.int16))
         layouts = [None] * world
@@ -62,15 +66,15 @@ def _worker(rank, world, port, path, queries, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_shard_exchange_gloo(oracle, tmp_path, world):
+@pytest.mark.parametrize("world,mode", [(2, 0), (3, 0), (2, 1), (3, 1)])
+def test_shard_exchange_gloo(oracle, tmp_path, world, mode):
     q_long = oracle.random_sequence(400, 21)
     planted = {3: 1.0, 200: 0.8, 777: 0.5, 1100: 0.95}
     path = cases.make_compact(cases.tmp(tmp_path, "d.cobs_compact"), 1200, 32, [600, 700, 800, 900, 1000], 1, 31, 1,
                               0.3, 4, planted=planted, query=q_long)
     queries = [q_long, q_long[:31], q_long[:200]]
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, path, queries, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, path, queries, str(tmp_path), mode), nprocs=world, join=True)
     for r in range(world):
         assert os.path.exists(os.path.join(str(tmp_path), "ok%d" % r))
 

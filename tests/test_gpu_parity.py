@@ -335,6 +335,15 @@ def test_large_host_batch_is_cut_into_passes(gpu_lib, oracle, tmp_path, monkeypa
     badq = _capi.C.c_size_t(999)
     st = s._lib.cobs_gpu_search_batch(s._h, arr, lens, len(bad), 0.0, 0, hits, len(hits), offs, _capi.C.byref(badq))
     assert st == _capi.ERR_INVALID_BASE and badq.value == 23
+    # a query that is too short is reported with ITS index (not the first query of its pass)
+    short = list(queries)
+    short[31] = short[31][:30]
+    arr = (_capi.C.c_char_p * len(short))(*short)
+    lens = (_capi.C.c_size_t * len(short))(*[len(q) for q in short])
+    badq = _capi.C.c_size_t(999)
+    st = s._lib.cobs_gpu_search_batch(s._h, arr, lens, len(short), 0.0, 0, hits, len(hits), offs, _capi.C.byref(badq))
+    assert st == _capi.ERR_QUERY_TOO_SHORT and badq.value == 31
+    assert b"(query 31)" in s._lib.cobs_gpu_last_error()
 
 
 def test_default_python_call_ranks_every_document(gpu_lib, oracle, tmp_path):

@@ -122,3 +122,34 @@ def test_random_budgets(gpu_lib, oracle, tmp_path, monkeypatch, no_pin):
         assert s.search_hits(queries, t, lim) == [cases.oracle_results([ix], q, t, lim) for q in queries], (path, budget, t, lim)
         done += 1
     assert done >= 15
+
+
+def test_budget_is_shared_by_all_files_of_a_handle(gpu_lib, oracle, tmp_path):
+    """several index files under ONE hbm budget (the budget is per handle): small files stay
+    resident, the others are streamed through one shared pair of buffers -- including the case
+    where MORE THAN ONE file has to be streamed, and the case where nothing can stay resident"""
+    q_long = oracle.random_sequence(500, 17)
+    pa = cases.make_compact(cases.tmp(tmp_path, "m1.cobs_compact"), 2400, 64, [900, 1000, 1100, 1200, 1300], 1, 31, 1,
+                            0.3, 3, planted={5: 1.0, 2300: 0.97}, query=q_long)                    # 352 KB
+    pb = cases.make_classic(cases.tmp(tmp_path, "m2.cobs_classic"), 1000, 1501, 2, 31, 1, 0.3, 4,
+                            planted={9: 1.0, 990: 0.8}, query=q_long)                              # 188 KB
+    pc = cases.make_compact(cases.tmp(tmp_path, "m3.cobs_compact"), 500, 8, [401, 503, 601, 701, 809, 907, 1009, 1103],
+                            1, 31, 1, 0.3, 5)                                                      # 48 KB
+    paths = [pa, pb, pc]
+    ixs = [oracle.Index.open(p) for p in paths]
+    queries = [q_long, q_long[:31], q_long[:250]]
+    want = [np.concatenate([ix.counts(q) for ix in ixs]) for q in queries]
+    for budget in (10 << 20, 400 * 1024, 200 * 1024, 90 * 1024):
+        s = gpu_lib.Search(paths, hbm_budget=budget)
+        total_hbm = sum(s.info(f).hbm_bytes for f in range(3))
+        assert total_hbm <= budget, (budget, total_hbm)
+        for q, w in zip(queries, want):
+            assert np.array_equal(s.counts(q), w), budget
+        for t, lim in ((0.0, 4), (0.4, 0)):
+            assert s.search_hits(queries, t, lim) == [cases.oracle_results(ixs, q, t, lim) for q in queries]
+    # at 200 KB the two large files cannot both stay: at least two files are streamed
+    s = gpu_lib.Search(paths, hbm_budget=200 * 1024)
+    with pytest.raises(gpu_lib.CobsGpuError):
+        s.read_row(0, 0, 0, 64)                 # file 0 is streamed: its rows are not resident
+    with pytest.raises(gpu_lib.CobsGpuError):
+        s.read_row(1, 0, 0, 8)
