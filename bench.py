@@ -331,6 +331,8 @@ def timed(step, steps, warmup, world, backend, after_warmup=None):
 def all_ranks_ok(ok, backend):
     """every rank must agree that its set-up succeeded before the next collective, so that a
     local failure (out of memory, ...) cannot strand the others inside RCCL"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return bool(ok)
     flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     return int(flag.item()) == 1
@@ -465,6 +467,8 @@ def main():
                     help="N>1: skip the additional measurements (overlap, all-gather, replicated, hits, configs[3])")
     ap.add_argument("--hbm-budget-gb", type=float, default=0.0, help="per-GPU HBM budget of the index (0 = resident)")
     ap.add_argument("--index-file", default="", help="c5: path of the index file (written once if missing)")
+    ap.add_argument("--one-rank-sharded", action="store_true",
+                    help="N=1 smoke run of the multi-GPU code path: one-rank RCCL communicator, sharded layout, exchange")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real multi-GPU runs; gloo only "
                     "for smoke-testing the launch path with several ranks on one GPU")
     args = ap.parse_args()
@@ -503,7 +507,7 @@ def main():
         if not budget:
             budget = int(6e9)
             args.hbm_budget_gb = 6.0
-    shard_index = world > 1 and args.shard_mode == "index"
+    shard_index = (world > 1 or args.one_rank_sharded) and args.shard_mode == "index"
     queries = make_queries(args.queries, args.kmers, seed=42 + (rank if world > 1 and not shard_index else 0))
 
     comm = None
@@ -512,7 +516,7 @@ def main():
         # the native RCCL communicator; torch.distributed is only the launcher that passes the id
         if args.dist_backend == "nccl":
             from cobs_amd.distributed import Comm
-            comm = Comm.from_torch(None, dev)
+            comm = Comm.from_torch(None, dev) if world > 1 else Comm(Comm.unique_id(), 0, 1, dev)
         ok, err = True, ""
         try:
             run = ShardedRun(cfg, queries, world, rank, dev, comm, args.exchange_chunks, args.threshold,
@@ -641,7 +645,7 @@ def main():
         out["streaming"] = {"hbm_budget_bytes": budget, "index_bytes": index_bytes, "file": path,
                             "scan_launches_per_step": nlaunch,
                             "pcie_GBps_rank0": round(index_bytes / max(world if shard_index else 1, 1) / (dt / args.steps) / 1e9, 2)}
-    if world > 1 and shard_index and not args.no_extras:
+    if shard_index and not args.no_extras:
         del run, batch, s
         torch.cuda.empty_cache()
         out["other_forms"] = side_measurements(args, cfg, queries, world, rank, dev, comm)

@@ -61,3 +61,26 @@ def test_sharded_search_processes(gpu_lib, oracle, tmp_path, world):
     mp.spawn(_worker, args=(world, port, [pa, pb], queries, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert os.path.exists(os.path.join(str(tmp_path), "ok%d" % r))
+
+
+def test_bench_sharded_code_path_on_one_rank(gpu_lib):
+    """bench.py's N > 1 flow (native RCCL communicator, byte-balanced shard, all-to-all exchange,
+    the other forms) with a one-rank communicator: the JSON line carries the fields the driver
+    and DESIGN.md name; no N > 1 hardware is needed to catch a broken call sequence"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--one-rank-sharded", "--scale", "0.02",
+                        "--queries", "512", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1]
+    j = json.loads(line)
+    assert j["rccl_ranks"] == 1 and j["scaling"] == "strong" and j["n_gpus"] == 1
+    assert j["exchange"]["mode"] == "alltoall" and j["exchange"]["transport"].startswith("RCCL")
+    assert "sharded by sub-index block" in j["config"]["parallelism"]
+    assert j["value"] > 0 and j["roofline"]["frac"] > 0
+    other = j["other_forms"]
+    for k in ("sharded_overlap_2_sub_batches", "sharded_allgather", "index_replicated_weak", "sharded_hits_threshold_0.8"):
+        assert "queries_per_s" in other[k], (k, other[k])
