@@ -255,6 +255,15 @@ cobs_gpu_status check_meta(const IndexMeta& m) {
     const uint64_t prb = m.page_row_bytes();
     if (prb == 0 || prb > (1ull << 28)) return fail(COBS_GPU_ERR_UNSUPPORTED, "row too wide");
     if (m.signature_sizes.empty()) return fail(COBS_GPU_ERR_FORMAT, "index holds no sub-index");
+    // every byte count derived from the geometry stays far below 2^64 (a procedural index has no
+    // file length to bound it): one sub-index at most 2^47 bytes, the file at most 2^50
+    uint64_t total = 0;
+    for (uint64_t s : m.signature_sizes) {
+        uint64_t bytes = 0;
+        if (__builtin_mul_overflow(s + 1, round_up(prb, 128), &bytes) || bytes > (1ull << 47) ||
+            __builtin_add_overflow(total, bytes, &total) || total > (1ull << 50))
+            return fail(COBS_GPU_ERR_UNSUPPORTED, "index geometry too large (a sub-index beyond 128 TiB or a file beyond 1 PiB)");
+    }
     if ((uint64_t)m.num_pages() * prb > 0xFFFFFFF0ull / 8)
         return fail(COBS_GPU_ERR_UNSUPPORTED, "more than 2^32 score slots in one file");
     return COBS_GPU_OK;
@@ -775,6 +784,18 @@ cobs_gpu_status cobs_gpu_open_synthetic(const cobs_gpu_synth* d, const cobs_gpu_
         pt.meta.num_hashes = d->num_hashes;
         pt.meta.header_page_size = d->kind ? d->page_size : 0;
         pt.meta.signature_sizes.assign(d->signature_sizes, d->signature_sizes + d->num_pages);
+        {   // geometry first: an absurd size must not cost a multi-gigabyte name table
+            IndexMeta probe = pt.meta;
+            if (!d->kind) probe.doc_names.resize(1);
+            const uint64_t prb = d->kind ? d->page_size : (d->num_docs + 7) / 8;
+            if (prb == 0 || prb > (1ull << 28)) return fail(COBS_GPU_ERR_UNSUPPORTED, "row too wide");
+            for (uint64_t sg : probe.signature_sizes) {
+                uint64_t bytes = 0;
+                if (sg == 0 || sg > (1ull << 46) || __builtin_mul_overflow(sg + 1, round_up(prb, 128), &bytes) ||
+                    bytes > (1ull << 47))
+                    return fail(COBS_GPU_ERR_UNSUPPORTED, "index geometry too large (a sub-index beyond 128 TiB)");
+            }
+        }
         pt.meta.doc_names.resize(d->num_docs);
         char nm[32];
         for (uint64_t i = 0; i < d->num_docs; ++i) {      // names as classic_construct_random, classic_index.cpp:668-670

@@ -137,3 +137,15 @@ def test_header_is_plain_c_and_cpp(tmp_path):
     cpp = tmp_path / "t.cpp"
     cpp.write_text('#include "cobs_gpu_search.hpp"\nint main() { cobs_gpu::SearchResult r; return r.score != 0; }\n')
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", inc, "-fsyntax-only", str(cpp)])
+
+
+def test_absurd_procedural_geometry_is_refused():
+    """sizes whose byte counts would wrap 64-bit arithmetic are an error before any allocation"""
+    import cobs_amd
+    from cobs_amd import _capi
+    for kind, sigs, docs, ps in (("compact", [1 << 46] * 4, 4 * 8 * (1 << 27), 1 << 27),
+                                 ("classic", [1 << 46], 4000000000, 0),
+                                 ("compact", [1 << 40] * 2000, 2000 * 8 * 4096, 4096)):
+        with pytest.raises(cobs_amd.CobsGpuError) as e:
+            cobs_amd.Search.synthetic(kind, sigs, docs, page_size=ps)
+        assert e.value.status in (_capi.ERR_UNSUPPORTED, _capi.ERR_ARG, _capi.ERR_NO_DEVICE), (kind, e.value)
