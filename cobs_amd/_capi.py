@@ -53,6 +53,17 @@ class BuildParams(C.Structure):
                 ("device", C.c_int32), ("text_batch_bytes", C.c_uint32), ("doc_terms", C.POINTER(C.c_uint64))]
 
 
+class Xfer(C.Structure):
+    _fields_ = [("peer", C.c_uint64), ("send_offset", C.c_uint64), ("send_bytes", C.c_uint64),
+                ("recv_offset", C.c_uint64), ("recv_bytes", C.c_uint64)]
+
+
+class Copy2D(C.Structure):
+    _fields_ = [("src_rank", C.c_uint64), ("src_is_local", C.c_uint64), ("src_offset", C.c_uint64),
+                ("src_pitch", C.c_uint64), ("dst_offset", C.c_uint64), ("dst_pitch", C.c_uint64),
+                ("width", C.c_uint64), ("height", C.c_uint64)]
+
+
 class Synth(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("term_size", C.c_uint32), ("canonicalize", C.c_uint32),
                 ("num_pages", C.c_uint32), ("num_hashes", C.c_uint64), ("page_size", C.c_uint64),
@@ -110,6 +121,8 @@ SYMBOLS = {
     "cobs_gpu_batch_phase_stamps": (_int, [_vp, _pu64, _sz, C.POINTER(_sz)]),
     "cobs_gpu_graph_replays": (_u64, [_vp]),
     "cobs_gpu_timers": (_int, [_vp, C.POINTER(C.c_double * 5), _int]),
+    "cobs_gpu_exchange_plan": (_int, [_pu64, _pu64, _pu64, _sz, _sz, _u64, _sz, _u32, _u32, _sz,
+                                      C.POINTER(Xfer), C.POINTER(Copy2D), C.POINTER(_sz), _pu64]),
     "cobs_gpu_comm_unique_id": (_int, [_vp]),
     "cobs_gpu_comm_create": (_int, [_vp, _int, _int, _int, C.POINTER(_vp)]),
     "cobs_gpu_comm_destroy": (None, [_vp]),

@@ -110,27 +110,109 @@ cobs_gpu_status bind_layout(cobs_gpu_batch* b, const cobs_gpu_comm* c, hipStream
     return COBS_GPU_OK;
 }
 
-// strided copy of one rank's slice block [nrows][n_r] into global rows [nrows][total]
-cobs_gpu_status assemble(const cobs_gpu_batch* b, const Exchange& x, size_t r, const uint8_t* src, uint8_t* dst,
-                         size_t nrows, hipStream_t st) {
-    if (nrows == 0) return COBS_GPU_OK;
-    const cobs_gpu_index* ix = b->ix;
-    const size_t eb = b->elem_bytes, np = x.nparts;
-    uint64_t local_off = 0;
-    for (size_t f = 0; f < np; ++f) {
-        const uint64_t begin = x.layout[(r * np + f) * 2], count = x.layout[(r * np + f) * 2 + 1];
-        if (count)
-            HIP_TRY(hipMemcpy2DAsync(dst + (ix->parts[f].doc_offset + begin) * eb, ix->total_counts * eb,
-                                     src + local_off * eb, x.local_n[r] * eb, count * eb, nrows,
-                                     hipMemcpyDeviceToDevice, st));
-        local_off += count;
+// The exchange of the count slices as a PLAN: which byte ranges of this rank's count rows go to
+// which peer, where the peers' slices land in the staging buffer, and the strided copies that
+// assemble them into rows in global document order.  Pure host arithmetic on the ranks' slot
+// layouts -- the RCCL path below executes it, cobs_gpu_exchange_plan exposes it so that the
+// N > 1 arithmetic (matching send / receive sizes on both ends, full coverage of the assembled
+// rows) is tested without N GPUs.
+struct XferPlan {
+    size_t q_begin = 0, q_count = 0;             // queries whose assembled rows this rank ends up with
+    bool use_allgather = false;                  // same-size slices, every rank takes everything: one ncclAllGather
+    size_t staging_bytes = 0, global_bytes = 0, my_row_bytes = 0;
+    std::vector<cobs_gpu_xfer> xfers;            // one per rank (self included: its sizes are 0 unless use_allgather)
+    std::vector<cobs_gpu_copy2d> copies;         // assembly
+};
+
+XferPlan plan_exchange(const uint64_t* layout /*[N][F][2]*/, const uint64_t* doc_offset /*[F]*/, size_t N, size_t F,
+                       uint64_t total_counts, size_t nq, size_t eb, uint32_t mode, size_t me) {
+    XferPlan p;
+    std::vector<uint64_t> local_n(N, 0);
+    for (size_t r = 0; r < N; ++r)
+        for (size_t f = 0; f < F; ++f) local_n[r] += layout[(r * F + f) * 2 + 1];
+    auto q0_of = [&](size_t j) { return mode == COBS_GPU_XCHG_ALLTOALL ? nq * j / N : (size_t)0; };
+    auto q1_of = [&](size_t j) { return mode == COBS_GPU_XCHG_ALLTOALL ? nq * (j + 1) / N : nq; };
+    p.q_begin = q0_of(me);
+    p.q_count = q1_of(me) - p.q_begin;
+    p.my_row_bytes = (size_t)(local_n[me] * eb);
+    p.global_bytes = (size_t)(p.q_count * total_counts * eb);
+    p.use_allgather = mode == COBS_GPU_XCHG_ALLGATHER;
+    for (size_t r = 0; r < N; ++r) p.use_allgather = p.use_allgather && local_n[r] == local_n[me];
+    p.xfers.assign(N, cobs_gpu_xfer{});
+    std::vector<size_t> src_off(N, 0);           // where rank r's block starts in the staging buffer
+    if (p.use_allgather) {
+        // staging = [rank][nq][n] incl. our own block
+        for (size_t r = 0; r < N; ++r) {
+            src_off[r] = r * nq * p.my_row_bytes;
+            p.xfers[r].peer = r;
+            p.xfers[r].send_offset = 0;
+            p.xfers[r].send_bytes = nq * p.my_row_bytes;
+            p.xfers[r].recv_offset = src_off[r];
+            p.xfers[r].recv_bytes = nq * p.my_row_bytes;
+        }
+        p.staging_bytes = N * nq * p.my_row_bytes;
+    } else {
+        size_t off = 0;
+        for (size_t r = 0; r < N; ++r) {
+            cobs_gpu_xfer& x = p.xfers[r];
+            x.peer = r;
+            if (r == me) continue;               // our own slice is assembled straight from the count rows
+            const size_t sq0 = q0_of(r), snq = q1_of(r) - sq0;
+            x.send_offset = sq0 * p.my_row_bytes;
+            x.send_bytes = snq * p.my_row_bytes;
+            x.recv_offset = off;
+            x.recv_bytes = (size_t)(p.q_count * local_n[r] * eb);
+            src_off[r] = off;
+            off += x.recv_bytes;
+        }
+        p.staging_bytes = off;
     }
-    return COBS_GPU_OK;
+    for (size_t r = 0; r < N; ++r) {
+        uint64_t local_off = 0;
+        for (size_t f = 0; f < F; ++f) {
+            const uint64_t begin = layout[(r * F + f) * 2], count = layout[(r * F + f) * 2 + 1];
+            if (count && p.q_count) {
+                cobs_gpu_copy2d c{};
+                c.src_rank = r;
+                c.src_is_local = (!p.use_allgather && r == me) ? 1 : 0;
+                c.src_offset = (c.src_is_local ? p.q_begin * p.my_row_bytes : src_off[r]) + local_off * eb;
+                c.src_pitch = local_n[r] * eb;
+                c.dst_offset = (doc_offset[f] + begin) * eb;
+                c.dst_pitch = total_counts * eb;
+                c.width = count * eb;
+                c.height = p.q_count;
+                p.copies.push_back(c);
+            }
+            local_off += count;
+        }
+    }
+    return p;
 }
 
 }  // namespace
 
 extern "C" {
+
+cobs_gpu_status cobs_gpu_exchange_plan(const uint64_t* slot_begin, const uint64_t* slot_count, const uint64_t* doc_offset,
+                                       size_t nranks, size_t nfiles, uint64_t total_counts, size_t nq, uint32_t elem_bytes,
+                                       uint32_t mode, size_t rank, cobs_gpu_xfer* xfers, cobs_gpu_copy2d* copies,
+                                       size_t* n_copies, uint64_t out[6]) {
+    if (!slot_begin || !slot_count || !doc_offset || !xfers || !copies || !n_copies || !out || nranks == 0 ||
+        rank >= nranks || nfiles == 0 || mode > COBS_GPU_XCHG_ALLTOALL || (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4))
+        return fail(COBS_GPU_ERR_ARG, "bad argument");
+    return guarded([&]() -> cobs_gpu_status {
+        std::vector<uint64_t> layout(nranks * nfiles * 2);
+        for (size_t i = 0; i < nranks * nfiles; ++i) { layout[2 * i] = slot_begin[i]; layout[2 * i + 1] = slot_count[i]; }
+        const XferPlan p = plan_exchange(layout.data(), doc_offset, nranks, nfiles, total_counts, nq, elem_bytes, mode, rank);
+        if (p.copies.size() > *n_copies) { *n_copies = p.copies.size(); return fail(COBS_GPU_ERR_CAPACITY, "copy list too small"); }
+        for (size_t r = 0; r < nranks; ++r) xfers[r] = p.xfers[r];
+        for (size_t i = 0; i < p.copies.size(); ++i) copies[i] = p.copies[i];
+        *n_copies = p.copies.size();
+        out[0] = p.q_begin; out[1] = p.q_count; out[2] = p.staging_bytes; out[3] = p.global_bytes;
+        out[4] = p.use_allgather ? 1 : 0; out[5] = p.my_row_bytes;
+        return COBS_GPU_OK;
+    });
+}
 
 cobs_gpu_status cobs_gpu_comm_unique_id(uint8_t id[COBS_GPU_UNIQUE_ID_BYTES]) {
     if (!id) return fail(COBS_GPU_ERR_ARG, "NULL argument");
@@ -199,46 +281,35 @@ cobs_gpu_status cobs_gpu_batch_exchange_counts(cobs_gpu_batch* b, cobs_gpu_comm*
         cobs_gpu_status s = bind_layout(b, c, st);
         if (s != COBS_GPU_OK) return s;
         Exchange& x = *b->xchg;
-        const size_t N = (size_t)c->nranks, me = (size_t)c->rank, eb = b->elem_bytes, nq = b->nq;
-        // query group of rank j (ALLTOALL); ALLGATHER: every rank takes all queries
-        auto q0_of = [&](size_t j) { return mode == COBS_GPU_XCHG_ALLTOALL ? nq * j / N : (size_t)0; };
-        auto q1_of = [&](size_t j) { return mode == COBS_GPU_XCHG_ALLTOALL ? nq * (j + 1) / N : nq; };
-        const size_t my_q0 = q0_of(me), my_nq = q1_of(me) - my_q0;
-        // staging: the block of rank r is [my_nq][n_r]
-        std::vector<size_t> off(N + 1, 0);
-        for (size_t r = 0; r < N; ++r) off[r + 1] = off[r] + (r == me ? 0 : my_nq * x.local_n[r] * eb);
+        const size_t N = (size_t)c->nranks, me = (size_t)c->rank, nq = b->nq;
+        std::vector<uint64_t> doc_off(x.nparts);
+        for (size_t f = 0; f < x.nparts; ++f) doc_off[f] = ix->parts[f].doc_offset;
+        const XferPlan p = plan_exchange(x.layout.data(), doc_off.data(), N, x.nparts, ix->total_counts, nq, b->elem_bytes, mode, me);
+        HIP_TRY(x.staging.reserve(std::max<size_t>(p.staging_bytes, 1)));
+        HIP_TRY(x.global.reserve(std::max<size_t>(p.global_bytes, 1)));
         const uint8_t* mine = b->counts.p;
-        const size_t my_row = (size_t)(x.local_n[me] * eb);
-        // same-size slices (always so on one rank): the library collective, ncclAllGather
-        bool equal = mode == COBS_GPU_XCHG_ALLGATHER;
-        for (size_t r = 0; r < N; ++r) equal = equal && x.local_n[r] == x.local_n[me];
-        HIP_TRY(x.staging.reserve(std::max<size_t>(equal ? N * nq * my_row : off[N], 1)));
-        HIP_TRY(x.global.reserve(std::max<size_t>(my_nq * ix->total_counts * eb, 1)));
-        x.bytes_moved = equal ? (N - 1) * nq * my_row : off[N];
-        if (equal) {
-            // staging = [rank][nq][n] incl. our own block
-            NCCL_TRY(ncclAllGather(mine, x.staging.p, nq * my_row, ncclUint8, c->comm, st));
-            for (size_t r = 0; r < N; ++r) {
-                s = assemble(b, x, r, x.staging.p + r * nq * my_row, x.global.p, nq, st);
-                if (s != COBS_GPU_OK) return s;
-            }
+        if (p.use_allgather) {
+            // same-size slices (always so on one rank): the library collective
+            NCCL_TRY(ncclAllGather(mine, x.staging.p, nq * p.my_row_bytes, ncclUint8, c->comm, st));
+            x.bytes_moved = (N - 1) * nq * p.my_row_bytes;
         } else {
+            x.bytes_moved = p.staging_bytes;
             if (N > 1) {
                 NCCL_TRY(ncclGroupStart());
                 for (size_t j = 0; j < N; ++j) {
+                    const cobs_gpu_xfer& t = p.xfers[j];
                     if (j == me) continue;
-                    const size_t sq0 = q0_of(j), snq = q1_of(j) - sq0;
-                    if (snq && my_row) NCCL_TRY(ncclSend(mine + sq0 * my_row, snq * my_row, ncclUint8, (int)j, c->comm, st));
-                    if (off[j + 1] > off[j]) NCCL_TRY(ncclRecv(x.staging.p + off[j], off[j + 1] - off[j], ncclUint8, (int)j, c->comm, st));
+                    if (t.send_bytes) NCCL_TRY(ncclSend(mine + t.send_offset, t.send_bytes, ncclUint8, (int)j, c->comm, st));
+                    if (t.recv_bytes) NCCL_TRY(ncclRecv(x.staging.p + t.recv_offset, t.recv_bytes, ncclUint8, (int)j, c->comm, st));
                 }
                 NCCL_TRY(ncclGroupEnd());
             }
-            for (size_t r = 0; r < N; ++r) {
-                const uint8_t* src = r == me ? mine + my_q0 * my_row : x.staging.p + off[r];
-                s = assemble(b, x, r, src, x.global.p, my_nq, st);
-                if (s != COBS_GPU_OK) return s;
-            }
         }
+        for (const cobs_gpu_copy2d& cp : p.copies)
+            HIP_TRY(hipMemcpy2DAsync(x.global.p + cp.dst_offset, cp.dst_pitch,
+                                     (cp.src_is_local ? mine : x.staging.p) + cp.src_offset, cp.src_pitch, cp.width, cp.height,
+                                     hipMemcpyDeviceToDevice, st));
+        const size_t my_q0 = p.q_begin, my_nq = p.q_count;
         b->g_rows = x.global.p;
         b->g_q0 = my_q0;
         b->g_qn = my_nq;

@@ -321,6 +321,26 @@ typedef enum cobs_gpu_exchange_mode {
     COBS_GPU_XCHG_ALLTOALL = 1    /* rank j receives the slices of the queries [nq*j/N, nq*(j+1)/N) only:
                                      every count crosses the fabric once (grouped ncclSend / ncclRecv)      */
 } cobs_gpu_exchange_mode;
+/* The exchange as a plan (host arithmetic only, no device, no communicator): what rank `rank` of
+ * `nranks` sends to / receives from every peer and how the received slices are assembled, given all
+ * ranks' slot layouts (slot_begin / slot_count: [nranks][nfiles], as cobs_gpu_info reports them).
+ * cobs_gpu_batch_exchange_counts executes exactly this plan over RCCL; tests emulate N ranks with it. */
+typedef struct cobs_gpu_xfer {
+    uint64_t peer;
+    uint64_t send_offset, send_bytes;   /* inside this rank's local count rows */
+    uint64_t recv_offset, recv_bytes;   /* inside this rank's staging buffer */
+} cobs_gpu_xfer;
+typedef struct cobs_gpu_copy2d {        /* strided copy into the assembled rows (global document order) */
+    uint64_t src_rank;
+    uint64_t src_is_local;              /* 1: source is this rank's own count rows, 0: the staging buffer */
+    uint64_t src_offset, src_pitch, dst_offset, dst_pitch, width, height;
+} cobs_gpu_copy2d;
+/* xfers: nranks entries; copies: *n_copies capacity in, count out (at most nranks * nfiles);
+ * out = { q_begin, q_count, staging_bytes, assembled_bytes, uses_ncclAllGather, local_row_bytes } */
+cobs_gpu_status cobs_gpu_exchange_plan(const uint64_t* slot_begin, const uint64_t* slot_count, const uint64_t* doc_offset,
+                                       size_t nranks, size_t nfiles, uint64_t total_counts, size_t nq, uint32_t elem_bytes,
+                                       uint32_t mode, size_t rank, cobs_gpu_xfer* xfers, cobs_gpu_copy2d* copies,
+                                       size_t* n_copies, uint64_t out[6]);
 /* After cobs_gpu_batch_run on every rank: exchange the per-document counts of the shards on
  * `hip_stream` (asynchronous, ordered after the scan) and assemble rows in global document order. */
 cobs_gpu_status cobs_gpu_batch_exchange_counts(cobs_gpu_batch* b, cobs_gpu_comm* c, uint32_t mode, void* hip_stream);

@@ -100,3 +100,89 @@ def test_crafted_headers_are_rejected_not_trusted(tmp_path):
         b = (C.c_uint64 * 2)()
         c = (C.c_uint64 * 2)()
         assert _capi.load().cobs_gpu_plan_shards(os.fsencode(str(p)), 2, 0, b, c, None) == _capi.ERR_FORMAT, name
+
+
+def _exchange_plan(lib, begins, counts, doc_off, total, nq, eb, mode, rank):
+    from cobs_amd import _capi
+    N, F = len(begins), len(begins[0])
+    b = (C.c_uint64 * (N * F))(*[x for r in begins for x in r])
+    c = (C.c_uint64 * (N * F))(*[x for r in counts for x in r])
+    d = (C.c_uint64 * F)(*doc_off)
+    xf = (_capi.Xfer * N)()
+    cp = (_capi.Copy2D * (N * F))()
+    ncp = C.c_size_t(N * F)
+    out = (C.c_uint64 * 6)()
+    _capi.check(lib.cobs_gpu_exchange_plan(b, c, d, N, F, total, nq, eb, mode, rank, xf, cp, C.byref(ncp), out))
+    return list(xf), list(cp)[:ncp.value], list(out)
+
+
+@pytest.mark.parametrize("mode", [0, 1])                   # all-gather, all-to-all
+def test_exchange_plan_moves_every_count_exactly_once(oracle, tmp_path, mode):
+    """The multi-GPU exchange of libcobs_gpu.so is a host-computed plan executed over RCCL
+    (comm.cpp: plan_exchange).  Here N ranks are emulated on the CPU: every rank's local count rows
+    are the oracle's counts cut to the engine's own shard layout, the plans' sends / receives are
+    played with memcpy, the assembly copies are applied -- every rank must end with the oracle's
+    full rows of the queries it owns.  Also: send sizes match the peer's receive sizes (a mismatch
+    would hang or corrupt a real ncclSend / ncclRecv pair) and all ranks pick the same collective."""
+    from cobs_amd import _capi
+    lib = _capi.load()
+    q_long = oracle.random_sequence(400, 21)
+    ratio = 16.0 ** (1.0 / 7.0)
+    pa = cases.make_compact(cases.tmp(tmp_path, "x.cobs_compact"), 8 * 8 * 48 - 9, 48,
+                            [int(150 * ratio ** p) for p in range(8)], 1, 31, 1, 0.3, 8)
+    pb = cases.make_classic(cases.tmp(tmp_path, "x.cobs_classic"), 1000, 701, 1, 31, 1, 0.3, 9)
+    ixs = [oracle.Index.open(pa), oracle.Index.open(pb)]
+    doc_off = [0, ixs[0].counts_size]
+    total = ixs[0].counts_size + ixs[1].counts_size
+    for nq in (1, 3, 8, 13):
+        queries = [q_long[i:i + 40 + 9 * i] for i in range(nq)]
+        full = np.stack([np.concatenate([ix.counts(q) for ix in ixs]) for q in queries])
+        for eb, dt in ((1, np.uint8), (2, np.uint16), (4, np.uint32)):
+            rows = full.astype(dt)
+            for N in (1, 2, 3, 5, 8):
+                for shard_mode in (0, 1):
+                    lay = [_plan(p, N, shard_mode) for p in (pa, pb)]
+                    begins = [[lay[f][0][r] for f in range(2)] for r in range(N)]
+                    counts = [[lay[f][1][r] for f in range(2)] for r in range(N)]
+                    # what rank r's scan leaves in HBM: [nq][local slots] (its files' slices back to back)
+                    local = []
+                    for r in range(N):
+                        parts = [rows[:, doc_off[f] + begins[r][f]: doc_off[f] + begins[r][f] + counts[r][f]] for f in range(2)]
+                        local.append(np.ascontiguousarray(np.concatenate(parts, axis=1)).view(np.uint8).reshape(-1))
+                    plans = [_exchange_plan(lib, begins, counts, doc_off, total, nq, eb, mode, r) for r in range(N)]
+                    assert len({p[2][4] for p in plans}) == 1                      # same collective everywhere
+                    owned = []
+                    for i in range(N):
+                        xf, cps, out = plans[i]
+                        q0, qn, staging_bytes, global_bytes, use_ag, my_row = out
+                        owned.append((q0, qn))
+                        staging = np.zeros(staging_bytes, dtype=np.uint8)
+                        for j in range(N):
+                            if use_ag:
+                                # ncclAllGather: every rank's nq * row bytes land rank after rank
+                                assert xf[j].recv_bytes == nq * my_row and plans[j][2][5] == my_row
+                                staging[xf[j].recv_offset: xf[j].recv_offset + xf[j].recv_bytes] = local[j][:nq * my_row]
+                                continue
+                            if j == i:
+                                assert xf[j].send_bytes == 0 and xf[j].recv_bytes == 0
+                                continue
+                            peer = plans[j][0][i]                                   # what j sends to i
+                            assert peer.send_bytes == xf[j].recv_bytes, (N, i, j)   # ncclSend / ncclRecv sizes agree
+                            staging[xf[j].recv_offset: xf[j].recv_offset + xf[j].recv_bytes] = \
+                                local[j][peer.send_offset: peer.send_offset + peer.send_bytes]
+                        got = np.full(global_bytes, 0xAB, dtype=np.uint8)
+                        written = np.zeros(global_bytes, dtype=np.uint8)
+                        for c in cps:
+                            src = local[i] if c.src_is_local else staging
+                            for h in range(c.height):
+                                so, do = c.src_offset + h * c.src_pitch, c.dst_offset + h * c.dst_pitch
+                                got[do:do + c.width] = src[so:so + c.width]
+                                written[do:do + c.width] += 1
+                        assert (written == 1).all(), (N, i, mode)                  # every byte exactly once
+                        want = np.ascontiguousarray(rows[q0:q0 + qn]).view(np.uint8).reshape(-1)
+                        assert np.array_equal(got, want), (N, i, mode, eb, nq)
+                    if mode == 1:                                                  # the owners partition the batch
+                        assert [o[0] for o in owned] == [nq * j // N for j in range(N)]
+                        assert sum(o[1] for o in owned) == nq
+                    else:
+                        assert all(o == (0, nq) for o in owned)
