@@ -209,3 +209,28 @@ def test_large_files_cross_staging_boundaries(gpu_lib, oracle, construct, tmp_pa
         assert s.search_hits(queries, 0.26, 20) == [
             [(f, d, sc) for (f, d, _n, sc) in oracle.search(ix, q, 0.26, 20)] for q in queries]
         del s
+
+
+def test_streamed_file_at_scale_is_bit_exact(gpu_lib, oracle, tmp_path):
+    """BASELINE configs[4] in small: the C3 geometry at 1/4 scale as a 4.6 GB .cobs_compact FILE
+    (written by the generator), opened under a 1.5 GB HBM budget (whole sub-indexes and column
+    slices of the large ones stream through the two buffers), every query of a 64-query batch equal
+    to the oracle, which regenerates the procedural rows itself.  (The same run at the full
+    configs[4] size -- 183.7 GB file, 64 GB budget -- is profiles/r02_c5_184GB_bench.json.)"""
+    import cobs_amd
+    cfg = bench.c3_config(0.25)
+    path = str(tmp_path / "c5_quarter.cobs_compact")
+    cobs_amd.write_synthetic(path, "compact", cfg["signature_sizes"], cfg["num_docs"], page_size=cfg["page_size"], seed=1)
+    s = gpu_lib.Search(path, hbm_budget=1500 * 1000 * 1000)
+    assert s.info(0).hbm_bytes <= 1500 * 1000 * 1000
+    ix = _oracle_index(oracle, cfg)
+    queries = bench.make_queries(64, 1000)
+    b = gpu_lib.Batch(s)
+    b.set_queries(queries)
+    b.run(0.0)
+    b.sync()
+    assert b.stats()["scan_launches"] >= 4                      # really streamed in several chunks
+    for i, q in enumerate(queries):
+        assert np.array_equal(b.counts_host(i), ix.counts(q)), i
+    got = s.search_hits(queries[:8], 0.0, 5)
+    assert got == [[(f, d, sc) for (f, d, _n, sc) in oracle.search(ix, q, 0.0, 5)] for q in queries[:8]]
