@@ -699,17 +699,53 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
             }
         }
     } else {
-        // general H: AND the H hash rows of each term first (aggregate_rows)
-        uint4 X[8], Y[8];
-        for (uint32_t i = 0; i < nw; ++i) {
-            const IdxT* t = tab + blk_of(i);
-            issue_rows<NT>(X, lane_base, pitch, load_idx8(t));
-            for (uint32_t j = 1; j < H; ++j) {
-                issue_rows<NT>(Y, lane_base, pitch, load_idx8(t + 8u * j));
-                and_rows(X, Y);
+        // general H: AND the H hash rows of each term first (aggregate_rows), then count.
+        // The (block, hash) pairs of a wave form one stream of "sub-trips" that runs through the
+        // same three-stage pipeline as the H = 1 loop -- row indices of sub-trip s+2 | row loads of
+        // s+1 | AND / CSA of s -- so that 8..16 rows are always in flight (the first version
+        // issued a block's rows only after the previous block had been counted).
+        if (nw > 0) {
+            uint4 XA[8], XB[8], ACC[8];
+            const uint32_t total = nw * H;
+            uint32_t li = 0, lj = 0;                   // (trip, hash) of the next index load
+            auto next_idx = [&]() {
+                const Idx8<IdxT> r = load_idx8(tab + blk_of(li) + 8u * lj);     // trips >= nw point at the padding block
+                if (++lj == H) { lj = 0; ++li; }
+                return r;
+            };
+            uint32_t cj = 0;                           // hash of the sub-trip being consumed
+            auto consume = [&](const uint4 (&X)[8]) {
+                if (cj == 0) {
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) ACC[t] = X[t];
+                } else {
+                    and_rows(ACC, X);
+                }
+                if (++cj == H) {
+                    cj = 0;
+                    absorb_block<NP>(pl, ACC, ea);
+                    retire_single<NP>(pl, ea);
+                }
+            };
+            Idx8<IdxT> i0 = next_idx();
+            issue_rows<NT>(XA, lane_base, pitch, i0);
+            Idx8<IdxT> i1 = next_idx();
+            uint32_t sidx = 0;
+            for (; sidx + 2 < total; sidx += 2) {
+                i0 = next_idx();
+                issue_rows<NT>(XB, lane_base, pitch, i1);
+                consume(XA);
+                i1 = next_idx();
+                issue_rows<NT>(XA, lane_base, pitch, i0);
+                consume(XB);
             }
-            absorb_block<NP>(pl, X, ea);
-            retire_single<NP>(pl, ea);
+            if (sidx + 1 < total) {
+                issue_rows<NT>(XB, lane_base, pitch, i1);
+                consume(XA);
+                consume(XB);
+            } else {
+                consume(XA);
+            }
         }
     }
 
