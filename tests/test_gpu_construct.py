@@ -231,3 +231,40 @@ def test_build_into_hbm_and_text_batches(gpu_lib, oracle, construct, golden_dir,
         out = str(tmp_path / ("b." + ("cobs_" + kind)))
         (cobs_amd.classic_construct if kind == "classic" else cobs_amd.compact_construct)(fasta, out, params)
         assert open(out, "rb").read() == open(os.path.join(golden_dir, golden), "rb").read()
+
+
+def test_reference_construction_corpus_on_the_gpu(gpu_lib, oracle, construct, tmp_path):
+    """the corpus of /root/reference/tests/compact_index_construction.cpp / classic_index_construction.cpp
+    (generate_documents_all: 33 documents, 3 hashes, fpr 0.1, compact page_size 2) built by the GPU
+    builder from in-memory documents: the files equal the oracle's byte for byte, and queries
+    against them answer as the oracle does"""
+    import cobs_amd
+    query = oracle.random_sequence(10000, 1)
+    docs = construct.generate_documents_all(query, 33, num_hashes=3)
+    n = min(1000000, len(query) - 31)
+    members = [[] for _ in range(33)]
+    for i in range(n):
+        for j in range(0, 33, i % 32 + 1):
+            members[j].append(i)
+    dl = cobs_amd.DocumentList()
+    for d, m in zip(docs, members):
+        dl.add_document(d.name, [query[i:i + 31] for i in m])
+        assert len(m) == d.num_terms
+    for e, d in zip(dl, docs):
+        e.path = d.path                                      # same path order as the oracle's documents
+    for kind in ("classic", "compact"):
+        want, got = str(tmp_path / ("o.cobs_" + kind)), str(tmp_path / ("g.cobs_" + kind))
+        if kind == "classic":
+            construct.classic_construct(docs, want, num_hashes=3, false_positive_rate=0.1)
+            params = cobs_amd.ClassicIndexParameters()
+        else:
+            construct.compact_construct(docs, want, num_hashes=3, false_positive_rate=0.1, page_size=2)
+            params = cobs_amd.CompactIndexParameters()
+            params.page_size = 2
+        params.num_hashes, params.false_positive_rate = 3, 0.1
+        (cobs_amd.classic_construct_list if kind == "classic" else cobs_amd.compact_construct_list)(dl, got, params)
+        assert open(got, "rb").read() == open(want, "rb").read(), kind
+        s = gpu_lib.Search(got)
+        ix = oracle.Index.open(want)
+        for q in (query[:500], query[2000:2100], query):
+            assert np.array_equal(s.counts(q), ix.counts(q))

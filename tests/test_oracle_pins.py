@@ -428,3 +428,47 @@ def test_fasta_term_state_machine_restated_twice(oracle, construct, tmp_path):
         plain = [s[j:j + k] for s in construct.fasta_sequences(f) for j in range(len(s) - k + 1)]
         got = [b[j:j + k] for b in construct.fasta_term_buffers(f, k) for j in range(len(b) - k + 1)]
         assert got == plain
+
+
+def test_compact_construction_follows_the_reference_test(oracle, construct, tmp_path):
+    """/root/reference/tests/compact_index_construction.cpp:60-169 restated on the oracle's builder:
+    33 documents of generate_documents_all, 3 hashes, fpr 0.1, page_size 2 -> three sub-indexes of
+    16 documents; names in (size, then path inside a group of 16) order (:66-73, :89-94); every
+    document's ones within 1.02 x the expected fill of ITS sub-index (:120-141); and each
+    sub-index equals the classic index of the same 16 documents at the same signature size
+    (:143-169)."""
+    query = oracle.random_sequence(10000, 1)
+    docs = construct.generate_documents_all(query, 33, num_hashes=3)
+    p = str(tmp_path / "cc.cobs_compact")
+    page_size, params = construct.compact_construct(docs, p, num_hashes=3, false_positive_rate=0.1, page_size=2)
+    ix = oracle.Index.open(p)
+    assert (ix.num_docs, ix.num_pages, ix.page_size, ix.num_hashes) == (33, 3, 2, 3) and page_size == 2
+    by_size = sorted(docs, key=lambda d: (d.size, d.path))
+    order = []
+    for g in range(0, 33, 16):
+        order += sorted(by_size[g:g + 16], key=lambda d: d.path)
+    assert [ix.doc_name(i) for i in range(33)] == [d.name for d in order]
+    raw = np.frombuffer(open(p, "rb").read(), dtype=np.uint8)
+    off = ix.data_offset
+    for g in range(3):
+        sig = ix.signature_size(g)
+        group = order[16 * g:16 * g + 16]
+        assert sig == construct.calc_signature_size(max(d.num_terms for d in group), 3, 0.1) == params[g][0]
+        m = raw[off:off + sig * 2].reshape(sig, 2)
+        off += sig * 2
+        bits = np.unpackbits(m, axis=1, bitorder="little")
+        ratio = 1.0 - (1.0 - 1.0 / sig) ** (3 * max(d.num_terms for d in group))
+        assert bits.sum(axis=0).max() <= ratio * sig * 1.02
+        assert not bits[:, len(group):].any()                       # padding documents of the last group
+        pc = str(tmp_path / ("g%d.cobs_classic" % g))
+        construct.classic_construct(group, pc, num_hashes=3, signature_size=sig)
+        _, _, names, csig, _, cm = construct.read_classic(pc)
+        assert csig == sig and names == [d.name for d in group]
+        assert np.array_equal(cm, m[:, :cm.shape[1]])               # :163-168 content equality
+    assert off == len(raw)
+    # queries against it: every document scores at least its true number of terms (compact_index_query.cpp)
+    T = len(query) - 30
+    got = ix.counts(query)
+    idx_of = {d.name: i for i, d in enumerate(order)}
+    for d in docs:
+        assert got[idx_of[d.name]] >= d.num_terms or d.num_terms > T
