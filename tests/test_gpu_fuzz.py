@@ -104,3 +104,76 @@ def test_lds_staged_variant_is_bit_exact(gpu_lib, oracle):
             b.sync()
             for i in (0, 17, 47):
                 assert b.hits_host(i, 0) == cases.oracle_results([ix], qs[i], 0.3, 0)
+
+
+def test_random_shards(gpu_lib, oracle, tmp_path):
+    """random geometries x random shard counts / shard modes / HBM budgets: every shard computes
+    exactly its slot range, the shards' hits are its documents' hits, and the slices -- moved
+    according to the library's exchange plan -- assemble to the oracle's rows"""
+    import ctypes as C
+    from cobs_amd import _capi
+    lib = _capi.load()
+    rng = np.random.default_rng(777 + 100003 * int(os.environ.get("COBS_FUZZ_SEED", "0")))
+    for idx in range(24):
+        path, queries = _random_case(rng, oracle, tmp_path, idx)
+        ix = oracle.Index.open(path)
+        N = int(rng.integers(2, 7))
+        mode = int(rng.integers(0, 2))
+        want = np.stack([ix.counts(q) for q in queries])
+        t = float(rng.choice([0.25, 0.5]))
+        shards, local = [], []
+        budget = 0
+        if rng.random() < 0.4:
+            budget = int(os.path.getsize(path) * float(rng.uniform(0.6, 1.5)) / N) + 70000
+        for r in range(N):
+            try:
+                s = gpu_lib.Search(path, shard_rank=r, shard_count=N, shard_mode=mode, hbm_budget=budget)
+            except gpu_lib.CobsGpuError as e:
+                assert e.status == _capi.ERR_CAPACITY and budget, (path, e)       # budget below one column slice
+                s = gpu_lib.Search(path, shard_rank=r, shard_count=N, shard_mode=mode)
+            i = s.info(0)
+            b = gpu_lib.Batch(s)
+            b.set_queries(queries)
+            b.run(0.0)
+            b.sync()
+            rows = np.stack([b.counts_host(q) for q in range(len(queries))])
+            outside = np.ones(rows.shape[1], dtype=bool)
+            outside[i.slot_begin:i.slot_begin + i.slot_count] = False
+            assert not rows[:, outside].any(), (path, N, mode, r)
+            assert np.array_equal(rows[:, ~outside], want[:, ~outside]), (path, N, mode, r)
+            if i.slot_count:
+                got = s.search_hits(queries, t, 0)
+                for q, g in zip(queries, got):
+                    ref = [h for h in cases.oracle_results([ix], q, t, 0) if i.slot_begin <= h[1] < i.slot_begin + i.slot_count]
+                    assert g == ref, (path, N, mode, r)
+            shards.append((int(i.slot_begin), int(i.slot_count)))
+            local.append(np.ascontiguousarray(rows[:, ~outside].astype(np.uint32)).view(np.uint8).reshape(-1))
+        assert sum(c for _, c in shards) == want.shape[1]
+        # the exchange plan on these layouts (all-to-all), played with memcpy
+        nq, total = len(queries), want.shape[1]
+        bs = (C.c_uint64 * N)(*[s_[0] for s_ in shards])
+        cs = (C.c_uint64 * N)(*[s_[1] for s_ in shards])
+        d0 = (C.c_uint64 * 1)(0)
+        plans = []
+        for r in range(N):
+            xf, cp = (_capi.Xfer * N)(), (_capi.Copy2D * N)()
+            ncp, out = C.c_size_t(N), (C.c_uint64 * 6)()
+            _capi.check(lib.cobs_gpu_exchange_plan(bs, cs, d0, N, 1, total, nq, 4, 1, r, xf, cp, C.byref(ncp), out))
+            plans.append((list(xf), list(cp)[:ncp.value], list(out)))
+        for r in range(N):
+            xf, cps, out = plans[r]
+            staging = np.zeros(out[2], dtype=np.uint8)
+            for j in range(N):
+                if j != r and xf[j].recv_bytes:
+                    peer = plans[j][0][r]
+                    assert peer.send_bytes == xf[j].recv_bytes
+                    staging[xf[j].recv_offset:xf[j].recv_offset + xf[j].recv_bytes] = \
+                        local[j][peer.send_offset:peer.send_offset + peer.send_bytes]
+            got = np.zeros(out[3], dtype=np.uint8)
+            for c in cps:
+                src = local[r] if c.src_is_local else staging
+                for h in range(c.height):
+                    got[c.dst_offset + h * c.dst_pitch:c.dst_offset + h * c.dst_pitch + c.width] = \
+                        src[c.src_offset + h * c.src_pitch:c.src_offset + h * c.src_pitch + c.width]
+            ref = np.ascontiguousarray(want[out[0]:out[0] + out[1]].astype(np.uint32)).view(np.uint8).reshape(-1)
+            assert np.array_equal(got, ref), (path, N, mode, r)
