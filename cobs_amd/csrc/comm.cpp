@@ -457,12 +457,14 @@ cobs_gpu_status cobs_gpu_sharded_search_batch(cobs_gpu_index* ix, cobs_gpu_comm*
         hit_offsets[0] = 0;
         size_t used = 0;
         bool overflow = false;
-        // passes bounded like the single-GPU API (score rows / tables below the workspace limit)
+        // Passes bounded like the single-GPU API (score rows / tables below the workspace limit) --
+        // from quantities that are the SAME on every rank (whole-file geometry, not this shard's):
+        // all ranks must cut the batch at the same places, every pass is a set of collectives.
         uint32_t min_term = 0xFFFFFFFFu;
         uint64_t table_per_char = 0;
         for (const auto& p : ix->parts) {
             min_term = std::min(min_term, p.meta.term_size);
-            table_per_char += 4ull * p.meta.num_hashes * std::max<uint32_t>(p.num_tpages(), 1) * (p.idx64 ? 2 : 1);
+            table_per_char += 4ull * p.meta.num_hashes * std::max<uint32_t>(p.meta.num_pages(), 1) * (p.idx64 ? 2 : 1);
         }
         const size_t topk = num_results < ix->total_counts ? num_results : 0;
         const bool all_docs = threshold <= 0.0 && topk == 0;
@@ -475,8 +477,8 @@ cobs_gpu_status cobs_gpu_sharded_search_batch(cobs_gpu_index* ix, cobs_gpu_comm*
                 const uint64_t mt = std::max(max_terms, terms);
                 const int planes = scan_planes_for(mt);
                 const uint64_t eb = planes > 0 ? scan_score_bytes(planes) : 4u;
-                // local rows, plus the assembled global rows of the all-documents mode
-                const uint64_t sb = (uint64_t)(g1 - g0 + 1) * (ix->local_counts + (all_docs ? ix->total_counts : 0)) * eb;
+                // local rows (bounded by the whole vector), plus the assembled global rows of the all-documents mode
+                const uint64_t sb = (uint64_t)(g1 - g0 + 1) * (ix->total_counts + (all_docs ? ix->total_counts : 0)) * eb;
                 const uint64_t t = (uint64_t)(lens[g1] + 16) * table_per_char;
                 if (g1 > g0 && (sb > ix->tune.pass_bytes || tb + t > ix->tune.pass_bytes)) break;
                 max_terms = mt;
@@ -504,6 +506,10 @@ cobs_gpu_status cobs_gpu_sharded_search_batch(cobs_gpu_index* ix, cobs_gpu_comm*
             if (b->topk_k) {
                 s = cobs_gpu_batch_exchange_topk(b, c, st);
                 if (s != COBS_GPU_OK) return s;
+                // a query with a single hash in total is NOT ordered by score (max_counts <= 1,
+                // classic_search.cpp:134,177): its result is the first documents in index order, which
+                // K3's per-shard best-of lists do not determine -- such a pass also needs the rows
+                for (size_t q = 0; q < g1 - g0 && !need_rows; ++q) need_rows = total_hashes(b, q) <= 1;
             } else if (b->selected) {
                 int over = 0;
                 s = cobs_gpu_batch_exchange_hits(b, c, st, &over);
