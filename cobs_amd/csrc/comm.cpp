@@ -189,6 +189,19 @@ XferPlan plan_exchange(const uint64_t* layout /*[N][F][2]*/, const uint64_t* doc
     return p;
 }
 
+// max over all ranks of a status word (one tiny ncclAllReduce)
+cobs_gpu_status agree(const cobs_gpu_comm* c, cobs_gpu_batch* b, hipStream_t st, uint32_t mine, uint32_t* worst) {
+    if (!b->xchg) b->xchg = new Exchange;
+    Exchange& x = *b->xchg;
+    HIP_TRY(x.d_meta.reserve(64));
+    uint32_t* d = reinterpret_cast<uint32_t*>(x.d_meta.p);
+    HIP_TRY(hipMemcpyAsync(d, &mine, 4, hipMemcpyHostToDevice, st));
+    NCCL_TRY(ncclAllReduce(d, d + 1, 1, ncclUint32, ncclMax, c->comm, st));
+    HIP_TRY(hipMemcpyAsync(worst, d + 1, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return COBS_GPU_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -486,21 +499,27 @@ cobs_gpu_status cobs_gpu_sharded_search_batch(cobs_gpu_index* ix, cobs_gpu_comm*
                 ++g1;
             }
             size_t bad = 0;
-            cobs_gpu_status s = set_queries_on(b, queries + g0, lens + g0, g1 - g0, st, false, &bad, g0);
-            if (s != COBS_GPU_OK) {
-                if (bad_query) *bad_query = g0 + bad;
-                return s;
-            }
             const bool hits_only = threshold > 0.0 && topk == 0;
-            s = run_impl(b, threshold, topk, st, !hits_only);
-            if (s != COBS_GPU_OK) return s;
-            s = cobs_gpu_batch_sync(b, st, &bad);
-            if (s != COBS_GPU_OK) {
-                if (bad_query) *bad_query = g0 + bad;
+            cobs_gpu_status s = set_queries_on(b, queries + g0, lens + g0, g1 - g0, st, false, &bad, g0);
+            if (s == COBS_GPU_OK) s = run_impl(b, threshold, topk, st, !hits_only);
+            if (s == COBS_GPU_OK) {
+                s = cobs_gpu_batch_sync(b, st, &bad);
                 if (s == COBS_GPU_ERR_INVALID_BASE)       // the message names the query by its index in the call
-                    return fail(s, "Invalid DNA base pair in query string. Only ACGT are allowed. (query " +
-                                   std::to_string(g0 + bad) + ")");
-                return s;
+                    s = fail(s, "Invalid DNA base pair in query string. Only ACGT are allowed. (query " +
+                                std::to_string(g0 + bad) + ")");
+            }
+            if (s != COBS_GPU_OK && bad_query) *bad_query = g0 + bad;
+            // Every rank must know whether the scan went through EVERYWHERE before anybody enters the
+            // exchange: a rank that failed alone (out of memory, ...) would leave the others waiting in
+            // a collective.  (Bad input fails identically on all ranks; this covers the rest.)
+            {
+                const std::string keep = s != COBS_GPU_OK ? std::string(cobs_gpu_last_error()) : std::string();
+                uint32_t worst = 0;
+                const cobs_gpu_status as = agree(c, b, st, (uint32_t)s, &worst);
+                if (s != COBS_GPU_OK) return fail(s, keep);
+                if (as != COBS_GPU_OK) return as;
+                if (worst != COBS_GPU_OK)
+                    return fail(COBS_GPU_ERR_RCCL, "the pass failed on another rank (status " + std::to_string(worst) + ")");
             }
             bool need_rows = !hits_only && b->topk_k == 0;
             if (b->topk_k) {
