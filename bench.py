@@ -642,6 +642,8 @@ def main():
     if budget:
         info = s.info(0)
         index_bytes = sum(cfg["signature_sizes"]) * (cfg["page_size"] or (cfg["num_docs"] + 7) // 8)
+        out["roofline"]["note"] = ("streamed run: the step is bound by PCIe (streaming.pcie_GBps_rank0), the scan-kernel "
+                                   "interval includes waiting for the chunk copies")
         out["streaming"] = {"hbm_budget_bytes": budget, "index_bytes": index_bytes, "file": path,
                             "scan_launches_per_step": nlaunch,
                             "pcie_GBps_rank0": round(index_bytes / max(world if shard_index else 1, 1) / (dt / args.steps) / 1e9, 2)}

@@ -27,6 +27,7 @@
 // same call with the same batch contents.
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -38,13 +39,14 @@ using namespace cobs_amd;
 struct cobs_gpu_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1, device = 0;
+    uint64_t serial = 0;          // never reused: a batch remembers which communicator its layout came from
 };
 
 namespace cobs_amd {
 
 // per-batch exchange workspace
 struct Exchange {
-    const cobs_gpu_comm* bound = nullptr;        // communicator the layout below was gathered on
+    uint64_t bound = 0;                          // serial of the communicator the layout below was gathered on
     size_t nparts = 0;
     std::vector<uint64_t> layout;                // [rank][part][2] = slot_begin, slot_count
     std::vector<uint64_t> local_n;               // [rank] score slots per query on that rank
@@ -77,7 +79,7 @@ cobs_gpu_status nccl_fail(ncclResult_t r, const char* what) {
 cobs_gpu_status bind_layout(cobs_gpu_batch* b, const cobs_gpu_comm* c, hipStream_t st) {
     if (!b->xchg) b->xchg = new Exchange;
     Exchange& x = *b->xchg;
-    if (x.bound == c) return COBS_GPU_OK;
+    if (x.bound == c->serial) return COBS_GPU_OK;
     const cobs_gpu_index* ix = b->ix;
     const size_t np = ix->parts.size(), per = 2 * np + 2, N = (size_t)c->nranks;
     std::vector<uint64_t> mine(per);
@@ -106,7 +108,7 @@ cobs_gpu_status bind_layout(cobs_gpu_batch* b, const cobs_gpu_comm* c, hipStream
         }
     }
     x.nparts = np;
-    x.bound = c;
+    x.bound = c->serial;
     return COBS_GPU_OK;
 }
 
@@ -257,6 +259,8 @@ cobs_gpu_status cobs_gpu_comm_create(const uint8_t id[COBS_GPU_UNIQUE_ID_BYTES],
         ncclUniqueId u;
         std::memcpy(&u, id, sizeof u);
         NCCL_TRY(ncclCommInitRank(&c->comm, nranks, u, rank));
+        static std::atomic<uint64_t> next_serial{1};
+        c->serial = next_serial.fetch_add(1);
         *out = c.release();
         return COBS_GPU_OK;
     });
