@@ -472,3 +472,83 @@ def test_compact_construction_follows_the_reference_test(oracle, construct, tmp_
     idx_of = {d.name: i for i, d in enumerate(order)}
     for d in docs:
         assert got[idx_of[d.name]] >= d.num_terms or d.num_terms > T
+
+
+def _independent_counts(path, query):
+    """A second, independent restatement of the query path (no code shared with oracle/): header
+    parsed here, canonicalisation as util/query.cpp:143-199 written from its description, hashes
+    from the real xxHash library (python-xxhash), rows ANDed and summed with numpy."""
+    import struct
+    import xxhash
+    raw = open(path, "rb").read()
+    comp = {65: 84, 67: 71, 71: 67, 84: 65}
+
+    def canon(kmer):
+        n = len(kmer)
+        for i in range(n // 2):
+            f, r = kmer[i], comp[kmer[n - 1 - i]]
+            if f < r:
+                return kmer
+            if f > r:
+                return bytes(comp[c] for c in reversed(kmer))
+        return kmer
+
+    if raw.startswith(b"COBS:CLASSIC_INDEX"):
+        _, k, can, ndocs, sig, nh = struct.unpack_from("<IIBIQQ", raw, 18)
+        pos = 18 + 29
+        for _ in range(ndocs):
+            pos = raw.index(b"\n", pos) + 1
+        pos += 13
+        row = (ndocs + 7) // 8
+        pages = [(sig, np.frombuffer(raw, np.uint8, sig * row, pos).reshape(sig, row))]
+    else:
+        assert raw.startswith(b"COBS:COMPACT_INDEX")
+        _, k, can, nparams, ndocs, ps = struct.unpack_from("<IIBIIQ", raw, 18)
+        pos = 18 + 25
+        params = [struct.unpack_from("<QQ", raw, pos + 16 * i) for i in range(nparams)]
+        pos += 16 * nparams
+        for _ in range(ndocs):
+            pos = raw.index(b"\n", pos) + 1
+        pos += (ps - ((pos + 13) % ps)) % ps + 13
+        nh = params[0][1]
+        pages = []
+        for sig, _h in params:
+            pages.append((sig, np.frombuffer(raw, np.uint8, sig * ps, pos).reshape(sig, ps)))
+            pos += sig * ps
+    T = len(query) - k + 1
+    out = []
+    for sig, m in pages:
+        acc = np.zeros(m.shape[1] * 8, dtype=np.int64)
+        for i in range(T):
+            kmer = query[i:i + k]
+            if can:
+                kmer = canon(kmer)
+            rowbits = None
+            for j in range(nh):
+                r = m[xxhash.xxh64_intdigest(kmer, seed=j) % sig]
+                rowbits = r if rowbits is None else (rowbits & r)
+            acc += np.unpackbits(rowbits, bitorder="little")
+        out.append(acc)
+    return np.concatenate(out)
+
+
+def test_oracle_against_an_independent_restatement(oracle, golden_dir, tmp_path):
+    """the C oracle (oracle/cobs_oracle.c) and a from-scratch numpy + python-xxhash restatement
+    agree on the golden fixtures and on random classic / compact indexes (H 1..3, canonicalize
+    0/1, odd document counts, several sub-indexes)"""
+    q50 = b"AGTCAACGCTAAGGCATTTCCCCCCTGCCTCCTGCCTGCTGCCAAGCCCT"
+    for name in ("c1.cobs_classic", "c1.cobs_compact"):
+        p = os.path.join(golden_dir, name)
+        assert np.array_equal(_independent_counts(p, q50), oracle.Index.open(p).counts(q50).astype(np.int64))
+    q = oracle.random_sequence(180, 5)
+    files = [
+        cases.make_classic(cases.tmp(tmp_path, "i1.cobs_classic"), 77, 499, 1, 31, 1, 0.3, 1, planted={3: 1.0}, query=q),
+        cases.make_classic(cases.tmp(tmp_path, "i2.cobs_classic"), 130, 701, 3, 21, 0, 0.4, 2),
+        cases.make_compact(cases.tmp(tmp_path, "i3.cobs_compact"), 3 * 8 * 4 - 5, 4, [211, 307, 401], 2, 31, 1, 0.3, 3,
+                           planted={9: 0.7}, query=q),
+        cases.make_compact(cases.tmp(tmp_path, "i4.cobs_compact"), 8 * 16 + 3, 16, [257, 263], 1, 15, 1, 0.5, 4),
+    ]
+    for p in files:
+        ix = oracle.Index.open(p)
+        for qq in (q, q[:31 if ix.term_size <= 31 else ix.term_size], q[40:140]):
+            assert np.array_equal(_independent_counts(p, qq), ix.counts(qq).astype(np.int64)), p
