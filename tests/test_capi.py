@@ -108,6 +108,8 @@ def test_python_mirror_surface():
                       (cobs_amd.classic_construct_list, "list"), (cobs_amd.compact_construct_list, "list")):
         ps = list(inspect.signature(fn).parameters)
         assert ps[:3] == [first, "out_file", "index_params"], ps
+    import cobs_index                       # the reference's module name, same objects
+    assert cobs_index.Search is cobs_amd.Search and cobs_index.SearchResult is cobs_amd.SearchResult
     p = cobs_amd.ClassicIndexParameters()
     assert (p.term_size, p.canonicalize, p.num_hashes, p.false_positive_rate) == (31, True, 1, 0.3)
     assert cobs_amd.CompactIndexParameters().page_size == 0

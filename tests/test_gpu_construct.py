@@ -268,3 +268,29 @@ def test_reference_construction_corpus_on_the_gpu(gpu_lib, oracle, construct, tm
         ix = oracle.Index.open(want)
         for q in (query[:500], query[2000:2100], query):
             assert np.array_equal(s.counts(q), ix.counts(q))
+
+
+def test_drop_in_module_name(gpu_lib, golden_dir, tmp_path):
+    """`import cobs_index as cobs` (the reference's module name): the flow of the reference's
+    own python/tests/test_cobs_index.py, statement for statement, against this engine"""
+    import cobs_index as cobs
+    datadir = os.path.join(golden_dir)
+    cobs.disable_cache()
+    l1 = cobs.DocumentList(datadir + "/fasta")
+    assert l1.size() == 7
+    l2 = cobs.DocumentList()
+    l2.add_recursive(datadir + "/fasta")
+    assert l2.size() == 7
+    for ext, params, construct_fn in ((".cobs_classic", cobs.ClassicIndexParameters, cobs.classic_construct),
+                                      (".cobs_compact", cobs.CompactIndexParameters, cobs.compact_construct)):
+        index_file = str(tmp_path / ("python_test" + ext))
+        p = params()
+        p.clobber = True
+        construct_fn(input=datadir + "/fasta", out_file=index_file, index_params=p)
+        assert os.path.isfile(index_file)
+        s = cobs.Search(index_file)
+        r = s.search("AGTCAACGCTAAGGCATTTCCCCCCTGCCTCCTGCCTGCTGCCAAGCCCT")
+        assert len(r) == 7
+        assert r[0].doc_name == "sample1"
+        assert r[0].score == 20
+    assert isinstance(cobs.__version__, str)
