@@ -1446,13 +1446,11 @@ static cobs_gpu_status fetch_counts(cobs_gpu_batch* b, size_t q, uint32_t* count
 // stable counting sort by score of the documents taken in (file, doc) order -- O(documents),
 // where std::partial_sort of 100 000 documents costs ~9 ms per query.  Writes the first `want`
 // results straight into `hits` (when it is large enough) and returns their number.
-static cobs_gpu_status rank_row(cobs_gpu_batch* b, size_t q, size_t num_results, cobs_gpu_hit* hits, size_t cap,
-                                size_t* n_hits) {
-    cobs_gpu_index* ix = b->ix;
-    if (!b->have_counts) return fail(COBS_GPU_ERR_ARG, "the last run did not keep the score rows");
-    const uint8_t* raw = nullptr;
-    cobs_gpu_status st = fetch_row(b, q, &raw);
-    if (st != COBS_GPU_OK) return st;
+// (rank_raw touches nothing of the batch but `hist`: several host threads rank different queries of
+// one row window at the same time, see rank_window)
+static cobs_gpu_status rank_raw(const cobs_gpu_batch* b, size_t q, const uint8_t* raw, std::vector<uint32_t>& hist,
+                                size_t num_results, cobs_gpu_hit* hits, size_t cap, size_t* n_hits) {
+    const cobs_gpu_index* ix = b->ix;
     const uint32_t eb = b->elem_bytes;
     const bool glob = b->view_global;
     const bool by_score = total_hashes(b, q) > 1;       // max_counts <= 1: index order, no sort (:134, :177)
@@ -1461,7 +1459,6 @@ static cobs_gpu_status rank_row(cobs_gpu_batch* b, size_t q, size_t num_results,
     for (const Part& p : ix->parts)
         max_score = std::max<uint64_t>(max_score, (uint64_t)b->lens[q] - p.meta.term_size + 1);
     if (max_score > (1u << 24)) return COBS_GPU_ERR_UNSUPPORTED;      // caller falls back to the generic sort
-    std::vector<uint32_t>& hist = b->rank_hist;
     hist.assign((size_t)max_score + 2, 0u);
     size_t passing = 0;
     for (size_t f = 0; f < ix->parts.size(); ++f) {
@@ -1502,6 +1499,47 @@ static cobs_gpu_status rank_row(cobs_gpu_batch* b, size_t q, size_t num_results,
             const uint32_t at = hist[by_score ? std::min<uint64_t>(s, max_score) : 0]++;
             if (at < want) hits[at] = cobs_gpu_hit{(uint32_t)f, (uint32_t)d, s};
         }
+    }
+    return COBS_GPU_OK;
+}
+
+static cobs_gpu_status rank_row(cobs_gpu_batch* b, size_t q, size_t num_results, cobs_gpu_hit* hits, size_t cap,
+                                size_t* n_hits) {
+    if (!b->have_counts) return fail(COBS_GPU_ERR_ARG, "the last run did not keep the score rows");
+    const uint8_t* raw = nullptr;
+    cobs_gpu_status st = fetch_row(b, q, &raw);
+    if (st != COBS_GPU_OK) return st;
+    return rank_raw(b, q, raw, b->rank_hist, num_results, hits, cap, n_hits);
+}
+
+// The reference's default call (threshold 0, no limit) ranks EVERY document of every query: with
+// thousands of queries per pass that is host work worth spreading.  Queries [q0, q1) of the last run,
+// every one yielding exactly `per_query` hits (threshold <= 0: all real documents pass), written to
+// hits + (q - q0) * per_query by up to 16 host threads, one row window (one DMA) at a time.
+static cobs_gpu_status rank_window(cobs_gpu_batch* b, size_t q0, size_t q1, size_t per_query, cobs_gpu_hit* hits) {
+    const size_t row_bytes = (size_t)(b->ix->local_counts * b->elem_bytes);
+    for (size_t q = q0; q < q1;) {
+        const uint8_t* raw0 = nullptr;
+        cobs_gpu_status st = fetch_row(b, q, &raw0);               // loads the window that starts at q
+        if (st != COBS_GPU_OK) return st;
+        const size_t qe = std::min(q1, b->rows_q1);
+        const unsigned nthr = (unsigned)std::min<size_t>(std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())), qe - q);
+        std::vector<cobs_gpu_status> res(nthr, COBS_GPU_OK);
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nthr; ++t)
+            pool.emplace_back([=, &res]() {
+                std::vector<uint32_t> hist;
+                for (size_t i = q + t; i < qe; i += nthr) {
+                    size_t n = 0;
+                    const cobs_gpu_status r = rank_raw(b, i, raw0 + (i - q) * row_bytes, hist, 0, hits + (i - q0) * per_query,
+                                                       per_query, &n);
+                    if (r != COBS_GPU_OK || n != per_query) { res[t] = r != COBS_GPU_OK ? r : COBS_GPU_ERR_ARG; return; }
+                }
+            });
+        for (auto& th : pool) th.join();
+        for (cobs_gpu_status r : res)
+            if (r != COBS_GPU_OK) return r == COBS_GPU_ERR_UNSUPPORTED ? r : fail(r, "ranking a row window failed");
+        q = qe;
     }
     return COBS_GPU_OK;
 }
@@ -1861,6 +1899,30 @@ static cobs_gpu_status search_batch_impl(cobs_gpu_index* ix, const char* const* 
             return st;
         }
         cobs_gpu_batch* sb = ix->scratch[ps.slot];
+        // all documents of every query (the reference's default call): every query yields the same
+        // number of hits, so the queries of the pass are ranked by several host threads at once
+        if (!overflow && threshold <= 0.0 && num_results == 0 && sb->have_counts && !sb->selected && sb->topk_k == 0 &&
+            !sb->view_global && ps.g1 - ps.g0 >= 4 && sb->max_terms <= (1u << 24)) {
+            size_t per_query = 0;
+            for (const Part& p : ix->parts) {
+                const uint64_t d1 = std::min<uint64_t>(p.slot_begin + p.slot_count, p.meta.doc_names.size());
+                per_query += d1 > p.slot_begin ? (size_t)(d1 - p.slot_begin) : 0;
+            }
+            // (a single-hash query is not ordered by score but yields the same number of hits: rank_raw handles it)
+            if (per_query * (ps.g1 - ps.g0) <= cap - used) {
+                double t0 = now_s();
+                st = rank_window(sb, 0, ps.g1 - ps.g0, per_query, hits + used);
+                ix->timers[4] += now_s() - t0;
+                if (st == COBS_GPU_OK) {
+                    for (size_t q = ps.g0; q < ps.g1; ++q) {
+                        used += per_query;
+                        hit_offsets[q + 1] = used;
+                    }
+                    return COBS_GPU_OK;
+                }
+                if (st != COBS_GPU_ERR_UNSUPPORTED) return st;      // else: scores too wide for the counting sort
+            }
+        }
         for (size_t q = ps.g0; q < ps.g1; ++q) {
             size_t n = 0;
             if (sb->selected && sb->pool_fetched && sb->h_nhits() <= sb->hit_cap &&

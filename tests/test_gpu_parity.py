@@ -620,3 +620,26 @@ def test_small_calls_replay_a_captured_graph(gpu_lib, oracle, tmp_path):
     for _ in range(4):
         assert s.search_hits([good], 0.0, 1) == [cases.oracle_results([ix], good, 0.0, 1)]
     assert s.graph_replays == r
+
+
+def test_default_call_in_batches_is_ranked_by_host_threads(gpu_lib, oracle, tmp_path):
+    """threshold 0, no limit (the reference's default arguments) for MANY queries per call: the
+    passes' score rows are ranked by several host threads -- every document, in the reference's
+    order incl. ties and the unsorted single-hash case, over two files, whole and sharded"""
+    q = oracle.random_sequence(400, 5)
+    pa = cases.make_classic(cases.tmp(tmp_path, "ra.cobs_classic"), 611, 701, 1, 31, 1, 0.3, 3, planted={7: 1.0, 600: 0.5}, query=q)
+    pb = cases.make_compact(cases.tmp(tmp_path, "rb.cobs_compact"), 3 * 8 * 16 - 3, 16, [401, 503, 601], 1, 31, 1, 0.3, 4)
+    ixs = [oracle.Index.open(pa), oracle.Index.open(pb)]
+    queries = [q[i:i + 31 + (13 * i) % 300] for i in range(37)] + [q[:31]] * 3
+    s = gpu_lib.Search([pa, pb])
+    got = s.search_hits(queries, 0.0, 0)
+    assert got == [cases.oracle_results(ixs, qq, 0.0, 0) for qq in queries]
+    assert all(len(g) == 611 + 381 for g in got)
+    s.set_tuning("pass_bytes", 9 * s.local_counts * 2)                   # several passes, several windows
+    assert s.search_hits(queries, 0.0, 0) == got
+    for n, r in ((3, 1), (2, 0)):
+        sh = gpu_lib.Search([pa, pb], shard_rank=r, shard_count=n)
+        lim = [(sh.info(f).slot_begin, sh.info(f).slot_begin + sh.info(f).slot_count) for f in range(2)]
+        part = sh.search_hits(queries, 0.0, 0)
+        for g, full in zip(part, got):
+            assert g == [h for h in full if lim[h[0]][0] <= h[1] < lim[h[0]][1]]
