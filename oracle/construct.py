@@ -14,8 +14,11 @@ reference's construction side:
                                     cobs/file/compact_index_header.cpp:20-43
   * test corpus generators          tests/test_util.hpp:44-84
 
-Construction is out of scope for the product; nothing
-under cobs_amd/ imports this file.
+  * classic_combine                 cobs/construction/classic_index.cpp:195-327
+  * classic_construct_random        cobs/construction/classic_index.cpp:661-725
+
+It is also the checker of the product's own GPU construction (SURVEY.md section 8f rank 4:
+cobs_amd/csrc/build.cpp must write these bytes); nothing under cobs_amd/ imports this file.
 """
 import gzip
 import math
