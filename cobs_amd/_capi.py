@@ -119,6 +119,12 @@ SYMBOLS = {
     "cobs_gpu_batch_stats": (_int, [_vp, C.POINTER(_u64 * 4)]),
     "cobs_gpu_batch_kernel_ms": (_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "cobs_gpu_batch_phase_stamps": (_int, [_vp, _pu64, _sz, C.POINTER(_sz)]),
+    "cobs_gpu_multi_open": (_int, [C.POINTER(_cp), _sz, C.POINTER(_int), _sz, C.POINTER(Options), C.POINTER(_vp)]),
+    "cobs_gpu_multi_close": (None, [_vp]),
+    "cobs_gpu_multi_size": (_sz, [_vp]),
+    "cobs_gpu_multi_index": (_vp, [_vp, _sz]),
+    "cobs_gpu_multi_search_batch": (_int, [_vp, C.POINTER(_cp), C.POINTER(_sz), _sz, _dbl, _sz,
+                                           C.POINTER(Hit), _sz, C.POINTER(_sz), C.POINTER(_sz)]),
     "cobs_gpu_graph_replays": (_u64, [_vp]),
     "cobs_gpu_timers": (_int, [_vp, C.POINTER(C.c_double * 5), _int]),
     "cobs_gpu_exchange_plan": (_int, [_pu64, _pu64, _pu64, _sz, _sz, _u64, _sz, _u32, _u32, _sz,

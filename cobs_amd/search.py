@@ -195,8 +195,8 @@ class Search:
         bad = C.c_size_t(0)
         while True:
             hits = np.empty(cap, dtype=self.HIT_DTYPE)
-            st = self._lib.cobs_gpu_search_batch(
-                self._h, arr, lens, nq, float(threshold), int(num_results),
+            st = self._search_batch_call(
+                arr, lens, nq, float(threshold), int(num_results),
                 C.cast(hits.ctypes.data, C.POINTER(Hit)), cap,
                 C.cast(offs.ctypes.data, C.POINTER(C.c_size_t)), C.byref(bad))
             if st == _capi.ERR_CAPACITY and int(offs[nq]) > cap:
@@ -205,6 +205,9 @@ class Search:
             check(st)
             break
         return offs, hits[:int(offs[nq])]
+
+    def _search_batch_call(self, *args):
+        return self._lib.cobs_gpu_search_batch(self._h, *args)
 
     def sharded_search_hits(self, comm, queries, threshold=0.0, num_results=0):
         """cobs_gpu_sharded_search_batch: collective over `comm` (every rank, same queries);
@@ -276,6 +279,50 @@ class Search:
         t = (C.c_double * 5)()
         check(self._lib.cobs_gpu_timers(self._h, C.byref(t), 1 if reset else 0))
         return dict(zip(["hashes", "h2d", "scan", "d2h", "rank"], list(t)))
+
+
+class MultiSearch(Search):
+    """The same Search over SEVERAL GPUs of one node from ONE process (cobs_gpu_multi_*): the
+    index is sharded by sub-index block over `devices`, the library runs one worker thread per
+    device and the exchange over RCCL; search / search_batch / search_arrays / search_packed
+    return exactly what Search returns on one GPU."""
+
+    def __init__(self, path, devices, hbm_budget=0, shard_mode=0):
+        self._lib = _capi.load()
+        self._m = C.c_void_p()
+        self._h = C.c_void_p()
+        paths = [path] if isinstance(path, (str, bytes, os.PathLike)) else list(path)
+        arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+        devs = (C.c_int * max(1, len(devices)))(*[int(d) for d in devices])
+        opts = _options(-1, 0, 1, hbm_budget, shard_mode)
+        check(self._lib.cobs_gpu_multi_open(arr, len(paths), devs, len(devices), C.byref(opts), C.byref(self._m)))
+        # rank 0's shard handle answers the geometry / name calls of the base class (not owned)
+        self._h = C.c_void_p(self._lib.cobs_gpu_multi_index(self._m, 0))
+
+    def close(self):
+        if getattr(self, "_m", None):
+            self._lib.cobs_gpu_multi_close(self._m)
+            self._m = C.c_void_p()
+            self._h = C.c_void_p()
+
+    @property
+    def comm_size(self):
+        return int(self._lib.cobs_gpu_multi_size(self._m))
+
+    def shard(self, rank):
+        """geometry view of one rank's shard (a borrowed handle: valid until close())"""
+        h = self._lib.cobs_gpu_multi_index(self._m, rank)
+        if not h:
+            raise IndexError(rank)
+        v = Search(None, _handle=C.c_void_p(h))
+        v.close = lambda: None          # the multi handle owns it
+        return v
+
+    def _search_batch_call(self, *args):
+        return self._lib.cobs_gpu_multi_search_batch(self._m, *args)
+
+    def counts(self, query):
+        raise NotImplementedError("raw counts are per shard: use shard(rank).counts(query)")
 
 
 class _DevArray:

@@ -371,6 +371,23 @@ cobs_gpu_status cobs_gpu_batch_phase_stamps(cobs_gpu_batch* b, uint64_t* out, si
  * this counts the replays (diagnostics; tuning key "graph" = 0 turns the path off). */
 uint64_t cobs_gpu_graph_replays(const cobs_gpu_index* ix);
 
+/* ---- multi-GPU, one process: a device list behind ONE handle -----------------------------------
+ * cobs_gpu_multi_open shards the index over devices[0..n_devices) (opts: hbm_budget_bytes and
+ * shard_mode are honoured per shard; device / shard_rank / shard_count are set by the library),
+ * starts one worker thread per device and joins them in an RCCL communicator;
+ * cobs_gpu_multi_search_batch is cobs_gpu_search_batch over all of them (same arguments, same
+ * result, same error behaviour; one call in flight per handle). */
+typedef struct cobs_gpu_multi cobs_gpu_multi;
+cobs_gpu_status cobs_gpu_multi_open(const char* const* paths, size_t n_paths, const int* devices, size_t n_devices,
+                                    const cobs_gpu_options* opts, cobs_gpu_multi** out);
+void cobs_gpu_multi_close(cobs_gpu_multi* m);
+size_t cobs_gpu_multi_size(const cobs_gpu_multi* m);                      /* ncclCommCount of its communicator */
+/* the shard handle of one rank (geometry; document names via cobs_gpu_doc_name work on any rank) */
+cobs_gpu_index* cobs_gpu_multi_index(const cobs_gpu_multi* m, size_t rank);
+cobs_gpu_status cobs_gpu_multi_search_batch(cobs_gpu_multi* m, const char* const* queries, const size_t* lens, size_t nq,
+                                            double threshold, size_t num_results, cobs_gpu_hit* hits, size_t cap,
+                                            size_t* hit_offsets, size_t* bad_query);
+
 /* phase timers of the host-buffer search API since the last reset, seconds:
  * out[0] hashes (K1), out[1] h2d, out[2] scan (K2), out[3] d2h, out[4] rank  */
 cobs_gpu_status cobs_gpu_timers(cobs_gpu_index* ix, double out[5], int reset);

@@ -129,3 +129,44 @@ def test_byte_balanced_shards_assemble_to_the_whole(gpu_lib, oracle, tmp_path, m
                     assert got == ref
             assert covered == len(want)
             assert np.array_equal(total, want)
+
+
+def test_multi_handle_device_list(gpu_lib, oracle, tmp_path):
+    """cobs_gpu_multi_*: the device list behind one handle of the C ABI (worker thread per device
+    and the communicator live inside the library).  On this box the list is [0]: one rank, the
+    same open / collective / close sequence as eight."""
+    from cobs_amd import _capi
+    paths, queries = _files(oracle, tmp_path)
+    ixs = [oracle.Index.open(p) for p in paths]
+    m = gpu_lib.MultiSearch(paths, devices=[0])
+    assert m.comm_size == 1 and m.num_files == 2
+    assert m.total_counts == sum(ix.counts(queries[0]).size for ix in ixs)
+    for t, lim in ((0.0, 0), (0.3, 0), (0.3, 4), (0.0, 6), (0.95, 0)):
+        assert m.search_hits(queries, t, lim) == [cases.oracle_results(ixs, q, t, lim) for q in queries], (t, lim)
+    # the reference's surface: names and scores of one query
+    res = m.search(queries[0], 0.3)
+    want = oracle.search(ixs, queries[0], 0.3)
+    assert [(r.doc_name, r.score) for r in res] == [(n, s) for (_, _, n, s) in want]
+    # errors come back from the worker with the query's index; the handle stays usable
+    bad = list(queries)
+    bad[1] = b"ACGT"
+    with pytest.raises(gpu_lib.CobsGpuError) as e:
+        m.search_hits(bad, 0.0, 3)
+    assert e.value.status == _capi.ERR_QUERY_TOO_SHORT
+    assert m.search_hits(queries[:2], 0.0, 2) == [cases.oracle_results(ixs, q, 0.0, 2) for q in queries[:2]]
+    assert m.search_hits([], 0.0, 0) == []
+    assert m.shard(0).info(0).slot_count == m.info(0).slot_count
+    m.close()
+    m.close()
+    # streamed shards under a budget
+    m = gpu_lib.MultiSearch(paths, devices=[0], hbm_budget=260 * 1024)
+    assert m.info(0).hbm_bytes <= 260 * 1024
+    assert m.search_hits(queries, 0.3, 0) == [cases.oracle_results(ixs, q, 0.3, 0) for q in queries]
+    del m
+    # everything that can fail on one rank alone is refused before the ranks would meet
+    for devs in ([0, 0], [0, 99], [-1], []):
+        with pytest.raises(gpu_lib.CobsGpuError) as e:
+            gpu_lib.MultiSearch(paths, devices=devs)
+        assert e.value.status == _capi.ERR_ARG
+    with pytest.raises(gpu_lib.CobsGpuError):
+        gpu_lib.MultiSearch(str(tmp_path / "missing.cobs_compact"), devices=[0])
