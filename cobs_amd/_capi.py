@@ -53,6 +53,12 @@ class BuildParams(C.Structure):
                 ("device", C.c_int32), ("text_batch_bytes", C.c_uint32), ("doc_terms", C.POINTER(C.c_uint64))]
 
 
+class DocEntry(C.Structure):
+    _fields_ = [("path", C.c_char_p), ("name", C.c_char_p), ("type", C.c_uint32), ("reserved", C.c_uint32),
+                ("size", C.c_uint64), ("subdoc_index", C.c_uint64), ("term_size", C.c_uint64),
+                ("term_count", C.c_uint64)]
+
+
 class Xfer(C.Structure):
     _fields_ = [("peer", C.c_uint64), ("send_offset", C.c_uint64), ("send_bytes", C.c_uint64),
                 ("recv_offset", C.c_uint64), ("recv_bytes", C.c_uint64)]
@@ -100,6 +106,20 @@ SYMBOLS = {
     "cobs_gpu_write_synthetic": (_int, [C.POINTER(Synth), _cp, _int]),
     "cobs_gpu_build_index": (_int, [_u32, C.POINTER(_cp), C.POINTER(_cp), C.POINTER(_sz), _sz,
                                     C.POINTER(BuildParams), C.POINTER(Options), C.POINTER(_vp)]),
+    "cobs_gpu_doclist_create": (_int, [C.POINTER(_vp)]),
+    "cobs_gpu_doclist_free": (None, [_vp]),
+    "cobs_gpu_doclist_add": (_int, [_vp, _cp]),
+    "cobs_gpu_doclist_add_recursive": (_int, [_vp, _cp, _u32]),
+    "cobs_gpu_doclist_add_memory": (_int, [_vp, _cp, _cp, _sz]),
+    "cobs_gpu_doclist_size": (_sz, [_vp]),
+    "cobs_gpu_doclist_entry": (_int, [_vp, _sz, C.POINTER(DocEntry)]),
+    "cobs_gpu_doclist_sort": (_int, [_vp, _u32]),
+    "cobs_gpu_doclist_num_terms": (_int, [_vp, _sz, _u32, C.POINTER(_u64)]),
+    "cobs_gpu_doclist_terms": (_int, [_vp, _sz, _u32, _vp, _sz, C.POINTER(_u64)]),
+    "cobs_gpu_filetype_from_string": (_int, [_cp, C.POINTER(_u32)]),
+    "cobs_gpu_build_classic_list": (_int, [_vp, C.POINTER(BuildParams), _cp]),
+    "cobs_gpu_build_compact_list": (_int, [_vp, C.POINTER(BuildParams), _cp]),
+    "cobs_gpu_build_index_list": (_int, [_u32, _vp, C.POINTER(BuildParams), C.POINTER(Options), C.POINTER(_vp)]),
     "cobs_gpu_combine_classic": (_int, [C.POINTER(_cp), _sz, _cp, _u64, _int]),
     "cobs_gpu_construct_random": (_int, [_cp, _u64, _u64, _u64, _u64, _u64, _int]),
     "cobs_gpu_search": (_int, [_vp, _cp, _sz, _dbl, _sz, C.POINTER(Hit), _sz, C.POINTER(_sz)]),

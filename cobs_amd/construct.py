@@ -1,170 +1,136 @@
-"""Host-side mirror of the reference's Python construction API (python/module.cpp:149-348):
-DocumentList, ClassicIndexParameters, CompactIndexParameters, classic_construct,
-compact_construct, disable_cache -- same names, arguments and defaults.  Parsing of
-FASTA input (plain or .gz) happens here on the host; hashing the terms and setting the
-signature bits happens on the GPU (cobs_gpu_build_classic / cobs_gpu_build_compact).
-
-Input scope: FASTA documents (.fa/.fasta/.fna/.ffn/.faa/.frn, optionally .gz) and
-in-memory documents; the reference's other parsers (FASTQ, McCortex, multi-FASTA, text,
-.cobs_doc) are out of scope (component 8).
+"""Host-side mirror of the reference's Python construction API (python/module.cpp:106-348):
+FileType, DocumentEntry, DocumentList, ClassicIndexParameters, CompactIndexParameters,
+classic_construct, compact_construct, their *_list variants, disable_cache -- same names,
+arguments and defaults.  The document list, the file readers (text, McCortex, .cobs_doc, FASTA,
+FASTQ, multi-FASTA; .gz where the reference reads it) and the ordering / sizing rules of
+classic_construct / compact_construct live in libcobs_gpu.so (cobs_amd/csrc/documents.cpp,
+build.cpp): host threads parse files while the GPU hashes the terms and sets the signature bits.
+This module only binds those entry points.
 """
 import ctypes as C
-import gzip
+import enum
 import os
 
 from . import _capi
 from ._capi import BuildParams, check
 
-_FASTA_EXT = (".fa", ".fasta", ".fna", ".ffn", ".faa", ".frn")
+
+class FileType(enum.IntEnum):
+    """cobs::FileType (document_list.hpp:35-54), values of COBS_GPU_FILETYPE_*"""
+    Any = 0
+    Text = 1
+    Cortex = 2
+    KMerBuffer = 3
+    Fasta = 4
+    Fastq = 5
+    FastaMulti = 6
+    FastqMulti = 7
+    List = 8
+    Memory = 9
+
+
+Any, Text, Cortex, KMerBuffer, Fasta, Fastq, FastaMulti, FastqMulti = (
+    FileType.Any, FileType.Text, FileType.Cortex, FileType.KMerBuffer, FileType.Fasta, FileType.Fastq,
+    FileType.FastaMulti, FileType.FastqMulti)            # py::enum_::export_values()
+
+
+def _filetype(ft):
+    if isinstance(ft, str):                                  # StringToFileType (document_list.cpp:15-32)
+        out = C.c_uint32(0)
+        check(_capi.load().cobs_gpu_filetype_from_string(ft.encode(), C.byref(out)))
+        return int(out.value)
+    return int(ft)
 
 
 def disable_cache(disable=True):
-    """The reference caches FASTA statistics in .cobs_cache files; this mirror never
-    writes caches, so this is a no-op kept for API compatibility (module.cpp:100-105)."""
+    """The reference caches document statistics in .cobs_cache files; this engine never writes
+    caches, so this is a no-op kept for API compatibility (module.cpp:100-105)."""
     return None
 
 
-def _is_fasta(path):
-    p = path[:-3] if path.endswith(".gz") else path
-    return p.endswith(_FASTA_EXT)
-
-
-def _base_name(path):
-    """cobs::base_name: file name cut at the first '.' (reference cobs/util/file.hpp:69-76)"""
-    return os.path.basename(path).split(".")[0]
-
-
-def _fasta_runs(lines, k):
-    """The character runs whose k-grams FastaFile::process_terms hashes (reference
-    cobs/fasta_file.hpp:155-182), including what its line buffer does at the edges: a run ends at
-    a comment ('>' ';') or empty line -- but the test looks at index `pos` of the buffer, which is
-    0 while the run so far is shorter than k (then a comment line is swallowed INTO the run) and
-    keeps its old value k-1 after a clear (then a line of exactly k-1 characters counts as empty).
-    Reads past the end of the buffer (undefined in the reference) are taken as sequence."""
-    runs, cur = [], bytearray()
-    held, pos = 0, 0             # held = characters of the run the reference still has in its buffer
-    for ln in lines:
-        size = held + len(ln)
-        if size == pos:
-            comment = True
-        elif pos < size:
-            ch = cur[len(cur) - held + pos] if pos < held else ln[pos - held]
-            comment = ch in b">;"
-        else:
-            comment = False
-        if comment:
-            if cur:
-                runs.append(bytes(cur))
-            cur, held = bytearray(), 0
-            continue
-        cur += ln
-        if size > k - 1:
-            held, pos = k - 1, k - 1
-        else:
-            held, pos = size, 0
-    if cur:
-        runs.append(bytes(cur))
-    return runs
-
-
-def _fasta_lines(path):
-    opener = gzip.open if path.endswith(".gz") else open
-    with opener(path, "rb") as f:
-        data = f.read()
-    lines = data.split(b"\n")
-    if lines and lines[-1] == b"":
-        lines.pop()
-    return lines
-
-
-def _read_fasta(path, k=31):
-    """-> (runs joined by newlines, size, number of terms).  The bits of a document come from
-    process_terms (the runs above); size = FastaFile::size() and the term count that sizes a
-    signature come from the file's index (compute_index / num_terms, fasta_file.hpp:53-91,
-    147-153): maximal runs of non-comment, non-empty lines."""
-    lines = _fasta_lines(path)
-    size = sum(len(ln) + 1 for ln in lines)
-    num_terms, run = 0, 0
-    for ln in lines[1:] + [b""]:
-        if len(ln) == 0 or ln[:1] in (b">", b";"):
-            num_terms += max(run - k + 1, 0)
-            run = 0
-        else:
-            run += len(ln)
-    return b"\n".join(_fasta_runs(lines, k)), size, num_terms
-
-
 class DocumentEntry:
-    """cobs::DocumentEntry (document_list.hpp:62-76) as far as construction needs it"""
+    """cobs::DocumentEntry (document_list.hpp:62-76): a view of one entry of a DocumentList"""
 
-    def __init__(self, path, name, size, text=None):
-        self.path = path
-        self.name = name
-        self.size = size
-        self.type = "fasta"
-        self._text = text            # in-memory documents: sequences joined by newlines
-        self._by_k = {}
-
-    def text(self, k=31):
-        """the character runs whose k-grams are hashed, joined by newlines"""
-        if self._text is not None:
-            return self._text
-        if k not in self._by_k:
-            t, _, n = _read_fasta(self.path, k)
-            self._by_k[k] = (t, n)
-        return self._by_k[k][0]
+    def __init__(self, owner, index):
+        e = _capi.DocEntry()
+        check(owner._lib.cobs_gpu_doclist_entry(owner._h, index, C.byref(e)))
+        self._owner, self._index = owner, index
+        self.path = os.fsdecode(e.path)
+        self.name = e.name.decode("latin-1")
+        self.type = FileType(e.type)
+        self.size = int(e.size)
+        self.subdoc_index = int(e.subdoc_index)
+        self.term_size = int(e.term_size)
+        self.term_count = int(e.term_count)
 
     def num_terms(self, k=31):
-        """FastaFile::num_terms(k): what sizes a signature (fasta_file.hpp:147-153)"""
-        if self._text is not None:
-            return sum(max(len(sq) - k + 1, 0) for sq in self._text.split(b"\n"))
-        self.text(k)
-        return self._by_k[k][1]
+        """DocumentEntry::num_terms(k) (:85-112): what sizes a signature"""
+        n = C.c_uint64(0)
+        check(self._owner._lib.cobs_gpu_doclist_num_terms(self._owner._h, self._index, k, C.byref(n)))
+        return int(n.value)
+
+    def terms(self, k=31):
+        """DocumentEntry::process_terms(k, callback) (:116-151): the terms in callback order"""
+        lib, h = self._owner._lib, self._owner._h
+        n = C.c_uint64(0)
+        check(lib.cobs_gpu_doclist_terms(h, self._index, k, None, 0, C.byref(n)))
+        buf = C.create_string_buffer(max(1, int(n.value) * k))
+        check(lib.cobs_gpu_doclist_terms(h, self._index, k, buf, int(n.value) * k, C.byref(n)))
+        raw = buf.raw
+        return [raw[i * k:(i + 1) * k] for i in range(int(n.value))]
+
+    def __repr__(self):
+        return "DocumentEntry(%r, %s, size=%d)" % (self.name, self.type.name, self.size)
 
 
 class DocumentList:
-    """cobs::DocumentList: a directory scan (recursive, sorted by path) or an explicit list"""
+    """cobs::DocumentList (document_list.hpp:154-411): a directory scan (recursive, sorted by path),
+    a .list file, single files, or in-memory documents"""
 
-    def __init__(self, root=None, file_type="any"):
-        self._list = []
+    def __init__(self, root=None, filter=FileType.Any, file_type=None):
+        self._lib = _capi.load()
+        self._h = C.c_void_p()
+        check(self._lib.cobs_gpu_doclist_create(C.byref(self._h)))
         if root is not None:
-            self.add_recursive(root, file_type)
+            self.add_recursive(root, file_type if file_type is not None else filter)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.cobs_gpu_doclist_free(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
 
     def size(self):
-        return len(self._list)
+        return int(self._lib.cobs_gpu_doclist_size(self._h))
 
     __len__ = size
 
     def __getitem__(self, i):
-        return self._list[i]
+        if not 0 <= i < self.size():
+            raise IndexError(i)
+        return DocumentEntry(self, i)
 
     def __iter__(self):
-        return iter(self._list)
+        return (DocumentEntry(self, i) for i in range(self.size()))
 
     def add(self, path):
-        size = sum(len(ln) + 1 for ln in _fasta_lines(path))
-        self._list.append(DocumentEntry(path, _base_name(path), size))
+        check(self._lib.cobs_gpu_doclist_add(self._h, os.fsencode(path)))
+
+    def add_recursive(self, path, filter=FileType.Any):
+        check(self._lib.cobs_gpu_doclist_add_recursive(self._h, os.fsencode(path), _filetype(filter)))
 
     def add_document(self, name, sequences):
-        """in-memory document: a name and its sequences (bytes)"""
+        """in-memory document: a name and its sequences (bytes); no reference counterpart"""
         text = b"\n".join(sequences)
-        self._list.append(DocumentEntry(name, name, len(text) + 1, text))
-
-    def add_recursive(self, root, file_type="any"):
-        if os.path.isfile(root):
-            self.add(root)
-        else:
-            for dirpath, _, files in os.walk(root):
-                for fn in files:
-                    if _is_fasta(fn):
-                        self.add(os.path.join(dirpath, fn))
-        self.sort_by_path()
+        check(self._lib.cobs_gpu_doclist_add_memory(self._h, name.encode("latin-1"), text, len(text)))
 
     def sort_by_path(self):
-        self._list.sort(key=lambda d: d.path)
+        check(self._lib.cobs_gpu_doclist_sort(self._h, 0))
 
     def sort_by_size(self):
-        self._list.sort(key=lambda d: (d.size, d.path))
+        check(self._lib.cobs_gpu_doclist_sort(self._h, 1))
 
 
 class ClassicIndexParameters:
@@ -216,30 +182,15 @@ def _check_output(out_file, ext, params):
         raise FileExistsError("Output file exists, will not overwrite without --clobber")
 
 
-def _build(fn, docs, params, out_file, device):
-    lib = _capi.load()
-    names = (C.c_char_p * len(docs))(*[d.name.encode() for d in docs])
-    k = params.term_size
-    texts = [d.text(k) for d in docs]
-    tarr = (C.c_char_p * len(docs))(*texts)
-    lens = (C.c_size_t * len(docs))(*[len(t) for t in texts])
-    b = _params(params, device)
-    # the term counts that size the signatures (the reference takes them from the documents'
-    # indexes, not from what process_terms later hashes)
-    terms = (C.c_uint64 * len(docs))(*[d.num_terms(k) for d in docs])
-    b.doc_terms = C.cast(terms, C.POINTER(C.c_uint64))
-    check(getattr(lib, fn)(names, tarr, lens, len(docs), C.byref(b), os.fsencode(out_file)))
-
-
 def classic_construct(input=None, out_file=None, index_params=None, file_type="any", tmp_path="",
                       list=None, device=-1):
-    """cobs_index.classic_construct (module.cpp:235-270): documents in path order, one
-    signature size from the largest document, file written in the reference's format"""
+    """cobs_index.classic_construct (module.cpp:235-270): documents in list order, one signature
+    size from the largest document, file written in the reference's format"""
     params = index_params or ClassicIndexParameters()
     docs = _as_list(list if list is not None else input, file_type)
     _check_output(out_file, ".cobs_classic", params)
-    ordered = sorted(docs, key=lambda d: d.path)
-    _build("cobs_gpu_build_classic", ordered, params, out_file, device)
+    b = _params(params, device)
+    check(_capi.load().cobs_gpu_build_classic_list(docs._h, C.byref(b), os.fsencode(out_file)))
 
 
 def compact_construct(input=None, out_file=None, index_params=None, file_type="any", tmp_path="",
@@ -249,22 +200,8 @@ def compact_construct(input=None, out_file=None, index_params=None, file_type="a
     params = index_params or CompactIndexParameters()
     docs = _as_list(list if list is not None else input, file_type)
     _check_output(out_file, ".cobs_compact", params)
-    ordered = sorted(docs, key=lambda d: (d.size, d.path))
-    page_size = params.page_size
-    if page_size == 0:      # compact_index.cpp:184-189
-        v = int((len(ordered) // 8) ** 0.5)
-        p2 = 1
-        while p2 < v:
-            p2 *= 2
-        page_size = min(max(p2 if v else 0, 8), 4096)
-    group = 8 * page_size
-    final = []
-    for g in range(0, len(ordered), group):
-        final.extend(sorted(ordered[g:g + group], key=lambda d: d.path))
-    fixed = CompactIndexParameters()
-    fixed.__dict__.update(params.__dict__)
-    fixed.page_size = page_size
-    _build("cobs_gpu_build_compact", final, fixed, out_file, device)
+    b = _params(params, device)
+    check(_capi.load().cobs_gpu_build_compact_list(docs._h, C.byref(b), os.fsencode(out_file)))
 
 
 def classic_construct_list(list, out_file, index_params=None, tmp_path="", device=-1):
@@ -278,7 +215,7 @@ def compact_construct_list(list, out_file, index_params=None, tmp_path="", devic
 
 
 def build_search(input=None, index_params=None, kind="classic", file_type="any", list=None, device=-1):
-    """classic_construct / compact_construct straight into a query handle (cobs_gpu_build_index):
+    """classic_construct / compact_construct straight into a query handle (cobs_gpu_build_index_list):
     the matrix is built in HBM at the engine's row pitch and searched where it lies -- no index
     file in between.  -> cobs_amd.Search"""
     from ._capi import Options
@@ -286,38 +223,12 @@ def build_search(input=None, index_params=None, kind="classic", file_type="any",
     compact = kind in (1, "compact")
     params = index_params or (CompactIndexParameters() if compact else ClassicIndexParameters())
     docs = _as_list(list if list is not None else input, file_type)
-    if compact:
-        ordered = sorted(docs, key=lambda d: (d.size, d.path))
-        page_size = getattr(params, "page_size", 0)
-        if page_size == 0:
-            v = int((len(ordered) // 8) ** 0.5)
-            p2 = 1
-            while p2 < v:
-                p2 *= 2
-            page_size = min(max(p2 if v else 0, 8), 4096)
-        final = []
-        for g in range(0, len(ordered), 8 * page_size):
-            final.extend(sorted(ordered[g:g + 8 * page_size], key=lambda d: d.path))
-        fixed = CompactIndexParameters()
-        fixed.__dict__.update(params.__dict__)
-        fixed.page_size = page_size
-        docs, params = final, fixed
-    else:
-        docs = sorted(docs, key=lambda d: d.path)
-    lib = _capi.load()
-    k = params.term_size
-    names = (C.c_char_p * len(docs))(*[d.name.encode() for d in docs])
-    texts = [d.text(k) for d in docs]
-    tarr = (C.c_char_p * len(docs))(*texts)
-    lens = (C.c_size_t * len(docs))(*[len(t) for t in texts])
     b = _params(params, device)
-    terms = (C.c_uint64 * len(docs))(*[d.num_terms(k) for d in docs])
-    b.doc_terms = C.cast(terms, C.POINTER(C.c_uint64))
     o = Options()
     o.struct_size = C.sizeof(Options)
     o.device = device
     h = C.c_void_p()
-    check(lib.cobs_gpu_build_index(1 if compact else 0, names, tarr, lens, len(docs), C.byref(b), C.byref(o), C.byref(h)))
+    check(_capi.load().cobs_gpu_build_index_list(1 if compact else 0, docs._h, C.byref(b), C.byref(o), C.byref(h)))
     return Search(None, _handle=h)
 
 
@@ -352,6 +263,6 @@ def write_synthetic(out_file, kind, signature_sizes, num_docs, page_size=0, term
     check(lib.cobs_gpu_write_synthetic(C.byref(d), os.fsencode(out_file), device))
 
 
-__all__ = ["write_synthetic", "build_search", "classic_combine", "classic_construct_random", "DocumentList", "DocumentEntry", "ClassicIndexParameters", "CompactIndexParameters",
+__all__ = ["write_synthetic", "build_search", "classic_combine", "classic_construct_random", "DocumentList", "DocumentEntry", "FileType", "ClassicIndexParameters", "CompactIndexParameters",
            "classic_construct", "classic_construct_list", "compact_construct", "compact_construct_list",
            "disable_cache"]

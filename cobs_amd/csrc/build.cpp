@@ -3,18 +3,24 @@
 // process_term / set_bit (cobs/construction/classic_index.cpp:40-130) and writes files in
 // the reference's formats (cobs/file/classic_index_header.cpp:26-37,
 // cobs/file/compact_index_header.cpp:20-43), so that `cobs query`, the reference's tests
-// and this engine can read them.  Document parsing (FASTA, ...) stays with the caller:
-// a document arrives as its sequences joined by '\n'.
+// and this engine can read them.  Documents come either already parsed (a document = its
+// sequences joined by '\n') or as a document list whose files the library reads itself
+// (documents.cpp): host threads parse the next window of documents into a pinned staging buffer
+// while the GPU hashes the previous one.
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
+#include <tuple>
 #include <vector>
 
+#include "documents.hpp"
 #include "engine.hpp"
 
 using namespace cobs_amd;
@@ -102,65 +108,201 @@ cobs_gpu_status pick_device(int device) {
     return COBS_GPU_OK;
 }
 
-// Documents reach the device in batches of at most this many text bytes (the reference batches
-// documents by a memory budget too: classic_index.cpp:565-659 builds one small index per batch
-// and interleaves them afterwards; here every batch sets its bits straight at the documents'
+// ---- where the documents come from ---------------------------------------------------------------
+struct DocSource {
+    virtual ~DocSource() = default;
+    virtual size_t size() const = 0;
+    virtual const char* name(size_t d) const = 0;
+    virtual uint64_t terms(size_t d, uint32_t k) const = 0;          // what sizes a signature
+    virtual uint64_t bytes_hint(size_t d) const = 0;                 // rough term-text size, to cut windows
+    virtual bool parses() const = 0;                                 // loading reads and parses files
+    virtual cobs_gpu_status load(size_t d, uint32_t k, std::string& text, std::vector<TermSeg>& segs) const = 0;
+};
+
+// documents handed over as texts (cobs_gpu_build_classic / _compact / _index)
+struct ArraySource final : DocSource {
+    const char* const* names;
+    const char* const* texts;
+    const size_t* lens;
+    size_t n;
+    const uint64_t* doc_terms;
+    ArraySource(const char* const* nm, const char* const* tx, const size_t* ln, size_t nd, const uint64_t* dt)
+        : names(nm), texts(tx), lens(ln), n(nd), doc_terms(dt) {}
+    size_t size() const override { return n; }
+    const char* name(size_t d) const override { return names[d]; }
+    uint64_t terms(size_t d, uint32_t k) const override { return doc_terms ? doc_terms[d] : count_terms(texts[d], lens[d], k); }
+    uint64_t bytes_hint(size_t d) const override { return lens[d] + 1; }
+    bool parses() const override { return false; }
+    cobs_gpu_status load(size_t d, uint32_t, std::string& text, std::vector<TermSeg>& segs) const override {
+        const uint64_t begin = text.size();
+        text.append(texts[d], lens[d]);
+        text.push_back('\n');
+        segs.push_back(TermSeg{begin, (uint64_t)lens[d] + 1, false});
+        return COBS_GPU_OK;
+    }
+};
+
+// a document list (cobs_gpu_build_*_list)
+struct ListSource final : DocSource {
+    const std::vector<DocEntry>& list;
+    explicit ListSource(const std::vector<DocEntry>& l) : list(l) {}
+    size_t size() const override { return list.size(); }
+    const char* name(size_t d) const override { return list[d].name.c_str(); }
+    uint64_t terms(size_t d, uint32_t k) const override { return num_terms(list[d], k); }
+    uint64_t bytes_hint(size_t d) const override {
+        const DocEntry& e = list[d];
+        if (e.type == FileType::Cortex || e.type == FileType::KMerBuffer) return e.term_count * (e.term_size + 1);
+        if (e.type == FileType::Memory) return e.text.size() + 1;
+        return e.size + 1;
+    }
+    bool parses() const override { return true; }
+    cobs_gpu_status load(size_t d, uint32_t k, std::string& text, std::vector<TermSeg>& segs) const override {
+        return load_terms(list[d], k, text, segs);
+    }
+};
+
+// Documents reach the device in batches of at most this many bytes of term text (the reference
+// batches documents by a memory budget too: classic_index.cpp:565-659 builds one small index per
+// batch and interleaves them afterwards; here every batch sets its bits straight at the documents'
 // final columns of the one matrix in HBM, so there is nothing to combine).
 constexpr uint64_t kTextBatchBytes = 256ull << 20;
+constexpr size_t kWindowDocs = 1024;            // documents parsed together by the host threads
+constexpr size_t kTextPad = 64;                 // readable bytes behind the text (build_kernel loads dwords)
 
-// Set the bits of documents [d0, d1) -- columns doc_bit0 + (d - d0) -- in a zeroed device matrix of
-// `sig` rows, `row_bytes` (multiple of 4) apart.
-cobs_gpu_status build_into(uint32_t* d_matrix, uint64_t sig, uint64_t row_bytes, const char* const* texts,
-                           const size_t* lens, size_t d0, size_t d1, uint32_t doc_bit0, const Params& pr) {
+struct Loaded {
+    std::string text;
+    std::vector<TermSeg> segs;
+    cobs_gpu_status status = COBS_GPU_OK;
+    std::string error;
+};
+
+// one of the two staging sets: pinned text + stretch tables, their device copies, the event that
+// tells when the GPU is done with them
+struct Stage {
+    PinnedBuf<uint8_t> text;
+    PinnedBuf<uint64_t> seg_off;
+    PinnedBuf<uint32_t> seg_col;
+    DevBuf<uint8_t> d_text;
+    DevBuf<uint64_t> d_off;
+    DevBuf<uint32_t> d_col;
+    size_t fill = 0, nsegs = 0;
+    hipEvent_t done = nullptr;
+    bool busy = false;
+    ~Stage() { if (done) (void)hipEventDestroy(done); }
+};
+
+// Set the bits of documents docs[0..n) -- document docs[i] in column i -- in a zeroed device
+// matrix of `sig` rows, `row_bytes` (multiple of 4) apart.
+cobs_gpu_status build_into(uint32_t* d_matrix, uint64_t sig, uint64_t row_bytes, const DocSource& src,
+                           const size_t* docs, size_t n, const Params& pr) {
     const uint64_t text_batch = pr.text_batch ? pr.text_batch : kTextBatchBytes;
     if (sig == 0 || sig > (1ull << 46)) return cobs_gpu_set_error(COBS_GPU_ERR_UNSUPPORTED, "signature_size must be in 1..2^46");
-    DevMem d_text, d_off;
-    size_t text_cap = 0, off_cap = 0;
-    std::vector<uint8_t> text;
-    std::vector<uint64_t> off;
-    for (size_t b0 = d0; b0 < d1;) {
-        // documents [b0, b1): as many as fit the batch (at least one)
-        size_t b1 = b0;
-        uint64_t total = 0;
-        while (b1 < d1 && (b1 == b0 || total + lens[b1] + 1 <= text_batch)) total += lens[b1++] + 1;
-        off.assign(b1 - b0 + 1, 0);
-        text.resize((size_t)total);
-        uint64_t pos = 0;
-        for (size_t d = b0; d < b1; ++d) {
-            off[d - b0] = pos;
-            std::memcpy(text.data() + pos, texts[d], lens[d]);
-            text[(size_t)(pos + lens[d])] = '\n';          // every document is followed by a separator
-            pos += lens[d] + 1;
-        }
-        off[b1 - b0] = pos;
-        if (total > text_cap) {
-            if (d_text.p) { (void)hipFree(d_text.p); d_text.p = nullptr; }
-            BUILD_TRY(hipMalloc(&d_text.p, (size_t)total));
-            text_cap = (size_t)total;
-        }
-        if (off.size() > off_cap) {
-            if (d_off.p) { (void)hipFree(d_off.p); d_off.p = nullptr; }
-            BUILD_TRY(hipMalloc(&d_off.p, off.size() * 8));
-            off_cap = off.size();
-        }
-        if (total) BUILD_TRY(hipMemcpy(d_text.p, text.data(), (size_t)total, hipMemcpyHostToDevice));
-        BUILD_TRY(hipMemcpy(d_off.p, off.data(), off.size() * 8, hipMemcpyHostToDevice));
+    if (n >= kBuildRawStretch) return cobs_gpu_set_error(COBS_GPU_ERR_UNSUPPORTED, "too many documents in one matrix");
+    hipStream_t stream = nullptr;
+    BUILD_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } } sg{stream};
+    Stage stage[2];
+    for (Stage& s : stage) BUILD_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    int cur = 0;
+
+    auto begin = [&](Stage& s) -> cobs_gpu_status {
+        if (s.busy) { BUILD_TRY(hipEventSynchronize(s.done)); s.busy = false; }
+        s.fill = 0;
+        s.nsegs = 0;
+        return COBS_GPU_OK;
+    };
+    auto flush = [&](Stage& s) -> cobs_gpu_status {
+        if (s.fill == 0) return COBS_GPU_OK;
+        s.seg_off.p[s.nsegs] = s.fill;
+        BUILD_TRY(s.d_text.reserve(s.text.cap + kTextPad));
+        BUILD_TRY(s.d_off.reserve(s.seg_off.cap));
+        BUILD_TRY(s.d_col.reserve(s.seg_col.cap));
+        BUILD_TRY(hipMemcpyAsync(s.d_text.p, s.text.p, s.fill, hipMemcpyHostToDevice, stream));
+        BUILD_TRY(hipMemcpyAsync(s.d_off.p, s.seg_off.p, (s.nsegs + 1) * 8, hipMemcpyHostToDevice, stream));
+        BUILD_TRY(hipMemcpyAsync(s.d_col.p, s.seg_col.p, s.nsegs * 4, hipMemcpyHostToDevice, stream));
         BuildArgs a;
-        a.text = (const uint8_t*)d_text.p;
-        a.doc_off = (const uint64_t*)d_off.p;
+        a.text = s.d_text.p;
+        a.seg_off = s.d_off.p;
+        a.seg_col = s.d_col.p;
         a.matrix = d_matrix;
         a.signature_size = sig;
         a.magic = ~0ull / sig;
         a.row_bytes = row_bytes;
-        a.ndocs = (uint32_t)(b1 - b0);
-        a.doc_bit0 = doc_bit0 + (uint32_t)(b0 - d0);
+        a.nsegs = (uint32_t)s.nsegs;
         a.term_size = pr.term_size;
         a.canonicalize = pr.canonicalize;
         a.num_hashes = pr.num_hashes;
-        BUILD_TRY(launch_build(a, total, nullptr));
-        BUILD_TRY(hipStreamSynchronize(nullptr));
-        b0 = b1;
+        BUILD_TRY(launch_build(a, s.fill, stream));
+        BUILD_TRY(hipEventRecord(s.done, stream));
+        s.busy = true;
+        return COBS_GPU_OK;
+    };
+    // grow-only pinned arrays that keep their content
+    auto grow = [&](auto& buf, size_t need, size_t used) -> cobs_gpu_status {
+        if (need <= buf.cap) return COBS_GPU_OK;
+        std::remove_reference_t<decltype(buf)> bigger;
+        BUILD_TRY(bigger.reserve(std::max(need, buf.cap * 2)));
+        if (used) std::memcpy(bigger.p, buf.p, used * sizeof(*buf.p));
+        std::swap(buf.p, bigger.p);
+        std::swap(buf.cap, bigger.cap);
+        return COBS_GPU_OK;
+    };
+
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t max_threads = src.parses() ? std::min<size_t>(hw, 64) : 1;
+    std::vector<Loaded> window;
+    cobs_gpu_status st = begin(stage[cur]);
+    if (st != COBS_GPU_OK) return st;
+    for (size_t w0 = 0; w0 < n;) {
+        // the next window: documents whose term text adds up to about one batch
+        size_t w1 = w0;
+        uint64_t hint = 0;
+        while (w1 < n && w1 - w0 < kWindowDocs && (w1 == w0 || hint + src.bytes_hint(docs[w1]) <= text_batch))
+            hint += src.bytes_hint(docs[w1++]);
+        window.assign(w1 - w0, Loaded{});
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (size_t i; (i = next.fetch_add(1)) < window.size();) {
+                Loaded& l = window[i];
+                l.status = src.load(docs[w0 + i], pr.term_size, l.text, l.segs);
+                if (l.status != COBS_GPU_OK) l.error = cobs_gpu_last_error();
+            }
+        };
+        const size_t nthreads = std::min(max_threads, window.size());
+        if (nthreads <= 1) {
+            work();
+        } else {
+            std::vector<std::thread> pool;
+            for (size_t t = 0; t < nthreads; ++t) pool.emplace_back(work);
+            for (auto& t : pool) t.join();
+        }
+        for (size_t i = 0; i < window.size(); ++i) {
+            Loaded& l = window[i];
+            if (l.status != COBS_GPU_OK) return cobs_gpu_set_error(l.status, l.error.c_str());
+            Stage* s = &stage[cur];
+            if (s->fill > 0 && s->fill + l.text.size() > text_batch) {
+                if ((st = flush(*s)) != COBS_GPU_OK) return st;
+                cur ^= 1;
+                s = &stage[cur];
+                if ((st = begin(*s)) != COBS_GPU_OK) return st;
+            }
+            if ((st = grow(s->text, s->fill + l.text.size() + 1, s->fill)) != COBS_GPU_OK) return st;
+            if ((st = grow(s->seg_off, s->nsegs + l.segs.size() + 1, s->nsegs)) != COBS_GPU_OK) return st;
+            if ((st = grow(s->seg_col, s->nsegs + l.segs.size() + 1, s->nsegs)) != COBS_GPU_OK) return st;
+            std::memcpy(s->text.p + s->fill, l.text.data(), l.text.size());
+            for (const TermSeg& g : l.segs) {
+                if (g.len == 0) continue;
+                s->seg_off.p[s->nsegs] = s->fill + g.begin;
+                s->seg_col.p[s->nsegs] = (uint32_t)(w0 + i) | (g.raw ? kBuildRawStretch : 0u);
+                ++s->nsegs;
+            }
+            s->fill += l.text.size();
+            std::string().swap(l.text);
+        }
+        w0 = w1;
     }
+    if ((st = flush(stage[cur])) != COBS_GPU_OK) return st;
+    BUILD_TRY(hipStreamSynchronize(stream));
     return COBS_GPU_OK;
 }
 
@@ -198,6 +340,222 @@ bool write_all(FILE* f, const void* p, size_t n) { return n == 0 || std::fwrite(
 template <typename T>
 void put(std::string& s, T v) { s.append(reinterpret_cast<const char*>(&v), sizeof v); }
 
+// ---- the layout of an index: which documents, in which order, in which sub-index -----------------
+struct Group {
+    std::vector<size_t> docs;       // source documents in column order
+    uint64_t sig = 0;
+};
+struct Layout {
+    bool compact = false;
+    uint64_t page_size = 0;         // compact only
+    std::vector<Group> groups;      // classic: one
+};
+
+uint64_t default_page_size(size_t ndocs) {      // compact_construct, compact_index.cpp:184-189
+    const uint64_t v = (uint64_t)std::sqrt((double)(ndocs / 8));
+    uint64_t p2 = 1;
+    while (p2 < v) p2 <<= 1;
+    return std::min<uint64_t>(std::max<uint64_t>(v == 0 ? 0 : p2, 8), 4096);
+}
+
+// documents already in their final order (the array entry points)
+cobs_gpu_status layout_in_order(const DocSource& src, bool compact, const Params& pr, Layout& out) {
+    const size_t n = src.size();
+    out.compact = compact;
+    if (!compact) {
+        Group g;
+        uint64_t max_terms = 0;
+        for (size_t d = 0; d < n; ++d) {
+            g.docs.push_back(d);
+            if (pr.signature_size == 0) max_terms = std::max(max_terms, src.terms(d, pr.term_size));
+        }
+        // classic_construct, classic_index.cpp:571-575 (the caller's doc_terms name the largest document)
+        g.sig = pr.signature_size ? pr.signature_size : signature_size_for(max_terms, (double)pr.num_hashes, pr.fpr);
+        if (g.sig == 0) return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "documents hold no terms");
+        out.groups.push_back(std::move(g));
+        return COBS_GPU_OK;
+    }
+    out.page_size = pr.page_size ? pr.page_size : default_page_size(n);
+    const size_t per = (size_t)(8 * out.page_size);
+    for (size_t g0 = 0; g0 < n; g0 += per) {
+        Group g;
+        uint64_t max_terms = 0;
+        for (size_t d = g0; d < std::min(n, g0 + per); ++d) {
+            g.docs.push_back(d);
+            max_terms = std::max(max_terms, src.terms(d, pr.term_size));
+        }
+        if (max_terms == 0) continue;                           // compact_index.cpp:285-286: empty group is dropped
+        g.sig = pr.signature_size ? pr.signature_size : signature_size_for(max_terms, (double)pr.num_hashes, pr.fpr);
+        out.groups.push_back(std::move(g));
+    }
+    if (out.groups.empty()) return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "documents hold no terms");
+    return COBS_GPU_OK;
+}
+
+// a document list, ordered and sized the way classic_construct / compact_construct do it
+cobs_gpu_status layout_of_list(const std::vector<DocEntry>& list, bool compact, const Params& pr, Layout& out) {
+    const size_t n = list.size();
+    out.compact = compact;
+    if (!compact) {
+        Group g;
+        for (size_t d = 0; d < n; ++d) g.docs.push_back(d);     // list order (process_batches_parallel, document_list.hpp:475-514)
+        g.sig = pr.signature_size;
+        if (g.sig == 0) {
+            // get_max_file_size, classic_index.cpp:521-563: the num_terms of the largest document by
+            // (size, path) -- std::max_element, the first of equals
+            size_t big = 0;
+            for (size_t d = 1; d < n; ++d)
+                if (std::tie(list[big].size, list[big].path) < std::tie(list[d].size, list[d].path)) big = d;
+            g.sig = signature_size_for(num_terms(list[big], pr.term_size), (double)pr.num_hashes, pr.fpr);
+        }
+        if (g.sig == 0) return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "documents hold no terms");
+        out.groups.push_back(std::move(g));
+        return COBS_GPU_OK;
+    }
+    std::vector<size_t> order(n);
+    for (size_t d = 0; d < n; ++d) order[d] = d;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {      // sort_by_size, compact_index.cpp:182
+        return std::tie(list[a].size, list[a].path) < std::tie(list[b].size, list[b].path);
+    });
+    out.page_size = pr.page_size ? pr.page_size : default_page_size(n);
+    const size_t per = (size_t)(8 * out.page_size);
+    for (size_t g0 = 0; g0 < n; g0 += per) {
+        Group g;
+        g.docs.assign(order.begin() + g0, order.begin() + std::min(n, g0 + per));
+        // DocumentList batch_list(files), compact_index.cpp:315: sorted by (path, sub-document)
+        std::stable_sort(g.docs.begin(), g.docs.end(), [&](size_t a, size_t b) {
+            return std::tie(list[a].path, list[a].subdoc_index) < std::tie(list[b].path, list[b].subdoc_index);
+        });
+        uint64_t max_terms = 0;
+        for (size_t d : g.docs) max_terms = std::max(max_terms, num_terms(list[d], pr.term_size));
+        if (max_terms == 0) continue;                           // :285-286
+        g.sig = pr.signature_size ? pr.signature_size : signature_size_for(max_terms, (double)pr.num_hashes, pr.fpr);
+        out.groups.push_back(std::move(g));
+    }
+    if (out.groups.empty()) return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "documents hold no terms");
+    return COBS_GPU_OK;
+}
+
+// ---- layout + source -> index file ---------------------------------------------------------------
+cobs_gpu_status write_index_file(const DocSource& src, const Layout& lay, const Params& pr, const char* out_path) {
+    std::string h;
+    uint64_t row_size, row_bytes;
+    if (!lay.compact) {
+        const Group& g = lay.groups[0];
+        h = "COBS:CLASSIC_INDEX";
+        put<uint32_t>(h, 1);
+        put<uint32_t>(h, pr.term_size);
+        put<uint8_t>(h, (uint8_t)pr.canonicalize);
+        put<uint32_t>(h, (uint32_t)g.docs.size());
+        put<uint64_t>(h, g.sig);
+        put<uint64_t>(h, (uint64_t)pr.num_hashes);
+        for (size_t d : g.docs) { h += src.name(d); h += '\n'; }
+        h += "CLASSIC_INDEX";
+        row_size = (g.docs.size() + 7) / 8;
+    } else {
+        const uint64_t ps = lay.page_size;
+        size_t kept = 0;
+        for (const Group& g : lay.groups) kept += g.docs.size();
+        h = "COBS:COMPACT_INDEX";
+        put<uint32_t>(h, 1);
+        put<uint32_t>(h, pr.term_size);
+        put<uint8_t>(h, (uint8_t)pr.canonicalize);
+        put<uint32_t>(h, (uint32_t)lay.groups.size());
+        put<uint32_t>(h, (uint32_t)kept);
+        put<uint64_t>(h, ps);
+        for (const Group& g : lay.groups) { put<uint64_t>(h, g.sig); put<uint64_t>(h, (uint64_t)pr.num_hashes); }
+        for (const Group& g : lay.groups)
+            for (size_t d : g.docs) { h += src.name(d); h += '\n'; }
+        const uint64_t pad = (ps - ((h.size() + 13) % ps)) % ps;     // data starts page-aligned
+        h.append((size_t)pad, '\0');
+        h += "COMPACT_INDEX";
+        row_size = ps;                                               // rows padded to page_size (:116-156)
+    }
+    row_bytes = (row_size + 3) / 4 * 4;
+    FILE* f = std::fopen(out_path, "wb");
+    if (!f) return cobs_gpu_set_error(COBS_GPU_ERR_OPEN, (std::string("could not create ") + out_path).c_str());
+    struct Closer { FILE* f; ~Closer() { if (f) std::fclose(f); } } closer{f};
+    if (!write_all(f, h.data(), h.size())) return cobs_gpu_set_error(COBS_GPU_ERR_OPEN, "short write");
+    // one (sub-)index after the other: built in HBM (288 GB; never in host RAM), streamed out
+    for (const Group& g : lay.groups) {
+        DevMem d_mat;
+        BUILD_TRY(hipMalloc(&d_mat.p, (size_t)(g.sig * row_bytes)));
+        BUILD_TRY(hipMemset(d_mat.p, 0, (size_t)(g.sig * row_bytes)));
+        cobs_gpu_status st = build_into((uint32_t*)d_mat.p, g.sig, row_bytes, src, g.docs.data(), g.docs.size(), pr);
+        if (st != COBS_GPU_OK) return st;
+        st = stream_rows_to_file(f, (const uint8_t*)d_mat.p, row_bytes, row_size, g.sig);
+        if (st != COBS_GPU_OK) return st;
+    }
+    closer.f = nullptr;
+    if (std::fclose(f) != 0) return cobs_gpu_set_error(COBS_GPU_ERR_OPEN, "short write");
+    return COBS_GPU_OK;
+}
+
+// ---- layout + source -> resident query handle ------------------------------------------------------
+cobs_gpu_status build_resident(const DocSource& src, const Layout& lay, const Params& pr, const cobs_gpu_options* opts,
+                               cobs_gpu_index** out) {
+    IndexMeta meta;
+    meta.kind = lay.compact ? IndexKind::Compact : IndexKind::Classic;
+    meta.term_size = pr.term_size;
+    meta.canonicalize = (uint8_t)pr.canonicalize;
+    meta.num_hashes = pr.num_hashes;
+    if (lay.compact) meta.header_page_size = lay.page_size;
+    for (const Group& g : lay.groups) {
+        meta.signature_sizes.push_back(g.sig);
+        for (size_t d : g.docs) meta.doc_names.emplace_back(src.name(d));
+    }
+    cobs_gpu_options o{};
+    if (opts) std::memcpy(&o, opts, std::min<size_t>(opts->struct_size, sizeof o));
+    o.struct_size = sizeof o;
+    if (pr.device >= 0) o.device = pr.device;
+    else if (!opts) o.device = -1;
+    cobs_gpu_index* ix = nullptr;
+    cobs_gpu_status st = open_zeroed(std::move(meta), &o, &ix);
+    if (st != COBS_GPU_OK) return st;
+    std::unique_ptr<cobs_gpu_index, void (*)(cobs_gpu_index*)> guard(ix, cobs_gpu_close);
+    Part& pt = ix->parts[0];
+    for (Chunk& c : pt.chunks)
+        for (size_t i = 0; i < c.vp.size(); ++i) {
+            const Group& g = lay.groups[c.vp[i].fp];
+            st = build_into(reinterpret_cast<uint32_t*>(c.d_data + c.pages[i].base), c.pages[i].sig, c.pitch, src,
+                            g.docs.data(), g.docs.size(), pr);
+            if (st != COBS_GPU_OK) return st;
+        }
+    *out = guard.release();
+    return COBS_GPU_OK;
+}
+
+cobs_gpu_status build_from_arrays(bool compact, const char* const* names, const char* const* texts, const size_t* lens,
+                                  size_t ndocs, const cobs_gpu_build_params* params, const char* out_path,
+                                  const cobs_gpu_options* opts, cobs_gpu_index** out) {
+    return guarded([&]() -> cobs_gpu_status {
+        Params pr;
+        cobs_gpu_status st = read_params(params, pr);
+        if (st != COBS_GPU_OK) return st;
+        ArraySource src(names, texts, lens, ndocs, pr.doc_terms);
+        Layout lay;
+        if ((st = layout_in_order(src, compact, pr, lay)) != COBS_GPU_OK) return st;
+        if (out) return build_resident(src, lay, pr, opts, out);
+        if ((st = pick_device(pr.device)) != COBS_GPU_OK) return st;
+        return write_index_file(src, lay, pr, out_path);
+    });
+}
+
+cobs_gpu_status build_from_list(bool compact, const cobs_gpu_doclist* dl, const cobs_gpu_build_params* params,
+                                const char* out_path, const cobs_gpu_options* opts, cobs_gpu_index** out) {
+    return guarded([&]() -> cobs_gpu_status {
+        Params pr;
+        cobs_gpu_status st = read_params(params, pr);
+        if (st != COBS_GPU_OK) return st;
+        ListSource src(dl->list);
+        Layout lay;
+        if ((st = layout_of_list(dl->list, compact, pr, lay)) != COBS_GPU_OK) return st;
+        if (out) return build_resident(src, lay, pr, opts, out);
+        if ((st = pick_device(pr.device)) != COBS_GPU_OK) return st;
+        return write_index_file(src, lay, pr, out_path);
+    });
+}
+
 }  // namespace
 
 extern "C" {
@@ -206,108 +564,14 @@ cobs_gpu_status cobs_gpu_build_classic(const char* const* names, const char* con
                                        size_t ndocs, const cobs_gpu_build_params* params, const char* out_path) {
     if (!names || !texts || !lens || !out_path || ndocs == 0)
         return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "NULL argument or no documents");
-    Params pr;
-    cobs_gpu_status st = read_params(params, pr);
-    if (st != COBS_GPU_OK) return st;
-    st = pick_device(pr.device);
-    if (st != COBS_GPU_OK) return st;
-    uint64_t sig = pr.signature_size;
-    if (sig == 0) {     // classic_construct, classic_index.cpp:571-575: sized by the largest document
-        uint64_t max_terms = 0;
-        for (size_t d = 0; d < ndocs; ++d)
-            max_terms = std::max(max_terms, pr.doc_terms ? pr.doc_terms[d] : count_terms(texts[d], lens[d], pr.term_size));
-        sig = signature_size_for(max_terms, (double)pr.num_hashes, pr.fpr);
-    }
-    if (sig == 0) return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "documents hold no terms");
-    const uint64_t row_size = (ndocs + 7) / 8;
-    const uint64_t row_bytes = (row_size + 3) / 4 * 4;
-    DevMem d_mat;                                   // the whole matrix lives in HBM (288 GB), never in host RAM
-    BUILD_TRY(hipMalloc(&d_mat.p, (size_t)(sig * row_bytes)));
-    BUILD_TRY(hipMemset(d_mat.p, 0, (size_t)(sig * row_bytes)));
-    st = build_into((uint32_t*)d_mat.p, sig, row_bytes, texts, lens, 0, ndocs, 0, pr);
-    if (st != COBS_GPU_OK) return st;
-    std::string h = "COBS:CLASSIC_INDEX";
-    put<uint32_t>(h, 1);
-    put<uint32_t>(h, pr.term_size);
-    put<uint8_t>(h, (uint8_t)pr.canonicalize);
-    put<uint32_t>(h, (uint32_t)ndocs);
-    put<uint64_t>(h, sig);
-    put<uint64_t>(h, (uint64_t)pr.num_hashes);
-    for (size_t d = 0; d < ndocs; ++d) { h += names[d]; h += '\n'; }
-    h += "CLASSIC_INDEX";
-    FILE* f = std::fopen(out_path, "wb");
-    if (!f) return cobs_gpu_set_error(COBS_GPU_ERR_OPEN, (std::string("could not create ") + out_path).c_str());
-    struct Closer { FILE* f; ~Closer() { if (f) std::fclose(f); } } closer{f};
-    if (!write_all(f, h.data(), h.size())) return cobs_gpu_set_error(COBS_GPU_ERR_OPEN, "short write");
-    st = stream_rows_to_file(f, (const uint8_t*)d_mat.p, row_bytes, row_size, sig);
-    if (st != COBS_GPU_OK) return st;
-    closer.f = nullptr;
-    if (std::fclose(f) != 0) return cobs_gpu_set_error(COBS_GPU_ERR_OPEN, "short write");
-    return COBS_GPU_OK;
+    return build_from_arrays(false, names, texts, lens, ndocs, params, out_path, nullptr, nullptr);
 }
 
 cobs_gpu_status cobs_gpu_build_compact(const char* const* names, const char* const* texts, const size_t* lens,
                                        size_t ndocs, const cobs_gpu_build_params* params, const char* out_path) {
     if (!names || !texts || !lens || !out_path || ndocs == 0)
         return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "NULL argument or no documents");
-    Params pr;
-    cobs_gpu_status st = read_params(params, pr);
-    if (st != COBS_GPU_OK) return st;
-    st = pick_device(pr.device);
-    if (st != COBS_GPU_OK) return st;
-    uint64_t ps = pr.page_size;
-    if (ps == 0) {      // compact_construct, compact_index.cpp:184-189
-        const uint64_t v = (uint64_t)std::sqrt((double)(ndocs / 8));
-        uint64_t p2 = 1;
-        while (p2 < v) p2 <<= 1;
-        ps = std::min<uint64_t>(std::max<uint64_t>(v == 0 ? 0 : p2, 8), 4096);
-    }
-    const size_t group = (size_t)(8 * ps);
-    struct Group { size_t g0, g1; uint64_t sig; };
-    std::vector<Group> groups;
-    std::vector<size_t> kept;                                   // documents that made it into the file
-    for (size_t g0 = 0; g0 < ndocs; g0 += group) {
-        const size_t g1 = std::min(ndocs, g0 + group);
-        uint64_t max_terms = 0;
-        for (size_t d = g0; d < g1; ++d)
-            max_terms = std::max(max_terms, pr.doc_terms ? pr.doc_terms[d] : count_terms(texts[d], lens[d], pr.term_size));
-        if (max_terms == 0) continue;                           // compact_index.cpp:285-286: empty group is dropped
-        const uint64_t sig = pr.signature_size ? pr.signature_size
-                                               : signature_size_for(max_terms, (double)pr.num_hashes, pr.fpr);
-        groups.push_back(Group{g0, g1, sig});
-        for (size_t d = g0; d < g1; ++d) kept.push_back(d);
-    }
-    if (groups.empty()) return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "documents hold no terms");
-    std::string h = "COBS:COMPACT_INDEX";
-    put<uint32_t>(h, 1);
-    put<uint32_t>(h, pr.term_size);
-    put<uint8_t>(h, (uint8_t)pr.canonicalize);
-    put<uint32_t>(h, (uint32_t)groups.size());
-    put<uint32_t>(h, (uint32_t)kept.size());
-    put<uint64_t>(h, ps);
-    for (auto& g : groups) { put<uint64_t>(h, g.sig); put<uint64_t>(h, (uint64_t)pr.num_hashes); }
-    for (size_t d : kept) { h += names[d]; h += '\n'; }
-    const uint64_t pad = (ps - ((h.size() + 13) % ps)) % ps;     // data starts page-aligned
-    h.append((size_t)pad, '\0');
-    h += "COMPACT_INDEX";
-    FILE* f = std::fopen(out_path, "wb");
-    if (!f) return cobs_gpu_set_error(COBS_GPU_ERR_OPEN, (std::string("could not create ") + out_path).c_str());
-    struct Closer { FILE* f; ~Closer() { if (f) std::fclose(f); } } closer{f};
-    if (!write_all(f, h.data(), h.size())) return cobs_gpu_set_error(COBS_GPU_ERR_OPEN, "short write");
-    // one sub-index after the other: built in HBM (rows padded to page_size, :116-156), streamed out
-    const uint64_t row_bytes = (ps + 3) / 4 * 4;
-    for (auto& g : groups) {
-        DevMem d_mat;
-        BUILD_TRY(hipMalloc(&d_mat.p, (size_t)(g.sig * row_bytes)));
-        BUILD_TRY(hipMemset(d_mat.p, 0, (size_t)(g.sig * row_bytes)));
-        st = build_into((uint32_t*)d_mat.p, g.sig, row_bytes, texts, lens, g.g0, g.g1, 0, pr);
-        if (st != COBS_GPU_OK) return st;
-        st = stream_rows_to_file(f, (const uint8_t*)d_mat.p, row_bytes, ps, g.sig);
-        if (st != COBS_GPU_OK) return st;
-    }
-    closer.f = nullptr;
-    if (std::fclose(f) != 0) return cobs_gpu_set_error(COBS_GPU_ERR_OPEN, "short write");
-    return COBS_GPU_OK;
+    return build_from_arrays(true, names, texts, lens, ndocs, params, out_path, nullptr, nullptr);
 }
 
 // classic_construct / compact_construct straight into a resident query index: the matrix is built
@@ -319,67 +583,131 @@ cobs_gpu_status cobs_gpu_build_index(uint32_t kind, const char* const* names, co
     *out = nullptr;
     if (!names || !texts || !lens || ndocs == 0 || kind > 1)
         return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "NULL argument or no documents");
+    return build_from_arrays(kind == 1, names, texts, lens, ndocs, params, nullptr, opts, out);
+}
+
+cobs_gpu_status cobs_gpu_build_classic_list(const cobs_gpu_doclist* dl, const cobs_gpu_build_params* params,
+                                            const char* out_path) {
+    if (!dl || !out_path || dl->list.empty()) return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "NULL argument or no documents");
+    return build_from_list(false, dl, params, out_path, nullptr, nullptr);
+}
+
+cobs_gpu_status cobs_gpu_build_compact_list(const cobs_gpu_doclist* dl, const cobs_gpu_build_params* params,
+                                            const char* out_path) {
+    if (!dl || !out_path || dl->list.empty()) return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "NULL argument or no documents");
+    return build_from_list(true, dl, params, out_path, nullptr, nullptr);
+}
+
+cobs_gpu_status cobs_gpu_build_index_list(uint32_t kind, const cobs_gpu_doclist* dl, const cobs_gpu_build_params* params,
+                                          const cobs_gpu_options* opts, cobs_gpu_index** out) {
+    if (!out) return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!dl || dl->list.empty() || kind > 1) return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "NULL argument or no documents");
+    return build_from_list(kind == 1, dl, params, nullptr, opts, out);
+}
+
+// ---- document lists --------------------------------------------------------------------------------
+cobs_gpu_status cobs_gpu_doclist_create(cobs_gpu_doclist** out) {
+    if (!out) return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "out is NULL");
     return guarded([&]() -> cobs_gpu_status {
-        Params pr;
-        cobs_gpu_status st = read_params(params, pr);
-        if (st != COBS_GPU_OK) return st;
-        IndexMeta meta;
-        meta.kind = kind ? IndexKind::Compact : IndexKind::Classic;
-        meta.term_size = pr.term_size;
-        meta.canonicalize = (uint8_t)pr.canonicalize;
-        meta.num_hashes = pr.num_hashes;
-        struct Group { size_t g0, g1; };
-        std::vector<Group> groups;
-        auto terms_of = [&](size_t d) { return pr.doc_terms ? pr.doc_terms[d] : count_terms(texts[d], lens[d], pr.term_size); };
-        if (kind == 0) {
-            uint64_t sig = pr.signature_size, max_terms = 0;
-            for (size_t d = 0; d < ndocs; ++d) max_terms = std::max(max_terms, terms_of(d));
-            if (sig == 0) sig = signature_size_for(max_terms, (double)pr.num_hashes, pr.fpr);
-            if (sig == 0) return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "documents hold no terms");
-            meta.signature_sizes.assign(1, sig);
-            groups.push_back(Group{0, ndocs});
-            for (size_t d = 0; d < ndocs; ++d) meta.doc_names.emplace_back(names[d]);
-        } else {
-            uint64_t ps = pr.page_size;
-            if (ps == 0) {      // compact_construct, compact_index.cpp:184-189
-                const uint64_t v = (uint64_t)std::sqrt((double)(ndocs / 8));
-                uint64_t p2 = 1;
-                while (p2 < v) p2 <<= 1;
-                ps = std::min<uint64_t>(std::max<uint64_t>(v == 0 ? 0 : p2, 8), 4096);
-            }
-            meta.header_page_size = ps;
-            for (size_t g0 = 0; g0 < ndocs; g0 += (size_t)(8 * ps)) {
-                const size_t g1 = std::min(ndocs, g0 + (size_t)(8 * ps));
-                uint64_t max_terms = 0;
-                for (size_t d = g0; d < g1; ++d) max_terms = std::max(max_terms, terms_of(d));
-                if (max_terms == 0) continue;
-                meta.signature_sizes.push_back(pr.signature_size ? pr.signature_size
-                                                                 : signature_size_for(max_terms, (double)pr.num_hashes, pr.fpr));
-                groups.push_back(Group{g0, g1});
-                for (size_t d = g0; d < g1; ++d) meta.doc_names.emplace_back(names[d]);
-            }
-            if (groups.empty()) return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "documents hold no terms");
-        }
-        cobs_gpu_options o{};
-        if (opts) std::memcpy(&o, opts, std::min<size_t>(opts->struct_size, sizeof o));
-        o.struct_size = sizeof o;
-        if (pr.device >= 0) o.device = pr.device;
-        else if (!opts) o.device = -1;
-        cobs_gpu_index* ix = nullptr;
-        st = open_zeroed(std::move(meta), &o, &ix);
-        if (st != COBS_GPU_OK) return st;
-        std::unique_ptr<cobs_gpu_index, void (*)(cobs_gpu_index*)> guard(ix, cobs_gpu_close);
-        Part& pt = ix->parts[0];
-        for (Chunk& c : pt.chunks)
-            for (size_t i = 0; i < c.vp.size(); ++i) {
-                const Group& g = groups[c.vp[i].fp];
-                st = build_into(reinterpret_cast<uint32_t*>(c.d_data + c.pages[i].base), c.pages[i].sig, c.pitch, texts, lens,
-                                g.g0, g.g1, 0, pr);
-                if (st != COBS_GPU_OK) return st;
-            }
-        *out = guard.release();
+        *out = new cobs_gpu_doclist;
         return COBS_GPU_OK;
     });
+}
+
+void cobs_gpu_doclist_free(cobs_gpu_doclist* dl) { delete dl; }
+
+cobs_gpu_status cobs_gpu_doclist_add(cobs_gpu_doclist* dl, const char* path) {
+    if (!dl || !path) return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "NULL argument");
+    return guarded([&]() -> cobs_gpu_status { return load_entries(path, dl->list); });
+}
+
+cobs_gpu_status cobs_gpu_doclist_add_recursive(cobs_gpu_doclist* dl, const char* root, uint32_t filter) {
+    if (!dl || !root || filter > COBS_GPU_FILETYPE_LIST) return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "bad argument");
+    return guarded([&]() -> cobs_gpu_status { return add_recursive(root, (FileType)filter, dl->list); });
+}
+
+cobs_gpu_status cobs_gpu_doclist_add_memory(cobs_gpu_doclist* dl, const char* name, const char* text, size_t len) {
+    if (!dl || !name || (!text && len)) return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "NULL argument");
+    return guarded([&]() -> cobs_gpu_status {
+        DocEntry e;
+        e.path = name;
+        e.name = name;
+        e.type = FileType::Memory;
+        e.text.assign(text ? text : "", len);
+        e.size = len + 1;
+        dl->list.push_back(std::move(e));
+        return COBS_GPU_OK;
+    });
+}
+
+size_t cobs_gpu_doclist_size(const cobs_gpu_doclist* dl) { return dl ? dl->list.size() : 0; }
+
+cobs_gpu_status cobs_gpu_doclist_entry(const cobs_gpu_doclist* dl, size_t i, cobs_gpu_doc_entry* out) {
+    if (!dl || !out || i >= dl->list.size()) return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "bad argument");
+    const DocEntry& e = dl->list[i];
+    out->path = e.path.c_str();
+    out->name = e.name.c_str();
+    out->type = (uint32_t)e.type;
+    out->reserved = 0;
+    out->size = e.size;
+    out->subdoc_index = e.subdoc_index;
+    out->term_size = e.term_size;
+    out->term_count = e.term_count;
+    return COBS_GPU_OK;
+}
+
+cobs_gpu_status cobs_gpu_doclist_sort(cobs_gpu_doclist* dl, uint32_t by) {
+    if (!dl || by > COBS_GPU_SORT_BY_SIZE) return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "bad argument");
+    return guarded([&]() -> cobs_gpu_status {
+        if (by == COBS_GPU_SORT_BY_PATH)        // sort_by_path, document_list.hpp:416-421: by path only
+            std::stable_sort(dl->list.begin(), dl->list.end(),
+                             [](const DocEntry& a, const DocEntry& b) { return a.path < b.path; });
+        else
+            sort_entries(dl->list, by);
+        return COBS_GPU_OK;
+    });
+}
+
+cobs_gpu_status cobs_gpu_doclist_num_terms(const cobs_gpu_doclist* dl, size_t i, uint32_t term_size, uint64_t* out) {
+    if (!dl || !out || i >= dl->list.size() || term_size == 0) return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "bad argument");
+    *out = num_terms(dl->list[i], term_size);
+    return COBS_GPU_OK;
+}
+
+cobs_gpu_status cobs_gpu_doclist_terms(const cobs_gpu_doclist* dl, size_t i, uint32_t term_size, char* out,
+                                       size_t cap_bytes, uint64_t* n_terms) {
+    if (!dl || !n_terms || i >= dl->list.size() || term_size == 0 || (!out && cap_bytes))
+        return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "bad argument");
+    return guarded([&]() -> cobs_gpu_status {
+        std::string text;
+        std::vector<TermSeg> segs;
+        cobs_gpu_status st = load_terms(dl->list[i], term_size, text, segs);
+        if (st != COBS_GPU_OK) return st;
+        uint64_t n = 0;
+        const size_t k = term_size;
+        for (const TermSeg& g : segs) {
+            const char* p = text.data() + g.begin;
+            size_t run = 0;                      // characters since the last separator
+            for (size_t j = 0; j < g.len; ++j) {
+                run = (!g.raw && p[j] == '\n') ? 0 : run + 1;
+                if (run >= k) {
+                    if ((n + 1) * k <= cap_bytes) std::memcpy(out + n * k, p + j + 1 - k, k);
+                    ++n;
+                }
+            }
+        }
+        *n_terms = n;
+        return COBS_GPU_OK;
+    });
+}
+
+cobs_gpu_status cobs_gpu_filetype_from_string(const char* s, uint32_t* out) {
+    if (!s || !out) return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "NULL argument");
+    FileType ft;
+    if (!parse_filetype(s, ft)) return cobs_gpu_set_error(COBS_GPU_ERR_ARG, (std::string("Unknown file type ") + s).c_str());
+    *out = (uint32_t)ft;
+    return COBS_GPU_OK;
 }
 
 // classic_combine (classic_index.cpp:195-327) on the GPU: the rows of several classic indexes with

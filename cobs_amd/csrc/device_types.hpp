@@ -97,16 +97,20 @@ struct TopkArgs {
 };
 
 // Arguments of the construction kernel: set the signature bits of documents.
+// a stretch of term text whose k-grams are all terms (newlines included); otherwise a stretch is
+// sequences each followed by '\n' and no term holds a '\n'
+constexpr uint32_t kBuildRawStretch = 0x80000000u;
+
 struct BuildArgs {
-    const uint8_t* text;        // documents back to back, each followed by '\n'; sequences inside a
-                                // document are separated by '\n' too (terms never span a separator)
-    const uint64_t* doc_off;    // ndocs + 1 offsets into text (incl. the trailing separator)
+    const uint8_t* text;        // stretches of term text back to back (documents.hpp); the buffer is
+                                // padded by 8 readable bytes
+    const uint64_t* seg_off;    // nsegs + 1 offsets into text
+    const uint32_t* seg_col;    // nsegs: the document's column (slot) in the matrix | kBuildRawStretch
     uint32_t* matrix;           // signature_size rows of row_bytes (multiple of 4) bytes, as words
     uint64_t signature_size;
     uint64_t magic;             // floor((2^64-1) / signature_size)
     uint64_t row_bytes;
-    uint32_t ndocs;
-    uint32_t doc_bit0;          // column (document slot) of document 0 of this launch
+    uint32_t nsegs;
     uint32_t term_size;
     uint32_t canonicalize;
     uint32_t num_hashes;

@@ -47,6 +47,8 @@ bool parse_filetype(const std::string& s, FileType& out);                       
 cobs_gpu_status load_entries(const std::string& path, std::vector<DocEntry>& out);
 //! DocumentList::add_recursive: directory scan / .list file / single file, then sorted
 cobs_gpu_status add_recursive(const std::string& root, FileType filter, std::vector<DocEntry>& list);
+//! by = COBS_GPU_SORT_BY_PATH: (path, sub-document) -- DocumentEntry::operator<; _BY_SIZE: (size, path)
+void sort_entries(std::vector<DocEntry>& list, uint32_t by);
 //! DocumentEntry::num_terms(k) -- the count that sizes a signature
 uint64_t num_terms(const DocEntry& e, uint32_t k);
 //! DocumentEntry::process_terms(k) as term text appended to `text`

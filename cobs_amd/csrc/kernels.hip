@@ -1191,24 +1191,83 @@ __global__ __launch_bounds__(256) void topk_kernel(TopkArgs a) {
 // ---------------------------------------------------------------------------
 // Construction: the reference sets bit (doc % 8) of byte doc / 8
 // of row XXH64(canon(term), seed j) % signature_size for every term of every document
-// (cobs/construction/classic_index.cpp:40-73).  One thread per text position; a
-// position starts a term if the next k characters hold no separator.  With
-// canonicalize = 1 the reference hashes the canonicalised buffer even when it holds
-// invalid characters (mapped to 0), which the generic byte view reproduces.
+// (cobs/construction/classic_index.cpp:40-73).  One thread per position of the term text; the
+// text is a sequence of stretches (documents.hpp): in a raw stretch every k-gram is a term, in a
+// line stretch a position starts a term if the next k characters hold no '\n'.  With
+// canonicalize = 1 the reference hashes the canonicalised buffer even when it holds invalid
+// characters (mapped to 0), which the generic byte view reproduces; 31-mers of valid bases --
+// nearly all of a DNA collection -- take the register path of the query hash kernel instead
+// (unaligned dword loads, canon31, unrolled XXH64).
+__device__ __forceinline__ bool all_acgt(uint32_t w) {
+    // (c >> 1) & 3 maps A C G T to 0 1 3 2; v_perm rebuilds the letters from that code
+    const uint32_t code = (w >> 1) & 0x03030303u;
+    return __builtin_amdgcn_perm(0u, 0x47544341u, code) == w;
+}
+__device__ __forceinline__ bool has_newline(uint32_t w) {
+    const uint32_t x = w ^ 0x0A0A0A0Au;
+    return ((x - 0x01010101u) & ~x & 0x80808080u) != 0u;
+}
+
 __global__ __launch_bounds__(256) void build_kernel(BuildArgs a, uint64_t total_bytes) {
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total_bytes) return;
-    const uint32_t k = a.term_size;
-    if (gid + k > total_bytes) return;
-    const uint8_t* p = a.text + gid;
-    for (uint32_t i = 0; i < k; ++i)
-        if (p[i] == '\n') return;                     // term would span a sequence / document boundary
-    uint32_t lo = 0, hi = a.ndocs;
+    // the stretch of the block's first position (wave-uniform search), then a few steps per thread
+    const uint64_t base = (uint64_t)blockIdx.x * 256u;
+    uint32_t lo = 0, hi = a.nsegs;
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
-        if (a.doc_off[mid] <= gid) lo = mid; else hi = mid;
+        if (a.seg_off[mid] <= base) lo = mid; else hi = mid;
     }
-    const uint32_t doc = a.doc_bit0 + lo;
+    const uint64_t gid = base + threadIdx.x;
+    if (gid >= total_bytes) return;
+    while (a.seg_off[lo + 1] <= gid) ++lo;            // seg_off[nsegs] = total_bytes > gid
+    const uint32_t k = a.term_size;
+    if (gid + k > a.seg_off[lo + 1]) return;          // the term would leave its stretch
+    const uint32_t colw = a.seg_col[lo];
+    const bool raw = (colw & kBuildRawStretch) != 0u;
+    const uint32_t doc = colw & ~kBuildRawStretch;
+    const uint64_t byte_in_row = doc >> 3;
+    const uint32_t bit = 1u << ((uint32_t)(byte_in_row & 3u) * 8u + (doc & 7u));
+    const uint8_t* p = a.text + gid;
+    if (k == 31u) {
+        // the 31-mer and one following byte as 8 (unaligned) dwords; the text buffer is padded
+        uint32_t f[8];
+        {
+            const uint32_t mis = (uint32_t)((uintptr_t)p & 3u);
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(p - mis);
+            uint32_t r[9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) r[j] = w[j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                f[j] = mis == 0 ? r[j] : (uint32_t)(((uint64_t)r[j] | ((uint64_t)r[j + 1] << 32)) >> (8 * mis));
+        }
+        f[7] &= 0x00FFFFFFu;
+        if (!raw) {
+            bool nl = false;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) nl |= has_newline(f[j]);
+            if (nl) return;                           // the term would span a sequence boundary
+        }
+        bool fast = true;
+        uint32_t c[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[j] = f[j];
+        if (a.canonicalize != 0) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) fast &= all_acgt(f[j]);
+            fast &= all_acgt(f[7] | 0x41000000u);
+            if (fast) canon31(f, c);
+        }
+        if (fast) {
+            for (uint32_t j = 0; j < a.num_hashes; ++j) {
+                const uint64_t row = fast_mod(xxh64_31(c, (uint64_t)j), a.signature_size, a.magic);
+                atomicOr(a.matrix + (row * a.row_bytes + byte_in_row) / 4u, bit);
+            }
+            return;
+        }
+    } else if (!raw) {
+        for (uint32_t i = 0; i < k; ++i)
+            if (p[i] == '\n') return;                 // the term would span a sequence boundary
+    }
     KmerView kv{p, k, 0u};
     if (a.canonicalize != 0) {
         uint32_t mode = 1;
@@ -1220,8 +1279,6 @@ __global__ __launch_bounds__(256) void build_kernel(BuildArgs a, uint64_t total_
         }
         kv.mode = mode;
     }
-    const uint64_t byte_in_row = doc >> 3;
-    const uint32_t bit = 1u << ((uint32_t)(byte_in_row & 3u) * 8u + (doc & 7u));
     for (uint32_t j = 0; j < a.num_hashes; ++j) {
         const uint64_t row = fast_mod(xxh64_view(kv, (uint64_t)j), a.signature_size, a.magic);
         atomicOr(a.matrix + (row * a.row_bytes + byte_in_row) / 4u, bit);

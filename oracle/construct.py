@@ -228,12 +228,17 @@ def write_compact(path, term_size, canonicalize, page_size, params, names, matri
 
 def classic_construct(docs, out_path, term_size=31, canonicalize=1, num_hashes=1,
                       false_positive_rate=0.3, signature_size=0):
-    """classic_construct (classic_index.cpp:565-659): documents in path order, one
-    matrix of ceil(D/8)-byte rows; S from the largest document unless given."""
-    docs = sorted(docs, key=lambda d: d.path)
+    """classic_construct (classic_index.cpp:565-659): documents in DocumentList order (path,
+    sub-document), one matrix of ceil(D/8)-byte rows; S from the num_terms of the LARGEST document
+    by (size, path) -- get_max_file_size, :521-563, std::max_element: the first of equals --
+    unless given."""
+    docs = sorted(docs, key=lambda d: (d.path, getattr(d, "subdoc", 0)))
     if signature_size == 0:
-        signature_size = calc_signature_size(max(d.num_terms for d in docs), num_hashes,
-                                             false_positive_rate)
+        big = docs[0]
+        for d in docs[1:]:
+            if (big.size, big.path) < (d.size, d.path):
+                big = d
+        signature_size = calc_signature_size(big.num_terms, num_hashes, false_positive_rate)
     row_size = (len(docs) + 7) // 8
     m = build_matrix(docs, signature_size, row_size)
     write_classic(out_path, term_size, canonicalize, [d.name for d in docs], signature_size,
@@ -256,7 +261,7 @@ def compact_construct(docs, out_path, term_size=31, canonicalize=1, num_hashes=1
     group = 8 * page_size
     params, mats, names = [], [], []
     for g in range(0, len(docs), group):
-        part = sorted(docs[g:g + group], key=lambda d: d.path)
+        part = sorted(docs[g:g + group], key=lambda d: (d.path, getattr(d, "subdoc", 0)))   # DocumentList(files), :315
         max_terms = max(d.num_terms for d in part)
         s = calc_signature_size(max_terms, num_hashes, false_positive_rate)
         if max_terms == 0:

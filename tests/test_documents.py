@@ -1,0 +1,246 @@
+"""Document lists and document readers (input side), CPU only.
+
+1. Pins of the checker oracle/documents.py against the reference's own reader tests and their
+   data files (tests/cortex_file.cpp, fastq_file.cpp, fasta_multifile.cpp, text_file.cpp; data in
+   tests/golden/documents/, copied by tests/golden/copy_reference_documents.py).
+2. The product's readers (cobs_amd/csrc/documents.cpp through cobs_gpu_doclist_*; host code of
+   libcobs_gpu.so, no device call) against those known answers and, term for term, against the
+   checker on the fixtures and on generated files that exercise the readers' buffer edges."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from oracle import documents as D
+
+
+@pytest.fixture(scope="module")
+def docdir(golden_dir):
+    return os.path.join(golden_dir, "documents")
+
+
+@pytest.fixture(scope="module")
+def capi():
+    import cobs_amd
+    return cobs_amd
+
+
+def _lines(path):
+    return open(path, "rb").read().split(b"\n")[:-1]
+
+
+# ---- 1. the checker against the reference's expectations ---------------------------------------
+
+def test_oracle_cortex_reference_tests(docdir):
+    """tests/cortex_file.cpp:22-52 (header fields, 24158 k-mers, sorted list) and :54-88 (sample1
+    at k = 31, 19, 15: the k-mers in file order)"""
+    p = os.path.join(docdir, "cortex", "document.ctx")
+    h = D.cortex_header(p)
+    assert (h["version"], h["kmer_size"], h["words"], h["colors"], h["name"]) == (6, 31, 1, 1, "DRR030535")
+    assert h["num_kmers"] == 24158
+    kmers = D.windows(D.cortex_term_buffers(p, 31), 31)
+    assert len(kmers) == 24158
+    assert sorted(kmers) == _lines(os.path.join(docdir, "cortex", "document_sorted.txt"))
+    for k in (31, 19, 15):
+        got = D.windows(D.cortex_term_buffers(os.path.join(docdir, "cortex", "sample1-k%d.ctx" % k), k), k)
+        assert got == _lines(os.path.join(docdir, "cortex", "sample1-k%d.txt" % k))
+
+
+def test_oracle_fastq_reference_tests(docdir):
+    """tests/fastq_file.cpp:38-57, :59-64"""
+    s1, _ = D.fastq_index(os.path.join(docdir, "fastq", "sample1.fastq"))
+    s2, h2 = D.fastq_index(os.path.join(docdir, "fastq", "sample2.fastq.gz"))
+    assert (s1, s2) == (3518, 3001)
+    e = D.load(os.path.join(docdir, "fastq", "sample2.fastq.gz"))[0]
+    assert e.num_terms(31) == len(e.terms(31)) > 0
+    assert len(D.document_list(os.path.join(docdir, "fastq"))) == 3
+
+
+def test_oracle_multifasta_reference_tests(docdir):
+    """tests/fasta_multifile.cpp:36-52, :54-60"""
+    assert len(D.mfasta_index(os.path.join(docdir, "fasta_multi", "sample1.mfasta"))) == 1
+    ix = D.mfasta_index(os.path.join(docdir, "fasta_multi", "sample2.mfasta"))
+    assert len(ix) == 5 and ix[0][1] == 256 and ix[4][1] == 438
+    terms = D.windows(D.mfasta_term_buffers(os.path.join(docdir, "fasta_multi", "sample2.mfasta"), ix[0][0], 31), 31)
+    assert len(terms) == 256 - 30
+    ents = D.document_list(os.path.join(docdir, "fasta_multi"))
+    assert len(ents) == 6
+    assert [e.name for e in ents] == ["sample1_000000"] + ["sample2_%06d" % i for i in range(5)]
+
+
+def test_oracle_text_reference_tests(docdir):
+    """tests/text_file.cpp:17-30"""
+    p = os.path.join(docdir, "text", "sample1.txt")
+    assert os.path.getsize(p) == 76
+    assert len(D.windows(D.text_term_buffers(p, 31), 31)) == 76 - 30
+    assert len(D.document_list(os.path.join(docdir, "text"))) == 2
+
+
+def test_oracle_kmer_buffer_round_trip(tmp_path):
+    """KMer<31>::init / to_string are inverses (kmer.hpp:54-99); a .cobs_doc holds its header name
+    and (file size - header) / 8 k-mers (document_list.hpp:271-284)"""
+    rng = np.random.default_rng(5)
+    kmers = [bytes(rng.choice(list(b"ACGT"), 31).astype(np.uint8)) for _ in range(57)]
+    for km in kmers:
+        assert D.kmer_to_string(D.kmer_pack(km), 31) == km
+    assert D.kmer_pack(b"A" * 30 + b"C") == bytes([1, 0, 0, 0, 0, 0, 0, 0])      # last four bases in byte 0
+    assert D.kmer_pack(b"T" + b"A" * 30) == bytes([0, 0, 0, 0, 0, 0, 0, 0x30])   # 'A' pad, then the first three
+    p = str(tmp_path / "d.cobs_doc")
+    D.write_kmer_buffer(p, "document_000007", kmers)
+    e = D.load(p)[0]
+    assert (e.name, e.term_size, e.term_count, e.num_terms(31)) == ("document_000007", 31, 57, 57)
+    assert e.terms(31) == kmers
+
+
+# ---- 2. the product's readers ---------------------------------------------------------------------
+
+def _same_entry(e, g):
+    assert (e.path, e.name, e.type, e.size, e.subdoc_index, e.term_size, e.term_count) == \
+        (g.path, g.name, int(g.type), g.size, g.subdoc_index, g.term_size, g.term_count)
+
+
+def test_native_readers_reference_known_answers(capi, docdir):
+    dl = capi.DocumentList()
+    dl.add(os.path.join(docdir, "cortex", "document.ctx"))
+    e = dl[0]
+    assert (e.name, e.term_size, e.term_count, e.type) == ("DRR030535", 31, 24158, capi.FileType.Cortex)
+    assert sorted(e.terms(31)) == _lines(os.path.join(docdir, "cortex", "document_sorted.txt"))
+    for k in (31, 19, 15):
+        dl = capi.DocumentList(os.path.join(docdir, "cortex", "sample1-k%d.ctx" % k))
+        assert dl[0].terms(k) == _lines(os.path.join(docdir, "cortex", "sample1-k%d.txt" % k))
+    dl = capi.DocumentList(os.path.join(docdir, "fastq"))
+    assert [d.size for d in dl] == [3518, 3001, 4000] and [d.name for d in dl] == ["sample1", "sample2", "sample3"]
+    assert dl[1].num_terms(31) == len(dl[1].terms(31))
+    dl = capi.DocumentList(os.path.join(docdir, "fasta_multi"))
+    assert dl.size() == 6 and dl[1].size == 256 and dl[5].size == 438 and len(dl[1].terms(31)) == 256 - 30
+    dl = capi.DocumentList(os.path.join(docdir, "text"))
+    assert dl.size() == 2 and dl[0].size == 76 and len(dl[0].terms(31)) == 76 - 30
+
+
+@pytest.mark.parametrize("sub", ["cortex", "fastq", "fasta_multi", "text", "../fasta"])
+def test_native_readers_equal_the_checker_on_the_fixtures(capi, docdir, sub):
+    root = os.path.normpath(os.path.join(docdir, sub))
+    ents, dl = D.document_list(root), capi.DocumentList(root)
+    assert dl.size() == len(ents) > 0
+    for e, g in zip(ents, dl):
+        _same_entry(e, g)
+        for k in (31, 15, 4, 1, 40):
+            assert e.num_terms(k) == g.num_terms(k)
+            assert e.terms(k) == g.terms(k), (e.path, k)
+
+
+def _random_lines(rng, n, maxlen, alphabet=b"ACGT"):
+    return [bytes(rng.choice(list(alphabet), int(rng.integers(0, maxlen))).astype(np.uint8)) for _ in range(n)]
+
+
+def _write_corpus(rng, d):
+    """files of every type whose shapes hit the readers' edges: lines shorter than k, empty lines,
+    comments in odd places, CRLF, no final newline, text beyond the 64 KiB buffer"""
+    os.makedirs(d, exist_ok=True)
+    # FASTA / multi-FASTA
+    for i in range(10):
+        lines = []
+        for _ in range(int(rng.integers(1, 5))):
+            lines.append(b">" + bytes(rng.choice(list(b"abcdefghijklmnopqrstuvwxyz0123456789 "), int(rng.integers(0, 40))).astype(np.uint8)))
+            for ln in _random_lines(rng, int(rng.integers(0, 7)), 70, b"ACGTN"):
+                lines.append(ln)
+                if rng.random() < 0.15:
+                    lines.append(b";" + ln[:5])
+                if rng.random() < 0.1:
+                    lines.append(b"")
+        nl = b"\r\n" if i == 3 else b"\n"
+        body = nl.join(lines) + (b"" if i % 4 == 1 else nl)
+        with open(os.path.join(d, "f%02d.fasta" % i), "wb") as f:
+            f.write(body)
+        with open(os.path.join(d, "m%02d.mfasta" % i), "wb") as f:
+            f.write(body)
+        with gzip.open(os.path.join(d, "g%02d.fa.gz" % i), "wb") as f:
+            f.write(body)
+    # FASTQ
+    for i in range(4):
+        recs = []
+        for r in range(int(rng.integers(1, 30))):
+            read = _random_lines(rng, 1, 120, b"ACGTN")[0]
+            recs += [b"@read%d" % r, read, b"+", b"I" * len(read)]
+        body = b"\n".join(recs) + (b"" if i == 2 else b"\n")
+        opener = gzip.open if i == 1 else open
+        with opener(os.path.join(d, "q%02d.fastq%s" % (i, ".gz" if i == 1 else "")), "wb") as f:
+            f.write(body)
+    # text: small, around the buffer size, several refills
+    for i, n in enumerate((0, 7, 30, 31, 500, 65535, 65536, 65537, 65536 + 29, 65536 + 30, 131072 - 30, 200001)):
+        with open(os.path.join(d, "t%02d.txt" % i), "wb") as f:
+            f.write(bytes(rng.integers(32, 127, size=n).astype(np.uint8)).replace(b"~", b"\n"))
+    # .cobs_doc
+    for i in range(3):
+        kmers = [bytes(rng.choice(list(b"ACGT"), 31).astype(np.uint8)) for _ in range(int(rng.integers(0, 40)))]
+        D.write_kmer_buffer(os.path.join(d, "k%02d.cobs_doc" % i), "document_%06d" % i, kmers)
+
+
+def test_native_readers_equal_the_checker_on_generated_files(capi, tmp_path):
+    rng = np.random.default_rng(20240928)
+    root = str(tmp_path / "corpus")
+    _write_corpus(rng, root)
+    ents, dl = D.document_list(root), capi.DocumentList(root)
+    assert dl.size() == len(ents) > 40
+    for e, g in zip(ents, dl):
+        _same_entry(e, g)
+        ks = (31,) if e.type == D.KMER_BUFFER else (31, 9, 2, 64)
+        for k in ks:
+            assert e.num_terms(k) == g.num_terms(k), (e.path, k)
+            assert e.terms(k) == g.terms(k), (e.path, k)
+
+
+def test_list_files_filters_and_sorting(capi, docdir, tmp_path):
+    """.list files (document_list.hpp:360-381), type filters (:165-196), sort_by_size (:424-430),
+    DocumentList::add, StringToFileType"""
+    lst = tmp_path / "docs.list"
+    lst.write_text("# a comment\n\n%s\nrel.txt\n" % os.path.join(docdir, "fastq", "sample3.fastq"))
+    (tmp_path / "rel.txt").write_text("some text that is long enough for a 31-gram, yes\n")
+    dl = capi.DocumentList(str(lst))
+    assert [d.name for d in dl] == ["sample3", "rel"] or [d.name for d in dl] == ["rel", "sample3"]
+    assert [d.path for d in dl] == sorted(d.path for d in dl)
+    want = D.document_list(str(lst))
+    assert [(d.path, d.name) for d in dl] == [(e.path, e.name) for e in want]
+    # filters: by enum, by the CLI's strings
+    root = os.path.dirname(docdir)
+    everything = capi.DocumentList(root)
+    assert everything.size() == len(D.document_list(root))
+    for ft, name in ((capi.FileType.Fastq, "fastq"), (capi.FileType.Cortex, "cortex"), (capi.FileType.Text, "text"),
+                     (capi.FileType.Fasta, "fasta")):
+        a, b = capi.DocumentList(root, ft), capi.DocumentList(root, name)
+        assert a.size() == b.size() == len(D.document_list(root, int(ft))) > 0
+        assert all(d.type == ft for d in a)
+    with pytest.raises(capi.CobsGpuError):
+        capi.DocumentList(root, "no-such-type")
+    # sort_by_size / sort_by_path
+    everything.sort_by_size()
+    keys = [(d.size, d.path) for d in everything]
+    assert keys == sorted(keys)
+    everything.sort_by_path()
+    assert [d.path for d in everything] == sorted(d.path for d in everything)
+    # add: one file at a time, in call order; unknown types and broken files are errors
+    dl = capi.DocumentList()
+    dl.add(os.path.join(docdir, "text", "sample2.txt"))
+    dl.add(os.path.join(docdir, "fasta_multi", "sample2.mfasta"))
+    assert dl.size() == 6 and dl[0].name == "sample2" and dl[5].subdoc_index == 4
+    with pytest.raises(capi.CobsGpuError):
+        dl.add(str(tmp_path / "docs.list"))
+    bad = tmp_path / "bad.ctx"
+    bad.write_bytes(b"CORTEY" + b"\0" * 100)
+    with pytest.raises(capi.CobsGpuError) as e:
+        dl.add(str(bad))
+    assert "magic number not found" in str(e.value)
+    nofq = tmp_path / "bad.fastq"
+    nofq.write_bytes(b"@r\nACGT\nX\nIIII\n")
+    with pytest.raises(capi.CobsGpuError) as e:
+        dl.add(str(nofq))
+    assert "does not start with +" in str(e.value)
+    # a directory scan skips what it cannot load and goes on (:393-402)
+    (tmp_path / "ok.txt").write_text("x" * 40)
+    assert {d.name for d in capi.DocumentList(str(tmp_path))} == {"rel", "ok"}
+    # in-memory documents
+    dl = capi.DocumentList()
+    dl.add_document("mem", [b"ACGTACGTAC", b"", b"GGGTTTAAACCC"])
+    assert dl[0].type == capi.FileType.Memory and dl[0].num_terms(4) == 7 + 9 and len(dl[0].terms(4)) == 16
+    assert dl[0].terms(11) == [b"GGGTTTAAACC", b"GGTTTAAACCC"]

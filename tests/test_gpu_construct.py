@@ -294,3 +294,127 @@ def test_drop_in_module_name(gpu_lib, golden_dir, tmp_path):
         assert r[0].doc_name == "sample1"
         assert r[0].score == 20
     assert isinstance(cobs.__version__, str)
+
+
+# ---- document lists: every reader of the reference in front of the GPU builder ---------------------
+
+def _build_both(cobs_amd, construct, D, root, tmp_path, tag, k=31, canonicalize=1, num_hashes=1, fpr=0.3,
+                page_size=0, filter=0, batch=0):
+    """GPU files from the library's own DocumentList vs the checker's construction of the checker's
+    document list; -> paths of the two GPU files"""
+    ents = D.document_list(root, filter)
+    kdocs = D.docs(ents, k, canonicalize, num_hashes)
+    out = []
+    for ext, build_gpu, build_ref, params in (
+            (".cobs_classic", cobs_amd.classic_construct, construct.classic_construct, cobs_amd.ClassicIndexParameters()),
+            (".cobs_compact", cobs_amd.compact_construct, construct.compact_construct, cobs_amd.CompactIndexParameters())):
+        params.term_size, params.canonicalize, params.num_hashes, params.false_positive_rate = k, canonicalize, num_hashes, fpr
+        params.text_batch_bytes = batch
+        kw = {}
+        if "compact" in ext:
+            params.page_size = page_size
+            kw["page_size"] = page_size
+        pg, pr = str(tmp_path / (tag + "_g" + ext)), str(tmp_path / (tag + "_r" + ext))
+        build_gpu(cobs_amd.DocumentList(root, filter), pg, params)
+        build_ref(kdocs, pr, term_size=k, canonicalize=canonicalize, num_hashes=num_hashes, false_positive_rate=fpr, **kw)
+        assert open(pg, "rb").read() == open(pr, "rb").read(), (tag, ext)
+        out.append(pg)
+    return out
+
+
+@pytest.mark.parametrize("sub,canonicalize", [("fastq", 0), ("fasta_multi", 0), ("text", 0), ("cortex", 1),
+                                              ("fastq", 1), ("fasta_multi", 1), ("text", 1), ("", 1)])
+def test_index_from_each_document_type(gpu_lib, oracle, construct, golden_dir, tmp_path, sub, canonicalize):
+    """the reference's per-format construction tests (tests/fastq_file.cpp:59-101,
+    fasta_multifile.cpp:54-99: num_hashes 3, fpr 0.1, canonicalize 0; every k-mer of a document
+    finds its document) on the reference's own data files, plus the mixed tree ("" = all of
+    tests/golden/documents: text beyond the 64 KiB reader buffer, cortex files of three k-mer
+    sizes, gz): files byte-identical to the checker's construction"""
+    from oracle import documents as D
+    root = os.path.join(golden_dir, "documents", sub) if sub else os.path.join(golden_dir, "documents")
+    pc, pk = _build_both(gpu_lib, construct, D, root, tmp_path, sub or "all", canonicalize=canonicalize,
+                         num_hashes=3, fpr=0.1, page_size=2 if sub else 0)
+    ents = D.document_list(root)
+    for p in (pc, pk):
+        s = gpu_lib.Search(p)
+        names = [s.doc_name(0, d) for d in range(s.info(0).num_docs)]
+        for e in ents:
+            if sub == "":
+                break
+            terms = e.terms(31)[:200]
+            if canonicalize:
+                terms = [t for t in terms if set(t) <= set(b"ACGT")]      # the query path rejects other characters
+            for t, res in zip(terms, s.search_hits(terms, 0.0, 0)):
+                assert len(res) == len(ents)
+                # (names repeat in the cortex tree: three files carry the sample name "sample1")
+                assert max(sc for (_, d, sc) in res if names[d] == e.name) >= 1, (e.name, t)
+
+
+def test_index_from_generated_documents_small_batches(gpu_lib, oracle, construct, tmp_path):
+    """the generated corpus of tests/test_documents.py (reader edge cases of every type) through
+    the GPU builder with text batches of 4 KiB -- documents larger than a batch, many launches,
+    both staging buffers in flight -- and with the default batch"""
+    from oracle import documents as D
+    from tests.test_documents import _write_corpus
+    root = str(tmp_path / "corpus")
+    _write_corpus(np.random.default_rng(77), root)
+    for tag, batch, canon, nh in (("small", 4096, 1, 2), ("default", 0, 0, 1)):
+        _build_both(gpu_lib, construct, D, root, tmp_path, tag, canonicalize=canon, num_hashes=nh, fpr=0.2,
+                    page_size=1, batch=batch)
+    # other term sizes (the generic hashing path of build_kernel; .cobs_doc documents hold 31-mers only)
+    for k in (20, 32):
+        _build_both(gpu_lib, construct, D, root, tmp_path, "k%d" % k, k=k, num_hashes=2, fpr=0.2, page_size=2,
+                    filter=D.TEXT)
+        _build_both(gpu_lib, construct, D, root, tmp_path, "kq%d" % k, k=k, num_hashes=1, fpr=0.2, page_size=2,
+                    filter=D.FASTQ, batch=1000)
+
+
+def test_reference_corpus_as_cobs_doc_files(gpu_lib, oracle, construct, tmp_path):
+    """tests/classic_index_construction.cpp:39-72 / compact_index_construction.cpp: the corpus of
+    generate_documents_all written as .cobs_doc files (generate_test_case, tests/test_util.hpp:86-96),
+    indexed from the directory -- equal to the checker's index of the same corpus"""
+    from oracle import documents as D
+    query = oracle.random_sequence(10000, 1)
+    docs = construct.generate_documents_all(query, 33, num_hashes=3)
+    members = [[] for _ in range(33)]
+    for i in range(len(query) - 31):
+        for j in range(0, 33, i % 32 + 1):
+            members[j].append(i)
+    root = tmp_path / "docs"
+    root.mkdir()
+    for j, m in enumerate(members):
+        D.write_kmer_buffer(str(root / ("document_%06d.cobs_doc" % j)), "document_%06d" % j,
+                            [oracle.canonicalize_kmer(query[i:i + 31])[0] for i in m])
+    dl = gpu_lib.DocumentList(str(root))
+    assert dl.size() == 33 and [d.term_count for d in dl] == [d.num_terms for d in docs]
+    pc = gpu_lib.ClassicIndexParameters()
+    pc.num_hashes, pc.false_positive_rate = 3, 0.1
+    got, want = str(tmp_path / "g.cobs_classic"), str(tmp_path / "w.cobs_classic")
+    gpu_lib.classic_construct(str(root), got, pc)
+    construct.classic_construct(docs, want, num_hashes=3, false_positive_rate=0.1)
+    assert open(got, "rb").read() == open(want, "rb").read()
+    pk = gpu_lib.CompactIndexParameters()
+    pk.num_hashes, pk.false_positive_rate, pk.page_size = 3, 0.1, 2
+    got, want = str(tmp_path / "g.cobs_compact"), str(tmp_path / "w.cobs_compact")
+    gpu_lib.compact_construct(str(root), got, pk)
+    construct.compact_construct(docs, want, num_hashes=3, false_positive_rate=0.1, page_size=2)
+    assert open(got, "rb").read() == open(want, "rb").read()
+    # and straight into a query handle: no file in between
+    s = gpu_lib.build_search(str(root), pk, kind="compact")
+    ix = oracle.Index.open(want)
+    assert np.array_equal(s.counts(query[:1000]), ix.counts(query[:1000]))
+
+
+def test_classic_signature_comes_from_the_largest_file(gpu_lib, oracle, construct, tmp_path):
+    """get_max_file_size (classic_index.cpp:521-563): the signature is sized by num_terms of the
+    largest document BY SIZE, not by the largest term count -- a FASTA file that is mostly comments
+    is larger than one with more sequence"""
+    from oracle import documents as D
+    root = tmp_path / "two"
+    root.mkdir()
+    (root / "a.fasta").write_bytes(b">a\n" + oracle.random_sequence(300, 1) + b"\n")
+    (root / "b.fasta").write_bytes(b">b\n" + b";comment line, no sequence\n" * 30 + oracle.random_sequence(60, 2) + b"\n")
+    ents = D.document_list(str(root))
+    assert ents[1].size > ents[0].size and ents[1].num_terms(31) < ents[0].num_terms(31)
+    pc, _ = _build_both(gpu_lib, construct, D, str(root), tmp_path, "two", page_size=1)
+    assert oracle.Index.open(pc).signature_size(0) == construct.calc_signature_size(ents[1].num_terms(31), 1, 0.3)

@@ -401,20 +401,20 @@ def test_fasta_term_state_machine_restated_twice(oracle, construct, tmp_path):
     """FastaFile::process_terms (/root/reference/cobs/fasta_file.hpp:155-182) has edge behaviour
     that decides which bits an index holds (short sequences, comment lines after a sequence).
     The oracle follows the reference's loop literally (std::string buffer + pos); the product's
-    host mirror (cobs_amd/construct.py) derives character runs.  Both must hash the same terms,
-    and on ordinary FASTA both equal the plain grammar."""
-    from cobs_amd import construct as mirror
+    reader (cobs_amd/csrc/documents.cpp, host code of libcobs_gpu.so) derives character runs.  Both
+    must hash the same terms, and on ordinary FASTA both equal the plain grammar."""
+    import cobs_amd
     k = 31
     for name, raw in QUIRK_FASTAS.items():
         p = tmp_path / (name + ".fasta")
         p.write_bytes(raw)
         bufs = list(construct.fasta_term_buffers(str(p), k))
         terms_oracle = [b[i:i + k] for b in bufs for i in range(len(b) - k + 1)]
-        text, size, nterms = mirror._read_fasta(str(p), k)
-        terms_mirror = [r[i:i + k] for r in text.split(b"\n") for i in range(len(r) - k + 1)]
-        assert terms_mirror == terms_oracle, name
-        assert size == construct.fasta_size(str(p))
-        assert nterms == sum(max(len(s) - k + 1, 0) for s in construct.fasta_sequences(str(p))), name
+        dl = cobs_amd.DocumentList()
+        dl.add(str(p))
+        assert dl[0].terms(k) == terms_oracle, name
+        assert dl[0].size == construct.fasta_size(str(p))
+        assert dl[0].num_terms(k) == sum(max(len(s) - k + 1, 0) for s in construct.fasta_sequences(str(p))), name
     # the quirks are real: header text is hashed / a line is dropped
     p = tmp_path / "short_then_header.fasta"
     bufs = list(construct.fasta_term_buffers(str(p), k))
