@@ -15,6 +15,7 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <tuple>
@@ -114,9 +115,11 @@ struct DocSource {
     virtual size_t size() const = 0;
     virtual const char* name(size_t d) const = 0;
     virtual uint64_t terms(size_t d, uint32_t k) const = 0;          // what sizes a signature
-    virtual uint64_t bytes_hint(size_t d) const = 0;                 // rough term-text size, to cut windows
+    virtual uint64_t text_bound(size_t d, uint32_t k) const = 0;     // upper bound of the document's term text
     virtual bool parses() const = 0;                                 // loading reads and parses files
-    virtual cobs_gpu_status load(size_t d, uint32_t k, std::string& text, std::vector<TermSeg>& segs) const = 0;
+    // the document's term text into `out` (a span of the staging buffer), its stretches into `segs`
+    virtual cobs_gpu_status load(size_t d, uint32_t k, TermSink& out, std::vector<TermSeg>& segs,
+                                 std::string& scratch) const = 0;
 };
 
 // documents handed over as texts (cobs_gpu_build_classic / _compact / _index)
@@ -131,13 +134,12 @@ struct ArraySource final : DocSource {
     size_t size() const override { return n; }
     const char* name(size_t d) const override { return names[d]; }
     uint64_t terms(size_t d, uint32_t k) const override { return doc_terms ? doc_terms[d] : count_terms(texts[d], lens[d], k); }
-    uint64_t bytes_hint(size_t d) const override { return lens[d] + 1; }
+    uint64_t text_bound(size_t d, uint32_t) const override { return lens[d] + 1; }
     bool parses() const override { return false; }
-    cobs_gpu_status load(size_t d, uint32_t, std::string& text, std::vector<TermSeg>& segs) const override {
-        const uint64_t begin = text.size();
-        text.append(texts[d], lens[d]);
-        text.push_back('\n');
-        segs.push_back(TermSeg{begin, (uint64_t)lens[d] + 1, false});
+    cobs_gpu_status load(size_t d, uint32_t, TermSink& out, std::vector<TermSeg>& segs, std::string&) const override {
+        out.put(texts[d], lens[d]);
+        out.put('\n');
+        segs.push_back(TermSeg{0, (uint64_t)lens[d] + 1, false});
         return COBS_GPU_OK;
     }
 };
@@ -149,15 +151,10 @@ struct ListSource final : DocSource {
     size_t size() const override { return list.size(); }
     const char* name(size_t d) const override { return list[d].name.c_str(); }
     uint64_t terms(size_t d, uint32_t k) const override { return num_terms(list[d], k); }
-    uint64_t bytes_hint(size_t d) const override {
-        const DocEntry& e = list[d];
-        if (e.type == FileType::Cortex || e.type == FileType::KMerBuffer) return e.term_count * (e.term_size + 1);
-        if (e.type == FileType::Memory) return e.text.size() + 1;
-        return e.size + 1;
-    }
+    uint64_t text_bound(size_t d, uint32_t k) const override { return term_text_bound(list[d], k); }
     bool parses() const override { return true; }
-    cobs_gpu_status load(size_t d, uint32_t k, std::string& text, std::vector<TermSeg>& segs) const override {
-        return load_terms(list[d], k, text, segs);
+    cobs_gpu_status load(size_t d, uint32_t k, TermSink& out, std::vector<TermSeg>& segs, std::string& scratch) const override {
+        return load_terms(list[d], k, out, segs, scratch);
     }
 };
 
@@ -166,18 +163,12 @@ struct ListSource final : DocSource {
 // batch and interleaves them afterwards; here every batch sets its bits straight at the documents'
 // final columns of the one matrix in HBM, so there is nothing to combine).
 constexpr uint64_t kTextBatchBytes = 256ull << 20;
-constexpr size_t kWindowDocs = 1024;            // documents parsed together by the host threads
 constexpr size_t kTextPad = 64;                 // readable bytes behind the text (build_kernel loads dwords)
 
-struct Loaded {
-    std::string text;
-    std::vector<TermSeg> segs;
-    cobs_gpu_status status = COBS_GPU_OK;
-    std::string error;
-};
-
-// one of the two staging sets: pinned text + stretch tables, their device copies, the event that
-// tells when the GPU is done with them
+// One of the two staging sets of a build: pinned term text + stretch tables, their device copies,
+// the event that tells when the GPU is done with them.  Host threads parse documents straight into
+// `text` (every document of a batch owns a span sized by its text bound; what it leaves unused is
+// a gap stretch the kernel skips), so a character is written once between the file and the H2D copy.
 struct Stage {
     PinnedBuf<uint8_t> text;
     PinnedBuf<uint64_t> seg_off;
@@ -185,10 +176,51 @@ struct Stage {
     DevBuf<uint8_t> d_text;
     DevBuf<uint64_t> d_off;
     DevBuf<uint32_t> d_col;
-    size_t fill = 0, nsegs = 0;
-    hipEvent_t done = nullptr;
+    hipEvent_t done = nullptr, copied = nullptr;
     bool busy = false;
-    ~Stage() { if (done) (void)hipEventDestroy(done); }
+    ~Stage() {
+        if (done) (void)hipEventDestroy(done);
+        if (copied) (void)hipEventDestroy(copied);
+    }
+};
+
+// Staging memory outlives a build: pinning 2 x 256 MiB costs more than hashing them.  The sets are
+// checked out per build and handed back; never freed (a static destructor would run after the HIP
+// runtime's own).
+struct StagePool {
+    std::mutex mu;
+    std::vector<Stage*> idle;
+    int device = -1;
+    Stage* take(int dev) {
+        std::lock_guard<std::mutex> g(mu);
+        if (device != dev) {                    // buffers belong to the device they were made on
+            for (Stage* s : idle) delete s;
+            idle.clear();
+            device = dev;
+        }
+        if (idle.empty()) return new Stage;
+        Stage* s = idle.back();
+        idle.pop_back();
+        return s;
+    }
+    void give(Stage* s) {
+        std::lock_guard<std::mutex> g(mu);
+        idle.push_back(s);
+    }
+};
+StagePool& stage_pool() {
+    static StagePool* pool = new StagePool;
+    return *pool;
+}
+
+struct Slot {                                   // one document of a batch
+    size_t doc_col;                             // its column
+    size_t src;                                 // its index in the source
+    uint64_t begin, cap;                        // its span of the staging text
+    uint64_t used = 0;
+    std::vector<TermSeg> segs;
+    cobs_gpu_status status = COBS_GPU_OK;
+    std::string error;
 };
 
 // Set the bits of documents docs[0..n) -- document docs[i] in column i -- in a zeroed device
@@ -197,111 +229,135 @@ cobs_gpu_status build_into(uint32_t* d_matrix, uint64_t sig, uint64_t row_bytes,
                            const size_t* docs, size_t n, const Params& pr) {
     const uint64_t text_batch = pr.text_batch ? pr.text_batch : kTextBatchBytes;
     if (sig == 0 || sig > (1ull << 46)) return cobs_gpu_set_error(COBS_GPU_ERR_UNSUPPORTED, "signature_size must be in 1..2^46");
-    if (n >= kBuildRawStretch) return cobs_gpu_set_error(COBS_GPU_ERR_UNSUPPORTED, "too many documents in one matrix");
-    hipStream_t stream = nullptr;
+    if (n >= (kBuildRawStretch - 1)) return cobs_gpu_set_error(COBS_GPU_ERR_UNSUPPORTED, "too many documents in one matrix");
+    int dev = 0;
+    BUILD_TRY(hipGetDevice(&dev));
+    // two streams: the upload of batch i + 1 runs beside the kernel of batch i
+    hipStream_t stream = nullptr, copy_stream = nullptr;
     BUILD_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } } sg{stream};
-    Stage stage[2];
-    for (Stage& s : stage) BUILD_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
-    int cur = 0;
-
-    auto begin = [&](Stage& s) -> cobs_gpu_status {
-        if (s.busy) { BUILD_TRY(hipEventSynchronize(s.done)); s.busy = false; }
-        s.fill = 0;
-        s.nsegs = 0;
-        return COBS_GPU_OK;
-    };
-    auto flush = [&](Stage& s) -> cobs_gpu_status {
-        if (s.fill == 0) return COBS_GPU_OK;
-        s.seg_off.p[s.nsegs] = s.fill;
-        BUILD_TRY(s.d_text.reserve(s.text.cap + kTextPad));
-        BUILD_TRY(s.d_off.reserve(s.seg_off.cap));
-        BUILD_TRY(s.d_col.reserve(s.seg_col.cap));
-        BUILD_TRY(hipMemcpyAsync(s.d_text.p, s.text.p, s.fill, hipMemcpyHostToDevice, stream));
-        BUILD_TRY(hipMemcpyAsync(s.d_off.p, s.seg_off.p, (s.nsegs + 1) * 8, hipMemcpyHostToDevice, stream));
-        BUILD_TRY(hipMemcpyAsync(s.d_col.p, s.seg_col.p, s.nsegs * 4, hipMemcpyHostToDevice, stream));
-        BuildArgs a;
-        a.text = s.d_text.p;
-        a.seg_off = s.d_off.p;
-        a.seg_col = s.d_col.p;
-        a.matrix = d_matrix;
-        a.signature_size = sig;
-        a.magic = ~0ull / sig;
-        a.row_bytes = row_bytes;
-        a.nsegs = (uint32_t)s.nsegs;
-        a.term_size = pr.term_size;
-        a.canonicalize = pr.canonicalize;
-        a.num_hashes = pr.num_hashes;
-        BUILD_TRY(launch_build(a, s.fill, stream));
-        BUILD_TRY(hipEventRecord(s.done, stream));
-        s.busy = true;
-        return COBS_GPU_OK;
-    };
-    // grow-only pinned arrays that keep their content
-    auto grow = [&](auto& buf, size_t need, size_t used) -> cobs_gpu_status {
-        if (need <= buf.cap) return COBS_GPU_OK;
-        std::remove_reference_t<decltype(buf)> bigger;
-        BUILD_TRY(bigger.reserve(std::max(need, buf.cap * 2)));
-        if (used) std::memcpy(bigger.p, buf.p, used * sizeof(*buf.p));
-        std::swap(buf.p, bigger.p);
-        std::swap(buf.cap, bigger.cap);
-        return COBS_GPU_OK;
-    };
+    struct Guard {
+        hipStream_t s, c = nullptr;
+        Stage* st[2];
+        ~Guard() {
+            if (c) { (void)hipStreamSynchronize(c); (void)hipStreamDestroy(c); }
+            (void)hipStreamSynchronize(s);
+            (void)hipStreamDestroy(s);
+            for (Stage* x : st) { x->busy = false; stage_pool().give(x); }
+        }
+    } guard{stream, nullptr, {stage_pool().take(dev), stage_pool().take(dev)}};
+    BUILD_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    guard.c = copy_stream;
+    Stage* stage[2] = {guard.st[0], guard.st[1]};
+    for (Stage* s : stage) {
+        if (!s->done) BUILD_TRY(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
+        if (!s->copied) BUILD_TRY(hipEventCreateWithFlags(&s->copied, hipEventDisableTiming));
+    }
 
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const size_t max_threads = src.parses() ? std::min<size_t>(hw, 64) : 1;
-    std::vector<Loaded> window;
-    cobs_gpu_status st = begin(stage[cur]);
-    if (st != COBS_GPU_OK) return st;
-    for (size_t w0 = 0; w0 < n;) {
-        // the next window: documents whose term text adds up to about one batch
-        size_t w1 = w0;
-        uint64_t hint = 0;
-        while (w1 < n && w1 - w0 < kWindowDocs && (w1 == w0 || hint + src.bytes_hint(docs[w1]) <= text_batch))
-            hint += src.bytes_hint(docs[w1++]);
-        window.assign(w1 - w0, Loaded{});
+    const size_t max_threads = src.parses() ? std::min<size_t>(hw, 64) : std::min<size_t>(hw, 8);
+    std::vector<Slot> slots;
+    std::vector<std::string> scratch(max_threads);      // the file being parsed, one per worker, reused
+    int cur = 0;
+    for (size_t b0 = 0; b0 < n;) {
+        // documents [b0, b1): as many as fit the batch by their text bounds (at least one)
+        slots.clear();
+        uint64_t total = 0;
+        size_t b1 = b0;
+        while (b1 < n) {
+            const uint64_t bound = src.text_bound(docs[b1], pr.term_size);
+            if (b1 > b0 && total + bound > text_batch) break;
+            Slot sl;
+            sl.doc_col = b1;
+            sl.src = docs[b1];
+            sl.begin = total;
+            sl.cap = bound;
+            slots.push_back(std::move(sl));
+            total += bound;
+            ++b1;
+        }
+        Stage& s = *stage[cur];
+        if (s.busy) { BUILD_TRY(hipEventSynchronize(s.done)); s.busy = false; }
+        BUILD_TRY(s.text.reserve((size_t)std::max<uint64_t>(total, text_batch) + kTextPad));
+        // parse: every worker takes the next document and writes its term text into its span
         std::atomic<size_t> next{0};
-        auto work = [&]() {
-            for (size_t i; (i = next.fetch_add(1)) < window.size();) {
-                Loaded& l = window[i];
-                l.status = src.load(docs[w0 + i], pr.term_size, l.text, l.segs);
-                if (l.status != COBS_GPU_OK) l.error = cobs_gpu_last_error();
+        auto work = [&](size_t tid) {
+            for (size_t i; (i = next.fetch_add(1)) < slots.size();) {
+                Slot& sl = slots[i];
+                TermSink sink;
+                sink.data = reinterpret_cast<char*>(s.text.p) + sl.begin;
+                sink.cap = (size_t)sl.cap;
+                sl.status = src.load(sl.src, pr.term_size, sink, sl.segs, scratch[tid]);
+                if (sl.status == COBS_GPU_OK && sink.overflow) {
+                    sl.status = COBS_GPU_ERR_FORMAT;
+                    sl.error = "a document outgrew the size its list entry recorded";
+                } else if (sl.status != COBS_GPU_OK) {
+                    sl.error = cobs_gpu_last_error();
+                }
+                sl.used = sink.size;
             }
         };
-        const size_t nthreads = std::min(max_threads, window.size());
+        const size_t nthreads = std::min(max_threads, slots.size());
         if (nthreads <= 1) {
-            work();
+            work(0);
         } else {
             std::vector<std::thread> pool;
-            for (size_t t = 0; t < nthreads; ++t) pool.emplace_back(work);
+            for (size_t t = 0; t < nthreads; ++t) pool.emplace_back(work, t);
             for (auto& t : pool) t.join();
         }
-        for (size_t i = 0; i < window.size(); ++i) {
-            Loaded& l = window[i];
-            if (l.status != COBS_GPU_OK) return cobs_gpu_set_error(l.status, l.error.c_str());
-            Stage* s = &stage[cur];
-            if (s->fill > 0 && s->fill + l.text.size() > text_batch) {
-                if ((st = flush(*s)) != COBS_GPU_OK) return st;
-                cur ^= 1;
-                s = &stage[cur];
-                if ((st = begin(*s)) != COBS_GPU_OK) return st;
-            }
-            if ((st = grow(s->text, s->fill + l.text.size() + 1, s->fill)) != COBS_GPU_OK) return st;
-            if ((st = grow(s->seg_off, s->nsegs + l.segs.size() + 1, s->nsegs)) != COBS_GPU_OK) return st;
-            if ((st = grow(s->seg_col, s->nsegs + l.segs.size() + 1, s->nsegs)) != COBS_GPU_OK) return st;
-            std::memcpy(s->text.p + s->fill, l.text.data(), l.text.size());
-            for (const TermSeg& g : l.segs) {
-                if (g.len == 0) continue;
-                s->seg_off.p[s->nsegs] = s->fill + g.begin;
-                s->seg_col.p[s->nsegs] = (uint32_t)(w0 + i) | (g.raw ? kBuildRawStretch : 0u);
-                ++s->nsegs;
-            }
-            s->fill += l.text.size();
-            std::string().swap(l.text);
+        // the stretch table: a document's stretches, the rest of its span as a gap
+        size_t nsegs = 0;
+        for (const Slot& sl : slots) {
+            if (sl.status != COBS_GPU_OK) return cobs_gpu_set_error(sl.status, sl.error.c_str());
+            nsegs += 2 * sl.segs.size() + 2;
         }
-        w0 = w1;
+        BUILD_TRY(s.seg_off.reserve(nsegs + 1));
+        BUILD_TRY(s.seg_col.reserve(nsegs + 1));
+        size_t ns = 0;
+        auto add = [&](uint64_t off, uint32_t col) {
+            if (ns && s.seg_off.p[ns - 1] == off) { s.seg_col.p[ns - 1] = col; return; }   // the previous one was empty
+            s.seg_off.p[ns] = off;
+            s.seg_col.p[ns] = col;
+            ++ns;
+        };
+        for (const Slot& sl : slots) {
+            uint64_t at = sl.begin;                         // everything before `at` is described
+            for (const TermSeg& g : sl.segs) {
+                if (g.len == 0) continue;
+                if (sl.begin + g.begin > at) add(at, kBuildGapStretch);
+                add(sl.begin + g.begin, (uint32_t)sl.doc_col | (g.raw ? kBuildRawStretch : 0u));
+                at = sl.begin + g.begin + g.len;
+            }
+            if (at < sl.begin + sl.cap) add(at, kBuildGapStretch);
+        }
+        s.seg_off.p[ns] = total;
+        if (ns && total) {
+            BUILD_TRY(s.d_text.reserve(s.text.cap));
+            BUILD_TRY(s.d_off.reserve(s.seg_off.cap));
+            BUILD_TRY(s.d_col.reserve(s.seg_col.cap));
+            BUILD_TRY(hipMemcpyAsync(s.d_text.p, s.text.p, (size_t)total, hipMemcpyHostToDevice, copy_stream));
+            BUILD_TRY(hipMemcpyAsync(s.d_off.p, s.seg_off.p, (ns + 1) * 8, hipMemcpyHostToDevice, copy_stream));
+            BUILD_TRY(hipMemcpyAsync(s.d_col.p, s.seg_col.p, ns * 4, hipMemcpyHostToDevice, copy_stream));
+            BUILD_TRY(hipEventRecord(s.copied, copy_stream));
+            BUILD_TRY(hipStreamWaitEvent(stream, s.copied, 0));
+            BuildArgs a;
+            a.text = s.d_text.p;
+            a.seg_off = s.d_off.p;
+            a.seg_col = s.d_col.p;
+            a.matrix = d_matrix;
+            a.signature_size = sig;
+            a.magic = ~0ull / sig;
+            a.row_bytes = row_bytes;
+            a.nsegs = (uint32_t)ns;
+            a.term_size = pr.term_size;
+            a.canonicalize = pr.canonicalize;
+            a.num_hashes = pr.num_hashes;
+            BUILD_TRY(launch_build(a, total, stream));
+            BUILD_TRY(hipEventRecord(s.done, stream));
+            s.busy = true;
+        }
+        cur ^= 1;                                           // the other set is parsed into while this one is hashed
+        b0 = b1;
     }
-    if ((st = flush(stage[cur])) != COBS_GPU_OK) return st;
     BUILD_TRY(hipStreamSynchronize(stream));
     return COBS_GPU_OK;
 }
@@ -680,9 +736,13 @@ cobs_gpu_status cobs_gpu_doclist_terms(const cobs_gpu_doclist* dl, size_t i, uin
     if (!dl || !n_terms || i >= dl->list.size() || term_size == 0 || (!out && cap_bytes))
         return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "bad argument");
     return guarded([&]() -> cobs_gpu_status {
-        std::string text;
+        const DocEntry& e = dl->list[i];
+        std::string text((size_t)term_text_bound(e, term_size), '\0'), scratch;
         std::vector<TermSeg> segs;
-        cobs_gpu_status st = load_terms(dl->list[i], term_size, text, segs);
+        TermSink sink;
+        sink.data = &text[0];
+        sink.cap = text.size();
+        cobs_gpu_status st = load_terms(e, term_size, sink, segs, scratch);
         if (st != COBS_GPU_OK) return st;
         uint64_t n = 0;
         const size_t k = term_size;

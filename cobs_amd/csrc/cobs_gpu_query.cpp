@@ -31,6 +31,8 @@ static void usage() {
                  "        one scan per GPU + one RCCL exchange (same results as on one GPU)\n"
                  "       (--load-complete and -T/--threads of `cobs query` are accepted and ignored: the index\n"
                  "        always lives in HBM, or is streamed through it under --hbm-budget)\n"
+                 "       cobs_gpu_query doc-list | doc-dump | classic-construct | compact-construct | classic-combine ...\n"
+                 "        (the construction sub-tools of `cobs`, same arguments; see cobs_gpu_tools.cpp)\n"
                  "       cobs_gpu_query --benchmark -i INDEX [-k KMERS] [-q QUERIES] [-w WARMUP] [--seed S]\n"
                  "       cobs_gpu_query --write-synthetic OUT (--classic -n DOCS -s ROWS | --compact -n DOCS -p PAGE_SIZE\n"
                  "                      -s ROWS_0,ROWS_1,...) [--num-hashes H] [--seed S] [-d DEVICE]\n"
@@ -73,7 +75,14 @@ static int benchmark(cobs_gpu::BatchSearch& s, const std::string& index, unsigne
     return 0;
 }
 
+int cobs_gpu_tools_main(int argc, char** argv);      // cobs_gpu_tools.cpp: doc-list, doc-dump, *-construct, classic-combine
+
 int main(int argc, char** argv) {
+    {
+        const int rc = cobs_gpu_tools_main(argc, argv);
+        if (rc >= 0) return rc;
+        if (argc > 1 && std::string(argv[1]) == "query") { ++argv; --argc; }       // `cobs query ...`
+    }
     std::vector<std::string> index_paths;
     std::string query_line, query_file;
     double threshold = 0.8;

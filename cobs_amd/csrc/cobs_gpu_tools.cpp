@@ -1,0 +1,229 @@
+// cobs_amd/csrc/cobs_gpu_tools.cpp -- the construction-side sub-tools of the reference's `cobs`
+// program on top of libcobs_gpu.so, with their flags and output (reference src/cobs.cpp):
+//
+//   cobs_gpu_query doc-list PATH [--file-type T] [-k K]                           (:75-99)
+//   cobs_gpu_query doc-dump PATH [--file-type T] [-k K] [--no-canonicalize]       (:101-158)
+//   cobs_gpu_query classic-construct INPUT OUT.cobs_classic [flags]               (:163-244)
+//   cobs_gpu_query compact-construct INPUT OUT.cobs_compact [flags] [-p PAGE]     (:294-380)
+//   cobs_gpu_query classic-combine IN_DIR OUT.cobs_classic                        (:?)
+//
+// Flags of the two constructors: --file-type, -h/--num-hashes, -f/--false-positive-rate,
+// -k/--term-size, --no-canonicalize, -C/--clobber, --continue; -m/--memory, -T/--threads,
+// --keep-temporary, --tmp-path are accepted and ignored (there are no temporary files: the matrix
+// is built in HBM), -d/--device selects the GPU.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <filesystem>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../../include/cobs_gpu.h"
+
+namespace {
+
+int fail() {
+    std::fprintf(stderr, "EXCEPTION: %s\n", cobs_gpu_last_error());
+    return 1;
+}
+
+struct List {
+    cobs_gpu_doclist* dl = nullptr;
+    ~List() { cobs_gpu_doclist_free(dl); }
+};
+
+bool open_list(List& l, const std::string& path, const std::string& file_type) {
+    uint32_t ft = 0;
+    if (cobs_gpu_filetype_from_string(file_type.c_str(), &ft) != COBS_GPU_OK) return false;
+    if (cobs_gpu_doclist_create(&l.dl) != COBS_GPU_OK) return false;
+    return cobs_gpu_doclist_add_recursive(l.dl, path.c_str(), ft) == COBS_GPU_OK;
+}
+
+// print_document_list, src/cobs.cpp:41-73
+void print_document_list(const cobs_gpu_doclist* dl, unsigned k, std::ostream& os) {
+    const size_t n = cobs_gpu_doclist_size(dl);
+    uint64_t min_kmers = ~0ull, max_kmers = 0, total = 0;
+    os << "--- document list (" << n << " entries) ---" << std::endl;
+    for (size_t i = 0; i < n; ++i) {
+        cobs_gpu_doc_entry e;
+        uint64_t terms = 0;
+        cobs_gpu_doclist_entry(dl, i, &e);
+        cobs_gpu_doclist_num_terms(dl, i, k, &terms);
+        std::error_code ec;
+        const auto fsize = e.type == COBS_GPU_FILETYPE_MEMORY ? e.size : (uint64_t)std::filesystem::file_size(e.path, ec);
+        os << "document[" << i << "] size " << fsize << " " << k << "-mers " << terms << " : " << e.path << " : "
+           << e.name << std::endl;
+        min_kmers = std::min(min_kmers, terms);
+        max_kmers = std::max(max_kmers, terms);
+        total += terms;
+    }
+    os << "--- end of document list (" << n << " entries) ---" << std::endl;
+    os << "documents: " << n << std::endl;
+    if (n != 0) {
+        os << "minimum " << k << "-mers: " << min_kmers << std::endl;
+        os << "maximum " << k << "-mers: " << max_kmers << std::endl;
+        os << "average " << k << "-mers: " << (uint64_t)((double)total / (double)n) << std::endl;
+        os << "total " << k << "-mers: " << total << std::endl;
+    }
+}
+
+// canonicalize_kmer (cobs/util/query.cpp:143-199) for the dump's output: the k-mer or its reverse
+// complement, decided by the first position (of the first half) where they differ; false for a
+// character outside ACGT
+bool canonical(const char* in, char* out, size_t k) {
+    auto comp = [](char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : '\0'; };
+    bool good = true;
+    for (size_t i = 0; i < k; ++i) good &= comp(in[i]) != '\0';
+    if (!good) return false;
+    bool reverse = false;
+    for (size_t i = 0; i < k / 2; ++i) {
+        const char f = in[i], r = comp(in[k - 1 - i]);
+        if (f < r) break;
+        if (f > r) { reverse = true; break; }
+    }
+    for (size_t i = 0; i < k; ++i) out[i] = reverse ? comp(in[k - 1 - i]) : in[i];
+    return true;
+}
+
+struct Args {
+    std::vector<std::string> positional;
+    std::string file_type = "any";
+    cobs_gpu_build_params p{};
+    bool no_canonicalize = false, clobber = false, cont = false;
+    bool parse(int argc, char** argv, bool compact) {
+        p.struct_size = sizeof p;
+        p.term_size = 31;
+        p.canonicalize = 1;
+        p.num_hashes = 1;
+        p.false_positive_rate = 0.3;
+        p.device = -1;
+        for (int i = 0; i < argc; ++i) {
+            const std::string a = argv[i];
+            auto need = [&]() -> const char* {
+                if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(1); }
+                return argv[++i];
+            };
+            if (a == "--file-type") file_type = need();
+            else if (a == "-h" || a == "--num-hashes") p.num_hashes = (uint32_t)std::strtoul(need(), nullptr, 10);
+            else if (a == "-f" || a == "--false-positive-rate") p.false_positive_rate = std::atof(need());
+            else if (a == "-k" || a == "--term-size") p.term_size = (uint32_t)std::strtoul(need(), nullptr, 10);
+            else if (compact && (a == "-p" || a == "--page-size")) p.page_size = std::strtoull(need(), nullptr, 10);
+            else if (a == "--no-canonicalize") no_canonicalize = true;
+            else if (a == "-C" || a == "--clobber") clobber = true;
+            else if (a == "--continue") cont = true;
+            else if (a == "-d" || a == "--device") p.device = std::atoi(need());
+            else if (a == "-m" || a == "--memory" || a == "-T" || a == "--threads" || a == "--tmp-path") (void)need();
+            else if (a == "--keep-temporary") {}
+            else if (!a.empty() && a[0] == '-' && a.size() > 1) { std::fprintf(stderr, "unknown flag %s\n", a.c_str()); return false; }
+            else positional.push_back(a);
+        }
+        p.canonicalize = no_canonicalize ? 0 : 1;
+        return true;
+    }
+};
+
+bool ends_with(const std::string& s, const char* suffix) {
+    const size_t n = std::strlen(suffix);
+    return s.size() >= n && s.compare(s.size() - n, n, suffix) == 0;
+}
+
+int construct(int argc, char** argv, bool compact) {
+    Args a;
+    if (!a.parse(argc, argv, compact) || a.positional.size() != 2) {
+        std::fprintf(stderr, "usage: cobs_gpu_query %s INPUT OUT_FILE [--file-type T] [-h HASHES] [-f FPR] [-k K]%s "
+                             "[--no-canonicalize] [-C] [-d DEVICE]\n",
+                     compact ? "compact-construct" : "classic-construct", compact ? " [-p PAGE_SIZE]" : "");
+        return 1;
+    }
+    const std::string &input = a.positional[0], &out = a.positional[1];
+    const char* ext = compact ? ".cobs_compact" : ".cobs_classic";
+    if (!ends_with(out, ext)) {       // classic_index.cpp:596-599, compact_index.cpp:176-179
+        std::fprintf(stderr, "Error: COBS index file must end with %s\n", ext);
+        return 1;
+    }
+    if (std::filesystem::exists(out) && !a.clobber && !a.cont) {      // classic_index.cpp:602-612
+        std::fprintf(stderr, "Output file exists, will not overwrite without --clobber\n");
+        return 1;
+    }
+    List l;
+    if (!open_list(l, input, a.file_type)) return fail();
+    print_document_list(l.dl, a.p.term_size, std::cout);
+    const cobs_gpu_status st = compact ? cobs_gpu_build_compact_list(l.dl, &a.p, out.c_str())
+                                       : cobs_gpu_build_classic_list(l.dl, &a.p, out.c_str());
+    return st == COBS_GPU_OK ? 0 : fail();
+}
+
+}  // namespace
+
+// -> -1 if argv[1] is not one of the sub-tools, else the exit code
+int cobs_gpu_tools_main(int argc, char** argv) {
+    if (argc < 2) return -1;
+    const std::string tool = argv[1];
+    if (tool == "classic-construct") return construct(argc - 2, argv + 2, false);
+    if (tool == "compact-construct") return construct(argc - 2, argv + 2, true);
+    if (tool == "doc-list" || tool == "doc-dump") {
+        Args a;
+        if (!a.parse(argc - 2, argv + 2, false) || a.positional.size() != 1) {
+            std::fprintf(stderr, "usage: cobs_gpu_query %s PATH [--file-type T] [-k K]%s\n", tool.c_str(),
+                         tool == "doc-dump" ? " [--no-canonicalize]" : "");
+            return 1;
+        }
+        List l;
+        if (!open_list(l, a.positional[0], a.file_type)) return fail();
+        const unsigned k = a.p.term_size;
+        if (tool == "doc-list") {
+            print_document_list(l.dl, k, std::cout);
+            return 0;
+        }
+        const size_t n = cobs_gpu_doclist_size(l.dl);
+        std::cerr << "Found " << n << " documents." << std::endl;
+        std::vector<char> terms, canon(k);
+        for (size_t i = 0; i < n; ++i) {
+            cobs_gpu_doc_entry e;
+            cobs_gpu_doclist_entry(l.dl, i, &e);
+            std::cerr << "document[" << i << "] : " << e.path << " : " << e.name << std::endl;
+            uint64_t nt = 0;
+            if (cobs_gpu_doclist_terms(l.dl, i, k, nullptr, 0, &nt) != COBS_GPU_OK) return fail();
+            terms.resize((size_t)nt * k + 1);
+            if (cobs_gpu_doclist_terms(l.dl, i, k, terms.data(), (size_t)nt * k, &nt) != COBS_GPU_OK) return fail();
+            for (uint64_t t = 0; t < nt; ++t) {
+                const char* term = terms.data() + t * k;
+                if (a.no_canonicalize) std::cout.write(term, k) << '\n';
+                else if (canonical(term, canon.data(), k)) std::cout.write(canon.data(), k) << '\n';
+                else (std::cout << "Invalid DNA base pair: ").write(term, k) << std::endl;
+            }
+            std::cout.flush();
+            uint64_t listed = 0;
+            cobs_gpu_doclist_num_terms(l.dl, i, k, &listed);
+            std::cerr << "document[" << i << "] : " << listed << " terms." << std::endl;
+        }
+        return 0;
+    }
+    if (tool == "classic-combine") {
+        // `cobs classic-combine IN_DIR OUT_FILE`: the .cobs_classic files of a directory, in path order
+        std::vector<std::string> pos;
+        int device = -1;
+        uint64_t mem = 0;
+        for (int i = 2; i < argc; ++i) {
+            const std::string a = argv[i];
+            if ((a == "-d" || a == "--device") && i + 1 < argc) device = std::atoi(argv[++i]);
+            else if ((a == "-m" || a == "--memory") && i + 1 < argc) mem = std::strtoull(argv[++i], nullptr, 10);
+            else if ((a == "-T" || a == "--threads") && i + 1 < argc) ++i;
+            else if (a == "--keep-temporary") {}
+            else pos.push_back(a);
+        }
+        if (pos.size() != 2) { std::fprintf(stderr, "usage: cobs_gpu_query classic-combine IN_DIR OUT_FILE [-m BYTES] [-d DEVICE]\n"); return 1; }
+        std::vector<std::string> files;
+        std::error_code ec;
+        for (std::filesystem::recursive_directory_iterator it(pos[0], ec), end; !ec && it != end; it.increment(ec))
+            if (!it->is_directory() && ends_with(it->path().string(), ".cobs_classic")) files.push_back(it->path().string());
+        std::sort(files.begin(), files.end());
+        if (files.empty()) { std::fprintf(stderr, "no .cobs_classic files in %s\n", pos[0].c_str()); return 1; }
+        std::vector<const char*> cp;
+        for (auto& f : files) cp.push_back(f.c_str());
+        return cobs_gpu_combine_classic(cp.data(), cp.size(), pos[1].c_str(), mem, device) == COBS_GPU_OK ? 0 : fail();
+    }
+    return -1;
+}

@@ -100,6 +100,8 @@ struct TopkArgs {
 // a stretch of term text whose k-grams are all terms (newlines included); otherwise a stretch is
 // sequences each followed by '\n' and no term holds a '\n'
 constexpr uint32_t kBuildRawStretch = 0x80000000u;
+// a stretch that holds no term text at all (the unused rest of a document's span of the staging buffer)
+constexpr uint32_t kBuildGapStretch = 0xFFFFFFFFu;
 
 struct BuildArgs {
     const uint8_t* text;        // stretches of term text back to back (documents.hpp); the buffer is

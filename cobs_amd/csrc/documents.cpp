@@ -19,9 +19,11 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <filesystem>
+#include <thread>
 #include <tuple>
 
 namespace fs = std::filesystem;
@@ -59,14 +61,17 @@ cobs_gpu_status read_file(const std::string& path, bool gunzip, std::string& dat
     }
     FILE* f = std::fopen(path.c_str(), "rb");
     if (!f) return err(COBS_GPU_ERR_OPEN, "could not open document " + path);
-    std::error_code ec;
-    const auto sz = fs::file_size(path, ec);
-    if (!ec) data.reserve((size_t)sz);
-    char buf[1 << 16];
-    size_t n;
-    while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) data.append(buf, n);
+    // `data` is a scratch buffer its caller reuses: growing it is the only allocation
+    size_t have = 0;
+    for (;;) {
+        if (data.size() < have + (1u << 20)) data.resize(std::max<size_t>(data.size() * 2, have + (1u << 20)));
+        const size_t n = std::fread(&data[have], 1, data.size() - have, f);
+        have += n;
+        if (n == 0) break;
+    }
     const bool bad = std::ferror(f) != 0;
     std::fclose(f);
+    data.resize(have);
     return bad ? err(COBS_GPU_ERR_OPEN, "read error in " + path) : COBS_GPU_OK;
 }
 
@@ -103,7 +108,7 @@ std::string pad_index(uint64_t i, int width = 6) {      // cobs/util/misc.hpp:57
 // which are copied from offset wb - (k - 1), i.e. measured from the bytes READ, not from the
 // buffer's fill pos + wb; from the second refill on the carried characters are therefore not the
 // last ones.  Each buffer state is one raw stretch of term text.
-cobs_gpu_status text_terms(const std::string& data, uint32_t k, std::string& text, std::vector<TermSeg>& segs) {
+cobs_gpu_status text_terms(const std::string& data, uint32_t k, TermSink& out, std::vector<TermSeg>& segs) {
     constexpr size_t kBuf = 64 * 1024;
     if (k == 0 || k > kBuf) return err(COBS_GPU_ERR_UNSUPPORTED, "term size does not fit the text reader's buffer");
     std::vector<char> buffer(kBuf);
@@ -116,8 +121,8 @@ cobs_gpu_status text_terms(const std::string& data, uint32_t k, std::string& tex
         off += wb;
         eof = wb < want;                            // istream::read sets eofbit when it comes up short
         if (pos + wb >= k) {
-            segs.push_back(TermSeg{(uint64_t)text.size(), (uint64_t)(pos + wb), true});
-            text.append(buffer.data(), pos + wb);
+            segs.push_back(TermSeg{(uint64_t)out.size, (uint64_t)(pos + wb), true});
+            out.put(buffer.data(), pos + wb);
         }
         if (wb + 1 < k) break;
         std::memmove(buffer.data(), buffer.data() + wb - (k - 1), k - 1);
@@ -130,12 +135,14 @@ cobs_gpu_status text_terms(const std::string& data, uint32_t k, std::string& tex
 // The string of a packed k-mer reads its bytes from the last to the first, each byte its four
 // bases from the high bit pair down (00 A, 01 C, 10 G, 11 T); a k-mer whose length is not a
 // multiple of four leaves out the first 4 - k % 4 bases of the first byte read.
-void unpack_kmer(const uint8_t* packed, uint32_t kmer_size, std::string& out) {
+void unpack_kmer(const uint8_t* packed, uint32_t kmer_size, TermSink& out) {
     const uint32_t nbytes = (kmer_size + 3) / 4;
+    char buf[4];
     for (uint32_t i = 0; i < nbytes; ++i) {
         const uint8_t b = packed[nbytes - 1 - i];
         const uint32_t first = (i == 0 && kmer_size % 4 != 0) ? 4 - kmer_size % 4 : 0;
-        for (uint32_t j = first; j < 4; ++j) out.push_back("ACGT"[(b >> (6 - 2 * j)) & 3]);
+        for (uint32_t j = 0; j < 4; ++j) buf[j] = "ACGT"[(b >> (6 - 2 * j)) & 3];
+        out.put(buf + first, 4 - first);
     }
 }
 
@@ -194,22 +201,21 @@ uint64_t cortex_num_kmers(const CortexHeader& h, size_t file_size) {
 
 // one record = the packed k-mer (8 * words bytes) + 5 bytes of colour data; the k-mer string is a
 // sequence of its own (cortex_file.hpp:118-152)
-cobs_gpu_status cortex_terms(const std::string& d, const std::string& path, uint32_t k, std::string& text,
+cobs_gpu_status cortex_terms(const std::string& d, const std::string& path, uint32_t k, TermSink& out,
                              std::vector<TermSeg>& segs) {
     CortexHeader h;
     cobs_gpu_status st = cortex_header(d, path, h);
     if (st != COBS_GPU_OK) return st;
     const uint64_t n = cortex_num_kmers(h, d.size());
     const size_t rec = 8 * (size_t)h.words + 5 * (size_t)h.colors;
-    const uint64_t begin = text.size();
+    const uint64_t begin = out.size;
     if (k <= h.kmer_size) {
-        text.reserve(text.size() + (size_t)n * (h.kmer_size + 1));
         for (uint64_t r = 0; r < n; ++r) {
-            unpack_kmer((const uint8_t*)d.data() + h.data_begin + r * rec, h.kmer_size, text);
-            text.push_back('\n');
+            unpack_kmer((const uint8_t*)d.data() + h.data_begin + r * rec, h.kmer_size, out);
+            out.put('\n');
         }
     }
-    segs.push_back(TermSeg{begin, (uint64_t)text.size() - begin, false});
+    segs.push_back(TermSeg{begin, (uint64_t)out.size - begin, false});
     return COBS_GPU_OK;
 }
 
@@ -243,7 +249,7 @@ cobs_gpu_status kmer_buffer_header(const std::string& d, const std::string& path
     return COBS_GPU_OK;
 }
 
-cobs_gpu_status kmer_buffer_terms(const std::string& d, const std::string& path, uint32_t k, std::string& text,
+cobs_gpu_status kmer_buffer_terms(const std::string& d, const std::string& path, uint32_t k, TermSink& out,
                                   std::vector<TermSeg>& segs) {
     KMerBufferHeader h;
     cobs_gpu_status st = kmer_buffer_header(d, path, h);
@@ -252,13 +258,12 @@ cobs_gpu_status kmer_buffer_terms(const std::string& d, const std::string& path,
     if (k != 31 || h.kmer_size != 31) return err(COBS_GPU_ERR_UNSUPPORTED, ".cobs_doc documents hold 31-mers only: " + path);
     const size_t rec = 8;
     const uint64_t n = (d.size() - h.data_begin) / rec;
-    const uint64_t begin = text.size();
-    text.reserve(text.size() + (size_t)n * 32);
+    const uint64_t begin = out.size;
     for (uint64_t r = 0; r < n; ++r) {
-        unpack_kmer((const uint8_t*)d.data() + h.data_begin + r * rec, 31, text);
-        text.push_back('\n');
+        unpack_kmer((const uint8_t*)d.data() + h.data_begin + r * rec, 31, out);
+        out.put('\n');
     }
-    segs.push_back(TermSeg{begin, (uint64_t)text.size() - begin, false});
+    segs.push_back(TermSeg{begin, (uint64_t)out.size - begin, false});
     return COBS_GPU_OK;
 }
 
@@ -302,22 +307,22 @@ cobs_gpu_status fasta_index(const std::string& d, const std::string& path, DocEn
 // into it) and keeps its old value k - 1 after the string was cleared (a line of exactly k - 1
 // characters then counts as empty; a shorter one is read past its end, taken as sequence here).
 // Emitted: each sequence so far as one line of term text.
-void fasta_terms(const std::string& d, uint32_t k, std::string& text) {
-    std::string cur;                 // the sequence being collected (all of it, not only the kept tail)
+void fasta_terms(const std::string& d, uint32_t k, TermSink& out) {
+    size_t run_begin = out.size;     // the sequence being collected lies at out.data[run_begin, out.size)
     size_t held = 0, pos = 0;        // held = how many of its characters the reference still has
     auto flush = [&]() {
-        if (!cur.empty()) { text += cur; text.push_back('\n'); }
-        cur.clear();
+        if (out.size > run_begin) out.put('\n');
+        run_begin = out.size;
         held = 0;
     };
     for_lines(d, 0, [&](const char* ln, size_t n, size_t) {
         const size_t size = held + n;
         bool comment;
         if (size == pos) comment = true;
-        else if (pos < size) comment = is_comment(pos < held ? cur[cur.size() - held + pos] : ln[pos - held]);
+        else if (pos < size) comment = is_comment(pos < held ? out.data[out.size - held + pos] : ln[pos - held]);
         else comment = false;
         if (comment) { flush(); return true; }
-        cur.append(ln, n);
+        out.put(ln, n);
         if (size > k - 1) { held = k - 1; pos = k - 1; }
         else { held = size; pos = 0; }
         return true;
@@ -328,7 +333,7 @@ void fasta_terms(const std::string& d, uint32_t k, std::string& text) {
 // ---- FASTQ ------------------------------------------------------------------------------------
 // compute_index / process_terms (fastq_file.hpp:53-86, 163-182): records of four lines, the second
 // is the read
-cobs_gpu_status fastq_scan(const std::string& d, const std::string& path, DocEntry* index, std::string* text) {
+cobs_gpu_status fastq_scan(const std::string& d, const std::string& path, DocEntry* index, TermSink* text) {
     uint64_t line_num = 0, size = 0;
     std::string bad;
     for_lines(d, 0, [&](const char* ln, size_t n, size_t) {
@@ -339,7 +344,7 @@ cobs_gpu_status fastq_scan(const std::string& d, const std::string& path, DocEnt
             break;
         case 1:
             if (index) ++index->run_hist[n];
-            if (text) { text->append(ln, n); text->push_back('\n'); }
+            if (text) { text->put(ln, n); text->put('\n'); }
             break;
         case 2:
             if (n == 0 || ln[0] != '+') bad = " does not start with + - ";
@@ -384,24 +389,25 @@ cobs_gpu_status mfasta_index(const std::string& d, const std::string& path, std:
 // FastaSubfile::process_terms (fasta_multifile.hpp:38-63): lines are appended to one string whose
 // k-grams are emitted, then `data.erase(0, data.size() - k + 1)` keeps the last k - 1 characters --
 // computed in size_t, so a string shorter than k - 1 is erased completely.
-void mfasta_terms(const std::string& d, uint64_t pos_begin, uint32_t k, std::string& text) {
-    std::string cur;
+void mfasta_terms(const std::string& d, uint64_t pos_begin, uint32_t k, TermSink& out) {
+    size_t run_begin = out.size;     // the sequence so far lies at out.data[run_begin, out.size)
     size_t held = 0;
+    auto end_run = [&]() {
+        if (out.size - run_begin >= k) out.put('\n');
+        else out.size = run_begin;                  // no term in it: leave nothing behind
+        run_begin = out.size;
+        held = 0;
+    };
     for_lines(d, (size_t)pos_begin, [&](const char* ln, size_t n, size_t) {
         if (n && is_comment(ln[0])) return false;
         if (held + n == 0) return true;
-        cur.append(ln, n);
+        out.put(ln, n);
         const size_t size = held + n;
-        if (size + 1 < k) {                 // everything is dropped: the sequence so far ends here
-            if (cur.size() >= k) { text += cur; text.push_back('\n'); }
-            cur.clear();
-            held = 0;
-        } else {
-            held = k - 1;
-        }
+        if (size + 1 < k) end_run();        // everything is dropped: the sequence so far ends here
+        else held = k - 1;
         return true;
     });
-    if (cur.size() >= k) { text += cur; text.push_back('\n'); }
+    end_run();
 }
 
 }  // namespace
@@ -477,6 +483,7 @@ cobs_gpu_status load_entries(const std::string& path, std::vector<DocEntry>& out
     case FileType::Fasta: {
         if ((st = read_file(path, true, d)) != COBS_GPU_OK) return st;
         if ((st = fasta_index(d, path, e)) != COBS_GPU_OK) return st;
+        e.data_bytes = d.size();
         e.name = base_name(path);
         out.push_back(std::move(e));
         return COBS_GPU_OK;
@@ -484,6 +491,7 @@ cobs_gpu_status load_entries(const std::string& path, std::vector<DocEntry>& out
     case FileType::Fastq: {
         if ((st = read_file(path, true, d)) != COBS_GPU_OK) return st;
         if ((st = fastq_scan(d, path, &e, nullptr)) != COBS_GPU_OK) return st;
+        e.data_bytes = d.size();
         e.name = base_name(path);
         out.push_back(std::move(e));
         return COBS_GPU_OK;
@@ -549,16 +557,37 @@ cobs_gpu_status add_recursive(const std::string& root, FileType filter, std::vec
     }
     std::sort(paths.begin(), paths.end());
     const bool single = paths.size() == 1 && paths[0] == root;
-    for (const std::string& p : paths) {
-        std::vector<DocEntry> l;
+    // the index pass reads every file once; host threads share the files (the reference runs
+    // this loop in a parallel_for too, :387-403)
+    struct Loaded {
+        std::vector<DocEntry> entries;
+        cobs_gpu_status status = COBS_GPU_OK;
+        std::string error;
+    };
+    std::vector<Loaded> loaded(paths.size());
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (size_t i; (i = next.fetch_add(1)) < paths.size();) {
+            loaded[i].status = load_entries(paths[i], loaded[i].entries);
+            if (loaded[i].status != COBS_GPU_OK) loaded[i].error = cobs_gpu_last_error();
+        }
+    };
+    const size_t nthreads = std::min<size_t>({paths.size(), std::max(1u, std::thread::hardware_concurrency()), 64});
+    if (nthreads <= 1) {
+        work();
+    } else {
+        std::vector<std::thread> pool;
+        for (size_t t = 0; t < nthreads; ++t) pool.emplace_back(work);
+        for (auto& t : pool) t.join();
+    }
+    for (Loaded& l : loaded) {
+        if (l.status != COBS_GPU_OK && single) return err(l.status, l.error);
         // a file that cannot be read is reported and left out, the scan goes on (:393-402)
-        const cobs_gpu_status st = load_entries(p, l);
-        if (st != COBS_GPU_OK && single) return st;
-        if (st != COBS_GPU_OK) {
-            std::fprintf(stderr, "EXCEPTION: %s\n", cobs_gpu_last_error());
+        if (l.status != COBS_GPU_OK) {
+            std::fprintf(stderr, "EXCEPTION: %s\n", l.error.c_str());
             continue;
         }
-        for (DocEntry& e : l) list.push_back(std::move(e));
+        for (DocEntry& e : l.entries) list.push_back(std::move(e));
     }
     sort_entries(list, COBS_GPU_SORT_BY_PATH);
     return COBS_GPU_OK;
@@ -599,41 +628,67 @@ uint64_t num_terms(const DocEntry& e, uint32_t k) {          // document_list.hp
     }
 }
 
-cobs_gpu_status load_terms(const DocEntry& e, uint32_t k, std::string& text, std::vector<TermSeg>& segs) {
+uint64_t term_text_bound(const DocEntry& e, uint32_t k) {
+    switch (e.type) {
+    case FileType::Text:        // one stretch per refill of the reader's buffer, each carrying k - 1 characters over
+        return e.size + (uint64_t)(k - 1) * (e.size / (64 * 1024 - std::min<uint64_t>(k - 1, 64 * 1024 - 1)) + 2);
+    case FileType::Cortex:
+    case FileType::KMerBuffer:
+        return e.term_count * (e.term_size + 1);
+    case FileType::Memory:
+        return e.text.size() + 1;
+    case FileType::Fasta:
+    case FileType::Fastq:       // line formats: every sequence costs its characters plus one separator
+        return e.data_bytes + 1;
+    default:
+        return e.size + 1;
+    }
+}
+
+cobs_gpu_status load_terms(const DocEntry& e, uint32_t k, TermSink& out, std::vector<TermSeg>& segs, std::string& d) {
     if (k == 0) return err(COBS_GPU_ERR_ARG, "term size 0");
-    std::string d;
-    cobs_gpu_status st;
-    const uint64_t begin = text.size();
+    cobs_gpu_status st = COBS_GPU_OK;
+    const uint64_t begin = out.size;
+    bool one_stretch = true;
     switch (e.type) {
     case FileType::Memory:
-        text += e.text;
-        text.push_back('\n');
+        out.put(e.text.data(), e.text.size());
+        out.put('\n');
         break;
     case FileType::Text:
         if ((st = read_file(e.path, false, d)) != COBS_GPU_OK) return st;
-        return text_terms(d, k, text, segs);
+        st = text_terms(d, k, out, segs);
+        one_stretch = false;
+        break;
     case FileType::Cortex:
         if ((st = read_file(e.path, false, d)) != COBS_GPU_OK) return st;
-        return cortex_terms(d, e.path, k, text, segs);
+        st = cortex_terms(d, e.path, k, out, segs);
+        one_stretch = false;
+        break;
     case FileType::KMerBuffer:
         if ((st = read_file(e.path, false, d)) != COBS_GPU_OK) return st;
-        return kmer_buffer_terms(d, e.path, k, text, segs);
+        st = kmer_buffer_terms(d, e.path, k, out, segs);
+        one_stretch = false;
+        break;
     case FileType::Fasta:
         if ((st = read_file(e.path, true, d)) != COBS_GPU_OK) return st;
-        fasta_terms(d, k, text);
+        fasta_terms(d, k, out);
         break;
     case FileType::Fastq:
         if ((st = read_file(e.path, true, d)) != COBS_GPU_OK) return st;
-        if ((st = fastq_scan(d, e.path, nullptr, &text)) != COBS_GPU_OK) return st;
+        if ((st = fastq_scan(d, e.path, nullptr, &out)) != COBS_GPU_OK) return st;
         break;
     case FileType::FastaMulti:
         if ((st = read_file(e.path, false, d)) != COBS_GPU_OK) return st;
-        mfasta_terms(d, e.pos_begin, k, text);
+        mfasta_terms(d, e.pos_begin, k, out);
         break;
     default:
         return err(COBS_GPU_ERR_FORMAT, "DocumentEntry: unknown file type");
     }
-    segs.push_back(TermSeg{begin, (uint64_t)text.size() - begin, false});
+    if (st != COBS_GPU_OK) return st;
+    // the space was sized from what the list recorded about the file (term_text_bound)
+    if (out.overflow) return err(COBS_GPU_ERR_FORMAT, "document changed since it was listed: " + e.path);
+    if (one_stretch) segs.push_back(TermSeg{begin, (uint64_t)out.size - begin, false});
     return COBS_GPU_OK;
 }
 

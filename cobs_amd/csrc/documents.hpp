@@ -6,6 +6,7 @@
 #pragma once
 
 #include <cstdint>
+#include <cstring>
 #include <map>
 #include <string>
 #include <vector>
@@ -30,10 +31,24 @@ struct DocEntry {
     uint64_t size = 0, subdoc_index = 0, term_size = 0, term_count = 0;
     std::map<uint64_t, uint64_t> run_hist;   // Fasta / Fastq: sequence length -> how many
     uint64_t pos_begin = 0;                  // FastaMulti: file offset of the sub-document's first line
+    uint64_t data_bytes = 0;                 // Fasta / Fastq: (inflated) bytes of the file when it was listed
     std::string text;                        // Memory: sequences joined by '\n'
 };
 
-// One stretch of term text.  raw = every k-gram inside [begin, begin + len) is a term (newlines
+// Where a reader writes term text: a caller-provided span (pinned staging memory during a build).
+struct TermSink {
+    char* data = nullptr;
+    size_t cap = 0, size = 0;
+    bool overflow = false;
+    void put(const char* p, size_t n) {
+        if (size + n > cap) { overflow = true; return; }
+        std::memcpy(data + size, p, n);
+        size += n;
+    }
+    void put(char c) { put(&c, 1); }
+};
+
+// One stretch of term text (offsets relative to the sink).  raw = every k-gram inside [begin, begin + len) is a term (newlines
 // are ordinary characters); otherwise the stretch is sequences each FOLLOWED by '\n' and no term
 // holds a '\n'.
 struct TermSeg {
@@ -51,8 +66,11 @@ cobs_gpu_status add_recursive(const std::string& root, FileType filter, std::vec
 void sort_entries(std::vector<DocEntry>& list, uint32_t by);
 //! DocumentEntry::num_terms(k) -- the count that sizes a signature
 uint64_t num_terms(const DocEntry& e, uint32_t k);
-//! DocumentEntry::process_terms(k) as term text appended to `text`
-cobs_gpu_status load_terms(const DocEntry& e, uint32_t k, std::string& text, std::vector<TermSeg>& segs);
+//! an upper bound of the term text load_terms writes for this entry
+uint64_t term_text_bound(const DocEntry& e, uint32_t k);
+//! DocumentEntry::process_terms(k) as term text written to `out`; `scratch` holds the file while it
+//! is parsed (reused by the caller from document to document)
+cobs_gpu_status load_terms(const DocEntry& e, uint32_t k, TermSink& out, std::vector<TermSeg>& segs, std::string& scratch);
 
 }  // namespace cobs_amd
 

@@ -1222,6 +1222,7 @@ __global__ __launch_bounds__(256) void build_kernel(BuildArgs a, uint64_t total_
     const uint32_t k = a.term_size;
     if (gid + k > a.seg_off[lo + 1]) return;          // the term would leave its stretch
     const uint32_t colw = a.seg_col[lo];
+    if (colw == kBuildGapStretch) return;
     const bool raw = (colw & kBuildRawStretch) != 0u;
     const uint32_t doc = colw & ~kBuildRawStretch;
     const uint64_t byte_in_row = doc >> 3;

@@ -244,3 +244,34 @@ def test_list_files_filters_and_sorting(capi, docdir, tmp_path):
     dl.add_document("mem", [b"ACGTACGTAC", b"", b"GGGTTTAAACCC"])
     assert dl[0].type == capi.FileType.Memory and dl[0].num_terms(4) == 7 + 9 and len(dl[0].terms(4)) == 16
     assert dl[0].terms(11) == [b"GGGTTTAAACC", b"GGTTTAAACCC"]
+
+
+def test_doc_list_and_doc_dump_tools(docdir):
+    """`cobs doc-list` / `cobs doc-dump` (reference src/cobs.cpp:41-158): host-only sub-tools of
+    cobs_gpu_query, same output"""
+    import subprocess
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cobs_amd", "cobs_gpu_query")
+    root = os.path.join(docdir, "fastq")
+    r = subprocess.run([tool, "doc-list", root], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    ents = D.document_list(root)
+    want = "--- document list (3 entries) ---\n"
+    for i, e in enumerate(ents):
+        want += "document[%d] size %d 31-mers %d : %s : %s\n" % (i, os.path.getsize(e.path), e.num_terms(31), e.path, e.name)
+    terms = [e.num_terms(31) for e in ents]
+    want += "--- end of document list (3 entries) ---\ndocuments: 3\n"
+    want += "minimum 31-mers: %d\nmaximum 31-mers: %d\naverage 31-mers: %d\ntotal 31-mers: %d\n" % (
+        min(terms), max(terms), sum(terms) // 3, sum(terms))
+    assert r.stdout == want
+    # doc-dump: raw terms, and canonical terms (reverse complement where that is smaller)
+    p = os.path.join(docdir, "fasta_multi", "sample2.mfasta")
+    r = subprocess.run([tool, "doc-dump", p, "--no-canonicalize", "-k", "21"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.encode() == b"".join(t + b"\n" for e in D.document_list(p) for t in e.terms(21))
+    assert "Found 5 documents." in r.stderr and "document[4] : %d terms." % D.document_list(p)[4].num_terms(21) in r.stderr
+    from oracle import oracle as O
+    O.build()
+    p = os.path.join(docdir, "cortex", "sample1-k31.ctx")
+    r = subprocess.run([tool, "doc-dump", p], capture_output=True, text=True, timeout=120)
+    assert r.stdout.encode() == b"".join(O.canonicalize_kmer(t)[0] + b"\n" for t in D.load(p)[0].terms(31))
+    r = subprocess.run([tool, "doc-dump", os.path.join(docdir, "text", "sample1.txt")], capture_output=True, text=True, timeout=120)
+    assert r.stdout.startswith("Invalid DNA base pair: Hello, this is the first sample\n")

@@ -116,3 +116,53 @@ def test_sharded_class_and_generator_tool(gpu_lib, oracle, golden_dir, tmp_path)
     ixr = oracle.Index.open(rnd)
     assert (ixr.num_docs, ixr.num_hashes, ixr.term_size, ixr.signature_size(0)) == (40, 2, 31, 5003)
     assert ixr.doc_name(39) == "file_000039"
+
+
+def test_construction_sub_tools(gpu_lib, oracle, golden_dir, tmp_path):
+    """`cobs classic-construct`, `compact-construct`, `classic-combine`, then `query` (reference
+    src/cobs.cpp:163-244, :294-380, :1044-1060): flags of the reference, the index files of the
+    golden fixtures, and the reference's refusal rules"""
+    fasta = os.path.join(golden_dir, "fasta")
+    pc, pk = str(tmp_path / "c.cobs_classic"), str(tmp_path / "c.cobs_compact")
+    r = _run("classic-construct", fasta, pc)
+    assert r.returncode == 0, r.stderr
+    assert "--- document list (7 entries) ---" in r.stdout and "maximum 31-mers: 3120" in r.stdout
+    assert open(pc, "rb").read() == open(os.path.join(golden_dir, "c1.cobs_classic"), "rb").read()
+    r = _run("compact-construct", fasta, pk, "-T", "4", "-m", "1000000")
+    assert r.returncode == 0, r.stderr
+    assert open(pk, "rb").read() == open(os.path.join(golden_dir, "c1.cobs_compact"), "rb").read()
+    # will not overwrite without --clobber; wrong extension; unknown file type
+    r = _run("classic-construct", fasta, pc)
+    assert r.returncode != 0 and "will not overwrite without --clobber" in r.stderr
+    assert _run("classic-construct", fasta, pc, "-C").returncode == 0
+    r = _run("compact-construct", fasta, str(tmp_path / "x.cobs_classic"))
+    assert r.returncode != 0 and "must end with .cobs_compact" in r.stderr
+    r = _run("classic-construct", fasta, str(tmp_path / "y.cobs_classic"), "--file-type", "nonsense")
+    assert r.returncode != 0 and "Unknown file type" in r.stderr
+    # other parameters: 3 hashes, fpr 0.1, no canonicalisation, FASTQ documents, page size 1
+    fq = os.path.join(golden_dir, "documents", "fastq")
+    pq = str(tmp_path / "q.cobs_compact")
+    r = _run("compact-construct", fq, pq, "-h", "3", "-f", "0.1", "--no-canonicalize", "-p", "1", "--file-type", "fastq")
+    assert r.returncode == 0, r.stderr
+    ix = oracle.Index.open(pq)
+    assert (ix.num_docs, ix.num_hashes, ix.canonicalize, ix.page_size) == (3, 3, 0, 1)
+    # classic-combine: the classic indexes of a directory, in path order
+    d = tmp_path / "parts"
+    d.mkdir()
+    for name, sub in (("a", "sample1.fasta"), ("b", "sample2.fasta")):
+        one = tmp_path / ("in_" + name)
+        one.mkdir()
+        (one / sub).write_bytes(open(os.path.join(fasta, sub), "rb").read())
+        # the same signature size everywhere: classic_combine needs equal parameters
+        assert _run("classic-construct", str(one), str(d / (name + ".cobs_classic"))).returncode == 0
+    sa = oracle.Index.open(str(d / "a.cobs_classic")).signature_size(0)
+    sb = oracle.Index.open(str(d / "b.cobs_classic")).signature_size(0)
+    r = _run("classic-combine", str(d), str(tmp_path / "ab.cobs_classic"))
+    if sa == sb:
+        assert r.returncode == 0, r.stderr
+    else:
+        assert r.returncode != 0            # different signature sizes cannot be combined (:226-231)
+    # and `cobs query` with its sub-tool name
+    r = _run("query", "-i", pc, "-t", "0", Q50)
+    want = "".join("%s\t%d\n" % (n, s) for (_, _, n, s) in oracle.search(oracle.Index.open(pc), Q50.encode(), 0.0))
+    assert r.returncode == 0 and r.stdout == want
