@@ -24,6 +24,10 @@ __global__ __launch_bounds__(256) void probe(uint32_t* table, uint64_t words, in
     if (mode == 2) reinterpret_cast<uint8_t*>(table)[h % (words * 4)] = 1;            // scattered byte store
     else if (mode == 3) table[h % words] = 1u;                                             // scattered dword store
     else if (mode == 4) { if (table[h % words] == 0xdeadbeefu) table[0] = 1; }             // scattered dword load
+    else if (mode == 5 || mode == 6) {                                                     // L2-local (workgroup scope) atomic
+        uint32_t* b = mode == 6 ? table + (uint64_t)(blockIdx.x & 7u) * words : table;
+        __hip_atomic_fetch_or(b + (h % words), 1u << (h >> 59), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     else atomicOr(base + (h % words), 1u << (h >> 59));
 }
 
@@ -45,6 +49,10 @@ int main() {
         {"dword store 512 MiB", total_words, 3},
         {"dword load 512 MiB", total_words, 4},
         {"dword load 2 MiB", (2ull << 20) / 4, 4},
+        {"wg-scope 512 MiB", total_words, 5},
+        {"wg-scope 2 MiB", (2ull << 20) / 4, 5},
+        {"wg-scope/XCD 2 MiB", (2ull << 20) / 4, 6},
+        {"wg-scope/XCD 32 MiB", (32ull << 20) / 4, 6},
         {"per-XCD 1 MiB", (1ull << 20) / 4, 1},
         {"per-XCD 2 MiB", (2ull << 20) / 4, 1},
         {"per-XCD 3 MiB", (3ull << 20) / 4, 1},
