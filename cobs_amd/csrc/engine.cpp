@@ -152,8 +152,9 @@ uint64_t slice_bytes(uint64_t sig, uint64_t ncols, const Tuning& tune) {
 //   time, 512-byte pages -9 %, 128-byte pages -12 %, 30 M-row sub-indexes that cannot be
 //   cached -3 %; W = 4 (64-byte slices) halves throughput.
 // * Every virtual wave should keep about two to four blocks (merging and expansion cost per
-//   tile is fixed): NV = largest power of two <= blocks / 1.75, at most 32.  Measured optimum
-//   for 100/150/250-bp reads (9/15/28 blocks): (NW 2, W 32), (NW 2, W 16), (NW 2, W 8).
+//   tile is fixed): NV = largest power of two <= blocks / 1.5, at most 32.  Measured (round 2,
+//   after the in-register 8-bit epilogue) for 125/150/175/200/250-bp reads (12/15/18/21/28
+//   blocks): (NW 2, W 16) -- 10 % faster than (2, 32) --, (2, 16), (1, 8), (1, 8), (2, 8).
 // * Indexes narrower than a wave get the smallest tile that covers them (no idle lanes).
 // Tuning hooks (per handle): tile_w, waves, mq force a value.
 struct ScanGeom { uint32_t tile_w; int nwaves; bool multi_query; };
@@ -167,11 +168,11 @@ constexpr size_t kTopkSortLimit = 8192;
 ScanGeom scan_geometry(const Chunk& c, uint64_t mean_blocks, uint64_t max_blocks, uint64_t num_hashes,
                        uint32_t forced_waves, int planes, bool idx64, const Tuning& tune) {
     uint32_t nv = 1;
-    while (nv < 32 && (uint64_t)nv * 2 * 7 <= mean_blocks * 4) nv <<= 1;     // blocks / NV >= 1.75
+    while (nv < 32 && (uint64_t)nv * 2 * 3 <= mean_blocks * 2) nv <<= 1;     // blocks / NV >= 1.5
     ScanGeom g;
     if (nv >= 16) { g.nwaves = (int)(nv / 8); g.tile_w = 8; }
     else if (nv == 8) {
-        if (mean_blocks >= 24) { g.nwaves = 1; g.tile_w = 8; }
+        if (mean_blocks >= 17) { g.nwaves = 1; g.tile_w = 8; }
         else { g.nwaves = 2; g.tile_w = 16; }
     }
     else if (nv == 4) { g.nwaves = 2; g.tile_w = 32; }
@@ -199,14 +200,15 @@ ScanGeom scan_geometry(const Chunk& c, uint64_t mean_blocks, uint64_t max_blocks
     if (tune.tile_w) g.tile_w = tune.tile_w;
     // Very short queries (<= 10 blocks: reads up to ~110 bp): the lane groups of a wave serve 8
     // different queries instead of splitting one query's few blocks.  Interleaved A/B on the C3
-    // index: 50-bp reads -7.4 % scan time with (W 8, NW 2), 100-bp reads -4 % with (W 8, NW 1);
-    // from 150 bp on the one-query geometry above is faster (+2.4 %, 250 bp: equal, C3: +1.5 %).
+    // index (with the in-register 8-bit epilogue, which only the first wave runs): 50-bp reads
+    // 2.27 ms with one wave per group vs 2.38 with two, 75 bp equal, 100 bp 6.04 ms with two vs
+    // 6.11 with one; from 125 bp on the one-query geometry above is faster.
     g.multi_query = false;
     if (tune.mq != 0 && !idx64 && forced_waves == 0 && mean_blocks <= 10 && max_blocks <= 20 && c.total_chunks >= 8 &&
         scan_has_multi_query(planes, (uint32_t)num_hashes, 8)) {
         g.multi_query = true;
         g.tile_w = 8;
-        g.nwaves = mean_blocks <= 5 ? 2 : 1;
+        g.nwaves = mean_blocks >= 8 ? 2 : 1;
         if (tune.waves) g.nwaves = (int)tune.waves;
         if (tune.tile_w && tune.tile_w < 64) g.tile_w = tune.tile_w;
     }

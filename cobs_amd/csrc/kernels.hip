@@ -498,6 +498,54 @@ __device__ __forceinline__ void glds_rows(const uint8_t* lane_base, uint32_t pit
 #define COBS_STAMP(K) do { } while (0)
 #endif
 
+// LDS bytes in front of the expansion table / tile metadata: the merge buffers of the waves
+// ([NW/2 (min 1)][NP][64 lanes] of uint4), the row staging ring of the LDS-staged variant, or --
+// 8-bit scores -- the score staging buffer of the epilogue, whichever is largest
+template <int NP, int NW, size_t OutBytes, bool LDSS>
+__host__ __device__ constexpr size_t scan_lds_front() {
+    size_t f = LDSS ? (size_t)NW * 16384 : (size_t)(NW >= 2 ? NW / 2 : 1) * NP * 64 * sizeof(uint4);
+    if (OutBytes == 1 && f < 64 * 144) f = 64 * 144;
+    return f;
+}
+
+// 32 documents x NP (<= 8) bit planes -> the documents' 8-bit counts, in registers: byte b of every
+// plane is gathered with v_perm_b32 (two 4x4 byte transposes), then an 8x8 bit transpose (three
+// delta swaps) turns "bit i of byte k = bit k of document 8b+i" into one byte per document.
+// out[j] = counts of documents 4j .. 4j+3.  24 VALU per 8 documents, no LDS table.
+template <int NP>
+__device__ __forceinline__ void planes_to_bytes32(const uint32_t (&P)[NP], uint32_t (&out)[8]) {
+    static_assert(NP <= 8, "8-bit scores hold at most 8 planes");
+    uint32_t q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) q[k] = k < NP ? P[k] : 0u;
+    uint32_t x[4], y[4];
+    {
+        const uint32_t t0 = __builtin_amdgcn_perm(q[1], q[0], 0x05010400u), t1 = __builtin_amdgcn_perm(q[1], q[0], 0x07030602u);
+        const uint32_t t2 = __builtin_amdgcn_perm(q[3], q[2], 0x05010400u), t3 = __builtin_amdgcn_perm(q[3], q[2], 0x07030602u);
+        x[0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u); x[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+        x[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u); x[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+    }
+    {
+        const uint32_t t0 = __builtin_amdgcn_perm(q[5], q[4], 0x05010400u), t1 = __builtin_amdgcn_perm(q[5], q[4], 0x07030602u);
+        const uint32_t t2 = __builtin_amdgcn_perm(q[7], q[6], 0x05010400u), t3 = __builtin_amdgcn_perm(q[7], q[6], 0x07030602u);
+        y[0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u); y[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+        y[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u); y[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        uint32_t lo = x[b], hi = y[b], t;
+        t = (lo ^ (lo >> 7)) & 0x00AA00AAu; lo = lo ^ t ^ (t << 7);
+        t = (hi ^ (hi >> 7)) & 0x00AA00AAu; hi = hi ^ t ^ (t << 7);
+        t = (lo ^ (lo >> 14)) & 0x0000CCCCu; lo = lo ^ t ^ (t << 14);
+        t = (hi ^ (hi >> 14)) & 0x0000CCCCu; hi = hi ^ t ^ (t << 14);
+        out[2 * b] = (lo & 0x0F0F0F0Fu) | ((hi << 4) & 0xF0F0F0F0u);
+        out[2 * b + 1] = ((lo >> 4) & 0x0F0F0F0Fu) | (hi & 0xF0F0F0F0u);
+    }
+}
+// LDS bytes between the score blocks of two lanes in the staging buffer of the 8-bit epilogue:
+// 128 bytes of scores + 16 of padding, so that the 16-byte writes of 16 lanes hit 16 different banks
+constexpr uint32_t kStageStride = 144u;
+
 // MQ ("multi-query", short queries): the G = 64 / W lane groups of a wave belong to G
 // DIFFERENT queries (q = qi*G + grp) instead of splitting one query's blocks.  Every lane
 // group then walks all blocks of its own query (divided over the NW waves only): G times
@@ -511,24 +559,21 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     // merge buffers: [NW/2 (min 1)][NP][64 lanes] of uint4, then the 256-entry expansion table.
     // LDSS: the front of the buffer is the row staging ring (2 x 8 KiB per wave); the merge
     // buffers, needed only after the row loop, alias it.
-    constexpr size_t kFront = LDSS ? (size_t)NW * 16384 : (size_t)(NW >= 2 ? NW / 2 : 1) * NP * 64 * sizeof(uint4);
+    constexpr size_t kFront = scan_lds_front<NP, NW, sizeof(OutT), LDSS>();
     static_assert(!LDSS || kFront >= (size_t)(NW >= 2 ? NW / 2 : 1) * NP * 64 * sizeof(uint4), "ring holds the merge buffers");
     uint4* mbuf = reinterpret_cast<uint4*>(smem);
+    // 16/32-bit scores expand their planes through a 256-entry table; 8-bit scores transpose in
+    // registers (planes_to_bytes32) and have no table
+    constexpr size_t kLut = sizeof(OutT) == 1 ? 0 : 256 * sizeof(uint4);
     uint4* lut = reinterpret_cast<uint4*>(smem + kFront);
     // per-chunk metadata of this tile (first local score slot, valid row bytes left in the
     // chunk, first document id) and per-lane-group thresholds: the epilogue reads them from
     // LDS instead of chasing a.pages[] / a.thresholds[] through global memory per iteration
-    uint32_t* tmeta = reinterpret_cast<uint32_t*>(lut + 256);       // [64][3]
+    uint32_t* tmeta = reinterpret_cast<uint32_t*>(smem + kFront + kLut);   // [64][3]
     uint32_t* tthr = tmeta + 64 * 3;                                 // [64]
-    for (uint32_t v = threadIdx.x; v < 256u; v += NW * 64) {
-        uint4 e;
-        if constexpr (sizeof(OutT) == 1) {
-            // 8-bit scores (T <= 255, the reference's uint8_t path): bit j -> byte j, 8 bytes
-            e.x = (v & 1u) | ((v & 2u) << 7) | ((v & 4u) << 14) | ((v & 8u) << 21);
-            e.y = ((v >> 4) & 1u) | ((v & 32u) << 3) | ((v & 64u) << 10) | ((v & 128u) << 17);
-            e.z = 0u; e.w = 0u;
-            reinterpret_cast<uint2*>(lut)[v] = make_uint2(e.x, e.y);
-        } else {
+    if constexpr (sizeof(OutT) != 1) {
+        for (uint32_t v = threadIdx.x; v < 256u; v += NW * 64) {
+            uint4 e;
             e.x = (v & 1u) | ((v & 2u) << 15);
             e.y = ((v >> 2) & 1u) | ((v & 8u) << 13);
             e.z = ((v >> 4) & 1u) | ((v & 32u) << 11);
@@ -789,6 +834,86 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
         }
         __syncthreads();
     }
+    if constexpr (sizeof(OutT) == 1) {
+        // ---- 8-bit scores with the score rows wanted: wave 0 holds the final planes; its lanes
+        // transpose them to bytes in registers, stage the 128 bytes of their chunk in LDS, and all
+        // threads of the group copy the tile out in 16-byte pieces (coalesced stores)
+        if (a.write_counts || !a.thresholds) {
+            uint8_t* stage = smem;                       // the merge buffers are done with
+            if (wave == 0u && (MQ || lane < W)) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    uint32_t o[8];
+                    planes_to_bytes32<NP>(pl[w], o);
+                    uint4* dst = reinterpret_cast<uint4*>(stage + lane * kStageStride + w * 32);
+                    dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+                    dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+                }
+            }
+            __syncthreads();
+            COBS_STAMP(5);             // scores staged
+            const uint32_t npieces = (MQ ? 64u : W) * 8u;            // 16 documents each
+#pragma unroll 1
+            for (uint32_t pc0 = wave * 64u; pc0 < npieces; pc0 += NW * 64) {   // wave-uniform bounds
+                const uint32_t pc = pc0 + lane;
+                const bool act = pc < npieces;
+                const uint32_t L = act ? pc >> 3 : 0u, rb = (pc & 7u) * 2u;   // lane that staged it, first row byte
+                const uint32_t chunk = MQ ? (L & (W - 1u)) : L;
+                const uint32_t q2raw = MQ ? qi * G + L / W : qi;
+                const uint32_t q2 = q2raw < a.nq ? q2raw : a.nq - 1u;
+                const uint32_t vb = tmeta[chunk * 3 + 1];                     // valid row bytes of the chunk
+                const bool valid = act && q2raw < a.nq && rb < vb;
+                const uint4 v = *reinterpret_cast<const uint4*>(stage + L * kStageStride + rb * 8u);
+                const uint32_t slot = tmeta[chunk * 3 + 0] + rb * 8u;
+                if (valid && a.write_counts) {
+                    OutT* crow = reinterpret_cast<OutT*>(a.counts) + (uint64_t)q2 * a.counts_stride + a.counts_offset;
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    u32x2* dst = reinterpret_cast<u32x2*>(crow + slot);       // slots are multiples of 8, not of 16
+                    const u32x2 v0 = {v.x, v.y}, v1 = {v.z, v.w};
+                    dst[0] = v0;
+                    if (rb + 1u < vb) dst[1] = v1;
+                }
+                if (a.thresholds) {
+                    // counts_to_result filter: score >= threshold over real documents only
+                    const uint32_t thr = tthr[MQ ? L / W : 0u];
+                    const uint32_t doc = tmeta[chunk * 3 + 2] + rb * 8u;
+                    const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+                    uint32_t mask = 0u;
+                    if (valid) {
+                        const uint32_t nd = rb + 1u < vb ? 16u : 8u;
+#pragma unroll
+                        for (uint32_t d = 0; d < 16; ++d) {
+                            const uint32_t cnt = (vv[d >> 2] >> ((d & 3u) * 8u)) & 0xFFu;
+                            if (d < nd && cnt >= thr && doc + d < a.num_docs) mask |= 1u << d;
+                        }
+                    }
+                    if (__any(mask != 0u)) {
+                        const uint32_t n = __popc(mask);
+                        uint32_t incl = n;
+#pragma unroll
+                        for (int off = 1; off < 64; off <<= 1) {
+                            const uint32_t t = __shfl_up(incl, off);
+                            if (lane >= (uint32_t)off) incl += t;
+                        }
+                        const uint32_t total = __shfl(incl, 63);
+                        unsigned long long base = 0ull;
+                        if (lane == 63u) base = atomicAdd(a.hit_count, (unsigned long long)total);
+                        base = __shfl(base, 63);
+                        unsigned long long pos = base + incl - n;
+                        while (mask != 0u) {
+                            const uint32_t d = (uint32_t)__ffs((int)mask) - 1u;
+                            mask &= mask - 1u;
+                            if (pos < a.hit_cap)
+                                a.hits[pos] = HitDev{q2, a.part, doc + d, (vv[d >> 2] >> ((d & 3u) * 8u)) & 0xFFu};
+                            ++pos;
+                        }
+                    }
+                }
+            }
+            COBS_STAMP(6);             // scores stored
+            return;
+        }
+    }
     if (wave == 0) {
 #pragma unroll
         for (int k = 0; k < NP; ++k)
@@ -858,6 +983,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
         }
         return;
     }
+    if constexpr (sizeof(OutT) == 1) return;         // 8-bit scores left through one of the two paths above
     const uint32_t nbytes = MQ ? 1024u : W * 16u;    // MQ: every lane group holds a query's tile
     // MQ: 1024 / (NW * 64) = 4..16 iterations per thread.  Unrolled by four so that the score stores
     // of consecutive iterations use different registers: with one register set the next iteration's
@@ -1475,8 +1601,8 @@ static hipError_t launch_scan_inst(const ScanArgs& a, uint32_t ntiles, hipStream
                             ((a.nq + per_group - 1u) / per_group);
     if (groups == 0) return hipSuccess;
     if (groups > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    constexpr size_t front = LDSS ? (size_t)NW * 16384 : (size_t)(NW >= 2 ? NW / 2 : 1) * NP * 64 * sizeof(uint4);
-    constexpr size_t lds = front + 256 * sizeof(uint4) + 64 * 4 * sizeof(uint32_t);
+    constexpr size_t front = scan_lds_front<NP, NW, sizeof(OutT), LDSS>();
+    constexpr size_t lds = front + (sizeof(OutT) == 1 ? 0 : 256 * sizeof(uint4)) + 64 * 4 * sizeof(uint32_t);
     auto kern = scan_kernel<NP, NW, H1, OutT, MQ, IdxT, LDSS>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
