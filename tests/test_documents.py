@@ -275,3 +275,54 @@ def test_doc_list_and_doc_dump_tools(docdir):
     assert r.stdout.encode() == b"".join(O.canonicalize_kmer(t)[0] + b"\n" for t in D.load(p)[0].terms(31))
     r = subprocess.run([tool, "doc-dump", os.path.join(docdir, "text", "sample1.txt")], capture_output=True, text=True, timeout=120)
     assert r.stdout.startswith("Invalid DNA base pair: Hello, this is the first sample\n")
+
+
+def test_readers_survive_damaged_files(capi, docdir, tmp_path):
+    """truncated and bit-flipped copies of every fixture: the readers answer with an error or with
+    terms, never with a crash or an out-of-bounds read (the checker is not consulted: damaged files
+    have no reference behaviour worth pinning)"""
+    rng = np.random.default_rng(99)
+    sources = []
+    for sub in ("cortex", "fastq", "fasta_multi", "text"):
+        for fn in sorted(os.listdir(os.path.join(docdir, sub))):
+            if fn == "document_sorted.txt" or fn.endswith("-k15.txt") or fn.endswith("-k19.txt"):
+                continue
+            sources.append(os.path.join(docdir, sub, fn))
+    kdoc = str(tmp_path / "ok.cobs_doc")
+    D.write_kmer_buffer(kdoc, "doc", [b"ACGT" * 7 + b"ACG"] * 9)
+    sources.append(kdoc)
+    outcomes = {"ok": 0, "error": 0}
+    for src in sources:
+        raw = open(src, "rb").read()
+        ext = src[src.index(".", src.rfind(os.sep)):]
+        for trial in range(40):
+            b = bytearray(raw)
+            mode = trial % 4
+            if mode == 0:
+                b = b[:int(rng.integers(0, len(b) + 1))]
+            elif mode == 1:
+                for _ in range(int(rng.integers(1, 9))):
+                    b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+            elif mode == 2:
+                at = int(rng.integers(0, min(len(b), 64)))
+                b[at:at + 4] = (0xFFFFFFFF if trial % 8 == 2 else int(rng.integers(0, 2 ** 31))).to_bytes(4, "little")
+            else:
+                b = b[:int(rng.integers(0, 80))] + bytes(rng.integers(0, 256, size=int(rng.integers(0, 50))).astype(np.uint8))
+            p = str(tmp_path / ("damaged" + ext))
+            with open(p, "wb") as f:
+                f.write(bytes(b))
+            dl = capi.DocumentList()
+            try:
+                dl.add(p)
+            except capi.CobsGpuError:
+                outcomes["error"] += 1
+                continue
+            for e in dl:
+                for k in (31, 5):
+                    try:
+                        n = len(e.terms(k))
+                        assert n >= 0 and e.num_terms(k) >= 0
+                    except capi.CobsGpuError:
+                        pass
+            outcomes["ok"] += 1
+    assert outcomes["ok"] > 50 and outcomes["error"] > 50, outcomes
