@@ -189,7 +189,8 @@ cobs_gpu_status cortex_header(const std::string& d, const std::string& path, Cor
         p += n;                                     // graph name
     }
     if (!magic()) return err(COBS_GPU_ERR_FORMAT, bad);
-    if (h.kmer_size == 0 || h.words == 0 || (uint64_t)8 * h.words < (h.kmer_size + 3) / 4)
+    // (64-bit arithmetic: the fields are whatever the file says)
+    if (h.kmer_size == 0 || h.words == 0 || (uint64_t)8 * h.words < ((uint64_t)h.kmer_size + 3) / 4 || p > d.size())
         return err(COBS_GPU_ERR_FORMAT, "corrupted .ctx file");
     h.data_begin = p;
     return COBS_GPU_OK;
@@ -245,7 +246,7 @@ cobs_gpu_status kmer_buffer_header(const std::string& d, const std::string& path
     if (d.size() < p + 8 || std::memcmp(d.data() + p, "DOCUMENT", 8) != 0)
         return err(COBS_GPU_ERR_FORMAT, "invalid file type: " + path);
     h.data_begin = p + 8;
-    if (h.kmer_size == 0) return err(COBS_GPU_ERR_FORMAT, "invalid file type: " + path);
+    if (h.kmer_size == 0 || h.kmer_size > (1u << 20)) return err(COBS_GPU_ERR_FORMAT, "invalid file type: " + path);
     return COBS_GPU_OK;
 }
 
