@@ -240,6 +240,14 @@ def classic_combine(in_files, out_file, mem_bytes=0, device=-1):
     check(lib.cobs_gpu_combine_classic(arr, len(in_files), os.fsencode(out_file), int(mem_bytes), device))
 
 
+def compact_combine(in_files, out_file, page_size):
+    """compact_combine_into_compact (construction/compact_index.cpp:51-169): classic indexes -> the
+    sub-indexes of one compact index, rows padded to page_size bytes"""
+    lib = _capi.load()
+    arr = (C.c_char_p * len(in_files))(*[os.fsencode(p) for p in in_files])
+    check(lib.cobs_gpu_combine_compact(arr, len(in_files), os.fsencode(out_file), int(page_size)))
+
+
 def classic_construct_random(out_file, signature_size=2 * 1024 * 1024, num_documents=10000, document_size=1000000,
                              num_hashes=1, seed=1, device=-1):
     """`cobs classic-construct-random` (src/cobs.cpp:243-291, classic_index.cpp:661-725), defaults
@@ -263,6 +271,6 @@ def write_synthetic(out_file, kind, signature_sizes, num_docs, page_size=0, term
     check(lib.cobs_gpu_write_synthetic(C.byref(d), os.fsencode(out_file), device))
 
 
-__all__ = ["write_synthetic", "build_search", "classic_combine", "classic_construct_random", "DocumentList", "DocumentEntry", "FileType", "ClassicIndexParameters", "CompactIndexParameters",
+__all__ = ["write_synthetic", "build_search", "classic_combine", "compact_combine", "classic_construct_random", "DocumentList", "DocumentEntry", "FileType", "ClassicIndexParameters", "CompactIndexParameters",
            "classic_construct", "classic_construct_list", "compact_construct", "compact_construct_list",
            "disable_cache"]

@@ -1004,4 +1004,67 @@ cobs_gpu_status cobs_gpu_write_synthetic(const cobs_gpu_synth* d, const char* ou
     return COBS_GPU_OK;
 }
 
+// compact_combine_into_compact (compact_index.cpp:51-169; `cobs compact-construct-combine`):
+// classic indexes become the sub-indexes of one compact index, rows padded to page_size bytes.
+// File-to-file work without a kernel (nothing is hashed or counted); the inputs are left in place.
+cobs_gpu_status cobs_gpu_combine_compact(const char* const* in_paths, size_t n, const char* out_path, uint64_t page_size) {
+    if (!in_paths || n == 0 || !out_path || page_size == 0) return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "NULL argument, no inputs or page_size 0");
+    return guarded([&]() -> cobs_gpu_status {
+        std::vector<std::unique_ptr<MappedFile>> files;
+        std::vector<IndexMeta> metas(n);
+        std::string err;
+        size_t ndocs = 0;
+        for (size_t i = 0; i < n; ++i) {
+            files.emplace_back(new MappedFile);
+            if (!in_paths[i] || !files[i]->open(in_paths[i], err)) return cobs_gpu_set_error(COBS_GPU_ERR_OPEN, err.c_str());
+            if (!parse_index_header(files[i]->data(), files[i]->size(), metas[i], err) || metas[i].kind != IndexKind::Classic)
+                return cobs_gpu_set_error(COBS_GPU_ERR_FORMAT, (std::string(in_paths[i]) + ": not a classic index").c_str());
+            if (metas[i].term_size != metas[0].term_size || metas[i].canonicalize != metas[0].canonicalize)
+                return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "indexes to combine differ in term size or canonicalize");      // :77-78
+            // every index fills its page, the last one may be narrower (:85-90)
+            const uint64_t rs = metas[i].page_row_bytes();
+            if (i + 1 < n ? rs != page_size : rs > page_size)
+                return cobs_gpu_set_error(COBS_GPU_ERR_ARG, (std::string(in_paths[i]) + ": row size does not match page_size").c_str());
+            ndocs += metas[i].doc_names.size();
+        }
+        if (ndocs > 0xFFFFFFF0ull) return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "bad document count");
+        std::string h = "COBS:COMPACT_INDEX";
+        put<uint32_t>(h, 1);
+        put<uint32_t>(h, metas[0].term_size);
+        put<uint8_t>(h, metas[0].canonicalize);
+        put<uint32_t>(h, (uint32_t)n);
+        put<uint32_t>(h, (uint32_t)ndocs);
+        put<uint64_t>(h, page_size);
+        for (const IndexMeta& m : metas) { put<uint64_t>(h, m.signature_sizes[0]); put<uint64_t>(h, m.num_hashes); }
+        for (const IndexMeta& m : metas)
+            for (const std::string& nm : m.doc_names) { h += nm; h += '\n'; }
+        const uint64_t pad = (page_size - ((h.size() + 13) % page_size)) % page_size;
+        h.append((size_t)pad, '\0');
+        h += "COMPACT_INDEX";
+        FILE* f = std::fopen(out_path, "wb");
+        if (!f) return cobs_gpu_set_error(COBS_GPU_ERR_OPEN, (std::string("could not create ") + out_path).c_str());
+        struct Closer { FILE* f; ~Closer() { if (f) std::fclose(f); } } closer{f};
+        if (!write_all(f, h.data(), h.size())) return cobs_gpu_set_error(COBS_GPU_ERR_OPEN, "short write");
+        std::vector<uint8_t> buf;
+        for (size_t i = 0; i < n; ++i) {
+            const uint64_t rs = metas[i].page_row_bytes(), sig = metas[i].signature_sizes[0];
+            const uint8_t* src = files[i]->data() + metas[i].data_offset;
+            if (rs == page_size) {
+                if (!write_all(f, src, (size_t)(sig * rs))) return cobs_gpu_set_error(COBS_GPU_ERR_OPEN, "short write");
+                continue;
+            }
+            const uint64_t rows_per = std::max<uint64_t>(1, (64ull << 20) / page_size);
+            buf.assign((size_t)(std::min(rows_per, sig) * page_size), 0);
+            for (uint64_t r0 = 0; r0 < sig; r0 += rows_per) {
+                const uint64_t nr = std::min(rows_per, sig - r0);
+                for (uint64_t r = 0; r < nr; ++r) std::memcpy(buf.data() + r * page_size, src + (r0 + r) * rs, (size_t)rs);
+                if (!write_all(f, buf.data(), (size_t)(nr * page_size))) return cobs_gpu_set_error(COBS_GPU_ERR_OPEN, "short write");
+            }
+        }
+        closer.f = nullptr;
+        if (std::fclose(f) != 0) return cobs_gpu_set_error(COBS_GPU_ERR_OPEN, "short write");
+        return COBS_GPU_OK;
+    });
+}
+
 }  // extern "C"

@@ -5,7 +5,8 @@
 //   cobs_gpu_query doc-dump PATH [--file-type T] [-k K] [--no-canonicalize]       (:101-158)
 //   cobs_gpu_query classic-construct INPUT OUT.cobs_classic [flags]               (:163-244)
 //   cobs_gpu_query compact-construct INPUT OUT.cobs_compact [flags] [-p PAGE]     (:294-380)
-//   cobs_gpu_query classic-combine IN_DIR OUT.cobs_classic                        (:?)
+//   cobs_gpu_query classic-combine IN_DIR OUT.cobs_classic                        (:1044-1060)
+//   cobs_gpu_query compact-construct-combine IN_DIR OUT.cobs_compact [-p PAGE]   (:383-408)
 //
 // Flags of the two constructors: --file-type, -h/--num-hashes, -f/--false-positive-rate,
 // -k/--term-size, --no-canonicalize, -C/--clobber, --continue; -m/--memory, -T/--threads,
@@ -201,20 +202,26 @@ int cobs_gpu_tools_main(int argc, char** argv) {
         }
         return 0;
     }
-    if (tool == "classic-combine") {
+    if (tool == "classic-combine" || tool == "compact-construct-combine") {
         // `cobs classic-combine IN_DIR OUT_FILE`: the .cobs_classic files of a directory, in path order
         std::vector<std::string> pos;
         int device = -1;
-        uint64_t mem = 0;
+        uint64_t mem = 0, page_size = 8192;               // default of compact-construct-combine (src/cobs.cpp:392-395)
+        const bool compact = tool == "compact-construct-combine";
         for (int i = 2; i < argc; ++i) {
             const std::string a = argv[i];
             if ((a == "-d" || a == "--device") && i + 1 < argc) device = std::atoi(argv[++i]);
+            else if (compact && (a == "-p" || a == "--page-size") && i + 1 < argc) page_size = std::strtoull(argv[++i], nullptr, 10);
             else if ((a == "-m" || a == "--memory") && i + 1 < argc) mem = std::strtoull(argv[++i], nullptr, 10);
             else if ((a == "-T" || a == "--threads") && i + 1 < argc) ++i;
             else if (a == "--keep-temporary") {}
             else pos.push_back(a);
         }
-        if (pos.size() != 2) { std::fprintf(stderr, "usage: cobs_gpu_query classic-combine IN_DIR OUT_FILE [-m BYTES] [-d DEVICE]\n"); return 1; }
+        if (pos.size() != 2) {
+            std::fprintf(stderr, "usage: cobs_gpu_query classic-combine IN_DIR OUT_FILE [-m BYTES] [-d DEVICE]\n"
+                                 "       cobs_gpu_query compact-construct-combine IN_DIR OUT_FILE [-p PAGE_SIZE]\n");
+            return 1;
+        }
         std::vector<std::string> files;
         std::error_code ec;
         for (std::filesystem::recursive_directory_iterator it(pos[0], ec), end; !ec && it != end; it.increment(ec))
@@ -223,6 +230,7 @@ int cobs_gpu_tools_main(int argc, char** argv) {
         if (files.empty()) { std::fprintf(stderr, "no .cobs_classic files in %s\n", pos[0].c_str()); return 1; }
         std::vector<const char*> cp;
         for (auto& f : files) cp.push_back(f.c_str());
+        if (compact) return cobs_gpu_combine_compact(cp.data(), cp.size(), pos[1].c_str(), page_size) == COBS_GPU_OK ? 0 : fail();
         return cobs_gpu_combine_classic(cp.data(), cp.size(), pos[1].c_str(), mem, device) == COBS_GPU_OK ? 0 : fail();
     }
     return -1;

@@ -274,6 +274,12 @@ cobs_gpu_status cobs_gpu_build_index_list(uint32_t kind, const cobs_gpu_doclist*
  * interleaved on the device. */
 cobs_gpu_status cobs_gpu_combine_classic(const char* const* in_paths, size_t n, const char* out_path,
                                          uint64_t mem_bytes, int device);
+/* compact_combine_into_compact (compact_index.cpp:51-169; `cobs compact-construct-combine`): n
+ * classic indexes with equal term size / canonicalize become the sub-indexes of one compact index
+ * (own signature size and hash count each), rows padded to page_size bytes; every input but the
+ * last must have a row size of exactly page_size.  File to file, no device work; unlike the
+ * reference the inputs are not deleted. */
+cobs_gpu_status cobs_gpu_combine_compact(const char* const* in_paths, size_t n, const char* out_path, uint64_t page_size);
 /* classic_construct_random (classic_index.cpp:661-725; `cobs classic-construct-random`,
  * src/cobs.cpp:243-291): num_documents documents of document_size random 31-mers, canonicalised,
  * hashed num_hashes times into signature_size rows, written as a .cobs_classic file.  Same
