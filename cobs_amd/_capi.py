@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("COBS_GPU_LIBRARY") or os.path.join(_HERE, "libcobs_gp
 OK = 0
 ERR_OPEN, ERR_FORMAT, ERR_QUERY_TOO_SHORT, ERR_INVALID_BASE, ERR_QUERY_TOO_LONG = 1, 2, 3, 4, 5
 ERR_HIP, ERR_ARG, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_NO_DEVICE, ERR_RCCL = 6, 7, 8, 9, 10, 11
-XCHG_ALLGATHER, XCHG_ALLTOALL = 0, 1
+XCHG_ALLGATHER, XCHG_ALLTOALL, XCHG_REDUCE = 0, 1, 2
 UNIQUE_ID_BYTES = 128
 
 STATUS_NAMES = {

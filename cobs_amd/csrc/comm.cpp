@@ -290,7 +290,7 @@ int cobs_gpu_comm_size(const cobs_gpu_comm* c) {
 cobs_gpu_status cobs_gpu_batch_exchange_counts(cobs_gpu_batch* b, cobs_gpu_comm* c, uint32_t mode, void* hip_stream) {
     if (!b || !c) return fail(COBS_GPU_ERR_ARG, "NULL argument");
     if (!b->ran || !b->have_counts) return fail(COBS_GPU_ERR_ARG, "run the batch with score rows first");
-    if (mode > COBS_GPU_XCHG_ALLTOALL) return fail(COBS_GPU_ERR_ARG, "unknown exchange mode");
+    if (mode > COBS_GPU_XCHG_REDUCE) return fail(COBS_GPU_ERR_ARG, "unknown exchange mode");
     return guarded([&]() -> cobs_gpu_status {
         hipStream_t st = (hipStream_t)hip_stream;
         const cobs_gpu_index* ix = b->ix;
@@ -301,6 +301,35 @@ cobs_gpu_status cobs_gpu_batch_exchange_counts(cobs_gpu_batch* b, cobs_gpu_comm*
         const size_t N = (size_t)c->nranks, me = (size_t)c->rank, nq = b->nq;
         std::vector<uint64_t> doc_off(x.nparts);
         for (size_t f = 0; f < x.nparts; ++f) doc_off[f] = ix->parts[f].doc_offset;
+        if (mode == COBS_GPU_XCHG_REDUCE) {
+            // "per-document hit counts reduced over RCCL" taken literally (parity mode):
+            // every rank lays its slices into zeroed rows of global length and the rows are summed
+            // with one ncclAllReduce.  The slices are disjoint, so every BYTE of the result has one
+            // non-zero contributor: a sum over ncclUint8 cannot carry and is exact for 8-, 16- and
+            // 32-bit counters alike (RCCL has no 16-bit integer type).  Moves ~2x the full vector
+            // through every GPU (ring all-reduce) where the gather forms move 7/8 of it once.
+            const size_t eb = b->elem_bytes, row = (size_t)ix->total_counts * eb, bytes = nq * row;
+            HIP_TRY(x.global.reserve(std::max<size_t>(bytes, 1)));
+            HIP_TRY(hipMemsetAsync(x.global.p, 0, bytes, st));
+            uint64_t local_off = 0;
+            const uint64_t my_n = x.local_n[me];
+            for (size_t f = 0; f < x.nparts; ++f) {
+                const uint64_t begin = x.layout[(me * x.nparts + f) * 2], count = x.layout[(me * x.nparts + f) * 2 + 1];
+                if (count && nq)
+                    HIP_TRY(hipMemcpy2DAsync(x.global.p + (doc_off[f] + begin) * eb, row, b->counts.p + local_off * eb,
+                                             (size_t)(my_n * eb), (size_t)(count * eb), nq, hipMemcpyDeviceToDevice, st));
+                local_off += count;
+            }
+            if (bytes) NCCL_TRY(ncclAllReduce(x.global.p, x.global.p, bytes, ncclUint8, ncclSum, c->comm, st));
+            x.bytes_moved = N > 1 ? 2 * (N - 1) * bytes / N : 0;
+            b->g_rows = x.global.p;
+            b->g_q0 = 0;
+            b->g_qn = nq;
+            b->view_global = true;
+            b->rows_q0 = b->rows_q1 = 0;
+            HIP_TRY(hipEventRecord(b->run_done, st));
+            return COBS_GPU_OK;
+        }
         const XferPlan p = plan_exchange(x.layout.data(), doc_off.data(), N, x.nparts, ix->total_counts, nq, b->elem_bytes, mode, me);
         HIP_TRY(x.staging.reserve(std::max<size_t>(p.staging_bytes, 1)));
         HIP_TRY(x.global.reserve(std::max<size_t>(p.global_bytes, 1)));

@@ -392,8 +392,12 @@ int cobs_gpu_comm_size(const cobs_gpu_comm* c);     /* ncclCommCount, 0 on error
 typedef enum cobs_gpu_exchange_mode {
     COBS_GPU_XCHG_ALLGATHER = 0,  /* every rank receives the count slices of all ranks for all queries
                                      (ncclAllGather when the slices have one size, else grouped send/recv) */
-    COBS_GPU_XCHG_ALLTOALL = 1    /* rank j receives the slices of the queries [nq*j/N, nq*(j+1)/N) only:
+    COBS_GPU_XCHG_ALLTOALL = 1,   /* rank j receives the slices of the queries [nq*j/N, nq*(j+1)/N) only:
                                      every count crosses the fabric once (grouped ncclSend / ncclRecv)      */
+    COBS_GPU_XCHG_REDUCE = 2      /* the counts "reduced over RCCL": every rank lays its slices into zeroed
+                                     rows of global length, one ncclAllReduce(sum) over the bytes (disjoint
+                                     slices: no byte has two non-zero addends, so the byte-wise sum is exact
+                                     for every counter width).  The parity form; the gather forms move less */
 } cobs_gpu_exchange_mode;
 /* The exchange as a plan (host arithmetic only, no device, no communicator): what rank `rank` of
  * `nranks` sends to / receives from every peer and how the received slices are assembled, given all

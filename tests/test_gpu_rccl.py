@@ -42,7 +42,7 @@ def test_one_rank_exchange_is_the_real_collective(gpu_lib, oracle, tmp_path, com
     s = gpu_lib.Search(paths, device=0, shard_rank=0, shard_count=1)
     b = gpu_lib.Batch(s)
     b.set_queries(queries)
-    for mode in (_capi.XCHG_ALLGATHER, _capi.XCHG_ALLTOALL):
+    for mode in (_capi.XCHG_ALLGATHER, _capi.XCHG_ALLTOALL, _capi.XCHG_REDUCE):
         b.run(0.0)
         b.exchange_counts(comm, mode)
         b.sync()
