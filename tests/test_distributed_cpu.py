@@ -47,6 +47,13 @@ def _worker(rank, world, port, path, queries, out_dir, mode):
         assert [g.shape[1] for g in gathered] == [l[0][1] for l in layouts]
         whole = D.assemble_counts(gathered, layouts, ix.counts_size)
         assert np.array_equal(whole.numpy().astype(np.uint16), full)
+        # COBS_GPU_XCHG_REDUCE (comm.cpp): zero-padded rows of global length, summed as BYTES --
+        # disjoint slices leave one non-zero addend per byte, so the u16 counters come out exact
+        padded = np.zeros_like(full)
+        padded[:, begin:begin + count] = full[:, begin:begin + count]
+        as_bytes = torch.from_numpy(padded.view(np.uint8).copy())
+        dist.all_reduce(as_bytes, op=dist.ReduceOp.SUM)
+        assert np.array_equal(as_bytes.numpy().view(np.uint16), full)
         # hits mode: per-shard ranked lists -> global order
         for t, lim in ((0.0, 0), (0.3, 0), (0.3, 3), (0.9, 0)):
             for qi, q in enumerate(queries):
