@@ -21,7 +21,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/cobs_gpu.h"
+#include "../../include/cobs_gpu_construct.hpp"
 
 namespace {
 
@@ -30,32 +30,18 @@ int fail() {
     return 1;
 }
 
-struct List {
-    cobs_gpu_doclist* dl = nullptr;
-    ~List() { cobs_gpu_doclist_free(dl); }
-};
-
-bool open_list(List& l, const std::string& path, const std::string& file_type) {
-    uint32_t ft = 0;
-    if (cobs_gpu_filetype_from_string(file_type.c_str(), &ft) != COBS_GPU_OK) return false;
-    if (cobs_gpu_doclist_create(&l.dl) != COBS_GPU_OK) return false;
-    return cobs_gpu_doclist_add_recursive(l.dl, path.c_str(), ft) == COBS_GPU_OK;
-}
-
 // print_document_list, src/cobs.cpp:41-73
-void print_document_list(const cobs_gpu_doclist* dl, unsigned k, std::ostream& os) {
-    const size_t n = cobs_gpu_doclist_size(dl);
+void print_document_list(const cobs_gpu::DocumentList& filelist, unsigned k, std::ostream& os) {
+    const size_t n = filelist.size();
     uint64_t min_kmers = ~0ull, max_kmers = 0, total = 0;
     os << "--- document list (" << n << " entries) ---" << std::endl;
     for (size_t i = 0; i < n; ++i) {
-        cobs_gpu_doc_entry e;
-        uint64_t terms = 0;
-        cobs_gpu_doclist_entry(dl, i, &e);
-        cobs_gpu_doclist_num_terms(dl, i, k, &terms);
+        const cobs_gpu::DocumentEntry e = filelist[i];
+        const uint64_t terms = e.num_terms(k);
         std::error_code ec;
-        const auto fsize = e.type == COBS_GPU_FILETYPE_MEMORY ? e.size : (uint64_t)std::filesystem::file_size(e.path, ec);
-        os << "document[" << i << "] size " << fsize << " " << k << "-mers " << terms << " : " << e.path << " : "
-           << e.name << std::endl;
+        const uint64_t fsize = (uint64_t)std::filesystem::file_size(e.path_, ec);
+        os << "document[" << i << "] size " << (ec ? (uint64_t)e.size_ : fsize) << " " << k << "-mers " << terms << " : "
+           << e.path_ << " : " << e.name_ << std::endl;
         min_kmers = std::min(min_kmers, terms);
         max_kmers = std::max(max_kmers, terms);
         total += terms;
@@ -138,28 +124,42 @@ int construct(int argc, char** argv, bool compact) {
                      compact ? "compact-construct" : "classic-construct", compact ? " [-p PAGE_SIZE]" : "");
         return 1;
     }
-    const std::string &input = a.positional[0], &out = a.positional[1];
-    const char* ext = compact ? ".cobs_compact" : ".cobs_classic";
-    if (!ends_with(out, ext)) {       // classic_index.cpp:596-599, compact_index.cpp:176-179
-        std::fprintf(stderr, "Error: COBS index file must end with %s\n", ext);
-        return 1;
+    // the C++17 mirror of the reference's construction API (include/cobs_gpu_construct.hpp),
+    // statement for statement what src/cobs.cpp:235-241 / :373-377 do
+    cobs_gpu::DocumentList filelist(a.positional[0], cobs_gpu::StringToFileType(a.file_type));
+    print_document_list(filelist, a.p.term_size, std::cout);
+    if (compact) {
+        cobs_gpu::CompactIndexParameters p;
+        p.term_size = a.p.term_size; p.canonicalize = (uint8_t)a.p.canonicalize; p.num_hashes = a.p.num_hashes;
+        p.false_positive_rate = a.p.false_positive_rate; p.page_size = a.p.page_size;
+        p.clobber = a.clobber; p.continue_ = a.cont; p.device = a.p.device;
+        cobs_gpu::compact_construct(filelist, a.positional[1], "", p);
+    } else {
+        cobs_gpu::ClassicIndexParameters p;
+        p.term_size = a.p.term_size; p.canonicalize = (uint8_t)a.p.canonicalize; p.num_hashes = a.p.num_hashes;
+        p.false_positive_rate = a.p.false_positive_rate;
+        p.clobber = a.clobber; p.continue_ = a.cont; p.device = a.p.device;
+        cobs_gpu::classic_construct(filelist, a.positional[1], "", p);
     }
-    if (std::filesystem::exists(out) && !a.clobber && !a.cont) {      // classic_index.cpp:602-612
-        std::fprintf(stderr, "Output file exists, will not overwrite without --clobber\n");
-        return 1;
-    }
-    List l;
-    if (!open_list(l, input, a.file_type)) return fail();
-    print_document_list(l.dl, a.p.term_size, std::cout);
-    const cobs_gpu_status st = compact ? cobs_gpu_build_compact_list(l.dl, &a.p, out.c_str())
-                                       : cobs_gpu_build_classic_list(l.dl, &a.p, out.c_str());
-    return st == COBS_GPU_OK ? 0 : fail();
+    return 0;
 }
 
 }  // namespace
 
 // -> -1 if argv[1] is not one of the sub-tools, else the exit code
+static int tools(int argc, char** argv);
+
 int cobs_gpu_tools_main(int argc, char** argv) {
+    try {
+        return tools(argc, argv);
+    } catch (const cobs_gpu::Error& e) {
+        // the reference prints "EXCEPTION: ..." and returns -1 (src/cobs.cpp:1070-1076) or exits
+        std::fprintf(stderr, "%s%s\n", e.status == COBS_GPU_ERR_ARG && std::strncmp(e.what(), "COBS_GPU", 8) != 0 ? "" : "EXCEPTION: ", e.what());
+        return 1;
+    }
+}
+
+static int tools(int argc, char** argv) {
     if (argc < 2) return -1;
     const std::string tool = argv[1];
     if (tool == "classic-construct") return construct(argc - 2, argv + 2, false);
@@ -171,34 +171,25 @@ int cobs_gpu_tools_main(int argc, char** argv) {
                          tool == "doc-dump" ? " [--no-canonicalize]" : "");
             return 1;
         }
-        List l;
-        if (!open_list(l, a.positional[0], a.file_type)) return fail();
+        cobs_gpu::DocumentList filelist(a.positional[0], cobs_gpu::StringToFileType(a.file_type));
         const unsigned k = a.p.term_size;
         if (tool == "doc-list") {
-            print_document_list(l.dl, k, std::cout);
+            print_document_list(filelist, k, std::cout);
             return 0;
         }
-        const size_t n = cobs_gpu_doclist_size(l.dl);
+        const size_t n = filelist.size();
         std::cerr << "Found " << n << " documents." << std::endl;
-        std::vector<char> terms, canon(k);
+        std::vector<char> canon(k);
         for (size_t i = 0; i < n; ++i) {
-            cobs_gpu_doc_entry e;
-            cobs_gpu_doclist_entry(l.dl, i, &e);
-            std::cerr << "document[" << i << "] : " << e.path << " : " << e.name << std::endl;
-            uint64_t nt = 0;
-            if (cobs_gpu_doclist_terms(l.dl, i, k, nullptr, 0, &nt) != COBS_GPU_OK) return fail();
-            terms.resize((size_t)nt * k + 1);
-            if (cobs_gpu_doclist_terms(l.dl, i, k, terms.data(), (size_t)nt * k, &nt) != COBS_GPU_OK) return fail();
-            for (uint64_t t = 0; t < nt; ++t) {
-                const char* term = terms.data() + t * k;
+            const cobs_gpu::DocumentEntry e = filelist[i];
+            std::cerr << "document[" << i << "] : " << e.path_ << " : " << e.name_ << std::endl;
+            e.process_terms(k, [&](const char* term) {
                 if (a.no_canonicalize) std::cout.write(term, k) << '\n';
                 else if (canonical(term, canon.data(), k)) std::cout.write(canon.data(), k) << '\n';
                 else (std::cout << "Invalid DNA base pair: ").write(term, k) << std::endl;
-            }
+            });
             std::cout.flush();
-            uint64_t listed = 0;
-            cobs_gpu_doclist_num_terms(l.dl, i, k, &listed);
-            std::cerr << "document[" << i << "] : " << listed << " terms." << std::endl;
+            std::cerr << "document[" << i << "] : " << e.num_terms(k) << " terms." << std::endl;
         }
         return 0;
     }

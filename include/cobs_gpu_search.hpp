@@ -77,9 +77,13 @@ public:
         check(cobs_gpu_open(cp.data(), cp.size(), &o, &ix_));
     }
 
+    //! adopt an index handle that is already open (e.g. built by cobs_gpu_build_index_list)
+    explicit ClassicSearch(cobs_gpu_index* adopted) : ix_(adopted) {}
+
     ~ClassicSearch() override { cobs_gpu_close(ix_); }
     ClassicSearch(const ClassicSearch&) = delete;
     ClassicSearch& operator=(const ClassicSearch&) = delete;
+    ClassicSearch(ClassicSearch&& o) noexcept : ix_(o.ix_), hits_(std::move(o.hits_)) { o.ix_ = nullptr; }
 
     void search(const std::string& query, std::vector<SearchResult>& result,
                 double threshold = 0.0, size_t num_results = 0) final {
