@@ -499,44 +499,75 @@ cobs_gpu_status alloc_part(cobs_gpu_index* ix, Part& pt) {
 }
 
 // Resident chunks: copy the held columns of every held sub-index from the mapped file into HBM.
+// The index file (an mmap of the page cache) -> HBM.  Rows travel in slabs of up to 256 MiB: host
+// threads copy a slab from the mapping into one of two pinned buffers while the previous slab is on
+// its way over PCIe (and, when the device pitch differs from the file's row size, through the
+// re-pitch kernel) -- a plain hipMemcpy from pageable memory measured 10-25 GB/s here.
 cobs_gpu_status upload_resident(Part& pt, const uint8_t* file) {
     const IndexMeta& m = pt.meta;
     const uint64_t src_pitch = m.page_row_bytes();
-    DevBuf<uint8_t> stage;
+    constexpr uint64_t kSlab = 256ull << 20;
+    struct Slab {
+        PinnedBuf<uint8_t> host;
+        DevBuf<uint8_t> dev;                 // raw rows on the device, only when they are re-pitched
+        hipEvent_t done = nullptr;
+        bool busy = false;
+        ~Slab() { if (done) (void)hipEventDestroy(done); }
+    } slab[2];
+    hipStream_t stream = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } } sg{stream};
+    for (Slab& sl : slab) HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    const size_t nthreads = std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
+    auto copy_in = [&](uint8_t* dst, const uint8_t* src, uint64_t bytes) {
+        if (bytes < (8u << 20) || nthreads == 1) { std::memcpy(dst, src, (size_t)bytes); return; }
+        std::vector<std::thread> pool;
+        const uint64_t per = (bytes / nthreads + 4095) / 4096 * 4096;
+        for (size_t t = 0; t < nthreads; ++t) {
+            const uint64_t o = t * per;
+            if (o >= bytes) break;
+            pool.emplace_back([=]() { std::memcpy(dst + o, src + o, (size_t)std::min(per, bytes - o)); });
+        }
+        for (auto& t : pool) t.join();
+    };
+    int cur = 0;
     for (Chunk& c : pt.chunks) {
         for (size_t lp = 0; lp < c.vp.size(); ++lp) {
             const PageDev& pd = c.pages[lp];
             const VPage& v = c.vp[lp];
             const uint8_t* src = file + m.page_offset(v.fp);
             uint8_t* dst = c.d_data + pd.base;
-            if (src_pitch == c.pitch && v.col0 == 0) {
-                // rows already have the device pitch: one straight copy
-                const uint64_t total = pd.sig * src_pitch;
-                const uint64_t step = 1ull << 30;
-                for (uint64_t o = 0; o < total; o += step)
-                    HIP_TRY(hipMemcpy(dst + o, src + o, (size_t)std::min(step, total - o), hipMemcpyHostToDevice));
-            } else {
-                // stage raw rows, re-pitch on the device
-                const uint64_t rows_per = std::max<uint64_t>(1, (64ull << 20) / src_pitch);
-                HIP_TRY(stage.reserve((size_t)(std::min(rows_per, pd.sig) * src_pitch)));
-                for (uint64_t r = 0; r < pd.sig; r += rows_per) {
-                    const uint64_t n = std::min(rows_per, pd.sig - r);
-                    HIP_TRY(hipMemcpy(stage.p, src + r * src_pitch, (size_t)(n * src_pitch), hipMemcpyHostToDevice));
+            const bool straight = src_pitch == c.pitch && v.col0 == 0;      // rows already have the device pitch
+            const uint64_t rows_per = std::max<uint64_t>(1, kSlab / src_pitch);
+            for (uint64_t r = 0; r < pd.sig; r += rows_per) {
+                const uint64_t n = std::min(rows_per, pd.sig - r), bytes = n * src_pitch;
+                Slab& sl = slab[cur];
+                cur ^= 1;
+                if (sl.busy) { HIP_TRY(hipEventSynchronize(sl.done)); sl.busy = false; }
+                HIP_TRY(sl.host.reserve((size_t)(std::min(rows_per, pd.sig) * src_pitch)));
+                copy_in(sl.host.p, src + r * src_pitch, bytes);
+                if (straight) {
+                    HIP_TRY(hipMemcpyAsync(dst + r * src_pitch, sl.host.p, (size_t)bytes, hipMemcpyHostToDevice, stream));
+                } else {
+                    HIP_TRY(sl.dev.reserve(sl.host.cap));
+                    HIP_TRY(hipMemcpyAsync(sl.dev.p, sl.host.p, (size_t)bytes, hipMemcpyHostToDevice, stream));
                     RepitchArgs ra;
-                    ra.src = stage.p;
+                    ra.src = sl.dev.p;
                     ra.dst = dst + r * c.pitch;
                     ra.rows = n;
                     ra.src_pitch = (uint32_t)src_pitch;
                     ra.dst_pitch = c.pitch;
                     ra.copy_bytes = (uint32_t)v.ncols;
                     ra.src_col0 = (uint32_t)v.col0;
-                    HIP_TRY(launch_repitch(ra, nullptr));
-                    HIP_TRY(hipStreamSynchronize(nullptr));
+                    HIP_TRY(launch_repitch(ra, stream));
                 }
+                HIP_TRY(hipEventRecord(sl.done, stream));
+                sl.busy = true;
             }
-            HIP_TRY(hipMemset(dst + pd.sig * (uint64_t)c.pitch, 0, c.pitch));   // zero row
+            HIP_TRY(hipMemsetAsync(dst + pd.sig * (uint64_t)c.pitch, 0, c.pitch, stream));   // zero row
         }
     }
+    HIP_TRY(hipStreamSynchronize(stream));
     return COBS_GPU_OK;
 }
 
