@@ -326,3 +326,29 @@ def test_readers_survive_damaged_files(capi, docdir, tmp_path):
                         pass
             outcomes["ok"] += 1
     assert outcomes["ok"] > 50 and outcomes["error"] > 50, outcomes
+
+
+def test_cpp_construction_mirror(docdir, tmp_path):
+    """include/cobs_gpu_construct.hpp (cobs_gpu::DocumentList / DocumentEntry / FileType, the C++17
+    mirror of cobs/document_list.hpp): compiled with g++ against libcobs_gpu.so, host-only calls,
+    compared with the checker's view of the same files"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "construct_api")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "construct_api.cpp"), "-o", exe,
+                           "-L", os.path.join(root, "cobs_amd"), "-lcobs_gpu",
+                           "-Wl,-rpath," + os.path.join(root, "cobs_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([exe, docdir], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().split("\n")
+    ents = D.document_list(os.path.join(docdir, "fasta_multi"))
+    assert lines[0] == "fasta_multi %d" % len(ents)
+    for ln, e in zip(lines[1:], ents):
+        assert ln == "%s %d %d %d %d" % (e.name, e.size, e.subdoc_index, e.num_terms(31), len(e.terms(31)))
+    srt = _lines(os.path.join(docdir, "cortex", "document_sorted.txt"))
+    assert lines[1 + len(ents)] == "cortex DRR030535 31 24158 24158 %s %s" % (srt[0].decode(), srt[-1].decode())
+    fq = sorted(D.document_list(docdir, D.FASTQ), key=lambda e: (e.size, e.path))
+    assert lines[2 + len(ents):2 + len(ents) + 3] == ["fastq %s %d" % (e.name, e.size) for e in fq]
+    assert "Unknown file type nonsense" in lines[-2]
+    assert lines[-1] == "refused Error: COBS index file must end with .cobs_classic"
