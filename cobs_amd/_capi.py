@@ -50,7 +50,8 @@ class BuildParams(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("term_size", C.c_uint32), ("canonicalize", C.c_uint32),
                 ("num_hashes", C.c_uint32), ("false_positive_rate", C.c_double),
                 ("signature_size", C.c_uint64), ("page_size", C.c_uint64),
-                ("device", C.c_int32), ("text_batch_bytes", C.c_uint32), ("doc_terms", C.POINTER(C.c_uint64))]
+                ("device", C.c_int32), ("text_batch_bytes", C.c_uint32), ("doc_terms", C.POINTER(C.c_uint64)),
+                ("set_bits_mode", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class DocEntry(C.Structure):

@@ -166,6 +166,7 @@ def _params(p, device):
     b.page_size = getattr(p, "page_size", 0)
     b.device = device
     b.text_batch_bytes = int(getattr(p, "text_batch_bytes", 0))
+    b.set_bits_mode = int(getattr(p, "set_bits_mode", 0))
     return b
 
 

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -73,13 +74,16 @@ struct Params {
     int device = -1;
     const uint64_t* doc_terms = nullptr;
     uint64_t text_batch = 0;
+    uint32_t set_bits_mode = 0;
 };
 
 cobs_gpu_status read_params(const cobs_gpu_build_params* p, Params& out) {
     if (p) {
         if (p->struct_size < offsetof(cobs_gpu_build_params, doc_terms))
             return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "cobs_gpu_build_params.struct_size is too small");
-        if (p->struct_size >= sizeof(cobs_gpu_build_params)) out.doc_terms = p->doc_terms;
+        if (p->struct_size >= offsetof(cobs_gpu_build_params, set_bits_mode)) out.doc_terms = p->doc_terms;
+        if (p->struct_size >= sizeof(cobs_gpu_build_params)) out.set_bits_mode = p->set_bits_mode;
+        if (out.set_bits_mode > 2) return cobs_gpu_set_error(COBS_GPU_ERR_ARG, "set_bits_mode: 0, 1 or 2");
         out.term_size = p->term_size;
         out.canonicalize = p->canonicalize;
         out.num_hashes = p->num_hashes;
@@ -164,8 +168,11 @@ struct ListSource final : DocSource {
 // final columns of the one matrix in HBM, so there is nothing to combine).
 constexpr uint64_t kTextBatchBytes = 256ull << 20;
 constexpr size_t kTextPad = 64;                 // readable bytes behind the text (build_kernel loads dwords)
+// staging sets of a build: one being parsed into, one on its way over PCIe, one being hashed (with two,
+// parsing waits for the kernel of the batch before last: 8.2 ms per 256 MiB batch instead of 6)
+constexpr int kStages = 3;
 
-// One of the two staging sets of a build: pinned term text + stretch tables, their device copies,
+// One of the staging sets of a build: pinned term text + stretch tables, their device copies,
 // the event that tells when the GPU is done with them.  Host threads parse documents straight into
 // `text` (every document of a batch owns a span sized by its text bound; what it leaves unused is
 // a gap stretch the kernel skips), so a character is written once between the file and the H2D copy.
@@ -190,12 +197,33 @@ struct Stage {
 struct StagePool {
     std::mutex mu;
     std::vector<Stage*> idle;
+    std::vector<DevBuf<uint8_t>*> idle_planes;     // byte-map planes (one buffer per build in flight)
     int device = -1;
+    DevBuf<uint8_t>* take_planes(int dev) {
+        std::lock_guard<std::mutex> g(mu);
+        if (device != dev) {
+            for (Stage* s : idle) delete s;
+            idle.clear();
+            for (auto* b : idle_planes) delete b;
+            idle_planes.clear();
+            device = dev;
+        }
+        if (idle_planes.empty()) return new DevBuf<uint8_t>;
+        DevBuf<uint8_t>* b = idle_planes.back();
+        idle_planes.pop_back();
+        return b;
+    }
+    void give_planes(DevBuf<uint8_t>* b) {
+        std::lock_guard<std::mutex> g(mu);
+        idle_planes.push_back(b);
+    }
     Stage* take(int dev) {
         std::lock_guard<std::mutex> g(mu);
         if (device != dev) {                    // buffers belong to the device they were made on
             for (Stage* s : idle) delete s;
             idle.clear();
+            for (auto* b : idle_planes) delete b;
+            idle_planes.clear();
             device = dev;
         }
         if (idle.empty()) return new Stage;
@@ -237,24 +265,34 @@ cobs_gpu_status build_into(uint32_t* d_matrix, uint64_t sig, uint64_t row_bytes,
     BUILD_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     struct Guard {
         hipStream_t s, c = nullptr;
-        Stage* st[2];
+        Stage* st[kStages];
+        DevBuf<uint8_t>* planes;
         ~Guard() {
             if (c) { (void)hipStreamSynchronize(c); (void)hipStreamDestroy(c); }
             (void)hipStreamSynchronize(s);
             (void)hipStreamDestroy(s);
             for (Stage* x : st) { x->busy = false; stage_pool().give(x); }
+            stage_pool().give_planes(planes);
         }
-    } guard{stream, nullptr, {stage_pool().take(dev), stage_pool().take(dev)}};
+    } guard{stream, nullptr, {stage_pool().take(dev), stage_pool().take(dev), stage_pool().take(dev)}, stage_pool().take_planes(dev)};
+    static_assert(kStages == 3, "the guard's initialiser lists the staging sets");
+    // byte-map planes of a batch: one byte per (document of the batch, signature row)
+    const uint64_t bm_stride = (sig + 255) / 256 * 256;
+    constexpr uint64_t kPlaneBudget = 3ull << 30;
     BUILD_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
     guard.c = copy_stream;
-    Stage* stage[2] = {guard.st[0], guard.st[1]};
-    for (Stage* s : stage) {
+    Stage* const* stage = guard.st;
+    for (Stage* s : guard.st) {
         if (!s->done) BUILD_TRY(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
         if (!s->copied) BUILD_TRY(hipEventCreateWithFlags(&s->copied, hipEventDisableTiming));
     }
 
+    // COBS_GPU_BUILD_TRACE=1: where the host side of a build spends its time (stderr, one line per build)
+    static const bool trace = std::getenv("COBS_GPU_BUILD_TRACE") != nullptr;
+    double t_wait = 0, t_parse = 0, t_table = 0, t_issue = 0;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const size_t max_threads = src.parses() ? std::min<size_t>(hw, 64) : std::min<size_t>(hw, 8);
+    const size_t max_threads = src.parses() ? std::min<size_t>(hw, 128) : std::min<size_t>(hw, 8);
     std::vector<Slot> slots;
     std::vector<std::string> scratch(max_threads);      // the file being parsed, one per worker, reused
     int cur = 0;
@@ -276,8 +314,11 @@ cobs_gpu_status build_into(uint32_t* d_matrix, uint64_t sig, uint64_t row_bytes,
             ++b1;
         }
         Stage& s = *stage[cur];
+        double t0 = now();
         if (s.busy) { BUILD_TRY(hipEventSynchronize(s.done)); s.busy = false; }
         BUILD_TRY(s.text.reserve((size_t)std::max<uint64_t>(total, text_batch) + kTextPad));
+        t_wait += now() - t0;
+        t0 = now();
         // parse: every worker takes the next document and writes its term text into its span
         std::atomic<size_t> next{0};
         auto work = [&](size_t tid) {
@@ -304,6 +345,8 @@ cobs_gpu_status build_into(uint32_t* d_matrix, uint64_t sig, uint64_t row_bytes,
             for (size_t t = 0; t < nthreads; ++t) pool.emplace_back(work, t);
             for (auto& t : pool) t.join();
         }
+        t_parse += now() - t0;
+        t0 = now();
         // the stretch table: a document's stretches, the rest of its span as a gap
         size_t nsegs = 0;
         for (const Slot& sl : slots) {
@@ -330,6 +373,8 @@ cobs_gpu_status build_into(uint32_t* d_matrix, uint64_t sig, uint64_t row_bytes,
             if (at < sl.begin + sl.cap) add(at, kBuildGapStretch);
         }
         s.seg_off.p[ns] = total;
+        t_table += now() - t0;
+        t0 = now();
         if (ns && total) {
             BUILD_TRY(s.d_text.reserve(s.text.cap));
             BUILD_TRY(s.d_off.reserve(s.seg_off.cap));
@@ -351,14 +396,44 @@ cobs_gpu_status build_into(uint32_t* d_matrix, uint64_t sig, uint64_t row_bytes,
             a.term_size = pr.term_size;
             a.canonicalize = pr.canonicalize;
             a.num_hashes = pr.num_hashes;
+            a.bytemap = nullptr;
+            a.bm_stride = bm_stride;
+            a.col_base = (uint32_t)b0;
+            // byte stores into per-document planes + one packing pass beat the scattered atomics
+            // whenever the planes of the batch are affordable and there is enough text to pay for
+            // zeroing and packing them (mode 2 forces them, mode 1 the atomics)
+            const uint64_t plane_bytes = (uint64_t)(b1 - b0) * bm_stride;
+            const bool planes = pr.set_bits_mode == 2 ||
+                                (pr.set_bits_mode == 0 && plane_bytes <= kPlaneBudget && plane_bytes <= 16 * total);
+            if (planes) {
+                BUILD_TRY(guard.planes->reserve((size_t)plane_bytes));
+                BUILD_TRY(hipMemsetAsync(guard.planes->p, 0, (size_t)plane_bytes, stream));
+                a.bytemap = guard.planes->p;
+            }
             BUILD_TRY(launch_build(a, total, stream));
+            if (planes) {
+                PackArgs pk;
+                pk.bytemap = guard.planes->p;
+                pk.bm_stride = bm_stride;
+                pk.matrix = d_matrix;
+                pk.row_bytes = row_bytes;
+                pk.rows = sig;
+                pk.col_base = (uint32_t)b0;
+                pk.ndocs = (uint32_t)(b1 - b0);
+                BUILD_TRY(launch_pack_bytemap(pk, stream));
+            }
             BUILD_TRY(hipEventRecord(s.done, stream));
             s.busy = true;
         }
-        cur ^= 1;                                           // the other set is parsed into while this one is hashed
+        t_issue += now() - t0;
+        cur = (cur + 1) % kStages;                          // the next set is parsed into while this one is uploaded and hashed
         b0 = b1;
     }
+    const double t0 = now();
     BUILD_TRY(hipStreamSynchronize(stream));
+    if (trace)
+        std::fprintf(stderr, "[cobs_gpu build] %zu documents: wait for a staging set %.3f s, parse %.3f s, stretch table %.3f s, "
+                             "issue %.3f s, drain %.3f s\n", n, t_wait, t_parse, t_table, t_issue, now() - t0);
     return COBS_GPU_OK;
 }
 

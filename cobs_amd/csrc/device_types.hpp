@@ -116,6 +116,22 @@ struct BuildArgs {
     uint32_t term_size;
     uint32_t canonicalize;
     uint32_t num_hashes;
+    // byte-map mode (bytemap != nullptr): instead of an atomicOr into the matrix a term stores the
+    // byte 1 at bytemap[(column - col_base) * bm_stride + row] -- one plane of signature_size bytes
+    // per document of the launch; pack_bytemap_kernel folds the planes into the matrix afterwards
+    uint8_t* bytemap;
+    uint64_t bm_stride;
+    uint32_t col_base;
+};
+
+// byte-map planes of one build launch -> bits of the matrix
+struct PackArgs {
+    const uint8_t* bytemap;     // ndocs planes of bm_stride bytes (0 / 1), plane d = column col_base + d
+    uint64_t bm_stride;         // multiple of 256
+    uint32_t* matrix;           // rows of row_bytes (multiple of 4) bytes, as words
+    uint64_t row_bytes;
+    uint64_t rows;              // signature_size
+    uint32_t col_base, ndocs;
 };
 
 // classic_construct_random: documents of random 31-mers

@@ -1334,6 +1334,49 @@ __device__ __forceinline__ bool has_newline(uint32_t w) {
     return ((x - 0x01010101u) & ~x & 0x80808080u) != 0u;
 }
 
+// Where a term's bit goes.  Scattered atomics run at 22-27 G/s on this part whatever their locality
+// (they leave the L2 as 32-byte memory-side requests, profiles/r02_atomic_probe.txt) while plain
+// byte stores reach 41 G/s and more: in byte-map mode a term stores a byte into its document's
+// plane and pack_bytemap_kernel turns the planes of the launch into matrix bits afterwards.
+__device__ __forceinline__ void set_term_bit(const BuildArgs& a, uint32_t doc, uint64_t row) {
+    if (a.bytemap != nullptr) {
+        a.bytemap[(uint64_t)(doc - a.col_base) * a.bm_stride + row] = 1;
+    } else {
+        const uint64_t byte_in_row = doc >> 3;
+        const uint32_t bit = 1u << ((uint32_t)(byte_in_row & 3u) * 8u + (doc & 7u));
+        atomicOr(a.matrix + (row * a.row_bytes + byte_in_row) / 4u, bit);
+    }
+}
+
+// One thread per (four consecutive rows, one 32-document word of the matrix row): reads the rows'
+// bytes from every plane whose column falls into the word (dword loads, coalesced across the
+// rows of a wave), ORs the bits into the four words.  Launches of one build are ordered on one
+// stream and every (row, word) belongs to one thread, so the read-modify-write needs no atomic.
+__global__ __launch_bounds__(256) void pack_bytemap_kernel(PackArgs a) {
+    const uint32_t w0 = a.col_base >> 5, w1 = (a.col_base + a.ndocs - 1u) >> 5;      // words the launch touches
+    const uint64_t nquads = (a.rows + 3u) / 4u;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t quad = gid % nquads;                   // consecutive threads = consecutive rows
+    const uint32_t w = w0 + (uint32_t)(gid / nquads);
+    if (w > w1) return;
+    const uint64_t r0 = quad * 4u;
+    const uint32_t c0 = max(a.col_base, w << 5), c1 = min(a.col_base + a.ndocs, (w + 1u) << 5);
+    uint32_t acc[4] = {0u, 0u, 0u, 0u};
+    for (uint32_t c = c0; c < c1; ++c) {
+        const uint32_t x = *reinterpret_cast<const uint32_t*>(a.bytemap + (uint64_t)(c - a.col_base) * a.bm_stride + r0);
+        const uint32_t b = c & 31u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] |= ((x >> (8 * i)) & 1u) << b;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (r0 + i < a.rows && acc[i] != 0u) {
+            uint32_t* m = a.matrix + ((r0 + i) * a.row_bytes) / 4u + w;
+            *m |= acc[i];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void build_kernel(BuildArgs a, uint64_t total_bytes) {
     // the stretch of the block's first position (wave-uniform search), then a few steps per thread
     const uint64_t base = (uint64_t)blockIdx.x * 256u;
@@ -1351,8 +1394,6 @@ __global__ __launch_bounds__(256) void build_kernel(BuildArgs a, uint64_t total_
     if (colw == kBuildGapStretch) return;
     const bool raw = (colw & kBuildRawStretch) != 0u;
     const uint32_t doc = colw & ~kBuildRawStretch;
-    const uint64_t byte_in_row = doc >> 3;
-    const uint32_t bit = 1u << ((uint32_t)(byte_in_row & 3u) * 8u + (doc & 7u));
     const uint8_t* p = a.text + gid;
     if (k == 31u) {
         // the 31-mer and one following byte as 8 (unaligned) dwords; the text buffer is padded
@@ -1387,7 +1428,7 @@ __global__ __launch_bounds__(256) void build_kernel(BuildArgs a, uint64_t total_
         if (fast) {
             for (uint32_t j = 0; j < a.num_hashes; ++j) {
                 const uint64_t row = fast_mod(xxh64_31(c, (uint64_t)j), a.signature_size, a.magic);
-                atomicOr(a.matrix + (row * a.row_bytes + byte_in_row) / 4u, bit);
+                set_term_bit(a, doc, row);
             }
             return;
         }
@@ -1408,7 +1449,7 @@ __global__ __launch_bounds__(256) void build_kernel(BuildArgs a, uint64_t total_
     }
     for (uint32_t j = 0; j < a.num_hashes; ++j) {
         const uint64_t row = fast_mod(xxh64_view(kv, (uint64_t)j), a.signature_size, a.magic);
-        atomicOr(a.matrix + (row * a.row_bytes + byte_in_row) / 4u, bit);
+        set_term_bit(a, doc, row);
     }
 }
 
@@ -1714,6 +1755,16 @@ hipError_t launch_build(const BuildArgs& a, uint64_t total_bytes, hipStream_t st
     const uint64_t blocks = (total_bytes + 255) / 256;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(build_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, a, total_bytes);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_bytemap(const PackArgs& a, hipStream_t stream) {
+    if (a.ndocs == 0 || a.rows == 0) return hipSuccess;
+    const uint32_t nwords = ((a.col_base + a.ndocs - 1u) >> 5) - (a.col_base >> 5) + 1u;
+    const uint64_t threads = (a.rows + 3u) / 4u * nwords;
+    const uint64_t blocks = (threads + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pack_bytemap_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

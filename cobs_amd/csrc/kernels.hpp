@@ -29,6 +29,7 @@ hipError_t launch_topk(const TopkArgs& a, hipStream_t stream);
 
 // Index construction: one thread per text position hashes its term and sets the bits.
 hipError_t launch_build(const BuildArgs& a, uint64_t total_bytes, hipStream_t stream);
+hipError_t launch_pack_bytemap(const PackArgs& a, hipStream_t stream);
 
 hipError_t launch_random_build(const RandomBuildArgs& a, uint64_t ndocs, hipStream_t stream);
 hipError_t launch_combine(const CombineArgs& a, hipStream_t stream);

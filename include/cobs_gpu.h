@@ -177,6 +177,11 @@ typedef struct cobs_gpu_build_params {
      * index reports it (FastaFile::num_terms, fasta_file.hpp:147-153) -- what sizes a signature when
      * signature_size is 0.  NULL = count the k-grams of the given text. */
     const uint64_t* doc_terms;
+    /* how build_kernel sets bits: 0 = automatic, 1 = atomicOr into the matrix, 2 = byte stores into
+     * per-document planes that a second kernel packs into the matrix (faster than the part's
+     * scattered-atomic rate; used when the planes of a batch fit 3 GiB).  Same index either way. */
+    uint32_t set_bits_mode;
+    uint32_t reserved;
 } cobs_gpu_build_params;
 
 /* classic_construct (construction/classic_index.cpp:565-659) for documents that are already

@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--num-hashes", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--batch-mb", type=int, default=0, help="text batch size (0 = the library's default)")
+    ap.add_argument("--set-bits-mode", type=int, default=0, help="0 auto, 1 atomics, 2 byte planes")
     a = ap.parse_args()
     import torch  # noqa: F401
     import cobs_amd
@@ -63,6 +65,7 @@ def main():
 
     p = cobs_amd.ClassicIndexParameters()
     p.num_hashes, p.false_positive_rate, p.clobber = a.num_hashes, 0.3, True
+    p.text_batch_bytes, p.set_bits_mode = a.batch_mb << 20, a.set_bits_mode
     out = {"docs": a.docs, "file_bytes": file_bytes, "num_hashes": a.num_hashes, "generate_s": round(t_gen, 2)}
 
     t0 = time.time()

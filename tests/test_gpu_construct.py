@@ -315,9 +315,13 @@ def _build_both(cobs_amd, construct, D, root, tmp_path, tag, k=31, canonicalize=
             params.page_size = page_size
             kw["page_size"] = page_size
         pg, pr = str(tmp_path / (tag + "_g" + ext)), str(tmp_path / (tag + "_r" + ext))
-        build_gpu(cobs_amd.DocumentList(root, filter), pg, params)
         build_ref(kdocs, pr, term_size=k, canonicalize=canonicalize, num_hashes=num_hashes, false_positive_rate=fpr, **kw)
-        assert open(pg, "rb").read() == open(pr, "rb").read(), (tag, ext)
+        # both ways of setting bits: atomicOr into the matrix (1), byte planes + packing pass (2)
+        for mode in (1, 2):
+            params.set_bits_mode = mode
+            params.clobber = True
+            build_gpu(cobs_amd.DocumentList(root, filter), pg, params)
+            assert open(pg, "rb").read() == open(pr, "rb").read(), (tag, ext, mode)
         out.append(pg)
     return out
 
