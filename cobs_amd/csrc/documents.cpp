@@ -16,6 +16,10 @@
 // The .cobs_cache side files of the reference are never written or read.
 #include "documents.hpp"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -41,11 +45,33 @@ bool ends_with(const std::string& s, const char* suffix) {
     return s.size() >= n && std::memcmp(s.data() + s.size() - n, suffix, n) == 0;
 }
 
-// whole file into memory; .gz is inflated when `gunzip` (the reference does so for FASTA / FASTQ
-// paths ending in .gz only: fasta_file.hpp:92-103, fastq_file.hpp:93-104)
-cobs_gpu_status read_file(const std::string& path, bool gunzip, std::string& data) {
-    data.clear();
+// a file's bytes while it is parsed
+struct View {
+    const char* p = nullptr;
+    size_t n = 0;
+    const char* data() const { return p ? p : ""; }        // never null: memchr / memcpy of 0 bytes stay defined
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    char operator[](size_t i) const { return p[i]; }
+};
+
+// The bytes of a document file: a read-only mapping of the page cache (parsed in place: between
+// the page cache and the staging buffer a character is copied once), or -- .gz, when `gunzip`: the
+// reference inflates FASTA / FASTQ paths ending in .gz only, fasta_file.hpp:92-103,
+// fastq_file.hpp:93-104 -- inflated into the caller's scratch string.
+struct FileBytes {
+    void* map = nullptr;
+    size_t len = 0;
+    View v;
+    FileBytes() = default;
+    FileBytes(const FileBytes&) = delete;
+    FileBytes& operator=(const FileBytes&) = delete;
+    ~FileBytes() { if (map) ::munmap(map, len); }
+};
+
+cobs_gpu_status read_file(const std::string& path, bool gunzip, std::string& scratch, FileBytes& fb) {
     if (gunzip && ends_with(path, ".gz")) {
+        scratch.clear();
         gzFile g = gzopen(path.c_str(), "rb");
         if (!g) return err(COBS_GPU_ERR_OPEN, "could not open document " + path);
         gzbuffer(g, 1u << 20);
@@ -54,32 +80,39 @@ cobs_gpu_status read_file(const std::string& path, bool gunzip, std::string& dat
             const int n = gzread(g, buf, sizeof buf);
             if (n < 0) { gzclose(g); return err(COBS_GPU_ERR_FORMAT, "corrupt gzip stream in " + path); }
             if (n == 0) break;
-            data.append(buf, (size_t)n);
+            scratch.append(buf, (size_t)n);
         }
         gzclose(g);
+        fb.v = View{scratch.data(), scratch.size()};
         return COBS_GPU_OK;
     }
-    FILE* f = std::fopen(path.c_str(), "rb");
-    if (!f) return err(COBS_GPU_ERR_OPEN, "could not open document " + path);
-    // `data` is a scratch buffer its caller reuses: growing it is the only allocation
-    size_t have = 0;
-    for (;;) {
-        if (data.size() < have + (1u << 20)) data.resize(std::max<size_t>(data.size() * 2, have + (1u << 20)));
-        const size_t n = std::fread(&data[have], 1, data.size() - have, f);
-        have += n;
-        if (n == 0) break;
+    const int fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return err(COBS_GPU_ERR_OPEN, "could not open document " + path);
+    struct stat st;
+    if (::fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {
+        ::close(fd);
+        return err(COBS_GPU_ERR_OPEN, "could not open document " + path);
     }
-    const bool bad = std::ferror(f) != 0;
-    std::fclose(f);
-    data.resize(have);
-    return bad ? err(COBS_GPU_ERR_OPEN, "read error in " + path) : COBS_GPU_OK;
+    if (st.st_size > 0) {
+        void* m = ::mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+        if (m == MAP_FAILED) {
+            ::close(fd);
+            return err(COBS_GPU_ERR_OPEN, "could not map document " + path);
+        }
+        (void)::madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+        fb.map = m;
+        fb.len = (size_t)st.st_size;
+        fb.v = View{(const char*)m, (size_t)st.st_size};
+    }
+    ::close(fd);
+    return COBS_GPU_OK;
 }
 
 // std::getline over a buffer: calls fn(ptr, len) per line; a trailing '\n' does not start another
 // line, a last line without '\n' is a line.  fn returns false to stop.  -> offset after the last
 // line consumed (what tellg() reports)
 template <typename F>
-size_t for_lines(const std::string& data, size_t pos, F fn) {
+size_t for_lines(const View& data, size_t pos, F fn) {
     while (pos < data.size()) {
         const void* nl = std::memchr(data.data() + pos, '\n', data.size() - pos);
         const size_t end = nl ? (size_t)((const char*)nl - data.data()) : data.size();
@@ -108,7 +141,7 @@ std::string pad_index(uint64_t i, int width = 6) {      // cobs/util/misc.hpp:57
 // which are copied from offset wb - (k - 1), i.e. measured from the bytes READ, not from the
 // buffer's fill pos + wb; from the second refill on the carried characters are therefore not the
 // last ones.  Each buffer state is one raw stretch of term text.
-cobs_gpu_status text_terms(const std::string& data, uint32_t k, TermSink& out, std::vector<TermSeg>& segs) {
+cobs_gpu_status text_terms(const View& data, uint32_t k, TermSink& out, std::vector<TermSeg>& segs) {
     constexpr size_t kBuf = 64 * 1024;
     if (k == 0 || k > kBuf) return err(COBS_GPU_ERR_UNSUPPORTED, "term size does not fit the text reader's buffer");
     std::vector<char> buffer(kBuf);
@@ -153,7 +186,7 @@ struct CortexHeader {
     size_t data_begin = 0;
 };
 
-cobs_gpu_status cortex_header(const std::string& d, const std::string& path, CortexHeader& h) {
+cobs_gpu_status cortex_header(const View& d, const std::string& path, CortexHeader& h) {
     size_t p = 0;
     auto need = [&](size_t n) { return p + n <= d.size(); };
     auto magic = [&]() {
@@ -202,7 +235,7 @@ uint64_t cortex_num_kmers(const CortexHeader& h, size_t file_size) {
 
 // one record = the packed k-mer (8 * words bytes) + 5 bytes of colour data; the k-mer string is a
 // sequence of its own (cortex_file.hpp:118-152)
-cobs_gpu_status cortex_terms(const std::string& d, const std::string& path, uint32_t k, TermSink& out,
+cobs_gpu_status cortex_terms(const View& d, const std::string& path, uint32_t k, TermSink& out,
                              std::vector<TermSeg>& segs) {
     CortexHeader h;
     cobs_gpu_status st = cortex_header(d, path, h);
@@ -227,7 +260,7 @@ struct KMerBufferHeader {
     size_t data_begin = 0;
 };
 
-cobs_gpu_status kmer_buffer_header(const std::string& d, const std::string& path, KMerBufferHeader& h) {
+cobs_gpu_status kmer_buffer_header(const View& d, const std::string& path, KMerBufferHeader& h) {
     static const char kBegin[] = "COBS:DOCUMENT";
     size_t p = 0;
     if (d.size() < 13 + 8 || std::memcmp(d.data(), kBegin, 13) != 0)
@@ -250,7 +283,7 @@ cobs_gpu_status kmer_buffer_header(const std::string& d, const std::string& path
     return COBS_GPU_OK;
 }
 
-cobs_gpu_status kmer_buffer_terms(const std::string& d, const std::string& path, uint32_t k, TermSink& out,
+cobs_gpu_status kmer_buffer_terms(const View& d, const std::string& path, uint32_t k, TermSink& out,
                                   std::vector<TermSeg>& segs) {
     KMerBufferHeader h;
     cobs_gpu_status st = kmer_buffer_header(d, path, h);
@@ -273,7 +306,7 @@ bool is_comment(char c) { return c == '>' || c == ';'; }
 
 // compute_index (fasta_file.hpp:53-90): size and the histogram of sequence lengths, a sequence
 // being the lines between comment / empty lines
-cobs_gpu_status fasta_index(const std::string& d, const std::string& path, DocEntry& e) {
+cobs_gpu_status fasta_index(const View& d, const std::string& path, DocEntry& e) {
     e.size = 0;
     e.run_hist.clear();
     // the first getline running into the end of the file (no '\n' at all) leaves an empty index (:62-63)
@@ -308,7 +341,7 @@ cobs_gpu_status fasta_index(const std::string& d, const std::string& path, DocEn
 // into it) and keeps its old value k - 1 after the string was cleared (a line of exactly k - 1
 // characters then counts as empty; a shorter one is read past its end, taken as sequence here).
 // Emitted: each sequence so far as one line of term text.
-void fasta_terms(const std::string& d, uint32_t k, TermSink& out) {
+void fasta_terms(const View& d, uint32_t k, TermSink& out) {
     size_t run_begin = out.size;     // the sequence being collected lies at out.data[run_begin, out.size)
     size_t held = 0, pos = 0;        // held = how many of its characters the reference still has
     auto flush = [&]() {
@@ -334,7 +367,7 @@ void fasta_terms(const std::string& d, uint32_t k, TermSink& out) {
 // ---- FASTQ ------------------------------------------------------------------------------------
 // compute_index / process_terms (fastq_file.hpp:53-86, 163-182): records of four lines, the second
 // is the read
-cobs_gpu_status fastq_scan(const std::string& d, const std::string& path, DocEntry* index, TermSink* text) {
+cobs_gpu_status fastq_scan(const View& d, const std::string& path, DocEntry* index, TermSink* text) {
     uint64_t line_num = 0, size = 0;
     std::string bad;
     for_lines(d, 0, [&](const char* ln, size_t n, size_t) {
@@ -368,7 +401,7 @@ struct Subdoc {
 
 // compute_index (fasta_multifile.hpp:134-180): a sub-document per '>' line, running to the next
 // line that starts with '>' or ';'; its size is the sum of its line lengths
-cobs_gpu_status mfasta_index(const std::string& d, const std::string& path, std::vector<Subdoc>& out) {
+cobs_gpu_status mfasta_index(const View& d, const std::string& path, std::vector<Subdoc>& out) {
     if (d.empty() || !is_comment(d[0]))
         return err(COBS_GPU_ERR_FORMAT, "FastaMultifile: file does not start with > or ; - " + path);
     bool in_doc = false;
@@ -390,7 +423,7 @@ cobs_gpu_status mfasta_index(const std::string& d, const std::string& path, std:
 // FastaSubfile::process_terms (fasta_multifile.hpp:38-63): lines are appended to one string whose
 // k-grams are emitted, then `data.erase(0, data.size() - k + 1)` keeps the last k - 1 characters --
 // computed in size_t, so a string shorter than k - 1 is erased completely.
-void mfasta_terms(const std::string& d, uint64_t pos_begin, uint32_t k, TermSink& out) {
+void mfasta_terms(const View& d, uint64_t pos_begin, uint32_t k, TermSink& out) {
     size_t run_begin = out.size;     // the sequence so far lies at out.data[run_begin, out.size)
     size_t held = 0;
     auto end_run = [&]() {
@@ -449,7 +482,9 @@ cobs_gpu_status load_entries(const std::string& path, std::vector<DocEntry>& out
     e.path = path;
     e.type = ft;
     std::error_code ec;
-    std::string d;
+    std::string scratch;
+    FileBytes fb;
+    const View& d = fb.v;
     cobs_gpu_status st;
     switch (ft) {
     case FileType::Text: {
@@ -460,7 +495,7 @@ cobs_gpu_status load_entries(const std::string& path, std::vector<DocEntry>& out
         return COBS_GPU_OK;
     }
     case FileType::Cortex: {
-        if ((st = read_file(path, false, d)) != COBS_GPU_OK) return st;
+        if ((st = read_file(path, false, scratch, fb)) != COBS_GPU_OK) return st;
         CortexHeader h;
         if ((st = cortex_header(d, path, h)) != COBS_GPU_OK) return st;
         e.name = h.name;
@@ -471,7 +506,7 @@ cobs_gpu_status load_entries(const std::string& path, std::vector<DocEntry>& out
         return COBS_GPU_OK;
     }
     case FileType::KMerBuffer: {
-        if ((st = read_file(path, false, d)) != COBS_GPU_OK) return st;
+        if ((st = read_file(path, false, scratch, fb)) != COBS_GPU_OK) return st;
         KMerBufferHeader h;
         if ((st = kmer_buffer_header(d, path, h)) != COBS_GPU_OK) return st;
         e.name = h.name;
@@ -482,7 +517,7 @@ cobs_gpu_status load_entries(const std::string& path, std::vector<DocEntry>& out
         return COBS_GPU_OK;
     }
     case FileType::Fasta: {
-        if ((st = read_file(path, true, d)) != COBS_GPU_OK) return st;
+        if ((st = read_file(path, true, scratch, fb)) != COBS_GPU_OK) return st;
         if ((st = fasta_index(d, path, e)) != COBS_GPU_OK) return st;
         e.data_bytes = d.size();
         e.name = base_name(path);
@@ -490,7 +525,7 @@ cobs_gpu_status load_entries(const std::string& path, std::vector<DocEntry>& out
         return COBS_GPU_OK;
     }
     case FileType::Fastq: {
-        if ((st = read_file(path, true, d)) != COBS_GPU_OK) return st;
+        if ((st = read_file(path, true, scratch, fb)) != COBS_GPU_OK) return st;
         if ((st = fastq_scan(d, path, &e, nullptr)) != COBS_GPU_OK) return st;
         e.data_bytes = d.size();
         e.name = base_name(path);
@@ -498,7 +533,7 @@ cobs_gpu_status load_entries(const std::string& path, std::vector<DocEntry>& out
         return COBS_GPU_OK;
     }
     case FileType::FastaMulti: {
-        if ((st = read_file(path, false, d)) != COBS_GPU_OK) return st;
+        if ((st = read_file(path, false, scratch, fb)) != COBS_GPU_OK) return st;
         std::vector<Subdoc> subs;
         if ((st = mfasta_index(d, path, subs)) != COBS_GPU_OK) return st;
         for (size_t i = 0; i < subs.size(); ++i) {
@@ -543,8 +578,10 @@ cobs_gpu_status add_recursive(const std::string& root, FileType filter, std::vec
             if (!it->is_directory() && accept(it->path().string(), filter)) paths.push_back(it->path().string());
         if (ec) return err(COBS_GPU_ERR_OPEN, "could not scan directory " + root);
     } else if (ends_with(root, ".list") || filter == FileType::List) {
-        std::string d;
-        if (read_file(root, false, d) != COBS_GPU_OK) return err(COBS_GPU_ERR_OPEN, "DocumentList: could not open .list file: " + root);
+        std::string scratch;
+        FileBytes fb;
+        if (read_file(root, false, scratch, fb) != COBS_GPU_OK) return err(COBS_GPU_ERR_OPEN, "DocumentList: could not open .list file: " + root);
+        const View& d = fb.v;
         const fs::path parent = fs::path(root).parent_path();
         for_lines(d, 0, [&](const char* ln, size_t n, size_t) {
             if (n == 0 || ln[0] == '#') return true;
@@ -646,8 +683,10 @@ uint64_t term_text_bound(const DocEntry& e, uint32_t k) {
     }
 }
 
-cobs_gpu_status load_terms(const DocEntry& e, uint32_t k, TermSink& out, std::vector<TermSeg>& segs, std::string& d) {
+cobs_gpu_status load_terms(const DocEntry& e, uint32_t k, TermSink& out, std::vector<TermSeg>& segs, std::string& scratch) {
     if (k == 0) return err(COBS_GPU_ERR_ARG, "term size 0");
+    FileBytes fb;
+    const View& d = fb.v;
     cobs_gpu_status st = COBS_GPU_OK;
     const uint64_t begin = out.size;
     bool one_stretch = true;
@@ -657,30 +696,30 @@ cobs_gpu_status load_terms(const DocEntry& e, uint32_t k, TermSink& out, std::ve
         out.put('\n');
         break;
     case FileType::Text:
-        if ((st = read_file(e.path, false, d)) != COBS_GPU_OK) return st;
+        if ((st = read_file(e.path, false, scratch, fb)) != COBS_GPU_OK) return st;
         st = text_terms(d, k, out, segs);
         one_stretch = false;
         break;
     case FileType::Cortex:
-        if ((st = read_file(e.path, false, d)) != COBS_GPU_OK) return st;
+        if ((st = read_file(e.path, false, scratch, fb)) != COBS_GPU_OK) return st;
         st = cortex_terms(d, e.path, k, out, segs);
         one_stretch = false;
         break;
     case FileType::KMerBuffer:
-        if ((st = read_file(e.path, false, d)) != COBS_GPU_OK) return st;
+        if ((st = read_file(e.path, false, scratch, fb)) != COBS_GPU_OK) return st;
         st = kmer_buffer_terms(d, e.path, k, out, segs);
         one_stretch = false;
         break;
     case FileType::Fasta:
-        if ((st = read_file(e.path, true, d)) != COBS_GPU_OK) return st;
+        if ((st = read_file(e.path, true, scratch, fb)) != COBS_GPU_OK) return st;
         fasta_terms(d, k, out);
         break;
     case FileType::Fastq:
-        if ((st = read_file(e.path, true, d)) != COBS_GPU_OK) return st;
+        if ((st = read_file(e.path, true, scratch, fb)) != COBS_GPU_OK) return st;
         if ((st = fastq_scan(d, e.path, nullptr, &out)) != COBS_GPU_OK) return st;
         break;
     case FileType::FastaMulti:
-        if ((st = read_file(e.path, false, d)) != COBS_GPU_OK) return st;
+        if ((st = read_file(e.path, false, scratch, fb)) != COBS_GPU_OK) return st;
         mfasta_terms(d, e.pos_begin, k, out);
         break;
     default:
