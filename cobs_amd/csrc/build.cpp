@@ -13,6 +13,8 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
@@ -241,6 +243,66 @@ StagePool& stage_pool() {
     return *pool;
 }
 
+// Host threads that stay up for a whole build: a batch hands them one job (parse the documents of
+// the batch), run() returns when every worker has finished it.  Spawning 64-128 threads per batch
+// cost 1-2 ms of the ~6 ms a batch has.
+class WorkerPool {
+public:
+    explicit WorkerPool(size_t n) {
+        for (size_t t = 0; t < n; ++t) threads_.emplace_back([this, t]() { loop(t); });
+    }
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            quit_ = true;
+            ++gen_;
+        }
+        cv_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    size_t size() const { return threads_.size(); }
+    void run(const std::function<void(size_t)>& fn) {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            job_ = &fn;
+            done_ = 0;
+            ++gen_;
+        }
+        cv_.notify_all();
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_done_.wait(lk, [&] { return done_ == threads_.size(); });
+        job_ = nullptr;
+    }
+
+private:
+    void loop(size_t tid) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(size_t)>* job;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (quit_) return;
+                job = job_;
+            }
+            (*job)(tid);
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                ++done_;
+            }
+            cv_done_.notify_one();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex mu_;
+    std::condition_variable cv_, cv_done_;
+    const std::function<void(size_t)>* job_ = nullptr;
+    uint64_t gen_ = 0;
+    size_t done_ = 0;
+    bool quit_ = false;
+};
+
 struct Slot {                                   // one document of a batch
     size_t doc_col;                             // its column
     size_t src;                                 // its index in the source
@@ -295,6 +357,7 @@ cobs_gpu_status build_into(uint32_t* d_matrix, uint64_t sig, uint64_t row_bytes,
     const size_t max_threads = src.parses() ? std::min<size_t>(hw, 128) : std::min<size_t>(hw, 8);
     std::vector<Slot> slots;
     std::vector<std::string> scratch(max_threads);      // the file being parsed, one per worker, reused
+    std::unique_ptr<WorkerPool> workers;                // created by the first batch with more than one document
     int cur = 0;
     for (size_t b0 = 0; b0 < n;) {
         // documents [b0, b1): as many as fit the batch by their text bounds (at least one)
@@ -337,13 +400,11 @@ cobs_gpu_status build_into(uint32_t* d_matrix, uint64_t sig, uint64_t row_bytes,
                 sl.used = sink.size;
             }
         };
-        const size_t nthreads = std::min(max_threads, slots.size());
-        if (nthreads <= 1) {
+        if (max_threads <= 1 || slots.size() <= 1) {
             work(0);
         } else {
-            std::vector<std::thread> pool;
-            for (size_t t = 0; t < nthreads; ++t) pool.emplace_back(work, t);
-            for (auto& t : pool) t.join();
+            if (!workers) workers.reset(new WorkerPool(std::min(max_threads, std::max<size_t>(slots.size(), 8))));
+            workers->run(work);
         }
         t_parse += now() - t0;
         t0 = now();
