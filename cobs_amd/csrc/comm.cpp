@@ -27,8 +27,12 @@
 // same call with the same batch contents.
 #include <rccl/rccl.h>
 
+#include <unistd.h>
+
 #include <atomic>
+#include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -229,11 +233,41 @@ cobs_gpu_status cobs_gpu_exchange_plan(const uint64_t* slot_begin, const uint64_
     });
 }
 
+// RCCL prints a version banner with printf when a process first initialises it.  stdout belongs to
+// the caller (`cobs query` output, bench.py's one JSON line): while a communicator is being set up
+// file descriptor 1 points at stderr, and the C stdio buffer is flushed before it is put back.
+// Reference-counted: the worker threads of a device list are all inside ncclCommInitRank at once.
+struct QuietStdout {
+    static std::mutex& mu() { static std::mutex m; return m; }
+    static int& depth() { static int d = 0; return d; }
+    static int& saved() { static int fd = -1; return fd; }
+    QuietStdout() {
+        std::lock_guard<std::mutex> g(mu());
+        if (depth()++ == 0) {
+            std::fflush(stdout);
+            saved() = ::dup(1);
+            if (saved() >= 0) (void)::dup2(2, 1);
+        }
+    }
+    ~QuietStdout() {
+        std::lock_guard<std::mutex> g(mu());
+        if (--depth() == 0 && saved() >= 0) {
+            std::fflush(stdout);
+            (void)::dup2(saved(), 1);
+            ::close(saved());
+            saved() = -1;
+        }
+    }
+};
+
 cobs_gpu_status cobs_gpu_comm_unique_id(uint8_t id[COBS_GPU_UNIQUE_ID_BYTES]) {
     if (!id) return fail(COBS_GPU_ERR_ARG, "NULL argument");
     static_assert(sizeof(ncclUniqueId) == COBS_GPU_UNIQUE_ID_BYTES, "unique id size");
     ncclUniqueId u;
-    NCCL_TRY(ncclGetUniqueId(&u));
+    {
+        QuietStdout quiet;
+        NCCL_TRY(ncclGetUniqueId(&u));
+    }
     std::memcpy(id, &u, sizeof u);
     return COBS_GPU_OK;
 }
@@ -258,7 +292,10 @@ cobs_gpu_status cobs_gpu_comm_create(const uint8_t id[COBS_GPU_UNIQUE_ID_BYTES],
         c->device = device;
         ncclUniqueId u;
         std::memcpy(&u, id, sizeof u);
-        NCCL_TRY(ncclCommInitRank(&c->comm, nranks, u, rank));
+        {
+            QuietStdout quiet;
+            NCCL_TRY(ncclCommInitRank(&c->comm, nranks, u, rank));
+        }
         static std::atomic<uint64_t> next_serial{1};
         c->serial = next_serial.fetch_add(1);
         *out = c.release();
