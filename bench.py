@@ -655,10 +655,20 @@ def main():
         out["end_to_end"] = end_to_end(s, batch, queries)
         out["cpu_baseline"] = cpu_baseline(s, cfg, queries, batch=batch)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        _RESULT_STDOUT.write(json.dumps(out) + "\n")
+        _RESULT_STDOUT.flush()
     if world > 1:
         dist.destroy_process_group()
 
 
+# stdout carries the ONE JSON line and nothing else: RCCL (the library's own communicator and
+# torch.distributed's) prints a version banner with printf, which would land on stdout -- buffered
+# until exit, i.e. AFTER the JSON line.  File descriptor 1 is pointed at stderr for the whole run;
+# the result goes to a duplicate of the original stdout.
+_RESULT_STDOUT = sys.stdout
+
 if __name__ == "__main__":
+    sys.stdout.flush()
+    _RESULT_STDOUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     main()
