@@ -361,7 +361,7 @@ def test_index_from_generated_documents_small_batches(gpu_lib, oracle, construct
     from oracle import documents as D
     from tests.test_documents import _write_corpus
     root = str(tmp_path / "corpus")
-    _write_corpus(np.random.default_rng(77), root)
+    _write_corpus(np.random.default_rng(int(os.environ.get("COBS_FUZZ_SEED", "77"))), root)   # soak: other seeds
     for tag, batch, canon, nh in (("small", 4096, 1, 2), ("default", 0, 0, 1)):
         _build_both(gpu_lib, construct, D, root, tmp_path, tag, canonicalize=canon, num_hashes=nh, fpr=0.2,
                     page_size=1, batch=batch)
