@@ -178,7 +178,7 @@ def _write_corpus(rng, d):
 
 
 def test_native_readers_equal_the_checker_on_generated_files(capi, tmp_path):
-    rng = np.random.default_rng(20240928)
+    rng = np.random.default_rng(int(os.environ.get("COBS_FUZZ_SEED", "20240928")))     # soak: other seeds
     root = str(tmp_path / "corpus")
     _write_corpus(rng, root)
     ents, dl = D.document_list(root), capi.DocumentList(root)
