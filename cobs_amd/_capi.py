@@ -121,6 +121,7 @@ SYMBOLS = {
     "cobs_gpu_build_classic_list": (_int, [_vp, C.POINTER(BuildParams), _cp]),
     "cobs_gpu_build_compact_list": (_int, [_vp, C.POINTER(BuildParams), _cp]),
     "cobs_gpu_build_index_list": (_int, [_u32, _vp, C.POINTER(BuildParams), C.POINTER(Options), C.POINTER(_vp)]),
+    "cobs_gpu_build_release_buffers": (None, []),
     "cobs_gpu_combine_classic": (_int, [C.POINTER(_cp), _sz, _cp, _u64, _int]),
     "cobs_gpu_combine_compact": (_int, [C.POINTER(_cp), _sz, _cp, _u64]),
     "cobs_gpu_construct_random": (_int, [_cp, _u64, _u64, _u64, _u64, _u64, _int]),

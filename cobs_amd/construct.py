@@ -233,6 +233,11 @@ def build_search(input=None, index_params=None, kind="classic", file_type="any",
     return Search(None, _handle=h)
 
 
+def release_build_buffers():
+    """free the staging memory the builders keep between builds (cobs_gpu_build_release_buffers)"""
+    _capi.load().cobs_gpu_build_release_buffers()
+
+
 def classic_combine(in_files, out_file, mem_bytes=0, device=-1):
     """classic_combine (construction/classic_index.cpp:195-327): several classic indexes with the
     same parameters -> one, rows concatenated at bit granularity on the GPU"""
@@ -272,6 +277,6 @@ def write_synthetic(out_file, kind, signature_sizes, num_docs, page_size=0, term
     check(lib.cobs_gpu_write_synthetic(C.byref(d), os.fsencode(out_file), device))
 
 
-__all__ = ["write_synthetic", "build_search", "classic_combine", "compact_combine", "classic_construct_random", "DocumentList", "DocumentEntry", "FileType", "ClassicIndexParameters", "CompactIndexParameters",
+__all__ = ["write_synthetic", "build_search", "release_build_buffers", "classic_combine", "compact_combine", "classic_construct_random", "DocumentList", "DocumentEntry", "FileType", "ClassicIndexParameters", "CompactIndexParameters",
            "classic_construct", "classic_construct_list", "compact_construct", "compact_construct_list",
            "disable_cache"]

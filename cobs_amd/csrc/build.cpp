@@ -219,6 +219,13 @@ struct StagePool {
         std::lock_guard<std::mutex> g(mu);
         idle_planes.push_back(b);
     }
+    void release_idle() {
+        std::lock_guard<std::mutex> g(mu);
+        for (Stage* s : idle) delete s;
+        idle.clear();
+        for (auto* b : idle_planes) delete b;
+        idle_planes.clear();
+    }
     Stage* take(int dev) {
         std::lock_guard<std::mutex> g(mu);
         if (device != dev) {                    // buffers belong to the device they were made on
@@ -333,7 +340,9 @@ cobs_gpu_status build_into(uint32_t* d_matrix, uint64_t sig, uint64_t row_bytes,
             if (c) { (void)hipStreamSynchronize(c); (void)hipStreamDestroy(c); }
             (void)hipStreamSynchronize(s);
             (void)hipStreamDestroy(s);
-            for (Stage* x : st) { x->busy = false; stage_pool().give(x); }
+            // handed back last-to-first: the next build takes the set that was used first (and has
+            // its buffers) as its first set again
+            for (int i = kStages - 1; i >= 0; --i) { st[i]->busy = false; stage_pool().give(st[i]); }
             stage_pool().give_planes(planes);
         }
     } guard{stream, nullptr, {stage_pool().take(dev), stage_pool().take(dev), stage_pool().take(dev)}, stage_pool().take_planes(dev)};
@@ -464,8 +473,12 @@ cobs_gpu_status build_into(uint32_t* d_matrix, uint64_t sig, uint64_t row_bytes,
             // whenever the planes of the batch are affordable and there is enough text to pay for
             // zeroing and packing them (mode 2 forces them, mode 1 the atomics)
             const uint64_t plane_bytes = (uint64_t)(b1 - b0) * bm_stride;
-            const bool planes = pr.set_bits_mode == 2 ||
-                                (pr.set_bits_mode == 0 && plane_bytes <= kPlaneBudget && plane_bytes <= 16 * total);
+            bool planes = pr.set_bits_mode == 2 ||
+                          (pr.set_bits_mode == 0 && plane_bytes <= kPlaneBudget && plane_bytes <= 16 * total);
+            if (planes && pr.set_bits_mode == 0 && guard.planes->reserve((size_t)plane_bytes) != hipSuccess) {
+                (void)hipGetLastError();            // no room for the planes next to the index: the atomics need none
+                planes = false;
+            }
             if (planes) {
                 BUILD_TRY(guard.planes->reserve((size_t)plane_bytes));
                 BUILD_TRY(hipMemsetAsync(guard.planes->p, 0, (size_t)plane_bytes, stream));
@@ -751,6 +764,8 @@ cobs_gpu_status build_from_list(bool compact, const cobs_gpu_doclist* dl, const 
 }  // namespace
 
 extern "C" {
+
+void cobs_gpu_build_release_buffers(void) { stage_pool().release_idle(); }
 
 cobs_gpu_status cobs_gpu_build_classic(const char* const* names, const char* const* texts, const size_t* lens,
                                        size_t ndocs, const cobs_gpu_build_params* params, const char* out_path) {

@@ -273,6 +273,10 @@ cobs_gpu_status cobs_gpu_build_compact_list(const cobs_gpu_doclist* dl, const co
 cobs_gpu_status cobs_gpu_build_index_list(uint32_t kind, const cobs_gpu_doclist* dl, const cobs_gpu_build_params* params,
                                           const cobs_gpu_options* opts, cobs_gpu_index** out);
 
+/* The builders keep their staging memory (three pinned + device text buffers of 256 MiB, the byte
+ * planes) for the next build of the process; this frees what no build is using right now. */
+void cobs_gpu_build_release_buffers(void);
+
 /* classic_combine (construction/classic_index.cpp:195-327): the rows of n classic indexes with equal
  * term size / canonicalize / hashes / signature size concatenated at bit granularity into one
  * index, document names in input order; row batches of at most mem_bytes (0 = 1 GiB) are

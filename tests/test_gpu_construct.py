@@ -422,3 +422,19 @@ def test_classic_signature_comes_from_the_largest_file(gpu_lib, oracle, construc
     assert ents[1].size > ents[0].size and ents[1].num_terms(31) < ents[0].num_terms(31)
     pc, _ = _build_both(gpu_lib, construct, D, str(root), tmp_path, "two", page_size=1)
     assert oracle.Index.open(pc).signature_size(0) == construct.calc_signature_size(ents[1].num_terms(31), 1, 0.3)
+
+
+def test_build_buffers_are_kept_and_can_be_released(gpu_lib, golden_dir):
+    """the builders keep their staging memory for the next build of the process
+    (cobs_gpu_build_release_buffers frees it): device memory returns to where it was"""
+    import torch
+    from cobs_amd import construct as C
+    C.release_build_buffers()
+    free0 = torch.cuda.mem_get_info()[0]
+    C.build_search(os.path.join(golden_dir, "fasta")).close()
+    held = free0 - torch.cuda.mem_get_info()[0]
+    assert held >= (200 << 20)                     # one 256 MiB device text buffer at least
+    C.build_search(os.path.join(golden_dir, "fasta")).close()
+    assert free0 - torch.cuda.mem_get_info()[0] <= held + (64 << 20)      # reused, not re-allocated
+    C.release_build_buffers()
+    assert abs(free0 - torch.cuda.mem_get_info()[0]) < (64 << 20)
