@@ -320,53 +320,75 @@ struct Slot {                                   // one document of a batch
     std::string error;
 };
 
+// What one build call keeps across its matrices (a compact index is one build_into per
+// sub-index): the two streams, the staging sets and byte planes checked out of the pool, the
+// parser threads and their scratch buffers.
+struct BuildContext {
+    hipStream_t stream = nullptr, copy_stream = nullptr;   // kernels | uploads (batch i + 1 beside the kernel of batch i)
+    Stage* st[kStages] = {};
+    DevBuf<uint8_t>* planes = nullptr;
+    std::unique_ptr<WorkerPool> workers;                   // created by the first batch with more than one document
+    std::vector<std::string> scratch;                      // the file being parsed, one per worker, reused
+    size_t max_threads = 1;
+    bool ready = false;
+
+    cobs_gpu_status init(bool parses) {
+        if (ready) return COBS_GPU_OK;
+        int dev = 0;
+        BUILD_TRY(hipGetDevice(&dev));
+        BUILD_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        BUILD_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        for (Stage*& s : st) {
+            s = stage_pool().take(dev);
+            if (!s->done) BUILD_TRY(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
+            if (!s->copied) BUILD_TRY(hipEventCreateWithFlags(&s->copied, hipEventDisableTiming));
+        }
+        planes = stage_pool().take_planes(dev);
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        max_threads = parses ? std::min<size_t>(hw, 128) : std::min<size_t>(hw, 8);
+        scratch.resize(max_threads);
+        ready = true;
+        return COBS_GPU_OK;
+    }
+    BuildContext() = default;
+    BuildContext(const BuildContext&) = delete;
+    BuildContext& operator=(const BuildContext&) = delete;
+    ~BuildContext() {
+        workers.reset();
+        if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
+        if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+        // handed back last-to-first: the next build takes the set that was used first (and has its
+        // buffers) as its first set again
+        for (int i = kStages - 1; i >= 0; --i)
+            if (st[i]) { st[i]->busy = false; stage_pool().give(st[i]); }
+        if (planes) stage_pool().give_planes(planes);
+    }
+};
+
 // Set the bits of documents docs[0..n) -- document docs[i] in column i -- in a zeroed device
 // matrix of `sig` rows, `row_bytes` (multiple of 4) apart.
-cobs_gpu_status build_into(uint32_t* d_matrix, uint64_t sig, uint64_t row_bytes, const DocSource& src,
+cobs_gpu_status build_into(BuildContext& ctx, uint32_t* d_matrix, uint64_t sig, uint64_t row_bytes, const DocSource& src,
                            const size_t* docs, size_t n, const Params& pr) {
     const uint64_t text_batch = pr.text_batch ? pr.text_batch : kTextBatchBytes;
     if (sig == 0 || sig > (1ull << 46)) return cobs_gpu_set_error(COBS_GPU_ERR_UNSUPPORTED, "signature_size must be in 1..2^46");
     if (n >= (kBuildRawStretch - 1)) return cobs_gpu_set_error(COBS_GPU_ERR_UNSUPPORTED, "too many documents in one matrix");
-    int dev = 0;
-    BUILD_TRY(hipGetDevice(&dev));
-    // two streams: the upload of batch i + 1 runs beside the kernel of batch i
-    hipStream_t stream = nullptr, copy_stream = nullptr;
-    BUILD_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    struct Guard {
-        hipStream_t s, c = nullptr;
-        Stage* st[kStages];
-        DevBuf<uint8_t>* planes;
-        ~Guard() {
-            if (c) { (void)hipStreamSynchronize(c); (void)hipStreamDestroy(c); }
-            (void)hipStreamSynchronize(s);
-            (void)hipStreamDestroy(s);
-            // handed back last-to-first: the next build takes the set that was used first (and has
-            // its buffers) as its first set again
-            for (int i = kStages - 1; i >= 0; --i) { st[i]->busy = false; stage_pool().give(st[i]); }
-            stage_pool().give_planes(planes);
-        }
-    } guard{stream, nullptr, {stage_pool().take(dev), stage_pool().take(dev), stage_pool().take(dev)}, stage_pool().take_planes(dev)};
-    static_assert(kStages == 3, "the guard's initialiser lists the staging sets");
+    cobs_gpu_status ist = ctx.init(src.parses());
+    if (ist != COBS_GPU_OK) return ist;
+    hipStream_t stream = ctx.stream, copy_stream = ctx.copy_stream;
+    struct { DevBuf<uint8_t>* planes; } guard{ctx.planes};
+    Stage* const* stage = ctx.st;
     // byte-map planes of a batch: one byte per (document of the batch, signature row)
     const uint64_t bm_stride = (sig + 255) / 256 * 256;
     constexpr uint64_t kPlaneBudget = 3ull << 30;
-    BUILD_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
-    guard.c = copy_stream;
-    Stage* const* stage = guard.st;
-    for (Stage* s : guard.st) {
-        if (!s->done) BUILD_TRY(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
-        if (!s->copied) BUILD_TRY(hipEventCreateWithFlags(&s->copied, hipEventDisableTiming));
-    }
 
     // COBS_GPU_BUILD_TRACE=1: where the host side of a build spends its time (stderr, one line per build)
     static const bool trace = std::getenv("COBS_GPU_BUILD_TRACE") != nullptr;
     double t_wait = 0, t_parse = 0, t_table = 0, t_issue = 0;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const size_t max_threads = src.parses() ? std::min<size_t>(hw, 128) : std::min<size_t>(hw, 8);
+    const size_t max_threads = ctx.max_threads;
     std::vector<Slot> slots;
-    std::vector<std::string> scratch(max_threads);      // the file being parsed, one per worker, reused
-    std::unique_ptr<WorkerPool> workers;                // created by the first batch with more than one document
+    std::vector<std::string>& scratch = ctx.scratch;
+    std::unique_ptr<WorkerPool>& workers = ctx.workers;
     int cur = 0;
     for (size_t b0 = 0; b0 < n;) {
         // documents [b0, b1): as many as fit the batch by their text bounds (at least one)
@@ -682,11 +704,12 @@ cobs_gpu_status write_index_file(const DocSource& src, const Layout& lay, const 
     struct Closer { FILE* f; ~Closer() { if (f) std::fclose(f); } } closer{f};
     if (!write_all(f, h.data(), h.size())) return cobs_gpu_set_error(COBS_GPU_ERR_OPEN, "short write");
     // one (sub-)index after the other: built in HBM (288 GB; never in host RAM), streamed out
+    BuildContext ctx;
     for (const Group& g : lay.groups) {
         DevMem d_mat;
         BUILD_TRY(hipMalloc(&d_mat.p, (size_t)(g.sig * row_bytes)));
         BUILD_TRY(hipMemset(d_mat.p, 0, (size_t)(g.sig * row_bytes)));
-        cobs_gpu_status st = build_into((uint32_t*)d_mat.p, g.sig, row_bytes, src, g.docs.data(), g.docs.size(), pr);
+        cobs_gpu_status st = build_into(ctx, (uint32_t*)d_mat.p, g.sig, row_bytes, src, g.docs.data(), g.docs.size(), pr);
         if (st != COBS_GPU_OK) return st;
         st = stream_rows_to_file(f, (const uint8_t*)d_mat.p, row_bytes, row_size, g.sig);
         if (st != COBS_GPU_OK) return st;
@@ -719,10 +742,11 @@ cobs_gpu_status build_resident(const DocSource& src, const Layout& lay, const Pa
     if (st != COBS_GPU_OK) return st;
     std::unique_ptr<cobs_gpu_index, void (*)(cobs_gpu_index*)> guard(ix, cobs_gpu_close);
     Part& pt = ix->parts[0];
+    BuildContext ctx;
     for (Chunk& c : pt.chunks)
         for (size_t i = 0; i < c.vp.size(); ++i) {
             const Group& g = lay.groups[c.vp[i].fp];
-            st = build_into(reinterpret_cast<uint32_t*>(c.d_data + c.pages[i].base), c.pages[i].sig, c.pitch, src,
+            st = build_into(ctx, reinterpret_cast<uint32_t*>(c.d_data + c.pages[i].base), c.pages[i].sig, c.pitch, src,
                             g.docs.data(), g.docs.size(), pr);
             if (st != COBS_GPU_OK) return st;
         }
