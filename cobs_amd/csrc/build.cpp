@@ -539,21 +539,29 @@ bool write_all(FILE* f, const void* p, size_t n);
 // pinned buffers: the host writes chunk i while the device sends chunk i + 1
 cobs_gpu_status stream_rows_to_file(FILE* f, const uint8_t* d_matrix, uint64_t pitch, uint64_t row_size, uint64_t rows) {
     if (rows == 0 || row_size == 0) return COBS_GPU_OK;
-    const uint64_t rows_per = std::max<uint64_t>(1, (128ull << 20) / row_size);
+    // Rows travel as ONE contiguous copy per chunk, padding included (the device pitch is the row
+    // size rounded up to 4 bytes): a 2-D copy of millions of 2..11-byte rows -- compact indexes
+    // with a small, odd page size -- takes minutes in the runtime.  The padding is dropped on the
+    // host, in place, before the chunk is written.
+    const uint64_t rows_per = std::max<uint64_t>(1, (128ull << 20) / pitch);
     struct Pinned { void* p = nullptr; ~Pinned() { if (p) (void)hipHostFree(p); } } host[2];
-    for (auto& hb : host) BUILD_TRY(hipHostMalloc(&hb.p, (size_t)(std::min(rows_per, rows) * row_size), hipHostMallocDefault));
+    for (auto& hb : host) BUILD_TRY(hipHostMalloc(&hb.p, (size_t)(std::min(rows_per, rows) * pitch), hipHostMallocDefault));
     hipStream_t stream = nullptr;
     BUILD_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{stream};
+    auto squeeze = [&](uint8_t* p, uint64_t n) {
+        if (pitch == row_size) return;
+        for (uint64_t r = 1; r < n; ++r) std::memmove(p + r * row_size, p + r * pitch, (size_t)row_size);
+    };
     int cur = 0;
     uint64_t pending = 0;
     for (uint64_t r = 0; r < rows; r += rows_per) {
         const uint64_t n = std::min(rows_per, rows - r);
-        BUILD_TRY(hipMemcpy2DAsync(host[cur].p, (size_t)row_size, d_matrix + r * pitch, (size_t)pitch, (size_t)row_size,
-                                   (size_t)n, hipMemcpyDeviceToHost, stream));
+        BUILD_TRY(hipMemcpyAsync(host[cur].p, d_matrix + r * pitch, (size_t)(n * pitch), hipMemcpyDeviceToHost, stream));
         if (pending && !write_all(f, host[cur ^ 1].p, (size_t)pending))
             return cobs_gpu_set_error(COBS_GPU_ERR_OPEN, "short write");
         BUILD_TRY(hipStreamSynchronize(stream));
+        squeeze((uint8_t*)host[cur].p, n);
         pending = n * row_size;
         cur ^= 1;
     }
@@ -709,6 +717,7 @@ cobs_gpu_status write_index_file(const DocSource& src, const Layout& lay, const 
         DevMem d_mat;
         BUILD_TRY(hipMalloc(&d_mat.p, (size_t)(g.sig * row_bytes)));
         BUILD_TRY(hipMemset(d_mat.p, 0, (size_t)(g.sig * row_bytes)));
+        BUILD_TRY(hipStreamSynchronize(nullptr));       // the build runs on non-blocking streams: no implicit order with the null stream
         cobs_gpu_status st = build_into(ctx, (uint32_t*)d_mat.p, g.sig, row_bytes, src, g.docs.data(), g.docs.size(), pr);
         if (st != COBS_GPU_OK) return st;
         st = stream_rows_to_file(f, (const uint8_t*)d_mat.p, row_bytes, row_size, g.sig);
@@ -1143,7 +1152,7 @@ cobs_gpu_status cobs_gpu_write_synthetic(const cobs_gpu_synth* d, const char* ou
     hipStream_t stream = nullptr;
     BUILD_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{stream};
-    for (auto& hb : host) BUILD_TRY(hipHostMalloc(&hb.p, (size_t)(rows_per * prb), hipHostMallocDefault));
+    for (auto& hb : host) BUILD_TRY(hipHostMalloc(&hb.p, (size_t)(rows_per * pitch), hipHostMallocDefault));
     int cur = 0;
     uint64_t pending = 0;       // bytes of host[cur ^ 1] still to be written
     for (uint32_t p = 0; p < d->num_pages; ++p) {
@@ -1162,12 +1171,17 @@ cobs_gpu_status cobs_gpu_write_synthetic(const cobs_gpu_synth* d, const char* ou
             a.page = p;
             a.pitch = pitch;
             BUILD_TRY(launch_synth_rows(a, stream));
-            BUILD_TRY(hipMemcpy2DAsync(host[cur].p, (size_t)prb, d_rows.p, pitch, (size_t)prb, (size_t)n,
-                                       hipMemcpyDeviceToHost, stream));
+            // one contiguous copy incl. the pitch padding, dropped on the host (a 2-D copy of
+            // millions of tiny rows takes minutes in the runtime: see stream_rows_to_file)
+            BUILD_TRY(hipMemcpyAsync(host[cur].p, d_rows.p, (size_t)(n * pitch), hipMemcpyDeviceToHost, stream));
             // while the device produces this chunk the host writes the previous one
             if (pending && !write_all(f, host[cur ^ 1].p, (size_t)pending))
                 return cobs_gpu_set_error(COBS_GPU_ERR_OPEN, "short write");
             BUILD_TRY(hipStreamSynchronize(stream));
+            if (pitch != prb) {
+                uint8_t* hp = (uint8_t*)host[cur].p;
+                for (uint64_t q = 1; q < n; ++q) std::memmove(hp + q * prb, hp + q * (uint64_t)pitch, (size_t)prb);
+            }
             pending = n * prb;
             cur ^= 1;
         }
