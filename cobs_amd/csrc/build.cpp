@@ -331,6 +331,10 @@ struct BuildContext {
     std::vector<std::string> scratch;                      // the file being parsed, one per worker, reused
     size_t max_threads = 1;
     bool ready = false;
+    // writing an index file: the matrix of the current (sub-)index and the two pinned buffers its
+    // rows leave through -- allocated once per build, not once per sub-index
+    DevBuf<uint8_t> matrix;
+    PinnedBuf<uint8_t> out_host[2];
 
     cobs_gpu_status init(bool parses) {
         if (ready) return COBS_GPU_OK;
@@ -537,15 +541,17 @@ bool write_all(FILE* f, const void* p, size_t n);
 
 // rows [0, rows) of a device matrix (pitch bytes apart) -> file, row_size bytes each, through two
 // pinned buffers: the host writes chunk i while the device sends chunk i + 1
-cobs_gpu_status stream_rows_to_file(FILE* f, const uint8_t* d_matrix, uint64_t pitch, uint64_t row_size, uint64_t rows) {
+cobs_gpu_status stream_rows_to_file(FILE* f, const uint8_t* d_matrix, uint64_t pitch, uint64_t row_size, uint64_t rows,
+                                    PinnedBuf<uint8_t> (*keep)[2] = nullptr) {
     if (rows == 0 || row_size == 0) return COBS_GPU_OK;
     // Rows travel as ONE contiguous copy per chunk, padding included (the device pitch is the row
     // size rounded up to 4 bytes): a 2-D copy of millions of 2..11-byte rows -- compact indexes
     // with a small, odd page size -- takes minutes in the runtime.  The padding is dropped on the
     // host, in place, before the chunk is written.
     const uint64_t rows_per = std::max<uint64_t>(1, (128ull << 20) / pitch);
-    struct Pinned { void* p = nullptr; ~Pinned() { if (p) (void)hipHostFree(p); } } host[2];
-    for (auto& hb : host) BUILD_TRY(hipHostMalloc(&hb.p, (size_t)(std::min(rows_per, rows) * pitch), hipHostMallocDefault));
+    PinnedBuf<uint8_t> own[2];
+    PinnedBuf<uint8_t>* host = keep ? *keep : own;
+    for (int i = 0; i < 2; ++i) BUILD_TRY(host[i].reserve((size_t)(std::min(rows_per, rows) * pitch)));
     hipStream_t stream = nullptr;
     BUILD_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{stream};
@@ -714,13 +720,12 @@ cobs_gpu_status write_index_file(const DocSource& src, const Layout& lay, const 
     // one (sub-)index after the other: built in HBM (288 GB; never in host RAM), streamed out
     BuildContext ctx;
     for (const Group& g : lay.groups) {
-        DevMem d_mat;
-        BUILD_TRY(hipMalloc(&d_mat.p, (size_t)(g.sig * row_bytes)));
-        BUILD_TRY(hipMemset(d_mat.p, 0, (size_t)(g.sig * row_bytes)));
+        BUILD_TRY(ctx.matrix.reserve((size_t)(g.sig * row_bytes)));
+        BUILD_TRY(hipMemset(ctx.matrix.p, 0, (size_t)(g.sig * row_bytes)));
         BUILD_TRY(hipStreamSynchronize(nullptr));       // the build runs on non-blocking streams: no implicit order with the null stream
-        cobs_gpu_status st = build_into(ctx, (uint32_t*)d_mat.p, g.sig, row_bytes, src, g.docs.data(), g.docs.size(), pr);
+        cobs_gpu_status st = build_into(ctx, (uint32_t*)ctx.matrix.p, g.sig, row_bytes, src, g.docs.data(), g.docs.size(), pr);
         if (st != COBS_GPU_OK) return st;
-        st = stream_rows_to_file(f, (const uint8_t*)d_mat.p, row_bytes, row_size, g.sig);
+        st = stream_rows_to_file(f, ctx.matrix.p, row_bytes, row_size, g.sig, &ctx.out_host);
         if (st != COBS_GPU_OK) return st;
     }
     closer.f = nullptr;
