@@ -7,12 +7,15 @@
 //   cobs_gpu_query compact-construct INPUT OUT.cobs_compact [flags] [-p PAGE]     (:294-380)
 //   cobs_gpu_query classic-combine IN_DIR OUT.cobs_classic                        (:1044-1060)
 //   cobs_gpu_query compact-construct-combine IN_DIR OUT.cobs_compact [-p PAGE]   (:383-408)
+//   cobs_gpu_query print-parameters [-h H] [-f FPR] [-n N]                        (:532-568)
+//   cobs_gpu_query print-kmers QUERY [-k K]                                       (:570-600)
 //
 // Flags of the two constructors: --file-type, -h/--num-hashes, -f/--false-positive-rate,
 // -k/--term-size, --no-canonicalize, -C/--clobber, --continue; -m/--memory, -T/--threads,
 // --keep-temporary, --tmp-path are accepted and ignored (there are no temporary files: the matrix
 // is built in HBM), -d/--device selects the GPU.
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -190,6 +193,54 @@ static int tools(int argc, char** argv) {
             });
             std::cout.flush();
             std::cerr << "document[" << i << "] : " << e.num_terms(k) << " terms." << std::endl;
+        }
+        return 0;
+    }
+    if (tool == "print-parameters") {
+        // `cobs print-parameters` (src/cobs.cpp:532-568): the signature size a Bloom filter needs
+        unsigned num_hashes = 1;
+        double fpr = 0.3;
+        uint64_t num_elements = 0;
+        for (int i = 2; i < argc; ++i) {
+            const std::string a = argv[i];
+            if ((a == "-h" || a == "--num-hashes") && i + 1 < argc) num_hashes = (unsigned)std::strtoul(argv[++i], nullptr, 10);
+            else if ((a == "-f" || a == "--false-positive-rate") && i + 1 < argc) fpr = std::atof(argv[++i]);
+            else if ((a == "-n" || a == "--num-elements") && i + 1 < argc) num_elements = std::strtoull(argv[++i], nullptr, 10);
+            else { std::fprintf(stderr, "usage: cobs_gpu_query print-parameters [-h HASHES] [-f FPR] [-n NUM_ELEMENTS]\n"); return 1; }
+        }
+        if (num_hashes == 0 || !(fpr > 0.0 && fpr < 1.0)) { std::fprintf(stderr, "bad parameters\n"); return 1; }
+        // calc_signature_size_ratio / calc_signature_size, cobs/util/calc_signature_size.cpp:17-33
+        const double ratio = -(double)num_hashes / std::log(1.0 - std::pow(fpr, 1.0 / (double)num_hashes));
+        if (num_elements == 0) {
+            std::cout << ratio << '\n';
+        } else {
+            const uint64_t sig = (uint64_t)std::ceil((double)num_elements * ratio);
+            double b = (double)(sig / 8);
+            static const char* unit[] = {"", "Ki", "Mi", "Gi", "Ti", "Pi", "Ei"};
+            int u = 0;
+            while (b >= 1024.0 && u < 6) { b /= 1024.0; ++u; }
+            char iec[64];
+            std::snprintf(iec, sizeof iec, "%.3f %s", b, unit[u]);              // tlx::format_iec_units
+            std::cout << "signature_size = " << sig << '\n';
+            std::cout << "signature_bytes = " << sig / 8 << " = " << iec << '\n';
+        }
+        return 0;
+    }
+    if (tool == "print-kmers") {
+        // `cobs print-kmers QUERY [-k K]` (src/cobs.cpp:570-600): the canonical k-mers of a sequence
+        // (the reference's loop bound `i < size - k` leaves out the last one; so does this)
+        std::string query;
+        unsigned k = 31;
+        for (int i = 2; i < argc; ++i) {
+            const std::string a = argv[i];
+            if ((a == "-k" || a == "--kmer-size") && i + 1 < argc) k = (unsigned)std::strtoul(argv[++i], nullptr, 10);
+            else query = a;
+        }
+        if (query.empty() || k == 0) { std::fprintf(stderr, "usage: cobs_gpu_query print-kmers QUERY [-k K]\n"); return 1; }
+        std::vector<char> canon(k);
+        for (size_t i = 0; i + k < query.size(); ++i) {
+            if (canonical(query.data() + i, canon.data(), k)) std::cout.write(canon.data(), k) << '\n';
+            else (std::cout << "Invalid DNA base pair: ").write(query.data() + i, k) << std::endl;
         }
         return 0;
     }

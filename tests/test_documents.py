@@ -352,3 +352,20 @@ def test_cpp_construction_mirror(docdir, tmp_path):
     assert lines[2 + len(ents):2 + len(ents) + 3] == ["fastq %s %d" % (e.name, e.size) for e in fq]
     assert "Unknown file type nonsense" in lines[-2]
     assert lines[-1] == "refused Error: COBS index file must end with .cobs_classic"
+
+
+def test_print_parameters_and_print_kmers_tools(construct):
+    """`cobs print-parameters` / `cobs print-kmers` (reference src/cobs.cpp:532-600)"""
+    import subprocess
+    from oracle import oracle as O
+    O.build()
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cobs_amd", "cobs_gpu_query")
+    r = subprocess.run([tool, "print-parameters", "-n", "3120"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.startswith("signature_size = 8748\nsignature_bytes = 1093 = ")    # SURVEY 7.2: S = 8748
+    for h, f, n in ((3, 0.1, 1000000), (1, 0.3, 5), (2, 0.05, 123456789)):
+        r = subprocess.run([tool, "print-parameters", "-h", str(h), "-f", str(f), "-n", str(n)], capture_output=True, text=True, timeout=60)
+        assert r.stdout.split("\n")[0] == "signature_size = %d" % construct.calc_signature_size(n, h, f)
+    q = O.random_sequence(80, 4)
+    r = subprocess.run([tool, "print-kmers", q.decode(), "-k", "21"], capture_output=True, text=True, timeout=60)
+    # the reference's loop stops one k-mer early (i < size - k)
+    assert r.stdout.encode() == b"".join(O.canonicalize_kmer(q[i:i + 21])[0] + b"\n" for i in range(len(q) - 21))
