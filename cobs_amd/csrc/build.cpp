@@ -555,9 +555,23 @@ cobs_gpu_status stream_rows_to_file(FILE* f, const uint8_t* d_matrix, uint64_t p
     hipStream_t stream = nullptr;
     BUILD_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{stream};
+    // rows p[r * pitch .. + row_size) -> p[r * row_size ..): slices of rows are packed by a few threads
+    // (each inside its own slice), then the packed slices are moved together
     auto squeeze = [&](uint8_t* p, uint64_t n) {
         if (pitch == row_size) return;
-        for (uint64_t r = 1; r < n; ++r) std::memmove(p + r * row_size, p + r * pitch, (size_t)row_size);
+        const uint64_t nthr = std::min<uint64_t>(8, std::max<uint64_t>(1, n >> 20));
+        auto pack = [&](uint64_t r0, uint64_t r1) {     // rows [r0, r1) packed at p + r0 * pitch
+            uint8_t* base = p + r0 * pitch;
+            for (uint64_t r = 1; r < r1 - r0; ++r) std::memmove(base + r * row_size, base + r * pitch, (size_t)row_size);
+        };
+        if (nthr == 1) { pack(0, n); return; }
+        std::vector<std::thread> pool;
+        for (uint64_t t = 0; t < nthr; ++t) pool.emplace_back(pack, n * t / nthr, n * (t + 1) / nthr);
+        for (auto& th : pool) th.join();
+        for (uint64_t t = 1; t < nthr; ++t) {
+            const uint64_t r0 = n * t / nthr, r1 = n * (t + 1) / nthr;
+            std::memmove(p + r0 * row_size, p + r0 * pitch, (size_t)((r1 - r0) * row_size));
+        }
     };
     int cur = 0;
     uint64_t pending = 0;

@@ -32,6 +32,14 @@ for ps in (64, 8, 2):
     t0 = time.time()
     s = cobs_amd.build_search(list=dl, index_params=p, kind="compact")
     dr = time.time() - t0
+    # the file (rows through the pinned buffers, padding squeezed out on the host) holds the matrix of the handle
+    import numpy as np
+    sf = cobs_amd.Search(out)
+    for e in (dl[0], dl[dl.size() // 2]):
+        q = b"".join(open(e.path, "rb").read().split(b"\n")[1:])[1000:1400]
+        a, b = s.counts(q), sf.counts(q)
+        assert np.array_equal(a, b) and int(a.max()) == len(q) - 30, (ps, e.name)
+    sf.close()
     s.close()
     print("page_size %d (%d docs per sub-index, %d sub-indexes): file %.3f s, resident %.3f s, %d MB" % (
         ps, 8 * ps, (ndocs + 8 * ps - 1) // (8 * ps), dt, dr, os.path.getsize(out) >> 20), flush=True)
