@@ -771,6 +771,7 @@ cobs_gpu_status build_resident(const DocSource& src, const Layout& lay, const Pa
     std::unique_ptr<cobs_gpu_index, void (*)(cobs_gpu_index*)> guard(ix, cobs_gpu_close);
     Part& pt = ix->parts[0];
     BuildContext ctx;
+    BUILD_TRY(hipStreamSynchronize(nullptr));           // open_zeroed cleared the matrix on the null stream; the build's streams do not wait for it
     for (Chunk& c : pt.chunks)
         for (size_t i = 0; i < c.vp.size(); ++i) {
             const Group& g = lay.groups[c.vp[i].fp];
