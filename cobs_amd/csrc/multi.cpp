@@ -46,6 +46,7 @@ struct cobs_gpu_multi {
     cobs_gpu_hit* hits = nullptr;
     size_t* hit_offsets = nullptr;
     size_t bad_query = 0;
+    std::vector<std::vector<size_t>> offs_other;       // [rank] nq + 1 entries, ranks > 0
 
     void signal_done() {
         {
@@ -87,10 +88,10 @@ struct cobs_gpu_multi {
             }
             if (failed) { signal_done(); continue; }        // a rank never came up: nothing collective may run
             size_t bad = 0;
-            // ranks other than 0 take part in the collectives but keep no result (capacity 0)
-            std::vector<size_t> offs_local;
-            size_t* offs = hit_offsets;
-            if (r != 0) { offs_local.assign(nq + 1, 0); offs = offs_local.data(); }
+            // ranks other than 0 take part in the collectives but keep no result (capacity 0); their
+            // offset arrays were sized by the calling thread: nothing is allocated between the
+            // wake-up and the collective, so no rank can drop out of it on its own
+            size_t* offs = r == 0 ? hit_offsets : offs_other[r].data();
             me.status = cobs_gpu_sharded_search_batch(me.ix, me.comm, queries, lens, nq, threshold, num_results,
                                                       r == 0 ? hits : nullptr, r == 0 ? cap : 0, offs, &bad);
             if (r != 0 && me.status == COBS_GPU_ERR_CAPACITY) me.status = COBS_GPU_OK;
@@ -183,6 +184,8 @@ cobs_gpu_status cobs_gpu_multi_search_batch(cobs_gpu_multi* m, const char* const
     if (!m || !hit_offsets) return fail(COBS_GPU_ERR_ARG, "NULL argument");
     if (nq && (!queries || !lens)) return fail(COBS_GPU_ERR_ARG, "NULL argument");
     return guarded([&]() -> cobs_gpu_status {
+        m->offs_other.resize(m->ranks.size());
+        for (size_t r = 1; r < m->ranks.size(); ++r) m->offs_other[r].assign(nq + 1, 0);
         m->queries = queries;
         m->lens = lens;
         m->nq = nq;
