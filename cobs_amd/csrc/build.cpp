@@ -438,7 +438,10 @@ cobs_gpu_status build_into(BuildContext& ctx, uint32_t* d_matrix, uint64_t sig, 
         if (max_threads <= 1 || slots.size() <= 1) {
             work(0);
         } else {
-            if (!workers) workers.reset(new WorkerPool(std::min(max_threads, std::max<size_t>(slots.size(), 8))));
+            // as many workers as the largest batch so far has documents (a compact build may start
+            // with a small sub-index and go on to large ones)
+            const size_t want = std::min(max_threads, std::max<size_t>(slots.size(), 8));
+            if (!workers || workers->size() < want) workers.reset(new WorkerPool(want));
             workers->run(work);
         }
         t_parse += now() - t0;
