@@ -622,6 +622,32 @@ def test_small_calls_replay_a_captured_graph(gpu_lib, oracle, tmp_path):
     assert s.graph_replays == r
 
 
+def test_graph_replay_between_other_shapes(gpu_lib, oracle, tmp_path):
+    """a captured shape is replayed after calls of OTHER shapes ran in between (other score width,
+    other result mode): the replay must not inherit anything from them"""
+    q_long = oracle.random_sequence(900, 78)
+    p = cases.make_compact(cases.tmp(tmp_path, "g2.cobs_compact"), 2000, 64, [900, 1000, 1100, 1200], 1, 31, 1,
+                           0.3, 6, planted={5: 1.0, 700: 0.9, 1900: 0.6}, query=q_long)
+    ix = oracle.Index.open(p)
+    s = gpu_lib.Search(p)
+
+    def check(qs, t, lim):
+        assert s.search_hits(qs, t, lim) == [cases.oracle_results([ix], q, t, lim) for q in qs], (len(qs[0]), t, lim)
+
+    a = lambda i: [q_long[i:i + 331]]            # 301 terms: 16-bit scores
+    b = lambda i: [q_long[i:i + 100]]            # 70 terms: 8-bit scores
+    c = lambda i: [q_long[i:i + 600], q_long[i + 3:i + 3 + 45]]
+    for i in range(3):
+        check(a(i), 0.0, 5)                      # captured on the third call at the latest
+    r0 = s.graph_replays
+    for i in range(3, 12):
+        check(b(i), 0.4, 0)                      # hits only, other width
+        check(a(i), 0.0, 5)                      # shape A again
+        check(c(i), 0.0, 0)                      # every document ranked, two queries
+        check(a(i + 20), 0.0, 5)
+    assert s.graph_replays >= r0                 # (how many of these replay is the engine's business)
+
+
 def test_default_call_in_batches_is_ranked_by_host_threads(gpu_lib, oracle, tmp_path):
     """threshold 0, no limit (the reference's default arguments) for MANY queries per call: the
     passes' score rows are ranked by several host threads -- every document, in the reference's
