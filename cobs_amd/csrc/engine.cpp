@@ -90,6 +90,7 @@ StreamBufs::~StreamBufs() {
 cobs_gpu_batch::~cobs_gpu_batch() {
     if (xchg) destroy_exchange(xchg);
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    for (auto& e : graph_more) if (e.exec) (void)hipGraphExecDestroy(e.exec);
     if (graph_stream) (void)hipStreamDestroy(graph_stream);
     for (auto& r : ev) for (auto& e : r) if (e) (void)hipEventDestroy(e);
     if (run_done) (void)hipEventDestroy(run_done);
@@ -1784,6 +1785,20 @@ static cobs_gpu_status host_pass_begin(cobs_gpu_index* ix, int slot, const char*
             return key;
         };
         const uint64_t key = make_key();
+        if (!(b->graph_exec && b->graph_key == key)) {
+            // captured earlier, displaced by other shapes since?  make it the current one again
+            for (auto& e : b->graph_more) {
+                if (!e.exec || e.key != key) continue;
+                std::swap(e.exec, b->graph_exec);
+                std::swap(e.key, b->graph_key);
+                std::swap(e.res_topk, b->res_topk);
+                std::swap(e.res_pool, b->res_pool);
+                std::swap(e.res_pool_n, b->res_pool_n);
+                std::swap(e.res_rows, b->res_rows);
+                e.used = ++b->graph_clock;
+                break;
+            }
+        }
         if (b->graph_exec && b->graph_key == key) {
             set_run_state(b, threshold, topk, !hits_only);
             HIP_TRY(hipGraphLaunch(b->graph_exec, b->own_stream));
@@ -1794,7 +1809,9 @@ static cobs_gpu_status host_pass_begin(cobs_gpu_index* ix, int slot, const char*
             HIP_TRY(hipEventRecord(b->done, b->own_stream));
             return COBS_GPU_OK;
         }
-        if (b->graph_candidate == key) {
+        bool seen_before = b->graph_candidate == key;
+        for (uint64_t k : b->graph_recent) seen_before = seen_before || (k != 0 && k == key);
+        if (seen_before) {
             // same shape twice in a row: every buffer already has its size (no allocation inside the capture)
             hipGraph_t graph = nullptr;
             // the results travel back inside the graph too (pinned buffers sized before the capture):
@@ -1828,7 +1845,20 @@ static cobs_gpu_status host_pass_begin(cobs_gpu_index* ix, int slot, const char*
                 hipGraphExec_t exec = nullptr;
                 if (cs == COBS_GPU_OK && ee == hipSuccess && graph &&
                     hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-                    if (b->graph_exec) (void)hipGraphExecDestroy(b->graph_exec);
+                    if (b->graph_exec) {
+                        // the current graph moves to the least recently used of the older slots
+                        cobs_gpu_batch::GraphEntry* lru = &b->graph_more[0];
+                        for (auto& e : b->graph_more)
+                            if (!e.exec || (lru->exec && e.used < lru->used)) { lru = &e; if (!e.exec) break; }
+                        if (lru->exec) (void)hipGraphExecDestroy(lru->exec);
+                        lru->exec = b->graph_exec;
+                        lru->key = b->graph_key;
+                        lru->res_topk = b->res_topk;
+                        lru->res_pool = b->res_pool;
+                        lru->res_pool_n = b->res_pool_n;
+                        lru->res_rows = b->res_rows;
+                        lru->used = ++b->graph_clock;
+                    }
                     b->graph_exec = exec;
                     b->graph_key = make_key();          // with the addresses as they are now
                     b->res_topk = res_topk;
@@ -1849,6 +1879,7 @@ static cobs_gpu_status host_pass_begin(cobs_gpu_index* ix, int slot, const char*
         st = run_impl(b, threshold, topk, b->own_stream, !hits_only);
         if (st != COBS_GPU_OK) return st;
         b->graph_candidate = make_key();                // buffers have their sizes (and addresses) now
+        b->graph_recent[b->graph_clock++ % 4] = b->graph_candidate;
         HIP_TRY(hipEventRecord(b->done, b->own_stream));
         return COBS_GPU_OK;
     }

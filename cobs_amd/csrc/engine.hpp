@@ -259,6 +259,18 @@ struct cobs_gpu_batch {
     cobs_amd::PinnedBuf<uint8_t> h_res;
     size_t res_topk = 0, res_pool = 0, res_pool_n = 0;
     bool res_rows = false;            // ... and the score rows of an all-documents pass, into h_rows
+    // shapes captured earlier (a service sees a handful of read lengths, not one): the current graph
+    // above plus a few older ones, least recently used first to go; and the keys of shapes seen once
+    // (the second sighting of a shape captures it, whatever ran in between)
+    struct GraphEntry {
+        hipGraphExec_t exec = nullptr;
+        uint64_t key = 0, used = 0;
+        size_t res_topk = 0, res_pool = 0, res_pool_n = 0;
+        bool res_rows = false;
+    };
+    GraphEntry graph_more[3];
+    uint64_t graph_recent[4] = {0, 0, 0, 0};
+    uint64_t graph_clock = 0;
     hipStream_t graph_stream = nullptr;
     cobs_amd::DevBuf<uint64_t> phase;          // phase stamps of the last scan launch (tuning builds)
     cobs_amd::Exchange* xchg = nullptr;       // comm.cpp

@@ -51,6 +51,21 @@ for n in (1, 4, 16):
         print("nq=%5d  host API top-10, graph %s: %7.1f us per call (%d replays so far)"
               % (n, "off" if g == 0 else "on ", host * 1e6, s.graph_replays), flush=True)
 
+# single queries of FOUR lengths in rotation (a service sees a handful of read lengths): every shape keeps
+# its captured graph (the current one plus three older ones)
+rot = [qs[i][:L] for i, L in enumerate((100, 150, 250, 331))]
+for g in (0, -1):
+    s.set_tuning("graph", g)
+    for i in range(12):
+        s.search_hits([rot[i % 4]], 0.0, 10)
+    r0 = s.graph_replays
+    t0 = time.perf_counter()
+    for i in range(400):
+        s.search_hits([rot[i % 4]], 0.0, 10)
+    host = (time.perf_counter() - t0) / 400
+    print("nq=    1  four query lengths in rotation, graph %s: %7.1f us per call (%d of 400 calls replayed)"
+          % ("off" if g == 0 else "on ", host * 1e6, s.graph_replays - r0), flush=True)
+
 # the reference's default call, search(query) = threshold 0, num_results 0: EVERY document ranked
 for n in (1, 16, 256):
     s.search_arrays(qs[:n], 0.0, 0)

@@ -645,7 +645,8 @@ def test_graph_replay_between_other_shapes(gpu_lib, oracle, tmp_path):
         check(a(i), 0.0, 5)                      # shape A again
         check(c(i), 0.0, 0)                      # every document ranked, two queries
         check(a(i + 20), 0.0, 5)
-    assert s.graph_replays >= r0                 # (how many of these replay is the engine's business)
+    # three shapes in rotation: each is captured at its second sighting and replayed from then on
+    assert s.graph_replays - r0 >= 25
 
 
 def test_default_call_in_batches_is_ranked_by_host_threads(gpu_lib, oracle, tmp_path):
