@@ -13,7 +13,10 @@ A "step" is one pass of the hot path over the resident batch:
   HBM before the timed region; nothing is copied to the host inside it.
 
 Usage:  python bench.py --gpus N --steps K --warmup W
-For N > 1 it is launched by torch.distributed.run, one rank per GPU (RCCL).
+N > 1 = one rank per GPU over RCCL.  Launched by torch.distributed.run (WORLD_SIZE / RANK in the
+environment) the script is one rank of N; started plainly (`python bench.py --gpus 8`) it launches
+the N ranks itself (`launch_plan`): the same torch.distributed.run command, rendezvous on 127.0.0.1.
+Either way the printed line carries n_gpus == --gpus == rccl_ranks, or the run fails.
 """
 import argparse
 import json
@@ -439,6 +442,17 @@ def workload_text(args, cfg):
     return t
 
 
+def launch_plan(gpus, argv):
+    """`python bench.py --gpus N` started without a launcher: the command that runs the N ranks
+    (one process per GPU, rendezvous on 127.0.0.1, a free port)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -471,15 +485,44 @@ def main():
                     help="N=1 smoke run of the multi-GPU code path: one-rank RCCL communicator, sharded layout, exchange")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real multi-GPU runs; gloo only "
                     "for smoke-testing the launch path with several ranks on one GPU")
+    ap.add_argument("--dry-run-launch", action="store_true",
+                    help="print the launch plan of --gpus N (JSON) and exit; needs no GPU")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    launched = "WORLD_SIZE" in os.environ
+    if args.dry_run_launch:
+        plan = {"gpus": args.gpus, "launched_by": "torch.distributed.run (environment)" if launched else
+                ("self" if args.gpus > 1 else "none: one process"),
+                "command": None if launched or args.gpus == 1 else
+                launch_plan(args.gpus, [a for a in sys.argv[1:] if a != "--dry-run-launch"]),
+                "ranks": args.gpus, "devices": list(range(args.gpus))}
+        _RESULT_STDOUT.write(json.dumps(plan) + "\n")
+        _RESULT_STDOUT.flush()
+        return
+    if not launched and args.gpus > 1:
+        # started plainly: become the launcher of the N ranks (their rank 0 prints the JSON line to
+        # the stdout this process was given)
+        if args.dist_backend == "nccl" and torch.cuda.device_count() < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible" % (args.gpus, torch.cuda.device_count()))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.stderr.flush()
+        os.dup2(_RESULT_STDOUT.fileno(), 1)
+        cmd = launch_plan(args.gpus, sys.argv[1:])
+        os.execv(cmd[0], cmd)
 
     from cobs_amd import _capi
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d was launched with WORLD_SIZE=%d: the two must agree" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.dist_backend == "nccl" and torch.cuda.device_count() < world:
+            raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible" % (world, torch.cuda.device_count()))
         local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
         if args.dist_backend == "nccl":
@@ -655,6 +698,10 @@ def main():
         out["end_to_end"] = end_to_end(s, batch, queries)
         out["cpu_baseline"] = cpu_baseline(s, cfg, queries, batch=batch)
     if rank == 0:
+        # the line is only printed when it describes the run that was asked for
+        assert out["n_gpus"] == args.gpus, (out["n_gpus"], args.gpus)
+        if shard_index and args.dist_backend == "nccl":
+            assert out["rccl_ranks"] == args.gpus, (out["rccl_ranks"], args.gpus)
         _RESULT_STDOUT.write(json.dumps(out) + "\n")
         _RESULT_STDOUT.flush()
     if world > 1:

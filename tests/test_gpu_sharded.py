@@ -84,3 +84,53 @@ def test_bench_sharded_code_path_on_one_rank(gpu_lib):
     other = j["other_forms"]
     for k in ("sharded_overlap_2_sub_batches", "sharded_allgather", "index_replicated_weak", "sharded_hits_threshold_0.8"):
         assert "queries_per_s" in other[k], (k, other[k])
+
+
+def _bench(args, timeout=900, env=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True,
+                       timeout=timeout, env=e)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    return r, (json.loads(lines[-1]) if lines else None), r.stdout
+
+
+SMALL = ["--scale", "0.02", "--queries", "512", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+
+
+def test_bench_gpus_1_plain_and_one_rank_sharded(gpu_lib):
+    """`bench.py --gpus 1` started plainly is the single-GPU line; with --one-rank-sharded the same flag runs the
+    multi-GPU code path on a one-rank communicator.  Both lines carry n_gpus == --gpus, and stdout holds the line only."""
+    r, j, out = _bench(["--gpus", "1"] + SMALL)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert j["n_gpus"] == 1 and "rccl_ranks" not in j and j["config"]["parallelism"] == "1 gpu"
+    assert out.strip().count("\n") == 0
+    r, j, out = _bench(["--gpus", "1", "--one-rank-sharded", "--no-extras"] + SMALL)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert j["n_gpus"] == 1 and j["rccl_ranks"] == 1
+
+
+def test_bench_gpus_2_launches_its_own_ranks(gpu_lib):
+    """`python bench.py --gpus 2` with no launcher in the environment starts two ranks by itself (the flag used to be
+    parsed and ignored).  Two ranks on the one GPU of this box need gloo for the exchange (RCCL refuses two ranks on
+    one device); the launch path, the sharded layout and the line are the ones an 8-GPU node runs."""
+    r, j, out = _bench(["--gpus", "2", "--dist-backend", "gloo", "--no-extras"] + SMALL)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong"
+    assert "sharded by sub-index block" in j["config"]["parallelism"] and "over 2 GPUs" in j["config"]["parallelism"]
+    assert j["shard_rank0"]["slot_count"] < 100352
+    assert [ln for ln in out.splitlines() if ln.strip()] == [ln for ln in out.splitlines() if ln.startswith('{"metric"')]
+
+
+def test_bench_refuses_more_gpus_than_devices(gpu_lib):
+    import torch
+    n = torch.cuda.device_count() + 1
+    r, j, _ = _bench(["--gpus", str(n)] + SMALL, timeout=300)
+    assert r.returncode != 0 and j is None
+    assert "HIP device(s) visible" in r.stderr
