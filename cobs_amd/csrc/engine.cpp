@@ -1197,6 +1197,20 @@ static void set_run_state(cobs_gpu_batch* b, double threshold, size_t topk, bool
     b->have_counts = want_counts || !b->selected;
 }
 
+// The per-(file, query) thresholds ceil(threshold * T) (classic_search.cpp:444-449) in the pinned
+// buffer the H2D copies of a run read.  A captured graph holds those copies as nodes that read the
+// buffer when the graph is LAUNCHED, and the buffer is shared by every shape of the batch: a replay
+// has to write its own thresholds first (whatever ran in between left its own there).
+static void stage_thresholds(cobs_gpu_batch* b, double threshold) {
+    const cobs_gpu_index* ix = b->ix;
+    const size_t nq = b->nq;
+    for (size_t f = 0; f < ix->parts.size(); ++f) {
+        uint32_t* stage = b->h_thr_stage.p + f * nq;
+        for (size_t q = 0; q < nq; ++q)
+            stage[q] = threshold_for(threshold, (uint64_t)b->lens[q] - ix->parts[f].meta.term_size + 1);
+    }
+}
+
 cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t topk, void* hip_stream,
                                    bool want_counts) {
     if (!b) return fail(COBS_GPU_ERR_ARG, "NULL batch");
@@ -1217,12 +1231,9 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
     // device flags: first invalid query = none, selected hits = 0
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)b->flags.p, 0, 4, st));      // all zero: one fill
     if (need_thr) {
-        for (size_t f = 0; f < ix->parts.size(); ++f) {
-            uint32_t* stage = b->h_thr_stage.p + f * nq;
-            for (size_t q = 0; q < nq; ++q)
-                stage[q] = threshold_for(threshold, (uint64_t)b->lens[q] - ix->parts[f].meta.term_size + 1);
-            if (nq) HIP_TRY(hipMemcpyAsync(b->work[f].thr.p, stage, 4 * nq, hipMemcpyHostToDevice, st));
-        }
+        stage_thresholds(b, threshold);
+        for (size_t f = 0; f < ix->parts.size(); ++f)
+            if (nq) HIP_TRY(hipMemcpyAsync(b->work[f].thr.p, b->h_thr_stage.p + f * nq, 4 * nq, hipMemcpyHostToDevice, st));
     }
     hipEvent_t* ev = b->ev[b->run_seq % cobs_gpu_batch::kRing];
     HIP_TRY(hipEventRecord(ev[0], st));
@@ -1801,6 +1812,7 @@ static cobs_gpu_status host_pass_begin(cobs_gpu_index* ix, int slot, const char*
         }
         if (b->graph_exec && b->graph_key == key) {
             set_run_state(b, threshold, topk, !hits_only);
+            if (threshold > 0.0) stage_thresholds(b, threshold);     // the graph's H2D nodes read them now
             HIP_TRY(hipGraphLaunch(b->graph_exec, b->own_stream));
             b->graph_run = true;
             b->run_seq++;

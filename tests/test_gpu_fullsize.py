@@ -10,6 +10,15 @@ import bench
 
 pytestmark = pytest.mark.gpu
 
+_ORACLE_ROWS = {}
+
+
+def _oracle_rows(ix, key, queries):
+    """the checker's count rows of a query set, computed once per session (C4: 245 000 regenerated rows per query)"""
+    if key not in _ORACLE_ROWS:
+        _ORACLE_ROWS[key] = [ix.counts(q) for q in queries]
+    return _ORACLE_ROWS[key]
+
 
 def _open(gpu, cfg):
     return gpu.Search.synthetic(cfg["kind"], cfg["signature_sizes"], cfg["num_docs"],
@@ -44,8 +53,9 @@ def test_full_size_config(gpu_lib, oracle, name):
     dev_sum = t_all.sum(dim=1).cpu().numpy()
     dev_wsum = (t_all * w).sum(dim=1).cpu().numpy()
     wn = (np.arange(t_all.shape[1], dtype=np.int64) % 1021) + 1
+    wants = _oracle_rows(ix, (name, nq), queries)
     for i in range(nq):
-        want = ix.counts(queries[i])
+        want = wants[i]
         assert np.array_equal(b.counts_host(i), want), (name, i)
         assert int(dev_sum[i]) == int(want.sum()) and int(dev_wsum[i]) == int((want.astype(np.int64) * wn).sum())
     # a few rows of the index itself, incl. the last row of the largest sub-index
@@ -234,3 +244,103 @@ def test_streamed_file_at_scale_is_bit_exact(gpu_lib, oracle, tmp_path):
         assert np.array_equal(b.counts_host(i), ix.counts(q)), i
     got = s.search_hits(queries[:8], 0.0, 5)
     assert got == [[(f, d, sc) for (f, d, _n, sc) in oracle.search(ix, q, 0.0, 5)] for q in queries[:8]]
+
+
+def _shards_in_turn(gpu, opener, nshards, mode, queries, budget=0):
+    """every shard of an N-way sharded index opened one after another on this one GPU: -> (slot layout per rank,
+    local count rows per rank as the scan leaves them in HBM, score width)"""
+    import torch
+    begins, counts, local, eb, hbm = [], [], [], None, []
+    for r in range(nshards):
+        s = opener(shard_rank=r, shard_count=nshards, shard_mode=mode, hbm_budget=budget)
+        info = s.info(0)
+        begins.append([int(info.slot_begin)])
+        counts.append([int(info.slot_count)])
+        hbm.append(int(info.hbm_bytes))
+        if budget:
+            assert info.hbm_bytes <= budget
+        b = gpu.Batch(s)
+        b.set_queries(queries)
+        b.run(0.0)
+        b.sync()
+        t = b.counts_tensor()
+        assert t.shape[1] == info.slot_count == s.local_counts
+        eb = t.element_size()
+        local.append(t.cpu().numpy().view(np.uint8).reshape(-1).copy())
+        b.close()
+        s.close()
+        del t, b, s
+        torch.cuda.empty_cache()
+    return begins, counts, local, eb, hbm
+
+
+def _check_shard_union(lib, begins, counts, local, eb, total, wants, nshards):
+    from tests import xchg
+    nq = len(wants)
+    # the slot ranges of the shards partition counts_size
+    pos = 0
+    for r in range(nshards):
+        if counts[r][0]:
+            assert begins[r][0] == pos and begins[r][0] % 8 == 0 and counts[r][0] % 8 == 0
+            pos += counts[r][0]
+    assert pos == total
+    dt = {1: np.uint8, 2: np.uint16, 4: np.uint32}[eb]
+    want_rows = np.stack(wants).astype(dt)
+    # union of the local rows = the oracle
+    for r in range(nshards):
+        rows = local[r].view(dt).reshape(nq, counts[r][0])
+        assert np.array_equal(rows, want_rows[:, begins[r][0]:begins[r][0] + counts[r][0]]), r
+    # ... and the N-rank exchange of exactly these rows, played on the CPU from the library's own plan:
+    # all-to-all (every rank ends with the full rows of the queries it owns) and all-gather
+    for mode in (1, 0):
+        owned = 0
+        for q0, qn, got in xchg.emulate(lib, local, begins, counts, [0], total, nq, eb, mode):
+            assert np.array_equal(got, np.ascontiguousarray(want_rows[q0:q0 + qn]).view(np.uint8).reshape(-1)), mode
+            owned += qn
+        assert owned == (nq if mode == 1 else nq * nshards)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_c4_eight_shards_in_turn(gpu_lib, oracle, mode):
+    """BASELINE configs[3] at its own geometry -- 1 M documents, 245 sub-indexes, 68 GB -- cut into the 8 shards an
+    8-GPU node holds (mode 0: equal bytes, cuts inside sub-indexes; mode 1: whole sub-indexes), each 8.5 GB shard on
+    this GPU in turn, 64 queries: the slot ranges partition counts_size, the union of the shards' rows is the
+    oracle's, and the all-to-all / all-gather plans of the 8 ranks assemble those rows into the oracle's
+    (everything of the N = 8 run but the xGMI transfers themselves).
+    Shard boundary: reference cobs/query/compact_index/mmap_search_file.cpp:22-27, search_file.cpp:30-32."""
+    from cobs_amd import _capi
+    cfg = bench.c4_config()
+    ix = _oracle_index(oracle, cfg)
+    nq = 64
+    queries = bench.make_queries(nq, 1000)
+    wants = _oracle_rows(ix, ("c4", nq), queries)
+
+    def opener(**kw):
+        return gpu_lib.Search.synthetic(cfg["kind"], cfg["signature_sizes"], cfg["num_docs"], page_size=cfg["page_size"],
+                                        term_size=cfg["term_size"], canonicalize=cfg["canonicalize"],
+                                        num_hashes=cfg["num_hashes"], seed=cfg["seed"], **kw)
+    begins, counts, local, eb, hbm = _shards_in_turn(gpu_lib, opener, 8, mode, queries)
+    assert eb == 2
+    if mode == 0:       # byte-balanced: every shard holds an eighth of the 68 GB (documents per shard differ 8x)
+        assert max(hbm) < 1.1 * min(hbm) and 8.0e9 < min(hbm) and max(hbm) < 9.5e9
+    else:               # whole sub-indexes: every cut on a sub-index boundary
+        assert all(b[0] % (8 * cfg["page_size"]) == 0 for b in begins)
+    _check_shard_union(_capi.load(), begins, counts, local, eb, ix.counts_size, wants, 8)
+
+
+def test_c5_quarter_scale_eight_streamed_shards_in_turn(gpu_lib, oracle, tmp_path):
+    """BASELINE configs[4]'s N = 8 arithmetic at quarter scale: the 4.6 GB .cobs_compact FILE cut into 8 byte-balanced
+    shards, every shard opened under an HBM budget smaller than itself (so each rank streams its slices), in turn on
+    this GPU; union and exchange plans as above."""
+    import cobs_amd
+    from cobs_amd import _capi
+    cfg = bench.c3_config(0.25)
+    path = str(tmp_path / "c5q.cobs_compact")
+    cobs_amd.write_synthetic(path, "compact", cfg["signature_sizes"], cfg["num_docs"], page_size=cfg["page_size"], seed=1)
+    ix = _oracle_index(oracle, cfg)
+    nq = 48
+    queries = bench.make_queries(nq, 1000)
+    wants = [ix.counts(q) for q in queries]
+    budget = 200 * 1000 * 1000          # a shard is ~575 MB
+    begins, counts, local, eb, _ = _shards_in_turn(gpu_lib, lambda **kw: gpu_lib.Search(path, **kw), 8, 0, queries, budget)
+    _check_shard_union(_capi.load(), begins, counts, local, eb, ix.counts_size, wants, 8)

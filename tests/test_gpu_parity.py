@@ -649,6 +649,28 @@ def test_graph_replay_between_other_shapes(gpu_lib, oracle, tmp_path):
     assert s.graph_replays - r0 >= 25
 
 
+def test_graph_replay_of_two_thresholded_shapes(gpu_lib, oracle, tmp_path):
+    """two captured shapes that BOTH use a threshold, of different query lengths, in rotation (A,B,A,B,...), in
+    hits-only and in top-k mode: the thresholds ceil(t*T) differ per shape and reach the device through one pinned
+    staging buffer per batch, so a replay must stage its own (a replay that inherits the other shape's
+    threshold -- 85 for a query of 70 terms -- silently returns nothing)"""
+    q_long = oracle.random_sequence(600, 91)
+    planted = {3: 1.0, 11: 0.8, 500: 0.62, 1700: 0.55, 1999: 0.45}
+    p = cases.make_compact(cases.tmp(tmp_path, "g3.cobs_compact"), 2000, 64, [900, 1000, 1100, 1200], 1, 31, 1,
+                           0.3, 8, planted=planted, query=q_long)
+    ix = oracle.Index.open(p)
+    for lim in (0, 4):                              # hits only / K3 with a threshold
+        s = gpu_lib.Search(p)
+        r0 = s.graph_replays
+        for rnd in range(6):
+            for L in (100, 200, 331):               # 70 / 170 terms: 8-bit scores, 301 terms: 16-bit
+                qs = [q_long[:L]]                   # the SAME text: planted documents pass at 0.5 in every shape
+                want = [cases.oracle_results([ix], q, 0.5, lim) for q in qs]
+                assert len(want[0]) >= 3
+                assert s.search_hits(qs, 0.5, lim) == want, (rnd, L, lim)
+        assert s.graph_replays - r0 >= 6            # every shape was replayed (buffers that grow re-key a shape once)
+
+
 def test_default_call_in_batches_is_ranked_by_host_threads(gpu_lib, oracle, tmp_path):
     """threshold 0, no limit (the reference's default arguments) for MANY queries per call: the
     passes' score rows are ranked by several host threads -- every document, in the reference's

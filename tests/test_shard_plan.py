@@ -10,7 +10,7 @@ import struct
 import numpy as np
 import pytest
 
-from tests import cases
+from tests import cases, xchg
 
 
 def _plan(path, n, mode=0):
@@ -102,20 +102,6 @@ def test_crafted_headers_are_rejected_not_trusted(tmp_path):
         assert _capi.load().cobs_gpu_plan_shards(os.fsencode(str(p)), 2, 0, b, c, None) == _capi.ERR_FORMAT, name
 
 
-def _exchange_plan(lib, begins, counts, doc_off, total, nq, eb, mode, rank):
-    from cobs_amd import _capi
-    N, F = len(begins), len(begins[0])
-    b = (C.c_uint64 * (N * F))(*[x for r in begins for x in r])
-    c = (C.c_uint64 * (N * F))(*[x for r in counts for x in r])
-    d = (C.c_uint64 * F)(*doc_off)
-    xf = (_capi.Xfer * N)()
-    cp = (_capi.Copy2D * (N * F))()
-    ncp = C.c_size_t(N * F)
-    out = (C.c_uint64 * 6)()
-    _capi.check(lib.cobs_gpu_exchange_plan(b, c, d, N, F, total, nq, eb, mode, rank, xf, cp, C.byref(ncp), out))
-    return list(xf), list(cp)[:ncp.value], list(out)
-
-
 @pytest.mark.parametrize("mode", [0, 1])                   # all-gather, all-to-all
 def test_exchange_plan_moves_every_count_exactly_once(oracle, tmp_path, mode):
     """The multi-GPU exchange of libcobs_gpu.so is a host-computed plan executed over RCCL
@@ -149,38 +135,11 @@ def test_exchange_plan_moves_every_count_exactly_once(oracle, tmp_path, mode):
                     for r in range(N):
                         parts = [rows[:, doc_off[f] + begins[r][f]: doc_off[f] + begins[r][f] + counts[r][f]] for f in range(2)]
                         local.append(np.ascontiguousarray(np.concatenate(parts, axis=1)).view(np.uint8).reshape(-1))
-                    plans = [_exchange_plan(lib, begins, counts, doc_off, total, nq, eb, mode, r) for r in range(N)]
-                    assert len({p[2][4] for p in plans}) == 1                      # same collective everywhere
                     owned = []
-                    for i in range(N):
-                        xf, cps, out = plans[i]
-                        q0, qn, staging_bytes, global_bytes, use_ag, my_row = out
+                    for q0, qn, got in xchg.emulate(lib, local, begins, counts, doc_off, total, nq, eb, mode):
                         owned.append((q0, qn))
-                        staging = np.zeros(staging_bytes, dtype=np.uint8)
-                        for j in range(N):
-                            if use_ag:
-                                # ncclAllGather: every rank's nq * row bytes land rank after rank
-                                assert xf[j].recv_bytes == nq * my_row and plans[j][2][5] == my_row
-                                staging[xf[j].recv_offset: xf[j].recv_offset + xf[j].recv_bytes] = local[j][:nq * my_row]
-                                continue
-                            if j == i:
-                                assert xf[j].send_bytes == 0 and xf[j].recv_bytes == 0
-                                continue
-                            peer = plans[j][0][i]                                   # what j sends to i
-                            assert peer.send_bytes == xf[j].recv_bytes, (N, i, j)   # ncclSend / ncclRecv sizes agree
-                            staging[xf[j].recv_offset: xf[j].recv_offset + xf[j].recv_bytes] = \
-                                local[j][peer.send_offset: peer.send_offset + peer.send_bytes]
-                        got = np.full(global_bytes, 0xAB, dtype=np.uint8)
-                        written = np.zeros(global_bytes, dtype=np.uint8)
-                        for c in cps:
-                            src = local[i] if c.src_is_local else staging
-                            for h in range(c.height):
-                                so, do = c.src_offset + h * c.src_pitch, c.dst_offset + h * c.dst_pitch
-                                got[do:do + c.width] = src[so:so + c.width]
-                                written[do:do + c.width] += 1
-                        assert (written == 1).all(), (N, i, mode)                  # every byte exactly once
                         want = np.ascontiguousarray(rows[q0:q0 + qn]).view(np.uint8).reshape(-1)
-                        assert np.array_equal(got, want), (N, i, mode, eb, nq)
+                        assert np.array_equal(got, want), (N, mode, eb, nq)
                     if mode == 1:                                                  # the owners partition the batch
                         assert [o[0] for o in owned] == [nq * j // N for j in range(N)]
                         assert sum(o[1] for o in owned) == nq
