@@ -2,6 +2,8 @@
 #pragma once
 #include <cstdint>
 
+struct cobs_gpu_hit;
+
 namespace cobs_amd {
 
 // One sub-index ("page" in the reference's compact index; a classic index is a
@@ -94,6 +96,35 @@ struct TopkArgs {
     uint32_t levels;             // ceil(score_bits / level_bits): 1, 2 or 3
     uint32_t score_bytes;        // 1 (planes <= 8), 2 (<= 16) or 4
     uint32_t sort_limit;         // order the survivors on the device when there are at most this many (0 = never)
+};
+
+// Ranking of all documents of a query on the device (rank_kernels.hip): one index file as the
+// ranked score row holds it.
+struct RankPart {
+    const uint32_t* thr;         // [batch queries] thresholds of this file, or nullptr (= 0)
+    uint32_t slot0;              // first slot of the file's slice in the row
+    uint32_t doc_first;          // file-level id of the document at that slot
+    uint32_t ndocs;              // real documents among the slice's slots
+    uint32_t file_no;
+};
+
+// One pass of the stable radix sort by score (most passes: one).  Block b ranks query q0 + b.
+struct RankArgs {
+    const void* rows;            // score rows [batch queries][row_stride] of score_bytes each
+    uint64_t row_stride;         // elements
+    const RankPart* parts;       // nparts files, slices back to back in slot order
+    const uint8_t* by_score;     // [batch queries] 0: a single hash in total, the result keeps index order
+    const uint2* src;            // (score, slot) pairs of the previous pass [nq][pair_stride]
+    uint2* dst;                  // ... of this pass, unless it is the last
+    uint32_t* npass;             // [nq] passing documents: written by a first pass that is not the last, read by later ones
+    cobs_gpu_hit* out;           // last pass: results [nq][out_stride], at most `limit` per query
+    uint32_t* out_count;         // last pass: [nq] results written = min(limit, passing documents)
+    uint64_t pair_stride, out_stride;
+    uint32_t nparts, nslots;     // slots of a row that are ranked (the files' slices)
+    uint32_t q0, nq;
+    uint32_t shift, bits;        // digit of this pass = (score >> shift) & (2^bits - 1), bits <= 12
+    uint32_t limit;
+    uint32_t score_bytes;
 };
 
 // Arguments of the construction kernel: set the signature bits of documents.

@@ -67,6 +67,8 @@ Tuning Tuning::from_env() {
     if (getenv("COBS_GPU_NO_PIN")) t.no_pin = true;
     if (const char* e = getenv("COBS_GPU_GRAPH")) t.graph = atoi(e) != 0;
     if (const char* e = getenv("COBS_GPU_LDS_STAGED")) t.lds_staged = atoi(e) != 0;
+    if (const char* e = getenv("COBS_GPU_DEVICE_RANK")) t.device_rank = atoi(e) != 0;
+    if (const char* e = getenv("COBS_GPU_TRACE")) t.trace = atoi(e) != 0;
     return t;
 }
 
@@ -89,6 +91,7 @@ StreamBufs::~StreamBufs() {
 
 cobs_gpu_batch::~cobs_gpu_batch() {
     if (xchg) destroy_exchange(xchg);
+    if (rank) destroy_rank_work(rank);
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     for (auto& e : graph_more) if (e.exec) (void)hipGraphExecDestroy(e.exec);
     if (graph_stream) (void)hipStreamDestroy(graph_stream);
@@ -932,10 +935,12 @@ cobs_gpu_status cobs_gpu_set_tuning(cobs_gpu_index* ix, const char* key, int64_t
         t.graph = value < 0 ? -1 : value != 0;
     } else if (k == "lds_staged") {
         t.lds_staged = value > 0;
+    } else if (k == "device_rank") {
+        t.device_rank = value != 0;
     } else if (k == "phase_slots") {
         t.phase_slots = value > 0 ? (uint32_t)std::min<int64_t>(value, 1 << 20) : 0;
     } else {
-        return fail(COBS_GPU_ERR_ARG, "unknown tuning key (waves, tile_w, mq, pass_bytes, pipe_chars, graph, lds_staged)");
+        return fail(COBS_GPU_ERR_ARG, "unknown tuning key (waves, tile_w, mq, pass_bytes, pipe_chars, graph, lds_staged, device_rank)");
     }
     return COBS_GPU_OK;
 }
@@ -1966,7 +1971,9 @@ static cobs_gpu_status search_batch_impl(cobs_gpu_index* ix, const char* const* 
     };
     auto collect = [&](const Pass& ps) -> cobs_gpu_status {
         size_t bad = 0;
+        const double te0 = now_s();
         cobs_gpu_status st = host_pass_end(ix, ps.slot, threshold, topk, &bad);
+        if (ix->tune.trace) std::fprintf(stderr, "[cobs_gpu] pass of queries %zu..%zu: waited %.3f ms for the device\n", ps.g0, ps.g1, (now_s() - te0) * 1e3);
         if (st != COBS_GPU_OK) {
             if (bad_query) *bad_query = ps.g0 + bad;
             if (st == COBS_GPU_ERR_INVALID_BASE)          // the message names the query by its index in the call
@@ -1975,6 +1982,15 @@ static cobs_gpu_status search_batch_impl(cobs_gpu_index* ix, const char* const* 
             return st;
         }
         cobs_gpu_batch* sb = ix->scratch[ps.slot];
+        // results that have to come from whole score rows -- the reference's default call (threshold 0, no
+        // limit: every document of every query, src/cobs.cpp:618-626), a limit too large for K3, a hit pool
+        // that overflowed -- are ordered on the device and cross PCIe as finished records (rank.cpp)
+        if (ix->tune.device_rank != 0 && rank_on_device_applies(sb, ps.g1 - ps.g0)) {
+            double t0 = now_s();
+            st = rank_on_device(sb, ps.g1 - ps.g0, num_results, hits, cap, &used, hit_offsets + ps.g0, &overflow);
+            ix->timers[4] += now_s() - t0;
+            return st;
+        }
         // all documents of every query (the reference's default call): every query yields the same
         // number of hits, so the queries of the pass are ranked by several host threads at once
         if (!overflow && threshold <= 0.0 && num_results == 0 && sb->have_counts && !sb->selected && sb->topk_k == 0 &&
@@ -2042,8 +2058,10 @@ static cobs_gpu_status search_batch_impl(cobs_gpu_index* ix, const char* const* 
         }
         const int slot = (int)(pass_no % depth);
         size_t bad_local = 0;
+        const double tb0 = now_s();
         cobs_gpu_status st = host_pass_begin(ix, slot, queries + g0, lens + g0, g1 - g0, threshold, topk, prev_done,
                                              &bad_local, g0);
+        if (ix->tune.trace) std::fprintf(stderr, "[cobs_gpu] pass %zu: %zu queries staged + launched in %.3f ms\n", pass_no, g1 - g0, (now_s() - tb0) * 1e3);
         if (st != COBS_GPU_OK) {
             // passes before this one come first in the caller's order: report their error if they have one
             const size_t first_bad = g0 + bad_local;

@@ -98,6 +98,8 @@ struct Tuning {
     bool no_pin = false;        // COBS_GPU_NO_PIN: never hipHostRegister the mapped file
     int graph = -1;             // COBS_GPU_GRAPH: captured-graph path for small batches off / on
     bool lds_staged = false;    // COBS_GPU_LDS_STAGED: the LDS-staged scan variant (A/B measurements only)
+    int device_rank = 1;        // whole score rows are ranked on the device (0: by host threads, A/B and fallback)
+    bool trace = false;         // COBS_GPU_TRACE: where the host side of a search call spends its time, on stderr
     uint32_t phase_slots = 0;   // tuning builds (make timing): work-groups of a scan launch that record phase stamps
     static Tuning from_env();
 };
@@ -178,6 +180,7 @@ struct PartWork {    // per-file device workspace of a batch
 };
 
 struct Exchange;     // comm.cpp: buffers of the RCCL exchange bound to a batch
+struct RankWork;     // rank.cpp: buffers of the on-device ranking of whole score rows
 
 }  // namespace cobs_amd
 
@@ -274,6 +277,7 @@ struct cobs_gpu_batch {
     hipStream_t graph_stream = nullptr;
     cobs_amd::DevBuf<uint64_t> phase;          // phase stamps of the last scan launch (tuning builds)
     cobs_amd::Exchange* xchg = nullptr;       // comm.cpp
+    cobs_amd::RankWork* rank = nullptr;       // rank.cpp
     // set by an exchange, cleared by the next run: GLOBAL score rows (all shards' slices assembled
     // in global document order) of queries [g_q0, g_q0 + g_qn), owned by xchg
     const uint8_t* g_rows = nullptr;
@@ -295,6 +299,11 @@ uint64_t total_hashes(const cobs_gpu_batch* b, size_t q);
 bool hit_before(const cobs_gpu_hit& a, const cobs_gpu_hit& b);
 bool doc_before(const cobs_gpu_hit& a, const cobs_gpu_hit& b);
 void destroy_exchange(Exchange* x);       // comm.cpp
+// rank.cpp: counts_to_result over the score rows of the last run, on the device
+void destroy_rank_work(RankWork* w);
+bool rank_on_device_applies(const cobs_gpu_batch* b, size_t nq);
+cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t nq, size_t limit, cobs_gpu_hit* hits, size_t cap,
+                               size_t* used, size_t* hit_offsets, bool* overflow);
 cobs_gpu_status open_zeroed(IndexMeta&& meta, const cobs_gpu_options* opts, cobs_gpu_index** out);
 
 }  // namespace cobs_amd

@@ -27,6 +27,9 @@ bool scan_has_lds_staged(int planes, uint32_t num_hashes, int nw);
 // K3: per query the k best (score desc, doc asc) documents with score >= threshold.
 hipError_t launch_topk(const TopkArgs& a, hipStream_t stream);
 
+// Ranking of every document (rank_kernels.hip): one pass of the stable radix sort by score; a.nq work-groups.
+hipError_t launch_rank(const RankArgs& a, bool first, bool last, hipStream_t stream);
+
 // Index construction: one thread per text position hashes its term and sets the bits.
 hipError_t launch_build(const BuildArgs& a, uint64_t total_bytes, hipStream_t stream);
 hipError_t launch_pack_bytemap(const PackArgs& a, hipStream_t stream);

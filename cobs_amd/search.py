@@ -154,18 +154,21 @@ class Search:
 
     HIT_DTYPE = np.dtype([("file_no", "<u4"), ("doc", "<u4"), ("score", "<u4")])
 
-    def search_arrays(self, queries, threshold=0.0, num_results=0):
+    def search_arrays(self, queries, threshold=0.0, num_results=0, out=None):
         """-> (offsets uint64 [nq + 1], hits structured array of (file_no, doc, score)):
-        the hits of query i are hits[offsets[i]:offsets[i + 1]], in result order."""
+        the hits of query i are hits[offsets[i]:offsets[i + 1]], in result order.  The columnar form of
+        search(): no per-result Python objects (the default call returns every document of the index)."""
         qs = [q if type(q) is bytes else _as_bytes(q) for q in queries]
         offsets = np.zeros(len(qs) + 1, dtype=np.uint64)
         np.cumsum(np.fromiter(map(len, qs), dtype=np.uint64, count=len(qs)), out=offsets[1:])
-        return self.search_packed(b"".join(qs), offsets, threshold, num_results)
+        return self.search_packed(b"".join(qs), offsets, threshold, num_results, out=out)
 
-    def search_packed(self, text, offsets, threshold=0.0, num_results=0):
+    def search_packed(self, text, offsets, threshold=0.0, num_results=0, out=None):
         """The same for queries packed back to back: query i is text[offsets[i]:offsets[i + 1]]
         (text: bytes or a uint8 array, e.g. the sequence lines of a FASTQ block; offsets: nq + 1
-        integers).  No per-query Python objects: the pointer array is built with numpy."""
+        integers).  No per-query Python objects: the pointer array is built with numpy.
+        out: an optional HIT_DTYPE array to receive the hits (a caller that repeats large calls keeps
+        one buffer instead of page-faulting a fresh one per call); it is used when large enough."""
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         nq = len(offsets) - 1
         if nq < 0:
@@ -194,7 +197,10 @@ class Search:
         offs = np.zeros(nq + 1, dtype=np.uint64)
         bad = C.c_size_t(0)
         while True:
-            hits = np.empty(cap, dtype=self.HIT_DTYPE)
+            if out is not None and out.dtype == self.HIT_DTYPE and out.flags.c_contiguous and out.size >= cap:
+                hits, cap = out, out.size
+            else:
+                hits = np.empty(cap, dtype=self.HIT_DTYPE)
             st = self._search_batch_call(
                 arr, lens, nq, float(threshold), int(num_results),
                 C.cast(hits.ctypes.data, C.POINTER(Hit)), cap,

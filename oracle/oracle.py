@@ -233,6 +233,22 @@ def search(indexes, query: bytes, threshold=0.0, num_results=0, threads=1):
             for i in range(n.value)]
 
 
+def search_arrays(indexes, query: bytes, threshold=0.0, num_results=0, threads=1):
+    """cobs::ClassicSearch::search, columnar: -> (index_no, doc_id, score) uint32 arrays in result order
+    (no per-result Python objects: ranking 100 000 documents per query)"""
+    if isinstance(indexes, Index):
+        indexes = [indexes]
+    cap = sum(ix.counts_size for ix in indexes)
+    hs = (C.c_void_p * len(indexes))(*[ix._h for ix in indexes])
+    oi = np.zeros(max(cap, 1), dtype=np.uint32)
+    od = np.zeros(max(cap, 1), dtype=np.uint32)
+    os_ = np.zeros(max(cap, 1), dtype=np.uint32)
+    n = C.c_size_t(0)
+    _check(lib().oracle_search(hs, len(indexes), query, len(query), float(threshold), int(num_results),
+                               threads, oi.ctypes.data, od.ctypes.data, os_.ctypes.data, cap, C.byref(n)))
+    return oi[:n.value], od[:n.value], os_[:n.value]
+
+
 def search_many(indexes, queries, threshold=0.0, num_results=0, threads=1, seconds=5.0):
     """time ClassicSearch::search over `queries` inside C -> (queries done, seconds)"""
     if isinstance(indexes, Index):

@@ -66,17 +66,29 @@ for g in (0, -1):
     print("nq=    1  four query lengths in rotation, graph %s: %7.1f us per call (%d of 400 calls replayed)"
           % ("off" if g == 0 else "on ", host * 1e6, s.graph_replays - r0), flush=True)
 
-# the reference's default call, search(query) = threshold 0, num_results 0: EVERY document ranked
-for n in (1, 16, 256):
-    s.search_arrays(qs[:n], 0.0, 0)
-    t0 = time.perf_counter()
-    reps = 5 if n < 256 else 2
-    for _ in range(reps):
-        offs, hits = s.search_arrays(qs[:n], 0.0, 0)
-    host = (time.perf_counter() - t0) / reps
-    tm = s.timers(reset=True)
-    print("nq=%5d  host API all %d documents ranked per query %9.3f ms  %8.0f q/s  (rank %.3f s)"
-          % (n, len(hits) // n, host * 1e3, n / host, tm["rank"] / (reps + 1)), flush=True)
+# the reference's default call, search(query) = threshold 0, num_results 0: EVERY document ranked.
+# On the device (rank_kernels.hip: the ordered records cross PCIe) vs by host threads (the score rows cross);
+# into a fresh result array per call vs into one the caller keeps (no page faults on 307 MB).
+import numpy as np
+keep = np.zeros(256 * s.total_counts, dtype=s.HIT_DTYPE)
+for n in (1, 16, 64, 256, 1024):
+    for dr in (0, 1):
+        s.set_tuning("device_rank", dr)
+        for reuse in (False, True):
+            out = keep if reuse and n <= 256 else None
+            s.search_arrays(qs[:n], 0.0, 0, out=out)
+            s.timers(reset=True)
+            reps = 5 if n < 256 else 3
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                offs, hits = s.search_arrays(qs[:n], 0.0, 0, out=out)
+            host = (time.perf_counter() - t0) / reps
+            tm = s.timers(reset=True)
+            print("nq=%5d  all %d documents ranked per query, %s, %s result buffer: %9.3f ms  %8.0f q/s  %6.2f GB/s of records (phases, ms: %s)"
+                  % (n, len(hits) // n, "on the device" if dr else "by host threads", "kept " if out is not None else "fresh",
+                     host * 1e3, n / host, len(hits) * 12 / host / 1e9,
+                     " ".join("%s %.3f" % (k, v / reps * 1e3) for k, v in tm.items())), flush=True)
+s.set_tuning("device_rank", 1)
 
 # the Python mirror of that call: 100k SearchResult objects per query
 s.search(qs[0])

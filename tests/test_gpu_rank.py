@@ -1,0 +1,125 @@
+"""GPU: counts_to_result over whole score rows ON THE DEVICE (rank_kernels.hip / rank.cpp) against the
+oracle's ranking (reference cobs/query/classic_search.cpp:109-202: score descending, ties by (file,
+document) ascending, the unsorted single-hash case) -- the reference's default call (threshold 0, no limit;
+its own benchmark, src/cobs.cpp:618-626) at 100 000 documents, every score width and pass count of the radix
+sort, limits beyond K3's reach, thresholds after a hit-pool overflow, several files, shards."""
+import numpy as np
+import pytest
+
+import bench
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(got_offs, got_hits, i, want):
+    oi, od, osc = want
+    seg = got_hits[int(got_offs[i]):int(got_offs[i + 1])]
+    return (len(seg) == len(od) and np.array_equal(seg["file_no"], oi) and np.array_equal(seg["doc"], od)
+            and np.array_equal(seg["score"], osc))
+
+
+def _c3_small(scale=0.02):
+    cfg = bench.c3_config(scale)
+    return cfg
+
+
+def _open(gpu, cfg, **kw):
+    return gpu.Search.synthetic(cfg["kind"], cfg["signature_sizes"], cfg["num_docs"], page_size=cfg["page_size"],
+                                term_size=cfg["term_size"], canonicalize=cfg["canonicalize"],
+                                num_hashes=cfg["num_hashes"], seed=cfg["seed"], **kw)
+
+
+def _oracle_index(O, cfg):
+    return O.Index.synthetic(1, cfg["term_size"], cfg["canonicalize"], cfg["num_hashes"], cfg["page_size"],
+                             cfg["signature_sizes"], cfg["num_docs"], cfg["seed"])
+
+
+def test_default_call_ranks_100k_documents_on_the_device(gpu_lib, oracle):
+    """BASELINE configs[2]'s document count: 100 000 documents, 1000-k-mer queries (10-bit scores: one pass
+    straight from the score rows), 24 queries per call (two 64 MiB windows) -- every document of every query in the
+    reference's order.  Binomial(1000, 0.3) scores over 100 000 documents: ~60 distinct values, thousands of ties
+    per value, all broken by document id.  Same call with the device ranking off (host threads): identical."""
+    cfg = _c3_small()
+    s = _open(gpu_lib, cfg)
+    ix = _oracle_index(oracle, cfg)
+    queries = bench.make_queries(24, 1000, seed=7) + [bench.make_queries(1, 1, seed=8)[0]]   # + one single-k-mer query
+    offs, hits = s.search_arrays(queries, 0.0, 0)
+    assert int(offs[-1]) == len(queries) * 100000
+    for i, q in enumerate(queries):
+        assert _same(offs, hits, i, oracle.search_arrays(ix, q, 0.0, 0)), i
+    sc = hits[:100000]["score"].astype(np.int64)
+    assert (np.diff(sc) <= 0).all() and len(np.unique(sc)) < 200           # many ties
+    one = hits[int(offs[24]):int(offs[25])]
+    assert np.array_equal(one["doc"], np.arange(100000))                   # single hash: index order, not by score
+    s.set_tuning("device_rank", 0)
+    offs2, hits2 = s.search_arrays(queries, 0.0, 0)
+    assert np.array_equal(offs, offs2) and np.array_equal(hits, hits2)
+
+
+@pytest.mark.parametrize("terms", [12, 40, 255, 1023, 4095, 4096, 70000])
+def test_every_score_width_and_pass_count(gpu_lib, oracle, tmp_path, terms):
+    """4 / 8 / 10 / 12 score planes (one radix pass), 16 / 20 (two passes); 8-, 16- and 32-bit scores; two files with
+    different document counts (one classic with a ragged last byte, one compact), planted documents"""
+    k = 31
+    q = oracle.random_sequence(terms + k - 1, 1000 + terms)
+    pa = cases.make_classic(cases.tmp(tmp_path, "a.cobs_classic"), 1237, 997, 1, k, 1, 0.3, 3,
+                            planted={17: 1.0, 300: 0.5, 1236: 0.5}, query=q[:400 + k - 1])
+    pb = cases.make_compact(cases.tmp(tmp_path, "b.cobs_compact"), 5 * 8 * 24 - 7, 24, [509, 401, 307, 600, 450], 1, k, 1,
+                            0.3, 4, planted={0: 0.5, 900: 1.0}, query=q[:400 + k - 1])
+    ixs = [oracle.Index.open(pa), oracle.Index.open(pb)]
+    s = gpu_lib.Search([pa, pb])
+    queries = [q, q[:len(q) // 2 + k], q[5:], q[:k], q[1:k + 3], q[:k + 1]]
+    offs, hits = s.search_arrays(queries, 0.0, 0)
+    for i, qq in enumerate(queries):
+        assert _same(offs, hits, i, oracle.search_arrays(ixs, qq, 0.0, 0)), (terms, i)
+
+
+def test_three_radix_passes(gpu_lib, oracle, tmp_path):
+    """a query of more than 2^24 terms: 32 score planes, three passes of 11 bits through (score, slot) pairs"""
+    k = 31
+    T = (1 << 24) + 77
+    q = oracle.random_sequence(T + k - 1, 4242)
+    p = cases.make_classic(cases.tmp(tmp_path, "w.cobs_classic"), 203, 1511, 1, k, 1, 0.3, 3)
+    ix = oracle.Index.open(p)
+    s = gpu_lib.Search(p)
+    queries = [q, q[:5000], q[:k], q[100:9000]]
+    offs, hits = s.search_arrays(queries, 0.0, 0)
+    for i, qq in enumerate(queries):
+        assert _same(offs, hits, i, oracle.search_arrays(ix, qq, 0.0, 0)), i
+
+
+def test_limit_beyond_k3_and_thresholds_from_the_rows(gpu_lib, oracle):
+    """num_results = 70 000 of 100 000 documents (more than K3 selects): the first 70 000 of the full ranking;
+    threshold 0.29 over 16 queries selects ~1.1 M documents, more than the hit pool holds: the pass is repeated
+    with score rows and the passing documents are ranked on the device (per-query counts differ)"""
+    cfg = _c3_small()
+    s = _open(gpu_lib, cfg)
+    ix = _oracle_index(oracle, cfg)
+    queries = bench.make_queries(16, 1000, seed=9)
+    offs, hits = s.search_arrays(queries, 0.0, 70000)
+    for i in (0, 7, 15):
+        assert _same(offs, hits, i, oracle.search_arrays(ix, queries[i], 0.0, 70000)), i
+    offs, hits = s.search_arrays(queries, 0.29, 0)
+    assert int(offs[-1]) > (1 << 20)
+    for i in (0, 3, 15):
+        assert _same(offs, hits, i, oracle.search_arrays(ix, queries[i], 0.29, 0)), i
+    # a capacity that is too small is reported with the needed size, then the retry succeeds (search_arrays does that)
+    offs2, hits2 = s.search_arrays(queries[:5], 0.31, 0)
+    for i in range(5):
+        assert _same(offs2, hits2, i, oracle.search_arrays(ix, queries[i], 0.31, 0)), i
+
+
+def test_shards_rank_their_own_documents(gpu_lib, oracle):
+    """a shard (cut inside a sub-index) ranks the documents whose slots it computed: the full ranking filtered"""
+    cfg = _c3_small()
+    ix = _oracle_index(oracle, cfg)
+    queries = bench.make_queries(6, 1000, seed=11)
+    wants = [oracle.search_arrays(ix, q, 0.0, 0) for q in queries]
+    for n, r in ((3, 1), (8, 7), (8, 0)):
+        sh = _open(gpu_lib, cfg, shard_rank=r, shard_count=n)
+        lo, cnt = int(sh.info(0).slot_begin), int(sh.info(0).slot_count)
+        offs, hits = sh.search_arrays(queries, 0.0, 0)
+        for i, (oi, od, osc) in enumerate(wants):
+            keep = (od >= lo) & (od < lo + cnt)
+            assert _same(offs, hits, i, (oi[keep], od[keep], osc[keep])), (n, r, i)
