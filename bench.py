@@ -237,7 +237,7 @@ def kernels_hash():
     """identifies the kernel source a profile belongs to (the GPU box has no .git)"""
     import hashlib
     h = hashlib.sha256()
-    for fn in ("kernels.hip", "engine.cpp"):
+    for fn in ("kernels.hip", "engine.cpp", "rank_kernels.hip", "rank.cpp"):
         with open(os.path.join(ROOT, "cobs_amd", "csrc", fn), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -452,7 +452,8 @@ def workload_text(args, cfg):
             sum(cfg["signature_sizes"]) * cfg["page_size"] / 1e9,
             args.queries, args.kmers, cfg["num_hashes"], args.threshold))
     if args.num_results:
-        t += ", top-%d selected on device" % args.num_results
+        t += ", top-%d selected on device (%s)" % (args.num_results, "from score rows" if args.topk_with_rows
+                                                   else "per tile in the scan, no score rows")
     if args.hits_only:
         t += ", hits only (no score rows)"
     if args.hbm_budget_gb:
@@ -491,6 +492,8 @@ def main():
                          "layout, the default), or replicate the index and split the work (no collective)")
     ap.add_argument("--num-results", type=int, default=0,
                     help="k > 0: the step also selects the k best documents per query on the device (K3)")
+    ap.add_argument("--topk-with-rows", action="store_true",
+                    help="with --num-results: keep the score rows (K3 selects from them) instead of selecting per tile in K2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange-chunks", type=int, default=1,
                     help="N>1: sub-batches; with more than one the exchange of sub-batch i overlaps the scan of i+1")
@@ -596,7 +599,7 @@ def main():
 
         def step():
             if args.num_results > 0:
-                batch.run_topk(args.threshold, args.num_results, 0)
+                batch.run_topk(args.threshold, args.num_results, 0, keep_counts=args.topk_with_rows)
             elif args.hits_only and args.threshold > 0:
                 batch.run_hits(args.threshold, 0)
             else:
@@ -630,7 +633,7 @@ def main():
     traffic, traffic_source = None, None
     key = "%s_q%d_k%d_h%d%s%s" % (args.config, args.queries, args.kmers, args.num_hashes,
                                   "_hits" if args.hits_only and args.threshold > 0 else "",
-                                  "_top%d" % args.num_results if args.num_results else "")
+                                  "_top%d%s" % (args.num_results, "rows" if args.topk_with_rows else "") if args.num_results else "")
     tr_path = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tr_path) and n_gpus == 1 and args.scale == 1.0 and not budget:
         try:

@@ -135,6 +135,7 @@ SYMBOLS = {
     "cobs_gpu_batch_run": (_int, [_vp, _dbl, _vp]),
     "cobs_gpu_batch_run_hits": (_int, [_vp, _dbl, _vp]),
     "cobs_gpu_batch_run_topk": (_int, [_vp, _dbl, _sz, _vp]),
+    "cobs_gpu_batch_run_topk_only": (_int, [_vp, _dbl, _sz, _vp]),
     "cobs_gpu_batch_sync": (_int, [_vp, _vp, C.POINTER(_sz)]),
     "cobs_gpu_batch_counts_device": (_vp, [_vp, C.POINTER(_u32), C.POINTER(_u64)]),
     "cobs_gpu_batch_counts_host": (_int, [_vp, _sz, _vp, _sz]),

@@ -73,6 +73,10 @@ struct ScanArgs {
     uint32_t chunk_end;
     uint32_t idx64;             // 64-bit row indices in the table
     uint32_t lds_staged;        // measured variant: rows travel HBM -> LDS -> VGPR (global_load_lds)
+    // run_topk without score rows: every tile leaves its topk_k best (document, score) candidates at
+    // cand[query * cand_stride + (tile_base + tile) * topk_k ..]; nullptr = the other epilogues
+    uint2* cand;
+    uint32_t topk_k, cand_stride, tile_base;
     // tuning builds (COBS_SCAN_TIMING) only: s_memtime stamps [slot][wave 0..3][8] of every dbg_every-th work-group
     uint64_t* dbg;
     uint32_t dbg_every, dbg_slots;
@@ -96,6 +100,8 @@ struct TopkArgs {
     uint32_t levels;             // ceil(score_bits / level_bits): 1, 2 or 3
     uint32_t score_bytes;        // 1 (planes <= 8), 2 (<= 16) or 4
     uint32_t sort_limit;         // order the survivors on the device when there are at most this many (0 = never)
+    uint32_t from_pool;          // counts = candidate pool of K2 ([nq][counts_stride] (document, score) entries, the first
+                                 // nslots in use; counts_stride a multiple of 8) instead of score rows
 };
 
 // Ranking of all documents of a query on the device (rank_kernels.hip): one index file as the

@@ -168,6 +168,8 @@ constexpr size_t kGraphPoolPrefix = 2048;
 
 // K3 orders up to this many survivors per (query, file) on the device (8-byte keys in 64 KB of LDS)
 constexpr size_t kTopkSortLimit = 8192;
+// largest k for which K2 selects per tile (a tile holds 512 or more documents; the pool is queries x tiles x k entries)
+constexpr size_t kTileTopkMax = 128;
 
 ScanGeom scan_geometry(const Chunk& c, uint64_t mean_blocks, uint64_t max_blocks, uint64_t num_hashes,
                        uint32_t forced_waves, int planes, bool idx64, const Tuning& tune) {
@@ -937,10 +939,12 @@ cobs_gpu_status cobs_gpu_set_tuning(cobs_gpu_index* ix, const char* key, int64_t
         t.lds_staged = value > 0;
     } else if (k == "device_rank") {
         t.device_rank = value != 0;
+    } else if (k == "tile_topk") {
+        t.tile_topk = value != 0;
     } else if (k == "phase_slots") {
         t.phase_slots = value > 0 ? (uint32_t)std::min<int64_t>(value, 1 << 20) : 0;
     } else {
-        return fail(COBS_GPU_ERR_ARG, "unknown tuning key (waves, tile_w, mq, pass_bytes, pipe_chars, graph, lds_staged, device_rank)");
+        return fail(COBS_GPU_ERR_ARG, "unknown tuning key (waves, tile_w, mq, pass_bytes, pipe_chars, graph, lds_staged, device_rank, tile_topk)");
     }
     return COBS_GPU_OK;
 }
@@ -1199,7 +1203,17 @@ static void set_run_state(cobs_gpu_batch* b, double threshold, size_t topk, bool
     b->topk_sorted = use_topk && topk <= kTopkSortLimit;
     // with K3 the threshold is applied there; otherwise K2 selects into the hit pool
     b->selected = threshold > 0.0 && !use_topk;
-    b->have_counts = want_counts || !b->selected;
+    // a top-k pass whose caller does not want the score rows: K2 leaves the k best of every tile and K3 merges
+    // those (no score matrix at all) -- where that epilogue exists, for a k a tile can hold, and unless a query
+    // has a single hash in total (its result is index order, which only the rows give: classic_search.cpp:136,179)
+    b->topk_direct = false;
+    if (use_topk && !want_counts && topk <= kTileTopkMax && !ix->tune.lds_staged && ix->tune.tile_topk != 0) {
+        bool ok = b->nq > 0;
+        for (const Part& p : ix->parts) ok = ok && scan_has_tile_topk((uint32_t)p.meta.num_hashes, p.idx64);
+        for (size_t q = 0; ok && q < b->nq; ++q) ok = total_hashes(b, q) > 1;
+        b->topk_direct = ok;
+    }
+    b->have_counts = want_counts || (!b->selected && !b->topk_direct);
 }
 
 // The per-(file, query) thresholds ceil(threshold * T) (classic_search.cpp:444-449) in the pinned
@@ -1240,6 +1254,29 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
         for (size_t f = 0; f < ix->parts.size(); ++f)
             if (nq) HIP_TRY(hipMemcpyAsync(b->work[f].thr.p, b->h_thr_stage.p + f * nq, 4 * nq, hipMemcpyHostToDevice, st));
     }
+    // scan geometry of every (file, chunk); with tile-level top-k also the files' places in the candidate pool
+    std::vector<std::vector<ScanGeom>> geoms(ix->parts.size());
+    std::vector<uint64_t> cand_off(ix->parts.size() + 1, 0);
+    std::vector<uint32_t> cand_tiles(ix->parts.size(), 0), cand_stride(ix->parts.size(), 0);
+    for (size_t f = 0; f < ix->parts.size() && nq; ++f) {
+        const Part& p = ix->parts[f];
+        for (const Chunk& c : p.chunks) {
+            geoms[f].push_back(scan_geometry(c, b->work[f].h_blk_off[nq] / nq, (b->max_terms + 7) / 8, p.meta.num_hashes,
+                                             ix->waves_per_group, b->planes, p.idx64, ix->tune));
+            cand_tiles[f] += (c.total_chunks + geoms[f].back().tile_w - 1) / geoms[f].back().tile_w;
+        }
+        cand_stride[f] = (uint32_t)round_up((uint64_t)cand_tiles[f] * topk, 8);
+        cand_off[f + 1] = cand_off[f] + (b->topk_direct ? (uint64_t)nq * cand_stride[f] : 0);
+    }
+    if (b->topk_direct) {
+        if (cand_off.back() > (1ull << 31)) {            // 16 GiB of candidates: take the score rows instead
+            b->topk_direct = false;
+            b->have_counts = true;
+            HIP_TRY(b->counts.reserve((size_t)(nq * ix->local_counts * b->elem_bytes)));
+        } else {
+            HIP_TRY(b->cand.reserve((size_t)cand_off.back()));
+        }
+    }
     hipEvent_t* ev = b->ev[b->run_seq % cobs_gpu_batch::kRing];
     HIP_TRY(hipEventRecord(ev[0], st));
     bool hash_marked = false;
@@ -1270,6 +1307,7 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                 hash_marked = true;
             }
         }
+        uint32_t tile_base = 0;
         for (size_t ci = 0; ci < p.chunks.size(); ++ci) {
             const Chunk& c = p.chunks[ci];
             const uint8_t* data = c.d_data;
@@ -1308,10 +1346,15 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
             sa.part = (uint32_t)f;
             sa.write_counts = b->have_counts ? 1 : 0;
             sa.idx64 = p.idx64 ? 1u : 0u;
-            const ScanGeom geom = scan_geometry(c, b->work[f].h_blk_off[nq] / nq, (b->max_terms + 7) / 8,
-                                                 p.meta.num_hashes, ix->waves_per_group, b->planes, p.idx64, ix->tune);
+            const ScanGeom geom = geoms[f][ci];
             const int nwaves = geom.nwaves;
             sa.tile_w = geom.tile_w;
+            sa.cand = b->topk_direct ? b->cand.p + cand_off[f] : nullptr;
+            sa.topk_k = b->topk_direct ? (uint32_t)topk : 0u;
+            sa.cand_stride = cand_stride[f];
+            sa.tile_base = tile_base;
+            // K2 filters by threshold only when it selects: into the hit pool, or the tile's k best
+            if (b->topk_direct) sa.thresholds = need_thr ? b->work[f].thr.p : nullptr;
             sa.dbg = nullptr;
             sa.dbg_every = 1;
             sa.dbg_slots = 0;
@@ -1336,6 +1379,7 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                 sa.dbg_every = (uint32_t)std::max<uint64_t>(1, groups / sa.dbg_slots);
             }
             HIP_TRY(launch_scan(sa, ntiles, b->planes, nwaves, geom.multi_query, st));
+            tile_base += ntiles;
             ++launches;
             if (p.streamed) {
                 HIP_TRY(hipEventRecord(sbufs.scanned[buf], st));
@@ -1352,6 +1396,7 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
             ta.counts = b->counts.p;
             ta.score_bytes = b->elem_bytes;
             ta.thresholds = need_thr ? b->work[f].thr.p : nullptr;
+            ta.from_pool = 0;
             ta.out = b->topk_out.p + (uint64_t)f * nq * topk;
             ta.out_count = b->topk_cnt.p + f * nq;
             ta.counts_stride = ix->local_counts;
@@ -1365,6 +1410,14 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
             ta.levels = ((uint32_t)b->planes + 11u) / 12u;                       // radix levels of <= 12 bits
             ta.level_bits = ((uint32_t)b->planes + ta.levels - 1u) / ta.levels;
             ta.sort_limit = topk <= kTopkSortLimit ? (uint32_t)topk : 0u;        // survivors ordered on the device
+            if (b->topk_direct) {           // merge the tiles' candidates (threshold already applied by K2)
+                ta.from_pool = 1;
+                ta.counts = b->cand.p + cand_off[f];
+                ta.counts_stride = cand_stride[f];
+                ta.counts_offset = 0;
+                ta.nslots = cand_tiles[f] * (uint32_t)topk;
+                ta.thresholds = nullptr;
+            }
             HIP_TRY(launch_topk(ta, st));
         }
     }
@@ -1391,6 +1444,12 @@ cobs_gpu_status cobs_gpu_batch_run_hits(cobs_gpu_batch* b, double threshold, voi
 cobs_gpu_status cobs_gpu_batch_run_topk(cobs_gpu_batch* b, double threshold, size_t num_results,
                                         void* hip_stream) {
     return guarded([&]() { return run_impl(b, threshold, num_results, hip_stream); });
+}
+
+cobs_gpu_status cobs_gpu_batch_run_topk_only(cobs_gpu_batch* b, double threshold, size_t num_results,
+                                             void* hip_stream) {
+    if (num_results == 0) return fail(COBS_GPU_ERR_ARG, "a top-k pass needs num_results > 0");
+    return guarded([&]() { return run_impl(b, threshold, num_results, hip_stream, false); });
 }
 
 cobs_gpu_status cobs_gpu_batch_sync(cobs_gpu_batch* b, void* hip_stream, size_t* bad_query) {
@@ -1775,7 +1834,8 @@ static cobs_gpu_status host_pass_begin(cobs_gpu_index* ix, int slot, const char*
     if (after) HIP_TRY(hipStreamWaitEvent(b->own_stream, after, 0));
     // with a threshold and no limit only the selected hits travel back: skip the score rows,
     // unless the hit pool overflows (then the pass is repeated with them and ranked on the host)
-    const bool hits_only = threshold > 0.0 && topk == 0;
+    // ... and with a limit K2 / K3 select on the device (tile-level top-k where it applies): no score rows either
+    const bool hits_only = (threshold > 0.0 && topk == 0) || topk > 0;
     // Small calls (a single query is the reference's own entry point, search.hpp:39-42) are
     // launch-bound: fill + K1 + K2 (+ K3) are four launches for ~15 us of work.  The second time
     // the same shape comes along (same query lengths, parameters and buffers) the pass is captured
@@ -1793,11 +1853,12 @@ static cobs_gpu_status host_pass_begin(cobs_gpu_index* ix, int slot, const char*
             std::memcpy(&tb, &threshold, 8);
             mixin(tb); mixin(topk); mixin(hits_only);
             mixin((uint64_t)(uintptr_t)b->text.p); mixin((uint64_t)(uintptr_t)b->counts.p); mixin((uint64_t)(uintptr_t)b->hits.p);
-            mixin((uint64_t)(uintptr_t)b->topk_out.p); mixin((uint64_t)(uintptr_t)b->topk_cnt.p);
+            mixin((uint64_t)(uintptr_t)b->topk_out.p); mixin((uint64_t)(uintptr_t)b->topk_cnt.p); mixin((uint64_t)(uintptr_t)b->cand.p);
             for (auto& w : b->work) { mixin((uint64_t)(uintptr_t)w.table.p); mixin((uint64_t)(uintptr_t)w.thr.p); }
             mixin((uint64_t)(uintptr_t)b->h_res.p); mixin((uint64_t)(uintptr_t)b->h_rows.p);      // the graph writes there
             mixin((uint64_t)(uintptr_t)b->h_text.p); mixin((uint64_t)(uintptr_t)b->h_thr_stage.p);
             mixin(ix->tune.waves); mixin(ix->tune.tile_w); mixin((uint64_t)(int64_t)ix->tune.mq); mixin(ix->tune.lds_staged);
+            mixin((uint64_t)ix->tune.tile_topk);      // decides which buffers the pass needs (a capture must not allocate)
             return key;
         };
         const uint64_t key = make_key();

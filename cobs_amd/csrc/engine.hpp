@@ -98,6 +98,7 @@ struct Tuning {
     bool no_pin = false;        // COBS_GPU_NO_PIN: never hipHostRegister the mapped file
     int graph = -1;             // COBS_GPU_GRAPH: captured-graph path for small batches off / on
     bool lds_staged = false;    // COBS_GPU_LDS_STAGED: the LDS-staged scan variant (A/B measurements only)
+    int tile_topk = 1;          // top-k passes without score rows select per tile in K2 (0: score rows + K3, A/B)
     int device_rank = 1;        // whole score rows are ranked on the device (0: by host threads, A/B and fallback)
     bool trace = false;         // COBS_GPU_TRACE: where the host side of a search call spends its time, on stderr
     uint32_t phase_slots = 0;   // tuning builds (make timing): work-groups of a scan launch that record phase stamps
@@ -226,6 +227,8 @@ struct cobs_gpu_batch {
     uint32_t topk_k = 0;              // k of the last run (0 = K3 not run)
     bool topk_fetched = false;
     bool topk_sorted = false;         // K3 ordered the survivors of every (query, file) on the device
+    bool topk_direct = false;         // K2 left every tile's k best in `cand`, K3 merged those: no score rows
+    cobs_amd::DevBuf<uint2> cand;     // candidate pool [file][query][tiles x k (padded to 8)] of (document, score)
     // device flags: word 0 = first invalid query (2^32-1 - q, 0 = none), words 2..3 = 64-bit fill
     // of the hit pool (may exceed hit_cap: overflow)
     cobs_amd::DevBuf<uint32_t> flags;

@@ -546,12 +546,116 @@ __device__ __forceinline__ void planes_to_bytes32(const uint32_t (&P)[NP], uint3
 // 128 bytes of scores + 16 of padding, so that the 16-byte writes of 16 lanes hit 16 different banks
 constexpr uint32_t kStageStride = 144u;
 
+// Exact top-k of ONE tile, straight from the bit-sliced counters (run_topk without score rows): the k best
+// documents of a tile under (score desc, document asc) are a superset of the tile's share of the query's k
+// best (counts_to_result's partial_sort, classic_search.cpp:134-145), so K3 only has to merge tiles x k
+// candidates instead of reading a score row per query twice.  Radix descent over the planes, highest first,
+// on the candidate masks M (128 documents per lane): c = documents of M with the plane's bit set, summed over
+// the tile with a butterfly; c >= k_rem -> the k_rem best all have the bit: M &= plane; else those c
+// documents are in for sure (R |= ...), k_rem -= c, M &= ~plane.  What is left in M ties at the cut score:
+// the first k_rem in document order (lane = chunk order, then word, then bit) join R.  All in registers of
+// wave 0, NP rounds of ~12 VALU + log2(W) cross-lane adds; the LUT expansion and the score stores are not run.
+template <int NP, bool MQ>
+__device__ __forceinline__ void tile_topk(const ScanArgs& a, const uint32_t (&pl)[4][NP], uint32_t lane, uint32_t W,
+                                          uint32_t tile, uint32_t qi, const uint32_t* tmeta, const uint32_t* tthr) {
+    const uint32_t G = 64u / W;
+    const uint32_t col = lane & (W - 1u), grp = lane / W;
+    const uint32_t qraw = MQ ? qi * G + grp : qi;
+    const bool live = (MQ || lane < W) && qraw < a.nq;            // lanes that hold the final planes of a real query
+    const uint32_t q = qraw < a.nq ? qraw : a.nq - 1u;
+    const uint32_t doc0 = tmeta[col * 3 + 2];
+    uint32_t nvalid = live ? tmeta[col * 3 + 1] * 8u : 0u;         // row bytes inside the page ...
+    nvalid = min(nvalid, a.num_docs > doc0 ? a.num_docs - doc0 : 0u);   // ... that belong to real documents
+    const uint32_t thr = a.thresholds ? tthr[MQ ? grp : 0u] : 0u;
+    uint32_t M[4], R[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint32_t nw_ = nvalid > 32u * w ? min(nvalid - 32u * w, 32u) : 0u;
+        uint32_t v = nw_ >= 32u ? 0xFFFFFFFFu : (1u << nw_) - 1u;
+        if (a.thresholds) {      // count >= threshold on the planes (as the hits-only epilogue does)
+            uint32_t ge = (NP < 32 && (thr >> (NP < 32 ? NP : 0)) != 0u) ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) ge = ((thr >> k) & 1u) ? (ge & pl[w][k]) : (ge | pl[w][k]);
+            v &= ge;
+        }
+        M[w] = v;
+        R[w] = 0u;
+    }
+    uint32_t krem = a.topk_k;
+#pragma unroll
+    for (int p = NP - 1; p >= 0; --p) {
+        uint32_t A[4], c = 0u;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { A[w] = M[w] & pl[w][p]; c += (uint32_t)__popc(A[w]); }
+        for (uint32_t off = 1; off < W; off <<= 1) c += (uint32_t)__shfl_xor(c, off);
+        const bool take = c >= krem;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            R[w] |= take ? 0u : A[w];
+            M[w] = take ? A[w] : (M[w] & ~pl[w][p]);
+        }
+        krem -= take ? 0u : c;
+    }
+    auto group_excl = [&](uint32_t v, uint32_t* total) {
+        uint32_t incl = v;
+        for (uint32_t off = 1; off < W; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off);
+            if (col >= off) incl += t;
+        }
+        *total = __shfl(incl, lane | (W - 1u));
+        return incl - v;
+    };
+    {   // ties at the cut score: the first krem of M in document order
+        uint32_t cm = 0u, tot;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) cm += (uint32_t)__popc(M[w]);
+        uint32_t before = group_excl(cm, &tot);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t pc = (uint32_t)__popc(M[w]);
+            const uint32_t allow = krem > before ? krem - before : 0u;
+            uint32_t x = M[w];
+            if (allow < pc) {
+                uint32_t y = x;
+                for (uint32_t i = 0; i < allow; ++i) y &= y - 1u;          // y = x without its lowest `allow` bits
+                x &= ~y;
+            }
+            R[w] |= x;
+            before += pc;
+        }
+    }
+    uint32_t cs = 0u, total;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) cs += (uint32_t)__popc(R[w]);
+    uint32_t pos = group_excl(cs, &total);
+    uint2* dst = a.cand + (uint64_t)q * a.cand_stride + (uint64_t)(a.tile_base + tile) * a.topk_k;
+    if (live) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            uint32_t x = R[w];
+            while (x != 0u) {
+                const uint32_t d = (uint32_t)__ffs((int)x) - 1u;
+                x &= x - 1u;
+                uint32_t score = 0u;
+#pragma unroll
+                for (int k = 0; k < NP; ++k) score |= ((pl[w][k] >> d) & 1u) << k;
+                dst[pos++] = make_uint2(doc0 + 32u * w + d, score);
+            }
+        }
+        // entries the tile does not fill are marked (K3 skips them); the pool needs no clearing between runs
+        for (uint32_t i = total + col; i < a.topk_k; i += W) dst[i] = make_uint2(0xFFFFFFFFu, 0u);
+    }
+}
+
 // MQ ("multi-query", short queries): the G = 64 / W lane groups of a wave belong to G
 // DIFFERENT queries (q = qi*G + grp) instead of splitting one query's blocks.  Every lane
 // group then walks all blocks of its own query (divided over the NW waves only): G times
 // more trips per wave, so the load pipeline reaches its steady state even for 100-bp reads,
 // and the cross-lane merge disappears.
-template <int NP, int NW, bool H1, typename OutT, bool MQ, typename IdxT, bool LDSS = false>
+// TK: the epilogue is tile_topk (run_topk without score rows) instead of the score / hit epilogues -- its own
+// instantiations, so that the kernels that write scores keep their register budget (as a run-time branch
+// it cost the 100-bp multi-query kernel its fourth wave per SIMD: 126 -> 131 VGPRs).
+template <int NP, int NW, bool H1, typename OutT, bool MQ, typename IdxT, bool LDSS = false, bool TK = false>
 __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     // row loads stay temporal: non-temporal loads measured 18 % slower (they bypass the Infinity Cache)
     constexpr bool NT = false;
@@ -571,7 +675,7 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
     // LDS instead of chasing a.pages[] / a.thresholds[] through global memory per iteration
     uint32_t* tmeta = reinterpret_cast<uint32_t*>(smem + kFront + kLut);   // [64][3]
     uint32_t* tthr = tmeta + 64 * 3;                                 // [64]
-    if constexpr (sizeof(OutT) != 1) {
+    if constexpr (sizeof(OutT) != 1 && !TK) {
         for (uint32_t v = threadIdx.x; v < 256u; v += NW * 64) {
             uint4 e;
             e.x = (v & 1u) | ((v & 2u) << 15);
@@ -833,6 +937,12 @@ __global__ __launch_bounds__(NW * 64) void scan_kernel(ScanArgs a) {
             }
         }
         __syncthreads();
+    }
+    if constexpr (TK) {
+        // run_topk without score rows: wave 0 holds the final planes and selects the tile's k best from them
+        __syncthreads();                 // tile metadata / thresholds written at the start are read below (NW = 1: no barrier so far)
+        if (wave == 0u) tile_topk<NP, MQ>(a, pl, lane, W, tile, qi, tmeta, tthr);
+        return;
     }
     if constexpr (sizeof(OutT) == 1) {
         // ---- 8-bit scores with the score rows wanted: wave 0 holds the final planes; its lanes
@@ -1139,7 +1249,35 @@ __device__ __forceinline__ void load_scores8(const ST* row, uint32_t i, uint32_t
 
 // Dynamic LDS: hist[4 waves][NB] (NB = 2^level_bits <= 4096; reused by every level and, after
 // the emission, as the sort buffer: 8192 eight-byte keys) | partial[256] | sh[16]
-template <typename ST>
+// POOL: the input is not a score row but the candidate pool of run_topk without score rows (K2's tile_topk):
+// nslots (document, score) entries per query in ascending document order, unused ones marked with
+// document 0xFFFFFFFF; the same selection and ordering over tiles x k candidates.
+template <typename ST, bool POOL>
+__device__ __forceinline__ void load_elems8(const void* rowp, uint32_t i, uint32_t w1, uint32_t doc_base, uint32_t thr,
+                                            uint32_t (&s)[8], uint32_t (&d)[8], uint32_t& okmask) {
+    okmask = 0u;
+    if constexpr (POOL) {
+        const uint4* e = reinterpret_cast<const uint4*>(reinterpret_cast<const uint2*>(rowp) + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint4 v = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);
+            if (i + 2 * j < w1) v = e[j];            // two entries per load; the row is padded to 8 entries, i is a multiple of 8
+            d[2 * j] = v.x; s[2 * j] = v.y; d[2 * j + 1] = v.z; s[2 * j + 1] = v.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (i + j < w1 && d[j] != 0xFFFFFFFFu && s[j] >= thr) okmask |= 1u << j;
+    } else {
+        load_scores8<ST>(reinterpret_cast<const ST*>(rowp), i, s);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            d[j] = doc_base + i + j;
+            if (i + j < w1 && s[j] >= thr) okmask |= 1u << j;
+        }
+    }
+}
+
+template <typename ST, bool POOL = false>
 __global__ __launch_bounds__(256) void topk_kernel(TopkArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t NB = 1u << a.level_bits;
@@ -1149,11 +1287,14 @@ __global__ __launch_bounds__(256) void topk_kernel(TopkArgs a) {
     const uint32_t q = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const ST* row = reinterpret_cast<const ST*>(a.counts) + (uint64_t)q * a.counts_stride + a.counts_offset;
+    const void* row = POOL ? (const void*)(reinterpret_cast<const uint2*>(a.counts) + (uint64_t)q * a.counts_stride)
+                           : (const void*)(reinterpret_cast<const ST*>(a.counts) + (uint64_t)q * a.counts_stride + a.counts_offset);
     const uint32_t thr = a.thresholds ? a.thresholds[q] : 0u;
-    uint32_t n = a.nslots;                       // real documents among the local slots
-    if (a.doc_base >= a.num_docs) n = 0;
-    else if (a.num_docs - a.doc_base < n) n = a.num_docs - a.doc_base;
+    uint32_t n = a.nslots;                       // real documents among the local slots (POOL: pool entries)
+    if constexpr (!POOL) {
+        if (a.doc_base >= a.num_docs) n = 0;
+        else if (a.num_docs - a.doc_base < n) n = a.num_docs - a.doc_base;
+    }
     const uint32_t k = a.k;
     // wave w owns the contiguous document range [w0, w1); 512 documents per iteration
     const uint32_t per = ((n + 3u) / 4u + 511u) / 512u * 512u;
@@ -1173,14 +1314,14 @@ __global__ __launch_bounds__(256) void topk_kernel(TopkArgs a) {
         for (uint32_t i0 = w0; i0 < w1; i0 += 512) {
             const uint32_t i = i0 + lane * 8u;
             if (i < w1) {
-                uint32_t sc[8];
-                load_scores8<ST>(row, i, sc);
+                uint32_t sc[8], dc[8], ok;
+                load_elems8<ST, POOL>(row, i, w1, a.doc_base, thr, sc, dc, ok);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const uint32_t s = sc[j];
                     // the bits above this level must equal the prefix found so far
                     const bool in = level == 0 || (bits_left >= 32u ? true : (s >> bits_left) == prefix);
-                    if (i + j < w1 && s >= thr && in) atomicAdd(&myh[(s >> shift) & mask], 1u);
+                    if ((ok >> j & 1u) && in) atomicAdd(&myh[(s >> shift) & mask], 1u);
                 }
             }
         }
@@ -1242,14 +1383,15 @@ __global__ __launch_bounds__(256) void topk_kernel(TopkArgs a) {
     uint2* out = a.out + (uint64_t)q * k;
     for (uint32_t i0 = w0; i0 < w1; i0 += 512) {
         const uint32_t i = i0 + lane * 8u;
-        uint32_t s8[8];
+        uint32_t s8[8], d8[8];
         uint32_t gt = 0, eq = 0;
         if (i < w1) {
-            load_scores8<ST>(row, i, s8);
+            uint32_t ok;
+            load_elems8<ST, POOL>(row, i, w1, a.doc_base, thr, s8, d8, ok);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const uint32_t s = s8[j];
-                const bool pass = i + j < w1 && s >= thr;
+                const bool pass = (ok >> j & 1u) != 0u;
                 if (pass && (take_all || s > cut)) gt |= 1u << j;
                 if (pass && !take_all && s == cut) eq |= 1u << j;
             }
@@ -1263,7 +1405,7 @@ __global__ __launch_bounds__(256) void topk_kernel(TopkArgs a) {
             uint32_t pos = base + excl;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (gt & (1u << j)) out[pos++] = make_uint2(a.doc_base + i + j, s8[j]);
+                if (gt & (1u << j)) out[pos++] = make_uint2(d8[j], s8[j]);
         }
         if (__any(eq != 0u)) {
             uint32_t total;
@@ -1272,7 +1414,7 @@ __global__ __launch_bounds__(256) void topk_kernel(TopkArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 if (eq & (1u << j)) {
-                    if (r < need_eq) out[n_above + r] = make_uint2(a.doc_base + i + j, s8[j]);
+                    if (r < need_eq) out[n_above + r] = make_uint2(d8[j], s8[j]);
                     ++r;
                 }
             eq_base += total;
@@ -1634,7 +1776,7 @@ hipError_t launch_hash(const HashArgs& a, uint64_t total_threads, hipStream_t st
     return hipGetLastError();
 }
 
-template <int NP, int NW, bool H1, typename OutT, bool MQ = false, typename IdxT = uint32_t, bool LDSS = false>
+template <int NP, int NW, bool H1, typename OutT, bool MQ = false, typename IdxT = uint32_t, bool LDSS = false, bool TK = false>
 static hipError_t launch_scan_inst(const ScanArgs& a, uint32_t ntiles, hipStream_t stream) {
     (void)ntiles;
     const uint32_t per_group = MQ ? 64u / a.tile_w : 1u;
@@ -1644,7 +1786,7 @@ static hipError_t launch_scan_inst(const ScanArgs& a, uint32_t ntiles, hipStream
     if (groups > 0x7FFFFFFFull) return hipErrorInvalidValue;
     constexpr size_t front = scan_lds_front<NP, NW, sizeof(OutT), LDSS>();
     constexpr size_t lds = front + (sizeof(OutT) == 1 ? 0 : 256 * sizeof(uint4)) + 64 * 4 * sizeof(uint32_t);
-    auto kern = scan_kernel<NP, NW, H1, OutT, MQ, IdxT, LDSS>;
+    auto kern = scan_kernel<NP, NW, H1, OutT, MQ, IdxT, LDSS, TK>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1657,6 +1799,11 @@ static hipError_t launch_scan_inst(const ScanArgs& a, uint32_t ntiles, hipStream
 // multi-query variant: H = 1, u16 scores (short queries)
 template <int NP, typename OutT>
 static hipError_t launch_scan_mq(const ScanArgs& a, uint32_t ntiles, int nw, hipStream_t stream) {
+    if (a.cand) {           // run_topk without score rows
+        if (nw == 1) return launch_scan_inst<NP, 1, true, OutT, true, uint32_t, false, true>(a, ntiles, stream);
+        if (nw == 2) return launch_scan_inst<NP, 2, true, OutT, true, uint32_t, false, true>(a, ntiles, stream);
+        return launch_scan_inst<NP, 4, true, OutT, true, uint32_t, false, true>(a, ntiles, stream);
+    }
     if (nw == 1) return launch_scan_inst<NP, 1, true, OutT, true>(a, ntiles, stream);
     if (nw == 2) return launch_scan_inst<NP, 2, true, OutT, true>(a, ntiles, stream);
     return launch_scan_inst<NP, 4, true, OutT, true>(a, ntiles, stream);
@@ -1664,6 +1811,12 @@ static hipError_t launch_scan_mq(const ScanArgs& a, uint32_t ntiles, int nw, hip
 
 template <int NP, typename OutT>
 static hipError_t launch_scan_np(const ScanArgs& a, uint32_t ntiles, bool h1, int nw, hipStream_t stream) {
+    if (a.cand) {           // run_topk without score rows: H = 1, 32-bit row indices (scan_has_tile_topk)
+        if (!h1 || a.idx64) return hipErrorInvalidValue;
+        if (nw == 1) return launch_scan_inst<NP, 1, true, OutT, false, uint32_t, false, true>(a, ntiles, stream);
+        if (nw == 2) return launch_scan_inst<NP, 2, true, OutT, false, uint32_t, false, true>(a, ntiles, stream);
+        return launch_scan_inst<NP, 4, true, OutT, false, uint32_t, false, true>(a, ntiles, stream);
+    }
     if (a.idx64) {
         // sub-indexes with >= 2^32 rows: 64-bit row indices; two waves per group cover every
         // query length well enough for this rare geometry (keeps the instantiation count down)
@@ -1693,6 +1846,8 @@ bool scan_has_multi_query(int planes, uint32_t num_hashes, uint32_t tile_w) {
     return num_hashes == 1 && tile_w < 64 && (planes == 4 || planes == 8 || planes == 10 || planes == 12);
 }
 
+bool scan_has_tile_topk(uint32_t num_hashes, bool idx64) { return num_hashes == 1 && !idx64; }
+
 bool scan_has_lds_staged(int planes, uint32_t num_hashes, int nw) {
     return num_hashes == 1 && planes == 10 && (nw == 2 || nw == 4);
 }
@@ -1700,6 +1855,7 @@ bool scan_has_lds_staged(int planes, uint32_t num_hashes, int nw) {
 hipError_t launch_scan(const ScanArgs& a, uint32_t ntiles, int planes, int nw, bool multi_query,
                        hipStream_t stream) {
     const bool h1 = a.num_hashes == 1;
+    if (a.cand && (a.lds_staged || a.topk_k == 0 || !scan_has_tile_topk(a.num_hashes, a.idx64 != 0))) return hipErrorInvalidValue;
     if (a.lds_staged) {     // measured variant (A/B): rows through LDS
         if (multi_query || a.idx64 || !scan_has_lds_staged(planes, a.num_hashes, nw)) return hipErrorInvalidValue;
         return nw == 2 ? launch_scan_inst<10, 2, true, uint16_t, false, uint32_t, true>(a, ntiles, stream)
@@ -1738,8 +1894,10 @@ hipError_t launch_topk(const TopkArgs& a, hipStream_t stream) {
     uint32_t m = 2;
     while (m < a.sort_limit) m <<= 1;
     if (a.sort_limit) lds = std::max(lds, (size_t)m * 8);
-    auto kern = a.score_bytes == 1 ? topk_kernel<uint8_t> : a.score_bytes == 2 ? topk_kernel<uint16_t> : topk_kernel<uint32_t>;
+    auto kern = a.from_pool ? topk_kernel<uint32_t, true>
+              : a.score_bytes == 1 ? topk_kernel<uint8_t> : a.score_bytes == 2 ? topk_kernel<uint16_t> : topk_kernel<uint32_t>;
     if (a.score_bytes != 1 && a.score_bytes != 2 && a.score_bytes != 4) return hipErrorInvalidValue;
+    if (a.from_pool && ((a.counts_stride & 7u) != 0u || a.counts_stride < a.nslots)) return hipErrorInvalidValue;   // 64-byte rows
     if (lds > 64 * 1024 + 2048) return hipErrorInvalidValue;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

@@ -376,9 +376,11 @@ class Batch:
         """hot path without score rows: only the documents reaching the threshold are recorded"""
         check(self._lib.cobs_gpu_batch_run_hits(self._h, float(threshold), C.c_void_p(stream)))
 
-    def run_topk(self, threshold=0.0, num_results=10, stream=0):
-        """hot path + on-device selection of the num_results best documents per query"""
-        check(self._lib.cobs_gpu_batch_run_topk(self._h, float(threshold), int(num_results), C.c_void_p(stream)))
+    def run_topk(self, threshold=0.0, num_results=10, stream=0, keep_counts=True):
+        """hot path + on-device selection of the num_results best documents per query;
+        keep_counts=False: no score rows (K2 selects per tile, K3 merges the candidates)"""
+        fn = self._lib.cobs_gpu_batch_run_topk if keep_counts else self._lib.cobs_gpu_batch_run_topk_only
+        check(fn(self._h, float(threshold), int(num_results), C.c_void_p(stream)))
 
     def sync(self, stream=0):
         bad = C.c_size_t(0)

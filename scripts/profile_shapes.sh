@@ -6,7 +6,7 @@
 # another trace domain.  Raw output: gpurun_out/prof_TAG/<shape>/ (scratch);
 # scripts/collect_shapes.py TAG copies the summaries into profiles/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 shift || true
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
@@ -23,6 +23,8 @@ declare -A SHAPES=(
   [c3hits]="--threshold 0.8 --hits-only"
   [reads100hits]="--queries 40000 --kmers 70 --threshold 0.8 --hits-only"
   [c3top10]="--num-results 10"
+  [c3top10rows]="--num-results 10 --topk-with-rows"
+  [reads100top10]="--queries 40000 --kmers 70 --num-results 10"
 )
 FULL="c3 reads50"
 WANT=${*:-c3 c2 c4 c3h3 reads50 reads100 reads150 c3hits reads100hits c3top10}
