@@ -82,6 +82,22 @@ struct ScanArgs {
     uint32_t dbg_every, dbg_slots;
 };
 
+// Row-selective access to a chunk that is not resident (fetch_kernels.hip): fetch the rows K1's table names
+// from the registered file mapping into a gathered buffer shaped like a resident chunk.
+struct FetchArgs {
+    const uint8_t* file;         // device-visible address of the mapped index file
+    const void* table;           // K1's row indices (u32, or u64 when idx64)
+    void* table2;                // same layout: the rows' numbers inside the gathered buffer (written here)
+    const uint64_t* blk_off;     // nq + 1
+    const PageDev* pages;        // the chunk's pages as resident data would hold them
+    PageDev* pages2;             // ... as the gathered buffer holds them (written here)
+    const uint64_t* page_src;    // [npages] file offset of (row 0, first held column) of every slice
+    uint8_t* dst;                // gathered rows: [npages][entries] rows of `pitch` bytes, then one zero row
+    uint64_t entries;            // table entries per sub-index: (blk_off[nq] + nq) * 8 * num_hashes
+    uint64_t src_pitch;          // bytes between rows in the file
+    uint32_t nq, npages, table_npages, num_hashes, pitch, ncols;
+};
+
 // Arguments of the top-k selection kernel K3 for one index file.
 struct TopkArgs {
     const void* counts;          // [nq][counts_stride] scores of score_bytes (1 or 2) bytes

@@ -76,6 +76,8 @@ Part::~Part() {
     for (Chunk& c : chunks) {
         if (c.d_data) (void)hipFree(c.d_data);
         if (c.d_pages) (void)hipFree(c.d_pages);
+        if (c.d_src) (void)hipFree(c.d_src);
+        for (auto* p2 : c.d_pages2) if (p2) (void)hipFree(p2);
     }
     if (d_tpages) (void)hipFree(d_tpages);
     if (file_pinned && file) (void)hipHostUnregister(const_cast<uint8_t*>(file->data()));
@@ -84,6 +86,7 @@ Part::~Part() {
 StreamBufs::~StreamBufs() {
     for (auto& e : copied) if (e) (void)hipEventDestroy(e);
     for (auto& e : scanned) if (e) (void)hipEventDestroy(e);
+    if (hashed) (void)hipEventDestroy(hashed);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
 }
 
@@ -763,6 +766,24 @@ static cobs_gpu_status stage_index(cobs_gpu_index* ix, std::vector<std::unique_p
                 if (pe == hipSuccess) pt.file_pinned = true;
                 else (void)hipGetLastError();
             }
+            if (pt.file_pinned) {
+                // the device-visible address of the mapping and, per chunk, where its slices start in the
+                // file: the row-selective pass (fetch_kernels.hip) reads looked-up rows straight from it
+                void* dp = nullptr;
+                if (hipHostGetDevicePointer(&dp, const_cast<uint8_t*>(pt.file->data()), 0) == hipSuccess && dp) {
+                    pt.file_dev = static_cast<const uint8_t*>(dp);
+                    for (Chunk& c : pt.chunks) {
+                        std::vector<uint64_t> src(c.vp.size());
+                        for (size_t k = 0; k < c.vp.size(); ++k) src[k] = pt.meta.page_offset(c.vp[k].fp) + c.vp[k].col0;
+                        HIP_TRY(hipMalloc((void**)&c.d_src, 8 * src.size()));
+                        HIP_TRY(hipMemcpy(c.d_src, src.data(), 8 * src.size(), hipMemcpyHostToDevice));
+                        for (auto& p2 : c.d_pages2) HIP_TRY(hipMalloc((void**)&p2, sizeof(PageDev) * c.vp.size()));
+                    }
+                    if (!ix->stream.hashed) HIP_TRY(hipEventCreateWithFlags(&ix->stream.hashed, hipEventDisableTiming));
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
         } else {
             st = upload_resident(pt, files[i]->data());
             if (st != COBS_GPU_OK) return st;
@@ -941,10 +962,14 @@ cobs_gpu_status cobs_gpu_set_tuning(cobs_gpu_index* ix, const char* key, int64_t
         t.device_rank = value != 0;
     } else if (k == "tile_topk") {
         t.tile_topk = value != 0;
+    } else if (k == "row_fetch") {
+        t.row_fetch = value != 0;
+    } else if (k == "row_fetch_alpha") {
+        t.row_fetch_alpha = value >= 0 ? (uint32_t)std::min<int64_t>(value, 1 << 20) : 2;   // 0: whenever the rows fit
     } else if (k == "phase_slots") {
         t.phase_slots = value > 0 ? (uint32_t)std::min<int64_t>(value, 1 << 20) : 0;
     } else {
-        return fail(COBS_GPU_ERR_ARG, "unknown tuning key (waves, tile_w, mq, pass_bytes, pipe_chars, graph, lds_staged, device_rank, tile_topk)");
+        return fail(COBS_GPU_ERR_ARG, "unknown tuning key (waves, tile_w, mq, pass_bytes, pipe_chars, graph, lds_staged, device_rank, tile_topk, row_fetch, row_fetch_alpha)");
     }
     return COBS_GPU_OK;
 }
@@ -1308,25 +1333,78 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
             }
         }
         uint32_t tile_base = 0;
+        bool fetch_ready = false;
+        if (p.streamed && p.file_dev && ix->tune.row_fetch != 0) {
+            // a row-selective chunk gets its own row-index table (one per stream buffer); sized before the
+            // chunk loop, when no scan of this handle is reading the old ones any more
+            const size_t need = (size_t)b->work[f].table_entries * 4;
+            for (int i = 0; i < 2; ++i) {
+                if (sbufs.table2[i].cap >= need) continue;
+                if (sbufs.used[i]) HIP_TRY(hipEventSynchronize(sbufs.scanned[i]));
+                HIP_TRY(sbufs.table2[i].reserve(need));
+            }
+        }
         for (size_t ci = 0; ci < p.chunks.size(); ++ci) {
             const Chunk& c = p.chunks[ci];
             const uint8_t* data = c.d_data;
             int buf = 0;
+            const PageDev* pages_dev = c.d_pages;
+            const void* table_dev = b->work[f].table.p;
             if (p.streamed) {
                 // double buffer shared by all streamed files: the next chunk goes to the buffer
                 // whose last scan is done
                 buf = (int)(sbufs.seq++ & 1);
                 if (sbufs.used[buf]) HIP_TRY(hipEventSynchronize(sbufs.scanned[buf]));
-                cobs_gpu_status cs = stream_chunk_in(ix, p, c, buf);
-                if (cs != COBS_GPU_OK) return cs;
+                // Whole chunk, or only the rows this batch looks up?  The table holds E entries per sub-index;
+                // fetching them row by row moves E x (slices) x pitch bytes over PCIe at the rate random rows
+                // come in, copying the chunk moves all of its rows at the slab rate (row_fetch_alpha prices
+                // the difference).  The reference's mmap / AIO back-ends always take the first form
+                // (compact_index/mmap_search_file.cpp:34-67, aio_search_file.cpp:58-97).
+                const uint64_t E = (b->work[f].h_blk_off[nq] + nq) * 8ull * p.meta.num_hashes;
+                const uint64_t gathered = (E * c.vp.size() + 1) * (uint64_t)c.pitch;
+                const bool fetch = ix->tune.row_fetch != 0 && p.file_dev && c.d_src && !p.synthetic &&
+                                   gathered <= sbufs.sbuf[buf].cap && E * c.vp.size() < 0xFFFFFFF0ull &&
+                                   (gathered - c.pitch) * ix->tune.row_fetch_alpha <= c.bytes;
+                if (fetch) {
+                    if (!fetch_ready) {          // the fetch kernel reads K1's table: once per file and pass
+                        HIP_TRY(hipEventRecord(sbufs.hashed, st));
+                        HIP_TRY(hipStreamWaitEvent(sbufs.copy_stream, sbufs.hashed, 0));
+                        fetch_ready = true;
+                    }
+                    FetchArgs fa;
+                    fa.file = p.file_dev;
+                    fa.table = b->work[f].table.p;
+                    fa.table2 = sbufs.table2[buf].p;
+                    fa.blk_off = b->work[f].blk_off;
+                    fa.pages = c.d_pages;
+                    fa.pages2 = c.d_pages2[buf];
+                    fa.page_src = c.d_src;
+                    fa.dst = sbufs.sbuf[buf].p;
+                    fa.entries = E;
+                    fa.src_pitch = p.meta.page_row_bytes();
+                    fa.nq = (uint32_t)nq;
+                    fa.npages = (uint32_t)c.vp.size();
+                    fa.table_npages = p.num_tpages();
+                    fa.num_hashes = (uint32_t)p.meta.num_hashes;
+                    fa.pitch = c.pitch;
+                    fa.ncols = (uint32_t)c.vp[0].ncols;
+                    HIP_TRY(launch_fetch_rows(fa, p.idx64, sbufs.copy_stream));
+                    pages_dev = c.d_pages2[buf];
+                    table_dev = sbufs.table2[buf].p;
+                    ++sbufs.fetched_chunks;
+                } else {
+                    cobs_gpu_status cs = stream_chunk_in(ix, p, c, buf);
+                    if (cs != COBS_GPU_OK) return cs;
+                    ++sbufs.streamed_chunks;
+                }
                 HIP_TRY(hipEventRecord(sbufs.copied[buf], sbufs.copy_stream));
                 HIP_TRY(hipStreamWaitEvent(st, sbufs.copied[buf], 0));
                 data = sbufs.sbuf[buf].p;
             }
             ScanArgs sa;
             sa.blob = data;
-            sa.pages = c.d_pages;
-            sa.table = b->work[f].table.p;
+            sa.pages = pages_dev;
+            sa.table = table_dev;
             sa.blk_off = b->work[f].blk_off;
             sa.counts = b->counts.p;
             sa.thresholds = b->selected ? b->work[f].thr.p : nullptr;
@@ -2187,6 +2265,13 @@ cobs_gpu_status cobs_gpu_counts(cobs_gpu_index* ix, const char* query, size_t le
 }
 
 uint64_t cobs_gpu_graph_replays(const cobs_gpu_index* ix) { return ix ? ix->graph_replays : 0; }
+
+cobs_gpu_status cobs_gpu_stream_counters(const cobs_gpu_index* ix, uint64_t out[2]) {
+    if (!ix || !out) return fail(COBS_GPU_ERR_ARG, "NULL argument");
+    out[0] = ix->stream.fetched_chunks;
+    out[1] = ix->stream.streamed_chunks;
+    return COBS_GPU_OK;
+}
 
 cobs_gpu_status cobs_gpu_timers(cobs_gpu_index* ix, double out[5], int reset) {
     if (!ix) return fail(COBS_GPU_ERR_ARG, "NULL index");

@@ -98,6 +98,8 @@ struct Tuning {
     bool no_pin = false;        // COBS_GPU_NO_PIN: never hipHostRegister the mapped file
     int graph = -1;             // COBS_GPU_GRAPH: captured-graph path for small batches off / on
     bool lds_staged = false;    // COBS_GPU_LDS_STAGED: the LDS-staged scan variant (A/B measurements only)
+    int row_fetch = 1;          // streamed chunks are fetched row by row when a batch looks up few of their rows (0: always whole)
+    uint32_t row_fetch_alpha = 2;   // ... i.e. when alpha x (looked-up bytes) <= the chunk's bytes (PCIe serves random rows slower than slabs)
     int tile_topk = 1;          // top-k passes without score rows select per tile in K2 (0: score rows + K3, A/B)
     int device_rank = 1;        // whole score rows are ranked on the device (0: by host threads, A/B and fallback)
     bool trace = false;         // COBS_GPU_TRACE: where the host side of a search call spends its time, on stderr
@@ -125,6 +127,9 @@ struct Chunk {
     size_t bytes = 0;                // device bytes incl. zero rows
     size_t stage_bytes = 0;          // packed host bytes (rows x ncols)
     uint8_t* d_data = nullptr;       // resident chunk only
+    // streamed chunk of a file whose mapping is registered: what the row-selective pass needs on the device
+    uint64_t* d_src = nullptr;       // [vp.size()] file offset of (row 0, first held column) of every slice
+    PageDev* d_pages2[2] = {nullptr, nullptr};   // the pages as a gathered buffer holds them (written per pass), per stream buffer
 };
 
 // One index file as held by this device (possibly only a shard of it).
@@ -142,6 +147,7 @@ struct Part {
     // streaming (BASELINE config 5: index larger than the HBM budget)
     std::unique_ptr<MappedFile> file;        // source of the chunks
     bool file_pinned = false;                // the mapping is registered with HIP: DMA straight from it
+    const uint8_t* file_dev = nullptr;       // ... and this is its device-visible address (kernels read it over PCIe)
     bool synthetic = false;
     bool built = false;                      // rows are produced in place by index construction
     uint64_t synth_seed = 0;
@@ -167,6 +173,11 @@ struct StreamBufs {
     hipEvent_t copied[2] = {nullptr, nullptr}, scanned[2] = {nullptr, nullptr};
     bool used[2] = {false, false};
     uint64_t cap = 0;             // bytes per buffer
+    // row-selective passes: the row-index table of the gathered rows in buffer i, and the event after K1
+    // (the fetch kernel on the copy stream reads K1's table)
+    DevBuf<uint8_t> table2[2];
+    hipEvent_t hashed = nullptr;
+    uint64_t fetched_chunks = 0, streamed_chunks = 0;   // diagnostics: how the chunks of all passes were brought in
     size_t stage_need = 0;
     uint64_t seq = 0;             // chunks streamed so far: chunk goes to buffer seq % 2
     ~StreamBufs();

@@ -1,0 +1,109 @@
+// cobs_amd/csrc/fetch_kernels.hip -- row-selective access to an index that is NOT resident in HBM.
+//
+// The reference's out-of-core back-ends touch only the rows a query addresses: the mmap back-end maps the file
+// with MADV_RANDOM and copies the T*H addressed rows (cobs/util/query.cpp:43-55,
+// compact_index/mmap_search_file.cpp:34-67), the AIO back-end issues one pread per (sub-index, hash)
+// (aio_search_file.cpp:58-97).  Streaming a whole sub-index through HBM is the right thing only when a batch
+// looks up more bytes than the sub-index holds; for a single query it moves gigabytes to touch megabytes.
+//
+//   fetch_rows_kernel   for one streamed chunk (a group of equal-width sub-index slices): reads the row
+//                       indices K1 wrote, fetches exactly those rows from the index file -- whose mapping is
+//                       registered with HIP, so the loads go over PCIe straight from the page cache, 16
+//                       bytes per lane, a row's pieces on consecutive lanes (1 KiB per wave-load) -- into a
+//                       gathered buffer in HBM laid out like a resident chunk (same pitch, one shared zero
+//                       row), and writes the row-index table of that buffer (entry e -> gathered row e; padding
+//                       entries -> the zero row) plus the PageDev array describing it.  K2 then scans the
+//                       gathered buffer with the code it runs on resident data.
+//
+// A row looked up twice is fetched twice: the engine chooses this path only when the batch's lookups are a
+// fraction of the sub-index's rows (engine.cpp: run_impl), where repeats are rare.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "device_types.hpp"
+#include "kernels.hpp"
+
+namespace cobs_amd {
+
+namespace {
+
+// 16 bytes from an arbitrarily aligned address, reading only aligned dwords that hold wanted bytes
+__device__ __forceinline__ uint4 load16_any(const uint8_t* p, uint32_t nvalid) {
+    const uint32_t mis = (uint32_t)((uintptr_t)p & 3u);
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(p - mis);
+    if (mis == 0u && nvalid == 16u && ((uintptr_t)p & 15u) == 0u) return *reinterpret_cast<const uint4*>(p);
+    uint32_t r[5];
+#pragma unroll
+    for (uint32_t j = 0; j < 5; ++j) r[j] = (4u * j < mis + nvalid) ? w[j] : 0u;
+    uint32_t o[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j)
+        o[j] = mis == 0u ? r[j] : (uint32_t)(((uint64_t)r[j] | ((uint64_t)r[j + 1] << 32)) >> (8u * mis));
+    // bytes at and beyond nvalid read as zero (pitch padding of the resident layout)
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+        const uint32_t have = nvalid > 4u * j ? nvalid - 4u * j : 0u;
+        if (have < 4u) o[j] &= have == 0u ? 0u : (1u << (8u * have)) - 1u;
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+template <typename IdxT>
+__global__ __launch_bounds__(256) void fetch_rows_kernel(FetchArgs a) {
+    const uint32_t cpp = a.pitch / 16u;
+    const uint64_t E = a.entries;
+    const uint64_t rows = (uint64_t)a.npages * E;
+    const uint64_t gid = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint64_t rowno = gid / cpp;                      // page-major gathered row
+    const uint32_t c = (uint32_t)(gid - rowno * cpp);
+    if (rowno > rows) return;
+    uint8_t* out = a.dst + rowno * a.pitch + (uint64_t)c * 16u;
+    if (rowno == rows) {                                   // the zero row every padding entry points at
+        *reinterpret_cast<uint4*>(out) = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
+    const uint32_t i = (uint32_t)(rowno / E);              // page of the chunk
+    const uint64_t n = rowno - (uint64_t)i * E;            // entry of that page: [query][block + padding block][hash][8]
+    const PageDev pd = a.pages[i];
+    if (n == 0u && c == 0u) {                              // the page as the gathered buffer holds it
+        PageDev g = pd;
+        g.base = (uint64_t)i * E * a.pitch;
+        g.sig = E;
+        a.pages2[i] = g;
+    }
+    const uint64_t per = 8ull * a.num_hashes;
+    // query of entry n: the last q with (blk_off[q] + q) * per <= n
+    uint32_t lo = 0, hi = a.nq;
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((a.blk_off[mid] + mid) * per <= n) lo = mid; else hi = mid;
+    }
+    const uint64_t b0 = a.blk_off[lo];
+    const uint64_t nblk1 = a.blk_off[lo + 1] - b0 + 1u;   // blocks of the query incl. its padding block
+    const uint64_t within = n - (b0 + lo) * per;
+    const uint64_t e = ((b0 + lo) * a.table_npages + (uint64_t)pd.tpage * nblk1) * per + within;
+    const uint64_t r = reinterpret_cast<const IdxT*>(a.table)[e];
+    const bool pad = r >= pd.sig;                          // K1 points padded terms at row S_p
+    if (c == 0u)
+        reinterpret_cast<IdxT*>(a.table2)[e] = (IdxT)(pad ? (uint64_t)(a.npages - i) * E : n);
+    if (pad) return;                                       // never read: its table entry names the zero row
+    const uint32_t nvalid = a.ncols > c * 16u ? min(a.ncols - c * 16u, 16u) : 0u;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (nvalid) v = load16_any(a.file + a.page_src[i] + r * a.src_pitch + (uint64_t)c * 16u, nvalid);
+    *reinterpret_cast<uint4*>(out) = v;
+}
+
+}  // namespace
+
+hipError_t launch_fetch_rows(const FetchArgs& a, bool idx64, hipStream_t stream) {
+    if (a.npages == 0 || a.nq == 0 || a.entries == 0) return hipSuccess;
+    const uint64_t items = ((uint64_t)a.npages * a.entries + 1u) * (a.pitch / 16u);
+    const uint64_t blocks = (items + 255u) / 256u;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if (idx64) hipLaunchKernelGGL(fetch_rows_kernel<uint64_t>, dim3((uint32_t)blocks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(fetch_rows_kernel<uint32_t>, dim3((uint32_t)blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace cobs_amd

@@ -32,6 +32,9 @@ hipError_t launch_topk(const TopkArgs& a, hipStream_t stream);
 // Ranking of every document (rank_kernels.hip): one pass of the stable radix sort by score; a.nq work-groups.
 hipError_t launch_rank(const RankArgs& a, bool first, bool last, hipStream_t stream);
 
+// Row-selective out-of-core access (fetch_kernels.hip): one thread per (looked-up row, 16-byte piece).
+hipError_t launch_fetch_rows(const FetchArgs& a, bool idx64, hipStream_t stream);
+
 // Index construction: one thread per text position hashes its term and sets the bits.
 hipError_t launch_build(const BuildArgs& a, uint64_t total_bytes, hipStream_t stream);
 hipError_t launch_pack_bytemap(const PackArgs& a, hipStream_t stream);

@@ -281,6 +281,12 @@ class Search:
         """small host-API passes served by a captured hipGraph so far"""
         return int(self._lib.cobs_gpu_graph_replays(self._h))
 
+    def stream_counters(self):
+        """out-of-core handles: (chunks fetched row by row, chunks copied whole) over all passes so far"""
+        c = (C.c_uint64 * 2)()
+        check(self._lib.cobs_gpu_stream_counters(self._h, C.byref(c)))
+        return int(c[0]), int(c[1])
+
     def timers(self, reset=False):
         t = (C.c_double * 5)()
         check(self._lib.cobs_gpu_timers(self._h, C.byref(t), 1 if reset else 0))

@@ -130,7 +130,9 @@ void cobs_gpu_close(cobs_gpu_index* ix);
 /* Per-handle tuning hooks of the scan launch (the COBS_GPU_* environment variables are read once,
  * by cobs_gpu_open*; this changes them afterwards).  key: "waves" (0, 1, 2, 4), "tile_w" (0, 4..64),
  * "mq" (-1 auto, 0, 1), "pass_bytes", "pipe_chars", "graph" (-1 auto, 0, 1), "lds_staged" (0, 1: the
- * measured LDS-staged variant of the scan, headline shape only).  0 / -1 = automatic. */
+ * measured LDS-staged variant of the scan, headline shape only), "device_rank" / "tile_topk" / "row_fetch" (0 turns the
+ * on-device ranking of whole rows / the tile-level top-k / the row-selective out-of-core pass off: A/B and fallback),
+ * "row_fetch_alpha".  0 / -1 = automatic. */
 cobs_gpu_status cobs_gpu_set_tuning(cobs_gpu_index* ix, const char* key, int64_t value);
 /* Host only (no device needed): the score slots [slot_begin[r], slot_begin[r] + slot_count[r]) and
  * the index bytes shard r of shard_count would hold of the file at `path` (arrays of shard_count
@@ -465,6 +467,14 @@ cobs_gpu_status cobs_gpu_batch_phase_stamps(cobs_gpu_batch* b, uint64_t* out, si
  * the same shape (query lengths, parameters) comes along and replayed with one launch afterwards;
  * this counts the replays (diagnostics; tuning key "graph" = 0 turns the path off). */
 uint64_t cobs_gpu_graph_replays(const cobs_gpu_index* ix);
+
+/* Out-of-core handles (hbm_budget_bytes): how the chunks of all passes so far were brought into HBM.
+ * out[0] = chunks whose looked-up rows were fetched one by one from the registered file mapping (a batch that
+ * touches a fraction of the chunk's rows: the access pattern of the reference's mmap / AIO back-ends,
+ * compact_index/mmap_search_file.cpp:34-67, aio_search_file.cpp:58-97), out[1] = chunks copied whole.
+ * Tuning keys "row_fetch" (0 = always whole) and "row_fetch_alpha" (fetch when alpha x looked-up bytes <= the
+ * chunk's bytes; default 2, 0 = whenever the rows fit a stream buffer) steer the choice. */
+cobs_gpu_status cobs_gpu_stream_counters(const cobs_gpu_index* ix, uint64_t out[2]);
 
 /* ---- multi-GPU, one process: a device list behind ONE handle -----------------------------------
  * cobs_gpu_multi_open shards the index over devices[0..n_devices) (opts: hbm_budget_bytes and

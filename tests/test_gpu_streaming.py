@@ -153,3 +153,72 @@ def test_budget_is_shared_by_all_files_of_a_handle(gpu_lib, oracle, tmp_path):
         s.read_row(0, 0, 0, 64)                 # file 0 is streamed: its rows are not resident
     with pytest.raises(gpu_lib.CobsGpuError):
         s.read_row(1, 0, 0, 8)
+
+
+def test_row_selective_pass_equals_whole_streaming(gpu_lib, oracle, tmp_path):
+    """A batch that looks up few rows of a streamed chunk fetches exactly those rows from the registered file mapping
+    (fetch_kernels.hip; the access pattern of the reference's mmap / AIO back-ends, compact_index/
+    mmap_search_file.cpp:34-67) instead of copying the chunk.  Compact (16-byte aligned rows), classic (500-byte rows
+    at an odd file offset: unaligned loads), two hashes, column-sliced chunks; forced on, forced off and by the
+    engine's own cost rule -- counts and rankings identical to the oracle's every time."""
+    ps, D = 96, 5 * 8 * 96 - 11
+    q_long = oracle.random_sequence(700, 31)
+    pc = cases.make_compact(cases.tmp(tmp_path, "rf.cobs_compact"), D, ps, [700, 1500, 5000, 900, 2600], 2, 31, 1, 0.3, 6,
+                            planted={0: 1.0, D - 1: 0.95, 1000: 0.6, 2500: 0.85}, query=q_long)
+    pk = cases.make_classic(cases.tmp(tmp_path, "rf.cobs_classic"), 4003, 3001, 1, 31, 1, 0.3, 7,
+                            planted={5: 1.0, 4002: 0.9}, query=q_long)
+    for path, budget in ((pc, 400 * 1024), (pk, 600 * 1024), (pc, 200 * 1024)):
+        ix = oracle.Index.open(path)
+        queries = [q_long, q_long[:31], q_long[:300], q_long[100:180]]
+        want_counts = [ix.counts(q) for q in queries]
+        for mode in ("fetch", "whole", "auto"):
+            s = gpu_lib.Search(path, hbm_budget=budget)
+            if mode == "fetch":
+                s.set_tuning("row_fetch_alpha", 0)           # whenever the looked-up rows fit a stream buffer
+            elif mode == "whole":
+                s.set_tuning("row_fetch", 0)
+            for nq in (1, 4):
+                b = gpu_lib.Batch(s)
+                b.set_queries(queries[:nq])
+                b.run(0.0)
+                b.sync()
+                for i in range(nq):
+                    assert np.array_equal(b.counts_host(i), want_counts[i]), (path, mode, nq, i)
+            for t, lim in ((0.0, 0), (0.4, 3), (0.9, 0)):
+                got = s.search_hits(queries, t, lim)
+                assert got == [cases.oracle_results([ix], q, t, lim) for q in queries], (path, mode, t, lim)
+            fetched, whole = s.stream_counters()
+            if mode == "fetch":
+                assert fetched > 0, (path, budget)
+            if mode == "whole":
+                assert fetched == 0 and whole > 0
+
+
+def test_one_query_against_a_large_streamed_file_touches_only_its_rows(gpu_lib, oracle, tmp_path):
+    """BASELINE configs[4] in small: the C3 geometry at 1/8 scale as a 2.3 GB file under a 700 MB budget.  A single
+    1000-k-mer query looks up 8 000 of its 1.46 M rows: every chunk is fetched row by row (12.5 MB over PCIe instead
+    of 2.3 GB), bit-exact; a 4 000-query batch looks up more than the small sub-indexes hold and streams those whole."""
+    import bench
+    import cobs_amd
+    cfg = bench.c3_config(0.125)
+    path = str(tmp_path / "c5_eighth.cobs_compact")
+    cobs_amd.write_synthetic(path, "compact", cfg["signature_sizes"], cfg["num_docs"], page_size=cfg["page_size"], seed=1)
+    s = gpu_lib.Search(path, hbm_budget=700 * 1000 * 1000)
+    ix = oracle.Index.synthetic(1, 31, 1, 1, cfg["page_size"], cfg["signature_sizes"], cfg["num_docs"], 1)
+    queries = bench.make_queries(4000, 1000)
+    b = gpu_lib.Batch(s)
+    b.set_queries(queries[:1])
+    b.run(0.0)
+    b.sync()
+    f1, w1 = s.stream_counters()
+    assert f1 >= 1 and w1 == 0
+    assert np.array_equal(b.counts_host(0), ix.counts(queries[0]))
+    b.set_queries(queries)
+    b.run(0.0)
+    b.sync()
+    f2, w2 = s.stream_counters()
+    assert w2 > 0                                   # 4 000 x 1 008 lookups per sub-index: the small ones travel whole
+    for i in (0, 1999, 3999):
+        assert np.array_equal(b.counts_host(i), ix.counts(queries[i])), i
+    got = s.search_hits(queries[:3], 0.0, 5)
+    assert got == [[(f, d, sc) for (f, d, _n, sc) in oracle.search(ix, q, 0.0, 5)] for q in queries[:3]]
