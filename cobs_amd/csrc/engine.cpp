@@ -965,7 +965,7 @@ cobs_gpu_status cobs_gpu_set_tuning(cobs_gpu_index* ix, const char* key, int64_t
     } else if (k == "row_fetch") {
         t.row_fetch = value != 0;
     } else if (k == "row_fetch_alpha") {
-        t.row_fetch_alpha = value >= 0 ? (uint32_t)std::min<int64_t>(value, 1 << 20) : 2;   // 0: whenever the rows fit
+        t.row_fetch_alpha = value >= 0 ? (uint32_t)std::min<int64_t>(value, 1 << 20) : 1;   // 0: whenever the rows fit
     } else if (k == "phase_slots") {
         t.phase_slots = value > 0 ? (uint32_t)std::min<int64_t>(value, 1 << 20) : 0;
     } else {

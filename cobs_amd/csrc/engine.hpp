@@ -99,7 +99,8 @@ struct Tuning {
     int graph = -1;             // COBS_GPU_GRAPH: captured-graph path for small batches off / on
     bool lds_staged = false;    // COBS_GPU_LDS_STAGED: the LDS-staged scan variant (A/B measurements only)
     int row_fetch = 1;          // streamed chunks are fetched row by row when a batch looks up few of their rows (0: always whole)
-    uint32_t row_fetch_alpha = 2;   // ... i.e. when alpha x (looked-up bytes) <= the chunk's bytes (PCIe serves random rows slower than slabs)
+    uint32_t row_fetch_alpha = 1;   // ... i.e. when alpha x (looked-up bytes) <= the chunk's bytes.  Measured on MI355X: rows of 1568 bytes
+                                    // fetched by the kernel cross PCIe at 50.8 GB/s, whole chunks at 52.3 GB/s (profiles/r03_c5_selective.txt): 1
     int tile_topk = 1;          // top-k passes without score rows select per tile in K2 (0: score rows + K3, A/B)
     int device_rank = 1;        // whole score rows are ranked on the device (0: by host threads, A/B and fallback)
     bool trace = false;         // COBS_GPU_TRACE: where the host side of a search call spends its time, on stderr

@@ -473,7 +473,7 @@ uint64_t cobs_gpu_graph_replays(const cobs_gpu_index* ix);
  * touches a fraction of the chunk's rows: the access pattern of the reference's mmap / AIO back-ends,
  * compact_index/mmap_search_file.cpp:34-67, aio_search_file.cpp:58-97), out[1] = chunks copied whole.
  * Tuning keys "row_fetch" (0 = always whole) and "row_fetch_alpha" (fetch when alpha x looked-up bytes <= the
- * chunk's bytes; default 2, 0 = whenever the rows fit a stream buffer) steer the choice. */
+ * chunk's bytes; default 1, 0 = whenever the rows fit a stream buffer) steer the choice. */
 cobs_gpu_status cobs_gpu_stream_counters(const cobs_gpu_index* ix, uint64_t out[2]);
 
 /* ---- multi-GPU, one process: a device list behind ONE handle -----------------------------------
