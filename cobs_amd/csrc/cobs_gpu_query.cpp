@@ -21,6 +21,7 @@
 #include <string>
 #include <vector>
 
+#include "../../include/cobs_gpu_construct.h"
 #include "../../include/cobs_gpu_search.hpp"
 
 static void usage() {
@@ -31,7 +32,7 @@ static void usage() {
                  "        one scan per GPU + one RCCL exchange (same results as on one GPU)\n"
                  "       (--load-complete and -T/--threads of `cobs query` are accepted and ignored: the index\n"
                  "        always lives in HBM, or is streamed through it under --hbm-budget)\n"
-                 "       cobs_gpu_query doc-list | doc-dump | classic-construct | compact-construct | classic-combine ...\n"
+                 "       cobs_gpu_query classic-construct | compact-construct | classic-combine | compact-construct-combine ...\n"
                  "        (the construction sub-tools of `cobs`, same arguments; see cobs_gpu_tools.cpp)\n"
                  "       cobs_gpu_query --benchmark -i INDEX [-k KMERS] [-q QUERIES] [-w WARMUP] [--seed S]\n"
                  "       cobs_gpu_query --write-synthetic OUT (--classic -n DOCS -s ROWS | --compact -n DOCS -p PAGE_SIZE\n"
@@ -75,7 +76,7 @@ static int benchmark(cobs_gpu::BatchSearch& s, const std::string& index, unsigne
     return 0;
 }
 
-int cobs_gpu_tools_main(int argc, char** argv);      // cobs_gpu_tools.cpp: doc-list, doc-dump, *-construct, classic-combine
+int cobs_gpu_tools_main(int argc, char** argv);      // cobs_gpu_tools.cpp: *-construct, classic-combine, compact-construct-combine
 
 int main(int argc, char** argv) {
     {

@@ -1,14 +1,10 @@
 // cobs_amd/csrc/cobs_gpu_tools.cpp -- the construction-side sub-tools of the reference's `cobs`
 // program on top of libcobs_gpu.so, with their flags and output (reference src/cobs.cpp):
 //
-//   cobs_gpu_query doc-list PATH [--file-type T] [-k K]                           (:75-99)
-//   cobs_gpu_query doc-dump PATH [--file-type T] [-k K] [--no-canonicalize]       (:101-158)
 //   cobs_gpu_query classic-construct INPUT OUT.cobs_classic [flags]               (:163-244)
 //   cobs_gpu_query compact-construct INPUT OUT.cobs_compact [flags] [-p PAGE]     (:294-380)
 //   cobs_gpu_query classic-combine IN_DIR OUT.cobs_classic                        (:1044-1060)
 //   cobs_gpu_query compact-construct-combine IN_DIR OUT.cobs_compact [-p PAGE]   (:383-408)
-//   cobs_gpu_query print-parameters [-h H] [-f FPR] [-n N]                        (:532-568)
-//   cobs_gpu_query print-kmers QUERY [-k K]                                       (:570-600)
 //
 // Flags of the two constructors: --file-type, -h/--num-hashes, -f/--false-positive-rate,
 // -k/--term-size, --no-canonicalize, -C/--clobber, --continue; -m/--memory, -T/--threads,
@@ -31,50 +27,6 @@ namespace {
 int fail() {
     std::fprintf(stderr, "EXCEPTION: %s\n", cobs_gpu_last_error());
     return 1;
-}
-
-// print_document_list, src/cobs.cpp:41-73
-void print_document_list(const cobs_gpu::DocumentList& filelist, unsigned k, std::ostream& os) {
-    const size_t n = filelist.size();
-    uint64_t min_kmers = ~0ull, max_kmers = 0, total = 0;
-    os << "--- document list (" << n << " entries) ---" << std::endl;
-    for (size_t i = 0; i < n; ++i) {
-        const cobs_gpu::DocumentEntry e = filelist[i];
-        const uint64_t terms = e.num_terms(k);
-        std::error_code ec;
-        const uint64_t fsize = (uint64_t)std::filesystem::file_size(e.path_, ec);
-        os << "document[" << i << "] size " << (ec ? (uint64_t)e.size_ : fsize) << " " << k << "-mers " << terms << " : "
-           << e.path_ << " : " << e.name_ << std::endl;
-        min_kmers = std::min(min_kmers, terms);
-        max_kmers = std::max(max_kmers, terms);
-        total += terms;
-    }
-    os << "--- end of document list (" << n << " entries) ---" << std::endl;
-    os << "documents: " << n << std::endl;
-    if (n != 0) {
-        os << "minimum " << k << "-mers: " << min_kmers << std::endl;
-        os << "maximum " << k << "-mers: " << max_kmers << std::endl;
-        os << "average " << k << "-mers: " << (uint64_t)((double)total / (double)n) << std::endl;
-        os << "total " << k << "-mers: " << total << std::endl;
-    }
-}
-
-// canonicalize_kmer (cobs/util/query.cpp:143-199) for the dump's output: the k-mer or its reverse
-// complement, decided by the first position (of the first half) where they differ; false for a
-// character outside ACGT
-bool canonical(const char* in, char* out, size_t k) {
-    auto comp = [](char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : '\0'; };
-    bool good = true;
-    for (size_t i = 0; i < k; ++i) good &= comp(in[i]) != '\0';
-    if (!good) return false;
-    bool reverse = false;
-    for (size_t i = 0; i < k / 2; ++i) {
-        const char f = in[i], r = comp(in[k - 1 - i]);
-        if (f < r) break;
-        if (f > r) { reverse = true; break; }
-    }
-    for (size_t i = 0; i < k; ++i) out[i] = reverse ? comp(in[k - 1 - i]) : in[i];
-    return true;
 }
 
 struct Args {
@@ -130,7 +82,7 @@ int construct(int argc, char** argv, bool compact) {
     // the C++17 mirror of the reference's construction API (include/cobs_gpu_construct.hpp),
     // statement for statement what src/cobs.cpp:235-241 / :373-377 do
     cobs_gpu::DocumentList filelist(a.positional[0], cobs_gpu::StringToFileType(a.file_type));
-    print_document_list(filelist, a.p.term_size, std::cout);
+    std::cout << "documents: " << filelist.size() << std::endl;
     if (compact) {
         cobs_gpu::CompactIndexParameters p;
         p.term_size = a.p.term_size; p.canonicalize = (uint8_t)a.p.canonicalize; p.num_hashes = a.p.num_hashes;
@@ -167,83 +119,6 @@ static int tools(int argc, char** argv) {
     const std::string tool = argv[1];
     if (tool == "classic-construct") return construct(argc - 2, argv + 2, false);
     if (tool == "compact-construct") return construct(argc - 2, argv + 2, true);
-    if (tool == "doc-list" || tool == "doc-dump") {
-        Args a;
-        if (!a.parse(argc - 2, argv + 2, false) || a.positional.size() != 1) {
-            std::fprintf(stderr, "usage: cobs_gpu_query %s PATH [--file-type T] [-k K]%s\n", tool.c_str(),
-                         tool == "doc-dump" ? " [--no-canonicalize]" : "");
-            return 1;
-        }
-        cobs_gpu::DocumentList filelist(a.positional[0], cobs_gpu::StringToFileType(a.file_type));
-        const unsigned k = a.p.term_size;
-        if (tool == "doc-list") {
-            print_document_list(filelist, k, std::cout);
-            return 0;
-        }
-        const size_t n = filelist.size();
-        std::cerr << "Found " << n << " documents." << std::endl;
-        std::vector<char> canon(k);
-        for (size_t i = 0; i < n; ++i) {
-            const cobs_gpu::DocumentEntry e = filelist[i];
-            std::cerr << "document[" << i << "] : " << e.path_ << " : " << e.name_ << std::endl;
-            e.process_terms(k, [&](const char* term) {
-                if (a.no_canonicalize) std::cout.write(term, k) << '\n';
-                else if (canonical(term, canon.data(), k)) std::cout.write(canon.data(), k) << '\n';
-                else (std::cout << "Invalid DNA base pair: ").write(term, k) << std::endl;
-            });
-            std::cout.flush();
-            std::cerr << "document[" << i << "] : " << e.num_terms(k) << " terms." << std::endl;
-        }
-        return 0;
-    }
-    if (tool == "print-parameters") {
-        // `cobs print-parameters` (src/cobs.cpp:532-568): the signature size a Bloom filter needs
-        unsigned num_hashes = 1;
-        double fpr = 0.3;
-        uint64_t num_elements = 0;
-        for (int i = 2; i < argc; ++i) {
-            const std::string a = argv[i];
-            if ((a == "-h" || a == "--num-hashes") && i + 1 < argc) num_hashes = (unsigned)std::strtoul(argv[++i], nullptr, 10);
-            else if ((a == "-f" || a == "--false-positive-rate") && i + 1 < argc) fpr = std::atof(argv[++i]);
-            else if ((a == "-n" || a == "--num-elements") && i + 1 < argc) num_elements = std::strtoull(argv[++i], nullptr, 10);
-            else { std::fprintf(stderr, "usage: cobs_gpu_query print-parameters [-h HASHES] [-f FPR] [-n NUM_ELEMENTS]\n"); return 1; }
-        }
-        if (num_hashes == 0 || !(fpr > 0.0 && fpr < 1.0)) { std::fprintf(stderr, "bad parameters\n"); return 1; }
-        // calc_signature_size_ratio / calc_signature_size, cobs/util/calc_signature_size.cpp:17-33
-        const double ratio = -(double)num_hashes / std::log(1.0 - std::pow(fpr, 1.0 / (double)num_hashes));
-        if (num_elements == 0) {
-            std::cout << ratio << '\n';
-        } else {
-            const uint64_t sig = (uint64_t)std::ceil((double)num_elements * ratio);
-            double b = (double)(sig / 8);
-            static const char* unit[] = {"", "Ki", "Mi", "Gi", "Ti", "Pi", "Ei"};
-            int u = 0;
-            while (b >= 1024.0 && u < 6) { b /= 1024.0; ++u; }
-            char iec[64];
-            std::snprintf(iec, sizeof iec, "%.3f %s", b, unit[u]);              // tlx::format_iec_units
-            std::cout << "signature_size = " << sig << '\n';
-            std::cout << "signature_bytes = " << sig / 8 << " = " << iec << '\n';
-        }
-        return 0;
-    }
-    if (tool == "print-kmers") {
-        // `cobs print-kmers QUERY [-k K]` (src/cobs.cpp:570-600): the canonical k-mers of a sequence
-        // (the reference's loop bound `i < size - k` leaves out the last one; so does this)
-        std::string query;
-        unsigned k = 31;
-        for (int i = 2; i < argc; ++i) {
-            const std::string a = argv[i];
-            if ((a == "-k" || a == "--kmer-size") && i + 1 < argc) k = (unsigned)std::strtoul(argv[++i], nullptr, 10);
-            else query = a;
-        }
-        if (query.empty() || k == 0) { std::fprintf(stderr, "usage: cobs_gpu_query print-kmers QUERY [-k K]\n"); return 1; }
-        std::vector<char> canon(k);
-        for (size_t i = 0; i + k < query.size(); ++i) {
-            if (canonical(query.data() + i, canon.data(), k)) std::cout.write(canon.data(), k) << '\n';
-            else (std::cout << "Invalid DNA base pair: ").write(query.data() + i, k) << std::endl;
-        }
-        return 0;
-    }
     if (tool == "classic-combine" || tool == "compact-construct-combine") {
         // `cobs classic-combine IN_DIR OUT_FILE`: the .cobs_classic files of a directory, in path order
         std::vector<std::string> pos;

@@ -11,7 +11,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/cobs_gpu.h"
+#include "../../include/cobs_gpu_construct.h"
 
 namespace cobs_amd {
 

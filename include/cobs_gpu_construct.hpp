@@ -26,7 +26,7 @@
 #include <sys/stat.h>
 #include <vector>
 
-#include "cobs_gpu.h"
+#include "cobs_gpu_construct.h"
 #include "cobs_gpu_search.hpp"
 
 namespace cobs_gpu {

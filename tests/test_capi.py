@@ -10,10 +10,13 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "cobs_gpu.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(cobs_gpu_[a-z0-9_]+)\s*\(", text)))
+def _declared_symbols(headers=("cobs_gpu.h", "cobs_gpu_construct.h")):
+    names = set()
+    for h in headers:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(cobs_gpu_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():
@@ -26,6 +29,10 @@ def test_library_exports_every_declared_symbol():
         assert n in _capi.SYMBOLS, "cobs_amd/_capi.py does not bind " + n
     assert sorted(_capi.SYMBOLS) == names
     assert lib.cobs_gpu_abi_version() == 2
+    # the query path's header stands alone: construction and document lists live in cobs_gpu_construct.h
+    query_only = _declared_symbols(("cobs_gpu.h",))
+    assert not [n for n in query_only if "doclist" in n or "_build_" in n or "combine" in n or "construct" in n]
+    assert len(query_only) < len(names)
 
 
 def test_struct_layouts_match_header():
@@ -136,6 +143,11 @@ def test_header_is_plain_c_and_cpp(tmp_path):
                  'return (int)o.struct_size == 0; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc,
                            "-fsyntax-only", str(c)])
+    c2 = tmp_path / "t2.c"
+    c2.write_text('#include "cobs_gpu_construct.h"\nint main(void) { cobs_gpu_build_params p; p.struct_size = sizeof p; '
+                  'return (int)p.struct_size == 0; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc,
+                           "-fsyntax-only", str(c2)])
     cpp = tmp_path / "t.cpp"
     cpp.write_text('#include "cobs_gpu_search.hpp"\nint main() { cobs_gpu::SearchResult r; return r.score != 0; }\n')
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", inc, "-fsyntax-only", str(cpp)])

@@ -246,37 +246,6 @@ def test_list_files_filters_and_sorting(capi, docdir, tmp_path):
     assert dl[0].terms(11) == [b"GGGTTTAAACC", b"GGTTTAAACCC"]
 
 
-def test_doc_list_and_doc_dump_tools(docdir):
-    """`cobs doc-list` / `cobs doc-dump` (reference src/cobs.cpp:41-158): host-only sub-tools of
-    cobs_gpu_query, same output"""
-    import subprocess
-    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cobs_amd", "cobs_gpu_query")
-    root = os.path.join(docdir, "fastq")
-    r = subprocess.run([tool, "doc-list", root], capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0, r.stderr
-    ents = D.document_list(root)
-    want = "--- document list (3 entries) ---\n"
-    for i, e in enumerate(ents):
-        want += "document[%d] size %d 31-mers %d : %s : %s\n" % (i, os.path.getsize(e.path), e.num_terms(31), e.path, e.name)
-    terms = [e.num_terms(31) for e in ents]
-    want += "--- end of document list (3 entries) ---\ndocuments: 3\n"
-    want += "minimum 31-mers: %d\nmaximum 31-mers: %d\naverage 31-mers: %d\ntotal 31-mers: %d\n" % (
-        min(terms), max(terms), sum(terms) // 3, sum(terms))
-    assert r.stdout == want
-    # doc-dump: raw terms, and canonical terms (reverse complement where that is smaller)
-    p = os.path.join(docdir, "fasta_multi", "sample2.mfasta")
-    r = subprocess.run([tool, "doc-dump", p, "--no-canonicalize", "-k", "21"], capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0 and r.stdout.encode() == b"".join(t + b"\n" for e in D.document_list(p) for t in e.terms(21))
-    assert "Found 5 documents." in r.stderr and "document[4] : %d terms." % D.document_list(p)[4].num_terms(21) in r.stderr
-    from oracle import oracle as O
-    O.build()
-    p = os.path.join(docdir, "cortex", "sample1-k31.ctx")
-    r = subprocess.run([tool, "doc-dump", p], capture_output=True, text=True, timeout=120)
-    assert r.stdout.encode() == b"".join(O.canonicalize_kmer(t)[0] + b"\n" for t in D.load(p)[0].terms(31))
-    r = subprocess.run([tool, "doc-dump", os.path.join(docdir, "text", "sample1.txt")], capture_output=True, text=True, timeout=120)
-    assert r.stdout.startswith("Invalid DNA base pair: Hello, this is the first sample\n")
-
-
 def test_readers_survive_damaged_files(capi, docdir, tmp_path):
     """truncated and bit-flipped copies of every fixture: the readers answer with an error or with
     terms, never with a crash or an out-of-bounds read (the checker is not consulted: damaged files
@@ -352,20 +321,3 @@ def test_cpp_construction_mirror(docdir, tmp_path):
     assert lines[2 + len(ents):2 + len(ents) + 3] == ["fastq %s %d" % (e.name, e.size) for e in fq]
     assert "Unknown file type nonsense" in lines[-2]
     assert lines[-1] == "refused Error: COBS index file must end with .cobs_classic"
-
-
-def test_print_parameters_and_print_kmers_tools(construct):
-    """`cobs print-parameters` / `cobs print-kmers` (reference src/cobs.cpp:532-600)"""
-    import subprocess
-    from oracle import oracle as O
-    O.build()
-    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cobs_amd", "cobs_gpu_query")
-    r = subprocess.run([tool, "print-parameters", "-n", "3120"], capture_output=True, text=True, timeout=60)
-    assert r.returncode == 0 and r.stdout.startswith("signature_size = 8748\nsignature_bytes = 1093 = ")    # SURVEY 7.2: S = 8748
-    for h, f, n in ((3, 0.1, 1000000), (1, 0.3, 5), (2, 0.05, 123456789)):
-        r = subprocess.run([tool, "print-parameters", "-h", str(h), "-f", str(f), "-n", str(n)], capture_output=True, text=True, timeout=60)
-        assert r.stdout.split("\n")[0] == "signature_size = %d" % construct.calc_signature_size(n, h, f)
-    q = O.random_sequence(80, 4)
-    r = subprocess.run([tool, "print-kmers", q.decode(), "-k", "21"], capture_output=True, text=True, timeout=60)
-    # the reference's loop stops one k-mer early (i < size - k)
-    assert r.stdout.encode() == b"".join(O.canonicalize_kmer(q[i:i + 21])[0] + b"\n" for i in range(len(q) - 21))

@@ -126,7 +126,7 @@ def test_construction_sub_tools(gpu_lib, oracle, golden_dir, tmp_path):
     pc, pk = str(tmp_path / "c.cobs_classic"), str(tmp_path / "c.cobs_compact")
     r = _run("classic-construct", fasta, pc)
     assert r.returncode == 0, r.stderr
-    assert "--- document list (7 entries) ---" in r.stdout and "maximum 31-mers: 3120" in r.stdout
+    assert "documents: 7" in r.stdout
     assert open(pc, "rb").read() == open(os.path.join(golden_dir, "c1.cobs_classic"), "rb").read()
     r = _run("compact-construct", fasta, pk, "-T", "4", "-m", "1000000")
     assert r.returncode == 0, r.stderr
