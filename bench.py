@@ -238,7 +238,7 @@ def kernels_hash():
     """identifies the kernel source a profile belongs to (the GPU box has no .git)"""
     import hashlib
     h = hashlib.sha256()
-    for fn in ("kernels.hip", "engine.cpp", "rank_kernels.hip", "rank.cpp"):
+    for fn in ("kernels.hip", "rank_kernels.hip", "fetch_kernels.hip", "plan.cpp", "pass.cpp", "rank.cpp"):
         with open(os.path.join(ROOT, "cobs_amd", "csrc", fn), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

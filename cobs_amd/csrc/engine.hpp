@@ -305,7 +305,43 @@ struct cobs_gpu_batch {
 
 namespace cobs_amd {
 
-// engine.cpp internals used by comm.cpp
+// ---- plan.cpp: host arithmetic of an opened index
+cobs_gpu_status select_device(const cobs_gpu_options* o, int* device);
+uint32_t pitch_for(uint64_t ncols, const Tuning& tune);
+uint64_t slice_bytes(uint64_t sig, uint64_t ncols, const Tuning& tune);
+// geometry of a scan launch: tile width (16-byte column chunks), waves per work-group, work-group variant
+struct ScanGeom { uint32_t tile_w; int nwaves; bool multi_query; };
+ScanGeom scan_geometry(const Chunk& c, uint64_t mean_blocks, uint64_t max_blocks, uint64_t num_hashes,
+                       uint32_t forced_waves, int planes, bool idx64, const Tuning& tune);
+std::vector<VPage> held_slices(const IndexMeta& m, uint32_t rank, uint32_t count, uint32_t mode);
+cobs_gpu_status plan_part(Part& pt, const cobs_gpu_index* ix);
+cobs_gpu_status plan_index(cobs_gpu_index* ix);
+// a replayed small pass brings this many hit-pool entries home inside the graph
+constexpr size_t kGraphPoolPrefix = 2048;
+// K3 orders up to this many survivors per (query, file) on the device (8-byte keys in 64 KB of LDS)
+constexpr size_t kTopkSortLimit = 8192;
+// largest k for which K2 selects per tile (a tile holds 512 or more documents; the pool is queries x tiles x k entries)
+constexpr size_t kTileTopkMax = 128;
+
+// ---- stage.cpp: index data into HBM
+cobs_gpu_status alloc_part(cobs_gpu_index* ix, Part& pt);
+cobs_gpu_status upload_resident(Part& pt, const uint8_t* file);
+SynthArgs synth_args(const Part& pt, const Chunk& c, uint8_t* data);
+cobs_gpu_status stream_chunk_in(cobs_gpu_index* ix, Part& pt, const Chunk& c, int buf);
+
+// ---- engine.cpp: the thread's error text (cobs_gpu_last_error)
+std::string& last_error_text();
+
+// ---- pass.cpp
+uint64_t gathered_row_bytes(const Part& p);
+void set_run_state(cobs_gpu_batch* b, double threshold, size_t topk, bool want_counts);
+void stage_thresholds(cobs_gpu_batch* b, double threshold);
+
+// ---- results.cpp
+cobs_gpu_status fetch_counts(cobs_gpu_batch* b, size_t q, uint32_t* counts);
+cobs_gpu_status rank_window(cobs_gpu_batch* b, size_t q0, size_t q1, size_t per_query, cobs_gpu_hit* hits);
+
+// pass.cpp internals used by comm.cpp
 cobs_gpu_status run_impl(cobs_gpu_batch* b, double threshold, size_t topk, void* hip_stream, bool want_counts = true);
 cobs_gpu_status set_queries_on(cobs_gpu_batch* b, const char* const* queries, const size_t* lens, size_t nq,
                                hipStream_t up, bool wait, size_t* bad_query, size_t index_base = 0);

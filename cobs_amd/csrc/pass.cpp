@@ -1,0 +1,580 @@
+// cobs_amd/csrc/pass.cpp -- one pass of the hot path over a batch (ClassicSearch::search's body, reference
+// cobs/query/classic_search.cpp:403-505, for many queries at once): batch workspaces, the single upload of the
+// query text, K1 per file, then per chunk K2 -- on resident data, on a chunk streamed in whole, or on the rows a
+// row-selective fetch brought in --, K3 where a limit is given, and the events / counters a caller reads afterwards.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "engine.hpp"
+
+using namespace cobs_amd;
+
+namespace cobs_amd {
+
+// row bytes one hash lookup gathers from this part (all held slices)
+uint64_t gathered_row_bytes(const Part& p) {
+    uint64_t n = 0;
+    for (const VPage& v : p.held) n += v.ncols;
+    return n;
+}
+
+
+// total number of hashes of query `q` over all files: the reference's max_counts
+uint64_t total_hashes(const cobs_gpu_batch* b, size_t q) {
+    uint64_t n = 0;
+    for (const Part& p : b->ix->parts)
+        n += (uint64_t)(b->lens[q] - p.meta.term_size + 1) * p.meta.num_hashes;
+    return n;
+}
+
+uint32_t threshold_for(double threshold, uint64_t terms) {
+    // classic_search.cpp:446-448: std::ceil(threshold * T) in double
+    const double v = std::ceil(threshold * (double)terms);
+    if (!(v > 0)) return 0;
+    if (v >= 4294967295.0) return 0xFFFFFFFFu;
+    return (uint32_t)v;
+}
+
+
+}  // namespace cobs_amd
+
+extern "C" {
+
+// ---------------------------------------------------------------------------
+// batches
+
+cobs_gpu_status cobs_gpu_batch_create(cobs_gpu_index* ix, size_t max_queries, size_t max_query_len,
+                                      cobs_gpu_batch** out) {
+    if (!ix || !out) return fail(COBS_GPU_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    return guarded([&]() -> cobs_gpu_status {
+    HIP_TRY(hipSetDevice(ix->device));
+    std::unique_ptr<cobs_gpu_batch> b(new cobs_gpu_batch);
+    b->ix = ix;
+    b->max_queries = max_queries;
+    b->max_len = max_query_len;
+    b->work.resize(ix->parts.size());
+    for (auto& r : b->ev) for (auto& e : r) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipEventCreateWithFlags(&b->run_done, hipEventDisableTiming));
+    HIP_TRY(b->flags.reserve(4));
+    *out = b.release();
+    return COBS_GPU_OK;
+    });
+}
+
+void cobs_gpu_batch_destroy(cobs_gpu_batch* b) { delete b; }
+
+// Uploads go through `up` (asynchronously where the source is pinned); wait = false leaves them
+// in flight: the caller orders its kernels after them on the same stream.
+}  // extern "C"
+
+cobs_gpu_status cobs_amd::set_queries_on(cobs_gpu_batch* b, const char* const* queries, const size_t* lens,
+                                         size_t nq, hipStream_t up, bool wait, size_t* bad_query, size_t index_base) {
+    if (!b || (nq && (!queries || !lens))) return fail(COBS_GPU_ERR_ARG, "NULL argument");
+    cobs_gpu_index* ix = b->ix;
+    HIP_TRY(hipSetDevice(ix->device));
+    // the upload overwrites buffers a run still in flight would read: wait for a run nobody
+    // synced -- on that run's own event, other handles' streams on the device keep going
+    if (b->ran && !b->synced) HIP_TRY(hipEventSynchronize(b->run_done));
+    b->ran = false;
+    b->nq = 0;
+    if (nq >= 0xFFFFFFFEull) return fail(COBS_GPU_ERR_ARG, "too many queries");
+    // reference checks, classic_search.cpp:431-433 and :453-504
+    uint32_t max_term = 0, min_term = 0xFFFFFFFFu;
+    for (const Part& p : ix->parts) {
+        max_term = std::max(max_term, p.meta.term_size);
+        min_term = std::min(min_term, p.meta.term_size);
+    }
+    uint64_t max_terms = 1;
+    for (size_t q = 0; q < nq; ++q) {
+        if (bad_query) *bad_query = q;
+        if (!queries[q]) return fail(COBS_GPU_ERR_ARG, "NULL query (query " + std::to_string(index_base + q) + ")");
+        if (lens[q] < max_term)
+            return fail(COBS_GPU_ERR_QUERY_TOO_SHORT, "query too short, needs to be at least " +
+                        std::to_string(max_term) + " characters long (query " + std::to_string(index_base + q) + ")");
+        if (lens[q] - max_term >= 0xFFFFFFFFull || lens[q] >= 0xFFFFFFF0ull)
+            return fail(COBS_GPU_ERR_QUERY_TOO_LONG, "query too long (query " + std::to_string(index_base + q) + ")");
+        max_terms = std::max<uint64_t>(max_terms, lens[q] - min_term + 1);
+    }
+    if (bad_query) *bad_query = 0;
+    const int planes = scan_planes_for(max_terms);
+    if (planes < 0) return fail(COBS_GPU_ERR_QUERY_TOO_LONG, "query too long");
+    b->planes = planes;
+    b->max_terms = max_terms;
+    b->elem_bytes = scan_score_bytes(planes);
+
+    // thread spans of K1: every character and every (padded) term of every file
+    b->lens.resize(nq);
+    b->span_off.resize(nq + 1);
+    uint64_t off = 0;
+    for (size_t q = 0; q < nq; ++q) {
+        b->lens[q] = (uint32_t)lens[q];
+        b->span_off[q] = off;
+        uint64_t span = lens[q];
+        for (const Part& p : ix->parts)
+            span = std::max<uint64_t>(span, round_up(lens[q] - p.meta.term_size + 1, 8) + 8);   // + padding block
+        off += round_up(span, 8);
+    }
+    b->span_off[nq] = off;
+    // upload layout: text (+ 64: K1 reads whole dwords around a k-mer) | span_off | q_len | blk_off per file
+    const size_t o_span = (size_t)round_up(off + 64, 16);
+    const size_t o_qlen = o_span + (size_t)round_up(8 * (nq + 1), 16);
+    const size_t o_blk = o_qlen + (size_t)round_up(4 * std::max<size_t>(nq, 1), 16);
+    const size_t blk_stride = (size_t)round_up(8 * (nq + 1), 16);
+    const size_t upload_bytes = o_blk + blk_stride * ix->parts.size();
+    HIP_TRY(b->h_text.reserve(upload_bytes));
+    HIP_TRY(b->text.reserve(upload_bytes));
+    std::memset(b->h_text.p, 0, o_span);
+    for (size_t q = 0; q < nq; ++q) std::memcpy(b->h_text.p + b->span_off[q], queries[q], lens[q]);
+    std::memcpy(b->h_text.p + o_span, b->span_off.data(), 8 * (nq + 1));
+    if (nq) std::memcpy(b->h_text.p + o_qlen, b->lens.data(), 4 * nq);
+    b->d_span_off = reinterpret_cast<const uint64_t*>(b->text.p + o_span);
+    b->d_qlen = reinterpret_cast<const uint32_t*>(b->text.p + o_qlen);
+
+    uint64_t algo_bytes = 0, lookups = 0, table_bytes = 0;
+    for (size_t f = 0; f < ix->parts.size(); ++f) {
+        const Part& p = ix->parts[f];
+        PartWork& w = b->work[f];
+        w.h_blk_off.resize(nq + 1);
+        uint64_t blk = 0;
+        for (size_t q = 0; q < nq; ++q) {
+            w.h_blk_off[q] = blk;
+            const uint64_t T = lens[q] - p.meta.term_size + 1;
+            blk += (T + 7) / 8;
+            lookups += T;
+            // T * H * (row bytes gathered) + score bytes written
+            algo_bytes += T * p.meta.num_hashes * gathered_row_bytes(p);
+        }
+        w.h_blk_off[nq] = blk;
+        // per (query, sub-index): its 8-term blocks plus one padding block
+        const uint64_t idx_words = p.idx64 ? 2 : 1;      // u32 words per table entry
+        w.table_entries = (blk + nq) * 8 * p.meta.num_hashes * p.num_tpages() * idx_words;
+        table_bytes += w.table_entries * 4;
+        if (w.table_entries >= (1ull << 40)) return fail(COBS_GPU_ERR_CAPACITY, "batch too large");
+        HIP_TRY(w.table.reserve((size_t)w.table_entries));
+        HIP_TRY(w.thr.reserve(nq));
+        std::memcpy(b->h_text.p + o_blk + f * blk_stride, w.h_blk_off.data(), 8 * (nq + 1));
+        w.blk_off = reinterpret_cast<const uint64_t*>(b->text.p + o_blk + f * blk_stride);
+    }
+    HIP_TRY(hipMemcpyAsync(b->text.p, b->h_text.p, upload_bytes, hipMemcpyHostToDevice, up));
+    b->algo_row_bytes = algo_bytes;                          // the score bytes are added by the run that writes them
+    // selection pool: room for 1024 hits per query, at least 1 Mi entries
+    const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(1u << 20, nq * 1024ull), 1ull << 26);
+    HIP_TRY(b->hits.reserve((size_t)want));
+    b->hit_cap = (uint32_t)b->hits.cap;
+    HIP_TRY(b->h_thr_stage.reserve(std::max<size_t>(nq * ix->parts.size(), 1)));
+    b->stats[0] = algo_bytes + (uint64_t)nq * ix->local_counts * b->elem_bytes;      // until a run says otherwise
+    b->stats[1] = 0;
+    b->stats[2] = lookups;
+    b->stats[3] = table_bytes;
+    b->nq = nq;
+    if (wait) HIP_TRY(hipStreamSynchronize(up));
+    return COBS_GPU_OK;
+}
+
+extern "C" cobs_gpu_status cobs_gpu_batch_set_queries(cobs_gpu_batch* b, const char* const* queries,
+                                                      const size_t* lens, size_t nq) {
+    return guarded([&]() { return set_queries_on(b, queries, lens, nq, nullptr, true, nullptr); });
+}
+
+// want_counts = false: the caller only needs the selected hits (threshold > 0, no top-k), so the
+// scan does not write the score rows (for reads they are up to a third of the traffic).
+// what a run leaves behind on the host side of the batch (a replayed graph sets the same)
+void cobs_amd::set_run_state(cobs_gpu_batch* b, double threshold, size_t topk, bool want_counts) {
+    cobs_gpu_index* ix = b->ix;
+    b->ran = false;
+    b->synced = false;
+    b->pool_fetched = false;
+    b->topk_fetched = false;
+    b->rows_q0 = b->rows_q1 = 0;
+    b->view_global = false;
+    b->pool_global = false;
+    b->topk_stride = 0;
+    b->graph_run = false;
+    b->threshold = threshold;
+    // K3 (exact top-k on the device, every score width) needs a bounded k
+    const bool use_topk = topk > 0 && topk <= 65536 &&
+                          (uint64_t)topk * std::max<size_t>(b->nq, 1) * ix->parts.size() <= (1ull << 27);
+    b->topk_k = use_topk ? (uint32_t)topk : 0;
+    b->topk_sorted = use_topk && topk <= kTopkSortLimit;
+    // with K3 the threshold is applied there; otherwise K2 selects into the hit pool
+    b->selected = threshold > 0.0 && !use_topk;
+    // a top-k pass whose caller does not want the score rows: K2 leaves the k best of every tile and K3 merges
+    // those (no score matrix at all) -- where that epilogue exists, for a k a tile can hold, and unless a query
+    // has a single hash in total (its result is index order, which only the rows give: classic_search.cpp:136,179)
+    b->topk_direct = false;
+    if (use_topk && !want_counts && topk <= kTileTopkMax && !ix->tune.lds_staged && ix->tune.tile_topk != 0) {
+        bool ok = b->nq > 0;
+        for (const Part& p : ix->parts) ok = ok && scan_has_tile_topk((uint32_t)p.meta.num_hashes, p.idx64);
+        for (size_t q = 0; ok && q < b->nq; ++q) ok = total_hashes(b, q) > 1;
+        b->topk_direct = ok;
+    }
+    b->have_counts = want_counts || (!b->selected && !b->topk_direct);
+}
+
+// The per-(file, query) thresholds ceil(threshold * T) (classic_search.cpp:444-449) in the pinned
+// buffer the H2D copies of a run read.  A captured graph holds those copies as nodes that read the
+// buffer when the graph is LAUNCHED, and the buffer is shared by every shape of the batch: a replay
+// has to write its own thresholds first (whatever ran in between left its own there).
+void cobs_amd::stage_thresholds(cobs_gpu_batch* b, double threshold) {
+    const cobs_gpu_index* ix = b->ix;
+    const size_t nq = b->nq;
+    for (size_t f = 0; f < ix->parts.size(); ++f) {
+        uint32_t* stage = b->h_thr_stage.p + f * nq;
+        for (size_t q = 0; q < nq; ++q)
+            stage[q] = threshold_for(threshold, (uint64_t)b->lens[q] - ix->parts[f].meta.term_size + 1);
+    }
+}
+
+cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t topk, void* hip_stream,
+                                   bool want_counts) {
+    if (!b) return fail(COBS_GPU_ERR_ARG, "NULL batch");
+    cobs_gpu_index* ix = b->ix;
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIP_TRY(hipSetDevice(ix->device));
+    set_run_state(b, threshold, topk, want_counts);
+    const size_t nq = b->nq;
+    const bool use_topk = b->topk_k != 0;
+    // score rows are allocated by the first run that writes them (a hits-only caller never pays
+    // for them: 100k reads x 100k documents would be 10 GB)
+    if (b->have_counts) HIP_TRY(b->counts.reserve((size_t)(nq * ix->local_counts * b->elem_bytes)));
+    const bool need_thr = threshold > 0.0;
+    if (use_topk) {
+        HIP_TRY(b->topk_out.reserve((size_t)topk * std::max<size_t>(nq, 1) * ix->parts.size()));
+        HIP_TRY(b->topk_cnt.reserve(std::max<size_t>(nq, 1) * ix->parts.size()));
+    }
+    // device flags: first invalid query = none, selected hits = 0
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)b->flags.p, 0, 4, st));      // all zero: one fill
+    if (need_thr) {
+        stage_thresholds(b, threshold);
+        for (size_t f = 0; f < ix->parts.size(); ++f)
+            if (nq) HIP_TRY(hipMemcpyAsync(b->work[f].thr.p, b->h_thr_stage.p + f * nq, 4 * nq, hipMemcpyHostToDevice, st));
+    }
+    // scan geometry of every (file, chunk); with tile-level top-k also the files' places in the candidate pool
+    std::vector<std::vector<ScanGeom>> geoms(ix->parts.size());
+    std::vector<uint64_t> cand_off(ix->parts.size() + 1, 0);
+    std::vector<uint32_t> cand_tiles(ix->parts.size(), 0), cand_stride(ix->parts.size(), 0);
+    for (size_t f = 0; f < ix->parts.size() && nq; ++f) {
+        const Part& p = ix->parts[f];
+        for (const Chunk& c : p.chunks) {
+            geoms[f].push_back(scan_geometry(c, b->work[f].h_blk_off[nq] / nq, (b->max_terms + 7) / 8, p.meta.num_hashes,
+                                             ix->waves_per_group, b->planes, p.idx64, ix->tune));
+            cand_tiles[f] += (c.total_chunks + geoms[f].back().tile_w - 1) / geoms[f].back().tile_w;
+        }
+        cand_stride[f] = (uint32_t)round_up((uint64_t)cand_tiles[f] * topk, 8);
+        cand_off[f + 1] = cand_off[f] + (b->topk_direct ? (uint64_t)nq * cand_stride[f] : 0);
+    }
+    if (b->topk_direct) {
+        if (cand_off.back() > (1ull << 31)) {            // 16 GiB of candidates: take the score rows instead
+            b->topk_direct = false;
+            b->have_counts = true;
+            HIP_TRY(b->counts.reserve((size_t)(nq * ix->local_counts * b->elem_bytes)));
+        } else {
+            HIP_TRY(b->cand.reserve((size_t)cand_off.back()));
+        }
+    }
+    hipEvent_t* ev = b->ev[b->run_seq % cobs_gpu_batch::kRing];
+    HIP_TRY(hipEventRecord(ev[0], st));
+    bool hash_marked = false;
+    uint64_t launches = 0;
+    StreamBufs& sbufs = ix->stream;
+    for (size_t f = 0; f < ix->parts.size(); ++f) {
+        Part& p = ix->parts[f];
+        if (nq == 0 || p.chunks.empty()) continue;
+        {   // K1 once per file and pass: the row-index table covers every held sub-index,
+            // the chunks (launches) of the file pick their sub-indexes by PageDev::tpage
+            HashArgs ha;
+            ha.text = b->text.p;
+            ha.span_off = b->d_span_off;
+            ha.q_len = b->d_qlen;
+            ha.blk_off = b->work[f].blk_off;
+            ha.pages = p.d_tpages;
+            ha.table = b->work[f].table.p;
+            ha.err_query = b->flags.p;
+            ha.nq = (uint32_t)nq;
+            ha.npages = p.num_tpages();
+            ha.term_size = p.meta.term_size;
+            ha.canonicalize = p.meta.canonicalize;
+            ha.num_hashes = (uint32_t)p.meta.num_hashes;
+            ha.idx64 = p.idx64 ? 1u : 0u;
+            HIP_TRY(launch_hash(ha, b->span_off[nq], st));
+            if (!hash_marked) {      // K1 / K2 split of the timing events: first file only
+                HIP_TRY(hipEventRecord(ev[1], st));
+                hash_marked = true;
+            }
+        }
+        uint32_t tile_base = 0;
+        bool fetch_ready = false;
+        if (p.streamed && p.file_dev && ix->tune.row_fetch != 0) {
+            // a row-selective chunk gets its own row-index table (one per stream buffer); sized before the
+            // chunk loop, when no scan of this handle is reading the old ones any more
+            const size_t need = (size_t)b->work[f].table_entries * 4;
+            for (int i = 0; i < 2; ++i) {
+                if (sbufs.table2[i].cap >= need) continue;
+                if (sbufs.used[i]) HIP_TRY(hipEventSynchronize(sbufs.scanned[i]));
+                HIP_TRY(sbufs.table2[i].reserve(need));
+            }
+        }
+        for (size_t ci = 0; ci < p.chunks.size(); ++ci) {
+            const Chunk& c = p.chunks[ci];
+            const uint8_t* data = c.d_data;
+            int buf = 0;
+            const PageDev* pages_dev = c.d_pages;
+            const void* table_dev = b->work[f].table.p;
+            if (p.streamed) {
+                // double buffer shared by all streamed files: the next chunk goes to the buffer
+                // whose last scan is done
+                buf = (int)(sbufs.seq++ & 1);
+                if (sbufs.used[buf]) HIP_TRY(hipEventSynchronize(sbufs.scanned[buf]));
+                // Whole chunk, or only the rows this batch looks up?  The table holds E entries per sub-index;
+                // fetching them row by row moves E x (slices) x pitch bytes over PCIe at the rate random rows
+                // come in, copying the chunk moves all of its rows at the slab rate (row_fetch_alpha prices
+                // the difference).  The reference's mmap / AIO back-ends always take the first form
+                // (compact_index/mmap_search_file.cpp:34-67, aio_search_file.cpp:58-97).
+                const uint64_t E = (b->work[f].h_blk_off[nq] + nq) * 8ull * p.meta.num_hashes;
+                const uint64_t gathered = (E * c.vp.size() + 1) * (uint64_t)c.pitch;
+                const bool fetch = ix->tune.row_fetch != 0 && p.file_dev && c.d_src && !p.synthetic &&
+                                   gathered <= sbufs.sbuf[buf].cap && E * c.vp.size() < 0xFFFFFFF0ull &&
+                                   (gathered - c.pitch) * ix->tune.row_fetch_alpha <= c.bytes;
+                if (fetch) {
+                    if (!fetch_ready) {          // the fetch kernel reads K1's table: once per file and pass
+                        HIP_TRY(hipEventRecord(sbufs.hashed, st));
+                        HIP_TRY(hipStreamWaitEvent(sbufs.copy_stream, sbufs.hashed, 0));
+                        fetch_ready = true;
+                    }
+                    FetchArgs fa;
+                    fa.file = p.file_dev;
+                    fa.table = b->work[f].table.p;
+                    fa.table2 = sbufs.table2[buf].p;
+                    fa.blk_off = b->work[f].blk_off;
+                    fa.pages = c.d_pages;
+                    fa.pages2 = c.d_pages2[buf];
+                    fa.page_src = c.d_src;
+                    fa.dst = sbufs.sbuf[buf].p;
+                    fa.entries = E;
+                    fa.src_pitch = p.meta.page_row_bytes();
+                    fa.nq = (uint32_t)nq;
+                    fa.npages = (uint32_t)c.vp.size();
+                    fa.table_npages = p.num_tpages();
+                    fa.num_hashes = (uint32_t)p.meta.num_hashes;
+                    fa.pitch = c.pitch;
+                    fa.ncols = (uint32_t)c.vp[0].ncols;
+                    HIP_TRY(launch_fetch_rows(fa, p.idx64, sbufs.copy_stream));
+                    pages_dev = c.d_pages2[buf];
+                    table_dev = sbufs.table2[buf].p;
+                    ++sbufs.fetched_chunks;
+                } else {
+                    cobs_gpu_status cs = stream_chunk_in(ix, p, c, buf);
+                    if (cs != COBS_GPU_OK) return cs;
+                    ++sbufs.streamed_chunks;
+                }
+                HIP_TRY(hipEventRecord(sbufs.copied[buf], sbufs.copy_stream));
+                HIP_TRY(hipStreamWaitEvent(st, sbufs.copied[buf], 0));
+                data = sbufs.sbuf[buf].p;
+            }
+            ScanArgs sa;
+            sa.blob = data;
+            sa.pages = pages_dev;
+            sa.table = table_dev;
+            sa.blk_off = b->work[f].blk_off;
+            sa.counts = b->counts.p;
+            sa.thresholds = b->selected ? b->work[f].thr.p : nullptr;
+            sa.hits = b->hits.p;
+            sa.hit_count = reinterpret_cast<unsigned long long*>(b->flags.p + 2);
+            sa.counts_stride = ix->local_counts;
+            sa.counts_offset = p.local_offset;
+            sa.hit_cap = b->hit_cap;
+            sa.nq = (uint32_t)nq;
+            sa.npages = (uint32_t)c.vp.size();
+            sa.table_npages = p.num_tpages();
+            sa.pitch = c.pitch;
+            sa.cpp = c.cpp;
+            sa.total_chunks = c.total_chunks;
+            sa.num_hashes = (uint32_t)p.meta.num_hashes;
+            sa.num_docs = (uint32_t)p.meta.doc_names.size();
+            sa.part = (uint32_t)f;
+            sa.write_counts = b->have_counts ? 1 : 0;
+            sa.idx64 = p.idx64 ? 1u : 0u;
+            const ScanGeom geom = geoms[f][ci];
+            const int nwaves = geom.nwaves;
+            sa.tile_w = geom.tile_w;
+            sa.cand = b->topk_direct ? b->cand.p + cand_off[f] : nullptr;
+            sa.topk_k = b->topk_direct ? (uint32_t)topk : 0u;
+            sa.cand_stride = cand_stride[f];
+            sa.tile_base = tile_base;
+            // K2 filters by threshold only when it selects: into the hit pool, or the tile's k best
+            if (b->topk_direct) sa.thresholds = need_thr ? b->work[f].thr.p : nullptr;
+            sa.dbg = nullptr;
+            sa.dbg_every = 1;
+            sa.dbg_slots = 0;
+            if (ix->tune.phase_slots) {          // tuning builds: phase stamps of sampled work-groups (last launch wins)
+                HIP_TRY(b->phase.reserve((size_t)ix->tune.phase_slots * 32));
+                HIP_TRY(hipMemsetAsync(b->phase.p, 0, (size_t)ix->tune.phase_slots * 32 * 8, st));
+                sa.dbg = b->phase.p;
+                sa.dbg_slots = ix->tune.phase_slots;
+            }
+            // measured variant (A/B only): rows staged through LDS, where that kernel exists
+            sa.lds_staged = ix->tune.lds_staged && !geom.multi_query && !p.idx64 &&
+                            scan_has_lds_staged(b->planes, (uint32_t)p.meta.num_hashes, nwaves) ? 1u : 0u;
+            sa.chunk_begin = 0;
+            sa.chunk_end = c.total_chunks;
+            // one launch covers at most 2^31-1 work-groups
+            const uint32_t ntiles = (c.total_chunks + sa.tile_w - 1) / sa.tile_w;
+            if ((uint64_t)ntiles * nq > 0x7FFFFFFFull)
+                return fail(COBS_GPU_ERR_CAPACITY, "batch too large for one scan launch; use fewer queries");
+            if (sa.dbg) {
+                const uint64_t groups = geom.multi_query ? (uint64_t)ntiles * ((nq + 64 / sa.tile_w - 1) / (64 / sa.tile_w))
+                                                          : (uint64_t)ntiles * nq;
+                sa.dbg_every = (uint32_t)std::max<uint64_t>(1, groups / sa.dbg_slots);
+            }
+            HIP_TRY(launch_scan(sa, ntiles, b->planes, nwaves, geom.multi_query, st));
+            tile_base += ntiles;
+            ++launches;
+            if (p.streamed) {
+                HIP_TRY(hipEventRecord(sbufs.scanned[buf], st));
+                sbufs.used[buf] = true;
+            }
+        }
+    }
+    if (!hash_marked) HIP_TRY(hipEventRecord(ev[1], st));
+    HIP_TRY(hipEventRecord(ev[2], st));
+    if (use_topk && nq) {
+        for (size_t f = 0; f < ix->parts.size(); ++f) {
+            const Part& p = ix->parts[f];
+            TopkArgs ta;
+            ta.counts = b->counts.p;
+            ta.score_bytes = b->elem_bytes;
+            ta.thresholds = need_thr ? b->work[f].thr.p : nullptr;
+            ta.from_pool = 0;
+            ta.out = b->topk_out.p + (uint64_t)f * nq * topk;
+            ta.out_count = b->topk_cnt.p + f * nq;
+            ta.counts_stride = ix->local_counts;
+            ta.counts_offset = p.local_offset;
+            ta.nslots = (uint32_t)p.slot_count;
+            ta.doc_base = (uint32_t)p.slot_begin;
+            ta.num_docs = (uint32_t)p.meta.doc_names.size();
+            ta.k = (uint32_t)topk;
+            ta.nq = (uint32_t)nq;
+            ta.score_bits = (uint32_t)b->planes;
+            ta.levels = ((uint32_t)b->planes + 11u) / 12u;                       // radix levels of <= 12 bits
+            ta.level_bits = ((uint32_t)b->planes + ta.levels - 1u) / ta.levels;
+            ta.sort_limit = topk <= kTopkSortLimit ? (uint32_t)topk : 0u;        // survivors ordered on the device
+            if (b->topk_direct) {           // merge the tiles' candidates (threshold already applied by K2)
+                ta.from_pool = 1;
+                ta.counts = b->cand.p + cand_off[f];
+                ta.counts_stride = cand_stride[f];
+                ta.counts_offset = 0;
+                ta.nslots = cand_tiles[f] * (uint32_t)topk;
+                ta.thresholds = nullptr;
+            }
+            HIP_TRY(launch_topk(ta, st));
+        }
+    }
+    HIP_TRY(hipEventRecord(b->run_done, st));
+    b->run_seq++;
+    b->stats[1] = launches;
+    // T * H * (row bytes gathered) + score bytes WRITTEN (a hits-only pass writes none)
+    b->stats[0] = b->algo_row_bytes + (b->have_counts ? (uint64_t)nq * ix->local_counts * b->elem_bytes : 0);
+    b->ran = true;
+    return COBS_GPU_OK;
+}
+
+extern "C" {
+
+cobs_gpu_status cobs_gpu_batch_run(cobs_gpu_batch* b, double threshold, void* hip_stream) {
+    return guarded([&]() { return run_impl(b, threshold, 0, hip_stream); });
+}
+
+cobs_gpu_status cobs_gpu_batch_run_hits(cobs_gpu_batch* b, double threshold, void* hip_stream) {
+    if (!(threshold > 0.0)) return fail(COBS_GPU_ERR_ARG, "a hits-only pass needs a threshold > 0");
+    return guarded([&]() { return run_impl(b, threshold, 0, hip_stream, false); });
+}
+
+cobs_gpu_status cobs_gpu_batch_run_topk(cobs_gpu_batch* b, double threshold, size_t num_results,
+                                        void* hip_stream) {
+    return guarded([&]() { return run_impl(b, threshold, num_results, hip_stream); });
+}
+
+cobs_gpu_status cobs_gpu_batch_run_topk_only(cobs_gpu_batch* b, double threshold, size_t num_results,
+                                             void* hip_stream) {
+    if (num_results == 0) return fail(COBS_GPU_ERR_ARG, "a top-k pass needs num_results > 0");
+    return guarded([&]() { return run_impl(b, threshold, num_results, hip_stream, false); });
+}
+
+cobs_gpu_status cobs_gpu_batch_sync(cobs_gpu_batch* b, void* hip_stream, size_t* bad_query) {
+    if (!b) return fail(COBS_GPU_ERR_ARG, "NULL batch");
+    if (!b->ran) return fail(COBS_GPU_ERR_ARG, "batch has not been run");
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIP_TRY(hipSetDevice(b->ix->device));
+    if (b->graph_run && b->h_res.p) {            // the graph already copied the flags (and the results) home
+        HIP_TRY(hipStreamSynchronize(st));
+        std::memcpy(b->h_flags, b->h_res.p, sizeof b->h_flags);
+    } else {
+        HIP_TRY(hipMemcpyAsync(b->h_flags, b->flags.p, sizeof b->h_flags, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    b->synced = true;
+    if (b->h_flags[0] != 0u) {           // K1 keeps 2^32-1 - (first query with a non-ACGT character)
+        const uint32_t bad = 0xFFFFFFFFu - b->h_flags[0];
+        if (bad_query) *bad_query = bad;
+        return fail(COBS_GPU_ERR_INVALID_BASE,
+                    "Invalid DNA base pair in query string. Only ACGT are allowed. (query " +
+                    std::to_string(bad) + ")");
+    }
+    return COBS_GPU_OK;
+}
+
+
+cobs_gpu_status cobs_gpu_batch_phase_stamps(cobs_gpu_batch* b, uint64_t* out, size_t cap_words, size_t* n_words) {
+    if (!b || !n_words) return fail(COBS_GPU_ERR_ARG, "NULL argument");
+    const size_t n = (size_t)b->ix->tune.phase_slots * 32;
+    *n_words = n;
+    if (!b->phase.p || n == 0) { *n_words = 0; return COBS_GPU_OK; }
+    if (cap_words < n || !out) return fail(COBS_GPU_ERR_CAPACITY, "stamp buffer too small");
+    HIP_TRY(hipSetDevice(b->ix->device));
+    HIP_TRY(hipMemcpy(out, b->phase.p, n * 8, hipMemcpyDeviceToHost));
+    return COBS_GPU_OK;
+}
+
+cobs_gpu_status cobs_gpu_batch_stats(const cobs_gpu_batch* b, uint64_t out[4]) {
+    if (!b || !out) return fail(COBS_GPU_ERR_ARG, "NULL argument");
+    std::memcpy(out, b->stats, sizeof b->stats);
+    return COBS_GPU_OK;
+}
+
+cobs_gpu_status cobs_gpu_batch_kernel_ms(cobs_gpu_batch* b, float* scan_ms, float* hash_ms) {
+    if (!b) return fail(COBS_GPU_ERR_ARG, "NULL batch");
+    if (!b->ran || !b->synced) return fail(COBS_GPU_ERR_ARG, "run and sync the batch first");
+    // average over the runs since the previous call (at most the last kRing runs)
+    uint64_t first = b->read_seq;
+    if (b->run_seq - first > (uint64_t)cobs_gpu_batch::kRing) first = b->run_seq - cobs_gpu_batch::kRing;
+    if (first == b->run_seq) first = b->run_seq - 1;       // nothing new: report the last run again
+    double h = 0, s = 0;
+    for (uint64_t r = first; r < b->run_seq; ++r) {
+        hipEvent_t* ev = b->ev[r % cobs_gpu_batch::kRing];
+        float a = 0, c = 0;
+        HIP_TRY(hipEventElapsedTime(&a, ev[0], ev[1]));
+        HIP_TRY(hipEventElapsedTime(&c, ev[1], ev[2]));
+        h += a;
+        s += c;
+    }
+    const double n = (double)(b->run_seq - first);
+    b->read_seq = b->run_seq;
+    if (hash_ms) *hash_ms = (float)(h / n);
+    if (scan_ms) *scan_ms = (float)(s / n);
+    return COBS_GPU_OK;
+}
+
+
+}  // extern "C"

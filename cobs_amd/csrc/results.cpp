@@ -1,0 +1,334 @@
+// cobs_amd/csrc/results.cpp -- results of a finished pass on the host side: score rows through a pinned window,
+// counts widened to u32, and counts_to_result (reference cobs/query/classic_search.cpp:109-202) from whatever
+// the pass left -- K3's ordered lists, the hit pool, or whole score rows ranked by a stable counting sort
+// (the device-side ranking of whole rows is rank.cpp / rank_kernels.hip).
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "engine.hpp"
+
+using namespace cobs_amd;
+
+namespace cobs_amd {
+
+
+// ---------------------------------------------------------------------------
+// ranking (counts_to_result, reference classic_search.cpp:109-202)
+
+bool hit_before(const cobs_gpu_hit& a, const cobs_gpu_hit& b) {
+    if (a.score != b.score) return a.score > b.score;
+    if (a.file_no != b.file_no) return a.file_no < b.file_no;
+    return a.doc < b.doc;
+}
+
+bool doc_before(const cobs_gpu_hit& a, const cobs_gpu_hit& b) {
+    if (a.file_no != b.file_no) return a.file_no < b.file_no;
+    return a.doc < b.doc;
+}
+
+
+// Raw local score row of query q of the last run, through a pinned host window of up to 64 MiB
+// of consecutive rows (callers walk the queries in order: one DMA per window, not per query).
+// After an exchange (comm.cpp) the batch may expose GLOBAL rows instead: queries
+// [g_q0, g_q0 + g_qn), every row total_counts elements in global document order.
+static cobs_gpu_status fetch_row(cobs_gpu_batch* b, size_t q, const uint8_t** row) {
+    const bool glob = b->view_global;
+    const size_t row_bytes = (size_t)((glob ? b->ix->total_counts : b->ix->local_counts) * b->elem_bytes);
+    if (glob && (q < b->g_q0 || q >= b->g_q0 + b->g_qn))
+        return fail(COBS_GPU_ERR_ARG, "this rank does not hold the exchanged row of that query");
+    if (!glob && b->graph_run && b->res_rows && b->rows_q1 == 0) {
+        b->rows_q0 = 0;                 // the replayed graph copied all rows of this small pass into the window
+        b->rows_q1 = b->nq;
+    }
+    if (q < b->rows_q0 || q >= b->rows_q1) {
+        const size_t per = std::max<size_t>(1, (64u << 20) / std::max<size_t>(row_bytes, 1));
+        const size_t q1 = std::min(glob ? (size_t)(b->g_q0 + b->g_qn) : b->nq, q + per);
+        HIP_TRY(b->h_rows.reserve(std::max<size_t>((q1 - q) * row_bytes, 1)));
+        const uint8_t* src = glob ? b->g_rows + (q - b->g_q0) * row_bytes : b->counts.p + q * row_bytes;
+        if (row_bytes)
+            HIP_TRY(hipMemcpy(b->h_rows.p, src, (q1 - q) * row_bytes, hipMemcpyDeviceToHost));
+        b->rows_q0 = q;
+        b->rows_q1 = q1;
+    }
+    *row = b->h_rows.p + (q - b->rows_q0) * row_bytes;
+    return COBS_GPU_OK;
+}
+
+static inline uint32_t score_at(const uint8_t* row, uint32_t elem_bytes, uint64_t i) {
+    if (elem_bytes == 1) return row[i];
+    if (elem_bytes == 2) return reinterpret_cast<const uint16_t*>(row)[i];
+    return reinterpret_cast<const uint32_t*>(row)[i];
+}
+
+// local count row of query q, widened to u32, scattered into a global-layout vector
+cobs_gpu_status fetch_counts(cobs_gpu_batch* b, size_t q, uint32_t* counts) {
+    cobs_gpu_index* ix = b->ix;
+    if (!b->have_counts) return fail(COBS_GPU_ERR_ARG, "the last run did not keep the score rows");
+    const uint8_t* raw = nullptr;
+    cobs_gpu_status st = fetch_row(b, q, &raw);
+    if (st != COBS_GPU_OK) return st;
+    if (b->view_global) {
+        for (uint64_t i = 0; i < ix->total_counts; ++i) counts[i] = score_at(raw, b->elem_bytes, i);
+        return COBS_GPU_OK;
+    }
+    std::fill(counts, counts + ix->total_counts, 0u);
+    for (const Part& p : ix->parts) {
+        uint32_t* dst = counts + p.doc_offset + p.slot_begin;
+        if (b->elem_bytes == 1) {
+            const uint8_t* s = raw + p.local_offset;
+            for (uint64_t i = 0; i < p.slot_count; ++i) dst[i] = s[i];
+        } else if (b->elem_bytes == 2) {
+            const uint16_t* s = reinterpret_cast<const uint16_t*>(raw) + p.local_offset;
+            for (uint64_t i = 0; i < p.slot_count; ++i) dst[i] = s[i];
+        } else {
+            const uint32_t* s = reinterpret_cast<const uint32_t*>(raw) + p.local_offset;
+            for (uint64_t i = 0; i < p.slot_count; ++i) dst[i] = s[i];
+        }
+    }
+    return COBS_GPU_OK;
+}
+
+// counts_to_result over a whole score row (threshold <= 0: every document is a result):
+// the result order (score desc, then (file, doc) asc; classic_search.cpp:134-145, :179-188) is a
+// stable counting sort by score of the documents taken in (file, doc) order -- O(documents),
+// where std::partial_sort of 100 000 documents costs ~9 ms per query.  Writes the first `want`
+// results straight into `hits` (when it is large enough) and returns their number.
+// (rank_raw touches nothing of the batch but `hist`: several host threads rank different queries of
+// one row window at the same time, see rank_window)
+static cobs_gpu_status rank_raw(const cobs_gpu_batch* b, size_t q, const uint8_t* raw, std::vector<uint32_t>& hist,
+                                size_t num_results, cobs_gpu_hit* hits, size_t cap, size_t* n_hits) {
+    const cobs_gpu_index* ix = b->ix;
+    const uint32_t eb = b->elem_bytes;
+    const bool glob = b->view_global;
+    const bool by_score = total_hashes(b, q) > 1;       // max_counts <= 1: index order, no sort (:134, :177)
+    // pass 1: passing documents per score
+    uint64_t max_score = 0;
+    for (const Part& p : ix->parts)
+        max_score = std::max<uint64_t>(max_score, (uint64_t)b->lens[q] - p.meta.term_size + 1);
+    if (max_score > (1u << 24)) return COBS_GPU_ERR_UNSUPPORTED;      // caller falls back to the generic sort
+    hist.assign((size_t)max_score + 2, 0u);
+    size_t passing = 0;
+    for (size_t f = 0; f < ix->parts.size(); ++f) {
+        const Part& p = ix->parts[f];
+        const uint32_t thr = threshold_for(b->threshold, (uint64_t)b->lens[q] - p.meta.term_size + 1);
+        const uint64_t d0 = glob ? 0 : p.slot_begin;
+        const uint64_t d1 = glob ? p.meta.doc_names.size()
+                                 : std::min<uint64_t>(p.slot_begin + p.slot_count, p.meta.doc_names.size());
+        const uint64_t base = glob ? p.doc_offset : p.local_offset;
+        for (uint64_t d = d0; d < d1; ++d) {
+            const uint32_t s = score_at(raw, eb, base + d - d0);
+            if (s >= thr) { ++hist[by_score ? std::min<uint64_t>(s, max_score) : 0]; ++passing; }
+        }
+    }
+    size_t want = num_results == 0 ? (size_t)ix->total_counts : std::min<size_t>(num_results, (size_t)ix->total_counts);
+    want = std::min(want, passing);
+    *n_hits = want;
+    if (want > cap) return fail(COBS_GPU_ERR_CAPACITY, "hit buffer too small");
+    if (want && !hits) return fail(COBS_GPU_ERR_ARG, "NULL hit buffer");
+    // start position of every score, highest first
+    uint32_t pos = 0;
+    for (size_t s = hist.size(); s-- > 0;) {
+        const uint32_t c = hist[s];
+        hist[s] = pos;
+        pos += c;
+    }
+    // pass 2: scatter in (file, doc) order; positions >= want are dropped
+    for (size_t f = 0; f < ix->parts.size(); ++f) {
+        const Part& p = ix->parts[f];
+        const uint32_t thr = threshold_for(b->threshold, (uint64_t)b->lens[q] - p.meta.term_size + 1);
+        const uint64_t d0 = glob ? 0 : p.slot_begin;
+        const uint64_t d1 = glob ? p.meta.doc_names.size()
+                                 : std::min<uint64_t>(p.slot_begin + p.slot_count, p.meta.doc_names.size());
+        const uint64_t base = glob ? p.doc_offset : p.local_offset;
+        for (uint64_t d = d0; d < d1; ++d) {
+            const uint32_t s = score_at(raw, eb, base + d - d0);
+            if (s < thr) continue;
+            const uint32_t at = hist[by_score ? std::min<uint64_t>(s, max_score) : 0]++;
+            if (at < want) hits[at] = cobs_gpu_hit{(uint32_t)f, (uint32_t)d, s};
+        }
+    }
+    return COBS_GPU_OK;
+}
+
+static cobs_gpu_status rank_row(cobs_gpu_batch* b, size_t q, size_t num_results, cobs_gpu_hit* hits, size_t cap,
+                                size_t* n_hits) {
+    if (!b->have_counts) return fail(COBS_GPU_ERR_ARG, "the last run did not keep the score rows");
+    const uint8_t* raw = nullptr;
+    cobs_gpu_status st = fetch_row(b, q, &raw);
+    if (st != COBS_GPU_OK) return st;
+    return rank_raw(b, q, raw, b->rank_hist, num_results, hits, cap, n_hits);
+}
+
+// The reference's default call (threshold 0, no limit) ranks EVERY document of every query: with
+// thousands of queries per pass that is host work worth spreading.  Queries [q0, q1) of the last run,
+// every one yielding exactly `per_query` hits (threshold <= 0: all real documents pass), written to
+// hits + (q - q0) * per_query by up to 16 host threads, one row window (one DMA) at a time.
+cobs_gpu_status rank_window(cobs_gpu_batch* b, size_t q0, size_t q1, size_t per_query, cobs_gpu_hit* hits) {
+    const size_t row_bytes = (size_t)(b->ix->local_counts * b->elem_bytes);
+    for (size_t q = q0; q < q1;) {
+        const uint8_t* raw0 = nullptr;
+        cobs_gpu_status st = fetch_row(b, q, &raw0);               // loads the window that starts at q
+        if (st != COBS_GPU_OK) return st;
+        const size_t qe = std::min(q1, b->rows_q1);
+        const unsigned nthr = (unsigned)std::min<size_t>(std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())), qe - q);
+        std::vector<cobs_gpu_status> res(nthr, COBS_GPU_OK);
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nthr; ++t)
+            pool.emplace_back([=, &res]() {
+                std::vector<uint32_t> hist;
+                for (size_t i = q + t; i < qe; i += nthr) {
+                    size_t n = 0;
+                    const cobs_gpu_status r = rank_raw(b, i, raw0 + (i - q) * row_bytes, hist, 0, hits + (i - q0) * per_query,
+                                                       per_query, &n);
+                    if (r != COBS_GPU_OK || n != per_query) { res[t] = r != COBS_GPU_OK ? r : COBS_GPU_ERR_ARG; return; }
+                }
+            });
+        for (auto& th : pool) th.join();
+        for (cobs_gpu_status r : res)
+            if (r != COBS_GPU_OK) return r == COBS_GPU_ERR_UNSUPPORTED ? r : fail(r, "ranking a row window failed");
+        q = qe;
+    }
+    return COBS_GPU_OK;
+}
+
+static cobs_gpu_status hits_host_impl(cobs_gpu_batch* b, size_t q, size_t num_results,
+                                      cobs_gpu_hit* hits, size_t cap, size_t* n_hits) {
+    if (!b || !n_hits) return fail(COBS_GPU_ERR_ARG, "NULL argument");
+    if (!b->ran || !b->synced) return fail(COBS_GPU_ERR_ARG, "run and sync the batch first");
+    if (q >= b->nq) return fail(COBS_GPU_ERR_ARG, "query number out of range");
+    cobs_gpu_index* ix = b->ix;
+    HIP_TRY(hipSetDevice(ix->device));
+    std::vector<cobs_gpu_hit>& sel = b->sel_scratch;     // reused: no allocation per query
+    sel.clear();
+    const bool pool_ok = b->selected && (b->pool_global || b->h_nhits() <= b->hit_cap);
+    const bool topk_ok = b->topk_k > 0 && num_results > 0 && num_results <= b->topk_k && total_hashes(b, q) > 1;
+    if (topk_ok) {
+        // K3 left the k best documents of every file on the device: fetch once, merge per query
+        const size_t k = b->topk_k, nparts = ix->parts.size();
+        if (!b->topk_fetched) {
+            b->h_topk.resize(k * b->nq * nparts);
+            b->h_topk_cnt.resize(b->nq * nparts);
+            if (b->graph_run && b->h_res.p) {
+                std::memcpy(b->h_topk_cnt.data(), b->h_res.p + 16, 4 * b->h_topk_cnt.size());
+                std::memcpy(b->h_topk.data(), b->h_res.p + b->res_topk, sizeof(uint2) * b->h_topk.size());
+            } else {
+                HIP_TRY(hipMemcpy(b->h_topk.data(), b->topk_out.p, sizeof(uint2) * b->h_topk.size(), hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(b->h_topk_cnt.data(), b->topk_cnt.p, 4 * b->h_topk_cnt.size(), hipMemcpyDeviceToHost));
+            }
+            b->topk_fetched = true;
+        }
+        const size_t stride = b->topk_stride ? b->topk_stride : k;     // ranks * k after an exchange
+        if (nparts == 1 && b->topk_sorted && !b->topk_stride) {
+            // one file, one shard: K3 already left the survivors in result order
+            const uint2* e = b->h_topk.data() + q * k;
+            const size_t want1 = std::min<size_t>(std::min<size_t>(num_results, (size_t)ix->total_counts), b->h_topk_cnt[q]);
+            *n_hits = want1;
+            if (want1 > cap) return fail(COBS_GPU_ERR_CAPACITY, "hit buffer too small");
+            if (want1 && !hits) return fail(COBS_GPU_ERR_ARG, "NULL hit buffer");
+            for (size_t i = 0; i < want1; ++i) hits[i] = cobs_gpu_hit{0u, e[i].x, e[i].y};
+            return COBS_GPU_OK;
+        }
+        for (size_t f = 0; f < nparts; ++f) {
+            const uint2* e = b->h_topk.data() + (f * b->nq + q) * stride;
+            const uint32_t cnt = b->h_topk_cnt[f * b->nq + q];
+            for (uint32_t i = 0; i < cnt; ++i) sel.push_back(cobs_gpu_hit{(uint32_t)f, e[i].x, e[i].y});
+        }
+    } else if (pool_ok) {
+        if (!b->pool_fetched) {
+            // the pool arrives in arbitrary order: bucket it by query with a counting scatter
+            std::vector<HitDev> raw((size_t)b->h_nhits());
+            if (!raw.empty()) {
+                if (b->graph_run && b->h_res.p && raw.size() <= b->res_pool_n)
+                    std::memcpy(raw.data(), b->h_res.p + b->res_pool, sizeof(HitDev) * raw.size());
+                else
+                    HIP_TRY(hipMemcpy(raw.data(), b->hits.p, sizeof(HitDev) * raw.size(), hipMemcpyDeviceToHost));
+            }
+            b->h_hit_off.assign(b->nq + 1, 0);
+            for (const HitDev& h : raw) b->h_hit_off[h.query + 1]++;
+            for (size_t i = 0; i < b->nq; ++i) b->h_hit_off[i + 1] += b->h_hit_off[i];
+            b->h_hits.resize(raw.size());
+            std::vector<size_t> cur(b->h_hit_off.begin(), b->h_hit_off.end() - 1);
+            for (const HitDev& h : raw) b->h_hits[cur[h.query]++] = h;
+            b->pool_fetched = true;
+        }
+        for (size_t i = b->h_hit_off[q]; i < b->h_hit_off[q + 1]; ++i)
+            sel.push_back(cobs_gpu_hit{b->h_hits[i].part, b->h_hits[i].doc, b->h_hits[i].score});
+    } else {
+        // threshold <= 0 (every document is a hit) or pool overflow: rank the score row on the host
+        cobs_gpu_status rs = rank_row(b, q, num_results, hits, cap, n_hits);
+        if (rs != COBS_GPU_ERR_UNSUPPORTED) return rs;
+        // scores too wide for a counting sort: generic path
+        std::vector<uint32_t> counts((size_t)ix->total_counts);
+        cobs_gpu_status st = fetch_counts(b, q, counts.data());
+        if (st != COBS_GPU_OK) return st;
+        for (size_t f = 0; f < ix->parts.size(); ++f) {
+            const Part& p = ix->parts[f];
+            const uint32_t thr = threshold_for(b->threshold, (uint64_t)b->lens[q] - p.meta.term_size + 1);
+            // only documents whose slots this shard computed
+            const uint64_t d0 = b->view_global ? 0 : p.slot_begin;
+            const uint64_t d1 = b->view_global ? p.meta.doc_names.size()
+                                               : std::min<uint64_t>(p.slot_begin + p.slot_count, p.meta.doc_names.size());
+            for (uint64_t d = d0; d < d1; ++d) {
+                const uint32_t s = counts[p.doc_offset + d];
+                if (s >= thr) sel.push_back(cobs_gpu_hit{(uint32_t)f, (uint32_t)d, s});
+            }
+        }
+    }
+    // classic_search.cpp:450-451,134-145
+    size_t want = num_results == 0 ? (size_t)ix->total_counts : std::min<size_t>(num_results, (size_t)ix->total_counts);
+    want = std::min(want, sel.size());
+    if (total_hashes(b, q) > 1)
+        std::partial_sort(sel.begin(), sel.begin() + want, sel.end(), hit_before);
+    else
+        std::partial_sort(sel.begin(), sel.begin() + want, sel.end(), doc_before);
+    *n_hits = want;
+    if (want > cap) return fail(COBS_GPU_ERR_CAPACITY, "hit buffer too small");
+    if (want && !hits) return fail(COBS_GPU_ERR_ARG, "NULL hit buffer");
+    std::copy(sel.begin(), sel.begin() + want, hits);
+    return COBS_GPU_OK;
+}
+
+}  // namespace cobs_amd
+
+extern "C" {
+
+void* cobs_gpu_batch_counts_device(cobs_gpu_batch* b, uint32_t* elem_bytes, uint64_t* row_stride_bytes) {
+    if (!b) return nullptr;
+    if (elem_bytes) *elem_bytes = b->elem_bytes;
+    if (row_stride_bytes) *row_stride_bytes = b->ix->local_counts * b->elem_bytes;
+    // the rows are allocated lazily (see run_impl); a caller that asks for them before the first
+    // run (to size an exchange buffer, say) gets them now
+    if (hipSetDevice(b->ix->device) != hipSuccess ||
+        b->counts.reserve((size_t)(b->nq * b->ix->local_counts * b->elem_bytes)) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return b->counts.p;
+}
+
+cobs_gpu_status cobs_gpu_batch_counts_host(cobs_gpu_batch* b, size_t q, uint32_t* counts, size_t cap) {
+    if (!b || !counts) return fail(COBS_GPU_ERR_ARG, "NULL argument");
+    if (!b->ran || !b->synced) return fail(COBS_GPU_ERR_ARG, "run and sync the batch first");
+    if (q >= b->nq) return fail(COBS_GPU_ERR_ARG, "query number out of range");
+    if (cap < b->ix->total_counts) return fail(COBS_GPU_ERR_CAPACITY, "counts buffer too small");
+    HIP_TRY(hipSetDevice(b->ix->device));
+    return fetch_counts(b, q, counts);
+}
+
+cobs_gpu_status cobs_gpu_batch_hits_host(cobs_gpu_batch* b, size_t q, size_t num_results,
+                                         cobs_gpu_hit* hits, size_t cap, size_t* n_hits) {
+    return guarded([&]() { return hits_host_impl(b, q, num_results, hits, cap, n_hits); });
+}
+
+}  // extern "C"
