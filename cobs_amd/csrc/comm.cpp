@@ -569,9 +569,12 @@ cobs_gpu_status cobs_gpu_sharded_search_batch(cobs_gpu_index* ix, cobs_gpu_comm*
                 ++g1;
             }
             size_t bad = 0;
+            // no score rows for a pass that selects on the device: hits into the pool, or -- with a limit -- the
+            // k best of every tile (run_impl keeps the rows anyway where that does not apply, e.g. a query with
+            // a single hash in total; b->have_counts says which)
             const bool hits_only = threshold > 0.0 && topk == 0;
             cobs_gpu_status s = set_queries_on(b, queries + g0, lens + g0, g1 - g0, st, false, &bad, g0);
-            if (s == COBS_GPU_OK) s = run_impl(b, threshold, topk, st, !hits_only);
+            if (s == COBS_GPU_OK) s = run_impl(b, threshold, topk, st, !(hits_only || topk > 0));
             if (s == COBS_GPU_OK) {
                 s = cobs_gpu_batch_sync(b, st, &bad);
                 if (s == COBS_GPU_ERR_INVALID_BASE)       // the message names the query by its index in the call
@@ -582,15 +585,17 @@ cobs_gpu_status cobs_gpu_sharded_search_batch(cobs_gpu_index* ix, cobs_gpu_comm*
             // Every rank must know whether the scan went through EVERYWHERE before anybody enters the
             // exchange: a rank that failed alone (out of memory, ...) would leave the others waiting in
             // a collective.  (Bad input fails identically on all ranks; this covers the rest.)
-            {
-                const std::string keep = s != COBS_GPU_OK ? std::string(cobs_gpu_last_error()) : std::string();
+            auto all_ranks_ok = [&](cobs_gpu_status mine) -> cobs_gpu_status {
+                const std::string keep = mine != COBS_GPU_OK ? std::string(cobs_gpu_last_error()) : std::string();
                 uint32_t worst = 0;
-                const cobs_gpu_status as = agree(c, b, st, (uint32_t)s, &worst);
-                if (s != COBS_GPU_OK) return fail(s, keep);
+                const cobs_gpu_status as = agree(c, b, st, (uint32_t)mine, &worst);
+                if (mine != COBS_GPU_OK) return fail(mine, keep);
                 if (as != COBS_GPU_OK) return as;
                 if (worst != COBS_GPU_OK)
                     return fail(COBS_GPU_ERR_RCCL, "the pass failed on another rank (status " + std::to_string(worst) + ")");
-            }
+                return COBS_GPU_OK;
+            };
+            if ((s = all_ranks_ok(s)) != COBS_GPU_OK) return s;
             bool need_rows = !hits_only && b->topk_k == 0;
             if (b->topk_k) {
                 s = cobs_gpu_batch_exchange_topk(b, c, st);
@@ -605,9 +610,10 @@ cobs_gpu_status cobs_gpu_sharded_search_batch(cobs_gpu_index* ix, cobs_gpu_comm*
                 if (s != COBS_GPU_OK) return s;
                 if (over) {     // some shard selected more hits than the pool holds: score rows instead
                     s = run_impl(b, threshold, topk, st, true);
-                    if (s != COBS_GPU_OK) return s;
-                    s = cobs_gpu_batch_sync(b, st, &bad);
-                    if (s != COBS_GPU_OK) return s;
+                    if (s == COBS_GPU_OK) s = cobs_gpu_batch_sync(b, st, &bad);
+                    // the repeated pass may fail on one rank alone (its score rows did not fit, ...): agree
+                    // again before the row exchange, or the others wait in that collective for ever
+                    if ((s = all_ranks_ok(s)) != COBS_GPU_OK) return s;
                     b->selected = false;
                     need_rows = true;
                 }

@@ -350,6 +350,7 @@ void fasta_terms(const View& d, uint32_t k, TermSink& out) {
         held = 0;
     };
     for_lines(d, 0, [&](const char* ln, size_t n, size_t) {
+        if (out.overflow) return false;      // the sink is full (the file grew since it was listed): `held` would outrun out.size
         const size_t size = held + n;
         bool comment;
         if (size == pos) comment = true;
@@ -685,6 +686,9 @@ uint64_t term_text_bound(const DocEntry& e, uint32_t k) {
 
 cobs_gpu_status load_terms(const DocEntry& e, uint32_t k, TermSink& out, std::vector<TermSeg>& segs, std::string& scratch) {
     if (k == 0) return err(COBS_GPU_ERR_ARG, "term size 0");
+    // a text file is read through a 64 KiB buffer that carries k - 1 characters over: with k near the buffer size
+    // the term text (and its bound) grows to ~ size x k
+    if (e.type == FileType::Text && k > 32 * 1024) return err(COBS_GPU_ERR_UNSUPPORTED, "term size above 32768 for text documents");
     FileBytes fb;
     const View& d = fb.v;
     cobs_gpu_status st = COBS_GPU_OK;

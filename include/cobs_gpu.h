@@ -266,6 +266,9 @@ cobs_gpu_status cobs_gpu_batch_kernel_ms(cobs_gpu_batch* b, float* scan_ms, floa
  * The launcher (torch.distributed, MPI, threads of one process...) only has to hand the unique id
  * from rank 0 to the others.  All calls below are collective: every rank makes the same call.  */
 #define COBS_GPU_UNIQUE_ID_BYTES 128
+/* Side effect of the two calls below: RCCL prints a version banner to stdout when a process first initialises
+ * it; while they run, file descriptor 1 of the PROCESS points at stderr (and is put back afterwards), so that the
+ * caller's stdout stays clean -- output other threads write to stdout in that window lands on stderr. */
 cobs_gpu_status cobs_gpu_comm_unique_id(uint8_t id[COBS_GPU_UNIQUE_ID_BYTES]);          /* ncclGetUniqueId */
 cobs_gpu_status cobs_gpu_comm_create(const uint8_t id[COBS_GPU_UNIQUE_ID_BYTES], int rank, int nranks,
                                      int device /* -1 = current */, cobs_gpu_comm** out);  /* ncclCommInitRank */
