@@ -224,6 +224,7 @@ struct cobs_gpu_batch {
     // staging buffer / ONE device buffer (`text`): a batch is uploaded with a single async copy
     const uint64_t* d_span_off = nullptr;
     const uint32_t* d_qlen = nullptr;
+    const uint8_t* d_text = nullptr;      // query characters (behind the tables in `text`)
     cobs_amd::PinnedBuf<uint8_t> h_text;
     cobs_amd::PinnedBuf<uint32_t> h_thr_stage;
     std::vector<cobs_amd::PartWork> work;
@@ -334,6 +335,7 @@ std::string& last_error_text();
 
 // ---- pass.cpp
 uint64_t gathered_row_bytes(const Part& p);
+uint64_t pass_shape_class(const cobs_gpu_batch* b);
 void set_run_state(cobs_gpu_batch* b, double threshold, size_t topk, bool want_counts);
 void stage_thresholds(cobs_gpu_batch* b, double threshold);
 

@@ -53,17 +53,18 @@ static cobs_gpu_status host_pass_begin(cobs_gpu_index* ix, int slot, const char*
     const bool hits_only = (threshold > 0.0 && topk == 0) || topk > 0;
     // Small calls (a single query is the reference's own entry point, search.hpp:39-42) are
     // launch-bound: fill + K1 + K2 (+ K3) are four launches for ~15 us of work.  The second time
-    // the same shape comes along (same query lengths, parameters and buffers) the pass is captured
+    // a pass of the same shape class comes along (pass_shape_class: query count, score planes, launch geometry --
+    // not the exact lengths --, same parameters and buffers) it is captured
     // into a hipGraph and from then on replayed with one launch.
     bool any_streamed = false;
     for (const auto& p : ix->parts) any_streamed = any_streamed || p.streamed;
     if (nq > 0 && nq <= 16 && ix->tune.graph != 0 && !any_streamed && !ix->tune.phase_slots) {
-        // the shape of the pass and every address the captured nodes hold
+        // the shape class of the pass and every address the captured nodes hold
         auto make_key = [&]() {
             uint64_t key = 1469598103934665603ull;
             auto mixin = [&](uint64_t v) { key = (key ^ v) * 1099511628211ull; };
             mixin(nq);
-            for (size_t q = 0; q < nq; ++q) mixin(lens[q]);
+            mixin(pass_shape_class(b));       // not the exact lengths: one graph per shape class
             uint64_t tb;
             std::memcpy(&tb, &threshold, 8);
             mixin(tb); mixin(topk); mixin(hits_only);

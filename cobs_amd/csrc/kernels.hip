@@ -137,7 +137,8 @@ __device__ uint64_t xxh64_view(const KmerView& kv, uint64_t seed) {
 template <typename IdxT>
 __global__ __launch_bounds__(256) void hash_kernel(HashArgs a, uint64_t total_threads) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total_threads) return;
+    // the grid may be larger than the batch needs (a captured launch is replayed for other query lengths)
+    if (gid >= total_threads || gid >= a.span_off[a.nq]) return;
     // query of this thread: last q with span_off[q] <= gid
     uint32_t lo = 0, hi = a.nq;
     while (hi - lo > 1) {
@@ -260,7 +261,7 @@ __device__ __forceinline__ void canon31(const uint32_t (&f)[8], uint32_t (&c)[8]
 template <typename IdxT>
 __global__ __launch_bounds__(256) void hash_kernel_k31(HashArgs a, uint64_t total_threads) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total_threads) return;
+    if (gid >= total_threads || gid >= a.span_off[a.nq]) return;
     uint32_t lo = 0, hi = a.nq;
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;

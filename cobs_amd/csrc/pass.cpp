@@ -127,20 +127,27 @@ cobs_gpu_status cobs_amd::set_queries_on(cobs_gpu_batch* b, const char* const* q
         off += round_up(span, 8);
     }
     b->span_off[nq] = off;
-    // upload layout: text (+ 64: K1 reads whole dwords around a k-mer) | span_off | q_len | blk_off per file
-    const size_t o_span = (size_t)round_up(off + 64, 16);
+    // upload layout: span_off | q_len | blk_off per file | text (+ 64: K1 reads whole dwords around a k-mer).
+    // The tables come first so that their device addresses depend on the NUMBER of queries only, not on their
+    // lengths: a captured graph of a small pass (host_api.cpp) bakes those addresses in and is replayed for
+    // every batch of its shape class, whatever the exact lengths.
+    const size_t o_span = 0;
     const size_t o_qlen = o_span + (size_t)round_up(8 * (nq + 1), 16);
     const size_t o_blk = o_qlen + (size_t)round_up(4 * std::max<size_t>(nq, 1), 16);
     const size_t blk_stride = (size_t)round_up(8 * (nq + 1), 16);
-    const size_t upload_bytes = o_blk + blk_stride * ix->parts.size();
-    HIP_TRY(b->h_text.reserve(upload_bytes));
-    HIP_TRY(b->text.reserve(upload_bytes));
-    std::memset(b->h_text.p, 0, o_span);
-    for (size_t q = 0; q < nq; ++q) std::memcpy(b->h_text.p + b->span_off[q], queries[q], lens[q]);
+    const size_t o_text = o_blk + blk_stride * ix->parts.size();
+    const size_t upload_bytes = o_text + (size_t)round_up(off + 64, 16);
+    // small passes keep one allocation across lengths (a grown buffer would re-key their graphs)
+    const size_t upload_cap = nq <= 16 ? std::max<size_t>(upload_bytes, 256u << 10) : upload_bytes;
+    HIP_TRY(b->h_text.reserve(upload_cap));
+    HIP_TRY(b->text.reserve(upload_cap));
+    std::memset(b->h_text.p + o_text, 0, upload_bytes - o_text);
+    for (size_t q = 0; q < nq; ++q) std::memcpy(b->h_text.p + o_text + b->span_off[q], queries[q], lens[q]);
     std::memcpy(b->h_text.p + o_span, b->span_off.data(), 8 * (nq + 1));
     if (nq) std::memcpy(b->h_text.p + o_qlen, b->lens.data(), 4 * nq);
     b->d_span_off = reinterpret_cast<const uint64_t*>(b->text.p + o_span);
     b->d_qlen = reinterpret_cast<const uint32_t*>(b->text.p + o_qlen);
+    b->d_text = b->text.p + o_text;
 
     uint64_t algo_bytes = 0, lookups = 0, table_bytes = 0;
     for (size_t f = 0; f < ix->parts.size(); ++f) {
@@ -162,7 +169,8 @@ cobs_gpu_status cobs_amd::set_queries_on(cobs_gpu_batch* b, const char* const* q
         w.table_entries = (blk + nq) * 8 * p.meta.num_hashes * p.num_tpages() * idx_words;
         table_bytes += w.table_entries * 4;
         if (w.table_entries >= (1ull << 40)) return fail(COBS_GPU_ERR_CAPACITY, "batch too large");
-        HIP_TRY(w.table.reserve((size_t)w.table_entries));
+        // (small passes: room for longer queries of the same class, so that the table keeps its address)
+        HIP_TRY(w.table.reserve(nq <= 16 ? std::max<size_t>((size_t)w.table_entries, 1u << 18) : (size_t)w.table_entries));
         HIP_TRY(w.thr.reserve(nq));
         std::memcpy(b->h_text.p + o_blk + f * blk_stride, w.h_blk_off.data(), 8 * (nq + 1));
         w.blk_off = reinterpret_cast<const uint64_t*>(b->text.p + o_blk + f * blk_stride);
@@ -191,6 +199,31 @@ extern "C" cobs_gpu_status cobs_gpu_batch_set_queries(cobs_gpu_batch* b, const c
 // want_counts = false: the caller only needs the selected hits (threshold > 0, no top-k), so the
 // scan does not write the score rows (for reads they are up to a third of the traffic).
 // what a run leaves behind on the host side of the batch (a replayed graph sets the same)
+// The shape class of the batch's pass: everything a captured graph of it bakes in besides buffer addresses --
+// the number of queries, the score planes, K1's (rounded) grid, every chunk's launch geometry, and whether some
+// query has a single hash in total (such a batch keeps its score rows in a top-k pass).  Batches of one class
+// differ in their query lengths only, which the kernels read from device tables: one graph serves them all.
+uint64_t cobs_amd::pass_shape_class(const cobs_gpu_batch* b) {
+    const cobs_gpu_index* ix = b->ix;
+    uint64_t key = 1469598103934665603ull;
+    auto mixin = [&](uint64_t v) { key = (key ^ v) * 1099511628211ull; };
+    const size_t nq = b->nq;
+    mixin(nq); mixin((uint64_t)b->planes); mixin(b->elem_bytes);
+    mixin(round_up(nq ? b->span_off[nq] : 0, 1024));
+    bool single = false;
+    for (size_t q = 0; q < nq && !single; ++q) single = total_hashes(b, q) <= 1;
+    mixin(single);
+    for (size_t f = 0; f < ix->parts.size() && nq; ++f) {
+        const Part& p = ix->parts[f];
+        for (const Chunk& c : p.chunks) {
+            const ScanGeom g = scan_geometry(c, b->work[f].h_blk_off[nq] / nq, (b->max_terms + 7) / 8, p.meta.num_hashes,
+                                             ix->waves_per_group, b->planes, p.idx64, ix->tune);
+            mixin(g.tile_w); mixin((uint64_t)g.nwaves); mixin(g.multi_query);
+        }
+    }
+    return key;
+}
+
 void cobs_amd::set_run_state(cobs_gpu_batch* b, double threshold, size_t topk, bool want_counts) {
     cobs_gpu_index* ix = b->ix;
     b->ran = false;
@@ -295,7 +328,7 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
         {   // K1 once per file and pass: the row-index table covers every held sub-index,
             // the chunks (launches) of the file pick their sub-indexes by PageDev::tpage
             HashArgs ha;
-            ha.text = b->text.p;
+            ha.text = b->d_text;
             ha.span_off = b->d_span_off;
             ha.q_len = b->d_qlen;
             ha.blk_off = b->work[f].blk_off;
@@ -308,7 +341,9 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
             ha.canonicalize = p.meta.canonicalize;
             ha.num_hashes = (uint32_t)p.meta.num_hashes;
             ha.idx64 = p.idx64 ? 1u : 0u;
-            HIP_TRY(launch_hash(ha, b->span_off[nq], st));
+            // (the kernel bounds itself by span_off[nq] on the device; the grid is rounded up so that a
+            // captured launch serves every batch of its shape class)
+            HIP_TRY(launch_hash(ha, round_up(b->span_off[nq], 1024), st));
             if (!hash_marked) {      // K1 / K2 split of the timing events: first file only
                 HIP_TRY(hipEventRecord(ev[1], st));
                 hash_marked = true;

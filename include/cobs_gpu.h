@@ -332,7 +332,8 @@ cobs_gpu_status cobs_gpu_sharded_search_batch(cobs_gpu_index* ix, cobs_gpu_comm*
 cobs_gpu_status cobs_gpu_batch_phase_stamps(cobs_gpu_batch* b, uint64_t* out, size_t cap_words, size_t* n_words);
 
 /* Small calls of the host-buffer API (up to 16 queries) are captured into a hipGraph the second time
- * the same shape (query lengths, parameters) comes along and replayed with one launch afterwards;
+ * a pass of the same shape class (query count, score width, launch geometry -- not the exact query lengths --, same
+ * parameters) comes along and replayed with one launch afterwards;
  * this counts the replays (diagnostics; tuning key "graph" = 0 turns the path off). */
 uint64_t cobs_gpu_graph_replays(const cobs_gpu_index* ix);
 

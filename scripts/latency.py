@@ -66,6 +66,20 @@ for g in (0, -1):
     print("nq=    1  four query lengths in rotation, graph %s: %7.1f us per call (%d of 400 calls replayed)"
           % ("off" if g == 0 else "on ", host * 1e6, s.graph_replays - r0), flush=True)
 
+# single queries of TWENTY lengths of one shape class (131..150 bp) in rotation: graphs are keyed by shape class
+for g in (0, -1):
+    s.set_tuning("graph", g)
+    many = [qs[i][:131 + i] for i in range(20)]
+    for i in range(40):
+        s.search_hits([many[i % 20]], 0.0, 10)
+    r0 = s.graph_replays
+    t0 = time.perf_counter()
+    for i in range(400):
+        s.search_hits([many[i % 20]], 0.0, 10)
+    host = (time.perf_counter() - t0) / 400
+    print("nq=    1  twenty query lengths of one shape class in rotation, graph %s: %7.1f us per call (%d of 400 calls replayed)"
+          % ("off" if g == 0 else "on ", host * 1e6, s.graph_replays - r0), flush=True)
+
 # the reference's default call, search(query) = threshold 0, num_results 0: EVERY document ranked.
 # On the device (rank_kernels.hip: the ordered records cross PCIe) vs by host threads (the score rows cross);
 # into a fresh result array per call vs into one the caller keeps (no page faults on 307 MB).

@@ -671,6 +671,31 @@ def test_graph_replay_of_two_thresholded_shapes(gpu_lib, oracle, tmp_path):
         assert s.graph_replays - r0 >= 6            # every shape was replayed (buffers that grow re-key a shape once)
 
 
+def test_one_graph_serves_a_class_of_query_lengths(gpu_lib, oracle, tmp_path):
+    """graphs are keyed by shape class (query count, score planes, launch geometry), not by exact lengths: single
+    queries of twenty different lengths (131..150 bp: one class) are served by ONE captured graph -- lengths,
+    block counts and thresholds ceil(t * T) reach the kernels through device tables, not through the graph"""
+    q_long = oracle.random_sequence(400, 123)
+    p = cases.make_compact(cases.tmp(tmp_path, "g4.cobs_compact"), 2000, 64, [900, 1000, 1100, 1200], 1, 31, 1,
+                           0.3, 8, planted={3: 1.0, 11: 0.8, 500: 0.62, 1999: 0.45}, query=q_long)
+    ix = oracle.Index.open(p)
+    for t, lim in ((0.5, 0), (0.0, 7), (0.4, 3)):
+        s = gpu_lib.Search(p)
+        r0 = s.graph_replays
+        for rnd in range(2):
+            for L in range(131, 151):
+                q = q_long[rnd:rnd + L]
+                assert s.search_hits([q], t, lim) == [cases.oracle_results([ix], q, t, lim)], (t, lim, rnd, L)
+        assert s.graph_replays - r0 >= 36, (t, lim, s.graph_replays - r0)      # 40 calls: one plain, one capture, the rest replays
+    # two queries per call, lengths drawn independently
+    s = gpu_lib.Search(p)
+    r0 = s.graph_replays
+    for i in range(24):
+        qs = [q_long[i:i + 131 + (7 * i) % 20], q_long[2 * i:2 * i + 150 - (5 * i) % 20]]
+        assert s.search_hits(qs, 0.3, 5) == [cases.oracle_results([ix], q, 0.3, 5) for q in qs], i
+    assert s.graph_replays - r0 >= 18
+
+
 def test_default_call_in_batches_is_ranked_by_host_threads(gpu_lib, oracle, tmp_path):
     """threshold 0, no limit (the reference's default arguments) for MANY queries per call: the
     passes' score rows are ranked by several host threads -- every document, in the reference's
