@@ -425,13 +425,13 @@ def side_measurements(args, cfg, queries, world, rank, dev, comm):
             self.b.run_hits(0.8, 0)
             self.b.sync()
             if comm is not None:
-                self.b.exchange_hits(comm, 0)
+                self.b.exchange_hits_owned(comm, 0)
         def drop_warmup_events(self):
             self.b.kernel_ms()
         def finish(self):
             return self.b.kernel_ms()["scan_ms"], 0, 0, self.b.exchange_bytes() if comm is not None else 0
     measure("sharded_hits_threshold_0.8", HitsMode,
-            {"parallelism": "sharded as the headline; hits-only scan + sizes-first exchange of hit records"})
+            {"parallelism": "sharded as the headline; hits-only scan + sizes-first exchange of hit records, each to the rank that owns its query"})
 
     if args.config == "c3" and args.scale == 1.0:
         c4 = c4_config(args.scale)

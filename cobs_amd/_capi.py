@@ -163,6 +163,9 @@ SYMBOLS = {
     "cobs_gpu_batch_global_counts_device": (_vp, [_vp, _pu64, _pu64, C.POINTER(_u32), _pu64]),
     "cobs_gpu_batch_exchange_bytes": (_u64, [_vp]),
     "cobs_gpu_batch_exchange_hits": (_int, [_vp, _vp, _vp, C.POINTER(_int)]),
+    "cobs_gpu_batch_exchange_hits_owned": (_int, [_vp, _vp, _vp, C.POINTER(_int), _pu64, _pu64]),
+    "cobs_gpu_batch_bucketed_hits": (_int, [_vp, _u32, _pu64, C.POINTER(_u32), _sz, C.POINTER(_sz)]),
+    "cobs_gpu_hit_exchange_plan": (_int, [_pu64, _sz, _sz, C.POINTER(Xfer), _pu64]),
     "cobs_gpu_batch_exchange_topk": (_int, [_vp, _vp, _vp]),
     "cobs_gpu_sharded_search_batch": (_int, [_vp, _vp, C.POINTER(_cp), C.POINTER(_sz), _sz, _dbl, _sz,
                                              C.POINTER(Hit), _sz, C.POINTER(_sz), C.POINTER(_sz)]),

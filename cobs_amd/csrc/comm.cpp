@@ -17,7 +17,9 @@
 //                     same size, else grouped ncclSend/ncclRecv): N-1 times the traffic; the
 //                     parity / "every rank ranks everything" mode.
 //   hit lists         with a threshold only (query, file, doc, score) records leave a shard:
-//                     sizes first (ncclAllGather of the pool fills), then the records.
+//                     sizes first (ncclAllGather of the pool fills), then the records -- to every rank
+//                     (cobs_gpu_batch_exchange_hits), or each record once, to the rank that owns its query
+//                     (cobs_gpu_batch_exchange_hits_owned: bucketed on the device, xchg_kernels.hip).
 //   top-k             the k best of every shard (K3 output, same size on every rank):
 //                     one ncclAllGather; the global top-k is a subset of their union.
 //
@@ -58,6 +60,8 @@ struct Exchange {
     DevBuf<uint8_t> global;                      // assembled rows
     DevBuf<uint64_t> d_meta;                     // small device scratch for size exchanges
     DevBuf<HitDev> hits_all;                     // gathered hit pools
+    DevBuf<HitDev> hits_bucketed;                // this rank's pool, bucketed by the rank that owns each record's query
+    DevBuf<unsigned long long> d_cursor;         // [nranks] bucket counts / cursors
     DevBuf<uint2> topk_all;
     DevBuf<uint32_t> topk_cnt_all;
     uint64_t bytes_moved = 0;                    // bytes this rank received over the fabric in the last exchange
@@ -474,6 +478,160 @@ cobs_gpu_status cobs_gpu_batch_exchange_hits(cobs_gpu_batch* b, cobs_gpu_comm* c
             if (h.query < b->nq) b->h_hits[cur[h.query]++] = h;
         b->pool_fetched = true;
         b->pool_global = true;
+        return COBS_GPU_OK;
+    });
+}
+
+// The owner-routed hit exchange as a plan (host arithmetic): counts[r * nranks + j] = records rank r holds for the
+// queries rank j owns.  Rank `rank` sends bucket j of its bucketed pool to rank j and receives bucket `rank` of
+// every other rank; received records land rank after rank (its own bucket at its place).  Offsets / sizes in bytes.
+cobs_gpu_status cobs_gpu_hit_exchange_plan(const uint64_t* counts, size_t nranks, size_t rank, cobs_gpu_xfer* xfers,
+                                           uint64_t out[2]) {
+    if (!counts || !xfers || !out || nranks == 0 || rank >= nranks) return fail(COBS_GPU_ERR_ARG, "bad argument");
+    const uint64_t rec = sizeof(HitDev);
+    uint64_t send_off = 0, recv_off = 0;
+    for (size_t j = 0; j < nranks; ++j) {
+        cobs_gpu_xfer& x = xfers[j];
+        x.peer = j;
+        x.send_offset = send_off * rec;
+        x.send_bytes = counts[rank * nranks + j] * rec;
+        x.recv_offset = recv_off * rec;
+        x.recv_bytes = counts[j * nranks + rank] * rec;
+        send_off += counts[rank * nranks + j];
+        recv_off += counts[j * nranks + rank];
+    }
+    out[0] = recv_off * rec;        // bytes this rank ends up with (its own bucket included)
+    out[1] = send_off * rec;        // bytes of its bucketed pool
+    return COBS_GPU_OK;
+}
+
+// Hit lists routed to query owners: call after cobs_gpu_batch_sync of a run with a threshold.  Rank j owns the
+// queries [nq*j/N, nq*(j+1)/N) (as in the all-to-all exchange of count rows) and receives the records of
+// exactly those queries from every shard: each record crosses the fabric once, to one GPU, where
+// cobs_gpu_batch_exchange_hits sends every record to every rank.  Sizes first (one ncclAllGather of the
+// per-owner counts), then grouped ncclSend / ncclRecv.  *overflow as in cobs_gpu_batch_exchange_hits.
+cobs_gpu_status cobs_gpu_batch_exchange_hits_owned(cobs_gpu_batch* b, cobs_gpu_comm* c, void* hip_stream, int* overflow,
+                                                   uint64_t* q_begin, uint64_t* q_count) {
+    if (!b || !c) return fail(COBS_GPU_ERR_ARG, "NULL argument");
+    if (!b->ran || !b->synced || !b->selected)
+        return fail(COBS_GPU_ERR_ARG, "run the batch with a threshold and sync it first");
+    if (c->nranks > 64) return fail(COBS_GPU_ERR_UNSUPPORTED, "more than 64 ranks");
+    return guarded([&]() -> cobs_gpu_status {
+        hipStream_t st = (hipStream_t)hip_stream;
+        HIP_TRY(hipSetDevice(b->ix->device));
+        if (!b->xchg) b->xchg = new Exchange;
+        Exchange& x = *b->xchg;
+        const size_t N = (size_t)c->nranks, me = (size_t)c->rank;
+        const uint64_t q0 = (uint64_t)b->nq * me / N, q1 = (uint64_t)b->nq * (me + 1) / N;
+        if (q_begin) *q_begin = q0;
+        if (q_count) *q_count = q1 - q0;
+        const uint64_t mine = std::min<uint64_t>(b->h_nhits(), b->hit_cap);     // an overflowed pool is not routed (see below)
+        const bool over_here = b->h_nhits() > b->hit_cap;
+        // (1) records per owner on this rank
+        HIP_TRY(x.d_cursor.reserve(2 * N + 2));
+        HIP_TRY(hipMemsetAsync(x.d_cursor.p, 0, 8 * N, st));
+        BucketArgs ba;
+        ba.hits = b->hits.p;
+        ba.n = over_here ? 0 : mine;
+        ba.cursor = x.d_cursor.p;
+        ba.out = nullptr;
+        ba.nq = (uint32_t)b->nq;
+        ba.nranks = (uint32_t)N;
+        HIP_TRY(launch_bucket_hits(ba, true, st));
+        // (2) every rank's counts to every rank; an overflow travels as an impossible count
+        HIP_TRY(x.d_meta.reserve(N * (N + 1) + 64));
+        std::vector<unsigned long long> cnt(N, 0);
+        HIP_TRY(hipMemcpyAsync(cnt.data(), x.d_cursor.p, 8 * N, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (over_here) cnt[0] = ~0ull;
+        HIP_TRY(hipMemcpyAsync(x.d_meta.p, cnt.data(), 8 * N, hipMemcpyHostToDevice, st));
+        NCCL_TRY(ncclAllGather(x.d_meta.p, x.d_meta.p + N, 8 * N, ncclUint8, c->comm, st));
+        std::vector<uint64_t> all(N * N);
+        HIP_TRY(hipMemcpyAsync(all.data(), x.d_meta.p + N, 8 * N * N, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        bool over = false;
+        for (size_t r = 0; r < N; ++r) over = over || all[r * N] == ~0ull;
+        if (overflow) *overflow = over ? 1 : 0;
+        if (over) return COBS_GPU_OK;           // every rank sees the same flag and repeats the pass with score rows
+        // (3) bucket the pool: cursors = start of every owner's bucket
+        std::vector<unsigned long long> start(N, 0);
+        for (size_t j = 1; j < N; ++j) start[j] = start[j - 1] + all[me * N + j - 1];
+        HIP_TRY(x.hits_bucketed.reserve(std::max<size_t>((size_t)mine, 1)));
+        HIP_TRY(hipMemcpyAsync(x.d_cursor.p, start.data(), 8 * N, hipMemcpyHostToDevice, st));
+        ba.out = x.hits_bucketed.p;
+        HIP_TRY(launch_bucket_hits(ba, false, st));
+        // (4) the plan, then the records
+        std::vector<cobs_gpu_xfer> xf(N);
+        uint64_t tot[2];
+        cobs_gpu_status ps = cobs_gpu_hit_exchange_plan(all.data(), N, me, xf.data(), tot);
+        if (ps != COBS_GPU_OK) return ps;
+        const uint64_t total = tot[0] / sizeof(HitDev);
+        HIP_TRY(x.hits_all.reserve(std::max<size_t>((size_t)total, 1)));
+        uint8_t* recv = reinterpret_cast<uint8_t*>(x.hits_all.p);
+        const uint8_t* send = reinterpret_cast<const uint8_t*>(x.hits_bucketed.p);
+        if (N > 1) {
+            NCCL_TRY(ncclGroupStart());
+            for (size_t j = 0; j < N; ++j) {
+                if (j == me) continue;
+                if (xf[j].send_bytes) NCCL_TRY(ncclSend(send + xf[j].send_offset, xf[j].send_bytes, ncclUint8, (int)j, c->comm, st));
+                if (xf[j].recv_bytes) NCCL_TRY(ncclRecv(recv + xf[j].recv_offset, xf[j].recv_bytes, ncclUint8, (int)j, c->comm, st));
+            }
+            NCCL_TRY(ncclGroupEnd());
+        }
+        if (xf[me].send_bytes)
+            HIP_TRY(hipMemcpyAsync(recv + xf[me].recv_offset, send + xf[me].send_offset, xf[me].send_bytes, hipMemcpyDeviceToDevice, st));
+        std::vector<HitDev> raw((size_t)total);
+        if (total) HIP_TRY(hipMemcpyAsync(raw.data(), x.hits_all.p, total * sizeof(HitDev), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        x.bytes_moved = tot[0] - xf[me].recv_bytes;
+        // bucket by query (the order inside a bucket is fixed later by the ranking sort)
+        b->h_hit_off.assign(b->nq + 1, 0);
+        for (const HitDev& h : raw)
+            if (h.query < b->nq) b->h_hit_off[h.query + 1]++;
+        for (size_t i = 0; i < b->nq; ++i) b->h_hit_off[i + 1] += b->h_hit_off[i];
+        b->h_hits.resize(raw.size());
+        std::vector<size_t> cur(b->h_hit_off.begin(), b->h_hit_off.end() - 1);
+        for (const HitDev& h : raw)
+            if (h.query < b->nq) b->h_hits[cur[h.query]++] = h;
+        b->pool_fetched = true;
+        b->pool_global = true;
+        b->pool_owned = true;
+        b->own_q0 = q0;
+        b->own_qn = q1 - q0;
+        return COBS_GPU_OK;
+    });
+}
+
+// Diagnostics / tests: the device-side bucketing of the owner-routed exchange for ANY rank count, without a
+// communicator -- the hit pool of the last synced run bucketed as rank `nranks` ranks would (counts[j] records for
+// owner j, buckets back to back), copied to the host as (query, file, document, score) quadruples.
+cobs_gpu_status cobs_gpu_batch_bucketed_hits(cobs_gpu_batch* b, uint32_t nranks, uint64_t* counts, uint32_t* records,
+                                             size_t cap_records, size_t* n_records) {
+    if (!b || !counts || !n_records || nranks == 0 || nranks > 64) return fail(COBS_GPU_ERR_ARG, "bad argument");
+    if (!b->ran || !b->synced || !b->selected) return fail(COBS_GPU_ERR_ARG, "run the batch with a threshold and sync it first");
+    if (b->h_nhits() > b->hit_cap) return fail(COBS_GPU_ERR_CAPACITY, "the hit pool overflowed");
+    return guarded([&]() -> cobs_gpu_status {
+        HIP_TRY(hipSetDevice(b->ix->device));
+        if (!b->xchg) b->xchg = new Exchange;
+        Exchange& x = *b->xchg;
+        const uint64_t n = b->h_nhits();
+        *n_records = (size_t)n;
+        HIP_TRY(x.d_cursor.reserve(2 * (size_t)nranks + 2));
+        HIP_TRY(hipMemset(x.d_cursor.p, 0, 8 * nranks));
+        BucketArgs ba;
+        ba.hits = b->hits.p; ba.n = n; ba.cursor = x.d_cursor.p; ba.out = nullptr; ba.nq = (uint32_t)b->nq; ba.nranks = nranks;
+        HIP_TRY(launch_bucket_hits(ba, true, nullptr));
+        std::vector<unsigned long long> cnt(nranks, 0), start(nranks, 0);
+        HIP_TRY(hipMemcpy(cnt.data(), x.d_cursor.p, 8 * nranks, hipMemcpyDeviceToHost));
+        for (uint32_t j = 0; j < nranks; ++j) counts[j] = cnt[j];
+        for (uint32_t j = 1; j < nranks; ++j) start[j] = start[j - 1] + cnt[j - 1];
+        if (n > cap_records || (n && !records)) return fail(COBS_GPU_ERR_CAPACITY, "record buffer too small");
+        HIP_TRY(x.hits_bucketed.reserve(std::max<size_t>((size_t)n, 1)));
+        HIP_TRY(hipMemcpy(x.d_cursor.p, start.data(), 8 * nranks, hipMemcpyHostToDevice));
+        ba.out = x.hits_bucketed.p;
+        HIP_TRY(launch_bucket_hits(ba, false, nullptr));
+        static_assert(sizeof(HitDev) == 16, "records are four u32");
+        if (n) HIP_TRY(hipMemcpy(records, x.hits_bucketed.p, n * sizeof(HitDev), hipMemcpyDeviceToHost));
         return COBS_GPU_OK;
     });
 }

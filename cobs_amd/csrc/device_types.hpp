@@ -82,6 +82,15 @@ struct ScanArgs {
     uint32_t dbg_every, dbg_slots;
 };
 
+// Owner-routed hit exchange (xchg_kernels.hip): bucket the hit pool by the rank that owns each record's query.
+struct BucketArgs {
+    const HitDev* hits;
+    uint64_t n;
+    unsigned long long* cursor;  // [nranks]: counting pass: zeroed, receives the counts; scatter pass: the buckets' start positions
+    HitDev* out;                 // scatter pass: the bucketed pool
+    uint32_t nq, nranks;
+};
+
 // Row-selective access to a chunk that is not resident (fetch_kernels.hip): fetch the rows K1's table names
 // from the registered file mapping into a gathered buffer shaped like a resident chunk.
 struct FetchArgs {

@@ -300,6 +300,8 @@ struct cobs_gpu_batch {
     uint64_t g_q0 = 0, g_qn = 0;
     bool view_global = false;
     bool pool_global = false;         // h_hits holds the hit pools of ALL shards
+    bool pool_owned = false;          // ... of the queries [own_q0, own_q0 + own_qn) only (owner-routed exchange)
+    uint64_t own_q0 = 0, own_qn = 0;
     uint32_t topk_stride = 0;         // entries per (file, query) in h_topk (0 = topk_k; ranks * k after an exchange)
     ~cobs_gpu_batch();
 };

@@ -35,6 +35,9 @@ hipError_t launch_rank(const RankArgs& a, bool first, bool last, hipStream_t str
 // Row-selective out-of-core access (fetch_kernels.hip): one thread per (looked-up row, 16-byte piece).
 hipError_t launch_fetch_rows(const FetchArgs& a, bool idx64, hipStream_t stream);
 
+// Owner-routed hit exchange (xchg_kernels.hip): count == true -> records per owner into a.cursor, else scatter.
+hipError_t launch_bucket_hits(const BucketArgs& a, bool count, hipStream_t stream);
+
 // Index construction: one thread per text position hashes its term and sets the bits.
 hipError_t launch_build(const BuildArgs& a, uint64_t total_bytes, hipStream_t stream);
 hipError_t launch_pack_bytemap(const PackArgs& a, hipStream_t stream);

@@ -233,6 +233,7 @@ void cobs_amd::set_run_state(cobs_gpu_batch* b, double threshold, size_t topk, b
     b->rows_q0 = b->rows_q1 = 0;
     b->view_global = false;
     b->pool_global = false;
+    b->pool_owned = false;
     b->topk_stride = 0;
     b->graph_run = false;
     b->threshold = threshold;

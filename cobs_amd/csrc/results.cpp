@@ -245,6 +245,8 @@ static cobs_gpu_status hits_host_impl(cobs_gpu_batch* b, size_t q, size_t num_re
             for (uint32_t i = 0; i < cnt; ++i) sel.push_back(cobs_gpu_hit{(uint32_t)f, e[i].x, e[i].y});
         }
     } else if (pool_ok) {
+        if (b->pool_owned && (q < b->own_q0 || q >= b->own_q0 + b->own_qn))
+            return fail(COBS_GPU_ERR_ARG, "this rank does not hold the exchanged hits of that query");
         if (!b->pool_fetched) {
             // the pool arrives in arbitrary order: bucket it by query with a counting scatter
             std::vector<HitDev> raw((size_t)b->h_nhits());

@@ -419,6 +419,29 @@ class Batch:
         check(self._lib.cobs_gpu_batch_exchange_hits(self._h, comm._h, C.c_void_p(stream), C.byref(over)))
         return bool(over.value)
 
+    def exchange_hits_owned(self, comm, stream=0):
+        """every hit record to the rank that owns its query -> (overflowed, first owned query, owned queries)"""
+        over, q0, qn = C.c_int(0), C.c_uint64(0), C.c_uint64(0)
+        check(self._lib.cobs_gpu_batch_exchange_hits_owned(self._h, comm._h, C.c_void_p(stream), C.byref(over),
+                                                           C.byref(q0), C.byref(qn)))
+        return bool(over.value), int(q0.value), int(qn.value)
+
+    def bucketed_hits(self, nranks):
+        """diagnostics: the hit pool of the last run bucketed by query owner as `nranks` ranks would
+        -> (counts per owner, records uint32 [n][4] = query, file, doc, score)"""
+        counts = (C.c_uint64 * nranks)()
+        n = C.c_size_t(0)
+        cap = 1 << 16
+        while True:
+            rec = np.zeros((cap, 4), dtype=np.uint32)
+            st = self._lib.cobs_gpu_batch_bucketed_hits(self._h, nranks, counts, rec.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                        cap, C.byref(n))
+            if st == _capi.ERR_CAPACITY and n.value > cap:
+                cap = n.value
+                continue
+            check(st)
+            return list(counts), rec[:n.value]
+
     def exchange_topk(self, comm, stream=0):
         check(self._lib.cobs_gpu_batch_exchange_topk(self._h, comm._h, C.c_void_p(stream)))
 

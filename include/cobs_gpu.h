@@ -319,6 +319,22 @@ uint64_t cobs_gpu_batch_exchange_bytes(const cobs_gpu_batch* b);
  * shards (sizes first, then the records); cobs_gpu_batch_hits_host then returns global results.
  * *overflow = 1 if a shard's pool overflowed (lists incomplete on every rank: rerun with score rows). */
 cobs_gpu_status cobs_gpu_batch_exchange_hits(cobs_gpu_batch* b, cobs_gpu_comm* c, void* hip_stream, int* overflow);
+/* The same exchange with every record sent ONCE, to the rank that owns its query: rank j owns the queries
+ * [nq*j/N, nq*(j+1)/N) (as in COBS_GPU_XCHG_ALLTOALL) and ends with the hits of exactly those queries from every shard
+ * (*q_begin / *q_count, optional); cobs_gpu_batch_hits_host then answers for them and refuses the others. */
+cobs_gpu_status cobs_gpu_batch_exchange_hits_owned(cobs_gpu_batch* b, cobs_gpu_comm* c, void* hip_stream, int* overflow,
+                                                   uint64_t* q_begin, uint64_t* q_count);
+/* ... as a plan (host arithmetic only): counts[r * nranks + j] = records rank r holds for the queries of rank j;
+ * xfers[j] = what `rank` sends to / receives from rank j (bytes; send offsets inside its pool bucketed by owner,
+ * receive offsets inside its staging buffer, rank after rank); out = { bytes received incl. its own bucket,
+ * bytes of its pool }.  cobs_gpu_batch_exchange_hits_owned executes exactly this plan. */
+cobs_gpu_status cobs_gpu_hit_exchange_plan(const uint64_t* counts, size_t nranks, size_t rank, cobs_gpu_xfer* xfers,
+                                           uint64_t out[2]);
+/* Diagnostics / tests: the device-side half of that exchange for any rank count, without a communicator: the hit
+ * pool of the last synced thresholded run bucketed by owner as `nranks` ranks would bucket it -- counts[j] records
+ * for rank j, the buckets back to back in `records` as (query, file, document, score) quadruples of uint32. */
+cobs_gpu_status cobs_gpu_batch_bucketed_hits(cobs_gpu_batch* b, uint32_t nranks, uint64_t* counts, uint32_t* records,
+                                             size_t cap_records, size_t* n_records);
 /* After a run with num_results > 0: all-gather the k best documents of every shard. */
 cobs_gpu_status cobs_gpu_batch_exchange_topk(cobs_gpu_batch* b, cobs_gpu_comm* c, void* hip_stream);
 /* cobs_gpu_search_batch over the sharded index: same arguments and result on every rank. */

@@ -59,6 +59,28 @@ def test_one_rank_exchange_is_the_real_collective(gpu_lib, oracle, tmp_path, com
     assert b.exchange_hits(comm) is False
     for i, q in enumerate(queries):
         assert b.hits_host(i, 0) == cases.oracle_results(ixs, q, 0.3, 0)
+    # ... routed to query owners (device-side bucketing + grouped send / recv; one rank owns every query)
+    for t in (0.3, 0.05):
+        b.run_hits(t)
+        b.sync()
+        over, q0, qn = b.exchange_hits_owned(comm)
+        assert (over, q0, qn) == (False, 0, len(queries))
+        for i, q in enumerate(queries):
+            assert b.hits_host(i, 0) == cases.oracle_results(ixs, q, t, 0)
+        assert b.exchange_bytes() == 0
+        # the device-side bucketing for the rank counts an 8-GPU node uses: bucket j holds exactly the records of
+        # the queries rank j owns, nothing is lost or duplicated
+        want_recs = sorted((i, f, d, sc) for i, q in enumerate(queries) for (f, d, sc) in cases.oracle_results(ixs, q, t, 0))
+        for N in (1, 2, 3, 5, 8):
+            counts, rec = b.bucketed_hits(N)
+            assert sum(counts) == len(rec) == len(want_recs)
+            assert sorted(map(tuple, rec.tolist())) == want_recs
+            pos = 0
+            for j in range(N):
+                q0, q1 = len(queries) * j // N, len(queries) * (j + 1) // N
+                seg = rec[pos:pos + counts[j]]
+                assert ((seg[:, 0] >= q0) & (seg[:, 0] < q1)).all(), (N, j)
+                pos += counts[j]
     b.run_topk(0.0, 6)
     b.sync()
     b.exchange_topk(comm)

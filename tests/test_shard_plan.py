@@ -145,3 +145,53 @@ def test_exchange_plan_moves_every_count_exactly_once(oracle, tmp_path, mode):
                         assert sum(o[1] for o in owned) == nq
                     else:
                         assert all(o == (0, nq) for o in owned)
+
+
+def test_hit_exchange_plan_routes_every_record_to_its_query_owner(oracle, tmp_path):
+    """The owner-routed hit exchange (comm.cpp: cobs_gpu_batch_exchange_hits_owned) as a plan, N ranks emulated on the
+    CPU: every rank's hit pool = the oracle's hits of ITS documents (the engine's own shard layout), bucketed by the
+    rank that owns each record's query (rank j owns [nq*j/N, nq*(j+1)/N)); the plans' sends / receives are played with
+    slices.  Every rank must end with exactly the oracle's hits of its own queries, every send size must equal the
+    peer's receive size, and every record must cross exactly once."""
+    from cobs_amd import _capi
+    lib = _capi.load()
+    q_long = oracle.random_sequence(400, 33)
+    ratio = 16.0 ** (1.0 / 7.0)
+    p = cases.make_compact(cases.tmp(tmp_path, "h.cobs_compact"), 8 * 8 * 48 - 9, 48, [int(150 * ratio ** i) for i in range(8)],
+                           1, 31, 1, 0.3, 8, planted={3: 1.0, 700: 0.9, 1500: 0.7, 3000: 0.8}, query=q_long)
+    ix = oracle.Index.open(p)
+    for nq in (1, 3, 8, 13):
+        queries = [q_long[i:i + 60 + 9 * i] for i in range(nq)]
+        hits = [(q, f, d, sc) for q, qq in enumerate(queries) for (f, d, _n, sc) in oracle.search(ix, qq, 0.33, 0)]
+        assert len(hits) > nq
+        for N in (1, 2, 3, 5, 8):
+            for shard_mode in (0, 1):
+                begin, count, _ = _plan(p, N, shard_mode)
+                owner = lambda q: max(j for j in range(N) if nq * j // N <= q)
+                local = [[h for h in hits if begin[r] <= h[2] < begin[r] + count[r]] for r in range(N)]
+                assert sum(len(x) for x in local) == len(hits)
+                bucketed = [sorted(x, key=lambda h: owner(h[0])) for x in local]
+                counts = [[sum(1 for h in local[r] if owner(h[0]) == j) for j in range(N)] for r in range(N)]
+                flat = (C.c_uint64 * (N * N))(*[c for row in counts for c in row])
+                plans = []
+                for r in range(N):
+                    xf = (_capi.Xfer * N)()
+                    out = (C.c_uint64 * 2)()
+                    _capi.check(lib.cobs_gpu_hit_exchange_plan(flat, N, r, xf, out))
+                    plans.append((list(xf), list(out)))
+                moved = 0
+                for i in range(N):
+                    xf, out = plans[i]
+                    assert out[1] == 16 * len(local[i])
+                    got = [None] * (out[0] // 16)
+                    for j in range(N):
+                        peer = plans[j][0][i]                    # what j sends to i
+                        assert peer.send_bytes == xf[j].recv_bytes and peer.send_bytes % 16 == 0, (N, i, j)
+                        src = bucketed[j][peer.send_offset // 16:(peer.send_offset + peer.send_bytes) // 16]
+                        got[xf[j].recv_offset // 16:(xf[j].recv_offset + xf[j].recv_bytes) // 16] = src
+                        if j != i:
+                            moved += len(src)
+                    assert None not in got
+                    q0, q1 = nq * i // N, nq * (i + 1) // N
+                    assert sorted(got) == sorted(h for h in hits if q0 <= h[0] < q1), (N, i, nq)
+                assert moved == sum(1 for r in range(N) for h in local[r] if owner(h[0]) != r)
