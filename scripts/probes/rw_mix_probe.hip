@@ -1,0 +1,113 @@
+// scripts/probes/rw_mix_probe.hip -- what does this memory system deliver for the scan kernel's READ/WRITE MIX
+// with all arithmetic removed?  The short-read shapes write a large share of their traffic (50-bp reads: one
+// score byte per document and query against 20 gathered 128-byte lines per 1024 documents: 29 % writes); the
+// gather-only ceiling (scripts/gather_ceiling.cpp) says nothing about them.
+//
+// One wave = one work-group of the multi-query scan: 8 lane groups (queries) x one tile of 8 sixteen-byte chunks
+// (one 128-byte line per gathered row).  Per trip a wave-load fetches 8 random lines (16 B per lane); after
+// `trips` trips the wave stores `wlines` 128-byte lines per query into that query's score row
+// (rows 100 352 bytes apart, the tile's 1 KiB at the same offset of each: the kernel's store pattern).
+//   rw_mix_probe [table_GB]     prints GB/s (reads + writes) for several (trips, wlines) mixes
+// hipcc --offload-arch=gfx950 -O3 scripts/probes/rw_mix_probe.hip -o /tmp/rw_mix_probe && /tmp/rw_mix_probe
+#pragma clang diagnostic ignored "-Wunused-value"
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <cstdlib>
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+struct Pages { uint64_t base[8], rows[8]; };     // the C3 geometry: 8 sub-indexes of 250 k ... 4 M rows
+
+// grid: tiles x query-groups (tile-major, as the scan kernel).  `local`: the lines of tile t come from the t % 13-th
+// 128-byte column of sub-index t / 13 (pitch 1664 = 13 lines) -- the kernel's locality: all queries hit one column
+// of one sub-index before the grid moves on; else from anywhere in the table.
+__global__ __launch_bounds__(64) void probe(const uint8_t* table, uint64_t table_bytes, Pages pg, uint32_t pitch,
+                                            uint8_t* scores, uint32_t nqg, uint32_t trips, uint32_t wlines, int local,
+                                            uint64_t salt) {
+    const uint32_t lane = threadIdx.x, grp = lane >> 3, col = lane & 7u;
+    const uint32_t tile = blockIdx.x / nqg, qg = blockIdx.x - tile * nqg;
+    u32x4 acc = {0u, 0u, 0u, 0u};
+    u32x4 x[8];
+    for (uint32_t t = 0; t < trips; t += 8) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const uint64_t h = mix64(((uint64_t)blockIdx.x * 1024u + t + r) * 8u + grp + salt);
+            const uint32_t p = (tile / 13u) & 7u;
+            const uint64_t off = local ? pg.base[p] + (h % pg.rows[p]) * pitch + (uint64_t)(tile % 13u) * 128u
+                                       : (h % (table_bytes / 128u)) * 128u;
+            x[r] = *reinterpret_cast<const u32x4*>(table + off + col * 16u);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc ^= x[r];
+    }
+    // the query group's score bytes of this tile: 8 queries x wlines lines, rows 100 352 bytes apart
+    for (uint32_t i = lane; i < 8u * wlines * 8u; i += 64) {       // 16-byte pieces
+        const uint32_t q = i / (wlines * 8u), piece = i - q * wlines * 8u;
+        uint8_t* dst = scores + ((uint64_t)qg * 8u + q) * 100352u + (uint64_t)(tile % 98u) * 1024u + piece * 16u;
+        *reinterpret_cast<u32x4*>(dst) = acc;
+    }
+    if (wlines == 0 && acc.x == 0xdeadbeefu && acc.y == 0x12345u) scores[0] = 1;    // keep the loads
+}
+
+int main(int argc, char** argv) {
+    (void)argc; (void)argv;
+    const uint32_t pitch = 1664;
+    Pages pg;
+    uint64_t table_bytes = 0;
+    for (int p = 0; p < 8; ++p) {
+        double r = 250000.0;
+        for (int i = 0; i < p; ++i) r *= 1.4859942891369484;       // 16^(1/7)
+        pg.rows[p] = (uint64_t)(r + 0.5);
+        pg.base[p] = table_bytes;
+        table_bytes += pg.rows[p] * pitch;
+    }
+    const uint32_t nq = 40000, nqg = nq / 8, tiles = 104;
+    uint8_t *table, *scores;
+    if (hipMalloc(&table, table_bytes) != hipSuccess || hipMalloc(&scores, (uint64_t)nq * 100352u) != hipSuccess) {
+        fprintf(stderr, "allocation failed\n");
+        return 1;
+    }
+    hipMemset(table, 0x5a, table_bytes);
+    hipMemset(scores, 0, (uint64_t)nq * 100352u);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    struct Mix { const char* name; uint32_t trips, wlines; int local; } mixes[] = {
+        {"gather only, 24 lines per (query, tile), anywhere          ", 24, 0, 0},
+        {"gather only, 24 lines per (query, tile), the tile's column ", 24, 0, 1},
+        {"50-bp reads: 24 lines read, 8 lines (1 KiB) written, anywhere", 24, 8, 0},
+        {"50-bp reads: 24 lines read, 8 lines (1 KiB) written, column  ", 24, 8, 1},
+        {"100-bp reads: 72 lines read, 8 lines written, column         ", 72, 8, 1},
+        {"150-bp reads: 120 lines read, 8 lines written, column        ", 120, 8, 1},
+        {"1000-k-mer queries: 1000 lines read, 16 lines (u16) written  ", 1000, 16, 1},
+        {"stores only: 8 lines per (query, tile)                       ", 0, 8, 1},
+    };
+    printf("# table %.1f GB (rows of %u bytes), %u queries x %u tiles, one wave per 8 queries and tile; best of 3\n",
+           table_bytes / 1e9, pitch, nq, tiles);
+    for (const Mix& m : mixes) {
+        float best = 1e30f;
+        for (int rep = 0; rep < 4; ++rep) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(probe, dim3(tiles * nqg), dim3(64), 0, 0, table, table_bytes, pg, pitch, scores, nqg,
+                               m.trips, m.wlines, m.local, (uint64_t)rep * 7919u);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            if (rep > 0 && ms < best) best = ms;
+        }
+        const double rd = (double)tiles * nqg * 8.0 * ((m.trips + 7) / 8 * 8) * 128.0;
+        const double wr = (double)tiles * nqg * 8.0 * m.wlines * 128.0;
+        printf("%s  %8.3f ms   read %7.2f GB  written %6.2f GB (%4.1f %%)   %7.1f GB/s\n", m.name, best, rd / 1e9, wr / 1e9,
+               100.0 * wr / (rd + wr), (rd + wr) / best / 1e6);
+    }
+    return 0;
+}
