@@ -73,6 +73,7 @@ struct ScanArgs {
     uint32_t chunk_end;
     uint32_t idx64;             // 64-bit row indices in the table
     uint32_t lds_staged;        // measured variant: rows travel HBM -> LDS -> VGPR (global_load_lds)
+    uint32_t exp;               // bit field of experimental variants under A/B measurement (tuning key "exp")
     // run_topk without score rows: every tile leaves its topk_k best (document, score) candidates at
     // cand[query * cand_stride + (tile_base + tile) * topk_k ..]; nullptr = the other epilogues
     uint2* cand;

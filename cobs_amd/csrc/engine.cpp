@@ -383,6 +383,8 @@ cobs_gpu_status cobs_gpu_set_tuning(cobs_gpu_index* ix, const char* key, int64_t
         t.device_rank = value != 0;
     } else if (k == "tile_topk") {
         t.tile_topk = value != 0;
+    } else if (k == "exp") {
+        t.exp = (uint32_t)value;
     } else if (k == "row_fetch") {
         t.row_fetch = value != 0;
     } else if (k == "row_fetch_alpha") {

@@ -103,6 +103,7 @@ struct Tuning {
                                     // fetched by the kernel cross PCIe at 50.8 GB/s, whole chunks at 52.3 GB/s (profiles/r03_c5_selective.txt): 1
     int tile_topk = 1;          // top-k passes without score rows select per tile in K2 (0: score rows + K3, A/B)
     int device_rank = 1;        // whole score rows are ranked on the device (0: by host threads, A/B and fallback)
+    uint32_t exp = 0;           // experimental kernel variants under A/B measurement (bit field, ScanArgs::exp)
     bool trace = false;         // COBS_GPU_TRACE: where the host side of a search call spends its time, on stderr
     uint32_t phase_slots = 0;   // tuning builds (make timing): work-groups of a scan launch that record phase stamps
     static Tuning from_env();

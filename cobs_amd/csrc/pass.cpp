@@ -463,6 +463,7 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
             // measured variant (A/B only): rows staged through LDS, where that kernel exists
             sa.lds_staged = ix->tune.lds_staged && !geom.multi_query && !p.idx64 &&
                             scan_has_lds_staged(b->planes, (uint32_t)p.meta.num_hashes, nwaves) ? 1u : 0u;
+            sa.exp = ix->tune.exp;
             sa.chunk_begin = 0;
             sa.chunk_end = c.total_chunks;
             // one launch covers at most 2^31-1 work-groups

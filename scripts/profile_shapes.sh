@@ -27,7 +27,7 @@ declare -A SHAPES=(
   [reads100top10]="--queries 40000 --kmers 70 --num-results 10"
 )
 FULL="c3 reads50"
-WANT=${*:-c3 c2 c4 c3h3 reads50 reads100 reads150 c3hits reads100hits c3top10}
+WANT=${*:-c3 c2 c4 c3h3 reads50 reads100 reads150 c3hits reads100hits c3top10 c3top10rows reads100top10}
 cd /tmp
 for shape in $WANT; do
   EXTRA=${SHAPES[$shape]}
