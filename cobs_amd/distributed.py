@@ -153,6 +153,103 @@ def merge_hits(per_rank_hits, num_results=0, total_hashes=2, total_documents=Non
     return allh[:num_results] if num_results else allh
 
 
+def exchange_counts_by_plan(local, layouts, total_counts, nq, mode=_capi.XCHG_ALLTOALL, group=None):
+    """The count exchange exactly as libcobs_gpu.so plans it (cobs_gpu_exchange_plan, comm.cpp: plan_exchange),
+    executed with torch.distributed point-to-point transfers instead of grouped ncclSend / ncclRecv: every rank
+    sends and receives the byte ranges the native plan names and applies its assembly copies.  Any backend --
+    world_size > 1 gloo tests run the library's own plan across real processes (a size mismatch between a
+    sender's and a receiver's plan would hang or fail here, as it would on xGMI).
+    local: [nq, n_local] integer tensor (this rank's count rows); layouts: per rank, per file
+    (slot_begin, slot_count, doc_offset).  -> (q_begin, q_count, rows [q_count, total_counts])."""
+    lib = _capi.load()
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    nfiles = len(layouts[0])
+    begins = (C.c_uint64 * (world * nfiles))(*[f[0] for lay in layouts for f in lay])
+    counts = (C.c_uint64 * (world * nfiles))(*[f[1] for lay in layouts for f in lay])
+    docoff = (C.c_uint64 * nfiles)(*[f[2] for f in layouts[0]])
+    eb = local.element_size()
+    xf = (_capi.Xfer * world)()
+    cp = (_capi.Copy2D * (world * nfiles))()
+    ncp = C.c_size_t(world * nfiles)
+    out = (C.c_uint64 * 6)()
+    _capi.check(lib.cobs_gpu_exchange_plan(begins, counts, docoff, world, nfiles, total_counts, nq, eb, mode, rank,
+                                           xf, cp, C.byref(ncp), out))
+    q0, qn, staging_bytes, global_bytes, use_ag, my_row = [int(v) for v in out]
+    mine = local.contiguous().view(torch.uint8).reshape(-1)
+    staging = torch.zeros(max(staging_bytes, 1), dtype=torch.uint8, device=local.device)
+    if use_ag:      # one ncclAllGather: every rank's nq * row bytes, rank after rank
+        parts = [torch.empty(nq * my_row, dtype=torch.uint8, device=local.device) for _ in range(world)]
+        dist.all_gather(parts, mine[:nq * my_row].contiguous(), group=group)
+        for j in range(world):
+            staging[xf[j].recv_offset: xf[j].recv_offset + xf[j].recv_bytes] = parts[j]
+    else:
+        reqs, keep = [], []
+        for j in range(world):
+            if j == rank:
+                continue
+            if xf[j].send_bytes:
+                t = mine[xf[j].send_offset: xf[j].send_offset + xf[j].send_bytes].contiguous()
+                keep.append(t)
+                reqs.append(dist.isend(t, dist.get_global_rank(group, j) if group is not None else j, group=group))
+            if xf[j].recv_bytes:
+                t = torch.empty(xf[j].recv_bytes, dtype=torch.uint8, device=local.device)
+                keep.append((t, xf[j].recv_offset))
+                reqs.append(dist.irecv(t, dist.get_global_rank(group, j) if group is not None else j, group=group))
+        for r in reqs:
+            r.wait()
+        for k in keep:
+            if isinstance(k, tuple):
+                staging[k[1]: k[1] + k[0].numel()] = k[0]
+    got = torch.zeros(max(global_bytes, 1), dtype=torch.uint8, device=local.device)
+    for c in list(cp)[:ncp.value]:
+        src = mine if c.src_is_local else staging
+        for h in range(c.height):
+            so, do = c.src_offset + h * c.src_pitch, c.dst_offset + h * c.dst_pitch
+            got[do:do + c.width] = src[so:so + c.width]
+    rows = got[:global_bytes].view(local.dtype).reshape(qn, total_counts) if qn else got[:0].view(local.dtype).reshape(0, total_counts)
+    return q0, qn, rows
+
+
+def exchange_hits_by_plan(local_hits, nq, group=None):
+    """The owner-routed hit exchange as libcobs_gpu.so plans it (cobs_gpu_hit_exchange_plan), executed with
+    torch.distributed: local_hits = this rank's (query, file, doc, score) records; rank j owns the queries
+    [nq*j/N, nq*(j+1)/N).  -> (q_begin, q_count, the records of those queries from every rank)."""
+    lib = _capi.load()
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    owner = lambda q: max(j for j in range(world) if nq * j // world <= q)
+    buckets = [[h for h in local_hits if owner(h[0]) == j] for j in range(world)]
+    mine = [len(b) for b in buckets]
+    allc = [None] * world
+    dist.all_gather_object(allc, mine, group=group)
+    flat = (C.c_uint64 * (world * world))(*[c for row in allc for c in row])
+    xf = (_capi.Xfer * world)()
+    out = (C.c_uint64 * 2)()
+    _capi.check(lib.cobs_gpu_hit_exchange_plan(flat, world, rank, xf, out))
+    send = torch.tensor([v for b in buckets for h in b for v in h], dtype=torch.int32).reshape(-1, 4).view(torch.uint8).reshape(-1)
+    assert send.numel() == int(out[1])
+    recv = torch.zeros(max(int(out[0]), 1), dtype=torch.uint8)
+    reqs, keep = [], []
+    for j in range(world):
+        if j == rank:
+            recv[xf[j].recv_offset: xf[j].recv_offset + xf[j].recv_bytes] = send[xf[j].send_offset: xf[j].send_offset + xf[j].send_bytes]
+            continue
+        if xf[j].send_bytes:
+            t = send[xf[j].send_offset: xf[j].send_offset + xf[j].send_bytes].contiguous()
+            keep.append(t)
+            reqs.append(dist.isend(t, j, group=group))
+        if xf[j].recv_bytes:
+            t = torch.empty(xf[j].recv_bytes, dtype=torch.uint8)
+            keep.append((t, xf[j].recv_offset))
+            reqs.append(dist.irecv(t, j, group=group))
+    for r in reqs:
+        r.wait()
+    for k in keep:
+        if isinstance(k, tuple):
+            recv[k[1]: k[1] + k[0].numel()] = k[0]
+    recs = recv[:int(out[0])].view(torch.int32).reshape(-1, 4).tolist()
+    return nq * rank // world, nq * (rank + 1) // world - nq * rank // world, [tuple(r) for r in recs]
+
+
 class ShardedSearch:
     """cobs_index.Search over an index sharded by sub-index block across the ranks
     of `group`.  Every rank calls the same methods with the same arguments and
@@ -218,4 +315,5 @@ class ShardedSearch:
         return [SearchResult(self.search_local.doc_name(f, d), sc) for (f, d, sc) in hits]
 
 
-__all__ = ["Comm", "ShardedSearch", "shard_slots", "all_gather_counts", "assemble_counts", "merge_hits"]
+__all__ = ["Comm", "ShardedSearch", "shard_slots", "all_gather_counts", "assemble_counts", "merge_hits",
+           "exchange_counts_by_plan", "exchange_hits_by_plan"]

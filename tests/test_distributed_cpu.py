@@ -54,6 +54,22 @@ def _worker(rank, world, port, path, queries, out_dir, mode):
         as_bytes = torch.from_numpy(padded.view(np.uint8).copy())
         dist.all_reduce(as_bytes, op=dist.ReduceOp.SUM)
         assert np.array_equal(as_bytes.numpy().view(np.uint16), full)
+        # the library's OWN exchange plans (cobs_gpu_exchange_plan / cobs_gpu_hit_exchange_plan, what comm.cpp executes
+        # over RCCL) run across these processes with point-to-point transfers: all-to-all to query owners and
+        # all-gather for the count rows, owner-routed hit records
+        nq = len(queries)
+        for xmode, name in ((_capi.XCHG_ALLTOALL, "alltoall"), (_capi.XCHG_ALLGATHER, "allgather")):
+            q0, qn, rows = D.exchange_counts_by_plan(local, layouts, ix.counts_size, nq, xmode)
+            want_q = (nq * rank // world, nq * (rank + 1) // world - nq * rank // world) if xmode == _capi.XCHG_ALLTOALL else (0, nq)
+            assert (q0, qn) == want_q, name
+            assert np.array_equal(rows.numpy().astype(np.uint16), full[q0:q0 + qn]), name
+        thr = [int(np.ceil(0.3 * (len(q) - 30))) for q in queries]
+        mine_hits = [(qi, 0, d, int(full[qi, d])) for qi in range(nq) for d in range(begin, min(begin + count, ix.num_docs))
+                     if full[qi, d] >= thr[qi]]
+        q0, qn, recs = D.exchange_hits_by_plan(mine_hits, nq)
+        want_recs = sorted((qi, f, d, sc) for qi in range(q0, q0 + qn)
+                           for (f, d, sc) in cases.oracle_results([ix], queries[qi], 0.3, 0))
+        assert sorted(recs) == want_recs
         # hits mode: per-shard ranked lists -> global order
         for t, lim in ((0.0, 0), (0.3, 0), (0.3, 3), (0.9, 0)):
             for qi, q in enumerate(queries):
