@@ -608,6 +608,8 @@ def main():
             else:
                 batch.run(args.threshold, 0)
 
+    plain_run = run is None          # one GPU, no sharded layout: `step` and `batch` stay alive to the end
+
     def drop_warmup_events():
         if run is not None:
             run.drop_warmup_events()
@@ -737,7 +739,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not budget:
         out["end_to_end"] = end_to_end(s, batch, queries)
         out["cpu_baseline"] = cpu_baseline(s, cfg, queries, batch=batch)
-    if world == 1 and args.busy_tail > 0 and run is None:
+    if world == 1 and args.busy_tail > 0 and plain_run:
         # the timed region of a default run is half a second of a ~25 s process (the CPU baseline dominates): keep the
         # GPU busy with the same step for a moment so that coarse utilisation sampling sees the device in use
         t_end = time.perf_counter() + args.busy_tail

@@ -9,6 +9,7 @@ reference terminates the process on bad input (short query, non-ACGT base,
 unreadable index: classic_search.cpp:431-433, :93-96, :61-63) this mirror raises
 CobsGpuError carrying the C-ABI status instead.
 """
+import collections.abc
 import ctypes as C
 import os
 
@@ -32,6 +33,36 @@ class SearchResult:
     def __eq__(self, other):
         return (isinstance(other, SearchResult) and self.doc_name == other.doc_name
                 and self.score == other.score)
+
+
+class ResultList(collections.abc.Sequence):
+    """The result of one query when it is long (the default call returns every document of the index): behaves
+    like the reference's list of SearchResult -- len(), indexing, slicing, iteration, equality with a list -- but
+    creates a SearchResult only when one is looked at.  100 000 results cost 0.1 ms instead of the ~100 ms a list
+    of 100 000 Python objects takes to build; .doc / .score / .file_no are the columns (numpy)."""
+    __slots__ = ("_search", "file_no", "doc", "score")
+
+    def __init__(self, search, seg):
+        self._search = search
+        self.file_no, self.doc, self.score = seg["file_no"], seg["doc"], seg["score"]
+
+    def __len__(self):
+        return len(self.doc)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        return SearchResult(self._search._names(int(self.file_no[i]))[int(self.doc[i])], int(self.score[i]))
+
+    def __eq__(self, other):
+        return len(self) == len(other) and all(a == b for a, b in zip(self, other))
+
+    def __repr__(self):
+        return "ResultList(%d results, first %r)" % (len(self), self[0] if len(self) else None)
 
 
 def _as_bytes(q):
@@ -259,14 +290,8 @@ class Search:
             if len(seg) <= 64:
                 out.append([SearchResult(self.doc_name(f, d), s) for (f, d, s) in seg.tolist()])
                 continue
-            # many results (the default call ranks every document): column-wise, cached names
-            files = seg["file_no"]
-            names = [self._names(int(f)) for f in range(int(files.max()) + 1)]
-            if len(names) == 1:
-                picked = map(names[0].__getitem__, seg["doc"].tolist())
-            else:
-                picked = (names[f][d] for f, d in zip(files.tolist(), seg["doc"].tolist()))
-            out.append(list(map(SearchResult, picked, seg["score"].tolist())))
+            # many results (the default call ranks every document): a lazy sequence over the columns
+            out.append(ResultList(self, seg))
         return out
 
     def counts(self, query):
