@@ -782,6 +782,14 @@ cobs_gpu_status cobs_gpu_sharded_search_batch(cobs_gpu_index* ix, cobs_gpu_comm*
                 if (s != COBS_GPU_OK) return s;
                 HIP_TRY(hipStreamSynchronize(st));
             }
+            if (need_rows && ix->tune.device_rank != 0 && rank_on_device_applies(b, g1 - g0)) {
+                // whole (assembled, global) rows: ordered on the device, the records cross PCIe (rank.cpp) -- on a
+                // host thread this loop ranks ~90 queries x 100 000 documents per second
+                s = rank_on_device(b, 0, g1 - g0, num_results, hits, cap, &used, hit_offsets + g0, &overflow);
+                if (s != COBS_GPU_OK) return s;
+                g0 = g1;
+                continue;
+            }
             for (size_t q = g0; q < g1; ++q) {
                 size_t n = 0;
                 s = cobs_gpu_batch_hits_host(b, q - g0, num_results, overflow ? nullptr : hits + used,

@@ -154,6 +154,7 @@ struct RankArgs {
     uint64_t pair_stride, out_stride;
     uint32_t nparts, nslots;     // slots of a row that are ranked (the files' slices)
     uint32_t q0, nq;
+    uint32_t row_q0;             // batch query whose row is rows[0] (0 for a batch's own rows; the first owned query of exchanged rows)
     uint32_t shift, bits;        // digit of this pass = (score >> shift) & (2^bits - 1), bits <= 12
     uint32_t limit;
     uint32_t score_bytes;

@@ -264,7 +264,7 @@ static cobs_gpu_status search_batch_impl(cobs_gpu_index* ix, const char* const* 
         // that overflowed -- are ordered on the device and cross PCIe as finished records (rank.cpp)
         if (ix->tune.device_rank != 0 && rank_on_device_applies(sb, ps.g1 - ps.g0)) {
             double t0 = now_s();
-            st = rank_on_device(sb, ps.g1 - ps.g0, num_results, hits, cap, &used, hit_offsets + ps.g0, &overflow);
+            st = rank_on_device(sb, 0, ps.g1 - ps.g0, num_results, hits, cap, &used, hit_offsets + ps.g0, &overflow);
             ix->timers[4] += now_s() - t0;
             return st;
         }

@@ -56,18 +56,20 @@ void spread_copy(uint8_t* dst, const uint8_t* src, size_t bytes) {
 }  // namespace
 
 bool rank_on_device_applies(const cobs_gpu_batch* b, size_t nq) {
-    // the result has to come from the score rows (no K3 list, no complete hit pool), local view
-    if (!b->have_counts || b->topk_k != 0 || b->view_global || nq < 4) return false;
-    if (b->selected && b->h_nhits() <= b->hit_cap) return false;
-    if (b->ix->local_counts >= 0xFFFFFFF0ull || b->ix->local_counts == 0) return false;
+    // the result has to come from whole score rows (no K3 list, no complete hit pool): the batch's own rows, or --
+    // after an exchange (comm.cpp) -- the assembled global rows of the queries this rank holds
+    if (!b->have_counts || b->topk_k != 0 || nq < 4) return false;
+    if (b->selected && (b->pool_global || b->h_nhits() <= b->hit_cap)) return false;
+    if (b->ix->local_counts >= 0xFFFFFFF0ull || b->ix->local_counts == 0 || b->ix->total_counts >= 0xFFFFFFF0ull) return false;
+    if (b->view_global && (b->g_rows == nullptr || b->g_qn == 0)) return false;
     return true;
 }
 
-// Queries [0, nq) of the last (synced) run of `b`, ranked on the device.  Query i's results -- at most
+// Queries [q_first, q_first + nq) of the last (synced) run of `b`, ranked on the device.  Query q_first + i's results -- at most
 // `limit` (0 = all) -- are appended at hits + *used, hit_offsets[i + 1] = the new *used.  When the
 // caller's buffer is too small the offsets keep counting (the caller reports the needed capacity)
 // and *overflow is set; hits are then not valid, as in the host path.
-cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t nq, size_t limit, cobs_gpu_hit* hits, size_t cap,
+cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, size_t limit, cobs_gpu_hit* hits, size_t cap,
                                size_t* used, size_t* hit_offsets, bool* overflow) {
     cobs_gpu_index* ix = b->ix;
     HIP_TRY(hipSetDevice(ix->device));
@@ -79,19 +81,28 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t nq, size_t limit, cobs_
         for (auto& e : w.ranked) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto& e : w.landed) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    // the files' slices as the local rows hold them
+    // the files' slices as the ranked rows hold them: this shard's slots back to back (local rows), or every
+    // file whole at its document offset (global rows assembled by an exchange)
+    const bool glob = b->view_global;
+    const uint64_t row_elems = glob ? ix->total_counts : ix->local_counts;
     std::vector<RankPart> parts;
     size_t per_query = 0;
     for (size_t f = 0; f < ix->parts.size(); ++f) {
         const Part& p = ix->parts[f];
-        if (p.slot_count == 0) continue;
         RankPart rp;
         rp.thr = b->threshold > 0.0 ? b->work[f].thr.p : nullptr;
-        rp.slot0 = (uint32_t)p.local_offset;
-        rp.doc_first = (uint32_t)p.slot_begin;
-        const uint64_t d1 = std::min<uint64_t>(p.slot_begin + p.slot_count, p.meta.doc_names.size());
-        rp.ndocs = d1 > p.slot_begin ? (uint32_t)(d1 - p.slot_begin) : 0u;
         rp.file_no = (uint32_t)f;
+        if (glob) {
+            rp.slot0 = (uint32_t)p.doc_offset;
+            rp.doc_first = 0;
+            rp.ndocs = (uint32_t)p.meta.doc_names.size();
+        } else {
+            if (p.slot_count == 0) continue;
+            rp.slot0 = (uint32_t)p.local_offset;
+            rp.doc_first = (uint32_t)p.slot_begin;
+            const uint64_t d1 = std::min<uint64_t>(p.slot_begin + p.slot_count, p.meta.doc_names.size());
+            rp.ndocs = d1 > p.slot_begin ? (uint32_t)(d1 - p.slot_begin) : 0u;
+        }
         per_query += rp.ndocs;
         parts.push_back(rp);
     }
@@ -102,10 +113,12 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t nq, size_t limit, cobs_
     const size_t stride = limit == 0 ? per_query : std::min(limit, per_query);
     HIP_TRY(w.parts.reserve(parts.size()));
     HIP_TRY(hipMemcpyAsync(w.parts.p, parts.data(), parts.size() * sizeof(RankPart), hipMemcpyHostToDevice, st));
-    std::vector<uint8_t> by_score(nq);
-    for (size_t q = 0; q < nq; ++q) by_score[q] = total_hashes(b, q) > 1 ? 1 : 0;   // max_counts <= 1: index order
-    HIP_TRY(w.by_score.reserve(nq));
-    HIP_TRY(hipMemcpyAsync(w.by_score.p, by_score.data(), nq, hipMemcpyHostToDevice, st));
+    if (b->view_global && (q_first < b->g_q0 || q_first + nq > b->g_q0 + b->g_qn))
+        return fail(COBS_GPU_ERR_ARG, "this rank does not hold the exchanged rows of those queries");
+    std::vector<uint8_t> by_score(b->nq);
+    for (size_t q = 0; q < b->nq; ++q) by_score[q] = total_hashes(b, q) > 1 ? 1 : 0;   // max_counts <= 1: index order
+    HIP_TRY(w.by_score.reserve(b->nq));
+    HIP_TRY(hipMemcpyAsync(w.by_score.p, by_score.data(), b->nq, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));          // the two host vectors may go; everything below is asynchronous
 
     // radix passes of at most 12 bits over the score bits the scan produced
@@ -118,7 +131,7 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t nq, size_t limit, cobs_
         HIP_TRY(w.out[i].reserve(wq * stride));
         HIP_TRY(w.cnt[i].reserve(2 * wq));
         HIP_TRY(w.land[i].reserve(land_bytes + 4 * wq));
-        if (npasses > 1) HIP_TRY(w.pairs[i].reserve(wq * ix->local_counts));
+        if (npasses > 1) HIP_TRY(w.pairs[i].reserve(wq * row_elems));
     }
     struct Win { size_t q0, n; };
     std::vector<Win> wins;
@@ -128,18 +141,19 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t nq, size_t limit, cobs_
         const int s = (int)(wi & 1);
         if (wi >= 2) HIP_TRY(hipStreamWaitEvent(st, w.landed[s], 0));     // the window that used these buffers has left them
         RankArgs a{};
-        a.rows = b->counts.p;
-        a.row_stride = ix->local_counts;
+        a.rows = glob ? (const void*)b->g_rows : (const void*)b->counts.p;
+        a.row_stride = row_elems;
+        a.row_q0 = glob ? (uint32_t)b->g_q0 : 0u;
         a.parts = w.parts.p;
         a.by_score = w.by_score.p;
         a.npass = w.cnt[s].p + wq;
         a.out = w.out[s].p;
         a.out_count = w.cnt[s].p;
-        a.pair_stride = ix->local_counts;
+        a.pair_stride = row_elems;
         a.out_stride = stride;
         a.nparts = (uint32_t)parts.size();
-        a.nslots = (uint32_t)ix->local_counts;
-        a.q0 = (uint32_t)wn.q0;
+        a.nslots = (uint32_t)row_elems;
+        a.q0 = (uint32_t)(q_first + wn.q0);
         a.nq = (uint32_t)wn.n;
         a.limit = (uint32_t)std::min<size_t>(stride, 0xFFFFFFFFu);
         a.score_bytes = b->elem_bytes;

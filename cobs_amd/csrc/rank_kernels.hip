@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void rank_kernel(RankArgs a) {
     const uint32_t q = a.q0 + qb;                                // query inside the batch
     const bool by_score = a.by_score[q] != 0;
     const uint32_t dmask = NB - 1u;
-    const ST* row = reinterpret_cast<const ST*>(a.rows) + (uint64_t)q * a.row_stride;
+    const ST* row = reinterpret_cast<const ST*>(a.rows) + (uint64_t)(q - a.row_q0) * a.row_stride;
     const uint2* src = a.src + (uint64_t)qb * a.pair_stride;
     const uint32_t n = FIRST ? a.nslots : a.npass[qb];
     (void)row; (void)src;
