@@ -75,6 +75,17 @@ def test_random_geometries(gpu_lib, oracle, tmp_path, monkeypatch, tile_w, waves
         # threshold compare, no score rows)
         tt = t if t > 0 else 0.3
         assert s.search_hits(queries, tt, 0) == [cases.oracle_results([ix], q, tt, 0) for q in queries], (path, tt)
+        # a limit without score rows: the scan selects every tile's best, K3 merges the candidates (tile_topk) --
+        # where that applies (one hash function, no single-k-mer query in the batch), else rows + K3 as above
+        k2 = int(rng.choice([1, 2, 5, 17, 128]))
+        b.run_topk(t, k2, keep_counts=False)
+        b.sync()
+        for i, q in enumerate(queries):
+            assert b.hits_host(i, k2) == cases.oracle_results([ix], q, t, k2), (path, i, t, k2)
+        assert s.search_hits(queries, t, k2) == [cases.oracle_results([ix], q, t, k2) for q in queries], (path, t, k2)
+        # the reference's default call: every document of every query, ordered on the device from four queries on
+        if idx % 4 == 0:
+            assert s.search_hits(queries, 0.0, 0) == [cases.oracle_results([ix], q, 0.0, 0) for q in queries], path
 
 
 def test_lds_staged_variant_is_bit_exact(gpu_lib, oracle):

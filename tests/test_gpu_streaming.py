@@ -114,9 +114,15 @@ def test_random_budgets(gpu_lib, oracle, tmp_path, monkeypatch, no_pin):
             assert e.status == _capi.ERR_CAPACITY
             continue
         assert s.info(0).hbm_bytes <= budget
+        # how the chunks come in: the engine's cost rule, rows whenever they fit, or always whole
+        fetch_mode = int(rng.integers(0, 3))
+        if fetch_mode == 1:
+            s.set_tuning("row_fetch_alpha", 0)
+        elif fetch_mode == 2:
+            s.set_tuning("row_fetch", 0)
         ix = oracle.Index.open(path)
         for q in queries:
-            assert np.array_equal(s.counts(q), ix.counts(q)), (path, budget)
+            assert np.array_equal(s.counts(q), ix.counts(q)), (path, budget, fetch_mode)
         t = float(rng.choice([0.0, 0.3, 0.8]))
         lim = int(rng.choice([0, 0, 5]))
         assert s.search_hits(queries, t, lim) == [cases.oracle_results([ix], q, t, lim) for q in queries], (path, budget, t, lim)
