@@ -383,6 +383,9 @@ cobs_gpu_status cobs_gpu_set_tuning(cobs_gpu_index* ix, const char* key, int64_t
         t.device_rank = value != 0;
     } else if (k == "tile_topk") {
         t.tile_topk = value != 0;
+    } else if (k == "min_score_bytes") {
+        if (value != 0 && value != 1 && value != 2 && value != 4) return fail(COBS_GPU_ERR_ARG, "min_score_bytes: 0, 1, 2 or 4");
+        t.min_score_bytes = (uint32_t)value;
     } else if (k == "exp") {
         t.exp = (uint32_t)value;
     } else if (k == "row_fetch") {
@@ -392,7 +395,7 @@ cobs_gpu_status cobs_gpu_set_tuning(cobs_gpu_index* ix, const char* key, int64_t
     } else if (k == "phase_slots") {
         t.phase_slots = value > 0 ? (uint32_t)std::min<int64_t>(value, 1 << 20) : 0;
     } else {
-        return fail(COBS_GPU_ERR_ARG, "unknown tuning key (waves, tile_w, mq, pass_bytes, pipe_chars, graph, lds_staged, device_rank, tile_topk, row_fetch, row_fetch_alpha)");
+        return fail(COBS_GPU_ERR_ARG, "unknown tuning key (waves, tile_w, mq, pass_bytes, pipe_chars, graph, lds_staged, device_rank, tile_topk, row_fetch, row_fetch_alpha, min_score_bytes)");
     }
     return COBS_GPU_OK;
 }

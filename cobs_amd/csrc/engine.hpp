@@ -98,6 +98,7 @@ struct Tuning {
     bool no_pin = false;        // COBS_GPU_NO_PIN: never hipHostRegister the mapped file
     int graph = -1;             // COBS_GPU_GRAPH: captured-graph path for small batches off / on
     bool lds_staged = false;    // COBS_GPU_LDS_STAGED: the LDS-staged scan variant (A/B measurements only)
+    uint32_t min_score_bytes = 0;   // 2 / 4: scores at least that wide (the reference's classic_search_disable_8bit / _16bit)
     int row_fetch = 1;          // streamed chunks are fetched row by row when a batch looks up few of their rows (0: always whole)
     uint32_t row_fetch_alpha = 1;   // ... i.e. when alpha x (looked-up bytes) <= the chunk's bytes.  Measured on MI355X: rows of 1568 bytes
                                     // fetched by the kernel cross PCIe at 50.8 GB/s, whole chunks at 52.3 GB/s (profiles/r03_c5_selective.txt): 1

@@ -108,8 +108,12 @@ cobs_gpu_status cobs_amd::set_queries_on(cobs_gpu_batch* b, const char* const* q
         max_terms = std::max<uint64_t>(max_terms, lens[q] - min_term + 1);
     }
     if (bad_query) *bad_query = 0;
-    const int planes = scan_planes_for(max_terms);
+    int planes = scan_planes_for(max_terms);
     if (planes < 0) return fail(COBS_GPU_ERR_QUERY_TOO_LONG, "query too long");
+    // the reference's classic_search_disable_8bit / _16bit switches (classic_search.cpp:207-209, :453-504; its tests
+    // run one query under every Score width, tests/compact_index_query.cpp:54-140): a wider score type on request
+    if (ix->tune.min_score_bytes >= 2 && planes < 10) planes = 10;
+    if (ix->tune.min_score_bytes >= 4 && planes < 20) planes = 20;
     b->planes = planes;
     b->max_terms = max_terms;
     b->elem_bytes = scan_score_bytes(planes);

@@ -132,7 +132,8 @@ void cobs_gpu_close(cobs_gpu_index* ix);
  * "mq" (-1 auto, 0, 1), "pass_bytes", "pipe_chars", "graph" (-1 auto, 0, 1), "lds_staged" (0, 1: the
  * measured LDS-staged variant of the scan, headline shape only), "device_rank" / "tile_topk" / "row_fetch" (0 turns the
  * on-device ranking of whole rows / the tile-level top-k / the row-selective out-of-core pass off: A/B and fallback),
- * "row_fetch_alpha".  0 / -1 = automatic. */
+ * "row_fetch_alpha", "min_score_bytes" (2 / 4: score rows at least that wide -- the reference's
+ * classic_search_disable_8bit / _16bit switches, classic_search.cpp:207-209).  0 / -1 = automatic. */
 cobs_gpu_status cobs_gpu_set_tuning(cobs_gpu_index* ix, const char* key, int64_t value);
 /* Host only (no device needed): the score slots [slot_begin[r], slot_begin[r] + slot_count[r]) and
  * the index bytes shard r of shard_count would hold of the file at `path` (arrays of shard_count

@@ -696,6 +696,30 @@ def test_one_graph_serves_a_class_of_query_lengths(gpu_lib, oracle, tmp_path):
     assert s.graph_replays - r0 >= 18
 
 
+def test_every_score_width_on_one_query(gpu_lib, oracle, tmp_path):
+    """the reference's tests run ONE query under every Score width ("check all expansion tables",
+    tests/compact_index_query.cpp:54-140, classic_search_disable_8bit / _16bit / _32bit): the same short queries with
+    8-, 16- and 32-bit scores -- counts, thresholded hits, tile-level top-k and the full ranking are identical"""
+    import torch
+    q = oracle.random_sequence(230, 61)
+    p = cases.make_compact(cases.tmp(tmp_path, "w.cobs_compact"), 3 * 8 * 24 - 5, 24, [509, 401, 307], 3, 31, 1, 0.1, 4,
+                           planted={0: 0.5, 200: 1.0, 570: 0.8}, query=q)
+    ix = oracle.Index.open(p)
+    queries = [q, q[:80], q[10:45], q[:31], q[3:200]]
+    s = gpu_lib.Search(p)
+    for width, dtype in ((1, torch.uint8), (2, torch.int16), (4, torch.int32)):
+        s.set_tuning("min_score_bytes", width)
+        b = gpu_lib.Batch(s)
+        b.set_queries(queries)
+        b.run(0.0)
+        b.sync()
+        assert b.counts_tensor().element_size() == width
+        for i, qq in enumerate(queries):
+            assert np.array_equal(b.counts_host(i), ix.counts(qq)), (width, i)
+        for t, lim in ((0.0, 0), (0.5, 0), (0.0, 4), (0.3, 9)):
+            assert s.search_hits(queries, t, lim) == [cases.oracle_results([ix], qq, t, lim) for qq in queries], (width, t, lim)
+
+
 def test_default_call_in_batches_is_ranked_by_host_threads(gpu_lib, oracle, tmp_path):
     """threshold 0, no limit (the reference's default arguments) for MANY queries per call: the
     passes' score rows are ranked by several host threads -- every document, in the reference's
