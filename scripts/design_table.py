@@ -6,11 +6,12 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROWS = ["c3", "c2", "c4", "c3h3", "reads50", "reads100", "reads150", "c3hits", "reads100hits", "c3top10"]
+ROWS = ["c3", "c2", "c4", "c3h3", "reads50", "reads100", "reads150", "c3hits", "reads100hits", "c3top10", "c3top10rows",
+        "reads100top10"]
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     shapes = json.load(open(os.path.join(ROOT, "profiles", tag + "_shapes.json")))
     path = os.path.join(ROOT, "DESIGN.md")
     lines = open(path).read().split("\n")
