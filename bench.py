@@ -238,7 +238,8 @@ def kernels_hash():
     """identifies the kernel source a profile belongs to (the GPU box has no .git)"""
     import hashlib
     h = hashlib.sha256()
-    for fn in ("kernels.hip", "rank_kernels.hip", "fetch_kernels.hip", "plan.cpp", "pass.cpp", "rank.cpp"):
+    # (the scan kernels and what chooses their launch geometry: what the replayed PMC traffic depends on)
+    for fn in ("kernels.hip", "plan.cpp", "pass.cpp"):
         with open(os.path.join(ROOT, "cobs_amd", "csrc", fn), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

@@ -149,7 +149,7 @@ struct RankArgs {
     const uint2* src;            // (score, slot) pairs of the previous pass [nq][pair_stride]
     uint2* dst;                  // ... of this pass, unless it is the last
     uint32_t* npass;             // [nq] passing documents: written by a first pass that is not the last, read by later ones
-    cobs_gpu_hit* out;           // last pass: results [nq][out_stride], at most `limit` per query
+    uint2* out;                  // last pass: results [nq][out_stride] as (slot of the ranked row, score), at most `limit` per query
     uint32_t* out_count;         // last pass: [nq] results written = min(limit, passing documents)
     uint64_t pair_stride, out_stride;
     uint32_t nparts, nslots;     // slots of a row that are ranked (the files' slices)

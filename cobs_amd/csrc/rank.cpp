@@ -2,13 +2,17 @@
 // rank_kernels.hip.  The reference's default call (threshold 0, no limit; also its own benchmark,
 // src/cobs.cpp:618-626) returns EVERY document of every query in rank order
 // (cobs/query/classic_search.cpp:109-202).  The score rows stay in HBM; a window of queries is
-// ordered there (one work-group per query), the ordered records cross PCIe once as the
-// cobs_gpu_hit array the caller gets -- 12 bytes per document instead of a score row that host
-// threads then sort -- and while window w crosses, window w+1 is being ordered and the host copies
-// window w-1 from the pinned landing buffer into the caller's (pageable) memory.
+// ordered there (one work-group per query), the ordered (slot, score) records cross PCIe once -- 8 bytes per
+// result, already in rank order, instead of a score row that host threads then sort -- and while window w
+// crosses, window w+1 is being ordered and the host expands window w-1 from the pinned landing buffer into the
+// cobs_gpu_hit records (file, document, score) of the caller's (pageable) array.
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -16,15 +20,81 @@
 
 namespace cobs_amd {
 
+// A few host threads that stay around for the life of a batch's ranking workspace: expanding a window of records
+// is ~1 ms of work, spawning 16 threads per window would cost as much again.
+class ExpandPool {
+public:
+    explicit ExpandPool(unsigned n) {
+        for (unsigned i = 0; i < n; ++i) threads_.emplace_back([this]() { loop(); });
+    }
+    ~ExpandPool() {
+        { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    unsigned size() const { return (unsigned)threads_.size(); }
+    // run fn(i) for i in [0, n) on the pool (and the caller), return when all are done
+    void run(size_t n, const std::function<void(size_t)>& fn) {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            fn_ = &fn;
+            next_ = 0;
+            total_ = n;
+            pending_ = n;
+        }
+        cv_.notify_all();
+        for (;;) {                                  // the caller works too
+            size_t i;
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                if (next_ >= total_) break;
+                i = next_++;
+            }
+            fn(i);
+            std::lock_guard<std::mutex> g(mu_);
+            --pending_;
+        }
+        std::unique_lock<std::mutex> g(mu_);
+        done_.wait(g, [this]() { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    void loop() {
+        for (;;) {
+            size_t i;
+            const std::function<void(size_t)>* fn;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [this]() { return stop_ || (fn_ && next_ < total_); });
+                if (stop_) return;
+                i = next_++;
+                fn = fn_;
+            }
+            (*fn)(i);
+            std::lock_guard<std::mutex> g(mu_);
+            if (--pending_ == 0) done_.notify_all();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(size_t)>* fn_ = nullptr;
+    size_t next_ = 0, total_ = 0, pending_ = 0;
+    bool stop_ = false;
+};
+
 struct RankWork {
-    DevBuf<cobs_gpu_hit> out[2];
+    std::unique_ptr<ExpandPool> pool;
+    static constexpr int kDepth = 3;    // windows in flight: one being ordered, one crossing PCIe, one being expanded
+    DevBuf<uint2> out[kDepth];          // (slot, score) records of a window, in rank order
     DevBuf<uint2> pairs[2];
-    DevBuf<uint32_t> cnt[2];            // [window]: results per query; npass of multi-pass sorts behind it
+    DevBuf<uint32_t> cnt[kDepth];       // [window]: results per query; npass of multi-pass sorts behind it
     DevBuf<RankPart> parts;
     DevBuf<uint8_t> by_score;
-    PinnedBuf<uint8_t> land[2];         // records of a window, then its counts
+    PinnedBuf<uint8_t> land[kDepth];    // records of a window, then its counts
     hipStream_t copy_stream = nullptr;
-    hipEvent_t ranked[2] = {nullptr, nullptr}, landed[2] = {nullptr, nullptr};
+    hipEvent_t ranked[kDepth] = {nullptr, nullptr, nullptr}, landed[kDepth] = {nullptr, nullptr, nullptr};
     ~RankWork() {
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
         for (auto e : ranked) if (e) (void)hipEventDestroy(e);
@@ -38,19 +108,30 @@ namespace {
 
 constexpr size_t kWindowBytes = 32u << 20;     // per window: short head (first ordering) and tail (last host copy) of the pipeline
 
-// copy `bytes` from the pinned landing buffer into caller memory with a few threads
-void spread_copy(uint8_t* dst, const uint8_t* src, size_t bytes) {
-    const size_t kPiece = 4u << 20;
-    const unsigned nthr = (unsigned)std::min<size_t>(std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())),
-                                                      (bytes + kPiece - 1) / kPiece);
-    if (nthr <= 1) { std::memcpy(dst, src, bytes); return; }
-    std::vector<std::thread> pool;
-    const size_t per = (bytes + nthr - 1) / nthr;
-    for (unsigned t = 0; t < nthr; ++t) {
-        const size_t a = std::min(bytes, (size_t)t * per), e = std::min(bytes, a + per);
-        if (e > a) pool.emplace_back([=]() { std::memcpy(dst + a, src + a, e - a); });
-    }
-    for (auto& th : pool) th.join();
+// `n` (slot, score) records of the pinned landing buffer -> cobs_gpu_hit records in caller memory, with a few
+// threads: the slot of the ranked row becomes (file, document)
+void expand_records(ExpandPool* pool, cobs_gpu_hit* dst, const uint2* src, size_t n, const std::vector<RankPart>& parts) {
+    auto work = [&parts](cobs_gpu_hit* d, const uint2* s, size_t cnt) {
+        if (parts.size() == 1) {
+            const RankPart pt = parts[0];
+            const uint32_t bias = pt.doc_first - pt.slot0;
+            for (size_t i = 0; i < cnt; ++i) d[i] = cobs_gpu_hit{pt.file_no, s[i].x + bias, s[i].y};
+            return;
+        }
+        for (size_t i = 0; i < cnt; ++i) {
+            size_t p = 0;
+            while (p + 1 < parts.size() && s[i].x >= parts[p + 1].slot0) ++p;
+            d[i] = cobs_gpu_hit{parts[p].file_no, parts[p].doc_first + (s[i].x - parts[p].slot0), s[i].y};
+        }
+    };
+    const size_t kPiece = 128u << 10;        // records per job
+    const size_t jobs = (n + kPiece - 1) / kPiece;
+    if (jobs <= 1 || !pool) { work(dst, src, n); return; }
+    const std::function<void(size_t)> job = [&](size_t j) {
+        const size_t a = j * kPiece, e = std::min(n, a + kPiece);
+        work(dst + a, src + a, e - a);
+    };
+    pool->run(jobs, job);
 }
 
 }  // namespace
@@ -76,6 +157,7 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
     if (!b->rank) b->rank = new RankWork;
     RankWork& w = *b->rank;
     hipStream_t st = b->own_stream;             // the stream the pass ran on (host-buffer API)
+    if (!w.pool) w.pool.reset(new ExpandPool(std::min(15u, std::max(1u, std::thread::hardware_concurrency()) - 1u)));
     if (!w.copy_stream) {
         HIP_TRY(hipStreamCreateWithFlags(&w.copy_stream, hipStreamNonBlocking));
         for (auto& e : w.ranked) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -125,21 +207,22 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
     const uint32_t planes = (uint32_t)b->planes;
     const uint32_t npasses = (planes + 11u) / 12u;
     const uint32_t pbits = (planes + npasses - 1u) / npasses;
-    const size_t wq = std::max<size_t>(1, std::min<size_t>(nq, kWindowBytes / (stride * sizeof(cobs_gpu_hit))));
-    const size_t land_bytes = wq * stride * sizeof(cobs_gpu_hit);
-    for (int i = 0; i < 2; ++i) {
+    const size_t wq = std::max<size_t>(1, std::min<size_t>(nq, kWindowBytes / (stride * sizeof(uint2))));
+    const size_t land_bytes = wq * stride * sizeof(uint2);
+    constexpr size_t kDepth = RankWork::kDepth;
+    for (size_t i = 0; i < kDepth; ++i) {
         HIP_TRY(w.out[i].reserve(wq * stride));
         HIP_TRY(w.cnt[i].reserve(2 * wq));
         HIP_TRY(w.land[i].reserve(land_bytes + 4 * wq));
-        if (npasses > 1) HIP_TRY(w.pairs[i].reserve(wq * row_elems));
     }
+    if (npasses > 1) for (auto& pr : w.pairs) HIP_TRY(pr.reserve(wq * row_elems));
     struct Win { size_t q0, n; };
     std::vector<Win> wins;
     for (size_t q0 = 0; q0 < nq; q0 += wq) wins.push_back(Win{q0, std::min(wq, nq - q0)});
     auto launch = [&](size_t wi) -> cobs_gpu_status {
         const Win& wn = wins[wi];
-        const int s = (int)(wi & 1);
-        if (wi >= 2) HIP_TRY(hipStreamWaitEvent(st, w.landed[s], 0));     // the window that used these buffers has left them
+        const int s = (int)(wi % kDepth);
+        if (wi >= kDepth) HIP_TRY(hipStreamWaitEvent(st, w.landed[s], 0));     // the window that used these buffers has left them
         RankArgs a{};
         a.rows = glob ? (const void*)b->g_rows : (const void*)b->counts.p;
         a.row_stride = row_elems;
@@ -166,7 +249,7 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
         }
         HIP_TRY(hipEventRecord(w.ranked[s], st));
         HIP_TRY(hipStreamWaitEvent(w.copy_stream, w.ranked[s], 0));
-        HIP_TRY(hipMemcpyAsync(w.land[s].p, w.out[s].p, wn.n * stride * sizeof(cobs_gpu_hit), hipMemcpyDeviceToHost, w.copy_stream));
+        HIP_TRY(hipMemcpyAsync(w.land[s].p, w.out[s].p, wn.n * stride * sizeof(uint2), hipMemcpyDeviceToHost, w.copy_stream));
         HIP_TRY(hipMemcpyAsync(w.land[s].p + land_bytes, w.cnt[s].p, 4 * wn.n, hipMemcpyDeviceToHost, w.copy_stream));
         HIP_TRY(hipEventRecord(w.landed[s], w.copy_stream));
         return COBS_GPU_OK;
@@ -174,25 +257,30 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
     const bool trace = ix->tune.trace;
     double t_wait = 0, t_copy = 0, t_prep = now_s();
     cobs_gpu_status rs = launch(0);
-    if (rs != COBS_GPU_OK) return rs;
+    if (rs == COBS_GPU_OK && wins.size() > 1) rs = launch(1);
+    if (rs != COBS_GPU_OK) {                    // nothing of this batch may still be in flight when the caller sees the error
+        (void)hipStreamSynchronize(st);
+        (void)hipStreamSynchronize(w.copy_stream);
+        return rs;
+    }
     t_prep = now_s() - t_prep;
     for (size_t wi = 0; wi < wins.size(); ++wi) {
-        // window wi+1 is ordered and crosses PCIe while the host takes window wi out of its landing
-        // buffer -- which window wi+2 will reuse, so wi+2 is launched only after this copy
-        if (wi + 1 < wins.size() && (rs = launch(wi + 1)) != COBS_GPU_OK) break;
-        const int s = (int)(wi & 1);
+        // two windows ahead: while the host expands window wi out of its landing buffer, window wi+1 crosses PCIe
+        // and window wi+2 is being ordered (its landing buffer is the one the host left at iteration wi-1)
+        if (wi + 2 < wins.size() && (rs = launch(wi + 2)) != COBS_GPU_OK) break;
+        const int s = (int)(wi % kDepth);
         double t0 = now_s();
         if (hipEventSynchronize(w.landed[s]) != hipSuccess) { rs = hip_fail(hipGetLastError(), "rank window"); break; }
         t_wait += now_s() - t0;
         t0 = now_s();
         const Win& wn = wins[wi];
         const uint32_t* cnt = reinterpret_cast<const uint32_t*>(w.land[s].p + land_bytes);
-        const uint8_t* rec = w.land[s].p;
+        const uint2* rec = reinterpret_cast<const uint2*>(w.land[s].p);
         bool full = true;
         for (size_t i = 0; i < wn.n; ++i) full = full && cnt[i] == stride;
         if (full && !*overflow && wn.n * stride <= cap - *used) {
             // every query of the window yields `stride` results (the default call): one block copy
-            spread_copy(reinterpret_cast<uint8_t*>(hits + *used), rec, wn.n * stride * sizeof(cobs_gpu_hit));
+            expand_records(w.pool.get(), hits + *used, rec, wn.n * stride, parts);
             for (size_t i = 0; i < wn.n; ++i) {
                 *used += stride;
                 hit_offsets[wn.q0 + i + 1] = *used;
@@ -203,7 +291,7 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
         for (size_t i = 0; i < wn.n; ++i) {
             const size_t n = cnt[i];
             if (!*overflow && n <= cap - *used)
-                std::memcpy(hits + *used, rec + i * stride * sizeof(cobs_gpu_hit), n * sizeof(cobs_gpu_hit));
+                expand_records(w.pool.get(), hits + *used, rec + i * stride, n, parts);
             else
                 *overflow = true;
             *used += n;

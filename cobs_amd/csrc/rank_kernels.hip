@@ -16,7 +16,7 @@
 //                 (match-any), a lane's position is base[wave][digit] + its rank among them, the
 //                 first lane of each digit advances the base.
 //                 Scores of up to 12 bits (queries of up to 4095 terms) need ONE pass straight from
-//                 the score rows to the result records; wider scores take 2 (up to 24 bits) or 3
+//                 the score rows to the result records (8 bytes each: slot, score); wider scores take 2 (up to 24 bits) or 3
 //                 passes through (score, slot) pairs in HBM.
 //
 // The elements of the first pass are the local score slots of the row (the files' slices back to
@@ -80,7 +80,7 @@ __device__ __forceinline__ uint32_t part_of(const RankArgs& a, uint32_t slot) {
 }
 
 // FIRST: elements are the slots of the score row; else (score, slot) pairs of the previous pass.
-// LAST: results leave as cobs_gpu_hit records; else as (score, slot) pairs.
+// LAST: results leave as (slot, score) records in rank order; else as (score, slot) pairs for the next pass.
 template <typename ST, bool FIRST, bool LAST>
 __global__ __launch_bounds__(256) void rank_kernel(RankArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void rank_kernel(RankArgs a) {
     }
     // ---- (3) stable scatter: every wave walks its range in order
     uint2* dst = a.dst + (uint64_t)qb * a.pair_stride;
-    cobs_gpu_hit* out = a.out + (uint64_t)qb * a.out_stride;
+    uint2* out = a.out + (uint64_t)qb * a.out_stride;
     auto place = [&](bool valid, uint32_t score, uint32_t slot) {
         const uint32_t bin = dmask - (by_score ? (score >> a.shift) & dmask : 0u);
         // lanes of this step with the same bin
@@ -196,11 +196,9 @@ __global__ __launch_bounds__(256) void rank_kernel(RankArgs a) {
         wave_sync();
         if (!valid) return;
         if constexpr (LAST) {
-            if (pos < a.limit) {
-                const uint32_t p = part_of(a, slot);
-                const RankPart pt = a.parts[p];
-                out[pos] = cobs_gpu_hit{pt.file_no, pt.doc_first + (slot - pt.slot0), score};
-            }
+            // (slot of the ranked row, score): 8 bytes per result over PCIe; the host turns the slot into
+            // (file, document) while it copies the window into the caller's cobs_gpu_hit array (rank.cpp)
+            if (pos < a.limit) out[pos] = make_uint2(slot, score);
         } else {
             dst[pos] = make_uint2(score, slot);
         }
