@@ -102,7 +102,7 @@ struct FetchArgs {
     const PageDev* pages;        // the chunk's pages as resident data would hold them
     PageDev* pages2;             // ... as the gathered buffer holds them (written here)
     const uint64_t* page_src;    // [npages] file offset of (row 0, first held column) of every slice
-    uint8_t* dst;                // gathered rows: [npages][entries] rows of `pitch` bytes, then one zero row
+    uint8_t* dst;                // gathered rows: [npages][entries + 1] rows of `pitch` bytes (the last of each page all zero)
     uint64_t entries;            // table entries per sub-index: (blk_off[nq] + nq) * 8 * num_hashes
     uint64_t src_pitch;          // bytes between rows in the file
     uint32_t nq, npages, table_npages, num_hashes, pitch, ncols;

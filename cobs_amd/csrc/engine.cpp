@@ -81,6 +81,11 @@ Part::~Part() {
         if (c.d_src) (void)hipFree(c.d_src);
         for (auto* p2 : c.d_pages2) if (p2) (void)hipFree(p2);
     }
+    for (Chunk& c : fetch_groups) {
+        if (c.d_pages) (void)hipFree(c.d_pages);
+        if (c.d_src) (void)hipFree(c.d_src);
+        for (auto* p2 : c.d_pages2) if (p2) (void)hipFree(p2);
+    }
     if (d_tpages) (void)hipFree(d_tpages);
     if (file_pinned && file) (void)hipHostUnregister(const_cast<uint8_t*>(file->data()));
 }
@@ -199,6 +204,33 @@ static cobs_gpu_status stage_index(cobs_gpu_index* ix, std::vector<std::unique_p
                         HIP_TRY(hipMalloc((void**)&c.d_src, 8 * src.size()));
                         HIP_TRY(hipMemcpy(c.d_src, src.data(), 8 * src.size(), hipMemcpyHostToDevice));
                         for (auto& p2 : c.d_pages2) HIP_TRY(hipMalloc((void**)&p2, sizeof(PageDev) * c.vp.size()));
+                    }
+                    // the chunks of equal pitch as one unit each (pass.cpp uses them when every chunk is fetched by rows)
+                    if (pt.chunks.size() > 1) {
+                        for (const Chunk& c : pt.chunks) {
+                            Chunk* g = nullptr;
+                            for (Chunk& have : pt.fetch_groups)
+                                if (have.pitch == c.pitch) g = &have;
+                            if (!g) {
+                                pt.fetch_groups.emplace_back();
+                                g = &pt.fetch_groups.back();
+                                g->pitch = c.pitch;
+                                g->cpp = c.cpp;
+                            }
+                            g->vp.insert(g->vp.end(), c.vp.begin(), c.vp.end());
+                            g->pages.insert(g->pages.end(), c.pages.begin(), c.pages.end());
+                            g->bytes += c.bytes;
+                        }
+                        for (Chunk& g : pt.fetch_groups) {
+                            g.total_chunks = (uint32_t)g.vp.size() * g.cpp;
+                            std::vector<uint64_t> src(g.vp.size());
+                            for (size_t k = 0; k < g.vp.size(); ++k) src[k] = pt.meta.page_offset(g.vp[k].fp) + g.vp[k].col0;
+                            HIP_TRY(hipMalloc((void**)&g.d_pages, sizeof(PageDev) * g.pages.size()));
+                            HIP_TRY(hipMemcpy(g.d_pages, g.pages.data(), sizeof(PageDev) * g.pages.size(), hipMemcpyHostToDevice));
+                            HIP_TRY(hipMalloc((void**)&g.d_src, 8 * src.size()));
+                            HIP_TRY(hipMemcpy(g.d_src, src.data(), 8 * src.size(), hipMemcpyHostToDevice));
+                            for (auto& p2 : g.d_pages2) HIP_TRY(hipMalloc((void**)&p2, sizeof(PageDev) * g.vp.size()));
+                        }
                     }
                     if (!ix->stream.hashed) HIP_TRY(hipEventCreateWithFlags(&ix->stream.hashed, hipEventDisableTiming));
                 } else {

@@ -141,6 +141,9 @@ struct Part {
     uint32_t first_page = 0, end_page = 0;   // file-level sub-indexes (partly) held here
     std::vector<VPage> held;                 // the slices of those sub-indexes this shard holds, in slot order
     std::vector<Chunk> chunks;
+    // streamed file whose mapping is registered: the chunks of equal row pitch merged -- when a (small) batch fetches
+    // every chunk of the file by rows, one fetch + one scan per pitch does the pass instead of one pair per chunk
+    std::vector<Chunk> fetch_groups;
     std::vector<PageDev> tpages;             // sub-indexes [first_page, end_page): pages of the row-index table
     PageDev* d_tpages = nullptr;
     bool streamed = false;

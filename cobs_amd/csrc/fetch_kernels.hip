@@ -10,9 +10,9 @@
 //                       indices K1 wrote, fetches exactly those rows from the index file -- whose mapping is
 //                       registered with HIP, so the loads go over PCIe straight from the page cache, 16
 //                       bytes per lane, a row's pieces on consecutive lanes (1 KiB per wave-load) -- into a
-//                       gathered buffer in HBM laid out like a resident chunk (same pitch, one shared zero
-//                       row), and writes the row-index table of that buffer (entry e -> gathered row e; padding
-//                       entries -> the zero row) plus the PageDev array describing it.  K2 then scans the
+//                       gathered buffer in HBM laid out like a resident chunk (same pitch, a zero row behind
+//                       every slice's rows), and writes the row-index table of that buffer (entry e -> gathered
+//                       row e; padding entries -> the zero row) plus the PageDev array describing it.  K2 then scans the
 //                       gathered buffer with the code it runs on resident data.
 //
 // A row looked up twice is fetched twice: the engine chooses this path only when the batch's lookups are a
@@ -53,22 +53,22 @@ template <typename IdxT>
 __global__ __launch_bounds__(256) void fetch_rows_kernel(FetchArgs a) {
     const uint32_t cpp = a.pitch / 16u;
     const uint64_t E = a.entries;
-    const uint64_t rows = (uint64_t)a.npages * E;
+    const uint64_t rows = (uint64_t)a.npages * (E + 1u);   // every page: its E gathered rows, then its zero row
     const uint64_t gid = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     const uint64_t rowno = gid / cpp;                      // page-major gathered row
     const uint32_t c = (uint32_t)(gid - rowno * cpp);
-    if (rowno > rows) return;
+    if (rowno >= rows) return;
     uint8_t* out = a.dst + rowno * a.pitch + (uint64_t)c * 16u;
-    if (rowno == rows) {                                   // the zero row every padding entry points at
+    const uint32_t i = (uint32_t)(rowno / (E + 1u));       // page of the chunk
+    const uint64_t n = rowno - (uint64_t)i * (E + 1u);     // entry of that page: [query][block + padding block][hash][8]
+    if (n == E) {                                          // the page's zero row: what its padding entries point at
         *reinterpret_cast<uint4*>(out) = make_uint4(0u, 0u, 0u, 0u);
         return;
     }
-    const uint32_t i = (uint32_t)(rowno / E);              // page of the chunk
-    const uint64_t n = rowno - (uint64_t)i * E;            // entry of that page: [query][block + padding block][hash][8]
     const PageDev pd = a.pages[i];
     if (n == 0u && c == 0u) {                              // the page as the gathered buffer holds it
         PageDev g = pd;
-        g.base = (uint64_t)i * E * a.pitch;
+        g.base = (uint64_t)i * (E + 1u) * a.pitch;
         g.sig = E;
         a.pages2[i] = g;
     }
@@ -86,9 +86,9 @@ __global__ __launch_bounds__(256) void fetch_rows_kernel(FetchArgs a) {
     const uint64_t r = reinterpret_cast<const IdxT*>(a.table)[e];
     const bool pad = r >= pd.sig;                          // K1 points padded terms at row S_p
     if (c == 0u)
-        reinterpret_cast<IdxT*>(a.table2)[e] = (IdxT)(pad ? (uint64_t)(a.npages - i) * E : n);
+        reinterpret_cast<IdxT*>(a.table2)[e] = (IdxT)(pad ? E : n);     // (several slices of one sub-index share these entries)
     if (pad) return;                                       // never read: its table entry names the zero row
-    const uint32_t nvalid = a.ncols > c * 16u ? min(a.ncols - c * 16u, 16u) : 0u;
+    const uint32_t nvalid = pd.valid_bytes > c * 16u ? min(pd.valid_bytes - c * 16u, 16u) : 0u;   // slices of one pitch may differ in width
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
     if (nvalid) v = load16_any(a.file + a.page_src[i] + r * a.src_pitch + (uint64_t)c * 16u, nvalid);
     *reinterpret_cast<uint4*>(out) = v;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void fetch_rows_kernel(FetchArgs a) {
 
 hipError_t launch_fetch_rows(const FetchArgs& a, bool idx64, hipStream_t stream) {
     if (a.npages == 0 || a.nq == 0 || a.entries == 0) return hipSuccess;
-    const uint64_t items = ((uint64_t)a.npages * a.entries + 1u) * (a.pitch / 16u);
+    const uint64_t items = (uint64_t)a.npages * (a.entries + 1u) * (a.pitch / 16u);
     const uint64_t blocks = (items + 255u) / 256u;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     if (idx64) hipLaunchKernelGGL(fetch_rows_kernel<uint64_t>, dim3((uint32_t)blocks), dim3(256), 0, stream, a);

@@ -303,9 +303,30 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
     std::vector<std::vector<ScanGeom>> geoms(ix->parts.size());
     std::vector<uint64_t> cand_off(ix->parts.size() + 1, 0);
     std::vector<uint32_t> cand_tiles(ix->parts.size(), 0), cand_stride(ix->parts.size(), 0);
+    // the units of a file's pass: its chunks -- or, for a streamed file of which this batch would fetch EVERY chunk
+    // by rows, the chunks of equal pitch merged (one fetch + one scan per pitch: a single query against a file of ten
+    // chunks is 2-3 launch pairs instead of ten)
+    std::vector<std::vector<const Chunk*>> units(ix->parts.size());
+    std::vector<bool> grouped(ix->parts.size(), false);
     for (size_t f = 0; f < ix->parts.size() && nq; ++f) {
         const Part& p = ix->parts[f];
-        for (const Chunk& c : p.chunks) {
+        const uint64_t E = (b->work[f].h_blk_off[nq] + nq) * 8ull * p.meta.num_hashes;
+        auto fetchable = [&](const Chunk& c) {
+            const uint64_t gathered = (E + 1) * c.vp.size() * (uint64_t)c.pitch;
+            return ix->tune.row_fetch != 0 && p.streamed && p.file_dev && c.d_src && !p.synthetic &&
+                   gathered <= ix->stream.sbuf[0].cap && E < 0xFFFFFFF0ull &&
+                   gathered * ix->tune.row_fetch_alpha <= c.bytes;
+        };
+        bool all = !p.fetch_groups.empty();
+        for (const Chunk& c : p.chunks) all = all && fetchable(c);
+        for (const Chunk& g : p.fetch_groups) all = all && fetchable(g);
+        grouped[f] = all;
+        for (const Chunk& c : all ? p.fetch_groups : p.chunks) units[f].push_back(&c);
+    }
+    for (size_t f = 0; f < ix->parts.size() && nq; ++f) {
+        const Part& p = ix->parts[f];
+        for (const Chunk* cp : units[f]) {
+            const Chunk& c = *cp;
             geoms[f].push_back(scan_geometry(c, b->work[f].h_blk_off[nq] / nq, (b->max_terms + 7) / 8, p.meta.num_hashes,
                                              ix->waves_per_group, b->planes, p.idx64, ix->tune));
             cand_tiles[f] += (c.total_chunks + geoms[f].back().tile_w - 1) / geoms[f].back().tile_w;
@@ -329,7 +350,7 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
     StreamBufs& sbufs = ix->stream;
     for (size_t f = 0; f < ix->parts.size(); ++f) {
         Part& p = ix->parts[f];
-        if (nq == 0 || p.chunks.empty()) continue;
+        if (nq == 0 || p.chunks.empty() || units[f].empty()) continue;
         {   // K1 once per file and pass: the row-index table covers every held sub-index,
             // the chunks (launches) of the file pick their sub-indexes by PageDev::tpage
             HashArgs ha;
@@ -366,8 +387,8 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                 HIP_TRY(sbufs.table2[i].reserve(need));
             }
         }
-        for (size_t ci = 0; ci < p.chunks.size(); ++ci) {
-            const Chunk& c = p.chunks[ci];
+        for (size_t ci = 0; ci < units[f].size(); ++ci) {
+            const Chunk& c = *units[f][ci];
             const uint8_t* data = c.d_data;
             int buf = 0;
             const PageDev* pages_dev = c.d_pages;
@@ -383,10 +404,11 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                 // the difference).  The reference's mmap / AIO back-ends always take the first form
                 // (compact_index/mmap_search_file.cpp:34-67, aio_search_file.cpp:58-97).
                 const uint64_t E = (b->work[f].h_blk_off[nq] + nq) * 8ull * p.meta.num_hashes;
-                const uint64_t gathered = (E * c.vp.size() + 1) * (uint64_t)c.pitch;
-                const bool fetch = ix->tune.row_fetch != 0 && p.file_dev && c.d_src && !p.synthetic &&
-                                   gathered <= sbufs.sbuf[buf].cap && E * c.vp.size() < 0xFFFFFFF0ull &&
-                                   (gathered - c.pitch) * ix->tune.row_fetch_alpha <= c.bytes;
+                const uint64_t gathered = (E + 1) * c.vp.size() * (uint64_t)c.pitch;
+                const bool fetch = grouped[f] ||
+                                   (ix->tune.row_fetch != 0 && p.file_dev && c.d_src && !p.synthetic &&
+                                    gathered <= sbufs.sbuf[buf].cap && E < 0xFFFFFFF0ull &&
+                                    gathered * ix->tune.row_fetch_alpha <= c.bytes);
                 if (fetch) {
                     if (!fetch_ready) {          // the fetch kernel reads K1's table: once per file and pass
                         HIP_TRY(hipEventRecord(sbufs.hashed, st));
