@@ -71,7 +71,7 @@ def test_bench_sharded_code_path_on_one_rank(gpu_lib):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--one-rank-sharded", "--scale", "0.02",
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--one-rank-sharded", "--extras", "--scale", "0.02",
                         "--queries", "512", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
