@@ -284,8 +284,11 @@ class ShardedSearch:
             self.batch.sync()
             return self.batch.global_counts_tensor()[2]
         self.batch.sync()
-        gathered = all_gather_counts(self.batch.counts_tensor(), self.group)
-        return assemble_counts(gathered, self.layouts, self.total_counts)
+        # torch transport: the library's own exchange plan (what comm.cpp executes over RCCL), moved with
+        # torch.distributed transfers
+        _, _, rows = exchange_counts_by_plan(self.batch.counts_tensor(), self.layouts, self.total_counts, len(queries),
+                                             _capi.XCHG_ALLGATHER, self.group)
+        return rows
 
     def search_hits(self, queries, threshold=0.0, num_results=0):
         s = self.search_local
