@@ -169,6 +169,8 @@ SYMBOLS = {
     "cobs_gpu_batch_exchange_topk": (_int, [_vp, _vp, _vp]),
     "cobs_gpu_sharded_search_batch": (_int, [_vp, _vp, C.POINTER(_cp), C.POINTER(_sz), _sz, _dbl, _sz,
                                              C.POINTER(Hit), _sz, C.POINTER(_sz), C.POINTER(_sz)]),
+    "cobs_gpu_sharded_search_batch_split": (_int, [_vp, _vp, C.POINTER(_cp), C.POINTER(_sz), _sz, _dbl, _sz,
+                                                   C.POINTER(Hit), _sz, C.POINTER(_sz), C.POINTER(_sz)]),
 }
 
 _lib = None

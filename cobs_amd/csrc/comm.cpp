@@ -680,9 +680,12 @@ cobs_gpu_status cobs_gpu_batch_exchange_topk(cobs_gpu_batch* b, cobs_gpu_comm* c
 
 // ClassicSearch::search over the sharded index: every rank calls this with the same queries and
 // gets the same, global, result (hits ordered as cobs_gpu_search_batch orders them).
-cobs_gpu_status cobs_gpu_sharded_search_batch(cobs_gpu_index* ix, cobs_gpu_comm* c, const char* const* queries,
-                                              const size_t* lens, size_t nq, double threshold, size_t num_results,
-                                              cobs_gpu_hit* hits, size_t cap, size_t* hit_offsets, size_t* bad_query) {
+// split (cobs_gpu_sharded_search_batch_split): for the all-documents call (threshold <= 0, no limit) the ranks SHARE
+// the ranking instead of repeating it -- the count rows go all-to-all to query owners, rank j orders the queries
+// [n*j/N, n*(j+1)/N) of every pass and writes their results (and offsets) at their final places of the caller's arrays.
+static cobs_gpu_status sharded_search_impl(cobs_gpu_index* ix, cobs_gpu_comm* c, const char* const* queries,
+                                           const size_t* lens, size_t nq, double threshold, size_t num_results,
+                                           cobs_gpu_hit* hits, size_t cap, size_t* hit_offsets, size_t* bad_query, bool split) {
     if (!ix || !c || !hit_offsets) return fail(COBS_GPU_ERR_ARG, "NULL argument");
     if (nq && (!queries || !lens)) return fail(COBS_GPU_ERR_ARG, "NULL argument");
     return guarded([&]() -> cobs_gpu_status {
@@ -709,6 +712,16 @@ cobs_gpu_status cobs_gpu_sharded_search_batch(cobs_gpu_index* ix, cobs_gpu_comm*
         }
         const size_t topk = num_results < ix->total_counts ? num_results : 0;
         const bool all_docs = threshold <= 0.0 && topk == 0;
+        // shared ranking: every query yields one result per real document, so every result's place is known up front
+        const bool shared = split && all_docs;
+        size_t per_query = 0;
+        for (const auto& p : ix->parts) per_query += p.meta.doc_names.size();
+        if (shared) {
+            if (cap < nq * per_query || (nq * per_query && !hits)) {      // the same on every rank: nobody enters a collective
+                for (size_t q = 0; q < nq; ++q) hit_offsets[q + 1] = (q + 1) * per_query;
+                return fail(COBS_GPU_ERR_CAPACITY, "hit buffer too small; hit_offsets[nq] holds the needed size");
+            }
+        }
         size_t g0 = 0;
         do {
             size_t g1 = g0;
@@ -776,6 +789,31 @@ cobs_gpu_status cobs_gpu_sharded_search_batch(cobs_gpu_index* ix, cobs_gpu_comm*
                     need_rows = true;
                 }
             }
+            if (need_rows && shared) {
+                // each count row to the rank that owns its query; that rank orders it and writes the results where
+                // they belong: the ranking and its PCIe traffic are divided by the number of GPUs
+                s = cobs_gpu_batch_exchange_counts(b, c, COBS_GPU_XCHG_ALLTOALL, st);
+                if (s != COBS_GPU_OK) return s;
+                HIP_TRY(hipStreamSynchronize(st));
+                const size_t q0 = (size_t)b->g_q0, qn = (size_t)b->g_qn;         // owned queries of this pass
+                size_t u = (g0 + q0) * per_query;
+                bool ovf = false;
+                if (qn && ix->tune.device_rank != 0 && rank_on_device_applies(b, qn)) {
+                    s = rank_on_device(b, q0, qn, 0, hits, cap, &u, hit_offsets + g0 + q0, &ovf);
+                    if (s != COBS_GPU_OK) return s;
+                } else {
+                    for (size_t q = q0; q < q0 + qn; ++q) {
+                        size_t n = 0;
+                        s = cobs_gpu_batch_hits_host(b, q, 0, hits + u, cap - u, &n);
+                        if (s != COBS_GPU_OK) return s;
+                        u += n;
+                        hit_offsets[g0 + q + 1] = u;
+                    }
+                }
+                if (ovf || u != (g0 + q0 + qn) * per_query) return fail(COBS_GPU_ERR_ARG, "a query did not yield one result per document");
+                g0 = g1;
+                continue;
+            }
             if (need_rows) {
                 // every rank ranks every query (the contract of this call): all slices to all ranks
                 s = cobs_gpu_batch_exchange_counts(b, c, COBS_GPU_XCHG_ALLGATHER, st);
@@ -804,6 +842,18 @@ cobs_gpu_status cobs_gpu_sharded_search_batch(cobs_gpu_index* ix, cobs_gpu_comm*
         if (overflow) return fail(COBS_GPU_ERR_CAPACITY, "hit buffer too small; hit_offsets[nq] holds the needed size");
         return COBS_GPU_OK;
     });
+}
+
+cobs_gpu_status cobs_gpu_sharded_search_batch(cobs_gpu_index* ix, cobs_gpu_comm* c, const char* const* queries,
+                                              const size_t* lens, size_t nq, double threshold, size_t num_results,
+                                              cobs_gpu_hit* hits, size_t cap, size_t* hit_offsets, size_t* bad_query) {
+    return sharded_search_impl(ix, c, queries, lens, nq, threshold, num_results, hits, cap, hit_offsets, bad_query, false);
+}
+
+cobs_gpu_status cobs_gpu_sharded_search_batch_split(cobs_gpu_index* ix, cobs_gpu_comm* c, const char* const* queries,
+                                                    const size_t* lens, size_t nq, double threshold, size_t num_results,
+                                                    cobs_gpu_hit* hits, size_t cap, size_t* hit_offsets, size_t* bad_query) {
+    return sharded_search_impl(ix, c, queries, lens, nq, threshold, num_results, hits, cap, hit_offsets, bad_query, true);
 }
 
 }  // extern "C"

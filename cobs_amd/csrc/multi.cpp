@@ -5,8 +5,10 @@
 // one worker thread per device opens its shard and joins an RCCL communicator
 // (cobs_gpu_comm_create), and every search is one collective cobs_gpu_sharded_search_batch:
 // each GPU scans its slice for the whole batch, counts / hit records / top-k candidates are
-// exchanged over RCCL (comm.cpp), rank 0's global result goes to the caller.  Results are
-// identical to cobs_gpu_search_batch on one GPU.
+// exchanged over RCCL (comm.cpp), rank 0's global result goes to the caller -- except for the all-documents search
+// (threshold 0, no limit), whose ranking the devices SHARE: count rows go all-to-all to query owners, every worker
+// orders its queries and writes their results at their final places (cobs_gpu_sharded_search_batch_split).  Results
+// are identical to cobs_gpu_search_batch on one GPU.
 #include <algorithm>
 #include <condition_variable>
 #include <cstring>
@@ -43,6 +45,7 @@ struct cobs_gpu_multi {
     const size_t* lens = nullptr;
     size_t nq = 0, num_results = 0, cap = 0;
     double threshold = 0.0;
+    bool shared_ranking = false;     // this job is an all-documents search: the ranks split the ranking
     cobs_gpu_hit* hits = nullptr;
     size_t* hit_offsets = nullptr;
     size_t bad_query = 0;
@@ -91,6 +94,17 @@ struct cobs_gpu_multi {
             // ranks other than 0 take part in the collectives but keep no result (capacity 0); their
             // offset arrays were sized by the calling thread: nothing is allocated between the
             // wake-up and the collective, so no rank can drop out of it on its own
+            if (shared_ranking) {
+                // the all-documents search: the devices share the ranking -- every worker orders the queries its rank
+                // owns and writes their results and offsets at their final places of the caller's arrays
+                me.status = cobs_gpu_sharded_search_batch_split(me.ix, me.comm, queries, lens, nq, threshold, num_results,
+                                                                hits, cap, hit_offsets, &bad);
+                if (r != 0 && me.status == COBS_GPU_ERR_CAPACITY) me.status = COBS_GPU_OK;      // rank 0 reports it
+                if (me.status != COBS_GPU_OK) me.error = cobs_gpu_last_error();
+                if (r == 0) bad_query = bad;
+                signal_done();
+                continue;
+            }
             size_t* offs = r == 0 ? hit_offsets : offs_other[r].data();
             me.status = cobs_gpu_sharded_search_batch(me.ix, me.comm, queries, lens, nq, threshold, num_results,
                                                       r == 0 ? hits : nullptr, r == 0 ? cap : 0, offs, &bad);
@@ -191,6 +205,10 @@ cobs_gpu_status cobs_gpu_multi_search_batch(cobs_gpu_multi* m, const char* const
         m->nq = nq;
         m->threshold = threshold;
         m->num_results = num_results;
+        {
+            const cobs_gpu_index* ix0 = m->ranks[0].ix;
+            m->shared_ranking = threshold <= 0.0 && (num_results == 0 || num_results >= cobs_gpu_total_counts(ix0));
+        }
         m->hits = hits;
         m->cap = cap;
         m->hit_offsets = hit_offsets;

@@ -246,9 +246,11 @@ class Search:
     def _search_batch_call(self, *args):
         return self._lib.cobs_gpu_search_batch(self._h, *args)
 
-    def sharded_search_hits(self, comm, queries, threshold=0.0, num_results=0):
+    def sharded_search_hits(self, comm, queries, threshold=0.0, num_results=0, split=False):
         """cobs_gpu_sharded_search_batch: collective over `comm` (every rank, same queries);
-        -> per query the GLOBAL list of (file_no, doc, score) in result order."""
+        -> per query the GLOBAL list of (file_no, doc, score) in result order.
+        split=True: cobs_gpu_sharded_search_batch_split -- for the all-documents search the ranks share the
+        ranking and this rank's return holds the results of the queries it owns (empty lists for the others)."""
         qs = [q if type(q) is bytes else _as_bytes(q) for q in queries]
         nq = len(qs)
         arr = (C.c_char_p * max(nq, 1))(*qs)
@@ -264,7 +266,9 @@ class Search:
         bad = C.c_size_t(0)
         while True:
             hits = np.empty(cap, dtype=self.HIT_DTYPE)
-            st = self._lib.cobs_gpu_sharded_search_batch(
+            fn = self._lib.cobs_gpu_sharded_search_batch_split if split else self._lib.cobs_gpu_sharded_search_batch
+            offs[:] = 0
+            st = fn(
                 self._h, comm._h, arr, lens, nq, float(threshold), int(num_results),
                 C.cast(hits.ctypes.data, C.POINTER(Hit)), cap,
                 C.cast(offs.ctypes.data, C.POINTER(C.c_size_t)), C.byref(bad))
@@ -273,6 +277,8 @@ class Search:
                 continue
             check(st)
             break
+        if split:       # only the owned queries' places are filled (every place is, when one process holds all ranks)
+            return [hits[int(offs[q]):int(offs[q + 1])].tolist() if offs[q + 1] > offs[q] else [] for q in range(nq)]
         rows = hits[:int(offs[nq])].tolist()
         return [rows[int(offs[q]):int(offs[q + 1])] for q in range(nq)]
 

@@ -343,6 +343,16 @@ cobs_gpu_status cobs_gpu_sharded_search_batch(cobs_gpu_index* ix, cobs_gpu_comm*
                                               const size_t* lens, size_t nq, double threshold, size_t num_results,
                                               cobs_gpu_hit* hits, size_t cap, size_t* hit_offsets, size_t* bad_query);
 
+/* The same call with the ranking SHARED by the ranks where that is possible: for the all-documents search (threshold <= 0
+ * and no limit -- the reference's default call) every query yields one result per document, so every result's place in
+ * `hits` is known up front; the count rows go all-to-all to query owners and rank j writes the results and offsets of the
+ * queries [n*j/N, n*(j+1)/N) of every pass at their final places.  Ranks of ONE process pass the same arrays (together
+ * they fill them: cobs_gpu_multi_search_batch does this); ranks in several processes each get their part filled.  All
+ * ranks must pass the same cap.  Every other search behaves exactly like cobs_gpu_sharded_search_batch. */
+cobs_gpu_status cobs_gpu_sharded_search_batch_split(cobs_gpu_index* ix, cobs_gpu_comm* c, const char* const* queries,
+                                                    const size_t* lens, size_t nq, double threshold, size_t num_results,
+                                                    cobs_gpu_hit* hits, size_t cap, size_t* hit_offsets, size_t* bad_query);
+
 /* Diagnostics of tuning builds (libcobs_gpu_timing.so, `make -C cobs_amd/csrc timing`): s_memtime stamps
  * [work-group slot][wave 0..3][8 phases] of the work-groups sampled from the last scan launch after
  * cobs_gpu_set_tuning(ix, "phase_slots", n).  The production library records nothing (*n_words = 0). */

@@ -95,6 +95,14 @@ def test_sharded_search_batch_one_rank(gpu_lib, oracle, tmp_path, comm):
     for t, lim in ((0.0, 0), (0.3, 0), (0.3, 4), (0.0, 6), (0.95, 0)):
         got = s.sharded_search_hits(comm, queries, t, lim)
         assert got == [cases.oracle_results(ixs, q, t, lim) for q in queries], (t, lim)
+        # the ranks share the ranking of the all-documents search (count rows all-to-all to query owners, every rank
+        # writes its queries' results at their final places); every other search is the call above
+        assert s.sharded_search_hits(comm, queries, t, lim, split=True) == got, (t, lim)
+    s.set_tuning("pass_bytes", 2 * s.total_counts * 2 * 2)      # two queries per pass: owners per pass, offsets continue
+    want = [cases.oracle_results(ixs, q, 0.0, 0) for q in queries]
+    assert s.sharded_search_hits(comm, queries, 0.0, 0, split=True) == want
+    assert s.sharded_search_hits(comm, queries, 0.0, 0) == want
+    s.set_tuning("pass_bytes", 0)
     # bad input is reported with the query's index, as in the single-GPU call
     from cobs_amd import _capi
     bad = list(queries)
