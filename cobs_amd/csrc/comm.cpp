@@ -798,10 +798,12 @@ static cobs_gpu_status sharded_search_impl(cobs_gpu_index* ix, cobs_gpu_comm* c,
                 const size_t q0 = (size_t)b->g_q0, qn = (size_t)b->g_qn;         // owned queries of this pass
                 size_t u = (g0 + q0) * per_query;
                 bool ovf = false;
+                s = COBS_GPU_ERR_UNSUPPORTED;
                 if (qn && ix->tune.device_rank != 0 && rank_on_device_applies(b, qn)) {
                     s = rank_on_device(b, q0, qn, 0, hits, cap, &u, hit_offsets + g0 + q0, &ovf);
-                    if (s != COBS_GPU_OK) return s;
-                } else {
+                    if (s != COBS_GPU_OK && s != COBS_GPU_ERR_UNSUPPORTED) return s;
+                }
+                if (s == COBS_GPU_ERR_UNSUPPORTED) {
                     for (size_t q = q0; q < q0 + qn; ++q) {
                         size_t n = 0;
                         s = cobs_gpu_batch_hits_host(b, q, 0, hits + u, cap - u, &n);
@@ -824,9 +826,8 @@ static cobs_gpu_status sharded_search_impl(cobs_gpu_index* ix, cobs_gpu_comm* c,
                 // whole (assembled, global) rows: ordered on the device, the records cross PCIe (rank.cpp) -- on a
                 // host thread this loop ranks ~90 queries x 100 000 documents per second
                 s = rank_on_device(b, 0, g1 - g0, num_results, hits, cap, &used, hit_offsets + g0, &overflow);
-                if (s != COBS_GPU_OK) return s;
-                g0 = g1;
-                continue;
+                if (s == COBS_GPU_OK) { g0 = g1; continue; }
+                if (s != COBS_GPU_ERR_UNSUPPORTED) return s;       // (no room for its workspace: the host loop below)
             }
             for (size_t q = g0; q < g1; ++q) {
                 size_t n = 0;

@@ -266,7 +266,7 @@ static cobs_gpu_status search_batch_impl(cobs_gpu_index* ix, const char* const* 
             double t0 = now_s();
             st = rank_on_device(sb, 0, ps.g1 - ps.g0, num_results, hits, cap, &used, hit_offsets + ps.g0, &overflow);
             ix->timers[4] += now_s() - t0;
-            return st;
+            if (st != COBS_GPU_ERR_UNSUPPORTED) return st;          // (no room for its workspace: the host paths below)
         }
         // all documents of every query (the reference's default call): every query yields the same
         // number of hits, so the queries of the pass are ranked by several host threads at once

@@ -149,7 +149,8 @@ bool rank_on_device_applies(const cobs_gpu_batch* b, size_t nq) {
 // Queries [q_first, q_first + nq) of the last (synced) run of `b`, ranked on the device.  Query q_first + i's results -- at most
 // `limit` (0 = all) -- are appended at hits + *used, hit_offsets[i + 1] = the new *used.  When the
 // caller's buffer is too small the offsets keep counting (the caller reports the needed capacity)
-// and *overflow is set; hits are then not valid, as in the host path.
+// and *overflow is set; hits are then not valid, as in the host path.  COBS_GPU_ERR_UNSUPPORTED (nothing written
+// yet): the workspace could not be allocated, rank on the host.
 cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, size_t limit, cobs_gpu_hit* hits, size_t cap,
                                size_t* used, size_t* hit_offsets, bool* overflow) {
     cobs_gpu_index* ix = b->ix;
@@ -210,12 +211,18 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
     const size_t wq = std::max<size_t>(1, std::min<size_t>(nq, kWindowBytes / (stride * sizeof(uint2))));
     const size_t land_bytes = wq * stride * sizeof(uint2);
     constexpr size_t kDepth = RankWork::kDepth;
-    for (size_t i = 0; i < kDepth; ++i) {
-        HIP_TRY(w.out[i].reserve(wq * stride));
-        HIP_TRY(w.cnt[i].reserve(2 * wq));
-        HIP_TRY(w.land[i].reserve(land_bytes + 4 * wq));
+    {   // the workspace: if the device or the pinned pool cannot give it, the caller ranks on the host as before
+        bool ok = true;
+        for (size_t i = 0; i < kDepth && ok; ++i)
+            ok = w.out[i].reserve(wq * stride) == hipSuccess && w.cnt[i].reserve(2 * wq) == hipSuccess &&
+                 w.land[i].reserve(land_bytes + 4 * wq) == hipSuccess;
+        if (ok && npasses > 1)
+            for (auto& pr : w.pairs) ok = ok && pr.reserve(wq * row_elems) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            return COBS_GPU_ERR_UNSUPPORTED;
+        }
     }
-    if (npasses > 1) for (auto& pr : w.pairs) HIP_TRY(pr.reserve(wq * row_elems));
     struct Win { size_t q0, n; };
     std::vector<Win> wins;
     for (size_t q0 = 0; q0 < nq; q0 += wq) wins.push_back(Win{q0, std::min(wq, nq - q0)});
