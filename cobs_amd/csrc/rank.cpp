@@ -20,8 +20,9 @@
 
 namespace cobs_amd {
 
-// A few host threads that stay around for the life of a batch's ranking workspace: expanding a window of records
-// is ~1 ms of work, spawning 16 threads per window would cost as much again.
+// A few host threads that stay around for the life of the process (one pool, shared by every handle; a window's
+// expansion holds it for ~0.5 ms): expanding a window of records is ~1 ms of work, spawning 16 threads per window
+// would cost as much again.
 class ExpandPool {
 public:
     explicit ExpandPool(unsigned n) {
@@ -35,6 +36,7 @@ public:
     unsigned size() const { return (unsigned)threads_.size(); }
     // run fn(i) for i in [0, n) on the pool (and the caller), return when all are done
     void run(size_t n, const std::function<void(size_t)>& fn) {
+        std::lock_guard<std::mutex> one_job(run_mu_);      // callers of different handles take turns
         {
             std::lock_guard<std::mutex> g(mu_);
             fn_ = &fn;
@@ -77,15 +79,19 @@ private:
         }
     }
     std::vector<std::thread> threads_;
-    std::mutex mu_;
+    std::mutex mu_, run_mu_;
     std::condition_variable cv_, done_;
     const std::function<void(size_t)>* fn_ = nullptr;
     size_t next_ = 0, total_ = 0, pending_ = 0;
     bool stop_ = false;
 };
 
+ExpandPool* expand_pool() {
+    static ExpandPool pool(std::min(15u, std::max(2u, std::thread::hardware_concurrency()) - 1u));
+    return &pool;
+}
+
 struct RankWork {
-    std::unique_ptr<ExpandPool> pool;
     static constexpr int kDepth = 3;    // windows in flight: one being ordered, one crossing PCIe, one being expanded
     DevBuf<uint2> out[kDepth];          // (slot, score) records of a window, in rank order
     DevBuf<uint2> pairs[2];
@@ -158,7 +164,6 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
     if (!b->rank) b->rank = new RankWork;
     RankWork& w = *b->rank;
     hipStream_t st = b->own_stream;             // the stream the pass ran on (host-buffer API)
-    if (!w.pool) w.pool.reset(new ExpandPool(std::min(15u, std::max(1u, std::thread::hardware_concurrency()) - 1u)));
     if (!w.copy_stream) {
         HIP_TRY(hipStreamCreateWithFlags(&w.copy_stream, hipStreamNonBlocking));
         for (auto& e : w.ranked) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -287,7 +292,7 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
         for (size_t i = 0; i < wn.n; ++i) full = full && cnt[i] == stride;
         if (full && !*overflow && wn.n * stride <= cap - *used) {
             // every query of the window yields `stride` results (the default call): one block copy
-            expand_records(w.pool.get(), hits + *used, rec, wn.n * stride, parts);
+            expand_records(expand_pool(), hits + *used, rec, wn.n * stride, parts);
             for (size_t i = 0; i < wn.n; ++i) {
                 *used += stride;
                 hit_offsets[wn.q0 + i + 1] = *used;
@@ -298,7 +303,7 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
         for (size_t i = 0; i < wn.n; ++i) {
             const size_t n = cnt[i];
             if (!*overflow && n <= cap - *used)
-                expand_records(w.pool.get(), hits + *used, rec + i * stride, n, parts);
+                expand_records(expand_pool(), hits + *used, rec + i * stride, n, parts);
             else
                 *overflow = true;
             *used += n;
