@@ -92,18 +92,19 @@ ExpandPool* expand_pool() {
 }
 
 struct RankWork {
-    static constexpr int kDepth = 3;    // windows in flight: one being ordered, one crossing PCIe, one being expanded
-    DevBuf<uint2> out[kDepth];          // (slot, score) records of a window, in rank order
+    static constexpr int kDepth = 3;    // landing buffers: one being filled over PCIe, one queued, one being expanded
+    DevBuf<uint2> out[2];               // (slot, score) records of a span of queries, in rank order
     DevBuf<uint2> pairs[2];
-    DevBuf<uint32_t> cnt[kDepth];       // [window]: results per query; npass of multi-pass sorts behind it
+    DevBuf<uint32_t> cnt[2];            // [span]: results per query; npass of multi-pass sorts behind it
     DevBuf<RankPart> parts;
     DevBuf<uint8_t> by_score;
-    PinnedBuf<uint8_t> land[kDepth];    // records of a window, then its counts
+    PinnedBuf<uint8_t> land[kDepth];    // records of a piece, then its counts
     hipStream_t copy_stream = nullptr;
-    hipEvent_t ranked[kDepth] = {nullptr, nullptr, nullptr}, landed[kDepth] = {nullptr, nullptr, nullptr};
+    hipEvent_t ranked[2] = {nullptr, nullptr}, drained[2] = {nullptr, nullptr}, landed[kDepth] = {nullptr, nullptr, nullptr};
     ~RankWork() {
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
         for (auto e : ranked) if (e) (void)hipEventDestroy(e);
+        for (auto e : drained) if (e) (void)hipEventDestroy(e);
         for (auto e : landed) if (e) (void)hipEventDestroy(e);
     }
 };
@@ -112,6 +113,7 @@ void destroy_rank_work(RankWork* w) { delete w; }
 
 namespace {
 
+constexpr size_t kSpanBytes = 512u << 20;      // records one kernel launch orders (two such device buffers)
 constexpr size_t kWindowBytes = 32u << 20;     // per window: short head (first ordering) and tail (last host copy) of the pipeline
 
 // `n` (slot, score) records of the pinned landing buffer -> cobs_gpu_hit records in caller memory, with a few
@@ -167,6 +169,7 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
     if (!w.copy_stream) {
         HIP_TRY(hipStreamCreateWithFlags(&w.copy_stream, hipStreamNonBlocking));
         for (auto& e : w.ranked) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto& e : w.drained) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto& e : w.landed) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     // the files' slices as the ranked rows hold them: this shard's slots back to back (local rows), or every
@@ -213,43 +216,53 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
     const uint32_t planes = (uint32_t)b->planes;
     const uint32_t npasses = (planes + 11u) / 12u;
     const uint32_t pbits = (planes + npasses - 1u) / npasses;
-    const size_t wq = std::max<size_t>(1, std::min<size_t>(nq, kWindowBytes / (stride * sizeof(uint2))));
-    const size_t land_bytes = wq * stride * sizeof(uint2);
+    // Two granularities.  A SPAN is what one kernel launch orders: up to 512 MiB of records -- one work-group per
+    // query, and a work-group alone takes ~0.8 ms for 100 000 documents (dependent loads, one group per CU), so a
+    // launch wants hundreds of queries to fill the device (launching per 32 MiB window left 84 % of the CUs idle and
+    // made the call kernel-bound: profiles/r03_rank_kernel_stats.csv).  A PIECE is what crosses PCIe at a time: 32 MiB
+    // of a span's records into one of three pinned landing buffers, expanded by the host while the next piece crosses.
+    const size_t sq = std::max<size_t>(1, std::min<size_t>(nq, kSpanBytes / (stride * sizeof(uint2))));     // queries per span
+    const size_t pq = std::max<size_t>(1, std::min<size_t>(sq, kWindowBytes / (stride * sizeof(uint2))));   // queries per piece
+    const size_t land_bytes = pq * stride * sizeof(uint2);
     constexpr size_t kDepth = RankWork::kDepth;
     {   // the workspace: if the device or the pinned pool cannot give it, the caller ranks on the host as before
         bool ok = true;
-        for (size_t i = 0; i < kDepth && ok; ++i)
-            ok = w.out[i].reserve(wq * stride) == hipSuccess && w.cnt[i].reserve(2 * wq) == hipSuccess &&
-                 w.land[i].reserve(land_bytes + 4 * wq) == hipSuccess;
+        for (int i = 0; i < 2 && ok; ++i)
+            ok = w.out[i].reserve(sq * stride) == hipSuccess && w.cnt[i].reserve(2 * sq) == hipSuccess;
+        for (size_t i = 0; i < kDepth && ok; ++i) ok = w.land[i].reserve(land_bytes + 4 * pq) == hipSuccess;
         if (ok && npasses > 1)
-            for (auto& pr : w.pairs) ok = ok && pr.reserve(wq * row_elems) == hipSuccess;
+            for (auto& pr : w.pairs) ok = ok && pr.reserve(sq * row_elems) == hipSuccess;
         if (!ok) {
             (void)hipGetLastError();
             return COBS_GPU_ERR_UNSUPPORTED;
         }
     }
-    struct Win { size_t q0, n; };
-    std::vector<Win> wins;
-    for (size_t q0 = 0; q0 < nq; q0 += wq) wins.push_back(Win{q0, std::min(wq, nq - q0)});
-    auto launch = [&](size_t wi) -> cobs_gpu_status {
-        const Win& wn = wins[wi];
-        const int s = (int)(wi % kDepth);
-        if (wi >= kDepth) HIP_TRY(hipStreamWaitEvent(st, w.landed[s], 0));     // the window that used these buffers has left them
+    struct Piece { size_t span, q0, n; bool last_of_span; };      // q0 relative to q_first
+    std::vector<Piece> pieces;
+    const size_t nspans = (nq + sq - 1) / sq;
+    for (size_t sp = 0; sp < nspans; ++sp) {
+        const size_t s0 = sp * sq, s1 = std::min(nq, s0 + sq);
+        for (size_t q0 = s0; q0 < s1; q0 += pq) pieces.push_back(Piece{sp, q0, std::min(pq, s1 - q0), q0 + pq >= s1});
+    }
+    auto launch_span = [&](size_t sp) -> cobs_gpu_status {
+        const int s = (int)(sp & 1);
+        const size_t s0 = sp * sq, n = std::min(nq, s0 + sq) - s0;
+        if (sp >= 2) HIP_TRY(hipStreamWaitEvent(st, w.drained[s], 0));       // the span that used this buffer has crossed PCIe
         RankArgs a{};
         a.rows = glob ? (const void*)b->g_rows : (const void*)b->counts.p;
         a.row_stride = row_elems;
         a.row_q0 = glob ? (uint32_t)b->g_q0 : 0u;
         a.parts = w.parts.p;
         a.by_score = w.by_score.p;
-        a.npass = w.cnt[s].p + wq;
+        a.npass = w.cnt[s].p + sq;
         a.out = w.out[s].p;
         a.out_count = w.cnt[s].p;
         a.pair_stride = row_elems;
         a.out_stride = stride;
         a.nparts = (uint32_t)parts.size();
         a.nslots = (uint32_t)row_elems;
-        a.q0 = (uint32_t)(q_first + wn.q0);
-        a.nq = (uint32_t)wn.n;
+        a.q0 = (uint32_t)(q_first + s0);
+        a.nq = (uint32_t)n;
         a.limit = (uint32_t)std::min<size_t>(stride, 0xFFFFFFFFu);
         a.score_bytes = b->elem_bytes;
         for (uint32_t ps = 0; ps < npasses; ++ps) {
@@ -260,38 +273,65 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
             HIP_TRY(launch_rank(a, ps == 0, ps + 1 == npasses, st));
         }
         HIP_TRY(hipEventRecord(w.ranked[s], st));
+        return COBS_GPU_OK;
+    };
+    size_t spans_launched = 0, pieces_issued = 0;
+    auto issue_piece = [&](size_t pi) -> cobs_gpu_status {
+        const Piece& pc = pieces[pi];
+        while (spans_launched <= pc.span) {                      // (a span is launched when its first piece is wanted ...
+            cobs_gpu_status ls = launch_span(spans_launched);
+            if (ls != COBS_GPU_OK) return ls;
+            ++spans_launched;
+        }
+        const int s = (int)(pc.span & 1), l = (int)(pi % kDepth);
+        const size_t off = pc.q0 - pc.span * sq;                 // queries into the span
         HIP_TRY(hipStreamWaitEvent(w.copy_stream, w.ranked[s], 0));
-        HIP_TRY(hipMemcpyAsync(w.land[s].p, w.out[s].p, wn.n * stride * sizeof(uint2), hipMemcpyDeviceToHost, w.copy_stream));
-        HIP_TRY(hipMemcpyAsync(w.land[s].p + land_bytes, w.cnt[s].p, 4 * wn.n, hipMemcpyDeviceToHost, w.copy_stream));
-        HIP_TRY(hipEventRecord(w.landed[s], w.copy_stream));
+        HIP_TRY(hipMemcpyAsync(w.land[l].p, w.out[s].p + off * stride, pc.n * stride * sizeof(uint2), hipMemcpyDeviceToHost, w.copy_stream));
+        HIP_TRY(hipMemcpyAsync(w.land[l].p + land_bytes, w.cnt[s].p + off, 4 * pc.n, hipMemcpyDeviceToHost, w.copy_stream));
+        HIP_TRY(hipEventRecord(w.landed[l], w.copy_stream));
+        if (pc.last_of_span) {
+            HIP_TRY(hipEventRecord(w.drained[s], w.copy_stream));
+            if (spans_launched < nspans && spans_launched == pc.span + 2) {   // ... or as soon as its buffer drains: it is
+                                                                              // ordered while the span in between crosses)
+                cobs_gpu_status ls = launch_span(spans_launched);
+                if (ls != COBS_GPU_OK) return ls;
+                ++spans_launched;
+            }
+        }
+        ++pieces_issued;
         return COBS_GPU_OK;
     };
     const bool trace = ix->tune.trace;
     double t_wait = 0, t_copy = 0, t_prep = now_s();
-    cobs_gpu_status rs = launch(0);
-    if (rs == COBS_GPU_OK && wins.size() > 1) rs = launch(1);
+    cobs_gpu_status rs = COBS_GPU_OK;
+    if (nspans > 1) {                            // both span buffers are free at the start: order two spans right away
+        rs = launch_span(0);
+        if (rs == COBS_GPU_OK) rs = launch_span(1);
+        spans_launched = rs == COBS_GPU_OK ? 2 : 0;
+    }
+    for (size_t pi = 0; rs == COBS_GPU_OK && pi < std::min<size_t>(2, pieces.size()); ++pi) rs = issue_piece(pi);
     if (rs != COBS_GPU_OK) {                    // nothing of this batch may still be in flight when the caller sees the error
         (void)hipStreamSynchronize(st);
         (void)hipStreamSynchronize(w.copy_stream);
         return rs;
     }
     t_prep = now_s() - t_prep;
-    for (size_t wi = 0; wi < wins.size(); ++wi) {
-        // two windows ahead: while the host expands window wi out of its landing buffer, window wi+1 crosses PCIe
-        // and window wi+2 is being ordered (its landing buffer is the one the host left at iteration wi-1)
-        if (wi + 2 < wins.size() && (rs = launch(wi + 2)) != COBS_GPU_OK) break;
+    for (size_t wi = 0; wi < pieces.size(); ++wi) {
+        // two pieces ahead: while the host expands piece wi out of its landing buffer, piece wi+1 crosses PCIe and
+        // piece wi+2 is queued behind it (into the landing buffer the host left at iteration wi-1)
+        if (wi + 2 < pieces.size() && (rs = issue_piece(wi + 2)) != COBS_GPU_OK) break;
         const int s = (int)(wi % kDepth);
         double t0 = now_s();
         if (hipEventSynchronize(w.landed[s]) != hipSuccess) { rs = hip_fail(hipGetLastError(), "rank window"); break; }
         t_wait += now_s() - t0;
         t0 = now_s();
-        const Win& wn = wins[wi];
+        const Piece& wn = pieces[wi];
         const uint32_t* cnt = reinterpret_cast<const uint32_t*>(w.land[s].p + land_bytes);
         const uint2* rec = reinterpret_cast<const uint2*>(w.land[s].p);
         bool full = true;
         for (size_t i = 0; i < wn.n; ++i) full = full && cnt[i] == stride;
         if (full && !*overflow && wn.n * stride <= cap - *used) {
-            // every query of the window yields `stride` results (the default call): one block copy
+            // every query of the piece yields `stride` results (the default call): one block
             expand_records(expand_pool(), hits + *used, rec, wn.n * stride, parts);
             for (size_t i = 0; i < wn.n; ++i) {
                 *used += stride;
@@ -311,9 +351,9 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
         }
     }
     if (trace)
-        std::fprintf(stderr, "[cobs_gpu] device ranking: %zu queries x %zu records in %zu windows; first launch %.3f ms, "
+        std::fprintf(stderr, "[cobs_gpu] device ranking: %zu queries x %zu records in %zu pieces; first launches %.3f ms, "
                      "waiting for windows %.3f ms, copying out of the landing buffers %.3f ms\n",
-                     nq, stride, wins.size(), t_prep * 1e3, t_wait * 1e3, t_copy * 1e3);
+                     nq, stride, pieces.size(), t_prep * 1e3, t_wait * 1e3, t_copy * 1e3);
     if (rs != COBS_GPU_OK) {                    // nothing of this batch may still be in flight when the caller sees the error
         (void)hipStreamSynchronize(st);
         (void)hipStreamSynchronize(w.copy_stream);
