@@ -106,9 +106,9 @@ __global__ __launch_bounds__(256) void rank_kernel(RankArgs a) {
 
     // score of slot `slot` if it takes part (a real document at or above its file's threshold), else kInvalid;
     // the 8 slots of one lane lie in one file
-    auto keys8 = [&](uint32_t i, uint32_t (&key)[8]) {
-        uint32_t s[8];
-        load8<ST>(row, i, s);
+    // (the raw scores are loaded one block ahead of their use: a work-group is alone on its CU, nothing else hides
+    // the latency of these dependent loads)
+    auto keys8 = [&](uint32_t i, const uint32_t (&s)[8], uint32_t (&key)[8]) {
         const RankPart pt = a.parts[part_of(a, i)];
         const uint32_t thr = pt.thr ? pt.thr[q] : 0u;
         const uint32_t d = i - pt.slot0;                         // document index inside the held slice
@@ -120,16 +120,21 @@ __global__ __launch_bounds__(256) void rank_kernel(RankArgs a) {
     __syncthreads();
     // ---- (1) histograms
     if constexpr (FIRST) {
+        uint32_t cur[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nxt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (w0 + lane * 8u < w1) load8<ST>(row, w0 + lane * 8u, cur);
         for (uint32_t i0 = w0; i0 < w1; i0 += 512) {
             const uint32_t i = i0 + lane * 8u;
+            if (i + 512u < w1) load8<ST>(row, i + 512u, nxt);
             if (i < w1) {
                 uint32_t key[8];
-                keys8(i, key);
+                keys8(i, cur, key);
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
                     if (key[j] != kInvalid)
                         atomicAdd(&myh[dmask - (by_score ? (key[j] >> a.shift) & dmask : 0u)], 1u);
             }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cur[j] = nxt[j];
         }
     } else {
         for (uint32_t i = w0 + lane; i < w1; i += 64)
@@ -204,10 +209,13 @@ __global__ __launch_bounds__(256) void rank_kernel(RankArgs a) {
         }
     };
     if constexpr (FIRST) {
+        uint32_t cur[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nxt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (w0 + lane * 8u < w1) load8<ST>(row, w0 + lane * 8u, cur);
         for (uint32_t i0 = w0; i0 < w1; i0 += 512) {
             const uint32_t i = i0 + lane * 8u;
+            if (i + 512u < w1) load8<ST>(row, i + 512u, nxt);
             uint32_t key[8];
-            if (i < w1) keys8(i, key);
+            if (i < w1) keys8(i, cur, key);
             else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) key[j] = kInvalid;
@@ -221,6 +229,8 @@ __global__ __launch_bounds__(256) void rank_kernel(RankArgs a) {
                 const uint32_t k = mystage[s * 64u + lane];
                 place(k != kInvalid, k, i0 + s * 64u + lane);
             }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cur[j] = nxt[j];
         }
     } else {
         for (uint32_t i0 = w0; i0 < w1; i0 += 64) {
