@@ -134,3 +134,49 @@ def test_bench_refuses_more_gpus_than_devices(gpu_lib):
     r, j, _ = _bench(["--gpus", str(n)] + SMALL, timeout=300)
     assert r.returncode != 0 and j is None
     assert "HIP device(s) visible" in r.stderr
+
+
+def test_owner_routed_hits_from_real_shards(gpu_lib, oracle, tmp_path):
+    """the owner-routed hit exchange end to end minus the wire: N shards of one index opened in turn on this GPU, each
+    runs the hits-only scan and buckets its pool on the device by query owner (what rank r would send), the library's
+    cobs_gpu_hit_exchange_plan moves the buckets (played here with slices): every owner ends with exactly the oracle's
+    hits of its queries"""
+    import ctypes as C
+    from cobs_amd import _capi
+    lib = _capi.load()
+    q_long = oracle.random_sequence(500, 71)
+    p = cases.make_compact(cases.tmp(tmp_path, "o.cobs_compact"), 5 * 8 * 64 - 9, 64, [900, 1000, 1100, 1200, 1300], 1, 31, 1,
+                           0.3, 3, planted={5: 1.0, 700: 0.9, 1500: 0.6, 2300: 0.97}, query=q_long)
+    ix = oracle.Index.open(p)
+    queries = [q_long[i:i + 60 + 17 * i] for i in range(11)]
+    nq = len(queries)
+    want = {qi: sorted((qi, f, d, sc) for (f, d, sc) in cases.oracle_results([ix], q, 0.31, 0)) for qi, q in enumerate(queries)}
+    assert sum(len(v) for v in want.values()) > 50
+    for N in (2, 3, 5, 8):
+        counts, buckets = [], []
+        for r in range(N):
+            s = gpu_lib.Search(p, shard_rank=r, shard_count=N)
+            b = gpu_lib.Batch(s)
+            b.set_queries(queries)
+            b.run_hits(0.31)
+            b.sync()
+            c, rec = b.bucketed_hits(N)
+            counts.append(c)
+            buckets.append(rec)
+        flat = (C.c_uint64 * (N * N))(*[c for row in counts for c in row])
+        plans = []
+        for r in range(N):
+            xf = (_capi.Xfer * N)()
+            out = (C.c_uint64 * 2)()
+            _capi.check(lib.cobs_gpu_hit_exchange_plan(flat, N, r, xf, out))
+            plans.append((list(xf), list(out)))
+        for i in range(N):
+            xf, out = plans[i]
+            got = np.zeros((out[0] // 16, 4), dtype=np.uint32)
+            for j in range(N):
+                peer = plans[j][0][i]
+                assert peer.send_bytes == xf[j].recv_bytes
+                got[xf[j].recv_offset // 16:(xf[j].recv_offset + xf[j].recv_bytes) // 16] = \
+                    buckets[j][peer.send_offset // 16:(peer.send_offset + peer.send_bytes) // 16]
+            q0, q1 = nq * i // N, nq * (i + 1) // N
+            assert sorted(map(tuple, got.tolist())) == sorted(h for qi in range(q0, q1) for h in want[qi]), (N, i)
