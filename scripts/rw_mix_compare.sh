@@ -5,6 +5,7 @@
 set -u
 OUT=gpurun_out/r03_rw_mix_compare.txt
 mkdir -p gpurun_out
+[ -x scripts/probes/rw_mix_probe ] || hipcc --offload-arch=gfx950 -O3 scripts/probes/rw_mix_probe.hip -o scripts/probes/rw_mix_probe
 {
   for l in 0 5120 10240; do scripts/probes/rw_mix_probe $l | grep -v "anywhere\|gather only"; done
   for args in "--queries 40000 --kmers 20" "--queries 40000 --kmers 70" "--queries 40000 --kmers 120" ""; do
