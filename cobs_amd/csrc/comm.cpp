@@ -698,7 +698,6 @@ static cobs_gpu_status sharded_search_impl(cobs_gpu_index* ix, cobs_gpu_comm* c,
         }
         cobs_gpu_batch* b = ix->scratch[0];
         hipStream_t st = b->own_stream;
-        hit_offsets[0] = 0;
         size_t used = 0;
         bool overflow = false;
         // Passes bounded like the single-GPU API (score rows / tables below the workspace limit) --
@@ -714,11 +713,13 @@ static cobs_gpu_status sharded_search_impl(cobs_gpu_index* ix, cobs_gpu_comm* c,
         const bool all_docs = threshold <= 0.0 && topk == 0;
         // shared ranking: every query yields one result per real document, so every result's place is known up front
         const bool shared = split && all_docs;
+        if (!shared || c->rank == 0) hit_offsets[0] = 0;          // (shared arrays: every entry has exactly one writer)
         size_t per_query = 0;
         for (const auto& p : ix->parts) per_query += p.meta.doc_names.size();
         if (shared) {
             if (cap < nq * per_query || (nq * per_query && !hits)) {      // the same on every rank: nobody enters a collective
-                for (size_t q = 0; q < nq; ++q) hit_offsets[q + 1] = (q + 1) * per_query;
+                if (c->rank == 0)           // (ranks of one process share the array: one writer)
+                    for (size_t q = 0; q < nq; ++q) hit_offsets[q + 1] = (q + 1) * per_query;
                 return fail(COBS_GPU_ERR_CAPACITY, "hit buffer too small; hit_offsets[nq] holds the needed size");
             }
         }

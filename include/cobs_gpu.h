@@ -347,7 +347,8 @@ cobs_gpu_status cobs_gpu_sharded_search_batch(cobs_gpu_index* ix, cobs_gpu_comm*
  * and no limit -- the reference's default call) every query yields one result per document, so every result's place in
  * `hits` is known up front; the count rows go all-to-all to query owners and rank j writes the results and offsets of the
  * queries [n*j/N, n*(j+1)/N) of every pass at their final places.  Ranks of ONE process pass the same arrays (together
- * they fill them: cobs_gpu_multi_search_batch does this); ranks in several processes each get their part filled.  All
+ * they fill them, every entry written by exactly one rank: cobs_gpu_multi_search_batch does this); ranks in several
+ * processes each get their part filled (hit_offsets[0] and, on ERR_CAPACITY, the needed sizes by rank 0 only).  All
  * ranks must pass the same cap.  Every other search behaves exactly like cobs_gpu_sharded_search_batch. */
 cobs_gpu_status cobs_gpu_sharded_search_batch_split(cobs_gpu_index* ix, cobs_gpu_comm* c, const char* const* queries,
                                                     const size_t* lens, size_t nq, double threshold, size_t num_results,
