@@ -659,7 +659,7 @@ __device__ __forceinline__ void tile_topk(const ScanArgs& a, const uint32_t (&pl
 // (the tile_topk instantiations of up to 10 planes are held to the 128 VGPRs of four waves per SIMD, like the
 // kernels whose epilogue they replace: the selection's masks would otherwise cost the multi-query ones a wave)
 template <int NP, int NW, bool H1, typename OutT, bool MQ, typename IdxT, bool LDSS = false, bool TK = false>
-__global__ __launch_bounds__(NW * 64, (TK && NP <= 10) ? 4 : 1) void scan_kernel(ScanArgs a) {
+__global__ __launch_bounds__(NW * 64, (TK && H1 && NP <= 10) ? 4 : 1) void scan_kernel(ScanArgs a) {
     // row loads stay temporal: non-temporal loads measured 18 % slower (they bypass the Infinity Cache)
     constexpr bool NT = false;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1816,11 +1816,14 @@ static hipError_t launch_scan_mq(const ScanArgs& a, uint32_t ntiles, int nw, hip
 
 template <int NP, typename OutT>
 static hipError_t launch_scan_np(const ScanArgs& a, uint32_t ntiles, bool h1, int nw, hipStream_t stream) {
-    if (a.cand) {           // run_topk without score rows: H = 1, 32-bit row indices (scan_has_tile_topk)
-        if (!h1 || a.idx64) return hipErrorInvalidValue;
-        if (nw == 1) return launch_scan_inst<NP, 1, true, OutT, false, uint32_t, false, true>(a, ntiles, stream);
-        if (nw == 2) return launch_scan_inst<NP, 2, true, OutT, false, uint32_t, false, true>(a, ntiles, stream);
-        return launch_scan_inst<NP, 4, true, OutT, false, uint32_t, false, true>(a, ntiles, stream);
+    if (a.cand) {           // run_topk without score rows: 32-bit row indices (scan_has_tile_topk)
+        if (a.idx64) return hipErrorInvalidValue;
+        if (nw == 1) return h1 ? launch_scan_inst<NP, 1, true, OutT, false, uint32_t, false, true>(a, ntiles, stream)
+                               : launch_scan_inst<NP, 1, false, OutT, false, uint32_t, false, true>(a, ntiles, stream);
+        if (nw == 2) return h1 ? launch_scan_inst<NP, 2, true, OutT, false, uint32_t, false, true>(a, ntiles, stream)
+                               : launch_scan_inst<NP, 2, false, OutT, false, uint32_t, false, true>(a, ntiles, stream);
+        return h1 ? launch_scan_inst<NP, 4, true, OutT, false, uint32_t, false, true>(a, ntiles, stream)
+                  : launch_scan_inst<NP, 4, false, OutT, false, uint32_t, false, true>(a, ntiles, stream);
     }
     if (a.idx64) {
         // sub-indexes with >= 2^32 rows: 64-bit row indices; two waves per group cover every
@@ -1851,7 +1854,7 @@ bool scan_has_multi_query(int planes, uint32_t num_hashes, uint32_t tile_w) {
     return num_hashes == 1 && tile_w < 64 && (planes == 4 || planes == 8 || planes == 10 || planes == 12);
 }
 
-bool scan_has_tile_topk(uint32_t num_hashes, bool idx64) { return num_hashes == 1 && !idx64; }
+bool scan_has_tile_topk(uint32_t num_hashes, bool idx64) { (void)num_hashes; return !idx64; }
 
 bool scan_has_lds_staged(int planes, uint32_t num_hashes, int nw) {
     return num_hashes == 1 && planes == 10 && (nw == 2 || nw == 4);

@@ -21,7 +21,7 @@ inline uint32_t scan_score_bytes(int planes) { return planes <= 8 ? 1u : planes 
 hipError_t launch_scan(const ScanArgs& a, uint32_t ntiles, int planes, int nw, bool multi_query,
                        hipStream_t stream);
 bool scan_has_multi_query(int planes, uint32_t num_hashes, uint32_t tile_w);
-// run_topk without score rows (ScanArgs::cand): the tile_topk epilogue exists for single-hash files with 32-bit row indices
+// run_topk without score rows (ScanArgs::cand): the tile_topk epilogue exists for files with 32-bit row indices
 bool scan_has_tile_topk(uint32_t num_hashes, bool idx64);
 // the LDS-staged A/B variant exists for the headline shape only (H = 1, 10 planes, 2 or 4 waves)
 bool scan_has_lds_staged(int planes, uint32_t num_hashes, int nw);

@@ -231,8 +231,8 @@ cobs_gpu_status cobs_gpu_batch_run_topk(cobs_gpu_batch* b, double threshold, siz
  * num_results best while it scans (classic_search.cpp:127-145) and needs no score matrix either.  K2 selects the
  * num_results best documents of every tile from its bit-sliced counters, K3 merges tiles x num_results
  * candidates per query; same result as cobs_gpu_batch_run_topk, cobs_gpu_batch_counts_* are not available
- * afterwards.  Where the tile-level selection does not apply (num_results > 128, several hashes, a query
- * with a single k-mer) the pass keeps score rows as cobs_gpu_batch_run_topk does. */
+ * afterwards.  Where the tile-level selection does not apply (num_results > 128, a query with a single hash in
+ * total, sub-indexes of 2^32 rows and more) the pass keeps score rows as cobs_gpu_batch_run_topk does. */
 cobs_gpu_status cobs_gpu_batch_run_topk_only(cobs_gpu_batch* b, double threshold, size_t num_results,
                                              void* hip_stream);
 /* wait for the stream and fetch device-side error flags (invalid bases, ...) */

@@ -110,3 +110,25 @@ def test_long_queries_and_shards_and_streaming(gpu_lib, oracle, tmp_path):
     b.sync()
     assert b.stats()["scan_launches"] >= 3
     _check(b, queries[:2], [ix], 0.0, 6)
+
+
+@pytest.mark.parametrize("H", [2, 3])
+def test_tile_topk_with_several_hash_functions(gpu_lib, oracle, tmp_path, H):
+    """the generic-H scan (aggregate_rows: the H rows of a term are ANDed before counting) ends a limited pass with the same
+    tile-level selection; the reference's own query tests build their indexes with three hash functions
+    (tests/compact_index_query.cpp:44-47)"""
+    q = oracle.random_sequence(500, 90 + H)
+    p = cases.make_compact(cases.tmp(tmp_path, "h%d.cobs_compact" % H), 4 * 8 * 40 - 3, 40, [2003, 2503, 3001, 3511], H, 31, 1,
+                           0.3, 6, planted={0: 1.0, 127: 1.0, 128: 1.0, 640: 0.8, 1000: 0.6, 1276: 1.0}, query=q)
+    ix = oracle.Index.open(p)
+    s = gpu_lib.Search(p)
+    queries = [q, q[:200], q[3:90], q[:40]]
+    b = gpu_lib.Batch(s)
+    b.set_queries(queries)
+    for t, k in ((0.0, 10), (0.5, 4), (0.0, 128)):
+        b.run_topk(t, k, keep_counts=False)
+        b.sync()
+        _check(b, queries, [ix], t, k, lims=[k])
+        with pytest.raises(gpu_lib.CobsGpuError):           # no score rows were kept: the tile-level path ran
+            b.counts_host(0)
+    assert s.search_hits(queries, 0.0, 7) == [cases.oracle_results([ix], x, 0.0, 7) for x in queries]
