@@ -335,12 +335,14 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
         cand_off[f + 1] = cand_off[f] + (b->topk_direct ? (uint64_t)nq * cand_stride[f] : 0);
     }
     if (b->topk_direct) {
-        if (cand_off.back() > (1ull << 31)) {            // 16 GiB of candidates: take the score rows instead
+        // a pool larger than the score rows it replaces (a large k on a narrow score type), 16 GiB of candidates, or no
+        // room for the pool: take the score rows instead
+        if (cand_off.back() * sizeof(uint2) > (uint64_t)nq * ix->local_counts * b->elem_bytes || cand_off.back() > (1ull << 31) ||
+            b->cand.reserve((size_t)cand_off.back()) != hipSuccess) {
+            (void)hipGetLastError();
             b->topk_direct = false;
             b->have_counts = true;
             HIP_TRY(b->counts.reserve((size_t)(nq * ix->local_counts * b->elem_bytes)));
-        } else {
-            HIP_TRY(b->cand.reserve((size_t)cand_off.back()));
         }
     }
     hipEvent_t* ev = b->ev[b->run_seq % cobs_gpu_batch::kRing];
