@@ -511,8 +511,6 @@ def main():
                     help="N=1 smoke run of the multi-GPU code path: one-rank RCCL communicator, sharded layout, exchange")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real multi-GPU runs; gloo only "
                     "for smoke-testing the launch path with several ranks on one GPU")
-    ap.add_argument("--busy-tail", type=float, default=3.0,
-                    help="N=1: seconds of the same step after the measurements (outside every timed region)")
     ap.add_argument("--dry-run-launch", action="store_true",
                     help="print the launch plan of --gpus N (JSON) and exit; needs no GPU")
     args = ap.parse_args()
@@ -611,8 +609,6 @@ def main():
                 batch.run_hits(args.threshold, 0)
             else:
                 batch.run(args.threshold, 0)
-
-    plain_run = run is None          # one GPU, no sharded layout: `step` and `batch` stay alive to the end
 
     def drop_warmup_events():
         if run is not None:
@@ -743,15 +739,6 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not budget:
         out["end_to_end"] = end_to_end(s, batch, queries)
         out["cpu_baseline"] = cpu_baseline(s, cfg, queries, batch=batch)
-    if world == 1 and args.busy_tail > 0 and plain_run:
-        # the timed region of a default run is half a second of a ~25 s process (the CPU baseline dominates): keep the
-        # GPU busy with the same step for a moment so that coarse utilisation sampling sees the device in use
-        t_end = time.perf_counter() + args.busy_tail
-        while time.perf_counter() < t_end:
-            for _ in range(8):
-                step()
-            torch.cuda.synchronize()
-        out["busy_tail_s"] = args.busy_tail
     if rank == 0:
         # the line is only printed when it describes the run that was asked for
         assert out["n_gpus"] == args.gpus, (out["n_gpus"], args.gpus)

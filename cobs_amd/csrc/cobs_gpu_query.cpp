@@ -76,6 +76,16 @@ static int benchmark(cobs_gpu::BatchSearch& s, const std::string& index, unsigne
     return 0;
 }
 
+// `s.timer().print("search")` of the reference's process_query (src/cobs.cpp:468, cobs/util/timer.cpp:77-85):
+// one "TIMER info=search name=seconds ... total=seconds" line on stderr.  The reference's phases are hashes / io /
+// and rows (/ add rows); here: hashes (K1), h2d (query text), scan (K2: gather + AND + count), d2h, rank.
+static void print_timer(const cobs_gpu::BatchSearch& s) {
+    double t[5] = {0, 0, 0, 0, 0};
+    if (cobs_gpu_timers(s.handle(), t, 0) != COBS_GPU_OK) return;
+    std::cerr << "TIMER info=search hashes=" << t[0] << " h2d=" << t[1] << " scan=" << t[2] << " d2h=" << t[3]
+              << " rank=" << t[4] << " total=" << t[0] + t[1] + t[2] + t[3] + t[4] << std::endl;
+}
+
 int cobs_gpu_tools_main(int argc, char** argv);      // cobs_gpu_tools.cpp: *-construct, classic-combine, compact-construct-combine
 
 int main(int argc, char** argv) {
@@ -209,6 +219,8 @@ int main(int argc, char** argv) {
             std::vector<cobs_gpu::SearchResult> result;
             s.search(query_line, result, threshold, num_results);
             for (const auto& r : result) std::cout << r.doc_name << '\t' << r.score << '\n';
+            std::cout.flush();
+            print_timer(s);
             return 0;
         }
         std::ifstream qf(query_file);
@@ -233,6 +245,8 @@ int main(int argc, char** argv) {
             std::cout << comments[q] << '\t' << results[q].size() << '\n';
             for (const auto& r : results[q]) std::cout << r.doc_name << '\t' << r.score << '\n';
         }
+        std::cout.flush();
+        print_timer(s);
     } catch (const cobs_gpu::Error& e) {
         // the reference prints "EXCEPTION: ..." and returns -1 (src/cobs.cpp:1070-1076) or exits
         std::fprintf(stderr, "EXCEPTION: %s\n", e.what());

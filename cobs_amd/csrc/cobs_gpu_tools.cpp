@@ -71,6 +71,33 @@ bool ends_with(const std::string& s, const char* suffix) {
     return s.size() >= n && s.compare(s.size() - n, n, suffix) == 0;
 }
 
+// what `cobs classic-construct` / `compact-construct` print before they build (reference src/cobs.cpp:41-73
+// print_document_list, called at :235 and :373): one line per document, then the k-mer statistics
+void print_document_list(const cobs_gpu::DocumentList& filelist, size_t term_size, std::ostream& os = std::cout) {
+    size_t min_kmers = size_t(-1), max_kmers = 0, total_kmers = 0;
+    const size_t n = filelist.size();
+    os << "--- document list (" << n << " entries) ---" << std::endl;
+    for (size_t i = 0; i < n; ++i) {
+        const cobs_gpu::DocumentEntry d = filelist[i];
+        const size_t num_terms = d.num_terms(term_size);
+        std::error_code ec;
+        const auto bytes = std::filesystem::file_size(d.path_, ec);
+        os << "document[" << i << "] size " << (ec ? (std::uintmax_t)d.size_ : bytes) << " " << term_size << "-mers " << num_terms
+           << " : " << d.path_ << " : " << d.name_ << std::endl;
+        min_kmers = std::min(min_kmers, num_terms);
+        max_kmers = std::max(max_kmers, num_terms);
+        total_kmers += num_terms;
+    }
+    os << "--- end of document list (" << n << " entries) ---" << std::endl;
+    os << "documents: " << n << std::endl;
+    if (n != 0) {
+        os << "minimum " << term_size << "-mers: " << min_kmers << std::endl;
+        os << "maximum " << term_size << "-mers: " << max_kmers << std::endl;
+        os << "average " << term_size << "-mers: " << static_cast<size_t>(static_cast<double>(total_kmers) / n) << std::endl;
+        os << "total " << term_size << "-mers: " << total_kmers << std::endl;
+    }
+}
+
 int construct(int argc, char** argv, bool compact) {
     Args a;
     if (!a.parse(argc, argv, compact) || a.positional.size() != 2) {
@@ -82,7 +109,7 @@ int construct(int argc, char** argv, bool compact) {
     // the C++17 mirror of the reference's construction API (include/cobs_gpu_construct.hpp),
     // statement for statement what src/cobs.cpp:235-241 / :373-377 do
     cobs_gpu::DocumentList filelist(a.positional[0], cobs_gpu::StringToFileType(a.file_type));
-    std::cout << "documents: " << filelist.size() << std::endl;
+    print_document_list(filelist, a.p.term_size);
     if (compact) {
         cobs_gpu::CompactIndexParameters p;
         p.term_size = a.p.term_size; p.canonicalize = (uint8_t)a.p.canonicalize; p.num_hashes = a.p.num_hashes;

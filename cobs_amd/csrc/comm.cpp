@@ -799,21 +799,24 @@ static cobs_gpu_status sharded_search_impl(cobs_gpu_index* ix, cobs_gpu_comm* c,
                 const size_t q0 = (size_t)b->g_q0, qn = (size_t)b->g_qn;         // owned queries of this pass
                 size_t u = (g0 + q0) * per_query;
                 bool ovf = false;
-                s = COBS_GPU_ERR_UNSUPPORTED;
-                if (qn && ix->tune.device_rank != 0 && rank_on_device_applies(b, qn)) {
-                    s = rank_on_device(b, q0, qn, 0, hits, cap, &u, hit_offsets + g0 + q0, &ovf);
-                    if (s != COBS_GPU_OK && s != COBS_GPU_ERR_UNSUPPORTED) return s;
-                }
-                if (s == COBS_GPU_ERR_UNSUPPORTED) {
-                    for (size_t q = q0; q < q0 + qn; ++q) {
+                // a rank may fail alone while it orders ITS queries (workspace, a D2H copy, ...): the status is agreed
+                // on before anybody goes on to the next pass's collectives, or the others would wait there for ever
+                cobs_gpu_status rs = COBS_GPU_ERR_UNSUPPORTED;
+                if (qn && ix->tune.device_rank != 0 && rank_on_device_applies(b, qn))
+                    rs = rank_on_device(b, q0, qn, 0, hits, cap, &u, hit_offsets + g0 + q0, &ovf);
+                if (rs == COBS_GPU_ERR_UNSUPPORTED) {
+                    rs = COBS_GPU_OK;
+                    u = (g0 + q0) * per_query;
+                    for (size_t q = q0; q < q0 + qn && rs == COBS_GPU_OK; ++q) {
                         size_t n = 0;
-                        s = cobs_gpu_batch_hits_host(b, q, 0, hits + u, cap - u, &n);
-                        if (s != COBS_GPU_OK) return s;
+                        rs = cobs_gpu_batch_hits_host(b, q, 0, hits + u, cap - u, &n);
                         u += n;
                         hit_offsets[g0 + q + 1] = u;
                     }
                 }
-                if (ovf || u != (g0 + q0 + qn) * per_query) return fail(COBS_GPU_ERR_ARG, "a query did not yield one result per document");
+                if (rs == COBS_GPU_OK && (ovf || u != (g0 + q0 + qn) * per_query))
+                    rs = fail(COBS_GPU_ERR_ARG, "a query did not yield one result per document");
+                if ((s = all_ranks_ok(rs)) != COBS_GPU_OK) return s;
                 g0 = g1;
                 continue;
             }

@@ -147,7 +147,7 @@ void expand_records(ExpandPool* pool, cobs_gpu_hit* dst, const uint2* src, size_
 bool rank_on_device_applies(const cobs_gpu_batch* b, size_t nq) {
     // the result has to come from whole score rows (no K3 list, no complete hit pool): the batch's own rows, or --
     // after an exchange (comm.cpp) -- the assembled global rows of the queries this rank holds
-    if (!b->have_counts || b->topk_k != 0 || nq < 4) return false;
+    if (!b->have_counts || b->topk_k != 0 || nq < 4 || b->planes < 1) return false;
     if (b->selected && (b->pool_global || b->h_nhits() <= b->hit_cap)) return false;
     if (b->ix->local_counts >= 0xFFFFFFF0ull || b->ix->local_counts == 0 || b->ix->total_counts >= 0xFFFFFFF0ull) return false;
     if (b->view_global && (b->g_rows == nullptr || b->g_qn == 0)) return false;

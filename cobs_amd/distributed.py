@@ -225,7 +225,9 @@ def exchange_hits_by_plan(local_hits, nq, group=None):
     xf = (_capi.Xfer * world)()
     out = (C.c_uint64 * 2)()
     _capi.check(lib.cobs_gpu_hit_exchange_plan(flat, world, rank, xf, out))
-    send = torch.tensor([v for b in buckets for h in b for v in h], dtype=torch.int32).reshape(-1, 4).view(torch.uint8).reshape(-1)
+    flat_send = [v for b in buckets for h in b for v in h]
+    send = torch.tensor(flat_send, dtype=torch.int32).reshape(len(flat_send) // 4, 4).view(torch.uint8).reshape(-1)
+    peer = (lambda j: dist.get_global_rank(group, j)) if group is not None else (lambda j: j)
     assert send.numel() == int(out[1])
     recv = torch.zeros(max(int(out[0]), 1), dtype=torch.uint8)
     reqs, keep = [], []
@@ -236,17 +238,17 @@ def exchange_hits_by_plan(local_hits, nq, group=None):
         if xf[j].send_bytes:
             t = send[xf[j].send_offset: xf[j].send_offset + xf[j].send_bytes].contiguous()
             keep.append(t)
-            reqs.append(dist.isend(t, j, group=group))
+            reqs.append(dist.isend(t, peer(j), group=group))
         if xf[j].recv_bytes:
             t = torch.empty(xf[j].recv_bytes, dtype=torch.uint8)
             keep.append((t, xf[j].recv_offset))
-            reqs.append(dist.irecv(t, j, group=group))
+            reqs.append(dist.irecv(t, peer(j), group=group))
     for r in reqs:
         r.wait()
     for k in keep:
         if isinstance(k, tuple):
             recv[k[1]: k[1] + k[0].numel()] = k[0]
-    recs = recv[:int(out[0])].view(torch.int32).reshape(-1, 4).tolist()
+    recs = recv[:int(out[0])].view(torch.int32).reshape(int(out[0]) // 16, 4).tolist()
     return nq * rank // world, nq * (rank + 1) // world - nq * rank // world, [tuple(r) for r in recs]
 
 

@@ -65,6 +65,22 @@ class ResultList(collections.abc.Sequence):
         return "ResultList(%d results, first %r)" % (len(self), self[0] if len(self) else None)
 
 
+def _split_segments(hits, offs, nq, threshold, num_results, search):
+    """per-query result lists of cobs_gpu_sharded_search_batch_split on THIS rank.  In the all-documents call the
+    ranks share the ranking: a rank fills only the places of the queries it owns and writes only hit_offsets[q + 1]
+    of those (hit_offsets[q], the start of its first owned query, belongs to the previous owner -- another
+    process's array unless one process holds all ranks).  Every query yields exactly one result per real document
+    there, so a query's segment is taken from its END; queries of other owners come back empty.  Any other call
+    (threshold > 0 or a limit) returns every query on every rank with complete offsets."""
+    topk = num_results if num_results < search.total_counts else 0
+    if threshold <= 0.0 and topk == 0:
+        per_query = sum(int(search.info(f).num_docs) for f in range(search.num_files))
+        return [hits[int(offs[q + 1]) - per_query:int(offs[q + 1])].tolist() if int(offs[q + 1]) >= per_query and offs[q + 1] > 0 else []
+                for q in range(nq)]
+    rows = hits[:int(offs[nq])].tolist()
+    return [rows[int(offs[q]):int(offs[q + 1])] for q in range(nq)]
+
+
 def _as_bytes(q):
     return q.encode("latin-1") if isinstance(q, str) else bytes(q)
 
@@ -277,8 +293,8 @@ class Search:
                 continue
             check(st)
             break
-        if split:       # only the owned queries' places are filled (every place is, when one process holds all ranks)
-            return [hits[int(offs[q]):int(offs[q + 1])].tolist() if offs[q + 1] > offs[q] else [] for q in range(nq)]
+        if split:
+            return _split_segments(hits, offs, nq, threshold, num_results, self)
         rows = hits[:int(offs[nq])].tolist()
         return [rows[int(offs[q]):int(offs[q + 1])] for q in range(nq)]
 

@@ -109,3 +109,39 @@ def test_merge_hits_order():
     assert merge_hits([a, b]) == [(0, 5, 9), (0, 9, 9), (1, 0, 9), (0, 1, 3), (0, 7, 1)]
     assert merge_hits([a, b], 2) == [(0, 5, 9), (0, 9, 9)]
     assert merge_hits([a, b], 0, total_hashes=1) == [(0, 1, 3), (0, 5, 9), (0, 7, 1), (0, 9, 9), (1, 0, 9)]
+
+
+def test_split_search_segments_on_a_rank_that_does_not_own_query_0():
+    """cobs_gpu_sharded_search_batch_split with ranks in separate processes: a rank writes hit_offsets[q + 1] of the
+    queries it owns only, so the start of its first owned query is NOT in its array (the wrapper sliced
+    hits[offs[q]:offs[q + 1]] and returned uninitialised memory in front of the real rows).  The offsets a rank 1 of
+    2 sees for 4 queries x 5 documents: entries 3 and 4 only."""
+    import numpy as np
+    from cobs_amd.search import Search, _split_segments
+
+    class Info:
+        num_docs = 5
+
+    class FakeSearch:
+        total_counts = 8
+        num_files = 1
+
+        def info(self, f):
+            return Info()
+
+    hits = np.zeros(20, dtype=Search.HIT_DTYPE)
+    hits["doc"] = 777                                   # what np.empty could hold where nothing was written
+    for q in (2, 3):
+        for i in range(5):
+            hits[q * 5 + i] = (0, i, 10 * q + 5 - i)
+    offs = np.array([0, 0, 0, 15, 20], dtype=np.uint64)
+    got = _split_segments(hits, offs, 4, 0.0, 0, FakeSearch())
+    assert got[0] == [] and got[1] == []
+    assert got[2] == [(0, i, 25 - i) for i in range(5)] and got[3] == [(0, i, 35 - i) for i in range(5)]
+    # one process holding all ranks: every entry is filled, same slicing
+    offs_all = np.array([0, 5, 10, 15, 20], dtype=np.uint64)
+    assert [len(x) for x in _split_segments(hits, offs_all, 4, 0.0, 0, FakeSearch())] == [5, 5, 5, 5]
+    # with a threshold or a limit the call is not shared: complete offsets on every rank
+    offs_t = np.array([0, 1, 1, 3, 3], dtype=np.uint64)
+    assert [len(x) for x in _split_segments(hits, offs_t, 4, 0.5, 0, FakeSearch())] == [1, 0, 2, 0]
+    assert [len(x) for x in _split_segments(hits, offs_t, 4, 0.0, 2, FakeSearch())] == [1, 0, 2, 0]

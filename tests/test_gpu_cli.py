@@ -25,6 +25,12 @@ def test_single_query_default_threshold(gpu_lib, oracle, golden_dir):
     r = _run("-i", idx, Q50)
     assert r.returncode == 0, r.stderr
     assert r.stdout == "sample1\t20\n"                       # default threshold 0.8 (src/cobs.cpp:481-484)
+    # `s.timer().print("search")` (src/cobs.cpp:468, util/timer.cpp:77-85): one TIMER line on stderr, name=seconds pairs
+    timer = [ln for ln in r.stderr.splitlines() if ln.startswith("TIMER info=search ")]
+    assert len(timer) == 1
+    kv = dict(f.split("=", 1) for f in timer[0].split()[2:])
+    assert list(kv)[0] == "hashes" and list(kv)[-1] == "total" and float(kv["scan"]) > 0
+    assert abs(sum(float(v) for k, v in kv.items() if k != "total") - float(kv["total"])) < 1e-6
     r = _run("-i", idx, "-t", "0", Q50)
     want = "".join("%s\t%d\n" % (n, s) for (_, _, n, s) in oracle.search(oracle.Index.open(idx), Q50.encode()))
     assert r.stdout == want
@@ -127,6 +133,14 @@ def test_construction_sub_tools(gpu_lib, oracle, golden_dir, tmp_path):
     r = _run("classic-construct", fasta, pc)
     assert r.returncode == 0, r.stderr
     assert "documents: 7" in r.stdout
+    # print_document_list (reference src/cobs.cpp:41-73): a line per document, then the k-mer statistics
+    out = r.stdout.splitlines()
+    assert out[0] == "--- document list (7 entries) ---" and out[8] == "--- end of document list (7 entries) ---"
+    docs = [ln for ln in out if ln.startswith("document[")]
+    kmers = [int(ln.split(" 31-mers ")[1].split(" : ")[0]) for ln in docs]
+    assert len(docs) == 7 and docs[0].endswith(" : sample1") and " size %d 31-mers " % os.path.getsize(os.path.join(fasta, "sample1.fasta")) in docs[0]
+    assert "minimum 31-mers: %d" % min(kmers) in out and "maximum 31-mers: %d" % max(kmers) in out
+    assert "average 31-mers: %d" % (sum(kmers) // 7) in out and "total 31-mers: %d" % sum(kmers) in out
     assert open(pc, "rb").read() == open(os.path.join(golden_dir, "c1.cobs_classic"), "rb").read()
     r = _run("compact-construct", fasta, pk, "-T", "4", "-m", "1000000")
     assert r.returncode == 0, r.stderr
