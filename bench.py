@@ -234,6 +234,46 @@ def end_to_end(search, batch, queries):
     return res
 
 
+def unique_row_bytes(cfg, nq, kmers, row_bytes):
+    """Expected bytes of DISTINCT index rows a batch looks up: sum over sub-indexes of
+    row_bytes * S_p * (1 - exp(-Q*T*H / S_p)) (uniform hashes); every further look-up of a row can be served by a
+    cache, these bytes have to come from HBM at least once.  -> (unique bytes, looked-up bytes)"""
+    import math
+    n = float(nq) * kmers * cfg["num_hashes"]
+    uniq = sum(row_bytes * sp * (1.0 - math.exp(-n / sp)) for sp in cfg["signature_sizes"])
+    return uniq, n * row_bytes * len(cfg["signature_sizes"])
+
+
+def cache_cold_probe(search, cfg, queries, kmers, row_bytes, nq=256, steps=10):
+    """The scan at a batch size where the caches cannot help: `nq` queries look up rows of which
+    < 15 % repeat inside the batch, and one launch touches 3 GB at C3 -- twelve times the Infinity Cache -- so a line
+    is gone before the next launch asks for it again.  Its algorithmic bandwidth IS HBM-side bandwidth (up to that
+    repeat fraction).  The grid of such a batch does not fill the device for long: a lower bound of what the pins give."""
+    nq = min(nq, len(queries))
+    b = cobs_amd.Batch(search)
+    b.set_queries(queries[:nq])
+    for _ in range(2):
+        b.run(0.0, 0)
+    b.sync()
+    b.kernel_ms()
+    for _ in range(steps):
+        b.run(0.0, 0)
+    b.sync()
+    ms = b.kernel_ms()["scan_ms"]
+    algo = b.stats()["algorithmic_bytes"]
+    uniq, looked = unique_row_bytes(cfg, nq, kmers, row_bytes)
+    score_bytes = algo - looked if algo > looked else 0
+    res = {"queries": nq, "scan_ms": round(ms, 4), "algorithmic_bytes": algo,
+           "achieved": round(algo / (ms * 1e-3) / 1e9, 1), "frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "repeat_frac": round(1.0 - uniq / looked, 4) if looked else None,
+           "hbm_side_lower_bound": round((uniq + score_bytes) / (ms * 1e-3) / 1e9, 1),
+           "hbm_side_lower_bound_frac": round((uniq + score_bytes) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "note": "rows looked up once per launch and evicted (one launch touches %.1f GB) before the next: achieved x (1 - repeat_frac) "
+                   "left the HBM pins at least" % (looked / 1e9)}
+    del b
+    return res
+
+
 def kernels_hash():
     """identifies the kernel source a profile belongs to (the GPU box has no .git)"""
     import hashlib
@@ -262,9 +302,13 @@ class ShardedRun:
     over RCCL / xGMI inside libcobs_gpu.so (comm.cpp).  mode ALLTOALL: rank j ends up with the
     complete count rows (global document order) of the queries [nq*j/N, nq*(j+1)/N) -- every
     count crosses the fabric once; ALLGATHER: every rank ends up with every row.
-    nsub > 1: the batch is cut into sub-batches, the exchange of sub-batch i (own stream)
-    overlaps the scan of sub-batch i+1.  --dist-backend gloo (several ranks on ONE GPU, smoke
-    tests only) uses the torch.distributed restatement of the same exchange."""
+    The batch is cut into nsub sub-batches (the reference's own loop is per batch of documents,
+    classic_search.cpp:355-400; here the cut is over queries): K1 of a sub-batch runs on the batch's own
+    stream (tuning key hash_stream), K2 on the scan stream, the exchange on the exchange stream, tied by
+    events only -- hash(i+1) | scan(i) | exchange(i-1) overlap, also across steps (scan i of step s+1 waits
+    for exchange i of step s, whose source it overwrites, and for nothing else).
+    --dist-backend gloo (several ranks on ONE GPU, smoke tests only) executes the library's own
+    exchange plan (cobs_gpu_exchange_plan) with torch.distributed transfers instead of RCCL."""
 
     def __init__(self, cfg, queries, world, rank, dev, comm, nsub=1, threshold=0.0, mode=None, hbm_budget=0,
                  path=None, backend="nccl"):
@@ -274,57 +318,206 @@ class ShardedRun:
         self.threshold = threshold
         self.s = make_index(cfg, dev, rank, world, hbm_budget, path)
         nsub = max(1, min(nsub, len(queries)))
-        self.sub = []
+        self.sub, self.sub_queries = [], []
         for i in range(nsub):
             bi = cobs_amd.Batch(self.s)
-            bi.set_queries(queries[i * len(queries) // nsub:(i + 1) * len(queries) // nsub])
+            qi = queries[i * len(queries) // nsub:(i + 1) * len(queries) // nsub]
+            bi.set_queries(qi)
             self.sub.append(bi)
-        self.overlap = nsub > 1 and comm is not None
-        if self.overlap:
+            self.sub_queries.append(qi)
+        self.layouts = None
+        if comm is not None:
+            if nsub > 1:
+                self.s.set_tuning("hash_stream", 1)
             self.scan_stream, self.x_stream = torch.cuda.Stream(), torch.cuda.Stream()
-            self.events = [torch.cuda.Event() for _ in self.sub]
+            self.x_done = [None] * nsub
+        else:
+            from cobs_amd.distributed import shard_slots
+            self.layouts = shard_slots(self.s, None)
+        self.x_events = []                  # (begin, end) of every exchange since the last reset (timing events)
+        self.x_host_s = 0.0                 # gloo path: host seconds inside the exchange
+        self.steps_seen = 0
+        self.tied = False
+        self.rows = [None] * nsub           # gloo path: (q_begin, q_count, assembled rows) of the last step
         self.moved = 0
 
     def step(self):
-        if self.comm is None:                       # gloo smoke path
-            from cobs_amd.distributed import all_gather_counts
-            for bi in self.sub:
+        self.steps_seen += 1
+        if self.comm is None:                       # gloo smoke path: the library's plan, torch.distributed transfers
+            from cobs_amd.distributed import exchange_counts_by_plan
+            self.moved = 0
+            for i, bi in enumerate(self.sub):
                 bi.run(self.threshold, 0)
-                parts = all_gather_counts(bi.counts_tensor(), None)
-                self.moved = sum(int(t.numel()) * t.element_size() for t in parts[:self.rank] + parts[self.rank + 1:])
+                bi.sync()
+                t0 = time.perf_counter()
+                local = bi.counts_tensor()
+                self.rows[i] = exchange_counts_by_plan(local, self.layouts, self.s.total_counts, len(self.sub_queries[i]),
+                                                       self.mode, None)
+                torch.cuda.synchronize()
+                self.x_host_s += time.perf_counter() - t0
+                q0, qn, rows = self.rows[i]
+                mine = self.layouts[self.rank]
+                self.moved += qn * (self.s.total_counts - sum(c for (_, c, _) in mine)) * rows.element_size()
             return
-        if not self.overlap:
-            for bi in self.sub:
-                bi.run(self.threshold, 0)
-                bi.exchange_counts(self.comm, self.mode, 0)
-            return
-        cur = torch.cuda.current_stream()
-        self.scan_stream.wait_stream(cur)
-        self.x_stream.wait_stream(cur)
-        for bi, ev in zip(self.sub, self.events):
-            bi.run(self.threshold, self.scan_stream.cuda_stream)
-            ev.record(self.scan_stream)
-            self.x_stream.wait_event(ev)
-            bi.exchange_counts(self.comm, self.mode, self.x_stream.cuda_stream)
-        cur.wait_stream(self.scan_stream)
-        cur.wait_stream(self.x_stream)
+        ss, xs = self.scan_stream, self.x_stream
+        if not self.tied:                            # once: everything queued so far on the current stream comes first
+            ss.wait_stream(torch.cuda.current_stream())
+            xs.wait_stream(torch.cuda.current_stream())
+            self.tied = True
+        for i, bi in enumerate(self.sub):
+            if self.x_done[i] is not None:
+                ss.wait_event(self.x_done[i])        # the previous step's exchange read the count rows this scan overwrites
+            bi.run(self.threshold, ss.cuda_stream)
+            scanned = torch.cuda.Event()
+            scanned.record(ss)
+            xs.wait_event(scanned)
+            xb, xe = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            xb.record(xs)
+            bi.exchange_counts(self.comm, self.mode, xs.cuda_stream)
+            xe.record(xs)
+            self.x_done[i] = xe
+            self.x_events.append((xb, xe))
+
+    def _sync_all(self):
+        for bi in self.sub:
+            bi.sync(self.scan_stream.cuda_stream if self.comm is not None else 0)
+        torch.cuda.synchronize()
 
     def finish(self):
-        """-> per step on this rank: (scan ms, hash ms, algorithmic bytes, bytes received), summed over sub-batches"""
+        """-> per step on this rank, summed over the sub-batches:
+        (scan ms, hash ms, exchange ms, algorithmic bytes, bytes received)"""
+        self._sync_all()
         scan = hsh = algo = moved = 0
         for bi in self.sub:
-            bi.sync(self.scan_stream.cuda_stream if self.overlap else 0)
             ms = bi.kernel_ms()
             scan += ms["scan_ms"]
             hsh += ms["hash_ms"]
             algo += bi.stats()["algorithmic_bytes"]
-            moved += bi.exchange_bytes() if self.comm is not None else self.moved
-        return scan, hsh, algo, moved
+            moved += bi.exchange_bytes() if self.comm is not None else 0
+        if self.comm is None:
+            moved = self.moved
+        steps = max(self.steps_seen, 1)
+        if self.comm is not None:
+            xms = sum(b.elapsed_time(e) for (b, e) in self.x_events) / steps
+        else:
+            xms = self.x_host_s * 1e3 / steps
+        return scan, hsh, xms, algo, moved
 
     def drop_warmup_events(self):
+        self._sync_all()
         for bi in self.sub:
-            bi.sync(self.scan_stream.cuda_stream if self.overlap else 0)
             bi.kernel_ms()
+        self.x_events, self.x_host_s, self.steps_seen = [], 0.0, 0
+
+    def owned_rows(self, i):
+        """after the last step: (first query, query count, rows [count, total_counts]) this rank holds of sub-batch i,
+        in GLOBAL document order -- what the exchange assembled"""
+        if self.comm is None:
+            return self.rows[i]
+        return self.sub[i].global_counts_tensor()
+
+    def local_rows(self, i):
+        return self.sub[i].counts_tensor()
+
+
+def _as_int64(t):
+    """count rows as int64 (the int16 / int32 views of u16 / u32 scores carry their bit patterns)"""
+    eb = t.element_size()
+    v = t.to(torch.int64)
+    return v.bitwise_and((1 << (8 * eb)) - 1) if eb > 1 else v
+
+
+def _row_sums(rows, weights, chunk=512):
+    """-> (sum, weighted sum) per row, int64 on the device; rows [n, m] any count width, weights int64 [m]"""
+    n = rows.shape[0]
+    a = torch.zeros(n, dtype=torch.int64, device=rows.device)
+    b = torch.zeros(n, dtype=torch.int64, device=rows.device)
+    for r0 in range(0, n, chunk):
+        v = _as_int64(rows[r0:r0 + chunk])
+        a[r0:r0 + chunk] = v.sum(dim=1)
+        b[r0:r0 + chunk] = (v * weights).sum(dim=1)
+    return a, b
+
+
+def verify_sharded(run, cfg, world, rank, backend, corrupt=False, seconds=20.0, exact_rows=16, checksum_rows=64):
+    """The N > 1 line proves itself.  After the timed region, on the rows of the LAST step:
+    (a) EVERY row of the batch: each rank sums its local count slices, weighted by the GLOBAL slot of every count
+        (plain sum and position-weighted sum), the partial sums of all ranks are added (one all-reduce of the checker,
+        not of the data path), and the owner of every assembled row compares the sums of what the exchange delivered --
+        a count lost, duplicated, routed to the wrong query or assembled at the wrong document changes them;
+    (b) a sample of the rows this rank owns against rows the ORACLE regenerates from the index's procedural
+        definition (nothing is read back from the GPU for them): `exact_rows` compared element by element,
+        `checksum_rows` by the same two sums, as many as `seconds` of host time allow.
+    The flag is the AND over all ranks.  corrupt: test hook -- one count of one assembled row (beyond the sampled ones)
+    is changed on the last rank before the check, which must then fail."""
+    from oracle import oracle as O
+    if rank == 0:
+        O.build()                       # (the checker's library: one rank compiles it if it is missing, the others wait)
+    if world > 1:
+        dist.barrier()
+    s = run.s
+    total = s.total_counts
+    dev = torch.device("cuda", torch.cuda.current_device())
+    w_glob = (torch.arange(total, device=dev, dtype=torch.int64) % 1021) + 1
+    # the global slot of every local count of this rank's rows (files' held slots back to back)
+    gidx = []
+    for f in range(s.num_files):
+        i = s.info(f)
+        gidx.append(torch.arange(int(i.slot_count), device=dev, dtype=torch.int64) + int(i.doc_offset) + int(i.slot_begin))
+    gidx = torch.cat(gidx) if gidx else torch.zeros(0, dtype=torch.int64, device=dev)
+    w_loc = (gidx % 1021) + 1
+    kind = 1 if cfg["kind"] == "compact" else 0
+    gen = O.Index.synthetic(kind, cfg["term_size"], cfg["canonicalize"], cfg["num_hashes"], cfg["page_size"],
+                            cfg["signature_sizes"], cfg["num_docs"], cfg["seed"])
+    wn = (np.arange(total, dtype=np.int64) % 1021) + 1
+    ok_exchange, ok_oracle = True, True
+    n_all = n_exact = n_sum = 0
+    t_end = time.perf_counter() + seconds
+    nsub = len(run.sub)
+    for i in range(nsub):
+        qi = run.sub_queries[i]
+        q0, qn, rows = run.owned_rows(i)
+        if corrupt and rank == world - 1 and i == nsub - 1 and qn > 0:
+            r = qn - 1                                    # the last owned row: outside every oracle sample
+            rows[r, total // 2] = rows[r, total // 2] ^ 1
+        # (a) expected sums of every row of the sub-batch from the shards' own slices
+        pa, pb = _row_sums(run.local_rows(i), w_loc)
+        part = torch.stack([pa, pb])
+        if world > 1:
+            if backend != "nccl":
+                part = part.cpu()
+            dist.all_reduce(part, op=dist.ReduceOp.SUM)
+            part = part.to(dev)
+        ga, gb = _row_sums(rows, w_glob)
+        if qn:
+            ok_exchange = ok_exchange and bool(torch.equal(ga, part[0][q0:q0 + qn])) and bool(torch.equal(gb, part[1][q0:q0 + qn]))
+        n_all += qn
+        # (b) the oracle on a sample of the owned rows
+        want_exact = (exact_rows * (i + 1)) // nsub - (exact_rows * i) // nsub
+        want_sum = (checksum_rows * (i + 1)) // nsub - (checksum_rows * i) // nsub
+        ga_h, gb_h = ga.cpu().numpy(), gb.cpu().numpy()
+        for j in range(min(qn, max(want_exact, want_sum))):
+            if j >= want_exact and time.perf_counter() > t_end:
+                break
+            want = gen.counts(qi[q0 + j])
+            good = int(ga_h[j]) == int(want.sum()) and int(gb_h[j]) == int((want.astype(np.int64) * wn).sum())
+            n_sum += 1
+            if j < want_exact:
+                got = _as_int64(rows[j]).cpu().numpy()
+                good = good and bool(np.array_equal(got, want.astype(np.int64)))
+                n_exact += 1
+            ok_oracle = ok_oracle and good
+    flags = torch.tensor([1 if ok_exchange else 0, 1 if ok_oracle else 0, n_all, n_exact, n_sum], dtype=torch.int64,
+                         device=dev if backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+    fl = [int(v) for v in flags.tolist()]
+    return {"bit_exact_vs_oracle": fl[0] == 1 and fl[1] == 1,
+            "exchange_consistent_all_rows": fl[0] == 1, "oracle_sample_exact": fl[1] == 1,
+            "checked_per_rank_at_least": {"rows_exchange_sums": fl[2], "rows_exact_vs_oracle": fl[3],
+                                          "rows_checksummed_vs_oracle": fl[4]},
+            "how": "every assembled row: (sum, slot-weighted sum) against the sums of the shards' local slices; sampled owned rows "
+                   "against rows the oracle regenerates (element by element / by the same sums); AND over ranks"}
 
 
 def timed(step, steps, warmup, world, backend, after_warmup=None):
@@ -378,7 +571,7 @@ def side_measurements(args, cfg, queries, world, rank, dev, comm):
             out[name] = {"skipped": err or "set-up failed on another rank"}
             return
         dt = timed(run.step, steps, 1, world, backend, run.drop_warmup_events)
-        scan, _, _, moved = run.finish()
+        scan, _, _, _, moved = run.finish()
         out[name] = dict(describe, queries_per_s=round(run.nq_total * steps / dt, 1),
                          ms_per_step=round(dt / steps * 1e3, 3), steps=steps,
                          scan_ms_per_step_rank0=round(scan, 4) if scan else None,
@@ -391,8 +584,10 @@ def side_measurements(args, cfg, queries, world, rank, dev, comm):
         r.nq_total = len(queries_)
         return r
 
-    measure("sharded_overlap_2_sub_batches", lambda: sharded(2, _capi.XCHG_ALLTOALL),
-            {"parallelism": "as the headline, batch cut in 2: exchange of sub-batch 1 overlaps the scan of sub-batch 2"})
+    measure("sharded_one_sub_batch", lambda: sharded(1, _capi.XCHG_ALLTOALL),
+            {"parallelism": "as the headline without the cut into sub-batches: hash, scan and exchange one after the other"})
+    measure("sharded_4_sub_batches", lambda: sharded(4, _capi.XCHG_ALLTOALL),
+            {"parallelism": "as the headline, batch cut in 4"})
     measure("sharded_allgather", lambda: sharded(1, _capi.XCHG_ALLGATHER),
             {"parallelism": "as the headline, but every rank receives every count row (N-1 times the traffic)"})
 
@@ -410,7 +605,7 @@ def side_measurements(args, cfg, queries, world, rank, dev, comm):
             self.b.kernel_ms()
         def finish(self):
             self.b.sync()
-            return self.b.kernel_ms()["scan_ms"], 0, 0, 0
+            return self.b.kernel_ms()["scan_ms"], 0, 0, 0, 0
     measure("index_replicated_weak", Replicated,
             {"parallelism": "index replicated on every GPU, one %d-query batch per GPU, no collective" % args.queries,
              "scaling": "weak"})
@@ -430,7 +625,7 @@ def side_measurements(args, cfg, queries, world, rank, dev, comm):
         def drop_warmup_events(self):
             self.b.kernel_ms()
         def finish(self):
-            return self.b.kernel_ms()["scan_ms"], 0, 0, self.b.exchange_bytes() if comm is not None else 0
+            return self.b.kernel_ms()["scan_ms"], 0, 0, 0, self.b.exchange_bytes() if comm is not None else 0
     measure("sharded_hits_threshold_0.8", HitsMode,
             {"parallelism": "sharded as the headline; hits-only scan + sizes-first exchange of hit records, each to the rank that owns its query"})
 
@@ -497,8 +692,11 @@ def main():
     ap.add_argument("--topk-with-rows", action="store_true",
                     help="with --num-results: keep the score rows (K3 selects from them) instead of selecting per tile in K2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--exchange-chunks", type=int, default=1,
-                    help="N>1: sub-batches; with more than one the exchange of sub-batch i overlaps the scan of i+1")
+    ap.add_argument("--exchange-chunks", type=int, default=0,
+                    help="sharded runs: sub-batches the batch is cut into; hash(i+1) | scan(i) | exchange(i-1) overlap on their own "
+                         "streams.  0 = automatic: 2 (1 for an out-of-core run, whose passes are bound by PCIe)")
+    ap.add_argument("--corrupt-exchange", action="store_true",
+                    help="test hook of the self-check: one count of one assembled row is changed before the check, which must fail")
     ap.add_argument("--exchange", choices=["alltoall", "allgather"], default="alltoall")
     ap.add_argument("--extras", action="store_true",
                     help="N>1: after the headline, also measure the other forms of the job (overlapped sub-batches, all-gather, "
@@ -587,8 +785,12 @@ def main():
             from cobs_amd.distributed import Comm
             comm = Comm.from_torch(None, dev) if world > 1 else Comm(Comm.unique_id(), 0, 1, dev)
         ok, err = True, ""
+        # Two sub-batches by default: the exchange (~0.2 ms per rank at C3 / N = 8 against 2.4 ms of scan) and K1
+        # (replicated on every rank: 0.23 ms) of one half hide behind the scan of the other; every further cut adds a launch
+        # tail to every rank's scan and halves what is left to hide.
+        nsub = args.exchange_chunks if args.exchange_chunks > 0 else (1 if budget else 2)
         try:
-            run = ShardedRun(cfg, queries, world, rank, dev, comm, args.exchange_chunks, args.threshold,
+            run = ShardedRun(cfg, queries, world, rank, dev, comm, nsub, args.threshold,
                              _capi.XCHG_ALLGATHER if args.exchange == "allgather" else _capi.XCHG_ALLTOALL,
                              hbm_budget=budget, path=path, backend=args.dist_backend)
         except Exception as e:                                      # noqa: BLE001
@@ -618,9 +820,9 @@ def main():
             batch.kernel_ms()
 
     dt = timed(step, args.steps, args.warmup, world, args.dist_backend, drop_warmup_events)
-    received = 0
+    received, xchg_ms = 0, 0.0
     if run is not None:
-        scan_ms, hash_ms, algo, received = run.finish()     # per step: summed over the sub-batches
+        scan_ms, hash_ms, xchg_ms, algo, received = run.finish()     # per step: summed over the sub-batches
     else:
         batch.sync()                               # also raises on invalid bases
         ms = batch.kernel_ms()                     # HIP events on the launch stream, averaged over the timed steps
@@ -703,10 +905,42 @@ def main():
             "hash_ms_per_launch": round(hash_ms, 4),
         },
     }
+    if not budget and not (args.hits_only and args.threshold > 0) and not args.num_results:
+        # HBM-side view of the same launch: the distinct rows of the batch have to leave the pins at least once, the
+        # scores are written once; what is looked up again may come from the Infinity Cache / L2
+        info0 = s.info(0)
+        row_bytes = int(info0.page_size) if cfg["kind"] == "compact" else int(info0.row_size)
+        shards = world if shard_index else 1
+        uniq, looked = unique_row_bytes(cfg, args.queries, args.kmers, row_bytes)
+        uniq, looked = uniq / shards, looked / shards
+        score_bytes = max(0, algo - looked)
+        out["roofline"]["unique_bytes_per_launch"] = int(uniq + score_bytes)
+        out["roofline"]["hbm_lower_bound_frac"] = round((uniq + score_bytes) / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        out["roofline"]["unique_bytes_is"] = ("sum_p row_bytes * S_p * (1 - exp(-Q*T*H/S_p)) distinct rows + the scores written: what must "
+                                              "cross the HBM pins at least once per launch (lower bound of the pin traffic; achieved / "
+                                              "frac above are algorithmic bytes, every look-up counted)")
+        if world == 1 and not shard_index and not args.no_cpu_baseline:
+            out["roofline"]["cache_cold"] = cache_cold_probe(s, cfg, queries, args.kmers, row_bytes)
     if shard_index:
         out["rccl_ranks"] = comm.size if comm is not None else None       # ncclCommCount
+        # what every rank measured with events on its own streams, per step (summed over the sub-batches)
+        mine = {"scan_ms": round(scan_ms, 4), "hash_ms": round(hash_ms, 4), "exchange_ms": round(xchg_ms, 4)}
+        per_rank = [mine]
+        if world > 1:
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
+        out["per_rank"] = {k: [r[k] for r in per_rank] for k in ("scan_ms", "hash_ms", "exchange_ms")}
+        # of the time hashing and exchanging take, the part that did not show up in the step: the streams overlap them
+        # with the scans (of the other sub-batch, of the next step)
+        hidden = [max(0.0, min(1.0, (r["scan_ms"] + r["hash_ms"] + r["exchange_ms"] - ms_per_step) /
+                                  max(r["hash_ms"] + r["exchange_ms"], 1e-9))) for r in per_rank]
         out["exchange"] = {"mode": args.exchange, "received_bytes_per_step_rank0": received,
+                           "sub_batches": len(run.sub),
+                           "hidden_frac": round(min(hidden), 4), "hidden_frac_per_rank": [round(h, 4) for h in hidden],
+                           "hidden_frac_is": "(scan + hash + exchange ms of a rank - ms_per_step) / (hash + exchange ms), clamped to [0, 1]; min over ranks",
                            "transport": "RCCL in libcobs_gpu.so" if comm is not None else "torch.distributed/" + args.dist_backend}
+        # the line proves itself: exchanged rows against the shards' slices (all rows) and against the oracle (sample)
+        out.update(verify_sharded(run, cfg, world, rank, args.dist_backend, corrupt=args.corrupt_exchange))
         info = s.info(0)
         out["shard_rank0"] = {"hbm_bytes": int(info.hbm_bytes), "slot_begin": int(info.slot_begin),
                               "slot_count": int(info.slot_count)}
@@ -736,9 +970,10 @@ def main():
         del run, batch, s
         torch.cuda.empty_cache()
         out["other_forms"] = side_measurements(args, cfg, queries, world, rank, dev, comm)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not budget:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not budget and not shard_index:
         out["end_to_end"] = end_to_end(s, batch, queries)
         out["cpu_baseline"] = cpu_baseline(s, cfg, queries, batch=batch)
+        out["bit_exact_vs_oracle"] = out["cpu_baseline"]["bit_exact_vs_gpu"]
     if rank == 0:
         # the line is only printed when it describes the run that was asked for
         assert out["n_gpus"] == args.gpus, (out["n_gpus"], args.gpus)
@@ -748,6 +983,11 @@ def main():
         _RESULT_STDOUT.flush()
     if world > 1:
         dist.destroy_process_group()
+    if out.get("bit_exact_vs_oracle") is False:
+        # (every rank holds the all-reduced flag: all of them leave with the same code)
+        sys.stderr.write("bench.py: the counts are NOT bit-exact against the oracle: %s\n"
+                         % json.dumps({k: out.get(k) for k in ("exchange_consistent_all_rows", "oracle_sample_exact")}))
+        sys.exit(3)
 
 
 # stdout carries the ONE JSON line and nothing else: RCCL (the library's own communicator and

@@ -109,6 +109,8 @@ cobs_gpu_batch::~cobs_gpu_batch() {
     if (run_done) (void)hipEventDestroy(run_done);
     if (done) (void)hipEventDestroy(done);
     if (own_stream) (void)hipStreamDestroy(own_stream);
+    if (hashed) (void)hipEventDestroy(hashed);
+    if (hash_stream) (void)hipStreamDestroy(hash_stream);
 }
 
 cobs_gpu_index::~cobs_gpu_index() { for (auto* b : scratch) delete b; }
@@ -413,6 +415,8 @@ cobs_gpu_status cobs_gpu_set_tuning(cobs_gpu_index* ix, const char* key, int64_t
         t.lds_staged = value > 0;
     } else if (k == "device_rank") {
         t.device_rank = value != 0;
+    } else if (k == "hash_stream") {
+        t.hash_stream = value != 0;
     } else if (k == "tile_topk") {
         t.tile_topk = value != 0;
     } else if (k == "min_score_bytes") {
@@ -427,7 +431,7 @@ cobs_gpu_status cobs_gpu_set_tuning(cobs_gpu_index* ix, const char* key, int64_t
     } else if (k == "phase_slots") {
         t.phase_slots = value > 0 ? (uint32_t)std::min<int64_t>(value, 1 << 20) : 0;
     } else {
-        return fail(COBS_GPU_ERR_ARG, "unknown tuning key (waves, tile_w, mq, pass_bytes, pipe_chars, graph, lds_staged, device_rank, tile_topk, row_fetch, row_fetch_alpha, min_score_bytes)");
+        return fail(COBS_GPU_ERR_ARG, "unknown tuning key (waves, tile_w, mq, pass_bytes, pipe_chars, graph, lds_staged, device_rank, hash_stream, tile_topk, row_fetch, row_fetch_alpha, min_score_bytes)");
     }
     return COBS_GPU_OK;
 }

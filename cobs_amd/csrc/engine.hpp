@@ -104,6 +104,8 @@ struct Tuning {
                                     // fetched by the kernel cross PCIe at 50.8 GB/s, whole chunks at 52.3 GB/s (profiles/r03_c5_selective.txt): 1
     int tile_topk = 1;          // top-k passes without score rows select per tile in K2 (0: score rows + K3, A/B)
     int device_rank = 1;        // whole score rows are ranked on the device (0: by host threads, A/B and fallback)
+    int hash_stream = 0;        // K1 of a device-resident batch runs on the batch's own stream, K2 waits for it by event: the hashing
+                                // of one (sub-)batch overlaps the scan / exchange of another (the sharded multi-GPU flow)
     uint32_t exp = 0;           // experimental kernel variants under A/B measurement (bit field, ScanArgs::exp)
     bool trace = false;         // COBS_GPU_TRACE: where the host side of a search call spends its time, on stderr
     uint32_t phase_slots = 0;   // tuning builds (make timing): work-groups of a scan launch that record phase stamps
@@ -267,7 +269,10 @@ struct cobs_gpu_batch {
     std::vector<cobs_gpu_hit> sel_scratch;
     // HIP events around K1 and K2 of the most recent runs (recorded on the launch stream)
     static constexpr int kRing = 64;
-    hipEvent_t ev[kRing][3] = {};
+    hipEvent_t ev[kRing][4] = {};     // before K1 | after K1 | after the last K2 | (K1 on its own stream) before the first K2
+    bool ev_split[kRing] = {};        // the run recorded ev[3]: its K2 time is ev[3]..ev[2]
+    hipStream_t hash_stream = nullptr;   // tuning key hash_stream: K1's own stream ...
+    hipEvent_t hashed = nullptr;         // ... and the event K2's stream waits for
     uint64_t run_seq = 0, read_seq = 0;
     uint64_t stats[4] = {0, 0, 0, 0};
     uint64_t algo_row_bytes = 0;      // gathered row bytes of the current queries (stats[0] adds the score bytes a run writes)

@@ -292,8 +292,23 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
         HIP_TRY(b->topk_out.reserve((size_t)topk * std::max<size_t>(nq, 1) * ix->parts.size()));
         HIP_TRY(b->topk_cnt.reserve(std::max<size_t>(nq, 1) * ix->parts.size()));
     }
+    // K1 on the batch's own stream (tuning key hash_stream; device-resident batches only -- the scratch batches of the
+    // host-buffer API live on one stream each and may be under graph capture): it is ordered after the previous run of
+    // THIS batch (and the exchange that followed it: both end with run_done), whose K2 read the row-index tables and
+    // the flags K1 is about to overwrite, and before this run's K2 by the event `hashed` -- nothing else.  The
+    // hashing of one sub-batch then runs under the scan / exchange of another (bench.py's sharded flow).
+    const bool split = ix->tune.hash_stream != 0 && b->own_stream == nullptr && nq > 0;
+    hipStream_t hs = st;
+    if (split) {
+        if (!b->hash_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&b->hash_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&b->hashed, hipEventDisableTiming));
+        }
+        hs = b->hash_stream;
+        if (b->run_seq) HIP_TRY(hipStreamWaitEvent(hs, b->run_done, 0));
+    }
     // device flags: first invalid query = none, selected hits = 0
-    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)b->flags.p, 0, 4, st));      // all zero: one fill
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)b->flags.p, 0, 4, hs));      // all zero: one fill
     if (need_thr) {
         stage_thresholds(b, threshold);
         for (size_t f = 0; f < ix->parts.size(); ++f)
@@ -346,8 +361,9 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
         }
     }
     hipEvent_t* ev = b->ev[b->run_seq % cobs_gpu_batch::kRing];
-    HIP_TRY(hipEventRecord(ev[0], st));
-    bool hash_marked = false;
+    b->ev_split[b->run_seq % cobs_gpu_batch::kRing] = split;
+    HIP_TRY(hipEventRecord(ev[0], hs));
+    bool hash_marked = false, scan_marked = false;
     uint64_t launches = 0;
     StreamBufs& sbufs = ix->stream;
     for (size_t f = 0; f < ix->parts.size(); ++f) {
@@ -371,10 +387,18 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
             ha.idx64 = p.idx64 ? 1u : 0u;
             // (the kernel bounds itself by span_off[nq] on the device; the grid is rounded up so that a
             // captured launch serves every batch of its shape class)
-            HIP_TRY(launch_hash(ha, round_up(b->span_off[nq], 1024), st));
+            HIP_TRY(launch_hash(ha, round_up(b->span_off[nq], 1024), hs));
             if (!hash_marked) {      // K1 / K2 split of the timing events: first file only
-                HIP_TRY(hipEventRecord(ev[1], st));
+                HIP_TRY(hipEventRecord(ev[1], hs));
                 hash_marked = true;
+            }
+            if (split) {             // this file's K2 launches wait for its table (and, the first time, for the flags fill)
+                HIP_TRY(hipEventRecord(b->hashed, hs));
+                HIP_TRY(hipStreamWaitEvent(st, b->hashed, 0));
+                if (!scan_marked) {
+                    HIP_TRY(hipEventRecord(ev[3], st));
+                    scan_marked = true;
+                }
             }
         }
         uint32_t tile_base = 0;
@@ -512,7 +536,12 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
             }
         }
     }
-    if (!hash_marked) HIP_TRY(hipEventRecord(ev[1], st));
+    if (!hash_marked) HIP_TRY(hipEventRecord(ev[1], hs));
+    if (split && !scan_marked) {         // (no file launched anything: keep the flags fill ordered before the caller's stream)
+        HIP_TRY(hipEventRecord(b->hashed, hs));
+        HIP_TRY(hipStreamWaitEvent(st, b->hashed, 0));
+        HIP_TRY(hipEventRecord(ev[3], st));
+    }
     HIP_TRY(hipEventRecord(ev[2], st));
     if (use_topk && nq) {
         for (size_t f = 0; f < ix->parts.size(); ++f) {
@@ -630,7 +659,7 @@ cobs_gpu_status cobs_gpu_batch_kernel_ms(cobs_gpu_batch* b, float* scan_ms, floa
         hipEvent_t* ev = b->ev[r % cobs_gpu_batch::kRing];
         float a = 0, c = 0;
         HIP_TRY(hipEventElapsedTime(&a, ev[0], ev[1]));
-        HIP_TRY(hipEventElapsedTime(&c, ev[1], ev[2]));
+        HIP_TRY(hipEventElapsedTime(&c, b->ev_split[r % cobs_gpu_batch::kRing] ? ev[3] : ev[1], ev[2]));
         h += a;
         s += c;
     }

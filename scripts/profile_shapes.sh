@@ -33,9 +33,9 @@ for shape in $WANT; do
   EXTRA=${SHAPES[$shape]}
   D="$OUT/$shape"
   mkdir -p "$D"
-  BENCH="python $REPO/bench.py --no-cpu-baseline --busy-tail 0 --steps 5 --warmup 2 $EXTRA"
+  BENCH="python $REPO/bench.py --no-cpu-baseline --steps 5 --warmup 2 $EXTRA"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$D/trace" -o bench -- $BENCH > "$D/trace.log" 2>&1
-  SHORT="python $REPO/bench.py --no-cpu-baseline --busy-tail 0 --steps 2 --warmup 1 $EXTRA"
+  SHORT="python $REPO/bench.py --no-cpu-baseline --steps 2 --warmup 1 $EXTRA"
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$D/pmc_fetch" -o bench -- $SHORT > "$D/pmc_fetch.log" 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$D/pmc_write" -o bench -- $SHORT > "$D/pmc_write.log" 2>&1
   if [[ " $FULL " == *" $shape "* ]]; then

@@ -9,7 +9,7 @@ mkdir -p gpurun_out
 {
   for l in 0 5120 10240; do scripts/probes/rw_mix_probe $l | grep -v "anywhere\|gather only"; done
   for args in "--queries 40000 --kmers 20" "--queries 40000 --kmers 70" "--queries 40000 --kmers 120" ""; do
-    python bench.py --no-cpu-baseline --busy-tail 0 --steps 6 --warmup 2 $args 2>/dev/null | python -c "
+    python bench.py --no-cpu-baseline --steps 6 --warmup 2 $args 2>/dev/null | python -c "
 import json,sys
 j=json.loads(sys.stdin.readline())
 print('scan kernel, %s: %.3f ms per launch (x4 for 40 000 queries: %.2f ms)  %.1f GB/s algorithmic' % (j['workload_key'], j['roofline']['scan_ms_per_launch'], 4*j['roofline']['scan_ms_per_launch'], j['roofline']['achieved']))"

@@ -81,9 +81,24 @@ def test_bench_sharded_code_path_on_one_rank(gpu_lib):
     assert j["exchange"]["mode"] == "alltoall" and j["exchange"]["transport"].startswith("RCCL")
     assert "sharded by sub-index block" in j["config"]["parallelism"]
     assert j["value"] > 0 and j["roofline"]["frac"] > 0
+    _check_self_proving_fields(j, 1)
     other = j["other_forms"]
-    for k in ("sharded_overlap_2_sub_batches", "sharded_allgather", "index_replicated_weak", "sharded_hits_threshold_0.8"):
+    for k in ("sharded_one_sub_batch", "sharded_4_sub_batches", "sharded_allgather", "index_replicated_weak",
+              "sharded_hits_threshold_0.8"):
         assert "queries_per_s" in other[k], (k, other[k])
+
+
+def _check_self_proving_fields(j, ranks):
+    """what makes an N > 1 line prove itself: the parity flag of the exchanged rows, who took part, what
+    every rank measured, and how much of the exchange + hashing the overlapped streams hid"""
+    assert j["bit_exact_vs_oracle"] is True and j["exchange_consistent_all_rows"] is True and j["oracle_sample_exact"] is True
+    chk = j["checked_per_rank_at_least"]
+    assert chk["rows_exchange_sums"] == 512 // ranks and chk["rows_exact_vs_oracle"] >= 16 and chk["rows_checksummed_vs_oracle"] >= 16
+    for k in ("scan_ms", "hash_ms", "exchange_ms"):
+        assert len(j["per_rank"][k]) == ranks and all(v > 0 for v in j["per_rank"][k]), (k, j["per_rank"])
+    x = j["exchange"]
+    assert x["sub_batches"] == 2 and 0.0 <= x["hidden_frac"] <= 1.0 and len(x["hidden_frac_per_rank"]) == ranks
+    assert "2 overlapped sub-batches" in j["config"]["parallelism"]
 
 
 def _bench(args, timeout=900, env=None):
@@ -114,6 +129,23 @@ def test_bench_gpus_1_plain_and_one_rank_sharded(gpu_lib):
     r, j, out = _bench(["--gpus", "1", "--one-rank-sharded", "--no-extras"] + SMALL)
     assert r.returncode == 0, r.stderr[-2000:]
     assert j["n_gpus"] == 1 and j["rccl_ranks"] == 1
+    _check_self_proving_fields(j, 1)
+    # one sub-batch on request: hash, scan, exchange in turn (the round-3 headline form)
+    r, j, out = _bench(["--gpus", "1", "--one-rank-sharded", "--exchange-chunks", "1"] + SMALL)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert j["exchange"]["sub_batches"] == 1 and j["bit_exact_vs_oracle"] is True
+
+
+def test_bench_fails_on_a_corrupted_exchange(gpu_lib):
+    """the self-check is worth something: with ONE count of ONE assembled row changed (a row outside the oracle's
+    sample, so only the all-rows sums can see it) the line says so and the run exits non-zero -- on the one-rank RCCL
+    communicator and across two gloo ranks"""
+    for extra in (["--gpus", "1", "--one-rank-sharded"], ["--gpus", "2", "--dist-backend", "gloo"]):
+        r, j, out = _bench(extra + ["--corrupt-exchange"] + SMALL)
+        assert r.returncode != 0, (extra, r.stderr[-2000:])
+        assert j is not None and j["bit_exact_vs_oracle"] is False
+        assert j["exchange_consistent_all_rows"] is False and j["oracle_sample_exact"] is True
+        assert "NOT bit-exact" in r.stderr
 
 
 def test_bench_gpus_2_launches_its_own_ranks(gpu_lib):
@@ -125,6 +157,8 @@ def test_bench_gpus_2_launches_its_own_ranks(gpu_lib):
     assert j["n_gpus"] == 2 and j["scaling"] == "strong"
     assert "sharded by sub-index block" in j["config"]["parallelism"] and "over 2 GPUs" in j["config"]["parallelism"]
     assert j["shard_rank0"]["slot_count"] < 100352
+    _check_self_proving_fields(j, 2)
+    assert j["rccl_ranks"] is None and j["exchange"]["transport"] == "torch.distributed/gloo"
     assert [ln for ln in out.splitlines() if ln.strip()] == [ln for ln in out.splitlines() if ln.startswith('{"metric"')]
 
 
