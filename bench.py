@@ -285,6 +285,37 @@ def kernels_hash():
     return h.hexdigest()[:16]
 
 
+def gpu_numa_node(dev):
+    """the NUMA node the GPU's PCIe root sits on (sysfs), or None"""
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
+            n = int(f.read().strip())
+        return n if n >= 0 else None
+    except Exception:                                               # noqa: BLE001
+        return None
+
+
+def bind_to_numa_node(node):
+    """this process (and the host threads the library starts: staging copies, pinned buffers they first touch) on the CPUs
+    of `node` -- with 8 ranks on two sockets every rank's host side then sits next to its GPU.  -> CPUs bound to, or 0"""
+    if node is None:
+        return 0
+    try:
+        cpus = set()
+        with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+            for part in f.read().strip().split(","):
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+        return len(cpus)
+    except Exception:                                               # noqa: BLE001
+        return 0
+
+
 def make_index(cfg, dev, rank=0, world=1, hbm_budget=0, path=None):
     if path:
         return cobs_amd.Search(path, device=dev, shard_rank=rank, shard_count=world, hbm_budget=hbm_budget)
@@ -757,6 +788,10 @@ def main():
         torch.cuda.set_device(0)
     n_gpus = world
     dev = torch.cuda.current_device()
+    # several ranks, or an out-of-core run (host staging in the data path): the host side next to the GPU.  A plain
+    # one-GPU run keeps all cores: its cpu_baseline leg uses them.
+    numa_node = gpu_numa_node(dev)
+    numa_cpus = bind_to_numa_node(numa_node) if (world > 1 or args.config == "c5" or args.hbm_budget_gb) else 0
 
     base = "c3" if args.config == "c5" else args.config
     cfg = {"c3": c3_config, "c2": c2_config, "c4": c4_config}[base](args.scale)
@@ -930,6 +965,7 @@ def main():
             per_rank = [None] * world
             dist.all_gather_object(per_rank, mine)
         out["per_rank"] = {k: [r[k] for r in per_rank] for k in ("scan_ms", "hash_ms", "exchange_ms")}
+        out["per_rank"]["numa_node_rank0"] = numa_node
         # of the time hashing and exchanging take, the part that did not show up in the step: the streams overlap them
         # with the scans (of the other sub-batch, of the next step)
         hidden = [max(0.0, min(1.0, (r["scan_ms"] + r["hash_ms"] + r["exchange_ms"] - ms_per_step) /
@@ -964,6 +1000,7 @@ def main():
                                                                            "scan_ms_per_launch")},
                            "note": "scan_ms_per_launch includes waiting for the chunks"}
         out["streaming"] = {"hbm_budget_bytes": budget, "index_bytes": index_bytes, "file": path,
+                            "gpu_numa_node": numa_node, "host_cpus_bound_to_that_node": numa_cpus,
                             "scan_launches_per_step": nlaunch, "chunks_fetched_by_rows": fetched, "chunks_copied_whole": whole,
                             "pcie_GBps_rank0": pcie}
     if shard_index and args.extras and not args.no_extras:

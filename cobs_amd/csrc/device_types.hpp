@@ -149,7 +149,8 @@ struct RankArgs {
     const uint2* src;            // (score, slot) pairs of the previous pass [nq][pair_stride]
     uint2* dst;                  // ... of this pass, unless it is the last
     uint32_t* npass;             // [nq] passing documents: written by a first pass that is not the last, read by later ones
-    uint2* out;                  // last pass: results [nq][out_stride] as (slot of the ranked row, score), at most `limit` per query
+    void* out;                   // last pass: results [nq][out_stride], at most `limit` per query: (slot of the ranked row, score) as
+                                 // uint2, or -- pack_bits > 0 -- as ONE u32 = score << pack_bits | slot (slot < 2^pack_bits)
     uint32_t* out_count;         // last pass: [nq] results written = min(limit, passing documents)
     uint64_t pair_stride, out_stride;
     uint32_t nparts, nslots;     // slots of a row that are ranked (the files' slices)
@@ -158,6 +159,7 @@ struct RankArgs {
     uint32_t shift, bits;        // digit of this pass = (score >> shift) & (2^bits - 1), bits <= 12
     uint32_t limit;
     uint32_t score_bytes;
+    uint32_t pack_bits;          // 0: 8-byte records
 };
 
 // Arguments of the construction kernel: set the signature bits of documents.

@@ -104,6 +104,8 @@ struct Tuning {
                                     // fetched by the kernel cross PCIe at 50.8 GB/s, whole chunks at 52.3 GB/s (profiles/r03_c5_selective.txt): 1
     int tile_topk = 1;          // top-k passes without score rows select per tile in K2 (0: score rows + K3, A/B)
     int device_rank = 1;        // whole score rows are ranked on the device (0: by host threads, A/B and fallback)
+    uint32_t rank_window_kib = 16u << 10;   // device-ranked records cross PCIe in pieces of this size (KiB)
+    int rank_pack = 1;          // device-ranked records cross PCIe as one u32 where slot and score fit (0: always 8-byte pairs, A/B)
     int hash_stream = 0;        // K1 of a device-resident batch runs on the batch's own stream, K2 waits for it by event: the hashing
                                 // of one (sub-)batch overlaps the scan / exchange of another (the sharded multi-GPU flow)
     uint32_t exp = 0;           // experimental kernel variants under A/B measurement (bit field, ScanArgs::exp)

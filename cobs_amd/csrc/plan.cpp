@@ -312,14 +312,23 @@ cobs_gpu_status chunk_part(Part& pt, uint64_t cap, const Tuning& tune) {
             continue;
         }
         flush();
-        // a single slice exceeds a buffer: cut it by columns (all rows, fewer documents)
-        uint64_t w = cap / (sig + 1);
-        w = w >= 128 ? w / 128 * 128 : w / 16 * 16;
-        while (w >= 16 && slice_bytes(sig, w, tune) > cap) w -= 16;
-        if (w < 16)
+        // a single slice exceeds a buffer: cut it by columns (all rows, fewer documents) -- into the FEWEST slices that
+        // fit, of about equal width.  A slice crosses PCIe as a 2-D copy of `width` bytes out of every row of the file,
+        // and what the link delivers falls with the width (MI355X, 1568-byte rows, profiles/r04_h2d_probe.txt: 56.2 GB/s
+        // whole rows, 55.1 at 1024 bytes, 53.6 at 640, 50.6 at 544, 43.0 at 288, 9.5 at 32): the widest slice a buffer
+        // holds plus a narrow remainder (round 3: 1536 + 32, 1024 + 544, 640 + 640 + 288 for the three largest
+        // sub-indexes of C3 under a 6 GB budget) spent 4 % of a pass on the remainders.
+        uint64_t wmax = cap / (sig + 1);
+        wmax = wmax >= 128 ? wmax / 128 * 128 : wmax / 16 * 16;
+        while (wmax >= 16 && slice_bytes(sig, wmax, tune) > cap) wmax -= 16;
+        if (wmax < 16)
             return fail(COBS_GPU_ERR_CAPACITY,
                         "hbm budget too small: a 16-byte column slice of the largest sub-index needs " +
                         std::to_string(2 * slice_bytes(sig, 16, tune)) + " bytes of streaming buffers");
+        const uint64_t nsl = (v.ncols + wmax - 1) / wmax;
+        uint64_t w = (v.ncols + nsl - 1) / nsl;                   // equal share ...
+        const uint64_t al = w >= 256 ? 128 : 16;                  // ... rounded up to whole cache lines where that is cheap
+        w = std::min(wmax, (w + al - 1) / al * al);
         for (uint64_t c0 = 0; c0 < v.ncols; c0 += w) {
             cur.vp.push_back(VPage{v.fp, v.col0 + c0, std::min<uint64_t>(w, v.ncols - c0)});
             flush();

@@ -2,10 +2,13 @@
 // rank_kernels.hip.  The reference's default call (threshold 0, no limit; also its own benchmark,
 // src/cobs.cpp:618-626) returns EVERY document of every query in rank order
 // (cobs/query/classic_search.cpp:109-202).  The score rows stay in HBM; a window of queries is
-// ordered there (one work-group per query), the ordered (slot, score) records cross PCIe once -- 8 bytes per
-// result, already in rank order, instead of a score row that host threads then sort -- and while window w
+// ordered there (one work-group per query), the ordered (slot, score) records cross PCIe once -- 4 bytes per
+// result where slot and score fit one word together (8 otherwise), already in rank order, instead of a score row
+// that host threads then sort -- and while window w
 // crosses, window w+1 is being ordered and the host expands window w-1 from the pinned landing buffer into the
 // cobs_gpu_hit records (file, document, score) of the caller's (pageable) array.
+#include <emmintrin.h>
+
 #include <algorithm>
 #include <condition_variable>
 #include <cstdio>
@@ -20,9 +23,9 @@
 
 namespace cobs_amd {
 
-// A few host threads that stay around for the life of the process (one pool, shared by every handle; a window's
-// expansion holds it for ~0.5 ms): expanding a window of records is ~1 ms of work, spawning 16 threads per window
-// would cost as much again.
+// Host threads that stay around for the life of the process (one pool of up to 31, shared by every handle; a
+// window's expansion holds it for a fraction of a millisecond): expanding a window of records is ~1 ms of work,
+// spawning the threads per window would cost as much again.
 class ExpandPool {
 public:
     explicit ExpandPool(unsigned n) {
@@ -87,7 +90,7 @@ private:
 };
 
 ExpandPool* expand_pool() {
-    static ExpandPool pool(std::min(15u, std::max(2u, std::thread::hardware_concurrency()) - 1u));
+    static ExpandPool pool(std::min(31u, std::max(2u, std::thread::hardware_concurrency()) - 1u));
     return &pool;
 }
 
@@ -114,30 +117,68 @@ void destroy_rank_work(RankWork* w) { delete w; }
 namespace {
 
 constexpr size_t kSpanBytes = 512u << 20;      // records one kernel launch orders (two such device buffers)
-constexpr size_t kWindowBytes = 32u << 20;     // per window: short head (first ordering) and tail (last host copy) of the pipeline
 
-// `n` (slot, score) records of the pinned landing buffer -> cobs_gpu_hit records in caller memory, with a few
-// threads: the slot of the ranked row becomes (file, document)
-void expand_records(ExpandPool* pool, cobs_gpu_hit* dst, const uint2* src, size_t n, const std::vector<RankPart>& parts) {
-    auto work = [&parts](cobs_gpu_hit* d, const uint2* s, size_t cnt) {
-        if (parts.size() == 1) {
-            const RankPart pt = parts[0];
-            const uint32_t bias = pt.doc_first - pt.slot0;
-            for (size_t i = 0; i < cnt; ++i) d[i] = cobs_gpu_hit{pt.file_no, s[i].x + bias, s[i].y};
-            return;
-        }
-        for (size_t i = 0; i < cnt; ++i) {
-            size_t p = 0;
-            while (p + 1 < parts.size() && s[i].x >= parts[p + 1].slot0) ++p;
-            d[i] = cobs_gpu_hit{parts[p].file_no, parts[p].doc_first + (s[i].x - parts[p].slot0), s[i].y};
+// `n` records of the pinned landing buffer -> cobs_gpu_hit records in caller memory, with the pool's threads: the slot
+// of the ranked row becomes (file, document).  pack_bits == 0: (slot, score) pairs of 8 bytes; else one u32 per record,
+// score << pack_bits | slot (the form the device writes whenever slot and score fit 32 bits together).
+// With 4-byte records the link delivers a window faster than the host used to expand it (2.75 ms of expansion against
+// 1.8 ms of PCIe for 256 queries x 100 000 documents): the 12-byte results are written four at a time as three
+// 16-byte non-temporal stores -- no read-for-ownership of 307 MB the caller has not looked at yet.
+void expand_records(ExpandPool* pool, cobs_gpu_hit* dst, const void* src, size_t n, uint32_t pack_bits,
+                    const std::vector<RankPart>& parts) {
+    static_assert(sizeof(cobs_gpu_hit) == 12, "three u32 per result");
+    const uint32_t smask = pack_bits ? (1u << pack_bits) - 1u : 0u;
+    auto work = [&parts, pack_bits, smask](cobs_gpu_hit* d, const void* sv, size_t first, size_t cnt) {
+        auto emit = [&](auto rec) {
+            if (parts.size() == 1) {
+                const RankPart pt = parts[0];
+                const uint32_t bias = pt.doc_first - pt.slot0, f = pt.file_no;
+                size_t i = 0;
+                if ((reinterpret_cast<uintptr_t>(d) & 3u) == 0) {
+                    for (; i < cnt && (reinterpret_cast<uintptr_t>(d + i) & 15u) != 0; ++i) {     // at most 3: 12 i mod 16
+                        uint32_t slot, score;
+                        rec(first + i, slot, score);
+                        d[i] = cobs_gpu_hit{f, slot + bias, score};
+                    }
+                    for (; i + 4 <= cnt; i += 4) {
+                        uint32_t sl[4], sc[4];
+                        for (int j = 0; j < 4; ++j) { rec(first + i + j, sl[j], sc[j]); sl[j] += bias; }
+                        __m128i* o = reinterpret_cast<__m128i*>(d + i);
+                        _mm_stream_si128(o + 0, _mm_set_epi32((int)f, (int)sc[0], (int)sl[0], (int)f));
+                        _mm_stream_si128(o + 1, _mm_set_epi32((int)sl[2], (int)f, (int)sc[1], (int)sl[1]));
+                        _mm_stream_si128(o + 2, _mm_set_epi32((int)sc[3], (int)sl[3], (int)f, (int)sc[2]));
+                    }
+                    _mm_sfence();
+                }
+                for (; i < cnt; ++i) {
+                    uint32_t slot, score;
+                    rec(first + i, slot, score);
+                    d[i] = cobs_gpu_hit{f, slot + bias, score};
+                }
+                return;
+            }
+            for (size_t i = 0; i < cnt; ++i) {
+                uint32_t slot, score;
+                rec(first + i, slot, score);
+                size_t p = 0;
+                while (p + 1 < parts.size() && slot >= parts[p + 1].slot0) ++p;
+                d[i] = cobs_gpu_hit{parts[p].file_no, parts[p].doc_first + (slot - parts[p].slot0), score};
+            }
+        };
+        if (pack_bits) {
+            const uint32_t* s = static_cast<const uint32_t*>(sv);
+            emit([=](size_t i, uint32_t& slot, uint32_t& score) { slot = s[i] & smask; score = s[i] >> pack_bits; });
+        } else {
+            const uint2* s = static_cast<const uint2*>(sv);
+            emit([=](size_t i, uint32_t& slot, uint32_t& score) { slot = s[i].x; score = s[i].y; });
         }
     };
-    const size_t kPiece = 128u << 10;        // records per job
+    const size_t kPiece = 64u << 10;         // records per job
     const size_t jobs = (n + kPiece - 1) / kPiece;
-    if (jobs <= 1 || !pool) { work(dst, src, n); return; }
+    if (jobs <= 1 || !pool) { work(dst, src, 0, n); return; }
     const std::function<void(size_t)> job = [&](size_t j) {
         const size_t a = j * kPiece, e = std::min(n, a + kPiece);
-        work(dst + a, src + a, e - a);
+        work(dst + a, src, a, e - a);
     };
     pool->run(jobs, job);
 }
@@ -216,19 +257,28 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
     const uint32_t planes = (uint32_t)b->planes;
     const uint32_t npasses = (planes + 11u) / 12u;
     const uint32_t pbits = (planes + npasses - 1u) / npasses;
+    // record width: slot and score in one word where they fit (C3: 17 + 10 bits), else a pair -- the default call moves
+    // one record per (query, document) over PCIe and is bound by exactly those bytes
+    uint32_t slot_bits = 1;
+    while (slot_bits < 32u && (1ull << slot_bits) < row_elems) ++slot_bits;
+    const uint32_t pack_bits = (ix->tune.rank_pack != 0 && slot_bits + planes <= 32u) ? slot_bits : 0u;
+    const size_t rec = pack_bits ? sizeof(uint32_t) : sizeof(uint2);
     // Two granularities.  A SPAN is what one kernel launch orders: up to 512 MiB of records -- one work-group per
     // query, and a work-group alone takes ~0.8 ms for 100 000 documents (dependent loads, one group per CU), so a
     // launch wants hundreds of queries to fill the device (launching per 32 MiB window left 84 % of the CUs idle and
     // made the call kernel-bound: profiles/r03_rank_kernel_stats.csv).  A PIECE is what crosses PCIe at a time: 32 MiB
     // of a span's records into one of three pinned landing buffers, expanded by the host while the next piece crosses.
-    const size_t sq = std::max<size_t>(1, std::min<size_t>(nq, kSpanBytes / (stride * sizeof(uint2))));     // queries per span
-    const size_t pq = std::max<size_t>(1, std::min<size_t>(sq, kWindowBytes / (stride * sizeof(uint2))));   // queries per piece
-    const size_t land_bytes = pq * stride * sizeof(uint2);
+    const size_t sq = std::max<size_t>(1, std::min<size_t>(nq, kSpanBytes / (stride * rec)));     // queries per span
+    // (a piece = what is in flight per stage of the PCIe | expansion pipeline: the head of a call is the first piece's
+    // crossing, its tail the last piece's expansion, in between both overlap -- tuning key rank_window_kib)
+    const size_t window = (size_t)std::max<uint32_t>(ix->tune.rank_window_kib, 256u) << 10;
+    const size_t pq = std::max<size_t>(1, std::min<size_t>(sq, window / (stride * rec)));   // queries per piece
+    const size_t land_bytes = (pq * stride * rec + 15) / 16 * 16;
     constexpr size_t kDepth = RankWork::kDepth;
     {   // the workspace: if the device or the pinned pool cannot give it, the caller ranks on the host as before
         bool ok = true;
         for (int i = 0; i < 2 && ok; ++i)
-            ok = w.out[i].reserve(sq * stride) == hipSuccess && w.cnt[i].reserve(2 * sq) == hipSuccess;
+            ok = w.out[i].reserve((sq * stride * rec + sizeof(uint2) - 1) / sizeof(uint2)) == hipSuccess && w.cnt[i].reserve(2 * sq) == hipSuccess;
         for (size_t i = 0; i < kDepth && ok; ++i) ok = w.land[i].reserve(land_bytes + 4 * pq) == hipSuccess;
         if (ok && npasses > 1)
             for (auto& pr : w.pairs) ok = ok && pr.reserve(sq * row_elems) == hipSuccess;
@@ -265,6 +315,7 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
         a.nq = (uint32_t)n;
         a.limit = (uint32_t)std::min<size_t>(stride, 0xFFFFFFFFu);
         a.score_bytes = b->elem_bytes;
+        a.pack_bits = pack_bits;
         for (uint32_t ps = 0; ps < npasses; ++ps) {
             a.shift = ps * pbits;
             a.bits = std::min(pbits, planes - a.shift);
@@ -286,7 +337,8 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
         const int s = (int)(pc.span & 1), l = (int)(pi % kDepth);
         const size_t off = pc.q0 - pc.span * sq;                 // queries into the span
         HIP_TRY(hipStreamWaitEvent(w.copy_stream, w.ranked[s], 0));
-        HIP_TRY(hipMemcpyAsync(w.land[l].p, w.out[s].p + off * stride, pc.n * stride * sizeof(uint2), hipMemcpyDeviceToHost, w.copy_stream));
+        HIP_TRY(hipMemcpyAsync(w.land[l].p, reinterpret_cast<const uint8_t*>(w.out[s].p) + off * stride * rec, pc.n * stride * rec,
+                               hipMemcpyDeviceToHost, w.copy_stream));
         HIP_TRY(hipMemcpyAsync(w.land[l].p + land_bytes, w.cnt[s].p + off, 4 * pc.n, hipMemcpyDeviceToHost, w.copy_stream));
         HIP_TRY(hipEventRecord(w.landed[l], w.copy_stream));
         if (pc.last_of_span) {
@@ -327,12 +379,12 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
         t0 = now_s();
         const Piece& wn = pieces[wi];
         const uint32_t* cnt = reinterpret_cast<const uint32_t*>(w.land[s].p + land_bytes);
-        const uint2* rec = reinterpret_cast<const uint2*>(w.land[s].p);
+        const uint8_t* recs = w.land[s].p;
         bool full = true;
         for (size_t i = 0; i < wn.n; ++i) full = full && cnt[i] == stride;
         if (full && !*overflow && wn.n * stride <= cap - *used) {
             // every query of the piece yields `stride` results (the default call): one block
-            expand_records(expand_pool(), hits + *used, rec, wn.n * stride, parts);
+            expand_records(expand_pool(), hits + *used, recs, wn.n * stride, pack_bits, parts);
             for (size_t i = 0; i < wn.n; ++i) {
                 *used += stride;
                 hit_offsets[wn.q0 + i + 1] = *used;
@@ -343,7 +395,7 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
         for (size_t i = 0; i < wn.n; ++i) {
             const size_t n = cnt[i];
             if (!*overflow && n <= cap - *used)
-                expand_records(expand_pool(), hits + *used, rec + i * stride, n, parts);
+                expand_records(expand_pool(), hits + *used, recs + i * stride * rec, n, pack_bits, parts);
             else
                 *overflow = true;
             *used += n;

@@ -16,7 +16,8 @@
 //                 (match-any), a lane's position is base[wave][digit] + its rank among them, the
 //                 first lane of each digit advances the base.
 //                 Scores of up to 12 bits (queries of up to 4095 terms) need ONE pass straight from
-//                 the score rows to the result records (8 bytes each: slot, score); wider scores take 2 (up to 24 bits) or 3
+//                 the score rows to the result records (slot, score: 4 bytes packed where both fit 32 bits, else 8);
+//                 wider scores take 2 (up to 24 bits) or 3
 //                 passes through (score, slot) pairs in HBM.
 //
 // The elements of the first pass are the local score slots of the row (the files' slices back to
@@ -181,7 +182,9 @@ __global__ __launch_bounds__(256) void rank_kernel(RankArgs a) {
     }
     // ---- (3) stable scatter: every wave walks its range in order
     uint2* dst = a.dst + (uint64_t)qb * a.pair_stride;
-    uint2* out = a.out + (uint64_t)qb * a.out_stride;
+    uint2* out = reinterpret_cast<uint2*>(a.out) + (uint64_t)qb * a.out_stride;
+    uint32_t* out32 = reinterpret_cast<uint32_t*>(a.out) + (uint64_t)qb * a.out_stride;
+    (void)out; (void)out32;
     auto place = [&](bool valid, uint32_t score, uint32_t slot) {
         const uint32_t bin = dmask - (by_score ? (score >> a.shift) & dmask : 0u);
         // lanes of this step with the same bin
@@ -201,9 +204,14 @@ __global__ __launch_bounds__(256) void rank_kernel(RankArgs a) {
         wave_sync();
         if (!valid) return;
         if constexpr (LAST) {
-            // (slot of the ranked row, score): 8 bytes per result over PCIe; the host turns the slot into
-            // (file, document) while it copies the window into the caller's cobs_gpu_hit array (rank.cpp)
-            if (pos < a.limit) out[pos] = make_uint2(slot, score);
+            // (slot of the ranked row, score) -- what crosses PCIe per result; the host turns the slot into
+            // (file, document) while it copies the window into the caller's cobs_gpu_hit array (rank.cpp).
+            // Where slot and score fit 32 bits together (C3: 17 + 10) the record is ONE word: the default
+            // call is bound by these bytes, not by the ordering.
+            if (pos < a.limit) {
+                if (a.pack_bits) out32[pos] = score << a.pack_bits | slot;
+                else out[pos] = make_uint2(slot, score);
+            }
         } else {
             dst[pos] = make_uint2(score, slot);
         }

@@ -123,3 +123,38 @@ def test_shards_rank_their_own_documents(gpu_lib, oracle):
         for i, (oi, od, osc) in enumerate(wants):
             keep = (od >= lo) & (od < lo + cnt)
             assert _same(offs, hits, i, (oi[keep], od[keep], osc[keep])), (n, r, i)
+
+
+def test_packed_and_pair_records_agree(gpu_lib, oracle):
+    """the ordered records cross PCIe as ONE u32 (score << slot_bits | slot) where slot and score fit 32 bits together
+    -- 100 000 documents x 10-bit scores: 17 + 10 -- and as (slot, score) pairs otherwise; tuning key rank_pack = 0
+    forces the pairs.  Same results either way, and the oracle's."""
+    cfg = _c3_small()
+    s = _open(gpu_lib, cfg)
+    ix = _oracle_index(oracle, cfg)
+    queries = bench.make_queries(9, 1000, seed=21) + bench.make_queries(3, 40, seed=22)
+    offs, hits = s.search_arrays(queries, 0.0, 0)
+    s.set_tuning("rank_pack", 0)
+    offs2, hits2 = s.search_arrays(queries, 0.0, 0)
+    assert np.array_equal(offs, offs2) and np.array_equal(hits, hits2)
+    for i in (0, 8, 9, 11):
+        assert _same(offs, hits, i, oracle.search_arrays(ix, queries[i], 0.0, 0)), i
+
+
+def test_more_than_2_pow_22_slots_fall_back_to_pairs(gpu_lib, oracle):
+    """4.2 M documents (129 sub-indexes of 32 768): a slot needs 23 bits.  With 10-bit scores (1000-k-mer queries) a
+    record does not fit one word -- 8-byte pairs --, with 4-bit scores (queries of up to 15 k-mers) it does: both against
+    the oracle, every document of every query"""
+    ndocs = (1 << 22) + 5000
+    page = 4096
+    npages = (ndocs + 8 * page - 1) // (8 * page)
+    sigs = [61 + 2 * (i % 7) for i in range(npages)]
+    s = gpu_lib.Search.synthetic("compact", sigs, ndocs, page_size=page, seed=5)
+    assert s.total_counts > (1 << 22)
+    ix = oracle.Index.synthetic(1, 31, 1, 1, page, sigs, ndocs, 5)
+    for kmers, seed in ((1000, 31), (12, 32)):
+        queries = bench.make_queries(4, kmers, seed=seed)
+        offs, hits = s.search_arrays(queries, 0.0, 0)
+        assert int(offs[-1]) == 4 * ndocs
+        for i in (0, 3):
+            assert _same(offs, hits, i, oracle.search_arrays(ix, queries[i], 0.0, 0)), (kmers, i)
