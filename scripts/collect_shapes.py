@@ -98,6 +98,17 @@ def main():
                     "kernels_hash": ent["kernels_hash"], "git_head": head,
                     "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE doubled per "
                               "MI355X_MICROARCH.md"}
+        if "TCC_EA0_RDREQ_sum" in pmc and "TCC_EA0_RDREQ_DRAM_sum" in pmc:
+            # can gfx950's counters tell HBM from the Infinity Cache?  "destined for DRAM" vs all memory-side read requests
+            rq, dr = pmc["TCC_EA0_RDREQ_sum"], pmc["TCC_EA0_RDREQ_DRAM_sum"]
+            ent["ea_read_requests"] = {"all": rq, "dram_destined": dr, "bytes_at_128_per_request": rq * 128,
+                                       "dram_destined_share": round(dr / rq, 6) if rq else None}
+            if ent["workload_key"] and ent["workload_key"] in traffic:
+                traffic[ent["workload_key"]]["infinity_cache_separable"] = (
+                    "no: TCC_EA0_RDREQ_DRAM_sum == TCC_EA0_RDREQ_sum (%d of %d requests): the Infinity Cache is memory-side, behind "
+                    "the counters of the L2's fabric interface; HBM-pin traffic is bounded from below by the distinct rows of a "
+                    "launch (bench.py roofline.unique_bytes_per_launch) and measured at a cache-cold batch (roofline.cache_cold)"
+                    % (dr, rq)) if abs(dr - rq) <= 1e-6 * max(rq, 1) else "share of DRAM-destined read requests: %.4f" % (dr / rq)
         if "TCC_HIT_sum" in pmc and "TCC_MISS_sum" in pmc:
             ent["l2_hit_rate"] = round(pmc["TCC_HIT_sum"] / (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]), 4)
         shapes[shape] = ent

@@ -246,6 +246,58 @@ def test_streamed_file_at_scale_is_bit_exact(gpu_lib, oracle, tmp_path):
     assert got == [[(f, d, sc) for (f, d, _n, sc) in oracle.search(ix, q, 0.0, 5)] for q in queries[:8]]
 
 
+def test_headline_geometry_from_a_20_gb_file(gpu_lib, oracle, tmp_path):
+    """The headline geometry (BASELINE configs[2]: 100 000 documents, 8 sub-indexes of 1568-byte pages, S_p geometric)
+    as a FILE of more than 20 GB, opened RESIDENT: the path a user's index takes -- parse_index_header, the slab
+    upload through pinned staging, re-pitching 1568 -> 1664 bytes -- instead of the in-HBM generator the other
+    full-size tests share with their checker.  The checker here reads the same FILE through its own header parser
+    and mmap (oracle.Index.open) and counts on the CPU: 64 queries, every score row element by element, plus
+    rows of the matrix read back from HBM against the file's bytes at the offsets the checker computes."""
+    import os
+    import shutil
+    import cobs_amd
+    cfg = bench.c3_config(1.1)
+    width = cfg["page_size"]
+    size = sum(cfg["signature_sizes"]) * width
+    assert size > 20 * 10 ** 9
+    free = shutil.disk_usage(str(tmp_path)).free
+    assert free > size + (2 << 30), "needs %.1f GB of scratch space under %s" % (size / 1e9, tmp_path)
+    path = str(tmp_path / "c3_x1.1.cobs_compact")
+    cobs_amd.write_synthetic(path, "compact", cfg["signature_sizes"], cfg["num_docs"], page_size=width, seed=7)
+    try:
+        assert os.path.getsize(path) > size
+        s = gpu_lib.Search(path)                                 # no budget: resident, uploaded from the file
+        info = s.info(0)
+        assert info.kind == 1 and info.num_pages == 8 and info.page_size == width and info.num_docs == cfg["num_docs"]
+        assert info.hbm_bytes > size                             # all of it in HBM (rows at their device pitch)
+        ix = oracle.Index.open(path)                             # the checker's own reader of the same file
+        assert [ix.signature_size(p) for p in range(8)] == cfg["signature_sizes"]
+        queries = bench.make_queries(64, 1000, seed=77)
+        b = gpu_lib.Batch(s)
+        b.set_queries(queries)
+        b.run(0.0)
+        b.sync()
+        for i, q in enumerate(queries):
+            assert np.array_equal(b.counts_host(i), ix.counts(q)), i
+        # ranking from the same rows
+        got = s.search_hits(queries[:4], 0.0, 7)
+        assert got == [[(f, d, sc) for (f, d, _n, sc) in oracle.search(ix, q, 0.0, 7)] for q in queries[:4]]
+        # rows of the matrix as HBM holds them against the FILE's bytes: first / last row of the first and last
+        # sub-index, rows on both sides of a 256 MiB upload slab (171 196 rows of 1568 bytes)
+        raw = np.memmap(path, dtype=np.uint8, mode="r")
+        data0 = os.path.getsize(path) - size                     # the matrix is the file's tail (SURVEY App. A)
+        off = [0]
+        for sp in cfg["signature_sizes"]:
+            off.append(off[-1] + sp * width)
+        for page, row in ((0, 0), (0, cfg["signature_sizes"][0] - 1), (7, 0), (7, cfg["signature_sizes"][7] - 1),
+                          (7, 171195), (7, 171196), (7, 171197), (3, 2 * 171196 - 1), (3, 2 * 171196)):
+            o = data0 + off[page] + row * width
+            assert np.array_equal(s.read_row(0, page, row, width), raw[o:o + width]), (page, row)
+        del raw, b, s
+    finally:
+        os.unlink(path)
+
+
 def _shards_in_turn(gpu, opener, nshards, mode, queries, budget=0):
     """every shard of an N-way sharded index opened one after another on this one GPU: -> (slot layout per rank,
     local count rows per rank as the scan leaves them in HBM, score width)"""
