@@ -547,6 +547,55 @@ __device__ __forceinline__ void planes_to_bytes32(const uint32_t (&P)[NP], uint3
 // 128 bytes of scores + 16 of padding, so that the 16-byte writes of 16 lanes hit 16 different banks
 constexpr uint32_t kStageStride = 144u;
 
+// Cross-lane steps inside a row of 16 lanes as DPP modifiers of the VALU (v_add_u32 ..._dpp: no trip through the
+// LDS crossbar, which a ds_bpermute-based __shfl costs -- ~100 cycles of latency per dependent step).
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF, bool BOUND_ZERO = true>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, BOUND_ZERO);
+}
+constexpr int kDppQuadXor1 = 0xB1;       // quad_perm:[1,0,3,2]
+constexpr int kDppQuadXor2 = 0x4E;       // quad_perm:[2,3,0,1]
+constexpr int kDppRowMirror = 0x140;     // lane i <- lane 15 - i of its row
+constexpr int kDppHalfMirror = 0x141;    // lane i <- lane 7 - i of its half row
+constexpr int kDppRowShr = 0x110;        // + n: lane i <- lane i - n of its row (0 shifted in)
+constexpr int kDppBcast15 = 0x142;       // lane 15 of a row -> every lane of the next row
+constexpr int kDppBcast31 = 0x143;       // lane 31 -> every lane of rows 2 and 3
+
+// sum of `c` over the W (power of two, 4..64) consecutive lanes of a lane group, in every lane of the group
+__device__ __forceinline__ uint32_t group_allsum(uint32_t c, uint32_t W) {
+    c += dpp_mov<kDppQuadXor1>(c);
+    c += dpp_mov<kDppQuadXor2>(c);                      // every lane: the sum of its quad
+    if (W >= 8u) c += dpp_mov<kDppHalfMirror>(c);       // + the other quad of the half row
+    if (W >= 16u) c += dpp_mov<kDppRowMirror>(c);       // + the other half of the row
+    if (W >= 32u) c += (uint32_t)__shfl_xor(c, 16);
+    if (W >= 64u) c += (uint32_t)__shfl_xor(c, 32);
+    return c;
+}
+
+// inclusive prefix sum of `v` over the lanes of a lane group (col = lane inside the group)
+__device__ __forceinline__ uint32_t group_incl_scan(uint32_t v, uint32_t W, uint32_t col) {
+    uint32_t t;
+    t = dpp_mov<kDppRowShr + 1>(v); v += col >= 1u ? t : 0u;
+    t = dpp_mov<kDppRowShr + 2>(v); v += col >= 2u ? t : 0u;
+    if (W >= 8u) { t = dpp_mov<kDppRowShr + 4>(v); v += col >= 4u ? t : 0u; }
+    if (W >= 16u) { t = dpp_mov<kDppRowShr + 8>(v); v += col >= 8u ? t : 0u; }
+    // (the row steps stop at row boundaries: what crosses them is the TOTAL of the rows before)
+    if (W >= 32u) v += dpp_mov<kDppBcast15, 0xA, 0xF, false>(v);      // rows 1 and 3 += lane 15 of the row before
+    if (W >= 64u) v += dpp_mov<kDppBcast31, 0xC, 0xF, false>(v);      // rows 2 and 3 += lane 31 (complete after the step above)
+    return v;
+}
+
+// inclusive prefix sum over the 64 lanes of a wave: four row steps, then lane 15 / lane 31 broadcasts (GFX9 DPP)
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
+    v += dpp_mov<kDppRowShr + 1>(v);
+    v += dpp_mov<kDppRowShr + 2>(v);
+    v += dpp_mov<kDppRowShr + 4>(v);
+    v += dpp_mov<kDppRowShr + 8>(v);
+    v += dpp_mov<kDppBcast15, 0xA, 0xF, false>(v);      // rows 1 and 3 += the total of the row before
+    v += dpp_mov<kDppBcast31, 0xC, 0xF, false>(v);      // rows 2 and 3 += the total of the first half
+    return v;
+}
+
 // Exact top-k of ONE tile, straight from the bit-sliced counters (run_topk without score rows): the k best
 // documents of a tile under (score desc, document asc) are a superset of the tile's share of the query's k
 // best (counts_to_result's partial_sort, classic_search.cpp:134-145), so K3 only has to merge tiles x k
@@ -588,7 +637,7 @@ __device__ __forceinline__ void tile_topk(const ScanArgs& a, const uint32_t (&pl
         uint32_t A[4], c = 0u;
 #pragma unroll
         for (int w = 0; w < 4; ++w) { A[w] = M[w] & pl[w][p]; c += (uint32_t)__popc(A[w]); }
-        for (uint32_t off = 1; off < W; off <<= 1) c += (uint32_t)__shfl_xor(c, off);
+        c = group_allsum(c, W);
         const bool take = c >= krem;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
@@ -598,11 +647,7 @@ __device__ __forceinline__ void tile_topk(const ScanArgs& a, const uint32_t (&pl
         krem -= take ? 0u : c;
     }
     auto group_excl = [&](uint32_t v, uint32_t* total) {
-        uint32_t incl = v;
-        for (uint32_t off = 1; off < W; off <<= 1) {
-            const uint32_t t = __shfl_up(incl, off);
-            if (col >= off) incl += t;
-        }
+        const uint32_t incl = group_incl_scan(v, W, col);
         *total = __shfl(incl, lane | (W - 1u));
         return incl - v;
     };
@@ -946,7 +991,11 @@ __global__ __launch_bounds__(NW * 64, (TK && H1 && NP <= 10) ? 4 : 1) void scan_
     if constexpr (TK) {
         // run_topk without score rows: wave 0 holds the final planes and selects the tile's k best from them
         __syncthreads();                 // tile metadata / thresholds written at the start are read below (NW = 1: no barrier so far)
-        if (wave == 0u) tile_topk<NP, MQ>(a, pl, lane, W, tile, qi, tmeta, tthr);
+        // (the lane number is taken afresh from the hardware: keeping threadIdx-derived values alive across the row loop
+        // is what pushed the 8-plane multi-query instantiation over its 128 registers -- 3 spills, the library's only
+        // scratch user in round 3)
+        if (wave == 0u)
+            tile_topk<NP, MQ>(a, pl, __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), W, tile, qi, tmeta, tthr);
         return;
     }
     if constexpr (sizeof(OutT) == 1) {
@@ -983,6 +1032,10 @@ __global__ __launch_bounds__(NW * 64, (TK && H1 && NP <= 10) ? 4 : 1) void scan_
                 if (valid && a.write_counts) {
                     OutT* crow = reinterpret_cast<OutT*>(a.counts) + (uint64_t)q2 * a.counts_stride + a.counts_offset;
                     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    // (two 8-byte stores per piece.  Round 4 measured the alternatives, interleaved inside one process: one 16-byte
+                    // store where all slots are multiples of 16 is 2.8 % SLOWER on 50-bp reads and 1.3 % on 150-bp reads; 8-byte
+                    // pieces laid out so that a wave-store covers 512 contiguous bytes came out 4 % faster in one build and 2 %
+                    // slower in the next -- below what separates two processes on one box: profiles/r04_short_read_experiments.txt)
                     u32x2* dst = reinterpret_cast<u32x2*>(crow + slot);       // slots are multiples of 8, not of 16
                     const u32x2 v0 = {v.x, v.y}, v1 = {v.z, v.w};
                     dst[0] = v0;
@@ -1004,12 +1057,7 @@ __global__ __launch_bounds__(NW * 64, (TK && H1 && NP <= 10) ? 4 : 1) void scan_
                     }
                     if (__any(mask != 0u)) {
                         const uint32_t n = __popc(mask);
-                        uint32_t incl = n;
-#pragma unroll
-                        for (int off = 1; off < 64; off <<= 1) {
-                            const uint32_t t = __shfl_up(incl, off);
-                            if (lane >= (uint32_t)off) incl += t;
-                        }
+                        const uint32_t incl = wave_incl_scan_dpp(n);
                         const uint32_t total = __shfl(incl, 63);
                         unsigned long long base = 0ull;
                         if (lane == 63u) base = atomicAdd(a.hit_count, (unsigned long long)total);
@@ -1073,12 +1121,7 @@ __global__ __launch_bounds__(NW * 64, (TK && H1 && NP <= 10) ? 4 : 1) void scan_
             if (!valid) ge = 0u;
             if (__any(ge != 0u)) {
                 const uint32_t n = __popc(ge);
-                uint32_t incl = n;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const uint32_t t = __shfl_up(incl, off);
-                    if (lane >= (uint32_t)off) incl += t;
-                }
+                const uint32_t incl = wave_incl_scan_dpp(n);
                 const uint32_t total = __shfl(incl, 63);
                 unsigned long long base = 0ull;
                 if (lane == 63u) base = atomicAdd(a.hit_count, (unsigned long long)total);
@@ -1181,12 +1224,7 @@ __global__ __launch_bounds__(NW * 64, (TK && H1 && NP <= 10) ? 4 : 1) void scan_
             }
             if (__any(mask != 0u)) {
                 const uint32_t n = __popc(mask);
-                uint32_t incl = n;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const uint32_t t = __shfl_up(incl, off);
-                    if (lane >= (uint32_t)off) incl += t;
-                }
+                const uint32_t incl = wave_incl_scan_dpp(n);
                 const uint32_t total = __shfl(incl, 63);
                 unsigned long long base = 0ull;
                 if (lane == 63u) base = atomicAdd(a.hit_count, (unsigned long long)total);

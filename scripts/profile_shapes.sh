@@ -1,6 +1,6 @@
 #!/bin/bash
-# scripts/profile_shapes.sh TAG [shape ...]   (run ONCE per round, at its end: scripts/collect_shapes.py TAG stamps profiles/)
-# scripts/profile_shapes.sh TAG [shape ...] -- rocprofv3 evidence for every shape DESIGN.md quotes,
+# scripts/profile_shapes.sh TAG [shape ...] -- run ONCE per round, at its end (scripts/collect_shapes.py TAG then stamps
+# profiles/): rocprofv3 evidence for every shape DESIGN.md quotes,
 # on the GPU box.  Per shape: one --kernel-trace --stats run of bench.py (per-kernel durations + the
 # bench line of the profiled process) and separate --pmc passes (FETCH_SIZE, WRITE_SIZE; for the
 # shapes marked "full" also L2 hits/misses and SQ wave/wait counters).  PMC passes never carry
