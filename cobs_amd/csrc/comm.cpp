@@ -723,6 +723,14 @@ static cobs_gpu_status sharded_search_impl(cobs_gpu_index* ix, cobs_gpu_comm* c,
                 return fail(COBS_GPU_ERR_CAPACITY, "hit buffer too small; hit_offsets[nq] holds the needed size");
             }
         }
+        {   // Which exchange a pass takes depends on whether its scan selected hits itself (run_impl); a rank whose
+            // streamed shard is counted in row ranges cannot -- then no rank does: one agreement per call.
+            uint32_t mine = 0, any = 0;
+            for (const auto& p : ix->parts) mine |= p.has_row_ranges ? 1u : 0u;
+            cobs_gpu_status as = agree(c, b, st, mine, &any);
+            if (as != COBS_GPU_OK) return as;
+            ix->peers_ranged = any != 0;
+        }
         size_t g0 = 0;
         do {
             size_t g1 = g0;
@@ -768,7 +776,9 @@ static cobs_gpu_status sharded_search_impl(cobs_gpu_index* ix, cobs_gpu_comm* c,
                 return COBS_GPU_OK;
             };
             if ((s = all_ranks_ok(s)) != COBS_GPU_OK) return s;
-            bool need_rows = !hits_only && b->topk_k == 0;
+            // (a handle whose streamed sub-indexes are counted in row ranges keeps score rows instead of selecting in K2,
+            // pass.cpp: set_run_state; peers_ranged above makes that the same on every rank)
+            bool need_rows = (!hits_only && b->topk_k == 0) || (hits_only && !b->selected);
             if (b->topk_k) {
                 s = cobs_gpu_batch_exchange_topk(b, c, st);
                 if (s != COBS_GPU_OK) return s;

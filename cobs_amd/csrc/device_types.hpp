@@ -14,6 +14,7 @@ struct PageDev {
     uint64_t base;         // byte offset of row 0 from the file's HBM blob
     uint64_t sig;          // signature_size S_p (row index = hash % S_p)
     uint64_t magic;        // floor((2^64 - 1) / S_p) for the exact fast modulo
+    uint64_t row0;         // streamed row-range chunk: `sig` rows starting at row0 of the sub-index are in the buffer (else 0)
     uint32_t slot0;        // first local score slot of this page (multiple of 8)
     uint32_t doc0;         // file-level document id of the page's first document
     uint32_t valid_bytes;  // row bytes that map to score slots (<= pitch)
@@ -94,6 +95,22 @@ struct BucketArgs {
 
 // Row-selective access to a chunk that is not resident (fetch_kernels.hip): fetch the rows K1's table names
 // from the registered file mapping into a gathered buffer shaped like a resident chunk.
+// Row-range chunks of a streamed sub-index (fetch_kernels.hip): K1's row indices of one sub-index rewritten for a
+// buffer that holds rows [row0, row0 + nrows) only, and the partial scores of such a chunk added to the score rows.
+struct RemapArgs {
+    const void* table;           // K1's row indices (u32, or u64 when idx64)
+    void* table2;                // same layout: index - row0 inside the range, else nrows (the buffer's zero row)
+    const uint64_t* blk_off;     // nq + 1
+    uint64_t row0, nrows;
+    uint32_t nq, tpage, table_npages, num_hashes;
+};
+struct AddScoresArgs {
+    void* dst;                   // score rows [nq][dst_stride] (elements of elem_bytes)
+    const void* src;             // partial scores [nq][nslots]
+    uint64_t dst_stride, dst_offset;   // elements
+    uint32_t nslots, nq, elem_bytes;
+};
+
 struct FetchArgs {
     const uint8_t* file;         // device-visible address of the mapped index file
     const void* table;           // K1's row indices (u32, or u64 when idx64)

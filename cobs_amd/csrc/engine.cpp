@@ -71,6 +71,7 @@ Tuning Tuning::from_env() {
     if (const char* e = getenv("COBS_GPU_LDS_STAGED")) t.lds_staged = atoi(e) != 0;
     if (const char* e = getenv("COBS_GPU_DEVICE_RANK")) t.device_rank = atoi(e) != 0;
     if (const char* e = getenv("COBS_GPU_TRACE")) t.trace = atoi(e) != 0;
+    if (const char* e = getenv("COBS_GPU_ROW_RANGES")) t.row_ranges = atoi(e) != 0;
     if (const char* e = getenv("COBS_GPU_EXP")) t.exp = (uint32_t)std::strtoul(e, nullptr, 0);      // A/B variants, also under the test suite
     return t;
 }
@@ -80,6 +81,7 @@ Part::~Part() {
         if (c.d_data) (void)hipFree(c.d_data);
         if (c.d_pages) (void)hipFree(c.d_pages);
         if (c.d_src) (void)hipFree(c.d_src);
+        if (c.d_pages_acc) (void)hipFree(c.d_pages_acc);
         for (auto* p2 : c.d_pages2) if (p2) (void)hipFree(p2);
     }
     for (Chunk& c : fetch_groups) {
@@ -203,7 +205,8 @@ static cobs_gpu_status stage_index(cobs_gpu_index* ix, std::vector<std::unique_p
                     pt.file_dev = static_cast<const uint8_t*>(dp);
                     for (Chunk& c : pt.chunks) {
                         std::vector<uint64_t> src(c.vp.size());
-                        for (size_t k = 0; k < c.vp.size(); ++k) src[k] = pt.meta.page_offset(c.vp[k].fp) + c.vp[k].col0;
+                        for (size_t k = 0; k < c.vp.size(); ++k)
+                            src[k] = pt.meta.page_offset(c.vp[k].fp) + c.vp[k].row0 * pt.meta.page_row_bytes() + c.vp[k].col0;
                         HIP_TRY(hipMalloc((void**)&c.d_src, 8 * src.size()));
                         HIP_TRY(hipMemcpy(c.d_src, src.data(), 8 * src.size(), hipMemcpyHostToDevice));
                         for (auto& p2 : c.d_pages2) HIP_TRY(hipMalloc((void**)&p2, sizeof(PageDev) * c.vp.size()));
@@ -219,6 +222,22 @@ static cobs_gpu_status stage_index(cobs_gpu_index* ix, std::vector<std::unique_p
                                 g = &pt.fetch_groups.back();
                                 g->pitch = c.pitch;
                                 g->cpp = c.cpp;
+                            }
+                            if (c.row_range) {
+                                // the row ranges of one sub-index are ONE unit here, with all of its rows: a pass that
+                                // fetches by rows gathers the looked-up rows wherever they are
+                                if (c.range_no != 0) continue;
+                                VPage whole = c.vp[0];
+                                whole.row0 = whole.nrows = 0;
+                                PageDev pd = c.pages[0];
+                                pd.sig = pt.meta.signature_sizes[whole.fp];
+                                pd.row0 = 0;
+                                pd.magic = ~0ull / pd.sig;
+                                pd.base = 0;                  // (a gathered buffer has its own bases: fetch_rows_kernel)
+                                g->vp.push_back(whole);
+                                g->pages.push_back(pd);
+                                g->bytes += slice_bytes(pd.sig, whole.ncols, ix->tune);
+                                continue;
                             }
                             g->vp.insert(g->vp.end(), c.vp.begin(), c.vp.end());
                             g->pages.insert(g->pages.end(), c.pages.begin(), c.pages.end());
@@ -418,6 +437,8 @@ cobs_gpu_status cobs_gpu_set_tuning(cobs_gpu_index* ix, const char* key, int64_t
         t.device_rank = value != 0;
     } else if (k == "rank_window_kib") {
         t.rank_window_kib = value > 0 ? (uint32_t)std::min<int64_t>(value, 1 << 20) : 16u << 10;
+    } else if (k == "row_ranges") {
+        return fail(COBS_GPU_ERR_ARG, "row_ranges shapes the chunks of an index: set COBS_GPU_ROW_RANGES before it is opened");
     } else if (k == "rank_pack") {
         t.rank_pack = value != 0;
     } else if (k == "hash_stream") {

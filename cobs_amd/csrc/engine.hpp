@@ -105,6 +105,7 @@ struct Tuning {
     int tile_topk = 1;          // top-k passes without score rows select per tile in K2 (0: score rows + K3, A/B)
     int device_rank = 1;        // whole score rows are ranked on the device (0: by host threads, A/B and fallback)
     uint32_t rank_window_kib = 16u << 10;   // device-ranked records cross PCIe in pieces of this size (KiB)
+    int row_ranges = 1;         // a streamed sub-index larger than a stream buffer is cut by ROWS (H = 1; 0: by columns, A/B and fallback)
     int rank_pack = 1;          // device-ranked records cross PCIe as one u32 where slot and score fit (0: always 8-byte pairs, A/B)
     int hash_stream = 0;        // K1 of a device-resident batch runs on the batch's own stream, K2 waits for it by event: the hashing
                                 // of one (sub-)batch overlaps the scan / exchange of another (the sharded multi-GPU flow)
@@ -118,6 +119,7 @@ struct Tuning {
 struct VPage {
     uint32_t fp = 0;
     uint64_t col0 = 0, ncols = 0;
+    uint64_t row0 = 0, nrows = 0;    // nrows != 0: only rows [row0, row0 + nrows) (a row-range chunk of a streamed sub-index)
 };
 
 // A group of slices (equal width) that is in HBM at the same time and is scanned by one
@@ -137,6 +139,12 @@ struct Chunk {
     // streamed chunk of a file whose mapping is registered: what the row-selective pass needs on the device
     uint64_t* d_src = nullptr;       // [vp.size()] file offset of (row 0, first held column) of every slice
     PageDev* d_pages2[2] = {nullptr, nullptr};   // the pages as a gathered buffer holds them (written per pass), per stream buffer
+    // A ROW-RANGE chunk: one sub-index too large for a stream buffer, cut by rows (all columns, `nrows` rows from `row0`) --
+    // whole rows cross PCIe at the link's best rate, column slices do not (plan.cpp: chunk_part).  Its scan counts only
+    // the terms whose row falls into the range; every range but the first writes partial scores that are ADDED to the rows.
+    bool row_range = false;
+    uint32_t range_no = 0;           // 0 = the first range of its sub-index (writes the scores), > 0 = adds to them
+    PageDev* d_pages_acc = nullptr;  // range_no > 0: the page with slot0 = 0 (partial scores go to a scratch matrix)
 };
 
 // One index file as held by this device (possibly only a shard of it).
@@ -151,6 +159,7 @@ struct Part {
     std::vector<PageDev> tpages;             // sub-indexes [first_page, end_page): pages of the row-index table
     PageDev* d_tpages = nullptr;
     bool streamed = false;
+    bool has_row_ranges = false;             // some chunk is a row range: K2 cannot select on its partial counts (pass.cpp)
     bool idx64 = false;                      // a sub-index has >= 2^32 - 1 rows: 64-bit row-index table
     size_t hbm_bytes = 0;
     uint64_t resident_bytes = 0;             // what the held slices need when they stay in HBM
@@ -215,6 +224,7 @@ struct cobs_gpu_index {
     std::vector<cobs_amd::Part> parts;
     cobs_amd::StreamBufs stream;
     uint64_t total_counts = 0, local_counts = 0;
+    bool peers_ranged = false;    // sharded search: some rank counts a streamed sub-index in row ranges -> every rank keeps score rows
     double timers[5] = {0, 0, 0, 0, 0};
     uint64_t graph_replays = 0;   // small passes of the host API served by a captured hipGraph
     static constexpr int kScratch = 3;
@@ -238,6 +248,7 @@ struct cobs_gpu_batch {
     cobs_amd::PinnedBuf<uint32_t> h_thr_stage;
     std::vector<cobs_amd::PartWork> work;
     cobs_amd::DevBuf<uint8_t> counts;
+    cobs_amd::DevBuf<uint8_t> counts_part;   // partial scores of a row-range chunk (streamed index), added to `counts`
     uint32_t elem_bytes = 2;
     int planes = 0;
     uint64_t max_terms = 0;              // longest query of the batch, in terms

@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256) void fetch_rows_kernel(FetchArgs a) {
         PageDev g = pd;
         g.base = (uint64_t)i * (E + 1u) * a.pitch;
         g.sig = E;
+        g.row0 = 0;
         a.pages2[i] = g;
     }
     const uint64_t per = 8ull * a.num_hashes;
@@ -83,7 +84,9 @@ __global__ __launch_bounds__(256) void fetch_rows_kernel(FetchArgs a) {
     const uint64_t nblk1 = a.blk_off[lo + 1] - b0 + 1u;   // blocks of the query incl. its padding block
     const uint64_t within = n - (b0 + lo) * per;
     const uint64_t e = ((b0 + lo) * a.table_npages + (uint64_t)pd.tpage * nblk1) * per + within;
-    const uint64_t r = reinterpret_cast<const IdxT*>(a.table)[e];
+    // (a row-range chunk holds rows [row0, row0 + sig) of its sub-index: a row outside it -- and K1's padding row S_p,
+    // which lies beyond every range -- reads as the zero row; page_src points at the range's first row)
+    const uint64_t r = (uint64_t)reinterpret_cast<const IdxT*>(a.table)[e] - pd.row0;
     const bool pad = r >= pd.sig;                          // K1 points padded terms at row S_p
     if (c == 0u)
         reinterpret_cast<IdxT*>(a.table2)[e] = (IdxT)(pad ? E : n);     // (several slices of one sub-index share these entries)
@@ -94,7 +97,58 @@ __global__ __launch_bounds__(256) void fetch_rows_kernel(FetchArgs a) {
     *reinterpret_cast<uint4*>(out) = v;
 }
 
+// Row-range chunk, streamed whole: K1's row indices of its sub-index, rewritten for a buffer that holds rows
+// [row0, row0 + nrows) only.  One thread per table entry of that sub-index ([query][block + padding block][hash][8]).
+template <typename IdxT>
+__global__ __launch_bounds__(256) void remap_rows_kernel(RemapArgs a, uint64_t entries) {
+    const uint64_t n = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (n >= entries) return;
+    const uint64_t per = 8ull * a.num_hashes;
+    uint32_t lo = 0, hi = a.nq;                            // query of entry n: the last q with (blk_off[q] + q) * per <= n
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((a.blk_off[mid] + mid) * per <= n) lo = mid; else hi = mid;
+    }
+    const uint64_t b0 = a.blk_off[lo];
+    const uint64_t nblk1 = a.blk_off[lo + 1] - b0 + 1u;
+    const uint64_t e = ((b0 + lo) * a.table_npages + (uint64_t)a.tpage * nblk1) * per + (n - (b0 + lo) * per);
+    const uint64_t r = (uint64_t)reinterpret_cast<const IdxT*>(a.table)[e] - a.row0;
+    reinterpret_cast<IdxT*>(a.table2)[e] = (IdxT)(r < a.nrows ? r : a.nrows);
+}
+
+// dst[q][dst_offset + i] += src[q][i]: whole 32-bit words (slots come in multiples of 8; the counters of a word
+// cannot carry into each other: every sum is a count of the query's terms, which the score type holds)
+__global__ __launch_bounds__(256) void add_scores_kernel(AddScoresArgs a) {
+    const uint64_t words_per_row = (uint64_t)a.nslots * a.elem_bytes / 4u;
+    const uint64_t gid = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint64_t q = gid / words_per_row;
+    if (q >= a.nq) return;
+    const uint64_t w = gid - q * words_per_row;
+    uint32_t* d = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(a.dst) + (q * a.dst_stride + a.dst_offset) * a.elem_bytes) + w;
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(a.src) + q * (uint64_t)a.nslots * a.elem_bytes) + w;
+    *d += *s;
+}
+
 }  // namespace
+
+hipError_t launch_remap_rows(const RemapArgs& a, uint64_t entries, bool idx64, hipStream_t stream) {
+    if (entries == 0 || a.nq == 0) return hipSuccess;
+    const uint64_t blocks = (entries + 255u) / 256u;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if (idx64) hipLaunchKernelGGL(remap_rows_kernel<uint64_t>, dim3((uint32_t)blocks), dim3(256), 0, stream, a, entries);
+    else hipLaunchKernelGGL(remap_rows_kernel<uint32_t>, dim3((uint32_t)blocks), dim3(256), 0, stream, a, entries);
+    return hipGetLastError();
+}
+
+hipError_t launch_add_scores(const AddScoresArgs& a, hipStream_t stream) {
+    if (a.nq == 0 || a.nslots == 0) return hipSuccess;
+    if ((a.nslots % 8u) != 0 || (a.dst_offset % 8u) != 0 || (a.dst_stride % 8u) != 0) return hipErrorInvalidValue;
+    const uint64_t items = (uint64_t)a.nq * ((uint64_t)a.nslots * a.elem_bytes / 4u);
+    const uint64_t blocks = (items + 255u) / 256u;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(add_scores_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
 
 hipError_t launch_fetch_rows(const FetchArgs& a, bool idx64, hipStream_t stream) {
     if (a.npages == 0 || a.nq == 0 || a.entries == 0) return hipSuccess;

@@ -34,6 +34,10 @@ hipError_t launch_rank(const RankArgs& a, bool first, bool last, hipStream_t str
 
 // Row-selective out-of-core access (fetch_kernels.hip): one thread per (looked-up row, 16-byte piece).
 hipError_t launch_fetch_rows(const FetchArgs& a, bool idx64, hipStream_t stream);
+// Row-range chunks of a streamed sub-index (fetch_kernels.hip): rewrite the `entries` row indices of one sub-index for
+// the rows a chunk holds; add a chunk's partial scores to the score rows.
+hipError_t launch_remap_rows(const RemapArgs& a, uint64_t entries, bool idx64, hipStream_t stream);
+hipError_t launch_add_scores(const AddScoresArgs& a, hipStream_t stream);
 
 // Owner-routed hit exchange (xchg_kernels.hip): count == true -> records per owner into a.cursor, else scatter.
 hipError_t launch_bucket_hits(const BucketArgs& a, bool count, hipStream_t stream);

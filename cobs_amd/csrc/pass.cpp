@@ -258,6 +258,15 @@ void cobs_amd::set_run_state(cobs_gpu_batch* b, double threshold, size_t topk, b
         for (size_t q = 0; ok && q < b->nq; ++q) ok = total_hashes(b, q) > 1;
         b->topk_direct = ok;
     }
+    // A streamed sub-index cut into ROW ranges is counted range by range: K2 sees partial counts and cannot compare
+    // them with a threshold or pick a tile's best.  Such a handle keeps score rows; hits and limits come from them
+    // (K3 from rows, the ranking kernel, or the host filter -- the paths a hit-pool overflow takes anyway).
+    bool ranged = ix->peers_ranged;          // (comm.cpp: the ranks of a sharded search take the same exchange path)
+    for (const Part& p : ix->parts) ranged = ranged || p.has_row_ranges;
+    if (ranged) {
+        b->selected = false;
+        b->topk_direct = false;
+    }
     b->have_counts = want_counts || (!b->selected && !b->topk_direct);
 }
 
@@ -328,12 +337,12 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
         const uint64_t E = (b->work[f].h_blk_off[nq] + nq) * 8ull * p.meta.num_hashes;
         auto fetchable = [&](const Chunk& c) {
             const uint64_t gathered = (E + 1) * c.vp.size() * (uint64_t)c.pitch;
-            return ix->tune.row_fetch != 0 && p.streamed && p.file_dev && c.d_src && !p.synthetic &&
+            return ix->tune.row_fetch != 0 && p.streamed && p.file_dev && c.d_src && !p.synthetic && !c.row_range &&
                    gathered <= ix->stream.sbuf[0].cap && E < 0xFFFFFFF0ull &&
                    gathered * ix->tune.row_fetch_alpha <= c.bytes;
         };
         bool all = !p.fetch_groups.empty();
-        for (const Chunk& c : p.chunks) all = all && fetchable(c);
+        for (const Chunk& c : p.chunks) all = all && (c.row_range || fetchable(c));    // (row ranges: their sub-index is one unit of the groups)
         for (const Chunk& g : p.fetch_groups) all = all && fetchable(g);
         grouped[f] = all;
         for (const Chunk& c : all ? p.fetch_groups : p.chunks) units[f].push_back(&c);
@@ -403,8 +412,8 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
         }
         uint32_t tile_base = 0;
         bool fetch_ready = false;
-        if (p.streamed && p.file_dev && ix->tune.row_fetch != 0) {
-            // a row-selective chunk gets its own row-index table (one per stream buffer); sized before the
+        if (p.streamed && ((p.file_dev && ix->tune.row_fetch != 0) || p.has_row_ranges)) {
+            // a row-selective chunk (and a row-range chunk) gets its own row-index table (one per stream buffer); sized before the
             // chunk loop, when no scan of this handle is reading the old ones any more
             const size_t need = (size_t)b->work[f].table_entries * 4;
             for (int i = 0; i < 2; ++i) {
@@ -432,7 +441,7 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                 const uint64_t E = (b->work[f].h_blk_off[nq] + nq) * 8ull * p.meta.num_hashes;
                 const uint64_t gathered = (E + 1) * c.vp.size() * (uint64_t)c.pitch;
                 const bool fetch = grouped[f] ||
-                                   (ix->tune.row_fetch != 0 && p.file_dev && c.d_src && !p.synthetic &&
+                                   (ix->tune.row_fetch != 0 && p.file_dev && c.d_src && !p.synthetic && !c.row_range &&
                                     gathered <= sbufs.sbuf[buf].cap && E < 0xFFFFFFF0ull &&
                                     gathered * ix->tune.row_fetch_alpha <= c.bytes);
                 if (fetch) {
@@ -470,18 +479,42 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                 HIP_TRY(hipEventRecord(sbufs.copied[buf], sbufs.copy_stream));
                 HIP_TRY(hipStreamWaitEvent(st, sbufs.copied[buf], 0));
                 data = sbufs.sbuf[buf].p;
+                if (c.row_range && !grouped[f]) {
+                    // the buffer holds rows [row0, row0 + n) of the sub-index: this chunk's scan reads K1's indices
+                    // shifted into the range, every row outside it as the buffer's zero row
+                    RemapArgs ra;
+                    ra.table = b->work[f].table.p;
+                    ra.table2 = sbufs.table2[buf].p;
+                    ra.blk_off = b->work[f].blk_off;
+                    ra.row0 = c.pages[0].row0;
+                    ra.nrows = c.pages[0].sig;
+                    ra.nq = (uint32_t)nq;
+                    ra.tpage = c.pages[0].tpage;
+                    ra.table_npages = p.num_tpages();
+                    ra.num_hashes = (uint32_t)p.meta.num_hashes;
+                    HIP_TRY(launch_remap_rows(ra, (b->work[f].h_blk_off[nq] + nq) * 8ull * p.meta.num_hashes, p.idx64, st));
+                    table_dev = sbufs.table2[buf].p;
+                }
+            }
+            // a later row range of a sub-index: its partial scores go to a scratch matrix and are added to the rows
+            const bool partial = c.row_range && c.range_no > 0 && !grouped[f];
+            uint32_t part_slots = 0;
+            if (partial) {
+                part_slots = (uint32_t)(c.vp[0].ncols * 8);
+                HIP_TRY(b->counts_part.reserve((size_t)nq * part_slots * b->elem_bytes));
+                pages_dev = c.d_pages_acc;
             }
             ScanArgs sa;
             sa.blob = data;
             sa.pages = pages_dev;
             sa.table = table_dev;
             sa.blk_off = b->work[f].blk_off;
-            sa.counts = b->counts.p;
+            sa.counts = partial ? b->counts_part.p : b->counts.p;
             sa.thresholds = b->selected ? b->work[f].thr.p : nullptr;
             sa.hits = b->hits.p;
             sa.hit_count = reinterpret_cast<unsigned long long*>(b->flags.p + 2);
-            sa.counts_stride = ix->local_counts;
-            sa.counts_offset = p.local_offset;
+            sa.counts_stride = partial ? part_slots : ix->local_counts;
+            sa.counts_offset = partial ? 0 : p.local_offset;
             sa.hit_cap = b->hit_cap;
             sa.nq = (uint32_t)nq;
             sa.npages = (uint32_t)c.vp.size();
@@ -530,6 +563,17 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
             HIP_TRY(launch_scan(sa, ntiles, b->planes, nwaves, geom.multi_query, st));
             tile_base += ntiles;
             ++launches;
+            if (partial) {
+                AddScoresArgs aa;
+                aa.dst = b->counts.p;
+                aa.src = b->counts_part.p;
+                aa.dst_stride = ix->local_counts;
+                aa.dst_offset = p.local_offset + c.pages[0].slot0;
+                aa.nslots = part_slots;
+                aa.nq = (uint32_t)nq;
+                aa.elem_bytes = b->elem_bytes;
+                HIP_TRY(launch_add_scores(aa, st));
+            }
             if (p.streamed) {
                 HIP_TRY(hipEventRecord(sbufs.scanned[buf], st));
                 sbufs.used[buf] = true;

@@ -148,7 +148,8 @@ void layout_chunk(const Part& pt, Chunk& c, const Tuning& tune) {
         PageDev& pd = c.pages[i];
         const uint64_t file_slot = ((m.kind == IndexKind::Compact ? (uint64_t)v.fp * prb : 0) + v.col0) * 8;
         pd.base = off;
-        pd.sig = m.signature_sizes[v.fp];
+        pd.sig = v.nrows ? v.nrows : m.signature_sizes[v.fp];      // rows in the buffer (its zero row sits at index sig)
+        pd.row0 = v.nrows ? v.row0 : 0;
         pd.magic = ~0ull / pd.sig;
         pd.slot0 = (uint32_t)(file_slot - pt.slot_begin);
         pd.doc0 = (uint32_t)file_slot;
@@ -291,6 +292,7 @@ cobs_gpu_status chunk_part(Part& pt, uint64_t cap, const Tuning& tune) {
     const IndexMeta& m = pt.meta;
     pt.chunks.clear();
     pt.streamed = cap != 0;
+    pt.has_row_ranges = false;
     Chunk cur;
     uint64_t cur_bytes = 0;
     auto flush = [&]() {
@@ -312,12 +314,37 @@ cobs_gpu_status chunk_part(Part& pt, uint64_t cap, const Tuning& tune) {
             continue;
         }
         flush();
-        // a single slice exceeds a buffer: cut it by columns (all rows, fewer documents) -- into the FEWEST slices that
-        // fit, of about equal width.  A slice crosses PCIe as a 2-D copy of `width` bytes out of every row of the file,
-        // and what the link delivers falls with the width (MI355X, 1568-byte rows, profiles/r04_h2d_probe.txt: 56.2 GB/s
-        // whole rows, 55.1 at 1024 bytes, 53.6 at 640, 50.6 at 544, 43.0 at 288, 9.5 at 32): the widest slice a buffer
-        // holds plus a narrow remainder (round 3: 1536 + 32, 1024 + 544, 640 + 640 + 288 for the three largest
-        // sub-indexes of C3 under a 6 GB budget) spent 4 % of a pass on the remainders.
+        // A single slice exceeds a buffer.  One hash function: cut it by ROWS -- every chunk holds whole rows of a range
+        // [row0, row0 + n) and counts the terms whose row falls into it (the others read the chunk's zero row); counts
+        // are sums over terms, so the ranges' partial scores add up (pass.cpp).  Whole rows cross PCIe at 56.2 GB/s,
+        // column slices at 50-55 (below).  With several hash functions the H rows of a term are ANDed before they are
+        // counted and may lie in different ranges: columns.  (Procedural indexes regenerate chunks: columns.)
+        if (m.num_hashes == 1 && tune.row_ranges != 0 && !pt.synthetic) {
+            const uint64_t pitch = pitch_for(v.ncols, tune);
+            const uint64_t fit = cap / pitch > 1 ? (cap / 256 * 256) / pitch - 1 : 0;      // rows per buffer (+ the zero row)
+            if (fit >= 1024) {
+                const uint64_t nr = (sig + fit - 1) / fit;
+                const uint64_t per = (sig + nr - 1) / nr;
+                uint32_t no = 0;
+                for (uint64_t r0 = 0; r0 < sig; r0 += per, ++no) {
+                    VPage rv = v;
+                    rv.row0 = r0;
+                    rv.nrows = std::min<uint64_t>(per, sig - r0);
+                    cur.vp.push_back(rv);
+                    cur.row_range = true;
+                    cur.range_no = no;
+                    pt.has_row_ranges = true;
+                    flush();
+                }
+                continue;
+            }
+        }
+        // Cut it by columns (all rows, fewer documents) -- into the FEWEST slices that fit, of about equal width.  A slice
+        // crosses PCIe as a 2-D copy of `width` bytes out of every row of the file, and what the link delivers falls with
+        // the width (MI355X, 1568-byte rows, profiles/r04_h2d_probe.txt: 56.2 GB/s whole rows, 55.1 at 1024 bytes, 53.6 at
+        // 640, 50.6 at 544, 43.0 at 288, 9.5 at 32): the widest slice a buffer holds plus a narrow remainder (round 3:
+        // 1536 + 32, 1024 + 544, 640 + 640 + 288 for the three largest sub-indexes of C3 under a 6 GB budget) spent 4 % of
+        // a pass on the remainders.
         uint64_t wmax = cap / (sig + 1);
         wmax = wmax >= 128 ? wmax / 128 * 128 : wmax / 16 * 16;
         while (wmax >= 16 && slice_bytes(sig, wmax, tune) > cap) wmax -= 16;

@@ -28,6 +28,12 @@ cobs_gpu_status alloc_part(cobs_gpu_index* ix, Part& pt) {
     for (Chunk& c : pt.chunks) {
         HIP_TRY(hipMalloc((void**)&c.d_pages, sizeof(PageDev) * c.pages.size()));
         HIP_TRY(hipMemcpy(c.d_pages, c.pages.data(), sizeof(PageDev) * c.pages.size(), hipMemcpyHostToDevice));
+        if (c.row_range && c.range_no > 0) {     // its partial scores go to a scratch matrix of the slice's own width
+            std::vector<PageDev> acc = c.pages;
+            for (PageDev& pd : acc) pd.slot0 = 0;
+            HIP_TRY(hipMalloc((void**)&c.d_pages_acc, sizeof(PageDev) * acc.size()));
+            HIP_TRY(hipMemcpy(c.d_pages_acc, acc.data(), sizeof(PageDev) * acc.size(), hipMemcpyHostToDevice));
+        }
     }
     if (pt.chunks.empty()) return COBS_GPU_OK;
     HIP_TRY(hipMalloc((void**)&pt.d_tpages, sizeof(PageDev) * pt.tpages.size()));
@@ -158,7 +164,7 @@ cobs_gpu_status stream_chunk_in(cobs_gpu_index* ix, Part& pt, const Chunk& c, in
     for (size_t i = 0; i < c.vp.size(); ++i) {
         const VPage& v = c.vp[i];
         const PageDev& pd = c.pages[i];
-        const uint8_t* src = pt.file->data() + m.page_offset(v.fp);
+        const uint8_t* src = pt.file->data() + m.page_offset(v.fp) + v.row0 * prb;     // (row-range chunk: its first row)
         uint8_t* dst = dev + pd.base;
         if (pt.file_pinned) {
             HIP_TRY(hipMemcpy2DAsync(dst, c.pitch, src + v.col0, (size_t)prb, (size_t)v.ncols, (size_t)pd.sig,

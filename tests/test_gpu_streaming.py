@@ -228,3 +228,72 @@ def test_one_query_against_a_large_streamed_file_touches_only_its_rows(gpu_lib, 
         assert np.array_equal(b.counts_host(i), ix.counts(queries[i])), i
     got = s.search_hits(queries[:3], 0.0, 5)
     assert got == [[(f, d, sc) for (f, d, _n, sc) in oracle.search(ix, q, 0.0, 5)] for q in queries[:3]]
+
+
+@pytest.mark.parametrize("kind,no_pin", [("compact", "0"), ("compact", "1"), ("classic", "0")])
+def test_row_range_chunks(gpu_lib, oracle, tmp_path, monkeypatch, kind, no_pin):
+    """A streamed sub-index larger than a stream buffer, ONE hash function: cut by ROWS (whole rows cross PCIe at the
+    link's best rate; plan.cpp) -- each range's scan counts the terms whose row falls into it, later ranges add their
+    partial scores to the rows.  Counts, thresholds, limits, the all-documents ranking, 8- and 16-bit scores, the
+    hits-only entry point and the sharded search on a one-rank communicator equal the oracle's; with
+    COBS_GPU_ROW_RANGES=0 the same file is cut by columns and gives the same results."""
+    from cobs_amd.distributed import Comm
+    if no_pin == "1":
+        monkeypatch.setenv("COBS_GPU_NO_PIN", "1")
+    q_long = oracle.random_sequence(700, 41)
+    if kind == "compact":
+        ps = 96
+        D = 3 * 8 * ps - 5
+        path = cases.make_compact(cases.tmp(tmp_path, "rr.cobs_compact"), D, ps, [900, 20011, 1500], 1, 31, 1, 0.3, 11,
+                                  planted={0: 1.0, 8 * ps + 3: 0.95, 2 * 8 * ps - 1: 0.6, D - 1: 0.85}, query=q_long)
+        budget = 1200 * 1024                       # 600 KB buffers: the 20 011-row sub-index (2.5 MB at pitch 128) in 5 ranges
+    else:
+        D = 4000                                    # 500-byte rows at an odd file offset, pitch 512
+        path = cases.make_classic(cases.tmp(tmp_path, "rr.cobs_classic"), D, 9001, 1, 31, 1, 0.3, 12,
+                                  planted={5: 1.0, 3999: 0.9}, query=q_long)
+        budget = 2400 * 1024                       # 1.2 MB buffers: 4.6 MB of rows in 4 ranges
+    ix = oracle.Index.open(path)
+    queries = [q_long, q_long[:31], q_long[:300], q_long[200:431], q_long[5:]]
+    s = _compare(gpu_lib, oracle, path, budget, queries)     # (few queries: the engine fetches most chunks by rows)
+    s.set_tuning("row_fetch", 0)                             # every chunk streamed whole: the ranges are separate scans
+    b = gpu_lib.Batch(s)
+    b.set_queries(queries)
+    b.run(0.0)
+    b.sync()
+    assert b.stats()["scan_launches"] >= 4
+    for i, q in enumerate(queries):
+        assert np.array_equal(b.counts_host(i), ix.counts(q))
+    for t, lim in ((0.0, 0), (0.4, 0), (0.4, 3), (0.9, 0)):
+        assert s.search_hits(queries, t, lim) == [cases.oracle_results([ix], q, t, lim) for q in queries], (t, lim)
+    # short queries only: 8-bit scores through the same accumulation
+    short = [q_long[i:i + 60 + 7 * i] for i in range(9)]
+    b.set_queries(short)
+    b.run(0.0)
+    b.sync()
+    assert b.counts_device()[1] == 1
+    for i, q in enumerate(short):
+        assert np.array_equal(b.counts_host(i), ix.counts(q))
+    # the hits-only entry point keeps score rows on such a handle and answers from them
+    b.run_hits(0.4)
+    b.sync()
+    for i, q in enumerate(short):
+        assert b.hits_host(i) == cases.oracle_results([ix], q, 0.4, 0)
+    # every document ranked (the device ranking reads the accumulated rows), limits, thresholds in one call each
+    for t, lim in ((0.0, 0), (0.0, 7), (0.35, 0)):
+        got = s.search_hits(short, t, lim)
+        assert got == [cases.oracle_results([ix], q, t, lim) for q in short], (t, lim)
+    # a small batch fetches by rows: the ranges of a sub-index are one unit there
+    s.set_tuning("row_fetch", 1)
+    one = s.search_hits([q_long], 0.0, 5)
+    assert one == [cases.oracle_results([ix], q_long, 0.0, 5)]
+    # the sharded search over a one-rank communicator: a ranged rank keeps rows, the ranks agree on that
+    comm = Comm(Comm.unique_id(), 0, 1, device=0)
+    for t, lim in ((0.4, 0), (0.0, 3), (0.0, 0)):
+        got = s.sharded_search_hits(comm, short, t, lim)
+        assert got == [cases.oracle_results([ix], q, t, lim) for q in short], (t, lim)
+    comm.close()
+    del b, s
+    # the same file cut by columns
+    monkeypatch.setenv("COBS_GPU_ROW_RANGES", "0")
+    s2 = _compare(gpu_lib, oracle, path, budget, queries)
+    del s2
