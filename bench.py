@@ -703,8 +703,8 @@ def launch_plan(gpus, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--queries", type=int, default=10000, help="queries per batch (whole job)")
     ap.add_argument("--kmers", type=int, default=1000)
     ap.add_argument("--config", choices=["c3", "c2", "c4", "c5"], default="c3",

@@ -723,13 +723,15 @@ static cobs_gpu_status sharded_search_impl(cobs_gpu_index* ix, cobs_gpu_comm* c,
                 return fail(COBS_GPU_ERR_CAPACITY, "hit buffer too small; hit_offsets[nq] holds the needed size");
             }
         }
-        {   // Which exchange a pass takes depends on whether its scan selected hits itself (run_impl); a rank whose
-            // streamed shard is counted in row ranges cannot -- then no rank does: one agreement per call.
+        if (ix->ranged_agreed != c->serial) {
+            // Which exchange a pass takes depends on whether its scan selected hits itself (run_impl); a rank whose
+            // streamed shard is counted in row ranges cannot -- then no rank does: one agreement per communicator.
             uint32_t mine = 0, any = 0;
             for (const auto& p : ix->parts) mine |= p.has_row_ranges ? 1u : 0u;
             cobs_gpu_status as = agree(c, b, st, mine, &any);
             if (as != COBS_GPU_OK) return as;
             ix->peers_ranged = any != 0;
+            ix->ranged_agreed = c->serial;
         }
         size_t g0 = 0;
         do {
