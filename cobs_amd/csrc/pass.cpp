@@ -38,6 +38,14 @@ uint64_t total_hashes(const cobs_gpu_batch* b, size_t q) {
     return n;
 }
 
+// bytes a row-selective fetch of chunk `c` moves over PCIe: the gathered rows -- of a ROW-RANGE chunk only the share
+// of the sub-index's lookups that falls into its range (the gathered buffer still has a place for every entry)
+uint64_t fetched_bytes(const Part& p, const Chunk& c, uint64_t gathered) {
+    if (!c.row_range || c.vp.empty()) return gathered;
+    const uint64_t sig = p.meta.signature_sizes[c.vp[0].fp];
+    return (uint64_t)((long double)gathered * (long double)c.pages[0].sig / (long double)std::max<uint64_t>(sig, 1));
+}
+
 uint32_t threshold_for(double threshold, uint64_t terms) {
     // classic_search.cpp:446-448: std::ceil(threshold * T) in double
     const double v = std::ceil(threshold * (double)terms);
@@ -337,9 +345,9 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
         const uint64_t E = (b->work[f].h_blk_off[nq] + nq) * 8ull * p.meta.num_hashes;
         auto fetchable = [&](const Chunk& c) {
             const uint64_t gathered = (E + 1) * c.vp.size() * (uint64_t)c.pitch;
-            return ix->tune.row_fetch != 0 && p.streamed && p.file_dev && c.d_src && !p.synthetic && !c.row_range &&
+            return ix->tune.row_fetch != 0 && p.streamed && p.file_dev && c.d_src && !p.synthetic &&
                    gathered <= ix->stream.sbuf[0].cap && E < 0xFFFFFFF0ull &&
-                   gathered * ix->tune.row_fetch_alpha <= c.bytes;
+                   fetched_bytes(p, c, gathered) * ix->tune.row_fetch_alpha <= c.bytes;
         };
         bool all = !p.fetch_groups.empty();
         for (const Chunk& c : p.chunks) all = all && (c.row_range || fetchable(c));    // (row ranges: their sub-index is one unit of the groups)
@@ -426,7 +434,10 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
             const Chunk& c = *units[f][ci];
             const uint8_t* data = c.d_data;
             int buf = 0;
-            const PageDev* pages_dev = c.d_pages;
+            // a later row range of a sub-index: its partial scores go to a scratch matrix and are added to the rows
+            // (however the range's rows come in: streamed whole, or only the looked-up ones fetched)
+            const bool partial = c.row_range && c.range_no > 0;
+            const PageDev* pages_dev = partial ? c.d_pages_acc : c.d_pages;
             const void* table_dev = b->work[f].table.p;
             if (p.streamed) {
                 // double buffer shared by all streamed files: the next chunk goes to the buffer
@@ -441,9 +452,9 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                 const uint64_t E = (b->work[f].h_blk_off[nq] + nq) * 8ull * p.meta.num_hashes;
                 const uint64_t gathered = (E + 1) * c.vp.size() * (uint64_t)c.pitch;
                 const bool fetch = grouped[f] ||
-                                   (ix->tune.row_fetch != 0 && p.file_dev && c.d_src && !p.synthetic && !c.row_range &&
+                                   (ix->tune.row_fetch != 0 && p.file_dev && c.d_src && !p.synthetic &&
                                     gathered <= sbufs.sbuf[buf].cap && E < 0xFFFFFFF0ull &&
-                                    gathered * ix->tune.row_fetch_alpha <= c.bytes);
+                                    fetched_bytes(p, c, gathered) * ix->tune.row_fetch_alpha <= c.bytes);
                 if (fetch) {
                     if (!fetch_ready) {          // the fetch kernel reads K1's table: once per file and pass
                         HIP_TRY(hipEventRecord(sbufs.hashed, st));
@@ -455,7 +466,7 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                     fa.table = b->work[f].table.p;
                     fa.table2 = sbufs.table2[buf].p;
                     fa.blk_off = b->work[f].blk_off;
-                    fa.pages = c.d_pages;
+                    fa.pages = pages_dev;               // (a later row range: the page with slot0 = 0, see `partial`)
                     fa.pages2 = c.d_pages2[buf];
                     fa.page_src = c.d_src;
                     fa.dst = sbufs.sbuf[buf].p;
@@ -479,7 +490,7 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                 HIP_TRY(hipEventRecord(sbufs.copied[buf], sbufs.copy_stream));
                 HIP_TRY(hipStreamWaitEvent(st, sbufs.copied[buf], 0));
                 data = sbufs.sbuf[buf].p;
-                if (c.row_range && !grouped[f]) {
+                if (c.row_range && !fetch) {
                     // the buffer holds rows [row0, row0 + n) of the sub-index: this chunk's scan reads K1's indices
                     // shifted into the range, every row outside it as the buffer's zero row
                     RemapArgs ra;
@@ -496,13 +507,10 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                     table_dev = sbufs.table2[buf].p;
                 }
             }
-            // a later row range of a sub-index: its partial scores go to a scratch matrix and are added to the rows
-            const bool partial = c.row_range && c.range_no > 0 && !grouped[f];
             uint32_t part_slots = 0;
             if (partial) {
                 part_slots = (uint32_t)(c.vp[0].ncols * 8);
                 HIP_TRY(b->counts_part.reserve((size_t)nq * part_slots * b->elem_bytes));
-                pages_dev = c.d_pages_acc;
             }
             ScanArgs sa;
             sa.blob = data;
