@@ -470,7 +470,8 @@ def _row_sums(rows, weights, chunk=512):
     return a, b
 
 
-def verify_sharded(run, cfg, world, rank, backend, corrupt=False, seconds=20.0, exact_rows=16, checksum_rows=64):
+def verify_sharded(run, cfg, world, rank, backend, corrupt=False, seconds=20.0, exact_rows=16, checksum_rows=64,
+                   exchanged=True):
     """The N > 1 line proves itself.  After the timed region, on the rows of the LAST step:
     (a) EVERY row of the batch: each rank sums its local count slices, weighted by the GLOBAL slot of every count
         (plain sum and position-weighted sum), the partial sums of all ranks are added (one all-reduce of the checker,
@@ -514,7 +515,7 @@ def verify_sharded(run, cfg, world, rank, backend, corrupt=False, seconds=20.0, 
         # (a) expected sums of every row of the sub-batch from the shards' own slices
         pa, pb = _row_sums(run.local_rows(i), w_loc)
         part = torch.stack([pa, pb])
-        if world > 1:
+        if world > 1 and exchanged:
             if backend != "nccl":
                 part = part.cpu()
             dist.all_reduce(part, op=dist.ReduceOp.SUM)
@@ -1007,6 +1008,15 @@ def main():
         del run, batch, s
         torch.cuda.empty_cache()
         out["other_forms"] = side_measurements(args, cfg, queries, world, rank, dev, comm)
+    if world > 1 and not shard_index:
+        # index replicated, one batch per rank: every rank checks a sample of ITS rows against the oracle
+        class _Own:
+            pass
+        own = _Own()
+        own.s, own.sub, own.sub_queries = s, [batch], [queries]
+        own.owned_rows = lambda i: (0, len(queries), batch.counts_tensor())
+        own.local_rows = lambda i: batch.counts_tensor()
+        out.update(verify_sharded(own, cfg, world, rank, args.dist_backend, exchanged=False))
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not budget and not shard_index:
         out["end_to_end"] = end_to_end(s, batch, queries)
         out["cpu_baseline"] = cpu_baseline(s, cfg, queries, batch=batch)

@@ -60,10 +60,16 @@ typedef struct cobs_gpu_options {
     uint32_t shard_mode;
     /* 0 = stage the whole (shard of the) index into HBM.  Otherwise the index may
      * use at most this many bytes of HBM: files that do not fit are cut into chunks
-     * (whole sub-indexes, or column ranges of one sub-index) that are streamed from
-     * the mapped file through two device buffers with hipMemcpyAsync, one scan pass
+     * (whole sub-indexes, or pieces of one sub-index larger than a buffer: row ranges
+     * when the file has one hash function, column ranges otherwise) that are streamed
+     * from the mapped file through two device buffers with hipMemcpyAsync, one scan pass
      * per chunk overlapping the next chunk's copy (the successor of the reference's
-     * mmap / AIO back-ends, util/query.cpp:38-88, compact_index/aio_search_file.cpp). */
+     * mmap / AIO back-ends, util/query.cpp:38-88, compact_index/aio_search_file.cpp).
+     * A handle with row-range chunks counts such a sub-index range by range (partial
+     * scores are added up), so its passes always keep score rows: the hits-only and
+     * top-k-only runs and every search call give the same results, selected from the
+     * rows; cobs_gpu_batch_exchange_hits / _hits_owned are not available on it
+     * (cobs_gpu_sharded_search_batch takes the row exchange by itself). */
     uint64_t hbm_budget_bytes;
 } cobs_gpu_options;
 

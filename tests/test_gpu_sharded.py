@@ -214,3 +214,12 @@ def test_owner_routed_hits_from_real_shards(gpu_lib, oracle, tmp_path):
                     buckets[j][peer.send_offset // 16:(peer.send_offset + peer.send_bytes) // 16]
             q0, q1 = nq * i // N, nq * (i + 1) // N
             assert sorted(map(tuple, got.tolist())) == sorted(h for qi in range(q0, q1) for h in want[qi]), (N, i)
+
+
+def test_bench_replicated_index_line_checks_its_rows(gpu_lib):
+    """--shard-mode queries (index replicated, one batch per rank, no collective; weak scaling): every rank checks a
+    sample of its own rows against the oracle and the flags are ANDed"""
+    r, j, out = _bench(["--gpus", "2", "--dist-backend", "gloo", "--shard-mode", "queries"] + SMALL)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and "rccl_ranks" not in j
+    assert j["bit_exact_vs_oracle"] is True and j["checked_per_rank_at_least"]["rows_exact_vs_oracle"] >= 16
