@@ -72,6 +72,7 @@ Tuning Tuning::from_env() {
     if (const char* e = getenv("COBS_GPU_DEVICE_RANK")) t.device_rank = atoi(e) != 0;
     if (const char* e = getenv("COBS_GPU_TRACE")) t.trace = atoi(e) != 0;
     if (const char* e = getenv("COBS_GPU_ROW_RANGES")) t.row_ranges = atoi(e) != 0;
+    if (const char* e = getenv("COBS_GPU_ROW_RANGE_MIN")) t.row_range_min = (uint32_t)std::max(1, atoi(e));
     if (const char* e = getenv("COBS_GPU_EXP")) t.exp = (uint32_t)std::strtoul(e, nullptr, 0);      // A/B variants, also under the test suite
     return t;
 }

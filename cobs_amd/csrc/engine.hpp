@@ -105,6 +105,7 @@ struct Tuning {
     int tile_topk = 1;          // top-k passes without score rows select per tile in K2 (0: score rows + K3, A/B)
     int device_rank = 1;        // whole score rows are ranked on the device (0: by host threads, A/B and fallback)
     uint32_t rank_window_kib = 16u << 10;   // device-ranked records cross PCIe in pieces of this size (KiB)
+    uint32_t row_range_min = 1024;  // ... unless a buffer holds fewer rows than this (then by columns); COBS_GPU_ROW_RANGE_MIN, tests
     int row_ranges = 1;         // a streamed sub-index larger than a stream buffer is cut by ROWS (H = 1; 0: by columns, A/B and fallback)
     int rank_pack = 1;          // device-ranked records cross PCIe as one u32 where slot and score fit (0: always 8-byte pairs, A/B)
     int hash_stream = 0;        // K1 of a device-resident batch runs on the batch's own stream, K2 waits for it by event: the hashing
