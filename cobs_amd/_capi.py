@@ -1,4 +1,4 @@
-"""ctypes binding of libcobs_gpu.so (the C ABI declared in include/cobs_gpu.h).
+"""ctypes binding of libcobs_gpu.so (the C ABI declared in include/cobs_gpu.h, cobs_gpu_batch.h, cobs_gpu_diag.h, cobs_gpu_construct.h).
 
 The library is the product; this module only declares its entry points.  It
 fails loudly if the shared object is missing -- there is no Python or CPU
@@ -78,7 +78,7 @@ class Synth(C.Structure):
                 ("signature_sizes", C.POINTER(C.c_uint64))]
 
 
-# name -> (restype, argtypes): every symbol include/cobs_gpu.h declares
+# name -> (restype, argtypes): every symbol the four headers under include/ declare
 _vp, _sz, _u32, _u64, _cp, _dbl, _int = (C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64,
                                         C.c_char_p, C.c_double, C.c_int)
 _pu64 = C.POINTER(C.c_uint64)

@@ -21,6 +21,7 @@
 #include <string>
 #include <vector>
 
+#include "../../include/cobs_gpu_batch.h"          // cobs_gpu_write_synthetic (the generator sub-tool)
 #include "../../include/cobs_gpu_construct.h"
 #include "../../include/cobs_gpu_search.hpp"
 

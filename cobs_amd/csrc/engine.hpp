@@ -1,6 +1,6 @@
 // cobs_amd/csrc/engine.hpp -- internal types of libcobs_gpu.so shared by engine.cpp (index
 // staging, batches, the search API), comm.cpp (RCCL exchange of the sharded layout) and
-// build.cpp.  Nothing here is part of the C ABI (include/cobs_gpu.h).
+// build.cpp.  Nothing here is part of the C ABI (include/cobs_gpu.h, cobs_gpu_batch.h, cobs_gpu_diag.h).
 #pragma once
 #include <hip/hip_runtime_api.h>
 
@@ -12,7 +12,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/cobs_gpu.h"
+#include "../../include/cobs_gpu_diag.h"      // (includes cobs_gpu_batch.h and cobs_gpu.h: the whole C ABI)
 #include "device_types.hpp"
 #include "index_file.hpp"
 #include "kernels.hpp"

@@ -2,7 +2,7 @@
 
 The exchange itself is native: libcobs_gpu.so calls RCCL (ncclAllGather / grouped
 ncclSend + ncclRecv over xGMI) through the cobs_gpu_comm_* / cobs_gpu_batch_exchange_* entry
-points of include/cobs_gpu.h (cobs_amd/csrc/comm.cpp); `Comm` below binds them.
+points of include/cobs_gpu_batch.h (cobs_amd/csrc/comm.cpp); `Comm` below binds them.
 torch.distributed is only the LAUNCHER there: it hands rank 0's unique id to the other
 ranks.  The torch-level functions further down (all_gather_counts, assemble_counts,
 merge_hits) are the same exchange written against torch.distributed; they run on any

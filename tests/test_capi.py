@@ -10,7 +10,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols(headers=("cobs_gpu.h", "cobs_gpu_construct.h")):
+def _declared_symbols(headers=("cobs_gpu.h", "cobs_gpu_batch.h", "cobs_gpu_diag.h", "cobs_gpu_construct.h")):
     names = set()
     for h in headers:
         text = open(os.path.join(ROOT, "include", h)).read()
@@ -29,10 +29,14 @@ def test_library_exports_every_declared_symbol():
         assert n in _capi.SYMBOLS, "cobs_amd/_capi.py does not bind " + n
     assert sorted(_capi.SYMBOLS) == names
     assert lib.cobs_gpu_abi_version() == 2
-    # the query path's header stands alone: construction and document lists live in cobs_gpu_construct.h
-    query_only = _declared_symbols(("cobs_gpu.h",))
+    # the query path's headers stand alone: construction and document lists live in cobs_gpu_construct.h
+    query_only = _declared_symbols(("cobs_gpu.h", "cobs_gpu_batch.h", "cobs_gpu_diag.h"))
     assert not [n for n in query_only if "doclist" in n or "_build_" in n or "combine" in n or "construct" in n]
     assert len(query_only) < len(names)
+    # the drop-in boundary itself is thin: open / geometry / search / timers (+ the device list); batches, the RCCL
+    # exchange and the procedural index are cobs_gpu_batch.h, planners and diagnostics cobs_gpu_diag.h
+    boundary = _declared_symbols(("cobs_gpu.h",))
+    assert len(boundary) <= 20 and not [n for n in boundary if "_batch_" in n or "_comm_" in n or "_plan" in n or "read_row" in n]
 
 
 def test_struct_layouts_match_header():
@@ -143,6 +147,11 @@ def test_header_is_plain_c_and_cpp(tmp_path):
                  'return (int)o.struct_size == 0; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc,
                            "-fsyntax-only", str(c)])
+    for hdr, probe in (("cobs_gpu_batch.h", "cobs_gpu_synth d; d.num_docs = 1; return (int)d.num_docs == 0;"),
+                       ("cobs_gpu_diag.h", "cobs_gpu_xfer x; x.peer = 1; return (int)x.peer == 0;")):
+        cx = tmp_path / ("t_" + hdr.replace(".h", ".c"))
+        cx.write_text('#include "%s"\nint main(void) { %s }\n' % (hdr, probe))
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(cx)])
     c2 = tmp_path / "t2.c"
     c2.write_text('#include "cobs_gpu_construct.h"\nint main(void) { cobs_gpu_build_params p; p.struct_size = sizeof p; '
                   'return (int)p.struct_size == 0; }\n')
