@@ -8,11 +8,16 @@
 // crosses, window w+1 is being ordered and the host expands window w-1 from the pinned landing buffer into the
 // cobs_gpu_hit records (file, document, score) of the caller's (pageable) array.
 #include <emmintrin.h>
+#include <pthread.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <condition_variable>
+#include <cctype>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <string>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -26,10 +31,51 @@ namespace cobs_amd {
 // Host threads that stay around for the life of the process (one pool of up to 31, shared by every handle; a
 // window's expansion holds it for a fraction of a millisecond): expanding a window of records is ~1 ms of work,
 // spawning the threads per window would cost as much again.
+// CPUs of the NUMA node the device's PCIe root sits on (sysfs), empty if unknown: the pool's threads read the pinned
+// landing buffers the DMA engine filled -- they live next to the GPU -- and stream the results out
+static std::vector<int> cpus_near_device(int device) {
+    std::vector<int> cpus;
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, sizeof bdf, device) != hipSuccess) { (void)hipGetLastError(); return cpus; }
+    for (char& ch : bdf) ch = (char)std::tolower((unsigned char)ch);
+    int node = -1;
+    if (FILE* f = std::fopen((std::string("/sys/bus/pci/devices/") + bdf + "/numa_node").c_str(), "r")) {
+        if (std::fscanf(f, "%d", &node) != 1) node = -1;
+        std::fclose(f);
+    }
+    if (node < 0) return cpus;
+    char list[4096] = {0};
+    if (FILE* f = std::fopen(("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist").c_str(), "r")) {
+        if (!std::fgets(list, sizeof list, f)) list[0] = 0;
+        std::fclose(f);
+    }
+    for (const char* p = list; *p && *p != '\n';) {
+        char* e = nullptr;
+        const long a = std::strtol(p, &e, 10);
+        if (e == p) break;
+        long b = a;
+        p = e;
+        if (*p == '-') { b = std::strtol(p + 1, &e, 10); p = e; }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) cpus.push_back((int)c);
+        if (*p == ',') ++p;
+    }
+    return cpus;
+}
+
 class ExpandPool {
 public:
-    explicit ExpandPool(unsigned n) {
+    explicit ExpandPool(unsigned n, const std::vector<int>& cpus) {
         for (unsigned i = 0; i < n; ++i) threads_.emplace_back([this]() { loop(); });
+        if (!cpus.empty()) {             // (the process's own affinity mask still applies: the intersection, if any)
+            cpu_set_t allowed, want;
+            CPU_ZERO(&want);
+            if (sched_getaffinity(0, sizeof allowed, &allowed) == 0) {
+                int n_ok = 0;
+                for (int c : cpus) if (CPU_ISSET(c, &allowed)) { CPU_SET(c, &want); ++n_ok; }
+                if (n_ok >= 2)
+                    for (auto& t : threads_) (void)pthread_setaffinity_np(t.native_handle(), sizeof want, &want);
+            }
+        }
     }
     ~ExpandPool() {
         { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
@@ -89,8 +135,9 @@ private:
     bool stop_ = false;
 };
 
-ExpandPool* expand_pool() {
-    static ExpandPool pool(std::min(31u, std::max(2u, std::thread::hardware_concurrency()) - 1u));
+ExpandPool* expand_pool(int device) {
+    // (one pool per process, placed by the first device that ranks: a process drives one GPU, or the GPUs of one node)
+    static ExpandPool pool(std::min(31u, std::max(2u, std::thread::hardware_concurrency()) - 1u), cpus_near_device(device));
     return &pool;
 }
 
@@ -384,7 +431,7 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
         for (size_t i = 0; i < wn.n; ++i) full = full && cnt[i] == stride;
         if (full && !*overflow && wn.n * stride <= cap - *used) {
             // every query of the piece yields `stride` results (the default call): one block
-            expand_records(expand_pool(), hits + *used, recs, wn.n * stride, pack_bits, parts);
+            expand_records(expand_pool(ix->device), hits + *used, recs, wn.n * stride, pack_bits, parts);
             for (size_t i = 0; i < wn.n; ++i) {
                 *used += stride;
                 hit_offsets[wn.q0 + i + 1] = *used;
@@ -395,7 +442,7 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
         for (size_t i = 0; i < wn.n; ++i) {
             const size_t n = cnt[i];
             if (!*overflow && n <= cap - *used)
-                expand_records(expand_pool(), hits + *used, recs + i * stride * rec, n, pack_bits, parts);
+                expand_records(expand_pool(ix->device), hits + *used, recs + i * stride * rec, n, pack_bits, parts);
             else
                 *overflow = true;
             *used += n;

@@ -36,6 +36,10 @@ def main():
         cfg = {"kind": "compact", "num_docs": 1000000, "page_size": 512,
                "signature_sizes": [int(100000 * r ** i) for i in range(245)]}
         nq, kmers = 6000, 1000
+    elif shape in ("big4", "small4"):     # only large (uncacheable tile columns) / only small sub-indexes of the C3 kind
+        rows = 4000000 if shape == "big4" else 300000
+        cfg = {"kind": "compact", "num_docs": 4 * 12544, "page_size": 1568, "signature_sizes": [rows] * 4}
+        nq, kmers = 10000, 1000
     elif shape == "ps128":
         r = 16 ** (1.0 / 97)
         cfg = {"kind": "compact", "num_docs": 100000, "page_size": 128,

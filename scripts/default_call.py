@@ -17,6 +17,10 @@ import cobs_amd  # noqa: E402
 
 def main():
     nq = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    if os.environ.get("BIND_NUMA"):          # caller (and its result array) on the GPU's NUMA node
+        import torch  # noqa: F401
+        n = bench.gpu_numa_node(0)
+        print("GPU on NUMA node %s: process bound to %d of its CPUs" % (n, bench.bind_to_numa_node(n)))
     cfg = bench.c3_config()
     s = cobs_amd.Search.synthetic(cfg["kind"], cfg["signature_sizes"], cfg["num_docs"], page_size=cfg["page_size"], seed=1)
     queries = bench.make_queries(nq, 1000)
