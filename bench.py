@@ -854,12 +854,16 @@ def main():
             else:
                 batch.run(args.threshold, 0)
 
+    stream_mark = {}
+
     def drop_warmup_events():
         if run is not None:
             run.drop_warmup_events()
         else:
             batch.sync()
             batch.kernel_ms()
+        if budget:
+            stream_mark["t0"] = s.stream_traffic()      # what the warm-up asked of PCIe is not the timed steps'
 
     dt = timed(step, args.steps, args.warmup, world, args.dist_backend, drop_warmup_events)
     received, xchg_ms = 0, 0.0
@@ -990,13 +994,12 @@ def main():
     if budget:
         info = s.info(0)
         index_bytes = sum(cfg["signature_sizes"]) * (cfg["page_size"] or (cfg["num_docs"] + 7) // 8)
-        fetched, whole = s.stream_counters()
-        # what crossed PCIe per step: whole chunks (the file's share of this rank) or, for chunks brought in
-        # row by row, the looked-up rows
-        share = index_bytes / max(world if shard_index else 1, 1)
-        looked = args.queries * (args.kmers + 7) // 8 * 8 * args.num_hashes * (cfg["page_size"] or (cfg["num_docs"] + 7) // 8) \
-            * (len(cfg["signature_sizes"]) if cfg["kind"] == "compact" else 1) / max(world if shard_index else 1, 1)
-        moved = share if fetched == 0 else (looked if whole == 0 else None)
+        # what the timed steps asked of PCIe on this rank (the library's own accounting, cobs_gpu_stream_counters): the
+        # rows of the chunks copied whole + the looked-up rows of the chunks fetched row by row
+        t0 = stream_mark.get("t0", (0, 0, 0, 0))
+        t1 = s.stream_traffic()
+        fetched, whole = t1[0] - t0[0], t1[1] - t0[1]
+        moved = ((t1[2] - t0[2]) + (t1[3] - t0[3])) / max(args.steps, 1)
         pcie = round(moved / (dt / args.steps) / 1e9, 2) if moved else None
         scan_roof = dict(out["roofline"])
         # an out-of-core step is bound by the link the index crosses, not by HBM
@@ -1009,13 +1012,14 @@ def main():
         out["streaming"] = {"hbm_budget_bytes": budget, "index_bytes": index_bytes, "file": path,
                             "gpu_numa_node": numa_node, "host_cpus_bound_to_that_node": numa_cpus,
                             "scan_launches_per_step": nlaunch, "chunks_fetched_by_rows": fetched, "chunks_copied_whole": whole,
-                            "pcie_GBps_rank0": pcie}
+                            "pcie_bytes_per_step_rank0": int(moved), "pcie_GBps_rank0": pcie}
     if shard_index and args.extras and not args.no_extras:
         del run, batch, s
         torch.cuda.empty_cache()
         out["other_forms"] = side_measurements(args, cfg, queries, world, rank, dev, comm)
-    if world > 1 and not shard_index:
-        # index replicated, one batch per rank: every rank checks a sample of ITS rows against the oracle
+    if (world > 1 and not shard_index) or (world == 1 and budget and not shard_index and args.threshold <= 0 and not args.num_results):
+        # index replicated, one batch per rank (or one GPU streaming a file under a budget: no cpu_baseline leg there):
+        # every rank checks a sample of ITS rows against the oracle
         class _Own:
             pass
         own = _Own()

@@ -198,6 +198,7 @@ struct StreamBufs {
     DevBuf<uint8_t> table2[2];
     hipEvent_t hashed = nullptr;
     uint64_t fetched_chunks = 0, streamed_chunks = 0;   // diagnostics: how the chunks of all passes were brought in
+    uint64_t fetched_bytes = 0, streamed_bytes = 0;     // ... and what that asked of PCIe: looked-up rows x pitch / the chunks' rows
     size_t stage_need = 0;
     uint64_t seq = 0;             // chunks streamed so far: chunk goes to buffer seq % 2
     ~StreamBufs();

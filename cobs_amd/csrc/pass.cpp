@@ -482,10 +482,12 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                     pages_dev = c.d_pages2[buf];
                     table_dev = sbufs.table2[buf].p;
                     ++sbufs.fetched_chunks;
+                    sbufs.fetched_bytes += fetched_bytes(p, c, gathered);
                 } else {
                     cobs_gpu_status cs = stream_chunk_in(ix, p, c, buf);
                     if (cs != COBS_GPU_OK) return cs;
                     ++sbufs.streamed_chunks;
+                    sbufs.streamed_bytes += c.stage_bytes;
                 }
                 HIP_TRY(hipEventRecord(sbufs.copied[buf], sbufs.copy_stream));
                 HIP_TRY(hipStreamWaitEvent(st, sbufs.copied[buf], 0));
