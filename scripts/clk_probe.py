@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""scripts/clk_probe.py -- clocks, package power and temperatures (rocm-smi, polled from a thread) next to the scan time
+of the headline shape, 2 s idle and then 8 s of back-to-back launches: the C3 scan runs with the package at its power
+limit (~1.2 kW) and sclk pulled below its 2.4 GHz maximum."""
 import os, sys, time, subprocess, threading, re
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import bench, cobs_amd

@@ -22,6 +22,7 @@ python scripts/default_call.py 256 > "$OUT/default_call.txt" 2>&1
 python scripts/latency.py > "$OUT/latency.txt" 2>&1
 python scripts/row_fetch_bench.py 1.0 6 > "$OUT/c5_selective.txt" 2>&1
 scripts/probes/h2d_probe 4 > "$OUT/h2d_probe.txt" 2>&1
+python scripts/clk_probe.py > "$OUT/clk_probe.txt" 2>&1
 bash scripts/profile_shapes.sh "$TAG" > "$OUT/profile_shapes.log" 2>&1
 tail -15 "$OUT/profile_shapes.log"
 ls "$OUT"
