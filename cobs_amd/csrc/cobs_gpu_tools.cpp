@@ -1,6 +1,7 @@
 // cobs_amd/csrc/cobs_gpu_tools.cpp -- the construction-side sub-tools of the reference's `cobs`
 // program on top of libcobs_gpu.so, with their flags and output (reference src/cobs.cpp):
 //
+//   cobs_gpu_query doc-list PATH / doc-dump PATH (host only)                       (:75-161)
 //   cobs_gpu_query classic-construct INPUT OUT.cobs_classic [flags]               (:163-244)
 //   cobs_gpu_query compact-construct INPUT OUT.cobs_compact [flags] [-p PAGE]     (:294-380)
 //   cobs_gpu_query classic-combine IN_DIR OUT.cobs_classic                        (:1044-1060)
@@ -126,6 +127,66 @@ int construct(int argc, char** argv, bool compact) {
     return 0;
 }
 
+// canonicalize_kmer of the reference (cobs/util/query.cpp:143-199) for `doc-dump`: the first strict difference between
+// the forward base and the complement of the mirrored base among the first k/2 positions decides (forward smaller or
+// no difference: the k-mer as it is; else its reverse complement); a character that is not A, C, G or T maps to 0 and
+// makes the k-mer invalid.  -> false if the k-mer holds such a character
+bool canonicalize_kmer(const char* in, char* out, size_t k) {
+    auto fwd = [](char c) -> char { return (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? c : 0; };
+    auto rev = [](char c) -> char { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 0; };
+    bool good = true, reverse = false;
+    for (size_t i = 0; i < k / 2; ++i) {
+        const char f = fwd(in[i]), r = rev(in[k - 1 - i]);
+        if (f != r) { reverse = r < f; break; }
+    }
+    for (size_t i = 0; i < k; ++i) {
+        const char c = reverse ? rev(in[k - 1 - i]) : fwd(in[i]);
+        good = good && c != 0;
+        out[i] = c;
+    }
+    return good;
+}
+
+// `cobs doc-list PATH [--file-type T] [-k K]` and `cobs doc-dump PATH [-k K] [--no-canonicalize] [--file-type T]`
+// (reference src/cobs.cpp:75-161): host-only views of a document list
+int doc_tool(int argc, char** argv, bool dump) {
+    std::string path, file_type = "any";
+    unsigned term_size = 31;
+    bool no_canonicalize = false;
+    for (int i = 0; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a == "--file-type" && i + 1 < argc) file_type = argv[++i];
+        else if ((a == "-k" || a == "--term-size") && i + 1 < argc) term_size = (unsigned)std::strtoul(argv[++i], nullptr, 10);
+        else if (dump && a == "--no-canonicalize") no_canonicalize = true;
+        else if (!a.empty() && a[0] == '-' && a.size() > 1) { std::fprintf(stderr, "unknown flag %s\n", a.c_str()); return 1; }
+        else path = a;
+    }
+    if (path.empty() || term_size == 0) {
+        std::fprintf(stderr, "usage: cobs_gpu_query %s PATH [-k K] [--file-type T]%s\n", dump ? "doc-dump" : "doc-list",
+                     dump ? " [--no-canonicalize]" : "");
+        return 1;
+    }
+    cobs_gpu::DocumentList filelist(path, cobs_gpu::StringToFileType(file_type));
+    if (!dump) {
+        print_document_list(filelist, term_size);
+        return 0;
+    }
+    std::cerr << "Found " << filelist.size() << " documents." << std::endl;
+    std::vector<char> kmer(term_size);
+    for (size_t i = 0; i < filelist.size(); ++i) {
+        const cobs_gpu::DocumentEntry d = filelist[i];
+        std::cerr << "document[" << i << "] : " << d.path_ << " : " << d.name_ << std::endl;
+        d.process_terms(term_size, [&](const char* t) {
+            if (no_canonicalize) { std::cout.write(t, term_size) << '\n'; return; }
+            if (!canonicalize_kmer(t, kmer.data(), term_size)) std::cout << "Invalid DNA base pair: " << std::string(t, term_size) << std::endl;
+            else std::cout.write(kmer.data(), term_size) << '\n';
+        });
+        std::cout.flush();
+        std::cerr << "document[" << i << "] : " << d.num_terms(term_size) << " terms." << std::endl;
+    }
+    return 0;
+}
+
 }  // namespace
 
 // -> -1 if argv[1] is not one of the sub-tools, else the exit code
@@ -144,6 +205,8 @@ int cobs_gpu_tools_main(int argc, char** argv) {
 static int tools(int argc, char** argv) {
     if (argc < 2) return -1;
     const std::string tool = argv[1];
+    if (tool == "doc-list") return doc_tool(argc - 2, argv + 2, false);
+    if (tool == "doc-dump") return doc_tool(argc - 2, argv + 2, true);
     if (tool == "classic-construct") return construct(argc - 2, argv + 2, false);
     if (tool == "compact-construct") return construct(argc - 2, argv + 2, true);
     if (tool == "classic-combine" || tool == "compact-construct-combine") {

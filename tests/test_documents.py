@@ -321,3 +321,42 @@ def test_cpp_construction_mirror(docdir, tmp_path):
     assert lines[2 + len(ents):2 + len(ents) + 3] == ["fastq %s %d" % (e.name, e.size) for e in fq]
     assert "Unknown file type nonsense" in lines[-2]
     assert lines[-1] == "refused Error: COBS index file must end with .cobs_classic"
+
+
+def test_doc_list_and_doc_dump_sub_tools(oracle, golden_dir):
+    """`cobs doc-list` / `cobs doc-dump` (reference src/cobs.cpp:75-161; host-only views of a document list): the list
+    lines of print_document_list, and every document's terms -- canonical k-mers as canonicalize_kmer writes them
+    (cobs/util/query.cpp:143-199), "Invalid DNA base pair: ..." for a term with a character that is not A/C/G/T --
+    against the checker's readers and its canonicalize_kmer"""
+    import subprocess
+    from oracle import documents as OD
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cobs_amd", "cobs_gpu_query")
+    assert os.path.exists(tool), "build cobs_amd/cobs_gpu_query first (make -C cobs_amd/csrc)"
+
+    def _run(*args):
+        return subprocess.run([tool] + list(args), capture_output=True, text=True, timeout=300)
+    fasta = os.path.join(golden_dir, "fasta")
+    r = _run("doc-list", fasta, "-k", "31")
+    assert r.returncode == 0, r.stderr
+    out = r.stdout.splitlines()
+    assert out[0] == "--- document list (7 entries) ---" and out[-5].startswith("documents: 7")
+    entries = OD.document_list(fasta)
+    assert [ln.split(" : ")[-1] for ln in out[1:8]] == [e.name for e in entries]
+    assert [int(ln.split(" 31-mers ")[1].split(" : ")[0]) for ln in out[1:8]] == [e.num_terms(31) for e in entries]
+    for k, flags in ((31, []), (15, []), (20, ["--no-canonicalize"])):
+        r = _run("doc-dump", fasta, "-k", str(k), *flags)
+        assert r.returncode == 0, r.stderr
+        want = []
+        for e in entries:
+            for t in e.terms(k):
+                if flags:
+                    want.append(t.decode("latin-1"))
+                    continue
+                canon, good = oracle.canonicalize_kmer(bytes(t))
+                want.append(canon.decode("latin-1") if good else "Invalid DNA base pair: " + t.decode("latin-1"))
+        assert r.stdout.splitlines() == want, k
+        assert "Found 7 documents." in r.stderr and ("document[6] : %d terms." % entries[6].num_terms(k)) in r.stderr
+    # a text document with characters outside ACGT: those terms are reported, not printed
+    text = os.path.join(golden_dir, "documents", "text")
+    r = _run("doc-dump", text, "-k", "7")
+    assert r.returncode == 0 and "Invalid DNA base pair: " in r.stdout

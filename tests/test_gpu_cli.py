@@ -180,3 +180,4 @@ def test_construction_sub_tools(gpu_lib, oracle, golden_dir, tmp_path):
     r = _run("query", "-i", pc, "-t", "0", Q50)
     want = "".join("%s\t%d\n" % (n, s) for (_, _, n, s) in oracle.search(oracle.Index.open(pc), Q50.encode(), 0.0))
     assert r.returncode == 0 and r.stdout == want
+
