@@ -741,3 +741,52 @@ def test_default_call_in_batches_is_ranked_by_host_threads(gpu_lib, oracle, tmp_
         part = sh.search_hits(queries, 0.0, 0)
         for g, full in zip(part, got):
             assert g == [h for h in full if lim[h[0]][0] <= h[1] < lim[h[0]][1]]
+
+
+def test_hash_stream_pipelines_batches_without_changing_results(gpu_lib, oracle, tmp_path):
+    """tuning key hash_stream: K1 of a device-resident batch runs on the batch's own stream, K2 on the caller's, tied by
+    one event (the overlapped multi-GPU flow of bench.py).  Two files (K1 per file, the event re-recorded), three
+    batches run back to back several times on one stream without a sync in between (the next run's K1 must wait for
+    the previous K2 of the SAME batch only), thresholds and top-k included: every result equals the oracle's and the
+    unpipelined run's."""
+    import torch
+    q = oracle.random_sequence(600, 5)
+    pa = cases.make_compact(cases.tmp(tmp_path, "h.cobs_compact"), 3 * 8 * 40 - 3, 40, [811, 1201, 977], 1, 31, 1, 0.3, 21,
+                            planted={0: 1.0, 500: 0.8}, query=q)
+    pb = cases.make_classic(cases.tmp(tmp_path, "h.cobs_classic"), 777, 1511, 2, 31, 1, 0.3, 22, planted={7: 0.9}, query=q)
+    ixs = [oracle.Index.open(pa), oracle.Index.open(pb)]
+    s = gpu_lib.Search([pa, pb])
+    sets = [[q, q[:31], q[10:300]], [q[100:400], q[5:]], [q[:64], q[3:90], q[7:500], q[:33]]]
+    want = [[np.concatenate([ix.counts(x) for ix in ixs]) for x in qs] for qs in sets]
+    s.set_tuning("hash_stream", 1)
+    batches = [gpu_lib.Batch(s) for _ in sets]
+    for b, qs in zip(batches, sets):
+        b.set_queries(qs)
+    st = torch.cuda.Stream()
+    for rnd in range(4):
+        for b in batches:                       # no sync between the runs of different batches, nor between rounds
+            b.run(0.0, st.cuda_stream)
+    for b, qs, w in zip(batches, sets, want):
+        b.sync(st.cuda_stream)
+        for i in range(len(qs)):
+            assert np.array_equal(b.counts_host(i), w[i])
+        ms = b.kernel_ms()
+        assert ms["scan_ms"] > 0 and ms["hash_ms"] > 0
+    for b, qs in zip(batches, sets):
+        b.run(0.35, st.cuda_stream)
+        b.sync(st.cuda_stream)
+        for i, x in enumerate(qs):
+            assert b.hits_host(i) == cases.oracle_results(ixs, x, 0.35, 0)
+        b.run_topk(0.0, 5, st.cuda_stream, keep_counts=False)
+        b.sync(st.cuda_stream)
+        for i, x in enumerate(qs):
+            assert b.hits_host(i, 5) == cases.oracle_results(ixs, x, 0.0, 5)
+    # the host-buffer calls (scratch batches on their own streams, graphs) are unaffected by the key
+    assert s.search_hits(sets[0], 0.3, 4) == [cases.oracle_results(ixs, x, 0.3, 4) for x in sets[0]]
+    s.set_tuning("hash_stream", 0)
+    b = gpu_lib.Batch(s)
+    b.set_queries(sets[2])
+    b.run(0.0)
+    b.sync()
+    for i in range(len(sets[2])):
+        assert np.array_equal(b.counts_host(i), want[2][i])
