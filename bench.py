@@ -732,7 +732,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange-chunks", type=int, default=0,
                     help="sharded runs: sub-batches the batch is cut into; hash(i+1) | scan(i) | exchange(i-1) overlap on their own "
-                         "streams.  0 = automatic: 2 (1 for an out-of-core run, whose passes are bound by PCIe)")
+                         "streams.  0 = automatic: 2 (1 for batches below 4000 queries and for an out-of-core run, whose passes are bound by PCIe)")
     ap.add_argument("--corrupt-exchange", action="store_true",
                     help="test hook of the self-check: one count of one assembled row is changed before the check, which must fail")
     ap.add_argument("--exchange", choices=["alltoall", "allgather"], default="alltoall")
@@ -830,7 +830,9 @@ def main():
         # Two sub-batches by default: the exchange (~0.2 ms per rank at C3 / N = 8 against 2.4 ms of scan) and K1
         # (replicated on every rank: 0.23 ms) of one half hide behind the scan of the other; every further cut adds a launch
         # tail to every rank's scan and halves what is left to hide.
-        nsub = args.exchange_chunks if args.exchange_chunks > 0 else (1 if budget else 2)
+        # (a small batch is not cut: at configs[3]'s 1000 queries two halves of 500 scan 14 % slower than the whole --
+        # fewer look-ups per cached line, smaller grids -- which is more than the exchange costs)
+        nsub = args.exchange_chunks if args.exchange_chunks > 0 else (1 if budget or args.queries < 4000 else 2)
         try:
             run = ShardedRun(cfg, queries, world, rank, dev, comm, nsub, args.threshold,
                              _capi.XCHG_ALLGATHER if args.exchange == "allgather" else _capi.XCHG_ALLTOALL,

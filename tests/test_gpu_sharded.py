@@ -72,7 +72,7 @@ def test_bench_sharded_code_path_on_one_rank(gpu_lib):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--one-rank-sharded", "--extras", "--scale", "0.02",
-                        "--queries", "512", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                        "--queries", "512", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--exchange-chunks", "2"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1]
@@ -116,7 +116,7 @@ def _bench(args, timeout=900, env=None):
     return r, (json.loads(lines[-1]) if lines else None), r.stdout
 
 
-SMALL = ["--scale", "0.02", "--queries", "512", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+SMALL = ["--scale", "0.02", "--queries", "512", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--exchange-chunks", "2"]
 
 
 def test_bench_gpus_1_plain_and_one_rank_sharded(gpu_lib):
@@ -131,7 +131,7 @@ def test_bench_gpus_1_plain_and_one_rank_sharded(gpu_lib):
     assert j["n_gpus"] == 1 and j["rccl_ranks"] == 1
     _check_self_proving_fields(j, 1)
     # one sub-batch on request: hash, scan, exchange in turn (the round-3 headline form)
-    r, j, out = _bench(["--gpus", "1", "--one-rank-sharded", "--exchange-chunks", "1"] + SMALL)
+    r, j, out = _bench(["--gpus", "1", "--one-rank-sharded"] + SMALL[:-2] + ["--exchange-chunks", "1"])
     assert r.returncode == 0, r.stderr[-2000:]
     assert j["exchange"]["sub_batches"] == 1 and j["bit_exact_vs_oracle"] is True
 
