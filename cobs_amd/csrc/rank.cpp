@@ -137,7 +137,11 @@ private:
 
 ExpandPool* expand_pool(int device) {
     // (one pool per process, placed by the first device that ranks: a process drives one GPU, or the GPUs of one node)
-    static ExpandPool pool(std::min(31u, std::max(2u, std::thread::hardware_concurrency()) - 1u), cpus_near_device(device));
+    static const unsigned want = []() {
+        const char* e = std::getenv("COBS_GPU_EXPAND_THREADS");            // (A/B of the pool size)
+        return e ? (unsigned)std::max(1, std::atoi(e)) : 31u;
+    }();
+    static ExpandPool pool(std::min(want, std::max(2u, std::thread::hardware_concurrency()) - 1u), cpus_near_device(device));
     return &pool;
 }
 
