@@ -334,7 +334,7 @@ def make_index(cfg, dev, rank=0, world=1, hbm_budget=0, path=None):
 
 class ShardedRun:
     """north_star's multi-GPU layout: the index sharded by sub-index block over the ranks
-    (byte-balanced: a cut may fall inside a sub-index), ONE query batch shared by all ranks,
+    (equal work per rank: a cut may fall inside a sub-index), ONE query batch shared by all ranks,
     every rank scans its slice for the whole batch, then one exchange of the per-document counts
     over RCCL / xGMI inside libcobs_gpu.so (comm.cpp).  mode ALLTOALL: rank j ends up with the
     complete count rows (global document order) of the queries [nq*j/N, nq*(j+1)/N) -- every
@@ -904,7 +904,7 @@ def main():
         except Exception:
             traffic = None
     if shard_index:
-        par = ("index sharded by sub-index block (byte-balanced) over %d GPUs, one shared batch, %s exchange of the "
+        par = ("index sharded by sub-index block (equal work per rank) over %d GPUs, one shared batch, %s exchange of the "
                "per-document counts over RCCL/xGMI inside libcobs_gpu.so%s"
                % (world, "all-to-all (query-owner)" if args.exchange == "alltoall" else "all-gather",
                   ", %d overlapped sub-batches" % len(run.sub) if len(run.sub) > 1 else ""))

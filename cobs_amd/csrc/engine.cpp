@@ -138,7 +138,7 @@ cobs_gpu_status read_options(const cobs_gpu_options* o, cobs_gpu_index* ix) {
     }
     if (o->waves_per_group == 1 || o->waves_per_group == 2 || o->waves_per_group == 4)
         ix->waves_per_group = o->waves_per_group;
-    if (o->shard_mode > 1) return fail(COBS_GPU_ERR_ARG, "unknown shard_mode");
+    if (o->shard_mode > 2) return fail(COBS_GPU_ERR_ARG, "unknown shard_mode");
     ix->shard_mode = o->shard_mode;
     if (has_field(o, offsetof(cobs_gpu_options, hbm_budget_bytes) + sizeof(uint64_t))) ix->hbm_budget = o->hbm_budget_bytes;
     return COBS_GPU_OK;
@@ -388,7 +388,7 @@ extern "C" {
 
 cobs_gpu_status cobs_gpu_plan_shards(const char* path, uint32_t shard_count, uint32_t shard_mode,
                                      uint64_t* slot_begin, uint64_t* slot_count, uint64_t* bytes) {
-    if (!path || !slot_begin || !slot_count || shard_count == 0 || shard_mode > 1)
+    if (!path || !slot_begin || !slot_count || shard_count == 0 || shard_mode > 2)
         return fail(COBS_GPU_ERR_ARG, "bad argument");
     return guarded([&]() -> cobs_gpu_status {
         MappedFile file;

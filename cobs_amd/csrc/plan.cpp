@@ -193,12 +193,18 @@ cobs_gpu_status check_meta(const IndexMeta& m) {
 // The slices of a file that shard `rank` of `count` holds (documents of different
 // sub-indexes / row-byte columns never combine, so any cut of the (sub-index, column) space
 // gives independent shards; reference compact_index/mmap_search_file.cpp:22-27,
-// search_file.cpp:30-32).  The unit is one 16-byte column chunk of one sub-index; its cost is
-// the sub-index's signature size (rows).
-//   mode 0 (default): equal BYTES per shard -- a cut may fall inside a sub-index (8 sub-indexes
-//     whose sizes differ 16x would otherwise give 8 GPUs a 3x speed-up at best); a cut within
-//     3 % of a shard's share of a sub-index boundary snaps to it.
+// search_file.cpp:30-32).  The unit is one 16-byte column chunk of one sub-index.
+//   mode 0 (default): equal WORK per shard.  The scan is a gather: a query term looks up ONE row in every sub-index,
+//     so what a shard does per term is the row BYTES it holds (its columns), whatever the number of rows behind them.
+//     A column chunk costs 1, or 1.1 in a sub-index whose 128-byte tile column (rows x 128 B) exceeds half the
+//     256 MiB Infinity Cache (measured, scripts/shard_times.py: the 8 sub-indexes of C3 one per GPU scan a 10k-query
+//     batch in 2.17 / 2.21 / 2.25 / 2.28 | 2.53 / 2.43 / 2.41 / 2.41 ms).  A cut may fall inside a sub-index, on a
+//     multiple of 8 chunks (whole 128-byte lines); one within 3 % of a shard's share of a sub-index boundary snaps to it.
+//     (Rounds 1-3 balanced the shards' BYTES in HBM, i.e. rows x columns: the shard with the small sub-indexes held
+//     3.4x the columns of the one with the largest and took 7.6 ms against 0.95 ms -- a 2.5x speed-up on 8 GPUs.)
 //   mode 1: whole sub-indexes, equal COUNT per shard (compact), 16-byte columns (classic).
+//   mode 2: equal BYTES in HBM per shard (rows x columns) -- for an index that only fits when its footprint is spread
+//     evenly; the scan times are then as uneven as the sub-indexes' signature sizes.
 // The held slices are contiguous in score-slot order: [tail columns of the first sub-index]
 // [whole sub-indexes] [head columns of the last].
 std::vector<VPage> held_slices(const IndexMeta& m, uint32_t rank, uint32_t count, uint32_t mode) {
@@ -210,6 +216,11 @@ std::vector<VPage> held_slices(const IndexMeta& m, uint32_t rank, uint32_t count
         for (uint32_t p = 0; p < P; ++p) out.push_back(VPage{p, 0, prb});
         return out;
     }
+    // cost of one column chunk of sub-index p
+    auto weight = [&](uint32_t p) -> long double {
+        if (mode == 2) return (long double)m.signature_sizes[p];
+        return m.signature_sizes[p] * 128ull > (128ull << 20) ? 1.1L : 1.0L;
+    };
     // a cut is a global chunk position in [0, P * nch]
     auto cut_of = [&](uint32_t r) -> uint64_t {
         if (r == 0) return 0;
@@ -219,17 +230,18 @@ std::vector<VPage> held_slices(const IndexMeta& m, uint32_t rank, uint32_t count
             return nch * r / count;
         }
         long double total = 0;
-        for (uint32_t p = 0; p < P; ++p) total += (long double)m.signature_sizes[p] * nch;
+        for (uint32_t p = 0; p < P; ++p) total += weight(p) * nch;
         const long double share = total / count, ideal = share * r;
         long double acc = 0;
         for (uint32_t p = 0; p < P; ++p) {
-            const long double w = (long double)m.signature_sizes[p] * nch;
+            const long double w = weight(p) * nch;
             if (acc + w < ideal) { acc += w; continue; }
             // the cut falls into sub-index p
             const long double tol = 0.03L * share;
             if (ideal - acc <= tol) return (uint64_t)p * nch;
             if (acc + w - ideal <= tol) return (uint64_t)(p + 1) * nch;
-            uint64_t c = (uint64_t)((ideal - acc) / (long double)m.signature_sizes[p] + 0.5L);
+            uint64_t c = (uint64_t)((ideal - acc) / weight(p) + 0.5L);
+            if (mode == 0 && nch >= 16) c = (c + 4) / 8 * 8;     // whole 128-byte lines on both sides of the cut
             if (c > nch) c = nch;
             return (uint64_t)p * nch + c;
         }

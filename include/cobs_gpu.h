@@ -57,8 +57,10 @@ typedef struct cobs_gpu_options {
     uint32_t waves_per_group; /* waves that split one query's terms: 1, 2 or 4; 0 = chosen by query length */
     /* how a file is cut into shard_count shards (the unit is a 16-byte column chunk of one sub-index;
      * every shard holds a contiguous range of score slots):
-     *   0 = equal bytes per shard; a cut may fall inside a sub-index (column range)
-     *   1 = whole sub-indexes, equal count per shard (classic: 16-byte columns)            */
+     *   0 = equal WORK per shard: a term looks up one row in every sub-index, so a shard's scan time follows the row
+     *       bytes (columns) it holds, not its bytes in HBM; a cut may fall inside a sub-index (column range)
+     *   1 = whole sub-indexes, equal count per shard (classic: 16-byte columns)
+     *   2 = equal bytes in HBM per shard (rows x columns): balances the footprint, not the scan time       */
     uint32_t shard_mode;
     /* 0 = stage the whole (shard of the) index into HBM.  Otherwise the index may
      * use at most this many bytes of HBM: files that do not fit are cut into chunks

@@ -7,7 +7,7 @@ S=gpurun_out/stamp_$TAG
 for f in bench_c3 bench_c3_one_rank_sharded bench_c3_one_rank_sharded_1chunk bench_c2 c5_bench c5_q256_bench c5_columns_bench; do
   [ -s "$S/$f.json" ] && grep -h '"metric"' "$S/$f.json" | tail -1 > "profiles/${TAG}_$f.json"
 done
-for f in default_call latency c5_selective h2d_probe clk_probe; do
+for f in default_call latency c5_selective h2d_probe clk_probe shard_times; do
   [ -s "$S/$f.txt" ] && grep -v "amdgpu.ids" "$S/$f.txt" > "profiles/${TAG}_$f.txt"
 done
 python scripts/collect_shapes.py "$TAG"

@@ -23,6 +23,7 @@ python scripts/latency.py > "$OUT/latency.txt" 2>&1
 python scripts/row_fetch_bench.py 1.0 6 > "$OUT/c5_selective.txt" 2>&1
 scripts/probes/h2d_probe 4 > "$OUT/h2d_probe.txt" 2>&1
 python scripts/clk_probe.py > "$OUT/clk_probe.txt" 2>&1
+(for a in "8 0" "4 0" "2 0" "3 0" "8 1" "8 2"; do echo "== shards: N mode = $a"; python scripts/shard_times.py $a; done) > "$OUT/shard_times.txt" 2>&1
 bash scripts/profile_shapes.sh "$TAG" > "$OUT/profile_shapes.log" 2>&1
 tail -15 "$OUT/profile_shapes.log"
 ls "$OUT"

@@ -41,19 +41,31 @@ def test_shards_are_a_partition_of_the_score_slots(oracle, tmp_path, golden_dir,
             assert pos == ix.counts_size, (p, n)
 
 
-def test_balanced_mode_equalises_bytes_not_sub_index_counts(oracle, tmp_path):
-    """sub-indexes whose sizes differ 16x (the shape of BASELINE configs[2]): whole sub-indexes
-    per shard leave the largest shard with a third of the bytes, byte-balanced cuts do not"""
+def test_default_mode_balances_work_not_bytes(oracle, tmp_path):
+    """sub-indexes whose sizes differ 16x (the shape of BASELINE configs[2]).  The scan is a gather -- a term looks up
+    one row in every sub-index -- so a shard's time follows the COLUMNS (score slots) it holds: mode 0 gives every
+    shard about the same number of slots (a chunk of a sub-index whose tile column overflows half the Infinity Cache
+    counts 1.1), whatever that does to its bytes; mode 2 equalises the bytes in HBM (rounds 1-3's default), which
+    leaves the shard of the small sub-indexes with several times the slots of the others"""
     ratio = 16.0 ** (1.0 / 7.0)
     sigs = [int(300 * ratio ** p) for p in range(8)]
     p = cases.make_compact(cases.tmp(tmp_path, "b.cobs_compact"), 8 * 8 * 160 - 5, 160, sigs, 1)
     total = sum(s * 160 for s in sigs)
-    for n in (2, 4, 8):
-        _, _, by0 = _plan(p, n, 0)
-        _, _, by1 = _plan(p, n, 1)
-        assert max(by0) <= 1.25 * total / n + 4096 * n            # pitch padding and zero rows aside
+    slots = 8 * 8 * 160
+    for n in (2, 3, 4, 5, 8):
+        _, c0, _ = _plan(p, n, 0)
+        _, c1, by1 = _plan(p, n, 1)
+        _, c2, by2 = _plan(p, n, 2)
+        assert max(c0) <= 1.1 * slots / n + 8 * 128 and min(c0) >= 0.9 * slots / n - 8 * 128      # equal work
+        assert max(by2) <= 1.25 * total / n + 4096 * n            # equal bytes (pitch padding and zero rows aside)
         if n == 8:
-            assert max(by1) >= 2.5 * total / n
+            assert max(by1) >= 2.5 * total / n and len(set(c1)) == 1
+            assert max(c2) >= 2.5 * slots / n                     # ... and with them several times the work
+    # a cut inside a sub-index of rows of 256 bytes and more falls on whole 128-byte lines (8 chunks of 16 bytes = 1024 slots)
+    pw = cases.make_compact(cases.tmp(tmp_path, "w.cobs_compact"), 4 * 8 * 384 - 9, 384, [400, 500, 600, 700], 1)
+    for n in (3, 5, 7):
+        bw, cw, _ = _plan(pw, n, 0)
+        assert all(b % 1024 == 0 for b in bw) and sum(cw) == 4 * 8 * 384
     # many small sub-indexes: cuts snap to sub-index boundaries (whole sub-indexes only)
     p2 = cases.make_compact(cases.tmp(tmp_path, "m.cobs_compact"), 100 * 8 * 16 - 3, 16, [50 + 3 * i for i in range(100)], 1)
     begin, count, _ = _plan(p2, 4, 0)
