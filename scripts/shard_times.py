@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""scripts/shard_times.py [N] [mode] -- the scan time of every shard of an N-way sharded C3 index, one after another on
+"""scripts/shard_times.py [N] [mode] [queries] -- the scan time of every shard of an N-way sharded C3 index, one after another on
 this GPU: what each rank of an N-GPU run spends scanning (the step is the slowest rank).  Byte-balanced shards (mode 0)
 are not time-balanced if a byte of a large sub-index costs more than a byte of a small one."""
 import os
@@ -15,8 +15,9 @@ import cobs_amd  # noqa: E402
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     mode = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    nq = int(sys.argv[3]) if len(sys.argv) > 3 else 10000
     cfg = bench.c3_config()
-    queries = bench.make_queries(10000, 1000)
+    queries = bench.make_queries(nq, 1000)
     times = []
     for r in range(n):
         s = cobs_amd.Search.synthetic(cfg["kind"], cfg["signature_sizes"], cfg["num_docs"], page_size=cfg["page_size"], seed=1,
