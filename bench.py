@@ -323,8 +323,12 @@ def bind_to_numa_node(node):
 
 
 def make_index(cfg, dev, rank=0, world=1, hbm_budget=0, path=None):
+    # Which balance a shard split wants: a RESIDENT shard's time is the work of its gather -- the columns it holds
+    # (shard_mode 0); a shard STREAMED under an HBM budget is bound by the bytes that cross its PCIe link per pass --
+    # rows x columns (shard_mode 2: equal bytes per rank).
     if path:
-        return cobs_amd.Search(path, device=dev, shard_rank=rank, shard_count=world, hbm_budget=hbm_budget)
+        return cobs_amd.Search(path, device=dev, shard_rank=rank, shard_count=world, hbm_budget=hbm_budget,
+                               shard_mode=2 if hbm_budget else 0)
     return cobs_amd.Search.synthetic(cfg["kind"], cfg["signature_sizes"], cfg["num_docs"],
                                      page_size=cfg["page_size"], term_size=cfg["term_size"],
                                      canonicalize=cfg["canonicalize"], num_hashes=cfg["num_hashes"],
@@ -904,7 +908,7 @@ def main():
         except Exception:
             traffic = None
     if shard_index:
-        par = ("index sharded by sub-index block (equal work per rank) over %d GPUs, one shared batch, %s exchange of the "
+        par = ("index sharded by sub-index block (" + ("equal bytes per rank: streamed" if budget else "equal work per rank") + ") over %d GPUs, one shared batch, %s exchange of the "
                "per-document counts over RCCL/xGMI inside libcobs_gpu.so%s"
                % (world, "all-to-all (query-owner)" if args.exchange == "alltoall" else "all-gather",
                   ", %d overlapped sub-batches" % len(run.sub) if len(run.sub) > 1 else ""))
