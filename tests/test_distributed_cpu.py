@@ -33,7 +33,7 @@ def _worker(rank, world, port, path, queries, out_dir, mode):
         from oracle import oracle as O
         ix = O.Index.open(path)
         # the engine's own shard layout (host-side planner of libcobs_gpu.so, no device needed):
-        # byte-balanced cuts (mode 0) may fall inside a sub-index
+        # work-balanced cuts (mode 0) may fall inside a sub-index
         import ctypes as C
         from cobs_amd import _capi
         b_, c_ = (C.c_uint64 * world)(), (C.c_uint64 * world)()

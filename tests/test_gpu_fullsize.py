@@ -352,11 +352,11 @@ def _check_shard_union(lib, begins, counts, local, eb, total, wants, nshards):
         assert owned == (nq if mode == 1 else nq * nshards)
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_c4_eight_shards_in_turn(gpu_lib, oracle, mode):
     """BASELINE configs[3] at its own geometry -- 1 M documents, 245 sub-indexes, 68 GB -- cut into the 8 shards an
-    8-GPU node holds (mode 0: equal bytes, cuts inside sub-indexes; mode 1: whole sub-indexes), each 8.5 GB shard on
-    this GPU in turn, 64 queries: the slot ranges partition counts_size, the union of the shards' rows is the
+    8-GPU node holds (mode 0: equal work = equal columns; mode 1: whole sub-indexes; mode 2: equal bytes, 8.5 GB each,
+    cuts inside sub-indexes), every shard on this GPU in turn, 64 queries: the slot ranges partition counts_size, the union of the shards' rows is the
     oracle's, and the all-to-all / all-gather plans of the 8 ranks assemble those rows into the oracle's
     (everything of the N = 8 run but the xGMI transfers themselves).
     Shard boundary: reference cobs/query/compact_index/mmap_search_file.cpp:22-27, search_file.cpp:30-32."""
@@ -373,16 +373,20 @@ def test_c4_eight_shards_in_turn(gpu_lib, oracle, mode):
                                         num_hashes=cfg["num_hashes"], seed=cfg["seed"], **kw)
     begins, counts, local, eb, hbm = _shards_in_turn(gpu_lib, opener, 8, mode, queries)
     assert eb == 2
-    if mode == 0:       # byte-balanced: every shard holds an eighth of the 68 GB (documents per shard differ 8x)
+    if mode == 2:       # byte-balanced: every shard holds an eighth of the 68 GB (documents per shard differ 8x)
         assert max(hbm) < 1.1 * min(hbm) and 8.0e9 < min(hbm) and max(hbm) < 9.5e9
-    else:               # whole sub-indexes: every cut on a sub-index boundary
+    elif mode == 1:     # whole sub-indexes: every cut on a sub-index boundary
         assert all(b[0] % (8 * cfg["page_size"]) == 0 for b in begins)
+    else:               # work-balanced: every shard holds about an eighth of the score slots (a gather's cost is its columns)
+        slots = [c[0] for c in counts]
+        assert max(slots) < 1.15 * min(slots) and sum(slots) == ix.counts_size
     _check_shard_union(_capi.load(), begins, counts, local, eb, ix.counts_size, wants, 8)
 
 
 def test_c5_quarter_scale_eight_streamed_shards_in_turn(gpu_lib, oracle, tmp_path):
     """BASELINE configs[4]'s N = 8 arithmetic at quarter scale: the 4.6 GB .cobs_compact FILE cut into 8 byte-balanced
-    shards, every shard opened under an HBM budget smaller than itself (so each rank streams its slices), in turn on
+    shards (shard_mode 2: what a streamed shard costs is the bytes that cross its PCIe link), every shard opened under an
+    HBM budget smaller than itself (so each rank streams its slices), in turn on
     this GPU; union and exchange plans as above."""
     import cobs_amd
     from cobs_amd import _capi
@@ -394,5 +398,5 @@ def test_c5_quarter_scale_eight_streamed_shards_in_turn(gpu_lib, oracle, tmp_pat
     queries = bench.make_queries(nq, 1000)
     wants = [ix.counts(q) for q in queries]
     budget = 200 * 1000 * 1000          # a shard is ~575 MB
-    begins, counts, local, eb, _ = _shards_in_turn(gpu_lib, lambda **kw: gpu_lib.Search(path, **kw), 8, 0, queries, budget)
+    begins, counts, local, eb, _ = _shards_in_turn(gpu_lib, lambda **kw: gpu_lib.Search(path, **kw), 8, 2, queries, budget)
     _check_shard_union(_capi.load(), begins, counts, local, eb, ix.counts_size, wants, 8)

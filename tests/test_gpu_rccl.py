@@ -4,7 +4,7 @@ A one-GPU box can only host a ONE-rank RCCL communicator (RCCL refuses two ranks
 device), but that runs the very code an 8-GPU node runs: ncclGetUniqueId / ncclCommInitRank,
 the layout all-gather, ncclAllGather of the count slices typed as bytes, the strided assembly
 into global rows, the sizes-first hit exchange, the top-k gather and
-cobs_gpu_sharded_search_batch.  The N > 1 arithmetic (slot layouts of byte-balanced shards,
+cobs_gpu_sharded_search_batch.  The N > 1 arithmetic (slot layouts of work- / byte-balanced shards,
 assembly, merge order) is covered on the same GPU by opening every shard in turn, and across
 processes by tests/test_gpu_sharded.py / tests/test_distributed_cpu.py."""
 import numpy as np
@@ -126,10 +126,10 @@ def test_streamed_shard_under_a_budget(gpu_lib, oracle, tmp_path, comm):
         assert s.sharded_search_hits(comm, queries, t, lim) == [cases.oracle_results(ixs, q, t, lim) for q in queries]
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("budget", [0, 200 * 1024])
-def test_byte_balanced_shards_assemble_to_the_whole(gpu_lib, oracle, tmp_path, mode, budget):
-    """every shard of 2..5 (cuts inside sub-indexes in mode 0) computes exactly its slot range;
+def test_shards_of_every_mode_assemble_to_the_whole(gpu_lib, oracle, tmp_path, mode, budget):
+    """every shard of 2..5 (cuts inside sub-indexes in the work-balanced mode 0 and the byte-balanced mode 2) computes exactly its slot range;
     their concatenation is the oracle's vector.  With a budget every shard also streams."""
     q = oracle.random_sequence(500, 3)
     ratio = 16.0 ** (1.0 / 7.0)

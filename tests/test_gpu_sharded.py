@@ -64,7 +64,7 @@ def test_sharded_search_processes(gpu_lib, oracle, tmp_path, world):
 
 
 def test_bench_sharded_code_path_on_one_rank(gpu_lib):
-    """bench.py's N > 1 flow (native RCCL communicator, byte-balanced shard, all-to-all exchange,
+    """bench.py's N > 1 flow (native RCCL communicator, work-balanced shard, all-to-all exchange,
     the other forms) with a one-rank communicator: the JSON line carries the fields the driver
     and DESIGN.md name; no N > 1 hardware is needed to catch a broken call sequence"""
     import json
