@@ -333,7 +333,8 @@ cobs_gpu_status chunk_part(Part& pt, uint64_t cap, const Tuning& tune) {
         // counted and may lie in different ranges: columns.  (Procedural indexes regenerate chunks: columns.)
         if (m.num_hashes == 1 && tune.row_ranges != 0 && !pt.synthetic) {
             const uint64_t pitch = pitch_for(v.ncols, tune);
-            const uint64_t fit = cap / pitch > 1 ? (cap / 256 * 256) / pitch - 1 : 0;      // rows per buffer (+ the zero row)
+            const uint64_t rows_fit = (cap / 256 * 256) / pitch;                 // a buffer is a multiple of 256 bytes
+            const uint64_t fit = rows_fit > 1 ? rows_fit - 1 : 0;                // rows per buffer, beside the zero row
             if (fit >= tune.row_range_min) {
                 const uint64_t nr = (sig + fit - 1) / fit;
                 const uint64_t per = (sig + nr - 1) / nr;
