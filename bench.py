@@ -285,7 +285,7 @@ def kernels_hash():
     import hashlib
     h = hashlib.sha256()
     # (the scan kernels and what chooses their launch geometry: what the replayed PMC traffic depends on)
-    for fn in ("kernels.hip", "plan.cpp", "pass.cpp"):
+    for fn in ("kernels.hip", "geometry.cpp"):
         with open(os.path.join(ROOT, "cobs_amd", "csrc", fn), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
