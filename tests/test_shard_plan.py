@@ -23,14 +23,17 @@ def _plan(path, n, mode=0):
     return list(b), list(c), list(by)
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_shards_are_a_partition_of_the_score_slots(oracle, tmp_path, golden_dir, mode):
     pc = cases.make_compact(cases.tmp(tmp_path, "p.cobs_compact"), 700, 16, [800, 900, 1000, 1100, 1200, 1300], 2)
     pk = cases.make_classic(cases.tmp(tmp_path, "p.cobs_classic"), 3000, 1999, 1)
     pw = cases.make_compact(cases.tmp(tmp_path, "w.cobs_compact"), 5000, 200, [300, 5000, 700, 9000], 1)
-    for p in (pc, pk, pw, os.path.join(golden_dir, "c1.cobs_compact"), os.path.join(golden_dir, "c1.cobs_classic")):
+    # rows of 400 bytes (25 chunks: cuts of the work-balanced mode are rounded to 8 chunks) and sub-indexes on both
+    # sides of the 1.1 weight (rows x 128 B above / below half the Infinity Cache is decided by the header alone)
+    pr = cases.make_compact(cases.tmp(tmp_path, "r.cobs_compact"), 3 * 8 * 400 - 1, 400, [64, 2000, 128], 1)
+    for p in (pc, pk, pw, pr, os.path.join(golden_dir, "c1.cobs_compact"), os.path.join(golden_dir, "c1.cobs_classic")):
         ix = oracle.Index.open(p)
-        for n in (1, 2, 3, 4, 7, 8, 16, 61):
+        for n in (1, 2, 3, 4, 5, 6, 7, 8, 9, 16, 61):
             begin, count, _ = _plan(p, n, mode)
             pos = 0
             for r in range(n):
