@@ -223,3 +223,14 @@ def test_bench_replicated_index_line_checks_its_rows(gpu_lib):
     assert r.returncode == 0, r.stderr[-3000:]
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and "rccl_ranks" not in j
     assert j["bit_exact_vs_oracle"] is True and j["checked_per_rank_at_least"]["rows_exact_vs_oracle"] >= 16
+
+
+def test_bench_three_ranks_cut_inside_sub_indexes(gpu_lib):
+    """an odd rank count: the work-balanced split cuts inside sub-indexes (on whole 128-byte lines), the owners' query
+    ranges are uneven (512 queries over 3 ranks in 2 sub-batches), and the line still proves itself"""
+    r, j, out = _bench(["--gpus", "3", "--dist-backend", "gloo"] + SMALL)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert j["n_gpus"] == 3 and j["bit_exact_vs_oracle"] is True and j["exchange_consistent_all_rows"] is True
+    assert len(j["per_rank"]["scan_ms"]) == 3 and j["checked_per_rank_at_least"]["rows_exchange_sums"] >= 512 // 3 - 1
+    cut = j["shard_rank0"]["slot_count"]                        # rank 0's cut: inside a sub-index (12 544 slots each) ...
+    assert 0 < cut < 100352 and (cut % 12544) % 1024 == 0       # ... on whole lines: 8 chunks of 16 bytes = 1024 score slots
