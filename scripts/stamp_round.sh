@@ -23,7 +23,9 @@ python scripts/latency.py > "$OUT/latency.txt" 2>&1
 python scripts/row_fetch_bench.py 1.0 6 > "$OUT/c5_selective.txt" 2>&1
 scripts/probes/h2d_probe 4 > "$OUT/h2d_probe.txt" 2>&1
 python scripts/clk_probe.py > "$OUT/clk_probe.txt" 2>&1
-(for a in "8 0" "4 0" "2 0" "3 0" "8 1" "8 2"; do echo "== shards: N mode = $a"; python scripts/shard_times.py $a; done) > "$OUT/shard_times.txt" 2>&1
+(for a in "8 0" "4 0" "2 0" "3 0" "8 1" "8 2"; do echo "== shards: N mode = $a"; python scripts/shard_times.py $a; done
+ for m in 2 0; do echo "== streamed shards of the C3 file, 0.75 GB budget each: N mode = 8 $m"; python scripts/shard_times.py 8 $m 10000 0.75; done
+ rm -f /tmp/cobs_c5_1.cobs_compact) > "$OUT/shard_times.txt" 2>&1
 bash scripts/profile_shapes.sh "$TAG" > "$OUT/profile_shapes.log" 2>&1
 tail -15 "$OUT/profile_shapes.log"
 ls "$OUT"
