@@ -17,7 +17,7 @@ def main():
     mode = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     nq = int(sys.argv[3]) if len(sys.argv) > 3 else 10000
     budget = int(float(sys.argv[4]) * 1e9) if len(sys.argv) > 4 else 0      # GB per shard: the shards of the C3 FILE, streamed
-    cfg = bench.c3_config()
+    cfg = bench.c4_config() if os.environ.get("SHAPE") == "c4" else bench.c3_config()      # SHAPE=c4: BASELINE configs[3]
     path = None
     if budget:
         path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "cobs_c5_1.cobs_compact")
