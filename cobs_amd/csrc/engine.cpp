@@ -72,6 +72,7 @@ Tuning Tuning::from_env() {
     if (const char* e = getenv("COBS_GPU_DEVICE_RANK")) t.device_rank = atoi(e) != 0;
     if (const char* e = getenv("COBS_GPU_TRACE")) t.trace = atoi(e) != 0;
     if (const char* e = getenv("COBS_GPU_ROW_RANGES")) t.row_ranges = atoi(e) != 0;
+    if (const char* e = getenv("COBS_GPU_STREAM_PACKED")) t.stream_packed = atoi(e) != 0;
     if (const char* e = getenv("COBS_GPU_ROW_RANGE_MIN")) t.row_range_min = (uint32_t)std::max(1, atoi(e));
     if (const char* e = getenv("COBS_GPU_EXP")) t.exp = (uint32_t)std::strtoul(e, nullptr, 0);      // A/B variants, also under the test suite
     return t;
@@ -237,7 +238,7 @@ static cobs_gpu_status stage_index(cobs_gpu_index* ix, std::vector<std::unique_p
                                 pd.base = 0;                  // (a gathered buffer has its own bases: fetch_rows_kernel)
                                 g->vp.push_back(whole);
                                 g->pages.push_back(pd);
-                                g->bytes += slice_bytes(pd.sig, whole.ncols, ix->tune);
+                                g->bytes += round_up((pd.sig + 1) * (uint64_t)c.pitch, 256);     // (= slice_bytes at this chunk's pitch)
                                 continue;
                             }
                             g->vp.insert(g->vp.end(), c.vp.begin(), c.vp.end());

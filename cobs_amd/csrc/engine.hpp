@@ -106,6 +106,8 @@ struct Tuning {
     int device_rank = 1;        // whole score rows are ranked on the device (0: by host threads, A/B and fallback)
     uint32_t rank_window_kib = 16u << 10;   // device-ranked records cross PCIe in pieces of this size (KiB)
     uint32_t row_range_min = 1024;  // ... unless a buffer holds fewer rows than this (then by columns); COBS_GPU_ROW_RANGE_MIN, tests
+    uint32_t packed_width = 0;  // (set by the planner for a streamed part: chunks of this many columns keep that pitch)
+    int stream_packed = 1;      // streamed chunks keep the file's row pitch (linear PCIe copies); 0: device pitch, 2-D copies (A/B)
     int row_ranges = 1;         // a streamed sub-index larger than a stream buffer is cut by ROWS (H = 1; 0: by columns, A/B and fallback)
     int rank_pack = 1;          // device-ranked records cross PCIe as one u32 where slot and score fit (0: always 8-byte pairs, A/B)
     int hash_stream = 0;        // K1 of a device-resident batch runs on the batch's own stream, K2 waits for it by event: the hashing

@@ -55,6 +55,7 @@ uint32_t pitch_for(uint64_t ncols, const Tuning& tune) {
         if (round_up(ncols, a) * 8 <= ncols * 9) { align = a; break; }
     }
     if (tune.row_align) align = tune.row_align;
+    if (tune.packed_width != 0 && ncols == tune.packed_width) align = 16;       // a streamed chunk of whole file rows
     return (uint32_t)round_up(ncols, align);
 }
 
@@ -229,7 +230,15 @@ cobs_gpu_status plan_part(Part& pt, const cobs_gpu_index* ix) {
 
 // Cut the held slices into chunks: resident (cap == 0) = one chunk per run of equal-width
 // slices; streamed = chunks of at most `cap` bytes each (two device buffers of `cap` bytes).
-cobs_gpu_status chunk_part(Part& pt, uint64_t cap, const Tuning& tune) {
+cobs_gpu_status chunk_part(Part& pt, uint64_t cap, const Tuning& tune_in) {
+    // A streamed chunk of WHOLE file rows keeps the file's row pitch where that is a multiple of 16 (no padding to
+    // 128-byte lines): it crosses PCIe as ONE linear copy (57.6 GB/s on MI355X against 56.2 for the 2-D copy that
+    // re-pitches 1568-byte rows to 1664, profiles/r04_h2d_probe.txt).  Its scan pays for rows that straddle cache lines
+    // (+8.5 % scan time) -- 2 ms of a pass that waits 320 ms for its copies.  Column slices are 2-D copies either way
+    // and keep the line-aligned pitch (packed, they measured 3-9 % slower: profiles/r04_shard_times.txt).
+    Tuning tune = tune_in;
+    if (cap != 0 && !pt.synthetic && tune.row_align == 0 && tune.stream_packed != 0 && pt.meta.page_row_bytes() % 16 == 0)
+        tune.packed_width = (uint32_t)pt.meta.page_row_bytes();
     const IndexMeta& m = pt.meta;
     pt.chunks.clear();
     pt.streamed = cap != 0;

@@ -167,8 +167,11 @@ cobs_gpu_status stream_chunk_in(cobs_gpu_index* ix, Part& pt, const Chunk& c, in
         const uint8_t* src = pt.file->data() + m.page_offset(v.fp) + v.row0 * prb;     // (row-range chunk: its first row)
         uint8_t* dst = dev + pd.base;
         if (pt.file_pinned) {
-            HIP_TRY(hipMemcpy2DAsync(dst, c.pitch, src + v.col0, (size_t)prb, (size_t)v.ncols, (size_t)pd.sig,
-                                     hipMemcpyHostToDevice, sb.copy_stream));
+            if (c.pitch == prb && v.col0 == 0 && v.ncols == prb)       // rows as the file holds them: one linear copy
+                HIP_TRY(hipMemcpyAsync(dst, src, (size_t)(pd.sig * prb), hipMemcpyHostToDevice, sb.copy_stream));
+            else
+                HIP_TRY(hipMemcpy2DAsync(dst, c.pitch, src + v.col0, (size_t)prb, (size_t)v.ncols, (size_t)pd.sig,
+                                         hipMemcpyHostToDevice, sb.copy_stream));
             HIP_TRY(hipMemsetAsync(dst + pd.sig * (uint64_t)c.pitch, 0, c.pitch, sb.copy_stream));
             continue;
         }

@@ -82,8 +82,8 @@ def test_streamed_synthetic_equals_resident(gpu_lib, oracle):
 @pytest.mark.parametrize("no_pin", ["0", "1"])
 def test_random_budgets(gpu_lib, oracle, tmp_path, monkeypatch, no_pin):
     """random geometries x random HBM budgets (chunks of whole sub-indexes, shared chunks, column
-    slices of a sub-index larger than a buffer; pinned-mapping DMA and the staged fallback):
-    streamed results equal the oracle's"""
+    slices of a sub-index larger than a buffer; pinned-mapping DMA and the staged fallback; chunks at the
+    file's own row pitch -- linear copies -- and at the device pitch): streamed results equal the oracle's"""
     import os
     from cobs_amd import _capi
     if no_pin == "1":
@@ -100,7 +100,7 @@ def test_random_budgets(gpu_lib, oracle, tmp_path, monkeypatch, no_pin):
                                       planted={0: 1.0, D - 1: 0.7}, query=q_long[:200])
             file_bytes = S * ((D + 7) // 8)
         else:
-            ps = int(rng.choice([8, 24, 64, 136, 256]))
+            ps = int(rng.choice([8, 24, 48, 64, 112, 136, 256]))
             P = int(rng.integers(1, 7))
             D = (P - 1) * 8 * ps + int(rng.integers(1, 8 * ps + 1))
             sigs = [int(x) for x in rng.integers(200, 4000, size=P)]
@@ -109,6 +109,7 @@ def test_random_budgets(gpu_lib, oracle, tmp_path, monkeypatch, no_pin):
             file_bytes = sum(sigs) * ps
         budget = int(file_bytes * float(rng.choice([0.15, 0.3, 0.6, 0.9])))
         queries = [q_long[:200], q_long[100:131], q_long[:31 + int(rng.integers(0, 400))]]
+        monkeypatch.setenv("COBS_GPU_STREAM_PACKED", str(idx % 2))
         try:
             s = gpu_lib.Search(path, hbm_budget=budget)
         except gpu_lib.CobsGpuError as e:       # budget below two 16-byte column slices of the largest sub-index
