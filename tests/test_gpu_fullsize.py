@@ -246,33 +246,47 @@ def test_streamed_file_at_scale_is_bit_exact(gpu_lib, oracle, tmp_path):
     assert got == [[(f, d, sc) for (f, d, _n, sc) in oracle.search(ix, q, 0.0, 5)] for q in queries[:8]]
 
 
-def test_headline_geometry_from_a_20_gb_file(gpu_lib, oracle, tmp_path):
+@pytest.mark.parametrize("shape", ["c3", "c4"])
+def test_full_geometries_from_20_gb_files(gpu_lib, oracle, tmp_path, shape):
     """The headline geometry (BASELINE configs[2]: 100 000 documents, 8 sub-indexes of 1568-byte pages, S_p geometric)
-    as a FILE of more than 20 GB, opened RESIDENT: the path a user's index takes -- parse_index_header, the slab
-    upload through pinned staging, re-pitching 1568 -> 1664 bytes -- instead of the in-HBM generator the other
-    full-size tests share with their checker.  The checker here reads the same FILE through its own header parser
-    and mmap (oracle.Index.open) and counts on the CPU: 64 queries, every score row element by element, plus
-    rows of the matrix read back from HBM against the file's bytes at the offsets the checker computes."""
+    and the geometry of configs[3] (1 M documents, 245 sub-indexes of 512-byte pages), each as a FILE of more than
+    20 GB, opened RESIDENT: the path a user's index takes -- parse_index_header, the slab upload through pinned
+    staging, re-pitching 1568 -> 1664 bytes (c3) or the straight copy of rows that already have the device pitch (c4)
+    -- instead of the in-HBM generator the other full-size tests share with their checker.  The checker here reads
+    the same FILE through its own header parser and mmap (oracle.Index.open) and counts on the CPU: every score row
+    of the queries element by element, plus rows of the matrix read back from HBM against the file's bytes at the
+    offsets the checker computes."""
     import os
     import shutil
     import cobs_amd
-    cfg = bench.c3_config(1.1)
+    import psutil
+    where = str(tmp_path)
+    cfg = bench.c3_config(1.1) if shape == "c3" else bench.c4_config(0.3)
+    if shape == "c4":
+        # configs[3] at the size BASELINE names (68 GB) where a tmpfs and the host's memory take it (the MI355X boxes
+        # of this project: 1.5 TB of /dev/shm over 3 TB of RAM, /tmp a 79 GB overlay), else 0.3 of its rows: 20.4 GB
+        full = bench.c4_config(1.0)
+        need = sum(full["signature_sizes"]) * full["page_size"]
+        if (os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 2 * need
+                and psutil.virtual_memory().available > 4 * need):
+            cfg, where = full, "/dev/shm"
+    npages = len(cfg["signature_sizes"])
     width = cfg["page_size"]
     size = sum(cfg["signature_sizes"]) * width
     assert size > 20 * 10 ** 9
-    free = shutil.disk_usage(str(tmp_path)).free
-    assert free > size + (2 << 30), "needs %.1f GB of scratch space under %s" % (size / 1e9, tmp_path)
-    path = str(tmp_path / "c3_x1.1.cobs_compact")
+    free = shutil.disk_usage(where).free
+    assert free > size + (2 << 30), "needs %.1f GB of scratch space under %s" % (size / 1e9, where)
+    path = os.path.join(where, "cobs_test_%d_%s.cobs_compact" % (os.getpid(), shape))
     cobs_amd.write_synthetic(path, "compact", cfg["signature_sizes"], cfg["num_docs"], page_size=width, seed=7)
     try:
         assert os.path.getsize(path) > size
         s = gpu_lib.Search(path)                                 # no budget: resident, uploaded from the file
         info = s.info(0)
-        assert info.kind == 1 and info.num_pages == 8 and info.page_size == width and info.num_docs == cfg["num_docs"]
+        assert info.kind == 1 and info.num_pages == npages and info.page_size == width and info.num_docs == cfg["num_docs"]
         assert info.hbm_bytes > size                             # all of it in HBM (rows at their device pitch)
         ix = oracle.Index.open(path)                             # the checker's own reader of the same file
-        assert [ix.signature_size(p) for p in range(8)] == cfg["signature_sizes"]
-        queries = bench.make_queries(64, 1000, seed=77)
+        assert [ix.signature_size(p) for p in range(npages)] == cfg["signature_sizes"]
+        queries = bench.make_queries(64 if shape == "c3" else 24, 1000, seed=77)
         b = gpu_lib.Batch(s)
         b.set_queries(queries)
         b.run(0.0)
@@ -289,8 +303,15 @@ def test_headline_geometry_from_a_20_gb_file(gpu_lib, oracle, tmp_path):
         off = [0]
         for sp in cfg["signature_sizes"]:
             off.append(off[-1] + sp * width)
-        for page, row in ((0, 0), (0, cfg["signature_sizes"][0] - 1), (7, 0), (7, cfg["signature_sizes"][7] - 1),
-                          (7, 171195), (7, 171196), (7, 171197), (3, 2 * 171196 - 1), (3, 2 * 171196)):
+        last = npages - 1
+        rows = [(0, 0), (0, cfg["signature_sizes"][0] - 1), (last, 0), (last, cfg["signature_sizes"][last] - 1)]
+        if shape == "c3":
+            rows += [(7, 171195), (7, 171196), (7, 171197), (3, 2 * 171196 - 1), (3, 2 * 171196)]
+        else:                                                    # (a sub-index is smaller than a slab here)
+            rows += [(1, 0), (122, 12345), (243, cfg["signature_sizes"][243] - 1), (244, 1)]
+            slab = (256 << 20) // width                          # rows of one upload slab
+            rows += [(244, r) for r in (slab - 1, slab, 2 * slab) if r < cfg["signature_sizes"][244]]
+        for page, row in rows:
             o = data0 + off[page] + row * width
             assert np.array_equal(s.read_row(0, page, row, width), raw[o:o + width]), (page, row)
         del raw, b, s
