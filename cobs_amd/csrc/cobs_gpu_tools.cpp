@@ -2,6 +2,7 @@
 // program on top of libcobs_gpu.so, with their flags and output (reference src/cobs.cpp):
 //
 //   cobs_gpu_query doc-list PATH / doc-dump PATH (host only)                       (:75-161)
+//   cobs_gpu_query print-parameters [-h H] [-f FPR] [-n N] / print-kmers QUERY [-k K] (host only)   (:532-599)
 //   cobs_gpu_query classic-construct INPUT OUT.cobs_classic [flags]               (:163-244)
 //   cobs_gpu_query compact-construct INPUT OUT.cobs_compact [flags] [-p PAGE]     (:294-380)
 //   cobs_gpu_query classic-combine IN_DIR OUT.cobs_classic                        (:1044-1060)
@@ -187,6 +188,91 @@ int doc_tool(int argc, char** argv, bool dump) {
     return 0;
 }
 
+// `cobs print-parameters [-h H] [-f FPR] [-n N]` (reference src/cobs.cpp:532-568): the signature size ratio
+// -h / ln(1 - fpr^(1/h)) (cobs/util/calc_signature_size.cpp:17-24), or with -n the signature size
+// ceil(n * ratio) (:26-34) in bits and bytes.  -n takes the reference's byte-size spellings (4096, 4K, 4Ki, 2Mi ...).
+int print_parameters(int argc, char** argv) {
+    unsigned num_hashes = 1;
+    double fpr = 0.3;
+    uint64_t num_elements = 0;
+    auto size_arg = [](const char* t, uint64_t& out) {
+        char* end = nullptr;
+        const double v = std::strtod(t, &end);
+        if (end == t || v < 0) return false;
+        double unit = 1;
+        if (*end != 0) {
+            const char* units = "KMGTPE";
+            const char c = *end >= 'a' && *end <= 'z' ? (char)(*end - 32) : *end;
+            const char* u = std::strchr(units, c);
+            if (u != nullptr) {
+                const bool iec = end[1] == 'i';
+                unit = std::pow(iec ? 1024.0 : 1000.0, (double)(u - units + 1));
+                end += iec ? 2 : 1;
+            }
+            if (*end == 'B' || *end == 'b') ++end;
+            if (*end != 0) return false;
+        }
+        out = (uint64_t)(v * unit);
+        return true;
+    };
+    for (int i = 0; i < argc; ++i) {
+        const std::string a = argv[i];
+        if ((a == "-h" || a == "--num-hashes") && i + 1 < argc) num_hashes = (unsigned)std::strtoul(argv[++i], nullptr, 10);
+        else if ((a == "-f" || a == "--false-positive-rate") && i + 1 < argc) fpr = std::strtod(argv[++i], nullptr);
+        else if ((a == "-n" || a == "--num-elements") && i + 1 < argc && size_arg(argv[i + 1], num_elements)) ++i;
+        else { std::fprintf(stderr, "usage: cobs_gpu_query print-parameters [-h NUM_HASHES] [-f FALSE_POSITIVE_RATE] [-n NUM_ELEMENTS]\n"); return 1; }
+    }
+    const double ratio = -(double)num_hashes / std::log(1 - std::pow(fpr, 1 / (double)num_hashes));
+    if (!(ratio > 0)) {          // (the reference dies here: die_unless(result > 0))
+        std::fprintf(stderr, "EXCEPTION: no signature size for %u hashes at false positive rate %g\n", num_hashes, fpr);
+        return 1;
+    }
+    if (num_elements == 0) {
+        std::cout << ratio << '\n';
+        return 0;
+    }
+    const uint64_t signature_size = (uint64_t)std::ceil((double)num_elements * ratio);
+    // tlx::format_iec_units (tlx is an un-vendored submodule of the reference; its published form): the number over
+    // the largest power of 1024 below it, three decimals, a space and "", "Ki", "Mi" ...
+    double scaled = (double)(signature_size / 8);
+    unsigned scale = 0;
+    static const char* endings[] = {"", "Ki", "Mi", "Gi", "Ti", "Pi", "Ei"};
+    while (scaled >= 1024.0) { scaled /= 1024.0; ++scale; }
+    char iec[64];
+    std::snprintf(iec, sizeof iec, "%.3f %s", scaled, endings[scale]);
+    std::cout << "signature_size = " << signature_size << '\n';
+    std::cout << "signature_bytes = " << signature_size / 8 << " = " << iec << '\n';
+    return 0;
+}
+
+// `cobs print-kmers QUERY [-k K]` (reference src/cobs.cpp:570-599): the canonical form of the query's k-mers, one per
+// line, "Invalid DNA base pair: ..." for one with a character outside ACGT.  Like the reference it walks
+// i < |query| - k: the query's LAST k-mer is not printed (and a query shorter than k prints nothing here; there the
+// unsigned difference wraps).
+int print_kmers(int argc, char** argv) {
+    std::string query;
+    unsigned k = 31;
+    bool have = false;
+    for (int i = 0; i < argc; ++i) {
+        const std::string a = argv[i];
+        if ((a == "-k" || a == "--kmer-size") && i + 1 < argc) k = (unsigned)std::strtoul(argv[++i], nullptr, 10);
+        else if (!have && (a.empty() || a[0] != '-')) { query = a; have = true; }
+        else { have = false; break; }
+    }
+    if (!have || k == 0) {
+        std::fprintf(stderr, "usage: cobs_gpu_query print-kmers QUERY [-k KMER_SIZE]\n");
+        return 1;
+    }
+    std::vector<char> kmer(k);
+    for (size_t i = 0; i + k < query.size(); ++i) {
+        if (!canonicalize_kmer(query.data() + i, kmer.data(), k))
+            std::cout << "Invalid DNA base pair: " << std::string(query.data() + i, k) << std::endl;
+        else
+            std::cout << std::string(kmer.data(), k) << '\n';
+    }
+    return 0;
+}
+
 }  // namespace
 
 // -> -1 if argv[1] is not one of the sub-tools, else the exit code
@@ -207,6 +293,8 @@ static int tools(int argc, char** argv) {
     const std::string tool = argv[1];
     if (tool == "doc-list") return doc_tool(argc - 2, argv + 2, false);
     if (tool == "doc-dump") return doc_tool(argc - 2, argv + 2, true);
+    if (tool == "print-parameters") return print_parameters(argc - 2, argv + 2);
+    if (tool == "print-kmers") return print_kmers(argc - 2, argv + 2);
     if (tool == "classic-construct") return construct(argc - 2, argv + 2, false);
     if (tool == "compact-construct") return construct(argc - 2, argv + 2, true);
     if (tool == "classic-combine" || tool == "compact-construct-combine") {

@@ -360,3 +360,43 @@ def test_doc_list_and_doc_dump_sub_tools(oracle, golden_dir):
     text = os.path.join(golden_dir, "documents", "text")
     r = _run("doc-dump", text, "-k", "7")
     assert r.returncode == 0 and "Invalid DNA base pair: " in r.stdout
+
+
+def test_print_parameters_and_print_kmers_sub_tools(oracle):
+    """`cobs print-parameters` / `cobs print-kmers` (reference src/cobs.cpp:532-599, host only): the sizing formula of
+    cobs/util/calc_signature_size.cpp:17-34 against the checker's, the canonical k-mers against the checker's
+    canonicalize_kmer -- including the reference's loop bound, which leaves out a query's last k-mer"""
+    import subprocess
+    from oracle import construct as OC
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cobs_amd", "cobs_gpu_query")
+    assert os.path.exists(tool), "build cobs_amd/cobs_gpu_query first (make -C cobs_amd/csrc)"
+
+    def _run(*args):
+        return subprocess.run([tool] + list(args), capture_output=True, text=True, timeout=60)
+    r = _run("print-parameters")
+    assert r.returncode == 0 and r.stdout == "%g\n" % (-1 / np.log(1 - 0.3))           # ostream's default: 6 digits
+    for h, f, n_text, n in ((1, 0.3, "1000", 1000), (3, 0.1, "4Mi", 4 << 20), (2, 0.01, "5M", 5 * 10 ** 6), (7, 0.5, "123456789", 123456789)):
+        r = _run("print-parameters", "-h", str(h), "-f", str(f), "-n", n_text)
+        assert r.returncode == 0, r.stderr
+        want = OC.calc_signature_size(n, h, f)
+        lines = r.stdout.splitlines()
+        assert lines[0] == "signature_size = %d" % want
+        assert lines[1].startswith("signature_bytes = %d = " % (want // 8))
+        num, unit = lines[1].split(" = ")[2].split(" ") if lines[1].count(" ") == 5 else (lines[1].split(" = ")[2].strip(), "")
+        scale = {"": 0, "Ki": 1, "Mi": 2, "Gi": 3}[unit]
+        assert abs(float(num) * 1024 ** scale - want // 8) <= 0.0005 * 1024 ** scale and float(num) < 1024
+    assert _run("print-parameters", "-f", "1.5").returncode != 0                          # no such filter
+    assert _run("print-parameters", "-n", "lots").returncode != 0
+    rng = np.random.default_rng(5)
+    for k in (31, 4, 15):
+        q = "".join(rng.choice(list("ACGT"), size=80)) + "N" + "".join(rng.choice(list("ACGT"), size=40))
+        r = _run("print-kmers", q, "-k", str(k))
+        assert r.returncode == 0, r.stderr
+        want = []
+        for i in range(len(q) - k):                                                       # (not len - k + 1: as the reference)
+            t = q[i:i + k].encode()
+            canon, good = oracle.canonicalize_kmer(t)
+            want.append(canon.decode() if good else "Invalid DNA base pair: " + t.decode())
+        assert r.stdout.splitlines() == want, k
+    assert _run("print-kmers", "ACGT", "-k", "31").stdout == ""
+    assert _run("print-kmers").returncode != 0
