@@ -41,8 +41,11 @@ __global__ __launch_bounds__(64) void probe(const uint8_t* table, uint64_t table
         for (int r = 0; r < 8; ++r) {
             const uint64_t h = mix64(((uint64_t)blockIdx.x * 1024u + t + r) * 8u + grp + salt);
             const uint32_t p = (tile / 13u) & 7u;
-            const uint64_t off = local ? pg.base[p] + (h % pg.rows[p]) * pitch + (uint64_t)(tile % 13u) * 128u
-                                       : (h % (table_bytes / 128u)) * 128u;
+            // local 2: the same sub-index stored COLUMN-major in 128-byte columns (a tile's lines are one contiguous
+            // array of rows[p] lines instead of lines 1664 bytes apart)
+            const uint64_t off = local == 2 ? pg.base[p] + ((uint64_t)(tile % 13u) * pg.rows[p] + h % pg.rows[p]) * 128u
+                                 : local ? pg.base[p] + (h % pg.rows[p]) * pitch + (uint64_t)(tile % 13u) * 128u
+                                         : (h % (table_bytes / 128u)) * 128u;
             // (the kernel pads a query's last block with the all-zero row, which stays cached: no traffic)
             x[r] = t + r < trips ? *reinterpret_cast<const u32x4*>(table + off + col * 16u) : acc;
         }
@@ -88,9 +91,14 @@ int main(int argc, char** argv) {
         {"gather only, 20 lines per (query, tile), the tile's column ", 20, 0, 1},
         {"50-bp reads: 20 lines read, 8 lines (1 KiB) written, anywhere", 20, 8, 0},
         {"50-bp reads: 20 lines read, 8 lines (1 KiB) written, column  ", 20, 8, 1},
+        {"50-bp reads: 20 read, 8 written, COLUMN-MAJOR table          ", 20, 8, 2},
         {"100-bp reads: 70 lines read, 8 lines written, column         ", 70, 8, 1},
+        {"100-bp reads: 70 read, 8 written, COLUMN-MAJOR table         ", 70, 8, 2},
         {"150-bp reads: 120 lines read, 8 lines written, column        ", 120, 8, 1},
         {"1000-k-mer queries: 1000 lines read, 16 lines (u16) written  ", 1000, 16, 1},
+        {"1000-k-mer queries: 1000 read, 16 written, COLUMN-MAJOR table", 1000, 16, 2},
+        {"gather only, 1000 lines per (query, tile), the tile's column ", 1000, 0, 1},
+        {"gather only, 1000 lines, COLUMN-MAJOR table                  ", 1000, 0, 2},
         {"stores only: 8 lines per (query, tile)                       ", 0, 8, 1},
     };
     if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(probe), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
