@@ -274,6 +274,8 @@ def test_full_geometries_from_20_gb_files(gpu_lib, oracle, tmp_path, shape):
     width = cfg["page_size"]
     size = sum(cfg["signature_sizes"]) * width
     assert size > 20 * 10 ** 9
+    if shutil.disk_usage(where).free <= size + (2 << 30) and os.path.isdir("/dev/shm"):
+        where = "/dev/shm"                                       # (pytest's tmp directory is short of space: a tmpfs)
     free = shutil.disk_usage(where).free
     assert free > size + (2 << 30), "needs %.1f GB of scratch space under %s" % (size / 1e9, where)
     path = os.path.join(where, "cobs_test_%d_%s.cobs_compact" % (os.getpid(), shape))
