@@ -92,7 +92,7 @@ Part::~Part() {
         for (auto* p2 : c.d_pages2) if (p2) (void)hipFree(p2);
     }
     if (d_tpages) (void)hipFree(d_tpages);
-    if (file_pinned && file) (void)hipHostUnregister(const_cast<uint8_t*>(file->data()));
+    if (file_pinned && file && pin_base) (void)hipHostUnregister(pin_base);       // (`file`: null in a moved-from Part)
 }
 
 StreamBufs::~StreamBufs() {
@@ -189,22 +189,33 @@ static cobs_gpu_status stage_index(cobs_gpu_index* ix, std::vector<std::unique_p
             // Pin the read-only mapping so that the copy engine reads it directly (no packing
             // through staging buffers).  Not every kernel/driver allows pinning file pages;
             // if it fails the staged path is used.
-            if (!ix->tune.no_pin) {
-                hipError_t pe = hipHostRegister(const_cast<uint8_t*>(pt.file->data()), pt.file->size(),
-                                                hipHostRegisterReadOnly);
+            // Only the pages this handle HOLDS are pinned (whole 4 KiB pages around them): a shard of an N-way sharded
+            // open reads one contiguous block of sub-indexes, and N ranks pinning all of a 184 GB mapping each would
+            // pay N times for pages N - 1 of them never touch.
+            uint64_t lo = pt.file->size(), hi = 0;
+            for (const VPage& v : pt.held) {
+                const uint64_t o = pt.meta.page_offset(v.fp);
+                lo = std::min(lo, o);
+                hi = std::max(hi, o + pt.meta.signature_sizes[v.fp] * pt.meta.page_row_bytes());
+            }
+            lo = lo / 4096 * 4096;
+            hi = std::min<uint64_t>(round_up(hi, 4096), pt.file->size());
+            if (!ix->tune.no_pin && lo < hi) {
+                uint8_t* base = const_cast<uint8_t*>(pt.file->data()) + lo;
+                hipError_t pe = hipHostRegister(base, hi - lo, hipHostRegisterReadOnly);
                 if (pe != hipSuccess) {
                     (void)hipGetLastError();
-                    pe = hipHostRegister(const_cast<uint8_t*>(pt.file->data()), pt.file->size(), hipHostRegisterDefault);
+                    pe = hipHostRegister(base, hi - lo, hipHostRegisterDefault);
                 }
-                if (pe == hipSuccess) pt.file_pinned = true;
+                if (pe == hipSuccess) { pt.file_pinned = true; pt.pin_base = base; }
                 else (void)hipGetLastError();
             }
             if (pt.file_pinned) {
                 // the device-visible address of the mapping and, per chunk, where its slices start in the
                 // file: the row-selective pass (fetch_kernels.hip) reads looked-up rows straight from it
                 void* dp = nullptr;
-                if (hipHostGetDevicePointer(&dp, const_cast<uint8_t*>(pt.file->data()), 0) == hipSuccess && dp) {
-                    pt.file_dev = static_cast<const uint8_t*>(dp);
+                if (hipHostGetDevicePointer(&dp, pt.pin_base, 0) == hipSuccess && dp) {
+                    pt.file_dev = static_cast<const uint8_t*>(dp) - lo;      // (offsets stay offsets into the file)
                     for (Chunk& c : pt.chunks) {
                         std::vector<uint64_t> src(c.vp.size());
                         for (size_t k = 0; k < c.vp.size(); ++k)

@@ -168,7 +168,8 @@ struct Part {
     uint64_t resident_bytes = 0;             // what the held slices need when they stay in HBM
     // streaming (BASELINE config 5: index larger than the HBM budget)
     std::unique_ptr<MappedFile> file;        // source of the chunks
-    bool file_pinned = false;                // the mapping is registered with HIP: DMA straight from it
+    bool file_pinned = false;                // the held pages of the mapping are registered with HIP: DMA straight from them
+    uint8_t* pin_base = nullptr;             // ... first registered byte (for hipHostUnregister)
     const uint8_t* file_dev = nullptr;       // ... and this is its device-visible address (kernels read it over PCIe)
     bool synthetic = false;
     bool built = false;                      // rows are produced in place by index construction
