@@ -224,12 +224,16 @@ static cobs_gpu_status stage_index(cobs_gpu_index* ix, std::vector<std::unique_p
                         HIP_TRY(hipMemcpy(c.d_src, src.data(), 8 * src.size(), hipMemcpyHostToDevice));
                         for (auto& p2 : c.d_pages2) HIP_TRY(hipMalloc((void**)&p2, sizeof(PageDev) * c.vp.size()));
                     }
-                    // the chunks of equal pitch as one unit each (pass.cpp uses them when every chunk is fetched by rows)
+                    // every RUN of consecutive chunks of equal pitch as one unit (pass.cpp uses them when every chunk is
+                    // fetched by rows).  Runs, not all chunks of a pitch: the units of a pass are scanned in this
+                    // order, and a top-k pass without score rows leaves its candidates in unit order, which K3 takes
+                    // to be DOCUMENT order when it cuts ties at the k-th score (topk_kernel<.., POOL>).  [Merging
+                    // pages 0, 1, 3 around a column-sliced page 2 returned a document of page 3 in place of one of
+                    // page 2 with the same score: scripts/fuzz_soak.sh, seed 35.]
                     if (pt.chunks.size() > 1) {
                         for (const Chunk& c : pt.chunks) {
                             Chunk* g = nullptr;
-                            for (Chunk& have : pt.fetch_groups)
-                                if (have.pitch == c.pitch) g = &have;
+                            if (!pt.fetch_groups.empty() && pt.fetch_groups.back().pitch == c.pitch) g = &pt.fetch_groups.back();
                             if (!g) {
                                 pt.fetch_groups.emplace_back();
                                 g = &pt.fetch_groups.back();
@@ -266,6 +270,19 @@ static cobs_gpu_status stage_index(cobs_gpu_index* ix, std::vector<std::unique_p
                             HIP_TRY(hipMemcpy(g.d_src, src.data(), 8 * src.size(), hipMemcpyHostToDevice));
                             for (auto& p2 : g.d_pages2) HIP_TRY(hipMalloc((void**)&p2, sizeof(PageDev) * g.vp.size()));
                         }
+                    }
+                    if (ix->tune.trace) {
+                        auto show = [&](const char* what, const Chunk& c) {
+                            std::fprintf(stderr, "[cobs_gpu] file %zu %s: pitch %u, %zu bytes%s:", i, what, c.pitch, (size_t)c.bytes,
+                                         c.row_range ? " (row range)" : "");
+                            for (size_t k = 0; k < c.vp.size(); ++k)
+                                std::fprintf(stderr, " [page %u cols %llu+%llu rows %llu+%llu slot0 %u]", c.vp[k].fp,
+                                             (unsigned long long)c.vp[k].col0, (unsigned long long)c.vp[k].ncols,
+                                             (unsigned long long)c.pages[k].row0, (unsigned long long)c.pages[k].sig, c.pages[k].slot0);
+                            std::fprintf(stderr, "\n");
+                        };
+                        for (const Chunk& c : pt.chunks) show("chunk", c);
+                        for (const Chunk& c : pt.fetch_groups) show("fetch group", c);
                     }
                     if (!ix->stream.hashed) HIP_TRY(hipEventCreateWithFlags(&ix->stream.hashed, hipEventDisableTiming));
                 } else {

@@ -7,6 +7,9 @@
 //                std::vector<SearchResult>& result, double threshold = 0.0,
 //                size_t num_results = 0) = 0; }                            (cobs/query/search.hpp:29-47)
 //   class  cobs::ClassicSearch : Search { ClassicSearch(std::string path); ... } (classic_search.hpp:19-37)
+//   class  cobs::IndexSearchFile, ClassicIndexMMapSearchFile(path), CompactIndexMMapSearchFile(path) and
+//          ClassicSearch(std::shared_ptr<IndexSearchFile>), ClassicSearch(std::vector<std::shared_ptr<...>>)
+//          (cobs/query/index_file.hpp:19-49, */mmap_search_file.hpp, classic_search.cpp:41-49)
 //
 // Same names, argument meaning and defaults.  Differences, all at the error
 // boundary: where the reference terminates the process (exit/abort on a short
@@ -17,6 +20,9 @@
 #pragma once
 
 #include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -57,8 +63,51 @@ public:
     virtual cobs_gpu_index* handle() const = 0;
 };
 
+//! The reference hands ClassicSearch its index files as objects (cobs/query/index_file.hpp:19-49) made from a path
+//! by the class of their kind, which refuses a file of the other kind when it reads the header
+//! (classic_index/mmap_search_file.cpp:21-25, compact_index/mmap_search_file.cpp:20-27).  Here such an object is
+//! the checked NAME of a file: the engine maps and stages it when a ClassicSearch is made from it.
+class IndexSearchFile {
+public:
+    virtual ~IndexSearchFile() = default;
+    const std::string& path() const { return path_; }
+
+protected:
+    IndexSearchFile(const std::string& path, const char* kind_word) : path_(path) {
+        // every index file starts with "COBS:" and the word of its kind (cobs/file/header.cpp)
+        const std::string want = std::string("COBS:") + kind_word;
+        char head[32] = {0};
+        std::FILE* f = std::fopen(path.c_str(), "rb");
+        if (!f) throw Error(COBS_GPU_ERR_OPEN, "cannot open index file " + path);
+        const size_t got = std::fread(head, 1, want.size(), f);
+        std::fclose(f);
+        if (got != want.size() || std::memcmp(head, want.data(), want.size()) != 0)
+            throw Error(COBS_GPU_ERR_FORMAT, path + " is not a " + kind_word + " file");
+    }
+
+private:
+    std::string path_;
+};
+
+class ClassicIndexMMapSearchFile : public IndexSearchFile {
+public:
+    explicit ClassicIndexMMapSearchFile(const std::string& path) : IndexSearchFile(path, "CLASSIC_INDEX") {}
+};
+
+class CompactIndexMMapSearchFile : public IndexSearchFile {
+public:
+    explicit CompactIndexMMapSearchFile(const std::string& path) : IndexSearchFile(path, "COMPACT_INDEX") {}
+};
+
 class ClassicSearch : public BatchSearch {
 public:
+    //! one index file object / several, searched together (classic_search.cpp:41-49)
+    explicit ClassicSearch(const std::shared_ptr<IndexSearchFile>& index, int device = -1, uint64_t hbm_budget_bytes = 0)
+        : ClassicSearch(std::vector<std::string>{index->path()}, device, hbm_budget_bytes) {}
+    explicit ClassicSearch(const std::vector<std::shared_ptr<IndexSearchFile>>& indices, int device = -1,
+                           uint64_t hbm_budget_bytes = 0)
+        : ClassicSearch(paths_of(indices), device, hbm_budget_bytes) {}
+
     //! auto-detect classic / compact and stage the index into HBM
     //! hbm_budget_bytes > 0: an index larger than the budget is streamed chunk-wise at every
     //! search (the role of the reference's mmap / AIO back-ends for indexes beyond memory)
@@ -139,6 +188,11 @@ public:
 private:
     static void check(cobs_gpu_status st) {
         if (st != COBS_GPU_OK) throw Error(st, cobs_gpu_last_error());
+    }
+    static std::vector<std::string> paths_of(const std::vector<std::shared_ptr<IndexSearchFile>>& indices) {
+        std::vector<std::string> out;
+        for (const auto& i : indices) out.push_back(i->path());
+        return out;
     }
     cobs_gpu_index* ix_ = nullptr;
     std::vector<cobs_gpu_hit> hits_;

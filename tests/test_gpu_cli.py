@@ -181,3 +181,63 @@ def test_construction_sub_tools(gpu_lib, oracle, golden_dir, tmp_path):
     want = "".join("%s\t%d\n" % (n, s) for (_, _, n, s) in oracle.search(oracle.Index.open(pc), Q50.encode(), 0.0))
     assert r.returncode == 0 and r.stdout == want
 
+
+
+_INDEX_OBJECT_PROGRAM = r'''
+// the reference's way of making a search from index-file OBJECTS (classic_search.cpp:41-49; its tests do
+// ClassicSearch s(std::make_shared<ClassicIndexMMapSearchFile>(path)), tests/classic_index_query.cpp)
+#include <cstdio>
+#include <memory>
+#include "cobs_gpu_search.hpp"
+int main(int argc, char** argv) {
+    using namespace cobs_gpu;
+    if (argc < 4) return 2;
+    try {
+        std::vector<SearchResult> r;
+        ClassicSearch one(std::make_shared<ClassicIndexMMapSearchFile>(argv[1]));
+        one.search(argv[3], r, 0.0, 5);
+        for (const auto& x : r) std::printf("one\t%s\t%u\n", x.doc_name, x.score);
+        std::vector<std::shared_ptr<IndexSearchFile>> both{std::make_shared<ClassicIndexMMapSearchFile>(argv[1]),
+                                                         std::make_shared<CompactIndexMMapSearchFile>(argv[2])};
+        ClassicSearch two(both);
+        two.search(argv[3], r, 0.0, 12);
+        for (const auto& x : r) std::printf("two\t%s\t%u\n", x.doc_name, x.score);
+        try {
+            CompactIndexMMapSearchFile wrong(argv[1]);          // a classic file
+            std::printf("accepted a file of the other kind\n");
+        } catch (const Error& e) { std::printf("refused %d\n", (int)e.status); }
+        try {
+            ClassicIndexMMapSearchFile missing("/nonexistent/x.cobs_classic");
+            std::printf("accepted a missing file\n");
+        } catch (const Error& e) { std::printf("refused %d\n", (int)e.status); }
+    } catch (const std::exception& e) { std::printf("EXCEPTION %s\n", e.what()); return 1; }
+    return 0;
+}
+'''
+
+
+def test_search_from_index_file_objects(gpu_lib, oracle, golden_dir, tmp_path):
+    """ClassicSearch(std::shared_ptr<IndexSearchFile>) and the vector form (classic_search.cpp:41-49) of the C++ mirror:
+    a program written the way the reference's tests make their searches, against the oracle; a file of the other kind
+    and a missing file are refused by the object's constructor"""
+    from cobs_amd import _capi
+    src = tmp_path / "index_objects.cpp"
+    src.write_text(_INDEX_OBJECT_PROGRAM)
+    exe = str(tmp_path / "index_objects")
+    lib_dir = os.path.join(ROOT, "cobs_amd")
+    cc = subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe,
+                         "-L", lib_dir, "-lcobs_gpu", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"],
+                        capture_output=True, text=True, timeout=300)
+    assert cc.returncode == 0, cc.stderr
+    classic = os.path.join(golden_dir, "c1.cobs_classic")
+    compact = cases.make_compact(cases.tmp(tmp_path, "o.cobs_compact"), 300, 16, [700, 900, 500], 1, 31, 1, 0.3, 4,
+                                 planted={7: 1.0}, query=Q50.encode())
+    r = subprocess.run([exe, classic, compact, Q50], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.splitlines()
+    i1, i2 = oracle.Index.open(classic), oracle.Index.open(compact)
+    want1 = [(n, s) for (_f, _d, n, s) in oracle.search([i1], Q50.encode(), 0.0, 5)]
+    want2 = [(n, s) for (_f, _d, n, s) in oracle.search([i1, i2], Q50.encode(), 0.0, 12)]
+    assert [tuple(ln.split("\t")[1:]) for ln in lines if ln.startswith("one\t")] == [(n, str(s)) for n, s in want1]
+    assert [tuple(ln.split("\t")[1:]) for ln in lines if ln.startswith("two\t")] == [(n, str(s)) for n, s in want2]
+    assert lines[-2:] == ["refused %d" % _capi.ERR_FORMAT, "refused %d" % _capi.ERR_OPEN]

@@ -299,3 +299,29 @@ def test_row_range_chunks(gpu_lib, oracle, tmp_path, monkeypatch, kind, no_pin):
     monkeypatch.setenv("COBS_GPU_ROW_RANGES", "0")
     s2 = _compare(gpu_lib, oracle, path, budget, queries)
     del s2
+
+
+def test_topk_ties_across_fetch_units_keep_document_order(gpu_lib, oracle, tmp_path):
+    """A top-k pass without score rows leaves every tile's k best in the order the pass scanned its units, and K3 cuts
+    ties at the k-th score in that order -- which has to be DOCUMENT order (classic_search.cpp:134-145).  This file
+    under this budget is five chunks: pages 0, 1 whole (pitch 144), page 2 in two column slices (H = 2: columns;
+    pitches 80 and 64), page 3 whole (144).  When a small batch fetches every chunk by rows the engine merges chunks
+    of one pitch into one fetch + one scan; merging pages 0, 1 and 3 AROUND page 2 returned document 4046 (page 3) in
+    place of 3011 (page 2) at equal score (found by scripts/fuzz_soak.sh, seed 35): only runs of consecutive chunks
+    may merge."""
+    D, ps, sigs, H = 4318, 136, [2382, 2710, 3328, 2604], 2
+    q_long = oracle.random_sequence(500, 902)
+    path = cases.make_compact(cases.tmp(tmp_path, "ties.cobs_compact"), D, ps, sigs, H, 31, 1, 0.3, 2,
+                              planted={0: 1.0, D - 1: 0.7}, query=q_long[:200])
+    queries = [q_long[:200], q_long[100:131], q_long[:251]]
+    ix = oracle.Index.open(path)
+    for alpha in (0, 1):                      # rows whenever they fit / the engine's cost rule
+        s = gpu_lib.Search(path, hbm_budget=899558)
+        s.set_tuning("row_fetch_alpha", alpha)
+        for lim in (5, 1, 2, 3, 4, 7, 16, 40, 100):
+            want = [cases.oracle_results([ix], q, 0.0, lim) for q in queries]
+            assert s.search_hits(queries, 0.0, lim) == want, (alpha, lim)
+            assert [s.search_hits([q], 0.0, lim)[0] for q in queries] == want, (alpha, lim)
+        if alpha == 0:
+            assert s.stream_counters()[0] > 0 and s.stream_counters()[1] == 0    # every pass fetched by rows
+        del s
