@@ -188,3 +188,61 @@ def test_random_shards(gpu_lib, oracle, tmp_path):
                         src[c.src_offset + h * c.src_pitch:c.src_offset + h * c.src_pitch + c.width]
             ref = np.ascontiguousarray(want[out[0]:out[0] + out[1]].astype(np.uint32)).view(np.uint8).reshape(-1)
             assert np.array_equal(got, ref), (path, N, mode, r)
+
+
+@pytest.mark.parametrize("streamed", [False, True])
+def test_random_ties(gpu_lib, oracle, tmp_path, monkeypatch, streamed):
+    """Ties at the cut are where an ordering mistake hides (the reference orders by (score desc, document asc) and
+    cuts there, classic_search.cpp:134-145): queries of 1..9 terms against dense filters score 0..9 over thousands of
+    documents, so every limit cuts through a run of equal scores.  One or two index files per handle, resident or
+    streamed under a random budget (whole chunks, row ranges, column slices, rows fetched), limits from 1 to beyond
+    the document count, thresholds incl. the all-documents default call, batch and single-query calls -- against the
+    oracle."""
+    from cobs_amd import _capi
+    monkeypatch.setenv("COBS_GPU_ROW_RANGE_MIN", "48")
+    rng = np.random.default_rng(31337 + int(streamed) + 100003 * int(os.environ.get("COBS_FUZZ_SEED", "0")))
+    done = 0
+    for idx in range(24):
+        k = int(rng.choice([15, 31, 31]))
+        paths = []
+        for f in range(int(rng.choice([1, 1, 2]))):
+            H = int(rng.choice([1, 1, 2]))
+            dens = float(rng.choice([0.3, 0.5, 0.7]))
+            if rng.random() < 0.4:
+                D, S = int(rng.integers(100, 5000)), int(rng.integers(200, 2500))
+                paths.append(cases.make_classic(cases.tmp(tmp_path, "t%d_%d.cobs_classic" % (idx, f)), D, S, H, k, 1, dens, 50 * idx + f))
+                size = S * ((D + 7) // 8)
+            else:
+                ps = int(rng.choice([8, 16, 48, 64, 136, 256]))
+                P = int(rng.integers(2, 7))
+                D = (P - 1) * 8 * ps + int(rng.integers(1, 8 * ps + 1))
+                sigs = [int(x) for x in rng.integers(150, 2500, size=P)]
+                paths.append(cases.make_compact(cases.tmp(tmp_path, "t%d_%d.cobs_compact" % (idx, f)), D, ps, sigs, H, k, 1, dens, 50 * idx + f))
+                size = sum(sigs) * ps
+        q_long = oracle.random_sequence(200, 4000 + idx)
+        queries = [q_long[o:o + k - 1 + int(rng.integers(1, 10))] for o in rng.integers(0, 150, size=int(rng.integers(1, 12)))]
+        budget = 0
+        if streamed:
+            budget = int(sum(os.path.getsize(p) for p in paths) * float(rng.choice([0.2, 0.4, 0.7])))
+            monkeypatch.setenv("COBS_GPU_STREAM_PACKED", str(idx % 2))
+        try:
+            s = gpu_lib.Search(paths if len(paths) > 1 else paths[0], hbm_budget=budget)
+        except gpu_lib.CobsGpuError as e:
+            assert streamed and e.status == _capi.ERR_CAPACITY, (paths, budget, e)
+            continue
+        if streamed:
+            mode = int(rng.integers(0, 3))
+            if mode == 1:
+                s.set_tuning("row_fetch_alpha", 0)
+            elif mode == 2:
+                s.set_tuning("row_fetch", 0)
+        ixs = [oracle.Index.open(p) for p in paths]
+        total = sum(ix.num_docs for ix in ixs)
+        for lim in [int(x) for x in rng.choice([1, 2, 3, 5, 8, 13, 64, 100, 1000, total, total + 5], size=4, replace=False)] + [0]:
+            for t in (0.0, float(rng.choice([0.2, 0.5, 1.0]))):
+                want = [cases.oracle_results(ixs, q, t, lim) for q in queries]
+                assert s.search_hits(queries, t, lim) == want, (paths, budget, t, lim)
+                qi = int(rng.integers(0, len(queries)))
+                assert s.search_hits([queries[qi]], t, lim)[0] == want[qi], (paths, budget, t, lim, qi)
+        done += 1
+    assert done >= 12
