@@ -140,6 +140,21 @@ hipError_t launch_remap_rows(const RemapArgs& a, uint64_t entries, bool idx64, h
     return hipGetLastError();
 }
 
+// The four flag words of a batch (first invalid query | - | 64-bit hit count) back to zero at the head of a pass.
+// A kernel, not hipMemsetD32Async: small host passes are captured into hipGraphs, and a captured MEMSET node of a graph
+// that is replayed after other graphs were instantiated on the stream wrote 16 bytes of stale host data over the
+// flags instead of zeros (ROCm 7.2, MI355X; the pass then reported "invalid base pair in query 998395903" for a
+// valid query -- found by tests/test_gpu_fuzz.py::test_random_ties under COBS_FUZZ_SEED=14).  A kernel node carries
+// its arguments by value.
+__global__ void clear_flags_kernel(uint32_t* flags) {
+    if (threadIdx.x < 4u) flags[threadIdx.x] = 0u;
+}
+
+hipError_t launch_clear_flags(uint32_t* flags, hipStream_t stream) {
+    hipLaunchKernelGGL(clear_flags_kernel, dim3(1), dim3(64), 0, stream, flags);
+    return hipGetLastError();
+}
+
 hipError_t launch_add_scores(const AddScoresArgs& a, hipStream_t stream) {
     if (a.nq == 0 || a.nslots == 0) return hipSuccess;
     if ((a.nslots % 8u) != 0 || (a.dst_offset % 8u) != 0 || (a.dst_stride % 8u) != 0) return hipErrorInvalidValue;

@@ -95,6 +95,9 @@ static cobs_gpu_status host_pass_begin(cobs_gpu_index* ix, int slot, const char*
         if (b->graph_exec && b->graph_key == key) {
             set_run_state(b, threshold, topk, !hits_only);
             if (threshold > 0.0) stage_thresholds(b, threshold);     // the graph's H2D nodes read them now
+            if (ix->tune.trace)
+                std::fprintf(stderr, "[cobs_gpu] slot %d: graph %016llx replayed (t %g, k %zu, h_res %p)\n", slot,
+                             (unsigned long long)key, threshold, topk, (void*)b->h_res.p);
             HIP_TRY(hipGraphLaunch(b->graph_exec, b->own_stream));
             b->graph_run = true;
             b->run_seq++;
@@ -155,6 +158,10 @@ static cobs_gpu_status host_pass_begin(cobs_gpu_index* ix, int slot, const char*
                     }
                     b->graph_exec = exec;
                     b->graph_key = make_key();          // with the addresses as they are now
+                    if (ix->tune.trace)
+                        std::fprintf(stderr, "[cobs_gpu] slot %d: graph %016llx captured (was candidate %016llx; t %g, k %zu, h_res %p + %zu)\n",
+                                     slot, (unsigned long long)b->graph_key, (unsigned long long)key, threshold, topk,
+                                     (void*)b->h_res.p, b->h_res.cap);
                     b->res_topk = res_topk;
                     b->res_pool = res_pool;
                     b->res_pool_n = pool_n;

@@ -38,6 +38,7 @@ hipError_t launch_fetch_rows(const FetchArgs& a, bool idx64, hipStream_t stream)
 // the rows a chunk holds; add a chunk's partial scores to the score rows.
 hipError_t launch_remap_rows(const RemapArgs& a, uint64_t entries, bool idx64, hipStream_t stream);
 hipError_t launch_add_scores(const AddScoresArgs& a, hipStream_t stream);
+hipError_t launch_clear_flags(uint32_t* flags, hipStream_t stream);
 
 // Owner-routed hit exchange (xchg_kernels.hip): count == true -> records per owner into a.cursor, else scatter.
 hipError_t launch_bucket_hits(const BucketArgs& a, bool count, hipStream_t stream);

@@ -325,7 +325,7 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
         if (b->run_seq) HIP_TRY(hipStreamWaitEvent(hs, b->run_done, 0));
     }
     // device flags: first invalid query = none, selected hits = 0
-    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)b->flags.p, 0, 4, hs));      // all zero: one fill
+    HIP_TRY(launch_clear_flags(b->flags.p, hs));      // (a kernel: a captured memset node is not safe to replay, fetch_kernels.hip)
     if (need_thr) {
         stage_thresholds(b, threshold);
         for (size_t f = 0; f < ix->parts.size(); ++f)

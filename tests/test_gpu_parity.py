@@ -649,6 +649,29 @@ def test_graph_replay_between_other_shapes(gpu_lib, oracle, tmp_path):
     assert s.graph_replays - r0 >= 25
 
 
+def test_graph_replay_of_a_shape_displaced_by_many_others(gpu_lib, oracle, tmp_path):
+    """eight shapes of one handle captured one after another (the batch keeps the current graph and three older
+    ones), then the kept ones again, oldest first: a graph that comes back after several other graphs were
+    instantiated must still clear the pass's flag words.  With the flags cleared by a captured MEMSET node such a
+    replay left 16 bytes of stale host data in them and the pass reported an invalid base in query 998395903 of a
+    one-query call (two classic files, threshold 0.2; found by test_gpu_fuzz.py::test_random_ties under
+    COBS_FUZZ_SEED=14) -- the flags are cleared by a kernel now (fetch_kernels.hip)."""
+    q = oracle.random_sequence(200, 4009)[40:75]
+    p1 = cases.make_classic(cases.tmp(tmp_path, "d0.cobs_classic"), 176, 615, 1, 31, 1, 0.3, 450)
+    p2 = cases.make_classic(cases.tmp(tmp_path, "d1.cobs_classic"), 4255, 247, 2, 31, 1, 0.7, 451)
+    ixs = [oracle.Index.open(p1), oracle.Index.open(p2)]
+    s = gpu_lib.Search([p1, p2])
+    shapes = [(0.0, 4431), (0.2, 4431), (0.0, 3), (0.2, 3), (0.2, 0), (0.0, 8), (0.2, 8), (0.0, 0)]
+    r0 = s.graph_replays
+    for t, lim in shapes:
+        for _ in range(2):                      # second sighting: captured
+            assert s.search_hits([q], t, lim) == [cases.oracle_results(ixs, q, t, lim)], (t, lim)
+    for rnd in range(3):
+        for t, lim in shapes[4:] + shapes[4:][::-1]:
+            assert s.search_hits([q], t, lim) == [cases.oracle_results(ixs, q, t, lim)], (rnd, t, lim)
+    assert s.graph_replays - r0 >= 12
+
+
 def test_graph_replay_of_two_thresholded_shapes(gpu_lib, oracle, tmp_path):
     """two captured shapes that BOTH use a threshold, of different query lengths, in rotation (A,B,A,B,...), in
     hits-only and in top-k mode: the thresholds ceil(t*T) differ per shape and reach the device through one pinned
