@@ -246,3 +246,61 @@ def test_random_ties(gpu_lib, oracle, tmp_path, monkeypatch, streamed):
                 assert s.search_hits([queries[qi]], t, lim)[0] == want[qi], (paths, budget, t, lim, qi)
         done += 1
     assert done >= 12
+
+
+def per_pass_hint(idx):
+    """every third index of test_random_pass_cuts is a large batch (queries x documents beyond the 1 Mi-entry hit pool)"""
+    return idx % 3 != 2
+
+
+@pytest.mark.parametrize("streamed", [False, True])
+def test_random_pass_cuts(gpu_lib, oracle, tmp_path, monkeypatch, streamed):
+    """One call of the host-buffer API is cut into device passes (workspace limit `pass_bytes`, pipelining over three
+    scratch batches from `pipe_chars` of query text on) whose results are concatenated: random limits that put 1..40
+    queries into a pass, batches of 20..300 ragged queries, thresholds from "everything passes" (the hit pool of a
+    pass overflows and the pass is repeated with score rows) to 1.0, limits, the all-documents default call (ordered
+    on the device from 4 queries per pass on), and now and then a query with a character outside ACGT somewhere in
+    the batch (the call reports the FIRST such query by its index in the call) -- against the oracle."""
+    from cobs_amd import _capi
+    monkeypatch.setenv("COBS_GPU_ROW_RANGE_MIN", "48")
+    rng = np.random.default_rng(8086 + int(streamed) + 100003 * int(os.environ.get("COBS_FUZZ_SEED", "0")))
+    done = 0
+    for idx in range(10):
+        k = int(rng.choice([15, 31]))
+        H = int(rng.choice([1, 1, 2]))
+        ps = int(rng.choice([16, 64, 136]))
+        P = int(rng.integers(1, 6))
+        D = (P - 1) * 8 * ps + int(rng.integers(1, 8 * ps + 1))
+        sigs = [int(x) for x in rng.integers(150, 2000, size=P)]
+        q_long = oracle.random_sequence(700, 7000 + idx)
+        path = cases.make_compact(cases.tmp(tmp_path, "p%d.cobs_compact" % idx), D, ps, sigs, H, k, 1, 0.4, 90 + idx,
+                                  planted={0: 1.0, D - 1: 0.6, D // 2: 0.8}, query=q_long[:300])
+        budget = int(os.path.getsize(path) * float(rng.choice([0.3, 0.6]))) if streamed else 0
+        try:
+            s = gpu_lib.Search(path, hbm_budget=budget)
+        except gpu_lib.CobsGpuError as e:
+            assert streamed and e.status == _capi.ERR_CAPACITY, (path, budget, e)
+            continue
+        ix = oracle.Index.open(path)
+        nq = int(rng.integers(20, 300)) if per_pass_hint(idx) else int(rng.integers(250, 420))
+        lens = rng.choice([k, k + 3, 60, 100, 300, 650], size=nq)
+        queries = [q_long[o:o + int(n)] for o, n in zip(rng.integers(0, 40, size=nq), lens)]
+        per_pass = int(rng.choice([0, 1, 2, 3, 7, 16, 40]))        # 0: the default limit, the whole batch in one pass (pool overflow)
+        s.set_tuning("pass_bytes", per_pass * s.local_counts * int(rng.choice([1, 2])))
+        s.set_tuning("pipe_chars", int(rng.choice([0, 1, 4096])))
+        for t, lim in ((0.0, 0), (float(rng.choice([0.01, 0.3])), 0), (float(rng.choice([0.0, 0.5, 1.0])), int(rng.choice([1, 4, 50, D]))),
+                       (0.8, 0)):
+            want = [cases.oracle_results([ix], q, t, lim) for q in queries]
+            assert s.search_hits(queries, t, lim) == want, (path, budget, per_pass, t, lim)
+        if idx % 2 == 0:
+            bad_at = sorted(int(x) for x in rng.choice(nq, size=2, replace=False))
+            broken = list(queries)
+            for i in bad_at:
+                pos = int(rng.integers(0, len(broken[i])))
+                broken[i] = broken[i][:pos] + b"N" + broken[i][pos + 1:]
+            with pytest.raises(gpu_lib.CobsGpuError) as ei:
+                s.search_hits(broken, 0.3, 0)
+            assert ei.value.status == _capi.ERR_INVALID_BASE and ("(query %d)" % bad_at[0]) in str(ei.value), (bad_at, str(ei.value))
+            assert s.search_hits(queries[:5], 0.3, 0) == [cases.oracle_results([ix], q, 0.3, 0) for q in queries[:5]]   # and goes on
+        done += 1
+    assert done >= 5
