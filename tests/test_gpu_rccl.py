@@ -200,3 +200,51 @@ def test_multi_handle_device_list(gpu_lib, oracle, tmp_path):
         assert e.value.status == _capi.ERR_ARG
     with pytest.raises(gpu_lib.CobsGpuError):
         gpu_lib.MultiSearch(str(tmp_path / "missing.cobs_compact"), devices=[0])
+
+
+def test_native_sharded_search_random_ties(gpu_lib, oracle, tmp_path, comm, monkeypatch):
+    """cobs_gpu_sharded_search_batch (the collective an N-GPU node calls, here over a one-rank RCCL communicator) on
+    tie-heavy inputs: queries of 1..9 terms on dense filters, one or two files, resident and streamed, random pass
+    cuts, limits through runs of equal scores, thresholds, the all-documents call with and without the shared
+    ranking -- against the oracle"""
+    import os
+    from cobs_amd import _capi
+    monkeypatch.setenv("COBS_GPU_ROW_RANGE_MIN", "48")
+    rng = np.random.default_rng(2718 + 100003 * int(os.environ.get("COBS_FUZZ_SEED", "0")))
+    done = 0
+    for idx in range(16):
+        k = int(rng.choice([15, 31]))
+        paths = []
+        for f in range(int(rng.choice([1, 2]))):
+            H = int(rng.choice([1, 2]))
+            dens = float(rng.choice([0.3, 0.6]))
+            if rng.random() < 0.3:
+                D, S = int(rng.integers(300, 4000)), int(rng.integers(200, 1500))
+                paths.append(cases.make_classic(cases.tmp(tmp_path, "n%d_%d.cobs_classic" % (idx, f)), D, S, H, k, 1, dens, 30 * idx + f))
+            else:
+                ps = int(rng.choice([16, 64, 136]))
+                P = int(rng.integers(2, 7))
+                D = (P - 1) * 8 * ps + int(rng.integers(1, 8 * ps + 1))
+                sigs = [int(x) for x in rng.integers(150, 1500, size=P)]
+                paths.append(cases.make_compact(cases.tmp(tmp_path, "n%d_%d.cobs_compact" % (idx, f)), D, ps, sigs, H, k, 1, dens, 30 * idx + f))
+        q_long = oracle.random_sequence(200, 8000 + idx)
+        queries = [q_long[o:o + k - 1 + int(rng.integers(1, 10))] for o in rng.integers(0, 150, size=int(rng.integers(1, 14)))]
+        budget = int(sum(os.path.getsize(p) for p in paths) * 0.5) if rng.random() < 0.4 else 0
+        try:
+            s = gpu_lib.Search(paths, device=0, hbm_budget=budget)
+        except gpu_lib.CobsGpuError as e:
+            assert budget and e.status == _capi.ERR_CAPACITY, (paths, budget, e)
+            continue
+        if rng.random() < 0.5:
+            s.set_tuning("pass_bytes", int(rng.integers(1, 5)) * (s.local_counts + s.total_counts) * 2)
+        ixs = [oracle.Index.open(p) for p in paths]
+        total = sum(ix.num_docs for ix in ixs)
+        combos = [(0.0, 0), (float(rng.choice([0.2, 0.5, 1.0])), 0)]
+        for lim in rng.choice([1, 2, 3, 5, 13, 100, total, total + 9], size=3, replace=False):
+            combos.append((float(rng.choice([0.0, 0.0, 0.5])), int(lim)))
+        for t, lim in combos:
+            want = [cases.oracle_results(ixs, q, t, lim) for q in queries]
+            assert s.sharded_search_hits(comm, queries, t, lim) == want, (paths, budget, t, lim)
+            assert s.sharded_search_hits(comm, queries, t, lim, split=True) == want, (paths, budget, t, lim, "split")
+        done += 1
+    assert done >= 8

@@ -234,3 +234,68 @@ def test_bench_three_ranks_cut_inside_sub_indexes(gpu_lib):
     assert len(j["per_rank"]["scan_ms"]) == 3 and j["checked_per_rank_at_least"]["rows_exchange_sums"] >= 512 // 3 - 1
     cut = j["shard_rank0"]["slot_count"]                        # rank 0's cut: inside a sub-index (12 544 slots each) ...
     assert 0 < cut < 100352 and (cut % 12544) % 1024 == 0       # ... on whole lines: 8 chunks of 16 bytes = 1024 score slots
+
+
+def _ties_worker(rank, world, port, cases_list, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["COBS_GPU_ROW_RANGE_MIN"] = "48"
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cobs_amd.distributed import ShardedSearch
+        from oracle import oracle as O
+        for no, (paths, queries, mode, budget, combos) in enumerate(cases_list):
+            ixs = [O.Index.open(p) for p in paths]
+            ss = ShardedSearch(paths if len(paths) > 1 else paths[0], device=0, shard_mode=mode, hbm_budget=budget)
+            for t, lim in combos:
+                res = ss.search_hits(queries, t, lim)
+                for q, r in zip(queries, res):
+                    assert [tuple(x) for x in r] == cases.oracle_results(ixs, q, t, lim), (no, paths, mode, budget, t, lim)
+            del ss
+        open(os.path.join(out_dir, "ties_ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_random_ties(gpu_lib, oracle, tmp_path, world):
+    """the sharded search over 2 and 3 ranks (processes sharing GPU 0, torch transport of the library's exchange plan)
+    on tie-heavy inputs: queries of 1..9 terms on dense filters, one or two files, every shard mode, resident and
+    streamed shards, limits that cut through runs of equal scores ACROSS shard boundaries, thresholds, the
+    all-documents default call -- every rank gets the oracle's result ((score desc, file, document asc) globally,
+    classic_search.cpp:134-145)"""
+    rng = np.random.default_rng(5150 + world + 100003 * int(os.environ.get("COBS_FUZZ_SEED", "0")))
+    cases_list = []
+    for idx in range(6):
+        k = int(rng.choice([15, 31]))
+        paths = []
+        for f in range(int(rng.choice([1, 2]))):
+            H = int(rng.choice([1, 2]))
+            dens = float(rng.choice([0.3, 0.6]))
+            if rng.random() < 0.3:
+                D, S = int(rng.integers(300, 4000)), int(rng.integers(200, 1500))
+                paths.append(cases.make_classic(cases.tmp(tmp_path, "w%d_%d_%d.cobs_classic" % (world, idx, f)), D, S, H, k, 1, dens, 70 * idx + f))
+            else:
+                ps = int(rng.choice([16, 64, 136]))
+                P = int(rng.integers(2, 7))
+                D = (P - 1) * 8 * ps + int(rng.integers(1, 8 * ps + 1))
+                sigs = [int(x) for x in rng.integers(150, 1500, size=P)]
+                paths.append(cases.make_compact(cases.tmp(tmp_path, "w%d_%d_%d.cobs_compact" % (world, idx, f)), D, ps, sigs, H, k, 1, dens, 70 * idx + f))
+        q_long = oracle.random_sequence(200, 6000 + idx)
+        queries = [q_long[o:o + k - 1 + int(rng.integers(1, 10))] for o in rng.integers(0, 150, size=int(rng.integers(1, 9)))]
+        mode = int(rng.integers(0, 3))
+        budget = 0
+        if rng.random() < 0.35:
+            budget = int(sum(os.path.getsize(p) for p in paths) * 0.7 / world) + 70000
+        total = sum(oracle.Index.open(p).num_docs for p in paths)
+        combos = [(0.0, 0), (float(rng.choice([0.2, 0.5, 1.0])), 0)]
+        for lim in rng.choice([1, 2, 3, 5, 13, 100, total], size=3, replace=False):
+            combos.append((float(rng.choice([0.0, 0.0, 0.5])), int(lim)))
+        cases_list.append((paths, queries, mode, budget, combos))
+    port = _free_port()
+    mp.spawn(_ties_worker, args=(world, port, cases_list, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert os.path.exists(os.path.join(str(tmp_path), "ties_ok%d" % r))
