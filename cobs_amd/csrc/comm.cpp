@@ -766,18 +766,33 @@ static cobs_gpu_status sharded_search_impl(cobs_gpu_index* ix, cobs_gpu_comm* c,
             if (s != COBS_GPU_OK && bad_query) *bad_query = g0 + bad;
             // Every rank must know whether the scan went through EVERYWHERE before anybody enters the
             // exchange: a rank that failed alone (out of memory, ...) would leave the others waiting in
-            // a collective.  (Bad input fails identically on all ranks; this covers the rest.)
-            auto all_ranks_ok = [&](cobs_gpu_status mine) -> cobs_gpu_status {
+            // a collective.  Bad input fails identically on every rank that HASHES the queries -- a rank whose shard
+            // is empty (more ranks than sub-index blocks) does not, so the ranks also agree on the first invalid
+            // query and all report it.  [Eight ranks on a four-block index answered an invalid query with "the pass
+            // failed on another rank (status 4)": found by tests/test_gpu_mock_ranks.py, the first run of this code
+            // with more than one rank.]
+            const uint32_t my_bad = s == COBS_GPU_ERR_INVALID_BASE ? 0xFFFFFFFFu - (uint32_t)(g0 + bad) : 0u;
+            auto all_ranks_ok = [&](cobs_gpu_status mine, bool scan_step = false) -> cobs_gpu_status {
                 const std::string keep = mine != COBS_GPU_OK ? std::string(cobs_gpu_last_error()) : std::string();
                 uint32_t worst = 0;
                 const cobs_gpu_status as = agree(c, b, st, (uint32_t)mine, &worst);
-                if (mine != COBS_GPU_OK) return fail(mine, keep);
                 if (as != COBS_GPU_OK) return as;
+                if (worst == COBS_GPU_ERR_INVALID_BASE && scan_step) {      // (every rank takes this branch: `worst` is the same everywhere)
+                    uint32_t first = 0;
+                    const cobs_gpu_status bs = agree(c, b, st, my_bad, &first);      // max of 2^32-1 - index: the lowest index
+                    if (bs != COBS_GPU_OK) return bs;
+                    if (mine == COBS_GPU_OK || mine == COBS_GPU_ERR_INVALID_BASE) {
+                        if (bad_query) *bad_query = 0xFFFFFFFFu - first;
+                        return fail(COBS_GPU_ERR_INVALID_BASE, "Invalid DNA base pair in query string. Only ACGT are allowed. (query " +
+                                                               std::to_string(0xFFFFFFFFu - first) + ")");
+                    }
+                }
+                if (mine != COBS_GPU_OK) return fail(mine, keep);
                 if (worst != COBS_GPU_OK)
                     return fail(COBS_GPU_ERR_RCCL, "the pass failed on another rank (status " + std::to_string(worst) + ")");
                 return COBS_GPU_OK;
             };
-            if ((s = all_ranks_ok(s)) != COBS_GPU_OK) return s;
+            if ((s = all_ranks_ok(s, true)) != COBS_GPU_OK) return s;
             // (a handle whose streamed sub-indexes are counted in row ranges keeps score rows instead of selecting in K2,
             // pass.cpp: set_run_state; peers_ranged above makes that the same on every rank)
             bool need_rows = (!hits_only && b->topk_k == 0) || (hits_only && !b->selected);

@@ -1,0 +1,36 @@
+"""GPU: the NATIVE multi-GPU path (cobs_amd/csrc/multi.cpp + comm.cpp) with N > 1 ranks on the one GPU of this box.
+
+RCCL refuses two ranks on one device, so until round 4 the native exchange had only ever run over a one-rank
+communicator (tests/test_gpu_rccl.py) while the N > 1 arithmetic was covered by a torch.distributed restatement.
+tests/mock_rccl/ is a stand-in for librccl for one process whose ranks are threads sharing a GPU (it moves the bytes
+through host staging and CHECKS what hardware answers with a hang: every rank in the same collective, every send met
+by a receive of the same size); a copy of the library linked against it runs the device-list handle of the C ABI --
+N worker threads, one communicator, collective searches -- exactly as an N-GPU node does, against the oracle."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def mock_library(gpu_lib):
+    r = subprocess.run(["bash", os.path.join(ROOT, "tests", "mock_rccl", "build.sh")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lib = os.path.join(ROOT, "cobs_amd", "libcobs_gpu_mockrccl.so")
+    assert os.path.exists(lib)
+    return lib
+
+
+@pytest.mark.parametrize("ranks", [2, 3, 4, 8])
+def test_device_list_handle_over_n_ranks_sharing_the_gpu(mock_library, ranks):
+    env = dict(os.environ, COBS_GPU_LIBRARY=mock_library)
+    seed = os.environ.get("COBS_FUZZ_SEED", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mock_rccl", "run_ranks.py"), str(ranks), seed],
+                       capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0 and r.stdout.strip().startswith("ok "), r.stdout[-3000:] + r.stderr[-6000:]
+    assert "[mock rccl]" not in r.stderr, r.stderr[-6000:]
