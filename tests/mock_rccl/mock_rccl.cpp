@@ -24,6 +24,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -86,9 +87,10 @@ bool barrier(Group* g) {
         g->cv.notify_all();
         return true;
     }
-    const bool ok = g->cv.wait_for(lk, std::chrono::seconds(120), [&] { return g->generation != gen || g->broken; });
+    static const int limit_s = getenv("MOCK_RCCL_TIMEOUT_S") ? atoi(getenv("MOCK_RCCL_TIMEOUT_S")) : 120;
+    const bool ok = g->cv.wait_for(lk, std::chrono::seconds(limit_s), [&] { return g->generation != gen || g->broken; });
     if (!ok || g->broken) {
-        if (!g->broken) std::fprintf(stderr, "[mock rccl] a rank waited 120 s for peers that never entered the collective\n");
+        if (!g->broken) std::fprintf(stderr, "[mock rccl] a rank waited for peers that never entered the collective (MOCK_RCCL_TIMEOUT_S, default 120 s)\n");
         g->broken = true;
         g->cv.notify_all();
         return false;

@@ -34,3 +34,17 @@ def test_device_list_handle_over_n_ranks_sharing_the_gpu(mock_library, ranks):
                        capture_output=True, text=True, timeout=1500, env=env)
     assert r.returncode == 0 and r.stdout.strip().startswith("ok "), r.stdout[-3000:] + r.stderr[-6000:]
     assert "[mock rccl]" not in r.stderr, r.stderr[-6000:]
+
+
+@pytest.mark.parametrize("ranks", [2, 3, 5])
+def test_batch_exchange_entry_points_over_n_ranks(mock_library, ranks):
+    """cobs_gpu_batch_exchange_counts (all-gather / all-to-all to query owners / all-reduce), _exchange_hits,
+    _exchange_hits_owned, _exchange_topk -- the calls bench.py's sharded flow and a torch.distributed launcher make,
+    one rank per process there -- with N ranks as threads of one process over the stand-in communicator; every rank's
+    view afterwards equals the oracle's"""
+    env = dict(os.environ, COBS_GPU_LIBRARY=mock_library, MOCK_RCCL_TIMEOUT_S="30")
+    seed = os.environ.get("COBS_FUZZ_SEED", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mock_rccl", "run_batch_ranks.py"), str(ranks), seed],
+                       capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0 and r.stdout.strip().startswith("ok "), r.stdout[-3000:] + r.stderr[-8000:]
+    assert "[mock rccl]" not in r.stderr, r.stderr[-6000:]
