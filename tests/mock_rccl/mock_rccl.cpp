@@ -3,8 +3,8 @@
 //
 // RCCL refuses two ranks on one device, and the boxes this project is built on have one GPU: the native multi-GPU
 // exchange of libcobs_gpu.so (cobs_amd/csrc/comm.cpp, multi.cpp) had therefore only ever run with ONE rank.  This
-// file implements the dozen RCCL entry points comm.cpp calls with the semantics RCCL documents for them, so that a
-// copy of the library linked against it (tests/mock_rccl/build.sh -> cobs_amd/libcobs_gpu_mockrccl.so) runs the very
+// file implements the dozen RCCL entry points comm.cpp calls with the semantics RCCL documents for them, so that the
+// shipped library with this one preloaded (LD_PRELOAD=cobs_amd/libmockrccl.so, tests/mock_rccl/build.sh) runs the very
 // code an N-GPU node runs -- the layout all-gather, plans, grouped send / receive pairs, all-reduces, pass loops,
 // the ranks' agreement protocol, the device-list handle's worker threads -- with N > 1 ranks on one MI355X
 // (tests/test_gpu_mock_ranks.py).  It moves bytes with hipMemcpy through host staging; it says nothing about xGMI.

@@ -16,7 +16,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("COBS_GPU_ROW_RANGE_MIN", "48")
-assert os.environ.get("COBS_GPU_LIBRARY", "").endswith("libcobs_gpu_mockrccl.so"), "run me through tests/test_gpu_mock_ranks.py"
+assert "libmockrccl.so" in os.environ.get("LD_PRELOAD", ""), "run me through tests/test_gpu_mock_ranks.py (LD_PRELOAD=cobs_amd/libmockrccl.so)"
 
 import cobs_amd  # noqa: E402
 from cobs_amd import _capi  # noqa: E402

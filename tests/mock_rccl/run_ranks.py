@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tests/mock_rccl/run_ranks.py N [SEED] -- TEST INFRASTRUCTURE.  Runs in its own process with
-COBS_GPU_LIBRARY=cobs_amd/libcobs_gpu_mockrccl.so (tests/test_gpu_mock_ranks.py sets it): the device-list handle of
+LD_PRELOAD=cobs_amd/libmockrccl.so (tests/test_gpu_mock_ranks.py sets it; the library is the shipped libcobs_gpu.so): the device-list handle of
 the C ABI over N ranks that share GPU 0 (cobs_gpu_multi_open with devices [0] * N: N worker threads, one communicator,
 every search ONE collective cobs_gpu_sharded_search_batch[_split] -- multi.cpp + comm.cpp as an N-GPU node runs them)
 on random tie-heavy and ordinary inputs, against the oracle.  Prints "ok <cases>" or raises."""
@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 os.environ["COBS_GPU_TEST_RANKS_SHARE_A_DEVICE"] = "1"
 os.environ.setdefault("COBS_GPU_ROW_RANGE_MIN", "48")
-assert os.environ.get("COBS_GPU_LIBRARY", "").endswith("libcobs_gpu_mockrccl.so"), "run me through tests/test_gpu_mock_ranks.py"
+assert "libmockrccl.so" in os.environ.get("LD_PRELOAD", ""), "run me through tests/test_gpu_mock_ranks.py (LD_PRELOAD=cobs_amd/libmockrccl.so)"
 
 import cobs_amd  # noqa: E402
 from cobs_amd import _capi  # noqa: E402
