@@ -90,6 +90,25 @@ def main():
         s.close()
         done += 1
     assert done >= 5
+    if N <= 4:
+        # every rank's hit pool (1 Mi records) overflows: the ranks agree to repeat the pass with score rows and
+        # exchange those (comm.cpp: `over`), the all-to-all to query owners and the shared ranking at a larger size
+        ps, P = 136, 5
+        D = P * 8 * ps - 37
+        sigs = [700, 900, 800, 1000, 600]
+        q_long = oracle.random_sequence(900, 12345)
+        path = cases.make_compact(os.path.join(tmp, "big.cobs_compact"), D, ps, sigs, 1, 31, 1, 0.4, 999,
+                                  planted={0: 1.0, D - 1: 0.7}, query=q_long[:300])
+        nq = 260 * N
+        queries = [q_long[o:o + int(n)] for o, n in zip(rng.integers(0, 200, size=nq), rng.choice([40, 60, 100, 300], size=nq))]
+        ix = oracle.Index.open(path)
+        s = cobs_amd.MultiSearch(path, [0] * N)
+        for t, lim in ((0.01, 0), (0.0, 0)):
+            want = [cases.oracle_results([ix], q, t, lim) for q in queries]
+            assert sum(len(w) for w in want) > N * (1 << 20)
+            assert s.search_hits(queries, t, lim) == want, (N, "pool overflow", t, lim)
+        s.close()
+        done += 1
     print("ok %d" % done)
 
 
