@@ -172,3 +172,20 @@ def test_absurd_procedural_geometry_is_refused():
         with pytest.raises(cobs_amd.CobsGpuError) as e:
             cobs_amd.Search.synthetic(kind, sigs, docs, page_size=ps)
         assert e.value.status in (_capi.ERR_UNSUPPORTED, _capi.ERR_ARG, _capi.ERR_NO_DEVICE), (kind, e.value)
+
+
+def test_mock_rccl_covers_every_rccl_symbol_the_library_imports():
+    """tests/mock_rccl (the stand-in communicator the N > 1 tests preload under the shipped library) must define every
+    nccl* symbol libcobs_gpu.so imports: a new RCCL call in comm.cpp that the stand-in lacks would silently go to
+    the real librccl in those tests"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["bash", os.path.join(root, "tests", "mock_rccl", "build.sh")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+    def syms(path, flag):
+        out = subprocess.run(["nm", "-D", flag, path], capture_output=True, text=True, check=True).stdout
+        return {ln.split()[-1].split("@")[0] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("nccl")}
+    wanted = syms(os.path.join(root, "cobs_amd", "libcobs_gpu.so"), "--undefined-only")
+    have = syms(os.path.join(root, "cobs_amd", "libmockrccl.so"), "--defined-only")
+    assert wanted and wanted <= have, sorted(wanted - have)
