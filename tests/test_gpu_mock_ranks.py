@@ -78,3 +78,15 @@ def test_cli_device_list_over_three_ranks(mock_library, oracle, golden_dir, tmp_
         assert r.stdout == want, extra
     r = subprocess.run([tool, "-d", "0,0,0", "-i", b, q50.replace("G", "N", 1)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0 and "Invalid DNA base pair" in r.stderr
+
+
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_bench_sharded_flow_over_n_ranks(mock_library, ranks):
+    """bench.py's ShardedRun -- the overlapped N > 1 flow the driver's scaling run times: sub-batches, hashing / scan /
+    exchange on three streams tied by events, the native all-to-all to query owners -- with N ranks as threads; every
+    rank's assembled rows equal the oracle's, for 1, 2 and 3 sub-batches"""
+    env = dict(os.environ, LD_PRELOAD=mock_library, MOCK_RCCL_TIMEOUT_S="30")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mock_rccl", "run_bench_ranks.py"), str(ranks)],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and r.stdout.strip().startswith("ok "), r.stdout[-3000:] + r.stderr[-8000:]
+    assert "[mock rccl]" not in r.stderr, r.stderr[-6000:]
