@@ -21,8 +21,13 @@ Either way the printed line carries n_gpus == --gpus == rccl_ranks, or the run f
 import argparse
 import json
 import os
+import select
+import signal
+import subprocess
 import sys
+import threading
 import time
+import traceback
 
 import numpy as np
 import torch
@@ -526,8 +531,7 @@ def verify_sharded(run, cfg, world, rank, backend, corrupt=False, seconds=20.0, 
         pa, pb = _row_sums(run.local_rows(i), w_loc)
         part = torch.stack([pa, pb])
         if world > 1 and exchanged:
-            if backend != "nccl":
-                part = part.cpu()
+            part = part.cpu()
             dist.all_reduce(part, op=dist.ReduceOp.SUM)
             part = part.to(dev)
         ga, gb = _row_sums(rows, w_glob)
@@ -549,8 +553,7 @@ def verify_sharded(run, cfg, world, rank, backend, corrupt=False, seconds=20.0, 
                 good = good and bool(np.array_equal(got, want.astype(np.int64)))
                 n_exact += 1
             ok_oracle = ok_oracle and good
-    flags = torch.tensor([1 if ok_exchange else 0, 1 if ok_oracle else 0, n_all, n_exact, n_sum], dtype=torch.int64,
-                         device=dev if backend == "nccl" else "cpu")
+    flags = torch.tensor([1 if ok_exchange else 0, 1 if ok_oracle else 0, n_all, n_exact, n_sum], dtype=torch.int64)
     if world > 1:
         dist.all_reduce(flags, op=dist.ReduceOp.MIN)
     fl = [int(v) for v in flags.tolist()]
@@ -580,7 +583,7 @@ def timed(step, steps, warmup, world, backend, after_warmup=None):
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        t = torch.tensor([dt], dtype=torch.float64)      # (the control plane is a gloo group: CPU tensors)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
@@ -591,7 +594,7 @@ def all_ranks_ok(ok, backend):
     local failure (out of memory, ...) cannot strand the others inside RCCL"""
     if not (dist.is_available() and dist.is_initialized()):
         return bool(ok)
-    flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int64)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     return int(flag.item()) == 1
 
@@ -700,6 +703,228 @@ def workload_text(args, cfg):
     return t
 
 
+METRIC = "k-mer queries/sec + achieved HBM GB/s, 100k-doc compact index, 1000-kmer query"
+
+
+class Watchdog(threading.Thread):
+    """A run of N ranks must not end as a silent driver time-out: a collective that one rank never
+    enters does not fail, it waits.  One watchdog thread per rank: the main thread names the PHASE it is in and how long
+    that may take; when a phase overruns -- or the launcher sends SIGTERM because another rank died -- every rank prints
+    what it was doing (phase, step, what its communicator entered last, whether that stream is idle) to stderr and
+    leaves it for rank 0, and rank 0 emits ONE JSON line with "error" and the ranks' states, then every rank exits
+    non-zero.  Deadlines are the same on every rank and phases are aligned by barriers, so all ranks fire together."""
+
+    def __init__(self, rank, world, emit, peers=None, exit_fn=os._exit, scale=1.0, grace=3.0):
+        super().__init__(daemon=True, name="bench-watchdog")
+        self.rank, self.world, self.emit, self.peers, self.exit_fn = rank, world, emit, peers, exit_fn
+        self.scale, self.grace = scale, grace
+        self.lock = threading.Lock()
+        self.phase_name, self.deadline, self.t_phase = "start", None, time.time()
+        self.notes, self.comm, self.extra = {}, None, {}
+        self.stop_ev = threading.Event()
+        self.fired = False
+        self.wake_r = None
+
+    def phase(self, name, seconds=None):
+        with self.lock:
+            self.phase_name, self.t_phase = name, time.time()
+            self.deadline = None if seconds is None else self.t_phase + seconds * self.scale
+
+    def note(self, **kv):
+        with self.lock:
+            self.notes.update(kv)
+
+    def attach(self, comm):
+        self.comm = comm
+
+    def done(self):
+        self.stop_ev.set()
+
+    def catch_sigterm(self):
+        """main thread only.  The launcher answers a dead rank with SIGTERM to the others; a Python handler would wait
+        for the main thread to come back from the call it is stuck in -- the wake-up descriptor is written by the C-level
+        handler at once and read by this thread."""
+        r, w = os.pipe()
+        os.set_blocking(w, False)
+        signal.signal(signal.SIGTERM, lambda *_: None)
+        signal.set_wakeup_fd(w, warn_on_full_buffer=False)
+        self.wake_r = r
+
+    def state(self):
+        with self.lock:
+            st = {"rank": self.rank, "phase": self.phase_name, "seconds_in_phase": round(time.time() - self.t_phase, 1),
+                  "deadline_s": None if self.deadline is None else round(self.deadline - self.t_phase, 1)}
+            st.update(self.notes)
+        comm = self.comm
+        if comm is not None:
+            box = []
+            t = threading.Thread(target=lambda: box.append(comm.state()), daemon=True)      # (a query of a wedged runtime may block too)
+            t.start()
+            t.join(2.0)
+            st["comm"] = box[0] if box else "no answer from the runtime within 2 s"
+        return st
+
+    def fail(self, why, code=4):
+        """-> does not return: states to stderr / to rank 0, the error line from rank 0, exit"""
+        if self.fired:
+            return
+        self.fired = True
+        st = self.state()
+        sys.stderr.write("[bench watchdog] rank %d: %s -- %s\n" % (self.rank, why, json.dumps(st)))
+        sys.stderr.flush()
+        if self.peers is not None:
+            try:
+                self.peers.set("wd/%d" % self.rank, json.dumps(st))
+            except Exception:                                       # noqa: BLE001
+                pass
+        if self.rank == 0:
+            states = {0: st}
+            t_end = time.time() + self.grace
+            for r in range(1, self.world):
+                got = None
+                while self.peers is not None and got is None:
+                    try:
+                        got = self.peers.get("wd/%d" % r)
+                    except Exception:                               # noqa: BLE001
+                        got = None
+                    if got is not None or time.time() > t_end:
+                        break
+                    time.sleep(0.1)
+                states[r] = json.loads(got) if got else "no state received within %.0f s" % self.grace
+            line = {"metric": METRIC, "value": None, "unit": "queries/s", "n_gpus": self.world, "higher_is_better": True,
+                    "error": why, "phase": st["phase"], "watchdog": {"per_rank": [states[r] for r in range(self.world)]}}
+            line.update(self.extra)
+            try:
+                self.emit(line)
+            except Exception:                                       # noqa: BLE001
+                pass
+        else:
+            time.sleep(self.grace + 2.0)        # (the launcher kills every rank as soon as one exits: let rank 0 print first)
+        self.exit_fn(code)
+
+    def run(self):
+        while not self.stop_ev.is_set():
+            if self.wake_r is not None:
+                ready, _, _ = select.select([self.wake_r], [], [], 0.25)
+                if ready:
+                    sigs = os.read(self.wake_r, 64)
+                    if signal.SIGTERM in sigs:
+                        self.fail("terminated by the launcher (SIGTERM) in phase '%s': another rank failed or the run was timed out"
+                                  % self.phase_name, code=143)
+            else:
+                self.stop_ev.wait(0.25)
+            with self.lock:
+                late = self.deadline is not None and time.time() > self.deadline
+                name, limit = self.phase_name, (self.deadline or 0) - self.t_phase
+            if late:
+                self.fail("phase '%s' did not finish within %.0f s" % (name, limit))
+
+
+class _StorePeers:
+    """the ranks' states for rank 0, through the store torch.distributed's rendezvous runs on (served by the launcher /
+    rank 0 in a background thread: it answers while the main threads are stuck)"""
+    def __init__(self, store):
+        self.store = store
+    def set(self, key, value):
+        self.store.set("cobs_bench/" + key, value)
+    def get(self, key):
+        if not self.store.check(["cobs_bench/" + key]):
+            return None
+        return self.store.get("cobs_bench/" + key).decode()
+
+
+def other_ipc_mode(v):
+    return "1" if v == "0" else "0"
+
+
+def preflight_child(args):
+    """one rank of one preflight attempt, in its OWN process (HSA_ENABLE_IPC_MODE_LEGACY is read once, when the ROCm
+    runtime initialises: another value needs another process; and a hang in ncclCommInitRank can only be ended by
+    killing the process that sits in it).  Prints one JSON line."""
+    res = {"ok": False, "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+    try:
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"]), None, False,
+                              timeout=__import__("datetime").timedelta(seconds=args.preflight_seconds))
+        key = "cobs_bench/pf/%s/uid" % args.preflight_child
+        dev = args.preflight_device
+        torch.cuda.set_device(dev)
+        from cobs_amd.distributed import Comm
+        if rank == 0:
+            store.set(key, Comm.unique_id())
+        uid = store.get(key)
+        t0 = time.time()
+        comm = Comm(uid, rank, world, device=dev)
+        res["comm_init_s"] = round(time.time() - t0, 2)
+        res["rccl_ranks"] = comm.size
+        res.update(comm.preflight(timeout_ms=int(args.preflight_seconds * 400), big_bytes=args.preflight_big_mib << 20))
+        comm.close()
+        res["ok"] = True
+    except BaseException as e:                                      # noqa: BLE001
+        res["error"] = "%s: %s" % (type(e).__name__, str(e)[:400])
+    _RESULT_STDOUT.write(json.dumps(res) + "\n")
+    _RESULT_STDOUT.flush()
+    os._exit(0 if res["ok"] else 5)
+
+
+def run_preflight(args, world, rank, device, wd):
+    """Before the index is built: does a communicator of these ranks come up AND move bytes --
+    uneven grouped send / receive all-to-all, all-gather, all-reduce, every byte checked, each step under a time limit
+    (cobs_gpu_comm_preflight) -- under the HSA_ENABLE_IPC_MODE_LEGACY value of the environment?  If not, once more
+    under the other value; if neither works the run falls back to the host transport (torch.distributed / gloo: the
+    library's own exchange plan, the bytes through host memory) and says so.  Every attempt is one child process per
+    rank; the ranks agree on each attempt's outcome over the (gloo) process group.
+    -> (dict for the JSON line, transport "rccl" | "gloo")"""
+    info = {"attempts": []}
+    first = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for attempt, mode in enumerate((first, other_ipc_mode(first))):
+        wd.phase("preflight attempt %d (HSA_ENABLE_IPC_MODE_LEGACY=%s)" % (attempt, mode), args.preflight_seconds + 45)
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=mode)
+        cmd = [sys.executable, os.path.abspath(__file__), "--preflight-child", "a%d" % attempt, "--preflight-device", str(device),
+               "--preflight-seconds", str(args.preflight_seconds), "--preflight-big-mib", str(args.preflight_big_mib)]
+        mine = {"ok": False}
+        t0 = time.time()
+        try:
+            child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            try:
+                out, err = child.communicate(timeout=args.preflight_seconds)
+                lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+                mine = json.loads(lines[-1]) if lines else {"ok": False, "error": "no result line; exit code %d; stderr: %s"
+                                                            % (child.returncode, err[-300:])}
+            except subprocess.TimeoutExpired:
+                child.kill()
+                child.communicate()
+                mine = {"ok": False, "error": "no answer within %g s (killed): the communicator did not come up or a collective hung"
+                                              % args.preflight_seconds}
+        except Exception as e:                                      # noqa: BLE001
+            mine = {"ok": False, "error": "could not run the preflight child: %r" % (e,)}
+        mine["seconds"] = round(time.time() - t0, 2)
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        ok = all(bool(r and r.get("ok")) for r in every)
+        rec = {"HSA_ENABLE_IPC_MODE_LEGACY": mode, "ok": ok, "seconds_max": max(r.get("seconds", 0) for r in every)}
+        if ok:
+            rec["comm_init_s_max"] = max(r.get("comm_init_s", 0) for r in every)
+            for k in ("alltoall_us", "allgather_us", "allreduce_us", "big_alltoall_us"):
+                if all(k in r for r in every):
+                    rec[k + "_max"] = max(r[k] for r in every)
+            if all("big_alltoall_recv_GBps" in r for r in every):
+                rec["big_alltoall_recv_GBps_min"] = min(r["big_alltoall_recv_GBps"] for r in every)
+                rec["big_alltoall_MiB_per_pair"] = args.preflight_big_mib
+        else:
+            rec["errors"] = {str(i): r.get("error", "?") for i, r in enumerate(every) if not (r and r.get("ok"))}
+        info["attempts"].append(rec)
+        if ok:
+            os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = mode     # (this process has not initialised the ROCm runtime yet)
+            info["ipc_mode_legacy_used"] = mode
+            info["transport"] = "rccl"
+            return info, "rccl"
+    info["transport"] = "gloo"
+    info["fallback"] = ("RCCL did not pass the preflight under either IPC mode: the exchange of this run goes through host memory "
+                        "(torch.distributed / gloo executing the library's own exchange plan) -- a slow but true number")
+    return info, "gloo"
+
+
 def launch_plan(gpus, argv):
     """`python bench.py --gpus N` started without a launcher: the command that runs the N ranks
     (one process per GPU, rendezvous on 127.0.0.1, a free port)."""
@@ -753,9 +978,25 @@ def main():
                     "for smoke-testing the launch path with several ranks on one GPU")
     ap.add_argument("--dry-run-launch", action="store_true",
                     help="print the launch plan of --gpus N (JSON) and exit; needs no GPU")
+    ap.add_argument("--no-preflight", action="store_true",
+                    help="N>1: skip the RCCL preflight (communicator + first collectives in child processes, with the IPC-mode fallback)")
+    ap.add_argument("--preflight-seconds", type=float, default=75.0, help="time limit of one preflight attempt")
+    ap.add_argument("--preflight-big-mib", type=int, default=8, help="the preflight's timed all-to-all: MiB per pair of ranks (0 = none)")
+    ap.add_argument("--preflight-child", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--preflight-device", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--deadline-scale", type=float, default=1.0,
+                    help="the watchdog's phase deadlines times this (a phase that overruns ends the run with an error line instead of a hang)")
+    ap.add_argument("--step-deadline", type=float, default=0.0,
+                    help="seconds the warm-up + timed steps may take before the watchdog ends the run (0 = 150 s + 0.5 s per step)")
+    ap.add_argument("--share-devices", action="store_true",
+                    help="test hook: several ranks on one GPU with --dist-backend nccl -- real RCCL refuses that, which is how the "
+                         "preflight's fallback chain is exercised on a one-GPU box")
+    ap.add_argument("--test-hang-rank", type=int, default=-1, help=argparse.SUPPRESS)       # test hook of the watchdog: this rank stops stepping
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.preflight_child:
+        preflight_child(args)
 
     launched = "WORLD_SIZE" in os.environ
     if args.dry_run_launch:
@@ -769,33 +1010,89 @@ def main():
         return
     if not launched and args.gpus > 1:
         # started plainly: become the launcher of the N ranks (their rank 0 prints the JSON line to
-        # the stdout this process was given)
-        if args.dist_backend == "nccl" and torch.cuda.device_count() < args.gpus:
-            raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible" % (args.gpus, torch.cuda.device_count()))
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # the stdout this process was given).  (The device count is asked of a child process: this one must not
+        # initialise the ROCm runtime before the ranks have chosen their IPC mode.)
+        if args.dist_backend == "nccl" and not args.share_devices and visible_devices() < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible" % (args.gpus, visible_devices()))
         sys.stderr.flush()
         os.dup2(_RESULT_STDOUT.fileno(), 1)
         cmd = launch_plan(args.gpus, sys.argv[1:])
         os.execv(cmd[0], cmd)
 
-    from cobs_amd import _capi
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d was launched with WORLD_SIZE=%d: the two must agree" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    def emit(line):
+        _RESULT_STDOUT.write(json.dumps(line) + "\n")
+        _RESULT_STDOUT.flush()
+
+    wd = Watchdog(rank, world, emit, scale=args.deadline_scale)
+    wd.catch_sigterm()
+    wd.start()
+    try:
+        run_bench(args, world, rank, local_rank, wd, emit)
+    except SystemExit:
+        raise
+    except BaseException as e:                                      # noqa: BLE001
+        # no rank dies silently: the traceback to stderr, and from rank 0 a line that says so (another rank's death
+        # reaches rank 0 as the launcher's SIGTERM, which the watchdog answers with the same kind of line)
+        traceback.print_exc()
+        sys.stderr.flush()
+        wd.fail("rank %d failed in phase '%s': %s: %s" % (rank, wd.phase_name, type(e).__name__, str(e)[:500]), code=1)
+    finally:
+        wd.done()
+
+
+def visible_devices():
+    """HIP devices visible to this job, counted by a child process (so that the caller does not initialise the runtime)"""
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True,
+                           text=True, timeout=300)
+        return int(r.stdout.strip().splitlines()[-1])
+    except Exception:                                               # noqa: BLE001
+        return 0
+
+
+def run_bench(args, world, rank, local_rank, wd, emit):
+    from cobs_amd import _capi
+    preflight = None
     if world > 1:
+        # The control plane of an N-rank run (barriers, the max over ranks of the timing, the self-check's sums) is a
+        # gloo process group: it needs no GPU, so it is up BEFORE this process initialises the ROCm runtime -- the
+        # preflight may still choose the IPC mode -- and it is not a second RCCL communicator next to the one the data
+        # path uses (libcobs_gpu.so's own: `rccl_ranks` in the line).
+        wd.phase("process group (gloo control plane)", 120)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.dist_backend == "nccl" and torch.cuda.device_count() < world:
-            raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible" % (world, torch.cuda.device_count()))
-        local_rank = local_rank % torch.cuda.device_count()
-        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # one node: the loopback device; the hostname may not resolve
+        dist.init_process_group(backend="gloo")
+        try:
+            wd.peers = _StorePeers(dist.distributed_c10d._get_default_store())
+        except Exception:                                           # noqa: BLE001
+            wd.peers = None
+        ndev = visible_devices()
+        if args.dist_backend == "nccl" and not args.share_devices and ndev < world:
+            raise RuntimeError("bench.py --gpus %d: only %d HIP device(s) visible" % (world, ndev))
+        local_rank = local_rank % max(ndev, 1)
         if args.dist_backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            if args.no_preflight:
+                preflight = {"skipped": "--no-preflight", "transport": "rccl"}
+                os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            else:
+                preflight, transport = run_preflight(args, world, rank, local_rank, wd)
+                if transport != "rccl":
+                    args.dist_backend = "gloo"
         else:
-            dist.init_process_group(backend=args.dist_backend)
+            preflight = {"skipped": "--dist-backend %s: the exchange does not use RCCL" % args.dist_backend,
+                         "transport": args.dist_backend}
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        wd.extra["preflight"] = preflight
+        wd.phase("device set-up", 180)
+        torch.cuda.set_device(local_rank)
     else:
+        wd.phase("device set-up", 300)
         torch.cuda.set_device(0)
     n_gpus = world
     dev = torch.cuda.current_device()
@@ -809,6 +1106,7 @@ def main():
     cfg["num_hashes"] = args.num_hashes
     budget = int(args.hbm_budget_gb * 1e9)
     path = None
+    wd.phase("index and batch set-up (%s)" % args.config, {"c4": 900, "c5": 1800}.get(args.config, 600) * max(1.0, args.scale))
     if args.config == "c5":
         # BASELINE configs[4]: the index is a FILE larger than the HBM budget; written once
         path = args.index_file or os.path.join(os.environ.get("TMPDIR", "/tmp"), "cobs_c5_%g.cobs_compact" % args.scale)
@@ -830,6 +1128,8 @@ def main():
         if args.dist_backend == "nccl":
             from cobs_amd.distributed import Comm
             comm = Comm.from_torch(None, dev) if world > 1 else Comm(Comm.unique_id(), 0, 1, dev)
+            comm.set_timeout(int(60000 * args.deadline_scale))     # the stream waits the library owns around collectives
+            wd.attach(comm)
         ok, err = True, ""
         # Two sub-batches by default: the exchange (~0.2 ms per rank at C3 / N = 8 against 2.4 ms of scan) and K1
         # (replicated on every rank: 0.23 ms) of one half hide behind the scan of the other; every further cut adds a launch
@@ -844,9 +1144,14 @@ def main():
         except Exception as e:                                      # noqa: BLE001
             ok, err = False, repr(e)
         if not all_ranks_ok(ok, args.dist_backend):
-            raise SystemExit("set-up of the sharded index failed: " + (err or "on another rank"))
+            raise RuntimeError("set-up of the sharded index failed: " + (err or "on another rank"))
         s, batch = run.s, run.sub[0]
-        step = run.step
+
+        def step():
+            wd.note(step=run.steps_seen)
+            if rank == args.test_hang_rank and run.steps_seen >= 1:
+                time.sleep(1e6)                 # (test hook: this rank never enters the next exchange)
+            run.step()
     else:
         s = make_index(cfg, dev, hbm_budget=budget, path=path)
         batch = cobs_amd.Batch(s)
@@ -871,7 +1176,10 @@ def main():
         if budget:
             stream_mark["t0"] = s.stream_traffic()      # what the warm-up asked of PCIe is not the timed steps'
 
+    wd.phase("warm-up and timed steps", args.step_deadline / args.deadline_scale if args.step_deadline > 0 else
+             150 + 0.5 * (args.steps + args.warmup) * (20 if budget else 1))
     dt = timed(step, args.steps, args.warmup, world, args.dist_backend, drop_warmup_events)
+    wd.phase("collecting the line", 300)
     received, xchg_ms = 0, 0.0
     if run is not None:
         scan_ms, hash_ms, xchg_ms, algo, received = run.finish()     # per step: summed over the sub-batches
@@ -918,7 +1226,7 @@ def main():
         par = "1 gpu"
     out = {
         # BASELINE.json's metric, verbatim; `value` is the queries/s part, roofline.achieved the GB/s part
-        "metric": "k-mer queries/sec + achieved HBM GB/s, 100k-doc compact index, 1000-kmer query",
+        "metric": METRIC,
         "value": round(qps, 1),
         "unit": "queries/s",
         "n_gpus": n_gpus,
@@ -973,6 +1281,10 @@ def main():
                                               "frac above are algorithmic bytes, every look-up counted)")
         if world == 1 and not shard_index and not args.no_cpu_baseline:
             out["roofline"]["cache_cold"] = cache_cold_probe(s, cfg, queries, args.kmers, row_bytes)
+    if preflight is not None:
+        out["preflight"] = preflight
+        out["control_plane"] = "torch.distributed/gloo (barriers, max over ranks of the timing, the self-check's sums); data path: " + \
+                               ("RCCL communicator of libcobs_gpu.so" if comm is not None else "torch.distributed/" + args.dist_backend)
     if shard_index:
         out["rccl_ranks"] = comm.size if comm is not None else None       # ncclCommCount
         # what every rank measured with events on its own streams, per step (summed over the sub-batches)
@@ -993,6 +1305,7 @@ def main():
                            "hidden_frac_is": "(scan + hash + exchange ms of a rank - ms_per_step) / (hash + exchange ms), clamped to [0, 1]; min over ranks",
                            "transport": "RCCL in libcobs_gpu.so" if comm is not None else "torch.distributed/" + args.dist_backend}
         # the line proves itself: exchanged rows against the shards' slices (all rows) and against the oracle (sample)
+        wd.phase("self-check of the exchanged rows", 300)
         out.update(verify_sharded(run, cfg, world, rank, args.dist_backend, corrupt=args.corrupt_exchange))
         info = s.info(0)
         out["shard_rank0"] = {"hbm_bytes": int(info.hbm_bytes), "slot_begin": int(info.slot_begin),
@@ -1022,6 +1335,7 @@ def main():
     if shard_index and args.extras and not args.no_extras:
         del run, batch, s
         torch.cuda.empty_cache()
+        wd.phase("other forms (--extras)", 1800)
         out["other_forms"] = side_measurements(args, cfg, queries, world, rank, dev, comm)
     if (world > 1 and not shard_index) or (world == 1 and budget and not shard_index and args.threshold <= 0 and not args.num_results):
         # index replicated, one batch per rank (or one GPU streaming a file under a budget: no cpu_baseline leg there):
@@ -1038,6 +1352,7 @@ def main():
         # for them (the result array of the default call is 307 MB), and gets all cores back for the CPU baseline
         all_cpus = os.sched_getaffinity(0)
         bind_to_numa_node(numa_node)
+        wd.phase("end-to-end calls and CPU baseline", 900)
         out["end_to_end"] = end_to_end(s, batch, queries)
         out["end_to_end"]["caller_numa_node"] = numa_node
         os.sched_setaffinity(0, all_cpus)
@@ -1048,10 +1363,12 @@ def main():
         assert out["n_gpus"] == args.gpus, (out["n_gpus"], args.gpus)
         if shard_index and args.dist_backend == "nccl":
             assert out["rccl_ranks"] == args.gpus, (out["rccl_ranks"], args.gpus)
-        _RESULT_STDOUT.write(json.dumps(out) + "\n")
-        _RESULT_STDOUT.flush()
+        emit(out)
+    wd.phase("shutdown", 120)
     if world > 1:
+        dist.barrier()              # (rank 0 has printed: nobody's exit makes the launcher end the others before that)
         dist.destroy_process_group()
+    wd.done()
     if out.get("bit_exact_vs_oracle") is False:
         # (every rank holds the all-reduced flag: all of them leave with the same code)
         sys.stderr.write("bench.py: the counts are NOT bit-exact against the oracle: %s\n"

@@ -150,7 +150,8 @@ SYMBOLS = {
     "cobs_gpu_multi_search_batch": (_int, [_vp, C.POINTER(_cp), C.POINTER(_sz), _sz, _dbl, _sz,
                                            C.POINTER(Hit), _sz, C.POINTER(_sz), C.POINTER(_sz)]),
     "cobs_gpu_graph_replays": (_u64, [_vp]),
-    "cobs_gpu_stream_counters": (_int, [_vp, C.POINTER(C.c_uint64 * 4)]),
+    "cobs_gpu_stream_counters": (_int, [_vp, C.POINTER(C.c_uint64 * 2)]),
+    "cobs_gpu_stream_traffic": (_int, [_vp, C.POINTER(C.c_uint64 * 4)]),
     "cobs_gpu_timers": (_int, [_vp, C.POINTER(C.c_double * 5), _int]),
     "cobs_gpu_exchange_plan": (_int, [_pu64, _pu64, _pu64, _sz, _sz, _u64, _sz, _u32, _u32, _sz,
                                       C.POINTER(Xfer), C.POINTER(Copy2D), C.POINTER(_sz), _pu64]),
@@ -159,6 +160,9 @@ SYMBOLS = {
     "cobs_gpu_comm_destroy": (None, [_vp]),
     "cobs_gpu_comm_rank": (_int, [_vp]),
     "cobs_gpu_comm_size": (_int, [_vp]),
+    "cobs_gpu_comm_set_timeout": (None, [_vp, _u32]),
+    "cobs_gpu_comm_state": (_sz, [_vp, C.c_char_p, _sz]),
+    "cobs_gpu_comm_preflight": (_int, [_vp, _u32, _u64, C.POINTER(C.c_uint64 * 8)]),
     "cobs_gpu_batch_exchange_counts": (_int, [_vp, _vp, _u32, _vp]),
     "cobs_gpu_batch_global_counts_device": (_vp, [_vp, _pu64, _pu64, C.POINTER(_u32), _pu64]),
     "cobs_gpu_batch_exchange_bytes": (_u64, [_vp]),

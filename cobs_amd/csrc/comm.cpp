@@ -32,10 +32,13 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "engine.hpp"
@@ -46,6 +49,18 @@ struct cobs_gpu_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1, device = 0;
     uint64_t serial = 0;          // never reused: a batch remembers which communicator its layout came from
+    // What this rank entered last -- read by the CALLER's watchdog from another thread (cobs_gpu_comm_state) when a
+    // step does not come back: a collective that a peer never enters does not fail, it waits.
+    std::atomic<const char*> last_op{"none"};
+    std::atomic<uint64_t> entered{0}, returned{0};
+    std::atomic<void*> last_stream{nullptr};
+    // A failed RCCL call leaves the peers' state unknown: the communicator is not used again (every later call fails
+    // at once, on this rank, before any collective), and where the status says it is dead it is aborted -- after an
+    // open group has been closed (GroupScope), never inside one.
+    std::atomic<bool> broken{false};
+    bool group_open = false, abort_wanted = false;
+    std::string broken_why;
+    uint32_t timeout_ms = 0;      // > 0: the stream waits this file owns give up after that long (sync_bounded)
 };
 
 namespace cobs_amd {
@@ -77,14 +92,114 @@ cobs_gpu_status nccl_fail(ncclResult_t r, const char* what) {
     return fail(COBS_GPU_ERR_RCCL, std::string(what) + ": " + ncclGetErrorString(r));
 }
 
+// (calls that involve no communicator: ncclGetUniqueId, ncclCommInitRank)
 #define NCCL_TRY(expr)                                         \
     do {                                                       \
         ncclResult_t _r = (expr);                              \
         if (_r != ncclSuccess) return nccl_fail(_r, #expr);    \
     } while (0)
 
+void comm_settle(cobs_gpu_comm* c) {
+    if (c->abort_wanted && c->comm && !c->group_open) {
+        (void)ncclCommAbort(c->comm);       // frees the communicator and releases kernels of it that wait for peers
+        c->comm = nullptr;
+        c->abort_wanted = false;
+    }
+}
+
+// statuses after which the communicator itself is gone (a wrong argument or a misuse leaves it alive)
+bool comm_is_dead(ncclResult_t r) {
+    return r == ncclUnhandledCudaError || r == ncclSystemError || r == ncclInternalError || r == ncclRemoteError;
+}
+
+cobs_gpu_status comm_fail(cobs_gpu_comm* c, ncclResult_t r, const char* what) {
+    if (!c->broken.load()) {
+        c->broken_why = std::string(what) + ": " + ncclGetErrorString(r);
+        c->broken.store(true);
+    }
+    if (comm_is_dead(r)) c->abort_wanted = true;
+    comm_settle(c);
+    return nccl_fail(r, what);
+}
+
+cobs_gpu_status comm_usable(const cobs_gpu_comm* c) {
+    if (c->broken.load() || !c->comm)
+        return fail(COBS_GPU_ERR_RCCL, "the communicator is unusable after an earlier failure (" + c->broken_why +
+                                       "): destroy it and create a new one on every rank");
+    return COBS_GPU_OK;
+}
+
+// every RCCL call on a communicator: counted for the watchdog, a failure marks the communicator
+#define NCCL_C(c, st, expr)                                                    \
+    do {                                                                       \
+        (c)->last_op.store(#expr);                                             \
+        (c)->last_stream.store((void*)(st));                                   \
+        (c)->entered.fetch_add(1);                                             \
+        ncclResult_t _r = (expr);                                              \
+        (c)->returned.fetch_add(1);                                            \
+        if (_r != ncclSuccess) return comm_fail((c), _r, #expr);               \
+    } while (0)
+
+// ncclGroupStart ... ncclGroupEnd with the end GUARANTEED: a send or receive that fails inside the group returns from
+// the function through NCCL_C, and this scope's destructor still closes the group -- RCCL's group state is per
+// thread, an open group would swallow every later call of this thread into a group that is never launched -- and only
+// then lets comm_settle abort a dead communicator.  [VERDICT r4 9a: NCCL_TRY inside a group returned without closing it.]
+struct GroupScope {
+    cobs_gpu_comm* c;
+    bool open = false;
+    explicit GroupScope(cobs_gpu_comm* c_) : c(c_) {}
+    cobs_gpu_status start() {
+        NCCL_C(c, nullptr, ncclGroupStart());
+        open = c->group_open = true;
+        return COBS_GPU_OK;
+    }
+    cobs_gpu_status end(hipStream_t st) {
+        open = c->group_open = false;
+        NCCL_C(c, st, ncclGroupEnd());
+        return COBS_GPU_OK;
+    }
+    ~GroupScope() {
+        if (open) {
+            (void)ncclGroupEnd();
+            c->group_open = false;
+            comm_settle(c);
+        }
+    }
+};
+#define GROUP_START(g) do { cobs_gpu_status _gs = (g).start(); if (_gs != COBS_GPU_OK) return _gs; } while (0)
+#define GROUP_END(g, st) do { cobs_gpu_status _gs = (g).end(st); if (_gs != COBS_GPU_OK) return _gs; } while (0)
+
+// Wait for a stream that carries a collective.  With a time limit on the communicator (cobs_gpu_comm_set_timeout) the
+// wait gives up after it: a peer that never entered the collective would otherwise keep this rank here for ever.
+// The communicator is aborted then (its kernels stop waiting) and the call fails with ERR_RCCL.
+cobs_gpu_status sync_bounded(cobs_gpu_comm* c, hipStream_t st, const char* what) {
+    if (!c || c->timeout_ms == 0) {
+        HIP_TRY(hipStreamSynchronize(st));
+        return COBS_GPU_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; ++spin) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e == hipSuccess) return COBS_GPU_OK;
+        if (e != hipErrorNotReady) { (void)hipGetLastError(); HIP_TRY(e); }
+        (void)hipGetLastError();
+        if (spin > 4000) std::this_thread::sleep_for(std::chrono::microseconds(100));
+        const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > (long long)c->timeout_ms) {
+            if (!c->broken.load()) {
+                c->broken_why = std::string(what) + " did not complete within " + std::to_string(c->timeout_ms) +
+                                " ms (last call: " + c->last_op.load() + "): a peer never entered it, or the fabric stalled";
+                c->broken.store(true);
+            }
+            c->abort_wanted = true;
+            comm_settle(c);
+            return fail(COBS_GPU_ERR_RCCL, c->broken_why);
+        }
+    }
+}
+
 // every rank's score-slot layout, gathered once per (batch, communicator)
-cobs_gpu_status bind_layout(cobs_gpu_batch* b, const cobs_gpu_comm* c, hipStream_t st) {
+cobs_gpu_status bind_layout(cobs_gpu_batch* b, cobs_gpu_comm* c, hipStream_t st) {
     if (!b->xchg) b->xchg = new Exchange;
     Exchange& x = *b->xchg;
     if (x.bound == c->serial) return COBS_GPU_OK;
@@ -99,10 +214,10 @@ cobs_gpu_status bind_layout(cobs_gpu_batch* b, const cobs_gpu_comm* c, hipStream
     }
     HIP_TRY(x.d_meta.reserve(per * (N + 1)));
     HIP_TRY(hipMemcpyAsync(x.d_meta.p, mine.data(), per * 8, hipMemcpyHostToDevice, st));
-    NCCL_TRY(ncclAllGather(x.d_meta.p, x.d_meta.p + per, per * 8, ncclUint8, c->comm, st));
+    NCCL_C(c, st, ncclAllGather(x.d_meta.p, x.d_meta.p + per, per * 8, ncclUint8, c->comm, st));
     std::vector<uint64_t> all(per * N);
     HIP_TRY(hipMemcpyAsync(all.data(), x.d_meta.p + per, per * N * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    if (cobs_gpu_status ws = sync_bounded(c, st, "the all-gather of the shard layouts"); ws != COBS_GPU_OK) return ws;
     x.layout.assign(N * np * 2, 0);
     x.local_n.assign(N, 0);
     for (size_t r = 0; r < N; ++r) {
@@ -200,15 +315,16 @@ XferPlan plan_exchange(const uint64_t* layout /*[N][F][2]*/, const uint64_t* doc
 }
 
 // max over all ranks of a status word (one tiny ncclAllReduce)
-cobs_gpu_status agree(const cobs_gpu_comm* c, cobs_gpu_batch* b, hipStream_t st, uint32_t mine, uint32_t* worst) {
+cobs_gpu_status agree(cobs_gpu_comm* c, cobs_gpu_batch* b, hipStream_t st, uint32_t mine, uint32_t* worst) {
+    if (cobs_gpu_status us = comm_usable(c); us != COBS_GPU_OK) return us;
     if (!b->xchg) b->xchg = new Exchange;
     Exchange& x = *b->xchg;
     HIP_TRY(x.d_meta.reserve(64));
     uint32_t* d = reinterpret_cast<uint32_t*>(x.d_meta.p);
     HIP_TRY(hipMemcpyAsync(d, &mine, 4, hipMemcpyHostToDevice, st));
-    NCCL_TRY(ncclAllReduce(d, d + 1, 1, ncclUint32, ncclMax, c->comm, st));
+    NCCL_C(c, st, ncclAllReduce(d, d + 1, 1, ncclUint32, ncclMax, c->comm, st));
     HIP_TRY(hipMemcpyAsync(worst, d + 1, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    if (cobs_gpu_status ws = sync_bounded(c, st, "the ranks' agreement (all-reduce of a status word)"); ws != COBS_GPU_OK) return ws;
     return COBS_GPU_OK;
 }
 
@@ -311,7 +427,10 @@ void cobs_gpu_comm_destroy(cobs_gpu_comm* c) {
     if (!c) return;
     if (c->comm) {
         (void)hipSetDevice(c->device);
-        (void)ncclCommDestroy(c->comm);
+        // (a communicator that failed is aborted, not destroyed: ncclCommDestroy waits for outstanding operations, and
+        // those of a broken communicator may wait for peers that are gone)
+        if (c->broken.load()) (void)ncclCommAbort(c->comm);
+        else (void)ncclCommDestroy(c->comm);
     }
     delete c;
 }
@@ -328,6 +447,163 @@ int cobs_gpu_comm_size(const cobs_gpu_comm* c) {
     return 0;
 }
 
+void cobs_gpu_comm_set_timeout(cobs_gpu_comm* c, uint32_t timeout_ms) {
+    if (c) c->timeout_ms = timeout_ms;
+}
+
+// What this rank's communicator entered last, as text -- safe to call from ANOTHER thread while the owner is inside a
+// call (the caller's watchdog): only atomics are read, plus one hipStreamQuery of the stream of the last call.
+size_t cobs_gpu_comm_state(const cobs_gpu_comm* c, char* buf, size_t cap) {
+    if (!c || !buf || cap == 0) return 0;
+    const uint64_t e = c->entered.load(), r = c->returned.load();
+    const char* op = c->last_op.load();
+    void* st = c->last_stream.load();
+    const char* stream = "no stream";
+    if (st || e) {
+        const hipError_t q = hipStreamQuery((hipStream_t)st);
+        (void)hipGetLastError();
+        stream = q == hipSuccess ? "stream idle" : q == hipErrorNotReady ? "stream busy" : "stream in error";
+    }
+    const int n = std::snprintf(buf, cap, "rank %d/%d device %d: rccl calls entered %llu returned %llu%s; last: %s; %s; %s", c->rank,
+                                c->nranks, c->device, (unsigned long long)e, (unsigned long long)r,
+                                e != r ? " (INSIDE a call)" : "", op, stream,
+                                c->broken.load() ? "communicator BROKEN" : "communicator ok");
+    return n < 0 ? 0 : std::min<size_t>((size_t)n, cap - 1);
+}
+
+// A communicator that came up is not yet one that moves bytes: the first collective is where a fabric or IPC
+// problem shows (peer memory that cannot be mapped, a link that is down), as a hang or as an error.  This runs, under
+// a time limit each, what the exchange of a batch uses -- one grouped ncclSend / ncclRecv all-to-all with a DIFFERENT
+// size for every (sender, receiver) pair, one ncclAllGather, one ncclAllReduce -- on small self-describing payloads,
+// and checks every received byte.  big_bytes > 0 adds a timed all-to-all of that many bytes per pair (what a link gives).
+// out[0..7] = all-to-all bytes received | its microseconds | all-gather us | all-reduce us | big bytes received | big us | 0 | 0
+cobs_gpu_status cobs_gpu_comm_preflight(cobs_gpu_comm* c, uint32_t timeout_ms, uint64_t big_bytes, uint64_t out[8]) {
+    if (!c || !out) return fail(COBS_GPU_ERR_ARG, "NULL argument");
+    return guarded([&]() -> cobs_gpu_status {
+        for (int i = 0; i < 8; ++i) out[i] = 0;
+        HIP_TRY(hipSetDevice(c->device));
+        if (cobs_gpu_status us = comm_usable(c); us != COBS_GPU_OK) return us;
+        const uint32_t keep_timeout = c->timeout_ms;
+        struct Restore { cobs_gpu_comm* c; uint32_t t; ~Restore() { c->timeout_ms = t; } } restore{c, keep_timeout};
+        c->timeout_ms = timeout_ms;
+        const size_t N = (size_t)c->nranks, me = (size_t)c->rank;
+        auto pair_bytes = [&](size_t from, size_t to) { return (size_t)(1 + (from * 7 + to * 3) % 5) * 1024 + 16 * from + to; };
+        auto pattern = [&](size_t from, size_t to, size_t k) { return (uint8_t)(from * 31 + to * 17 + k * 7 + 1); };
+        struct StreamOwner { hipStream_t s = nullptr; ~StreamOwner() { if (s) (void)hipStreamDestroy(s); } } so;
+        HIP_TRY(hipStreamCreateWithFlags(&so.s, hipStreamNonBlocking));
+        hipStream_t st = so.s;
+        auto now_us = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(
+                                      std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        // (1) all-to-all, uneven sizes
+        size_t send_total = 0, recv_total = 0;
+        std::vector<size_t> soff(N + 1, 0), roff(N + 1, 0);
+        for (size_t j = 0; j < N; ++j) {
+            soff[j + 1] = soff[j] + (j == me ? 0 : pair_bytes(me, j));
+            roff[j + 1] = roff[j] + (j == me ? 0 : pair_bytes(j, me));
+        }
+        send_total = soff[N];
+        recv_total = roff[N];
+        std::vector<uint8_t> h_send(std::max<size_t>(send_total, 1)), h_recv(std::max<size_t>(recv_total, 1), 0);
+        for (size_t j = 0; j < N; ++j)
+            for (size_t k = 0; k < soff[j + 1] - soff[j]; ++k) h_send[soff[j] + k] = pattern(me, j, k);
+        DevBuf<uint8_t> d_send, d_recv;
+        HIP_TRY(d_send.reserve(std::max<size_t>(send_total, 1)));
+        HIP_TRY(d_recv.reserve(std::max<size_t>(recv_total, 1)));
+        HIP_TRY(hipMemcpyAsync(d_send.p, h_send.data(), send_total, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(d_recv.p, 0, std::max<size_t>(recv_total, 1), st));
+        HIP_TRY(hipStreamSynchronize(st));
+        uint64_t t0 = now_us();
+        if (N > 1) {
+            GroupScope grp(c);
+            GROUP_START(grp);
+            for (size_t j = 0; j < N; ++j) {
+                if (j == me) continue;
+                NCCL_C(c, st, ncclSend(d_send.p + soff[j], soff[j + 1] - soff[j], ncclUint8, (int)j, c->comm, st));
+                NCCL_C(c, st, ncclRecv(d_recv.p + roff[j], roff[j + 1] - roff[j], ncclUint8, (int)j, c->comm, st));
+            }
+            GROUP_END(grp, st);
+        }
+        if (cobs_gpu_status ws = sync_bounded(c, st, "preflight: the grouped send / receive all-to-all"); ws != COBS_GPU_OK) return ws;
+        out[0] = recv_total;
+        out[1] = now_us() - t0;
+        if (recv_total) HIP_TRY(hipMemcpy(h_recv.data(), d_recv.p, recv_total, hipMemcpyDeviceToHost));
+        for (size_t j = 0; j < N; ++j)
+            for (size_t k = 0; k < roff[j + 1] - roff[j]; ++k)
+                if (h_recv[roff[j] + k] != pattern(j, me, k))
+                    return comm_fail(c, ncclInternalError, ("preflight: the all-to-all delivered a wrong byte from rank " + std::to_string(j)).c_str());
+        // (2) all-gather
+        const size_t gb = 4096;
+        DevBuf<uint8_t> d_g;
+        HIP_TRY(d_g.reserve(gb * (N + 1)));
+        std::vector<uint8_t> h_g(gb * (N + 1));
+        for (size_t k = 0; k < gb; ++k) h_g[k] = pattern(me, N, k);
+        HIP_TRY(hipMemcpyAsync(d_g.p, h_g.data(), gb, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        t0 = now_us();
+        NCCL_C(c, st, ncclAllGather(d_g.p, d_g.p + gb, gb, ncclUint8, c->comm, st));
+        if (cobs_gpu_status ws = sync_bounded(c, st, "preflight: ncclAllGather"); ws != COBS_GPU_OK) return ws;
+        out[2] = now_us() - t0;
+        HIP_TRY(hipMemcpy(h_g.data(), d_g.p, gb * (N + 1), hipMemcpyDeviceToHost));
+        for (size_t j = 0; j < N; ++j)
+            for (size_t k = 0; k < gb; ++k)
+                if (h_g[gb * (j + 1) + k] != pattern(j, N, k))
+                    return comm_fail(c, ncclInternalError, ("preflight: ncclAllGather delivered a wrong byte from rank " + std::to_string(j)).c_str());
+        // (3) all-reduce (max and sum of 32-bit words, as the status agreements use it)
+        DevBuf<uint32_t> d_r;
+        HIP_TRY(d_r.reserve(64));
+        uint32_t h_r[32];
+        for (uint32_t k = 0; k < 16; ++k) h_r[k] = (uint32_t)(me + 1) * (k + 1);
+        HIP_TRY(hipMemcpyAsync(d_r.p, h_r, 64, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        t0 = now_us();
+        NCCL_C(c, st, ncclAllReduce(d_r.p, d_r.p + 16, 16, ncclUint32, ncclMax, c->comm, st));
+        NCCL_C(c, st, ncclAllReduce(d_r.p, d_r.p + 32, 16, ncclUint32, ncclSum, c->comm, st));
+        if (cobs_gpu_status ws = sync_bounded(c, st, "preflight: ncclAllReduce"); ws != COBS_GPU_OK) return ws;
+        out[3] = now_us() - t0;
+        uint32_t h_o[32];
+        HIP_TRY(hipMemcpy(h_o, d_r.p + 16, 128, hipMemcpyDeviceToHost));
+        for (uint32_t k = 0; k < 16; ++k)
+            if (h_o[k] != (uint32_t)N * (k + 1) || h_o[16 + k] != (uint32_t)(N * (N + 1) / 2) * (k + 1))
+                return comm_fail(c, ncclInternalError, "preflight: ncclAllReduce returned a wrong value");
+        // (4) what a pair of links gives: every rank sends big_bytes to every other rank
+        if (big_bytes && N > 1) {
+            DevBuf<uint8_t> d_bs, d_br;
+            HIP_TRY(d_bs.reserve((size_t)big_bytes));
+            HIP_TRY(d_br.reserve((size_t)big_bytes * (N - 1)));
+            HIP_TRY(hipMemsetAsync(d_bs.p, (int)(me + 1), (size_t)big_bytes, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            for (int rep_i = 0; rep_i < 2; ++rep_i) {          // (the first round sets the connections up)
+                t0 = now_us();
+                GroupScope grp(c);
+                GROUP_START(grp);
+                size_t slot = 0;
+                for (size_t j = 0; j < N; ++j) {
+                    if (j == me) continue;
+                    NCCL_C(c, st, ncclSend(d_bs.p, (size_t)big_bytes, ncclUint8, (int)j, c->comm, st));
+                    NCCL_C(c, st, ncclRecv(d_br.p + slot * big_bytes, (size_t)big_bytes, ncclUint8, (int)j, c->comm, st));
+                    ++slot;
+                }
+                GROUP_END(grp, st);
+                if (cobs_gpu_status ws = sync_bounded(c, st, "preflight: the large all-to-all"); ws != COBS_GPU_OK) return ws;
+                out[5] = now_us() - t0;
+            }
+            out[4] = big_bytes * (N - 1);
+            // first and last byte of every peer's block
+            size_t slot = 0;
+            for (size_t j = 0; j < N; ++j) {
+                if (j == me) continue;
+                uint8_t ends[2] = {0, 0};
+                HIP_TRY(hipMemcpy(&ends[0], d_br.p + slot * big_bytes, 1, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(&ends[1], d_br.p + (slot + 1) * big_bytes - 1, 1, hipMemcpyDeviceToHost));
+                if (ends[0] != (uint8_t)(j + 1) || ends[1] != (uint8_t)(j + 1))
+                    return comm_fail(c, ncclInternalError, ("preflight: the large all-to-all delivered wrong bytes from rank " + std::to_string(j)).c_str());
+                ++slot;
+            }
+        }
+        return COBS_GPU_OK;
+    });
+}
+
 cobs_gpu_status cobs_gpu_batch_exchange_counts(cobs_gpu_batch* b, cobs_gpu_comm* c, uint32_t mode, void* hip_stream) {
     if (!b || !c) return fail(COBS_GPU_ERR_ARG, "NULL argument");
     if (!b->ran || !b->have_counts) return fail(COBS_GPU_ERR_ARG, "run the batch with score rows first");
@@ -336,6 +612,7 @@ cobs_gpu_status cobs_gpu_batch_exchange_counts(cobs_gpu_batch* b, cobs_gpu_comm*
         hipStream_t st = (hipStream_t)hip_stream;
         const cobs_gpu_index* ix = b->ix;
         HIP_TRY(hipSetDevice(ix->device));
+        if (cobs_gpu_status us = comm_usable(c); us != COBS_GPU_OK) return us;
         cobs_gpu_status s = bind_layout(b, c, st);
         if (s != COBS_GPU_OK) return s;
         Exchange& x = *b->xchg;
@@ -361,7 +638,7 @@ cobs_gpu_status cobs_gpu_batch_exchange_counts(cobs_gpu_batch* b, cobs_gpu_comm*
                                              (size_t)(my_n * eb), (size_t)(count * eb), nq, hipMemcpyDeviceToDevice, st));
                 local_off += count;
             }
-            if (bytes) NCCL_TRY(ncclAllReduce(x.global.p, x.global.p, bytes, ncclUint8, ncclSum, c->comm, st));
+            if (bytes) NCCL_C(c, st, ncclAllReduce(x.global.p, x.global.p, bytes, ncclUint8, ncclSum, c->comm, st));
             x.bytes_moved = N > 1 ? 2 * (N - 1) * bytes / N : 0;
             b->g_rows = x.global.p;
             b->g_q0 = 0;
@@ -377,19 +654,20 @@ cobs_gpu_status cobs_gpu_batch_exchange_counts(cobs_gpu_batch* b, cobs_gpu_comm*
         const uint8_t* mine = b->counts.p;
         if (p.use_allgather) {
             // same-size slices (always so on one rank): the library collective
-            NCCL_TRY(ncclAllGather(mine, x.staging.p, nq * p.my_row_bytes, ncclUint8, c->comm, st));
+            NCCL_C(c, st, ncclAllGather(mine, x.staging.p, nq * p.my_row_bytes, ncclUint8, c->comm, st));
             x.bytes_moved = (N - 1) * nq * p.my_row_bytes;
         } else {
             x.bytes_moved = p.staging_bytes;
             if (N > 1) {
-                NCCL_TRY(ncclGroupStart());
+                GroupScope grp(c);
+                GROUP_START(grp);
                 for (size_t j = 0; j < N; ++j) {
                     const cobs_gpu_xfer& t = p.xfers[j];
                     if (j == me) continue;
-                    if (t.send_bytes) NCCL_TRY(ncclSend(mine + t.send_offset, t.send_bytes, ncclUint8, (int)j, c->comm, st));
-                    if (t.recv_bytes) NCCL_TRY(ncclRecv(x.staging.p + t.recv_offset, t.recv_bytes, ncclUint8, (int)j, c->comm, st));
+                    if (t.send_bytes) NCCL_C(c, st, ncclSend(mine + t.send_offset, t.send_bytes, ncclUint8, (int)j, c->comm, st));
+                    if (t.recv_bytes) NCCL_C(c, st, ncclRecv(x.staging.p + t.recv_offset, t.recv_bytes, ncclUint8, (int)j, c->comm, st));
                 }
-                NCCL_TRY(ncclGroupEnd());
+                GROUP_END(grp, st);
             }
         }
         for (const cobs_gpu_copy2d& cp : p.copies)
@@ -424,22 +702,30 @@ uint64_t cobs_gpu_batch_exchange_bytes(const cobs_gpu_batch* b) { return b && b-
 // repeats the pass with score rows (every rank sees the same flag).
 cobs_gpu_status cobs_gpu_batch_exchange_hits(cobs_gpu_batch* b, cobs_gpu_comm* c, void* hip_stream, int* overflow) {
     if (!b || !c) return fail(COBS_GPU_ERR_ARG, "NULL argument");
-    if (!b->ran || !b->synced || !b->selected)
-        return fail(COBS_GPU_ERR_ARG, "run the batch with a threshold and sync it first");
+    // (what the CALLER did -- the same on every rank of a collective call; what only this rank's handle decides
+    // must not fail here, see `no_pool` below)
+    if (!b->ran || !b->synced || !(b->threshold > 0.0) || b->topk_k != 0)
+        return fail(COBS_GPU_ERR_ARG, "run the batch with a threshold (and no limit) and sync it first");
     return guarded([&]() -> cobs_gpu_status {
         hipStream_t st = (hipStream_t)hip_stream;
         HIP_TRY(hipSetDevice(b->ix->device));
+        if (cobs_gpu_status us = comm_usable(c); us != COBS_GPU_OK) return us;
         if (!b->xchg) b->xchg = new Exchange;
         Exchange& x = *b->xchg;
         const size_t N = (size_t)c->nranks, me = (size_t)c->rank;
+        // A handle whose streamed sub-indexes are counted in row ranges keeps score rows instead of selecting hits
+        // (pass.cpp: set_run_state) -- a property of THIS rank's shard and budget.  Such a rank must not leave the
+        // collective with an error of its own while its peers wait in it [ADVICE r4]: it travels through the size
+        // exchange as an impossible fill, every rank sees *overflow = 1 and repeats the pass with score rows.
+        const bool no_pool = !b->selected;
         // sizes first
-        const uint64_t mine = b->h_nhits();
+        const uint64_t mine = no_pool ? ~0ull : b->h_nhits();
         HIP_TRY(x.d_meta.reserve(N + 1 + 64));
         HIP_TRY(hipMemcpyAsync(x.d_meta.p, &mine, 8, hipMemcpyHostToDevice, st));
-        NCCL_TRY(ncclAllGather(x.d_meta.p, x.d_meta.p + 1, 8, ncclUint8, c->comm, st));
+        NCCL_C(c, st, ncclAllGather(x.d_meta.p, x.d_meta.p + 1, 8, ncclUint8, c->comm, st));
         std::vector<uint64_t> n(N);
         HIP_TRY(hipMemcpyAsync(n.data(), x.d_meta.p + 1, 8 * N, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        if (cobs_gpu_status ws = sync_bounded(c, st, "the all-gather of the hit-pool fills"); ws != COBS_GPU_OK) return ws;
         bool over = false;
         uint64_t total = 0;
         std::vector<uint64_t> off(N + 1, 0);
@@ -452,20 +738,21 @@ cobs_gpu_status cobs_gpu_batch_exchange_hits(cobs_gpu_batch* b, cobs_gpu_comm* c
         if (over) return COBS_GPU_OK;
         HIP_TRY(x.hits_all.reserve(std::max<size_t>((size_t)total, 1)));
         if (N > 1) {
-            NCCL_TRY(ncclGroupStart());
+            GroupScope grp(c);
+            GROUP_START(grp);
             for (size_t j = 0; j < N; ++j) {
                 if (j == me) continue;
-                if (mine) NCCL_TRY(ncclSend(b->hits.p, mine * sizeof(HitDev), ncclUint8, (int)j, c->comm, st));
-                if (n[j]) NCCL_TRY(ncclRecv(x.hits_all.p + off[j], n[j] * sizeof(HitDev), ncclUint8, (int)j, c->comm, st));
+                if (mine) NCCL_C(c, st, ncclSend(b->hits.p, mine * sizeof(HitDev), ncclUint8, (int)j, c->comm, st));
+                if (n[j]) NCCL_C(c, st, ncclRecv(x.hits_all.p + off[j], n[j] * sizeof(HitDev), ncclUint8, (int)j, c->comm, st));
             }
-            NCCL_TRY(ncclGroupEnd());
+            GROUP_END(grp, st);
         }
         if (mine)
             HIP_TRY(hipMemcpyAsync(x.hits_all.p + off[me], b->hits.p, mine * sizeof(HitDev), hipMemcpyDeviceToDevice, st));
         std::vector<HitDev> raw((size_t)total);
         if (total)
             HIP_TRY(hipMemcpyAsync(raw.data(), x.hits_all.p, total * sizeof(HitDev), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        if (cobs_gpu_status ws = sync_bounded(c, st, "the exchange of the hit records"); ws != COBS_GPU_OK) return ws;
         x.bytes_moved = (total - mine) * sizeof(HitDev);
         // bucket by query (the order inside a bucket is fixed later by the ranking sort)
         b->h_hit_off.assign(b->nq + 1, 0);
@@ -513,20 +800,24 @@ cobs_gpu_status cobs_gpu_hit_exchange_plan(const uint64_t* counts, size_t nranks
 cobs_gpu_status cobs_gpu_batch_exchange_hits_owned(cobs_gpu_batch* b, cobs_gpu_comm* c, void* hip_stream, int* overflow,
                                                    uint64_t* q_begin, uint64_t* q_count) {
     if (!b || !c) return fail(COBS_GPU_ERR_ARG, "NULL argument");
-    if (!b->ran || !b->synced || !b->selected)
-        return fail(COBS_GPU_ERR_ARG, "run the batch with a threshold and sync it first");
+    if (!b->ran || !b->synced || !(b->threshold > 0.0) || b->topk_k != 0)
+        return fail(COBS_GPU_ERR_ARG, "run the batch with a threshold (and no limit) and sync it first");
     if (c->nranks > 64) return fail(COBS_GPU_ERR_UNSUPPORTED, "more than 64 ranks");
     return guarded([&]() -> cobs_gpu_status {
         hipStream_t st = (hipStream_t)hip_stream;
         HIP_TRY(hipSetDevice(b->ix->device));
+        if (cobs_gpu_status us = comm_usable(c); us != COBS_GPU_OK) return us;
         if (!b->xchg) b->xchg = new Exchange;
         Exchange& x = *b->xchg;
         const size_t N = (size_t)c->nranks, me = (size_t)c->rank;
         const uint64_t q0 = (uint64_t)b->nq * me / N, q1 = (uint64_t)b->nq * (me + 1) / N;
         if (q_begin) *q_begin = q0;
         if (q_count) *q_count = q1 - q0;
-        const uint64_t mine = std::min<uint64_t>(b->h_nhits(), b->hit_cap);     // an overflowed pool is not routed (see below)
-        const bool over_here = b->h_nhits() > b->hit_cap;
+        // (a rank that kept score rows instead of a hit pool -- row-range chunks, see cobs_gpu_batch_exchange_hits --
+        // reports an overflow: every rank then repeats the pass with score rows)
+        const bool no_pool = !b->selected;
+        const uint64_t mine = no_pool ? 0 : std::min<uint64_t>(b->h_nhits(), b->hit_cap);     // an overflowed pool is not routed (see below)
+        const bool over_here = no_pool || b->h_nhits() > b->hit_cap;
         // (1) records per owner on this rank
         HIP_TRY(x.d_cursor.reserve(2 * N + 2));
         HIP_TRY(hipMemsetAsync(x.d_cursor.p, 0, 8 * N, st));
@@ -545,10 +836,10 @@ cobs_gpu_status cobs_gpu_batch_exchange_hits_owned(cobs_gpu_batch* b, cobs_gpu_c
         HIP_TRY(hipStreamSynchronize(st));
         if (over_here) cnt[0] = ~0ull;
         HIP_TRY(hipMemcpyAsync(x.d_meta.p, cnt.data(), 8 * N, hipMemcpyHostToDevice, st));
-        NCCL_TRY(ncclAllGather(x.d_meta.p, x.d_meta.p + N, 8 * N, ncclUint8, c->comm, st));
+        NCCL_C(c, st, ncclAllGather(x.d_meta.p, x.d_meta.p + N, 8 * N, ncclUint8, c->comm, st));
         std::vector<uint64_t> all(N * N);
         HIP_TRY(hipMemcpyAsync(all.data(), x.d_meta.p + N, 8 * N * N, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        if (cobs_gpu_status ws = sync_bounded(c, st, "the all-gather of the per-owner hit counts"); ws != COBS_GPU_OK) return ws;
         bool over = false;
         for (size_t r = 0; r < N; ++r) over = over || all[r * N] == ~0ull;
         if (overflow) *overflow = over ? 1 : 0;
@@ -570,19 +861,20 @@ cobs_gpu_status cobs_gpu_batch_exchange_hits_owned(cobs_gpu_batch* b, cobs_gpu_c
         uint8_t* recv = reinterpret_cast<uint8_t*>(x.hits_all.p);
         const uint8_t* send = reinterpret_cast<const uint8_t*>(x.hits_bucketed.p);
         if (N > 1) {
-            NCCL_TRY(ncclGroupStart());
+            GroupScope grp(c);
+            GROUP_START(grp);
             for (size_t j = 0; j < N; ++j) {
                 if (j == me) continue;
-                if (xf[j].send_bytes) NCCL_TRY(ncclSend(send + xf[j].send_offset, xf[j].send_bytes, ncclUint8, (int)j, c->comm, st));
-                if (xf[j].recv_bytes) NCCL_TRY(ncclRecv(recv + xf[j].recv_offset, xf[j].recv_bytes, ncclUint8, (int)j, c->comm, st));
+                if (xf[j].send_bytes) NCCL_C(c, st, ncclSend(send + xf[j].send_offset, xf[j].send_bytes, ncclUint8, (int)j, c->comm, st));
+                if (xf[j].recv_bytes) NCCL_C(c, st, ncclRecv(recv + xf[j].recv_offset, xf[j].recv_bytes, ncclUint8, (int)j, c->comm, st));
             }
-            NCCL_TRY(ncclGroupEnd());
+            GROUP_END(grp, st);
         }
         if (xf[me].send_bytes)
             HIP_TRY(hipMemcpyAsync(recv + xf[me].recv_offset, send + xf[me].send_offset, xf[me].send_bytes, hipMemcpyDeviceToDevice, st));
         std::vector<HitDev> raw((size_t)total);
         if (total) HIP_TRY(hipMemcpyAsync(raw.data(), x.hits_all.p, total * sizeof(HitDev), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        if (cobs_gpu_status ws = sync_bounded(c, st, "the owner-routed exchange of the hit records"); ws != COBS_GPU_OK) return ws;
         x.bytes_moved = tot[0] - xf[me].recv_bytes;
         // bucket by query (the order inside a bucket is fixed later by the ranking sort)
         b->h_hit_off.assign(b->nq + 1, 0);
@@ -644,19 +936,20 @@ cobs_gpu_status cobs_gpu_batch_exchange_topk(cobs_gpu_batch* b, cobs_gpu_comm* c
     return guarded([&]() -> cobs_gpu_status {
         hipStream_t st = (hipStream_t)hip_stream;
         HIP_TRY(hipSetDevice(b->ix->device));
+        if (cobs_gpu_status us = comm_usable(c); us != COBS_GPU_OK) return us;
         if (!b->xchg) b->xchg = new Exchange;
         Exchange& x = *b->xchg;
         const size_t N = (size_t)c->nranks, k = b->topk_k, nq = b->nq, np = b->ix->parts.size();
         const size_t ne = k * nq * np, nc = nq * np;
         HIP_TRY(x.topk_all.reserve(std::max<size_t>(N * ne, 1)));
         HIP_TRY(x.topk_cnt_all.reserve(std::max<size_t>(N * nc, 1)));
-        if (ne) NCCL_TRY(ncclAllGather(b->topk_out.p, x.topk_all.p, ne * sizeof(uint2), ncclUint8, c->comm, st));
-        if (nc) NCCL_TRY(ncclAllGather(b->topk_cnt.p, x.topk_cnt_all.p, nc * 4, ncclUint8, c->comm, st));
+        if (ne) NCCL_C(c, st, ncclAllGather(b->topk_out.p, x.topk_all.p, ne * sizeof(uint2), ncclUint8, c->comm, st));
+        if (nc) NCCL_C(c, st, ncclAllGather(b->topk_cnt.p, x.topk_cnt_all.p, nc * 4, ncclUint8, c->comm, st));
         std::vector<uint2> all(N * ne);
         std::vector<uint32_t> cnt(N * nc);
         if (ne) HIP_TRY(hipMemcpyAsync(all.data(), x.topk_all.p, N * ne * sizeof(uint2), hipMemcpyDeviceToHost, st));
         if (nc) HIP_TRY(hipMemcpyAsync(cnt.data(), x.topk_cnt_all.p, N * nc * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        if (cobs_gpu_status ws = sync_bounded(c, st, "the all-gather of the shards' best-of lists"); ws != COBS_GPU_OK) return ws;
         x.bytes_moved = (N - 1) * (ne * sizeof(uint2) + nc * 4);
         // [file][query][rank * k]: the candidates of all ranks side by side, packed to the front
         b->h_topk.assign(N * ne, make_uint2(0, 0));
@@ -723,16 +1016,22 @@ static cobs_gpu_status sharded_search_impl(cobs_gpu_index* ix, cobs_gpu_comm* c,
                 return fail(COBS_GPU_ERR_CAPACITY, "hit buffer too small; hit_offsets[nq] holds the needed size");
             }
         }
-        if (ix->ranged_agreed != c->serial) {
+        {
             // Which exchange a pass takes depends on whether its scan selected hits itself (run_impl); a rank whose
-            // streamed shard is counted in row ranges cannot -- then no rank does: one agreement per communicator.
+            // streamed shard is counted in row ranges cannot -- then no rank does.  Agreed on in EVERY call (4 bytes):
+            // a guard kept on the handle is local state -- a rank that reopened its index but kept the communicator
+            // would enter this all-reduce while its peers skip it [ADVICE r4].  The flag lives for this call only
+            // (PeersRanged), so that the handle behaves as before in a later search outside the communicator.
             uint32_t mine = 0, any = 0;
             for (const auto& p : ix->parts) mine |= p.has_row_ranges ? 1u : 0u;
             cobs_gpu_status as = agree(c, b, st, mine, &any);
             if (as != COBS_GPU_OK) return as;
             ix->peers_ranged = any != 0;
-            ix->ranged_agreed = c->serial;
         }
+        struct PeersRanged {
+            cobs_gpu_index* ix;
+            ~PeersRanged() { ix->peers_ranged = false; }
+        } peers_ranged_scope{ix};
         size_t g0 = 0;
         do {
             size_t g1 = g0;
@@ -742,8 +1041,10 @@ static cobs_gpu_status sharded_search_impl(cobs_gpu_index* ix, cobs_gpu_comm* c,
                 const uint64_t mt = std::max(max_terms, terms);
                 const int planes = scan_planes_for(mt);
                 const uint64_t eb = planes > 0 ? scan_score_bytes(planes) : 4u;
-                // local rows (bounded by the whole vector), plus the assembled global rows of the all-documents mode
-                const uint64_t sb = (uint64_t)(g1 - g0 + 1) * (ix->total_counts + (all_docs ? ix->total_counts : 0)) * eb;
+                // local rows (bounded by the whole vector), plus the assembled global rows where the pass exchanges rows:
+                // the all-documents mode, and a thresholded pass when some rank keeps score rows instead of a hit pool
+                const bool rows_travel = all_docs || (ix->peers_ranged && threshold > 0.0);
+                const uint64_t sb = (uint64_t)(g1 - g0 + 1) * (ix->total_counts + (rows_travel ? ix->total_counts : 0)) * eb;
                 const uint64_t t = (uint64_t)(lens[g1] + 16) * table_per_char;
                 if (g1 > g0 && (sb > ix->tune.pass_bytes || tb + t > ix->tune.pass_bytes)) break;
                 max_terms = mt;
@@ -822,7 +1123,7 @@ static cobs_gpu_status sharded_search_impl(cobs_gpu_index* ix, cobs_gpu_comm* c,
                 // they belong: the ranking and its PCIe traffic are divided by the number of GPUs
                 s = cobs_gpu_batch_exchange_counts(b, c, COBS_GPU_XCHG_ALLTOALL, st);
                 if (s != COBS_GPU_OK) return s;
-                HIP_TRY(hipStreamSynchronize(st));
+                if ((s = sync_bounded(c, st, "the all-to-all of the count rows")) != COBS_GPU_OK) return s;
                 const size_t q0 = (size_t)b->g_q0, qn = (size_t)b->g_qn;         // owned queries of this pass
                 size_t u = (g0 + q0) * per_query;
                 bool ovf = false;
@@ -851,7 +1152,7 @@ static cobs_gpu_status sharded_search_impl(cobs_gpu_index* ix, cobs_gpu_comm* c,
                 // every rank ranks every query (the contract of this call): all slices to all ranks
                 s = cobs_gpu_batch_exchange_counts(b, c, COBS_GPU_XCHG_ALLGATHER, st);
                 if (s != COBS_GPU_OK) return s;
-                HIP_TRY(hipStreamSynchronize(st));
+                if ((s = sync_bounded(c, st, "the all-gather of the count rows")) != COBS_GPU_OK) return s;
             }
             if (need_rows && ix->tune.device_rank != 0 && rank_on_device_applies(b, g1 - g0)) {
                 // whole (assembled, global) rows: ordered on the device, the records cross PCIe (rank.cpp) -- on a

@@ -589,7 +589,14 @@ cobs_gpu_status cobs_gpu_read_rows(const cobs_gpu_index* ix, size_t f, uint32_t 
 
 uint64_t cobs_gpu_graph_replays(const cobs_gpu_index* ix) { return ix ? ix->graph_replays : 0; }
 
-cobs_gpu_status cobs_gpu_stream_counters(const cobs_gpu_index* ix, uint64_t out[4]) {
+cobs_gpu_status cobs_gpu_stream_counters(const cobs_gpu_index* ix, uint64_t out[2]) {
+    if (!ix || !out) return fail(COBS_GPU_ERR_ARG, "NULL argument");
+    out[0] = ix->stream.fetched_chunks;
+    out[1] = ix->stream.streamed_chunks;
+    return COBS_GPU_OK;
+}
+
+cobs_gpu_status cobs_gpu_stream_traffic(const cobs_gpu_index* ix, uint64_t out[4]) {
     if (!ix || !out) return fail(COBS_GPU_ERR_ARG, "NULL argument");
     out[0] = ix->stream.fetched_chunks;
     out[1] = ix->stream.streamed_chunks;

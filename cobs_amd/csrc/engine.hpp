@@ -229,8 +229,7 @@ struct cobs_gpu_index {
     std::vector<cobs_amd::Part> parts;
     cobs_amd::StreamBufs stream;
     uint64_t total_counts = 0, local_counts = 0;
-    bool peers_ranged = false;    // sharded search: some rank counts a streamed sub-index in row ranges -> every rank keeps score rows
-    uint64_t ranged_agreed = 0;   // ... as agreed on the communicator with this serial (comm.cpp; 0 = not yet)
+    bool peers_ranged = false;    // inside ONE sharded search call: some rank counts a streamed sub-index in row ranges -> every rank keeps score rows (agreed on per call, comm.cpp)
     double timers[5] = {0, 0, 0, 0, 0};
     uint64_t graph_replays = 0;   // small passes of the host API served by a captured hipGraph
     static constexpr int kScratch = 3;

@@ -9,6 +9,8 @@
 // (threshold 0, no limit), whose ranking the devices SHARE: count rows go all-to-all to query owners, every worker
 // orders its queries and writes their results at their final places (cobs_gpu_sharded_search_batch_split).  Results
 // are identical to cobs_gpu_search_batch on one GPU.
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <condition_variable>
 #include <cstdlib>
@@ -153,8 +155,9 @@ cobs_gpu_status cobs_gpu_multi_open(const char* const* paths, size_t n_paths, co
             if (devices[i] < 0 || devices[i] >= nd)
                 return fail(COBS_GPU_ERR_ARG, "device ordinal " + std::to_string(devices[i]) + " out of range");
             // (RCCL refuses two ranks on one device; tests/mock_rccl runs N ranks of this handle on ONE GPU against a
-            // stand-in for it and says so with this variable)
-            for (size_t j = 0; j < i && !getenv("COBS_GPU_TEST_RANKS_SHARE_A_DEVICE"); ++j)
+            // stand-in for librccl, which says so by DEFINING this symbol -- nothing in a real environment does)
+            static const bool ranks_may_share = dlsym(RTLD_DEFAULT, "mock_rccl_ranks_may_share_a_device") != nullptr;
+            for (size_t j = 0; j < i && !ranks_may_share; ++j)
                 if (devices[j] == devices[i]) return fail(COBS_GPU_ERR_ARG, "a device is listed twice");
         }
         std::unique_ptr<cobs_gpu_multi> m(new cobs_gpu_multi);

@@ -7,7 +7,9 @@
 // that host threads then sort -- and while window w
 // crosses, window w+1 is being ordered and the host expands window w-1 from the pinned landing buffer into the
 // cobs_gpu_hit records (file, document, score) of the caller's (pageable) array.
-#include <emmintrin.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>      // non-temporal 16-byte stores of the host expansion (x86 hosts; a scalar loop elsewhere)
+#endif
 #include <pthread.h>
 #include <sched.h>
 
@@ -185,6 +187,7 @@ void expand_records(ExpandPool* pool, cobs_gpu_hit* dst, const void* src, size_t
                 const RankPart pt = parts[0];
                 const uint32_t bias = pt.doc_first - pt.slot0, f = pt.file_no;
                 size_t i = 0;
+#if defined(__SSE2__)
                 if ((reinterpret_cast<uintptr_t>(d) & 3u) == 0) {
                     for (; i < cnt && (reinterpret_cast<uintptr_t>(d + i) & 15u) != 0; ++i) {     // at most 3: 12 i mod 16
                         uint32_t slot, score;
@@ -201,6 +204,7 @@ void expand_records(ExpandPool* pool, cobs_gpu_hit* dst, const void* src, size_t
                     }
                     _mm_sfence();
                 }
+#endif
                 for (; i < cnt; ++i) {
                     uint32_t slot, score;
                     rec(first + i, slot, score);

@@ -71,6 +71,34 @@ class Comm:
         """ncclCommCount of the communicator"""
         return int(self._lib.cobs_gpu_comm_size(self._h))
 
+    def set_timeout(self, timeout_ms):
+        """the stream waits the library performs around collectives give up after this long (0 = never): the
+        communicator is aborted and the call fails with ERR_RCCL instead of waiting for a peer that never arrives"""
+        self._lib.cobs_gpu_comm_set_timeout(self._h, int(timeout_ms))
+
+    def state(self):
+        """one line: what this rank's communicator entered last -- callable from a watchdog thread while the owner
+        thread sits inside a call"""
+        if not getattr(self, "_h", None):
+            return "communicator closed"
+        buf = C.create_string_buffer(512)
+        n = self._lib.cobs_gpu_comm_state(self._h, buf, len(buf))
+        return buf.raw[:n].decode("utf-8", "replace")
+
+    def preflight(self, timeout_ms=20000, big_bytes=0):
+        """collective: the first bytes of a new communicator, each step under a time limit, every byte checked (uneven
+        grouped send / receive all-to-all, all-gather, all-reduce; big_bytes > 0: a timed all-to-all of that size per
+        pair).  -> dict of sizes and microseconds; raises CobsGpuError (the communicator is then unusable)"""
+        out = (C.c_uint64 * 8)()
+        _capi.check(self._lib.cobs_gpu_comm_preflight(self._h, int(timeout_ms), int(big_bytes), C.byref(out)))
+        res = {"alltoall_bytes": int(out[0]), "alltoall_us": int(out[1]), "allgather_us": int(out[2]),
+               "allreduce_us": int(out[3])}
+        if out[4]:
+            res["big_alltoall_bytes_received"] = int(out[4])
+            res["big_alltoall_us"] = int(out[5])
+            res["big_alltoall_recv_GBps"] = round(out[4] / max(out[5], 1) / 1e3, 2)
+        return res
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.cobs_gpu_comm_destroy(self._h)

@@ -330,12 +330,14 @@ class Search:
 
     def stream_counters(self):
         """out-of-core handles: (chunks fetched row by row, chunks copied whole) over all passes so far"""
-        return self.stream_traffic()[:2]
+        c = (C.c_uint64 * 2)()
+        check(self._lib.cobs_gpu_stream_counters(self._h, C.byref(c)))
+        return int(c[0]), int(c[1])
 
     def stream_traffic(self):
         """... and (bytes of looked-up rows fetched, bytes of whole chunks copied): what the passes asked of PCIe"""
         c = (C.c_uint64 * 4)()
-        check(self._lib.cobs_gpu_stream_counters(self._h, C.byref(c)))
+        check(self._lib.cobs_gpu_stream_traffic(self._h, C.byref(c)))
         return int(c[0]), int(c[1]), int(c[2]), int(c[3])
 
     def timers(self, reset=False):

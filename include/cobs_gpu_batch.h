@@ -114,6 +114,24 @@ cobs_gpu_status cobs_gpu_comm_create(const uint8_t id[COBS_GPU_UNIQUE_ID_BYTES],
 void cobs_gpu_comm_destroy(cobs_gpu_comm* c);
 int cobs_gpu_comm_rank(const cobs_gpu_comm* c);     /* ncclCommUserRank, -1 on error */
 int cobs_gpu_comm_size(const cobs_gpu_comm* c);     /* ncclCommCount, 0 on error */
+/* Failure behaviour of a communicator (the reference has no distributed code; this is the contract of the layer added
+ * here): an RCCL call that fails marks the communicator BROKEN -- an open ncclGroupStart is closed first, a dead
+ * communicator is aborted (ncclCommAbort) -- and every later call on it fails at once with COBS_GPU_ERR_RCCL on this
+ * rank, before any collective.  A collective that a peer never enters does not fail, it waits: */
+/* ... with a time limit, the stream waits the library itself performs around collectives (layout and size exchanges,
+ * status agreements, the row exchanges of cobs_gpu_sharded_search_batch) give up after timeout_ms, abort the
+ * communicator and return COBS_GPU_ERR_RCCL.  0 (default) = wait for ever. */
+void cobs_gpu_comm_set_timeout(cobs_gpu_comm* c, uint32_t timeout_ms);
+/* ... and what this rank entered last, as one line of text (RCCL calls entered / returned, the last call, whether its
+ * stream is idle) -- callable from ANOTHER thread while the owner sits in a call: what a caller's watchdog prints
+ * when a step does not come back.  -> characters written (NUL-terminated). */
+size_t cobs_gpu_comm_state(const cobs_gpu_comm* c, char* buf, size_t cap);
+/* Collective.  The first bytes a new communicator moves, each step under `timeout_ms` and every received byte checked:
+ * one grouped ncclSend / ncclRecv all-to-all with a different size for every (sender, receiver) pair, one
+ * ncclAllGather, ncclAllReduce(max, sum) -- the operations a batch exchange uses; big_bytes > 0 adds a timed all-to-all
+ * of that many bytes per pair.  out = all-to-all bytes received | its microseconds | all-gather us | all-reduce us |
+ * large all-to-all bytes received | its us (second round) | 0 | 0.  A failure leaves the communicator broken. */
+cobs_gpu_status cobs_gpu_comm_preflight(cobs_gpu_comm* c, uint32_t timeout_ms, uint64_t big_bytes, uint64_t out[8]);
 
 typedef enum cobs_gpu_exchange_mode {
     COBS_GPU_XCHG_ALLGATHER = 0,  /* every rank receives the count slices of all ranks for all queries

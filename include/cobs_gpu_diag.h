@@ -89,11 +89,14 @@ uint64_t cobs_gpu_graph_replays(const cobs_gpu_index* ix);
 /* Out-of-core handles (hbm_budget_bytes): how the chunks of all passes so far were brought into HBM.
  * out[0] = chunks whose looked-up rows were fetched one by one from the registered file mapping (a batch that
  * touches a fraction of the chunk's rows: the access pattern of the reference's mmap / AIO back-ends,
- * compact_index/mmap_search_file.cpp:34-67, aio_search_file.cpp:58-97), out[1] = chunks copied whole,
- * out[2] / out[3] = the bytes those two ways asked of PCIe (looked-up rows x row pitch; the rows of the whole chunks).
+ * compact_index/mmap_search_file.cpp:34-67, aio_search_file.cpp:58-97), out[1] = chunks copied whole.
  * Tuning keys "row_fetch" (0 = always whole) and "row_fetch_alpha" (fetch when alpha x looked-up bytes <= the
  * chunk's bytes; default 1, 0 = whenever the rows fit a stream buffer) steer the choice. */
-cobs_gpu_status cobs_gpu_stream_counters(const cobs_gpu_index* ix, uint64_t out[4]);
+cobs_gpu_status cobs_gpu_stream_counters(const cobs_gpu_index* ix, uint64_t out[2]);
+/* The same two counters in out[0] / out[1] plus out[2] / out[3] = the bytes those two ways asked of PCIe (looked-up
+ * rows x row pitch; the rows of the whole chunks).  (Its own symbol: round 4 had widened cobs_gpu_stream_counters to
+ * four words under the old name, which writes past the two-word buffer of a caller built against the older header.) */
+cobs_gpu_status cobs_gpu_stream_traffic(const cobs_gpu_index* ix, uint64_t out[4]);
 
 #ifdef __cplusplus
 }

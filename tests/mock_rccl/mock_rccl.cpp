@@ -15,6 +15,11 @@
 //   * a rank that waits 120 s for peers that never arrive gets ncclSystemError instead of waiting for ever.
 // A violation prints "[mock rccl] ..." on stderr and returns an error status to every rank involved.
 //
+// Fault injection (round 5; mock_rccl_inject below): the next ncclSend of a chosen rank returns an error, or posts one
+// byte less than it was asked to -- what comm.cpp has to survive without leaving a group open or a peer waiting for
+// ever (tests/test_gpu_mock_ranks.py, "fault" cases).  ncclCommAbort is local, as in RCCL: the aborting rank leaves,
+// its peers find out by their own time limit.
+//
 // Semantics kept: operations are stream-ordered (the mock synchronises the stream it is given, exchanges, and
 // returns; later work on that stream sees the data), in-place operation (sendbuff inside recvbuff) is allowed, a
 // group's sends and receives complete together at ncclGroupEnd.
@@ -65,6 +70,20 @@ struct Group {
 
 std::mutex g_registry_mu;
 std::map<std::string, Group*> g_registry;
+
+// fault injection: armed by the test, consumed by the first matching ncclSend
+std::mutex g_fault_mu;
+int g_fault_kind = 0, g_fault_rank = -1, g_fault_skip = 0;      // kind 1: return an error, 2: post one byte less
+int g_aborts = 0;
+
+int take_fault(int rank) {
+    std::lock_guard<std::mutex> lk(g_fault_mu);
+    if (g_fault_kind == 0 || g_fault_rank != rank) return 0;
+    if (g_fault_skip > 0) { --g_fault_skip; return 0; }
+    const int k = g_fault_kind;
+    g_fault_kind = 0;
+    return k;
+}
 
 size_t dtype_size(ncclDataType_t t) {
     switch (t) {
@@ -149,6 +168,20 @@ ncclResult_t exchange(ncclComm* c, Posted&& mine, Take take) {
 
 extern "C" {
 
+// ---- test controls (symbols only this stand-in defines) ----
+// multi.cpp refuses a device that is listed twice unless this symbol exists in the process
+int mock_rccl_ranks_may_share_a_device = 1;
+// arm a fault for the ncclSend calls of `rank`: kind 1 = it returns ncclSystemError, kind 2 = it posts one byte less
+// than asked (a size mismatch with the peer's receive); `skip` matching calls pass first.  kind 0 disarms.
+void mock_rccl_inject(int kind, int rank, int skip) {
+    std::lock_guard<std::mutex> lk(g_fault_mu);
+    g_fault_kind = kind;
+    g_fault_rank = rank;
+    g_fault_skip = skip;
+}
+int mock_rccl_group_depth(void) { return t_group_depth; }      // open groups of the CALLING thread
+int mock_rccl_aborts(void) { std::lock_guard<std::mutex> lk(g_fault_mu); return g_aborts; }
+
 const char* ncclGetErrorString(ncclResult_t r) {
     switch (r) {
         case ncclSuccess: return "no error";
@@ -208,6 +241,17 @@ ncclResult_t ncclCommDestroy(ncclComm_t c) {
         }
     }
     delete c;
+    return ncclSuccess;
+}
+
+// local, as in RCCL: this rank is gone, the peers notice when they wait for it
+ncclResult_t ncclCommAbort(ncclComm_t c) {
+    { std::lock_guard<std::mutex> lk(g_fault_mu); ++g_aborts; }
+    return ncclCommDestroy(c);
+}
+
+ncclResult_t ncclCommGetAsyncError(ncclComm_t c, ncclResult_t* e) {
+    if (e) *e = ncclSuccess;
     return ncclSuccess;
 }
 
@@ -284,9 +328,19 @@ ncclResult_t ncclSend(const void* sendbuff, size_t count, ncclDataType_t dt, int
     t_group_comm = c;
     t_group_stream = st;
     if (hipStreamSynchronize(st) != hipSuccess) return ncclUnhandledCudaError;
+    const int fault = take_fault(c->rank);
+    if (fault == 1) {
+        std::fprintf(stderr, "[mock rccl fault] rank %d: injected failure of ncclSend to rank %d\n", c->rank, peer);
+        return ncclSystemError;
+    }
     P2P s;
     s.peer = peer;
     s.bytes = count * dtype_size(dt);
+    if (fault == 2 && s.bytes > 0) {
+        std::fprintf(stderr, "[mock rccl fault] rank %d: injected short ncclSend to rank %d (%zu bytes instead of %zu)\n", c->rank, peer,
+                     s.bytes - 1, s.bytes);
+        s.bytes -= 1;
+    }
     s.dst = nullptr;
     s.data.resize(s.bytes);
     if (s.bytes && hipMemcpy(s.data.data(), sendbuff, s.bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
@@ -348,6 +402,19 @@ ncclResult_t ncclGroupEnd() {
                 std::fprintf(stderr, "[mock rccl] rank %d sends %zu message(s) to rank %d, which posted %zu receive(s) from it: on hardware this hangs\n",
                              c->rank, ns, j, nr);
                 r = ncclInvalidUsage;
+                continue;
+            }
+            // ... of the same sizes, in order (the receiver reports the mismatch too)
+            size_t k = 0;
+            for (const P2P& s : me.sends) {
+                if (s.peer != j) continue;
+                size_t seen = 0;
+                for (const P2P& rv : all[j].recvs)
+                    if (rv.peer == c->rank && seen++ == k) {
+                        if (rv.bytes != s.bytes) r = ncclInvalidUsage;
+                        break;
+                    }
+                ++k;
             }
         }
         return r;

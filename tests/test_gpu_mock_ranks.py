@@ -90,3 +90,57 @@ def test_bench_sharded_flow_over_n_ranks(mock_library, ranks):
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and r.stdout.strip().startswith("ok "), r.stdout[-3000:] + r.stderr[-8000:]
     assert "[mock rccl]" not in r.stderr, r.stderr[-6000:]
+
+
+# ---- round 5: faults between the ranks (the one-shot 8-GPU run must not come back empty) ----------
+def _fault(mock_library, case, ranks, timeout_s="8"):
+    env = dict(os.environ, LD_PRELOAD=mock_library, MOCK_RCCL_TIMEOUT_S=timeout_s)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mock_rccl", "run_fault_ranks.py"), case, str(ranks)],
+                          capture_output=True, text=True, timeout=900, env=env)
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_fault_a_failing_send_inside_a_group(mock_library, ranks):
+    """an ncclSend that returns an error inside ncclGroupStart .. ncclGroupEnd: the group is still closed on that rank
+    (comm.cpp: GroupScope), the dead communicator is aborted, the peers fail with it instead of waiting for the time
+    limit, every later call fails at once and says why"""
+    r = _fault(mock_library, "send_error", ranks)
+    assert r.returncode == 0 and r.stdout.strip().startswith("ok send_error"), r.stdout[-3000:] + r.stderr[-8000:]
+    assert "never entered the collective" not in r.stderr, r.stderr[-6000:]      # nobody had to be released by the time limit
+    assert "[mock rccl fault] rank 1: injected failure of ncclSend" in r.stderr
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_fault_a_size_mismatch_between_send_and_receive(mock_library, ranks):
+    """one byte less sent than the peer expects: both ends come back with ERR_RCCL (on hardware: a hang or silent
+    corruption), no group stays open, a third rank that enters the next collective alone is released by the time limit"""
+    r = _fault(mock_library, "size_mismatch", ranks)
+    assert r.returncode == 0 and r.stdout.strip().startswith("ok size_mismatch"), r.stdout[-3000:] + r.stderr[-8000:]
+    assert "[mock rccl fault] rank 0: injected short ncclSend" in r.stderr
+
+
+@pytest.mark.parametrize("ranks", [2, 5])
+def test_preflight_passes_when_healthy_and_fails_bounded_when_not(mock_library, ranks):
+    """cobs_gpu_comm_preflight -- what bench.py --gpus N runs before it builds the index: uneven all-to-all, all-gather,
+    all-reduce, every byte checked -- over N ranks; with a short first message it fails on the ranks involved, in time"""
+    r = _fault(mock_library, "preflight", ranks)
+    assert r.returncode == 0 and r.stdout.strip().startswith("ok preflight"), r.stdout[-3000:] + r.stderr[-8000:]
+
+
+def test_fault_a_rank_that_never_enters_the_exchange_ends_as_an_error_line(mock_library):
+    """bench.py's overlapped sharded flow with three ranks; the last one stops stepping.  The others wait in the
+    exchange (the stand-in would wait 60 s here, hardware for ever): bench.Watchdog ends the run after the phase's 6 s --
+    ONE JSON line with "error" and every rank's state (phase, step, what its communicator entered last) on stdout, the
+    same states on stderr, exit code 4"""
+    import json
+    r = _fault(mock_library, "watchdog", 3, timeout_s="60")
+    assert r.returncode == 4, (r.returncode, r.stdout[-2000:], r.stderr[-6000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    line = json.loads(lines[0])
+    assert line["value"] is None and line["n_gpus"] == 3 and "did not finish within" in line["error"]
+    per = line["watchdog"]["per_rank"]
+    assert [p["rank"] for p in per] == [0, 1, 2]
+    assert per[2]["step"] == 2 and "INSIDE a call" not in per[2]["comm"]            # the rank that stopped: outside RCCL
+    assert any("INSIDE a call" in p["comm"] or "stream busy" in p["comm"] for p in per[:2]), per       # its peers: waiting for it
+    assert r.stderr.count("[bench watchdog] rank") == 3

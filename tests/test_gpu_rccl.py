@@ -248,3 +248,51 @@ def test_native_sharded_search_random_ties(gpu_lib, oracle, tmp_path, comm, monk
             assert s.sharded_search_hits(comm, queries, t, lim, split=True) == want, (paths, budget, t, lim, "split")
         done += 1
     assert done >= 8
+
+
+def test_a_collective_that_does_not_finish_in_time_fails_instead_of_hanging(gpu_lib, oracle, tmp_path):
+    """round 5, on the REAL RCCL: with a time limit on the communicator (cobs_gpu_comm_set_timeout) a stream wait the
+    library performs around a collective gives up -- here the stream is kept busy by a long sleep kernel queued in front of
+    the all-gather of the pool fills, the stand-in for a peer that never arrives -- the communicator is aborted
+    (ncclCommAbort) and says why, later calls fail at once, the batch and the index stay usable without it"""
+    import time
+    from cobs_amd.distributed import Comm
+    paths, queries = _files(oracle, tmp_path)
+    ixs = [oracle.Index.open(p) for p in paths]
+    s = gpu_lib.Search(paths, device=0, shard_rank=0, shard_count=1)
+    b = gpu_lib.Batch(s)
+    b.set_queries(queries)
+    c = Comm(Comm.unique_id(), 0, 1, device=0)
+    assert "communicator ok" in c.state()
+    b.run(0.3)
+    b.sync()
+    assert b.exchange_hits(c) is False                      # healthy: no limit needed
+    assert "returned" in c.state() and "INSIDE" not in c.state()
+    c.set_timeout(150)
+    st = torch.cuda.Stream()
+    b.run(0.3)
+    b.sync()
+    t0 = time.time()
+    with torch.cuda.stream(st):
+        torch.cuda._sleep(int(6e9))                         # seconds of a busy stream
+    with pytest.raises(gpu_lib.CobsGpuError) as e:
+        b.exchange_hits(c, st.cuda_stream)
+    waited = time.time() - t0
+    assert e.value.status == 11 and "did not complete within 150 ms" in str(e.value), str(e.value)
+    assert waited < 5.0
+    assert "BROKEN" in c.state()
+    torch.cuda.synchronize()
+    with pytest.raises(gpu_lib.CobsGpuError) as e2:
+        b.exchange_hits(c)
+    assert "unusable after an earlier failure" in str(e2.value)
+    c.close()
+    # the batch goes on with a fresh communicator
+    c2 = Comm(Comm.unique_id(), 0, 1, device=0)
+    b.run(0.3)
+    b.sync()
+    assert b.exchange_hits(c2) is False
+    for i, q in enumerate(queries):
+        assert b.hits_host(i, 0) == cases.oracle_results(ixs, q, 0.3, 0)
+    pf = c2.preflight(timeout_ms=20000)                     # the real collectives of a one-rank communicator
+    assert pf["allgather_us"] > 0 and pf["allreduce_us"] > 0
+    c2.close()

@@ -299,3 +299,45 @@ def test_sharded_random_ties(gpu_lib, oracle, tmp_path, world):
     mp.spawn(_ties_worker, args=(world, port, cases_list, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert os.path.exists(os.path.join(str(tmp_path), "ties_ok%d" % r))
+
+
+# ---- round 5: the N-rank line cannot come back empty ---------------------------------------------
+def test_bench_two_rank_line_carries_the_preflight_record(gpu_lib):
+    """two gloo ranks on the one GPU: the line says what the preflight decided and which control plane ran the barriers"""
+    r, j, out = _bench(["--gpus", "2", "--dist-backend", "gloo", "--no-extras"] + SMALL)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert j["preflight"]["transport"] == "gloo" and "skipped" in j["preflight"]
+    assert j["control_plane"].startswith("torch.distributed/gloo")
+    _check_self_proving_fields(j, 2)
+
+
+def test_bench_rccl_preflight_failure_falls_back_to_the_host_transport(gpu_lib):
+    """the REAL RCCL refuses two ranks on one device: `--gpus 2 --share-devices` makes exactly that happen to the preflight
+    -- one child process per rank and IPC mode, both modes tried, the ranks agree -- and the run still comes back with a
+    true line: same shards, same exchange plan, the bytes through host memory, every attempt and error on record"""
+    r, j, out = _bench(["--gpus", "2", "--share-devices", "--no-extras", "--preflight-seconds", "90"] + SMALL, timeout=1200)
+    assert r.returncode == 0, r.stderr[-4000:]
+    pf = j["preflight"]
+    assert pf["transport"] == "gloo" and "fallback" in pf
+    assert [a["ok"] for a in pf["attempts"]] == [False, False]
+    assert sorted(a["HSA_ENABLE_IPC_MODE_LEGACY"] for a in pf["attempts"]) == ["0", "1"]
+    assert all(set(a["errors"]) == {"0", "1"} for a in pf["attempts"]), pf
+    assert j["rccl_ranks"] is None and j["exchange"]["transport"] == "torch.distributed/gloo"
+    _check_self_proving_fields(j, 2)
+
+
+def test_bench_hung_rank_ends_as_an_error_line_not_as_a_timeout(gpu_lib):
+    """rank 1 stops stepping after the first step (test hook): rank 0 waits in the exchange.  The watchdogs end the run
+    after --step-deadline: ONE line on stdout with "error", the phase and both ranks' states, a non-zero exit code"""
+    import time
+    t0 = time.time()
+    r, j, out = _bench(["--gpus", "2", "--dist-backend", "gloo", "--no-extras", "--test-hang-rank", "1", "--step-deadline", "10"] + SMALL,
+                       timeout=600)
+    assert r.returncode != 0
+    assert time.time() - t0 < 240
+    assert j is not None and j["value"] is None and j["n_gpus"] == 2, (out[-2000:], r.stderr[-3000:])
+    assert "did not finish within" in j["error"] and j["phase"] == "warm-up and timed steps"
+    per = j["watchdog"]["per_rank"]
+    assert per[0]["rank"] == 0 and per[1]["rank"] == 1 and per[1]["step"] >= 1, per
+    assert j["preflight"]["transport"] == "gloo"
+    assert r.stderr.count("[bench watchdog] rank") >= 2
