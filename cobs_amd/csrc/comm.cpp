@@ -74,6 +74,9 @@ struct Exchange {
     DevBuf<uint8_t> staging;                     // received slices, rank after rank
     DevBuf<uint8_t> global;                      // assembled rows
     DevBuf<uint64_t> d_meta;                     // small device scratch for size exchanges
+    // ... and its PINNED host side: a copy to or from pageable memory makes hipMemcpyAsync wait for the stream, i.e.
+    // for the collective in front of it -- inside the runtime, where no time limit reaches (sync_bounded below)
+    PinnedBuf<uint64_t> h_meta;
     DevBuf<HitDev> hits_all;                     // gathered hit pools
     DevBuf<HitDev> hits_bucketed;                // this rank's pool, bucketed by the rank that owns each record's query
     DevBuf<unsigned long long> d_cursor;         // [nranks] bucket counts / cursors
@@ -205,7 +208,8 @@ cobs_gpu_status bind_layout(cobs_gpu_batch* b, cobs_gpu_comm* c, hipStream_t st)
     if (x.bound == c->serial) return COBS_GPU_OK;
     const cobs_gpu_index* ix = b->ix;
     const size_t np = ix->parts.size(), per = 2 * np + 2, N = (size_t)c->nranks;
-    std::vector<uint64_t> mine(per);
+    HIP_TRY(x.h_meta.reserve(per * (N + 1)));
+    uint64_t* mine = x.h_meta.p;
     mine[0] = np;
     mine[1] = ix->total_counts;
     for (size_t f = 0; f < np; ++f) {
@@ -213,15 +217,15 @@ cobs_gpu_status bind_layout(cobs_gpu_batch* b, cobs_gpu_comm* c, hipStream_t st)
         mine[3 + 2 * f] = ix->parts[f].slot_count;
     }
     HIP_TRY(x.d_meta.reserve(per * (N + 1)));
-    HIP_TRY(hipMemcpyAsync(x.d_meta.p, mine.data(), per * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(x.d_meta.p, mine, per * 8, hipMemcpyHostToDevice, st));
     NCCL_C(c, st, ncclAllGather(x.d_meta.p, x.d_meta.p + per, per * 8, ncclUint8, c->comm, st));
-    std::vector<uint64_t> all(per * N);
-    HIP_TRY(hipMemcpyAsync(all.data(), x.d_meta.p + per, per * N * 8, hipMemcpyDeviceToHost, st));
+    const uint64_t* all = x.h_meta.p + per;
+    HIP_TRY(hipMemcpyAsync(x.h_meta.p + per, x.d_meta.p + per, per * N * 8, hipMemcpyDeviceToHost, st));
     if (cobs_gpu_status ws = sync_bounded(c, st, "the all-gather of the shard layouts"); ws != COBS_GPU_OK) return ws;
     x.layout.assign(N * np * 2, 0);
     x.local_n.assign(N, 0);
     for (size_t r = 0; r < N; ++r) {
-        const uint64_t* m = all.data() + r * per;
+        const uint64_t* m = all + r * per;
         if (m[0] != np || m[1] != ix->total_counts)
             return fail(COBS_GPU_ERR_ARG, "the ranks of the communicator did not open the same index files");
         for (size_t f = 0; f < np; ++f) {
@@ -320,11 +324,15 @@ cobs_gpu_status agree(cobs_gpu_comm* c, cobs_gpu_batch* b, hipStream_t st, uint3
     if (!b->xchg) b->xchg = new Exchange;
     Exchange& x = *b->xchg;
     HIP_TRY(x.d_meta.reserve(64));
+    HIP_TRY(x.h_meta.reserve(64));
     uint32_t* d = reinterpret_cast<uint32_t*>(x.d_meta.p);
-    HIP_TRY(hipMemcpyAsync(d, &mine, 4, hipMemcpyHostToDevice, st));
+    uint32_t* h = reinterpret_cast<uint32_t*>(x.h_meta.p);
+    h[0] = mine;
+    HIP_TRY(hipMemcpyAsync(d, h, 4, hipMemcpyHostToDevice, st));
     NCCL_C(c, st, ncclAllReduce(d, d + 1, 1, ncclUint32, ncclMax, c->comm, st));
-    HIP_TRY(hipMemcpyAsync(worst, d + 1, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h + 1, d + 1, 4, hipMemcpyDeviceToHost, st));
     if (cobs_gpu_status ws = sync_bounded(c, st, "the ranks' agreement (all-reduce of a status word)"); ws != COBS_GPU_OK) return ws;
+    *worst = h[1];
     return COBS_GPU_OK;
 }
 
@@ -721,11 +729,13 @@ cobs_gpu_status cobs_gpu_batch_exchange_hits(cobs_gpu_batch* b, cobs_gpu_comm* c
         // sizes first
         const uint64_t mine = no_pool ? ~0ull : b->h_nhits();
         HIP_TRY(x.d_meta.reserve(N + 1 + 64));
-        HIP_TRY(hipMemcpyAsync(x.d_meta.p, &mine, 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(x.h_meta.reserve(N + 1 + 64));
+        x.h_meta.p[0] = mine;
+        HIP_TRY(hipMemcpyAsync(x.d_meta.p, x.h_meta.p, 8, hipMemcpyHostToDevice, st));
         NCCL_C(c, st, ncclAllGather(x.d_meta.p, x.d_meta.p + 1, 8, ncclUint8, c->comm, st));
-        std::vector<uint64_t> n(N);
-        HIP_TRY(hipMemcpyAsync(n.data(), x.d_meta.p + 1, 8 * N, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(x.h_meta.p + 1, x.d_meta.p + 1, 8 * N, hipMemcpyDeviceToHost, st));
         if (cobs_gpu_status ws = sync_bounded(c, st, "the all-gather of the hit-pool fills"); ws != COBS_GPU_OK) return ws;
+        const std::vector<uint64_t> n(x.h_meta.p + 1, x.h_meta.p + 1 + N);
         bool over = false;
         uint64_t total = 0;
         std::vector<uint64_t> off(N + 1, 0);
@@ -749,10 +759,12 @@ cobs_gpu_status cobs_gpu_batch_exchange_hits(cobs_gpu_batch* b, cobs_gpu_comm* c
         }
         if (mine)
             HIP_TRY(hipMemcpyAsync(x.hits_all.p + off[me], b->hits.p, mine * sizeof(HitDev), hipMemcpyDeviceToDevice, st));
+        // (the bounded wait BEFORE the copy to pageable memory: that copy waits for the stream inside the runtime)
+        if (cobs_gpu_status ws = sync_bounded(c, st, "the exchange of the hit records"); ws != COBS_GPU_OK) return ws;
         std::vector<HitDev> raw((size_t)total);
         if (total)
             HIP_TRY(hipMemcpyAsync(raw.data(), x.hits_all.p, total * sizeof(HitDev), hipMemcpyDeviceToHost, st));
-        if (cobs_gpu_status ws = sync_bounded(c, st, "the exchange of the hit records"); ws != COBS_GPU_OK) return ws;
+        HIP_TRY(hipStreamSynchronize(st));
         x.bytes_moved = (total - mine) * sizeof(HitDev);
         // bucket by query (the order inside a bucket is fixed later by the ranking sort)
         b->h_hit_off.assign(b->nq + 1, 0);
@@ -837,9 +849,10 @@ cobs_gpu_status cobs_gpu_batch_exchange_hits_owned(cobs_gpu_batch* b, cobs_gpu_c
         if (over_here) cnt[0] = ~0ull;
         HIP_TRY(hipMemcpyAsync(x.d_meta.p, cnt.data(), 8 * N, hipMemcpyHostToDevice, st));
         NCCL_C(c, st, ncclAllGather(x.d_meta.p, x.d_meta.p + N, 8 * N, ncclUint8, c->comm, st));
-        std::vector<uint64_t> all(N * N);
-        HIP_TRY(hipMemcpyAsync(all.data(), x.d_meta.p + N, 8 * N * N, hipMemcpyDeviceToHost, st));
+        HIP_TRY(x.h_meta.reserve(N * N + 64));
+        HIP_TRY(hipMemcpyAsync(x.h_meta.p, x.d_meta.p + N, 8 * N * N, hipMemcpyDeviceToHost, st));
         if (cobs_gpu_status ws = sync_bounded(c, st, "the all-gather of the per-owner hit counts"); ws != COBS_GPU_OK) return ws;
+        const std::vector<uint64_t> all(x.h_meta.p, x.h_meta.p + N * N);
         bool over = false;
         for (size_t r = 0; r < N; ++r) over = over || all[r * N] == ~0ull;
         if (overflow) *overflow = over ? 1 : 0;
@@ -872,9 +885,10 @@ cobs_gpu_status cobs_gpu_batch_exchange_hits_owned(cobs_gpu_batch* b, cobs_gpu_c
         }
         if (xf[me].send_bytes)
             HIP_TRY(hipMemcpyAsync(recv + xf[me].recv_offset, send + xf[me].send_offset, xf[me].send_bytes, hipMemcpyDeviceToDevice, st));
+        if (cobs_gpu_status ws = sync_bounded(c, st, "the owner-routed exchange of the hit records"); ws != COBS_GPU_OK) return ws;
         std::vector<HitDev> raw((size_t)total);
         if (total) HIP_TRY(hipMemcpyAsync(raw.data(), x.hits_all.p, total * sizeof(HitDev), hipMemcpyDeviceToHost, st));
-        if (cobs_gpu_status ws = sync_bounded(c, st, "the owner-routed exchange of the hit records"); ws != COBS_GPU_OK) return ws;
+        HIP_TRY(hipStreamSynchronize(st));
         x.bytes_moved = tot[0] - xf[me].recv_bytes;
         // bucket by query (the order inside a bucket is fixed later by the ranking sort)
         b->h_hit_off.assign(b->nq + 1, 0);
@@ -945,11 +959,12 @@ cobs_gpu_status cobs_gpu_batch_exchange_topk(cobs_gpu_batch* b, cobs_gpu_comm* c
         HIP_TRY(x.topk_cnt_all.reserve(std::max<size_t>(N * nc, 1)));
         if (ne) NCCL_C(c, st, ncclAllGather(b->topk_out.p, x.topk_all.p, ne * sizeof(uint2), ncclUint8, c->comm, st));
         if (nc) NCCL_C(c, st, ncclAllGather(b->topk_cnt.p, x.topk_cnt_all.p, nc * 4, ncclUint8, c->comm, st));
+        if (cobs_gpu_status ws = sync_bounded(c, st, "the all-gather of the shards' best-of lists"); ws != COBS_GPU_OK) return ws;
         std::vector<uint2> all(N * ne);
         std::vector<uint32_t> cnt(N * nc);
         if (ne) HIP_TRY(hipMemcpyAsync(all.data(), x.topk_all.p, N * ne * sizeof(uint2), hipMemcpyDeviceToHost, st));
         if (nc) HIP_TRY(hipMemcpyAsync(cnt.data(), x.topk_cnt_all.p, N * nc * 4, hipMemcpyDeviceToHost, st));
-        if (cobs_gpu_status ws = sync_bounded(c, st, "the all-gather of the shards' best-of lists"); ws != COBS_GPU_OK) return ws;
+        HIP_TRY(hipStreamSynchronize(st));
         x.bytes_moved = (N - 1) * (ne * sizeof(uint2) + nc * 4);
         // [file][query][rank * k]: the candidates of all ranks side by side, packed to the front
         b->h_topk.assign(N * ne, make_uint2(0, 0));

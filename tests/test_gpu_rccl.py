@@ -252,7 +252,7 @@ def test_native_sharded_search_random_ties(gpu_lib, oracle, tmp_path, comm, monk
 
 def test_a_collective_that_does_not_finish_in_time_fails_instead_of_hanging(gpu_lib, oracle, tmp_path):
     """round 5, on the REAL RCCL: with a time limit on the communicator (cobs_gpu_comm_set_timeout) a stream wait the
-    library performs around a collective gives up -- here the stream is kept busy by a long sleep kernel queued in front of
+    library performs around a collective gives up -- here the stream is held by a host function queued in front of
     the all-gather of the pool fills, the stand-in for a peer that never arrives -- the communicator is aborted
     (ncclCommAbort) and says why, later calls fail at once, the batch and the index stay usable without it"""
     import time
@@ -272,14 +272,24 @@ def test_a_collective_that_does_not_finish_in_time_fails_instead_of_hanging(gpu_
     st = torch.cuda.Stream()
     b.run(0.3)
     b.sync()
+    # (a host function queued on the stream sleeps 2 s: tests/mock_rccl/stall.cpp, built here with g++)
+    import ctypes
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "libstall.so")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(root, "tests", "mock_rccl", "stall.cpp"), "-o", so, "-L/opt/rocm/lib", "-lamdhip64",
+                           "-lpthread", "-Wl,-rpath,/opt/rocm/lib"])
+    stall = ctypes.CDLL(so)
+    stall.stall_stream.argtypes = [ctypes.c_void_p, ctypes.c_long]
     t0 = time.time()
-    with torch.cuda.stream(st):
-        torch.cuda._sleep(int(6e9))                         # seconds of a busy stream
+    assert stall.stall_stream(st.cuda_stream, 2000) == 0
     with pytest.raises(gpu_lib.CobsGpuError) as e:
         b.exchange_hits(c, st.cuda_stream)
     waited = time.time() - t0
     assert e.value.status == 11 and "did not complete within 150 ms" in str(e.value), str(e.value)
-    assert waited < 5.0
+    assert waited < 10.0
     assert "BROKEN" in c.state()
     torch.cuda.synchronize()
     with pytest.raises(gpu_lib.CobsGpuError) as e2:
