@@ -78,6 +78,64 @@ def make_queries(n, kmers, seed=42):
     return [text[i].tobytes() for i in range(n)]
 
 
+PLANT_SALT = 0x5EED0FC0B5
+PLANT_KEEP = (1000, 950, 900, 850, 800, 700, 500)
+
+
+def planted_documents(cfg, kmers=1000, n_seq=64, docs_per_seq=48, seed=7):
+    """TRUE POSITIVES of the synthetic index ("for parity plant true positives"): random
+    bits alone score every document ~ Binomial(T, 0.3), so no query ever reaches the CLI's default threshold 0.8
+    (src/cobs.cpp:486-489) and the thresholded paths would be measured and tested empty-handed.  `n_seq` random
+    sequences of kmers + 230 bases; each is a part of `docs_per_seq` documents spread over the whole index, which hold
+    100 % ... 50 % of its terms (PLANT_KEEP in rotation; the rule: cobs_gpu_plant, include/cobs_gpu_batch.h).
+    -> list of (text, docs uint32[], keep_permille uint32[]); the same list for the GPU index and for the checker's"""
+    rs = np.random.RandomState(seed)
+    out = []
+    nd = int(cfg["num_docs"])
+    for _ in range(n_seq):
+        text = np.frombuffer(b"ACGT", dtype=np.uint8)[rs.randint(0, 4, size=kmers + 230)].tobytes()
+        docs = rs.choice(nd, size=min(docs_per_seq, nd), replace=False).astype(np.uint32)
+        keep = np.array([PLANT_KEEP[i % len(PLANT_KEEP)] for i in range(len(docs))], dtype=np.uint32)
+        out.append((text, docs, keep))
+    return out
+
+
+def planted_queries(plants, n, kmers=1000, seed=11):
+    """queries WITH hits: query q is a window of kmers + 30 bases of planted sequence q % n_seq with 0 / 0.2 / 0.5 / 1 %
+    of its bases changed (by q // n_seq % 4), so that (1 - m)^31 = 100 / 94 / 86 / 73 % of its terms are intact: together
+    with the documents' own shares the scores of the planted documents lie on both sides of 0.8 T"""
+    rs = np.random.RandomState(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    out = []
+    for q in range(n):
+        text = np.frombuffer(plants[q % len(plants)][0], dtype=np.uint8)
+        off = int(rs.randint(0, len(text) - (kmers + 30) + 1))
+        w = text[off:off + kmers + 30].copy()
+        m = (0.0, 0.002, 0.005, 0.01)[(q // len(plants)) % 4]
+        hit = np.nonzero(rs.random_sample(len(w)) < m)[0]
+        for i in hit:
+            w[i] = acgt[(int(np.searchsorted(acgt, w[i])) + 1 + int(rs.randint(0, 3))) % 4]
+        out.append(w.tobytes())
+    return out
+
+
+def apply_plants(index, plants):
+    """index: cobs_amd.Search (a shard plants the documents it holds) or the checker's oracle.Index"""
+    for text, docs, keep in plants:
+        index.plant(text, docs, keep, salt=PLANT_SALT)
+
+
+def oracle_index(cfg, plants=None):
+    """the checker's own instance of the procedural index (it regenerates rows from the definition; nothing is read back
+    from the GPU), with the same planted documents"""
+    from oracle import oracle as O
+    gen = O.Index.synthetic(1 if cfg["kind"] == "compact" else 0, cfg["term_size"], cfg["canonicalize"], cfg["num_hashes"],
+                            cfg["page_size"], cfg["signature_sizes"], cfg["num_docs"], cfg["seed"])
+    if plants:
+        apply_plants(gen, plants)
+    return gen
+
+
 def cpu_baseline(search, cfg, queries, seconds_target=12.0, check_queries=4, batch=None):
     """Time the oracle (plain-C port of the reference algorithm: per-batch row
     gather -> AND -> LUT/SSE2 expand-add -> threshold -> partial sort) on this
@@ -120,8 +178,7 @@ def cpu_baseline(search, cfg, queries, seconds_target=12.0, check_queries=4, bat
     # (the checker regenerates the procedural rows itself: nothing is read back from the GPU for it)
     bit_exact, checked = None, {}
     if batch is not None:
-        gen = O.Index.synthetic(kind, cfg["term_size"], cfg["canonicalize"], cfg["num_hashes"],
-                                cfg["page_size"], sigs, cfg["num_docs"], cfg["seed"])
+        gen = oracle_index(cfg, cfg.get("plants"))
         n_sum = min(64, len(queries))
         eb = batch.counts_device()[1]
         t_all = batch.counts_tensor()[:n_sum].to(torch.int64)
@@ -132,7 +189,7 @@ def cpu_baseline(search, cfg, queries, seconds_target=12.0, check_queries=4, bat
         dev_wsum = (t_all * w).sum(dim=1).cpu().numpy()
         wn = (np.arange(t_all.shape[1], dtype=np.int64) % 1021) + 1
         bit_exact = True
-        n_rows = min(16, len(queries))
+        n_rows = min(64, len(queries))
         for i in range(n_sum):
             want = gen.counts(queries[i])
             bit_exact = bit_exact and int(dev_sum[i]) == int(want.sum()) \
@@ -172,6 +229,9 @@ def cpu_baseline(search, cfg, queries, seconds_target=12.0, check_queries=4, bat
         qpsb, nb, dtb, best_threads = qps_all, n_all, dt_all, min(ncores, len(queries))
         how = "%d threads, one query per thread (all host cores)" % best_threads
     res = {"value": round(qpsb, 2), "unit": "queries/s", "cores": best_threads, "kind": "port",
+           # the port is bit-exact against the reference's known answers; its SPEED has one survey-time calibration
+           # point only (89 vs 87.5 queries/s full search on another CPU): a stated baseline, not a target
+           "calibrated_vs_reference": False,
            "sample": "%d of the batch's queries, per-document counts (same step as the GPU: hash + "
                      "gather + AND + expand-add), %s, %.1f s; %s; index resident in host RAM"
                      % (nb, how, dtb, sample),
@@ -187,24 +247,44 @@ def cpu_baseline(search, cfg, queries, seconds_target=12.0, check_queries=4, bat
     return res
 
 
-def end_to_end(search, batch, queries):
+def end_to_end(search, batch, queries, hit_queries=None):
     """PCIe-inclusive rates of the host-buffer API on the same batch (never `value`):
-    query text H2D + K1 + K2 (+ selection) + D2H of the results + host ordering."""
+    query text H2D + K1 + K2 (+ selection) + D2H of the results + host ordering.
+    hit_queries: a batch of the same shape whose queries HAVE hits at threshold 0.8 (planted_queries): the
+    thresholded call then carries records through compaction, D2H and the host-side ordering."""
     res = {}
     nq = len(queries)
-    # the query text as one host buffer + offsets (search_packed); the passes of a call are pipelined
-    text = np.frombuffer(b"".join(queries), dtype=np.uint8)
-    offsets = np.zeros(nq + 1, dtype=np.uint64)
-    np.cumsum([len(q) for q in queries], out=offsets[1:])
-    for name, thr, k in (("threshold_0.8_all_hits", 0.8, 0), ("threshold_0_top10", 0.0, 10)):
-        search.search_packed(text, offsets, thr, k)              # sizes the scratch workspaces
-        best = None
+
+    def packed(qs):
+        # the query text as one host buffer + offsets (search_packed); the passes of a call are pipelined
+        t = np.frombuffer(b"".join(qs), dtype=np.uint8)
+        o = np.zeros(len(qs) + 1, dtype=np.uint64)
+        np.cumsum([len(q) for q in qs], out=o[1:])
+        return t, o
+    text, offsets = packed(queries)
+    cases_ = [("threshold_0.8_random_queries", 0.8, 0, text, offsets), ("threshold_0_top10", 0.0, 10, text, offsets)]
+    if hit_queries:
+        ht, ho = packed(hit_queries)
+        cases_.insert(0, ("threshold_0.8_all_hits", 0.8, 0, ht, ho))
+    for name, thr, k, tx, of in cases_:
+        search.search_packed(tx, of, thr, k)              # sizes the scratch workspaces
+        best, tm_best = None, None
         for _ in range(3):
+            search.timers(reset=True)
             t0 = time.perf_counter()
-            offs, hits = search.search_packed(text, offsets, thr, k)
+            offs, hits = search.search_packed(tx, of, thr, k)
             dt = time.perf_counter() - t0
-            best = dt if best is None else min(best, dt)
-        res[name] = {"queries_per_s": round(nq / best, 1), "seconds": round(best, 4), "hits": int(len(hits))}
+            if best is None or dt < best:
+                best, tm_best = dt, search.timers()
+        res[name] = {"queries_per_s": round(nq / best, 1), "seconds": round(best, 4), "hits": int(len(hits)),
+                     "hit_bytes_to_host": int(len(hits)) * 12,
+                     "phase_seconds": {k_: round(v, 5) for k_, v in tm_best.items()}}
+        if name == "threshold_0.8_all_hits":
+            per = np.diff(np.asarray(offs, dtype=np.int64))
+            res[name]["queries_with_hits"] = int((per > 0).sum())
+            res[name]["hits_per_query_max"] = int(per.max()) if len(per) else 0
+            res[name]["is"] = ("queries that are mutated windows of the planted sequences: hit records selected in the scan, compacted "
+                               "into the pool, copied to the host and ordered there (phase_seconds: the library's own timers)")
     # the reference's default call (threshold 0, no limit; what its own benchmark times, src/cobs.cpp:618-626):
     # EVERY document of every query in rank order.  The rows are ordered on the device (rank_kernels.hip) and
     # the finished 12-byte records cross PCIe; 256 queries per call into a result array the caller keeps.
@@ -285,6 +365,64 @@ def cache_cold_probe(search, cfg, queries, kmers, row_bytes, nq=256, steps=10):
     return res
 
 
+def hbm_side_probe(args, queries, dev, scale=8.0, exact_rows=16):
+    """What leaves the HBM pins at FULL occupancy.  The headline batch -- the same 10 000 queries x
+    1000 k-mers, the same kernel and launch geometry -- against the C3 geometry with every sub-index `scale` times as
+    long: 147 GB resident in the 288 GB of one MI355X at scale 8.  A row is then looked up 0.3-5 times per batch instead
+    of 2.5-40 times, the working set of a 128-byte tile column (S_p x 128 B: 256 MB ... 4 GB) no longer fits the 256 MB
+    Infinity Cache, and 56 % of the algorithmic bytes are DISTINCT rows that have to cross the pins: `unique_frac` is a
+    floor of the pin-side fraction from a grid that fills the device for 21 ms (cache_cold's 256 queries fill it for half
+    a millisecond).  A quarter of the batch on the same index repeats even less (unique / algorithmic 0.84).
+    Parity: `exact_rows` rows of the batch element by element against rows the oracle regenerates for THAT index."""
+    from oracle import oracle as O
+    cfg = c3_config(scale)
+    cfg["num_hashes"] = args.num_hashes
+    if not args.no_plants:
+        cfg["plants"] = planted_documents(cfg, args.kmers)
+    s = make_index(cfg, dev)
+    info0 = s.info(0)
+    row_bytes = int(info0.page_size)
+    out = {"index_bytes": int(sum(cfg["signature_sizes"]) * row_bytes), "scale": scale,
+           "workload": "the headline batch on the C3 geometry with S_p x %g (%.0f GB resident)"
+                       % (scale, sum(cfg["signature_sizes"]) * row_bytes / 1e9)}
+    b = cobs_amd.Batch(s)
+    for name, nq in (("batch", len(queries)), ("quarter_batch", max(1, len(queries) // 4))):
+        b.set_queries(queries[:nq])
+        for _ in range(2):
+            b.run(0.0, 0)
+        b.sync()
+        b.kernel_ms()
+        for _ in range(5):
+            b.run(0.0, 0)
+        b.sync()
+        ms = b.kernel_ms()["scan_ms"]
+        algo = b.stats()["algorithmic_bytes"]
+        uniq, looked = unique_row_bytes(cfg, nq, args.kmers, row_bytes)
+        score_bytes = max(0, algo - looked)
+        ent = {"queries": nq, "scan_ms": round(ms, 4), "algorithmic_bytes": algo, "unique_bytes": int(uniq + score_bytes),
+               "achieved": round(algo / (ms * 1e-3) / 1e9, 1), "frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               "unique_GBps": round((uniq + score_bytes) / (ms * 1e-3) / 1e9, 1),
+               "unique_frac": round((uniq + score_bytes) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               "unique_over_algorithmic": round((uniq + score_bytes) / algo, 4)}
+        if name == "batch":
+            out.update(ent)
+            gen = oracle_index(cfg, cfg.get("plants"))
+            ok = True
+            step = max(1, nq // exact_rows)
+            rows = list(range(0, nq, step))[:exact_rows]
+            for i in rows:
+                ok = ok and bool(np.array_equal(b.counts_host(i), gen.counts(queries[i])))
+            out["bit_exact_vs_oracle"] = ok
+            out["exact_rows_checked"] = len(rows)
+        else:
+            out[name] = ent
+    out["is"] = ("frac: algorithmic bytes / scan time / 8 TB/s on this index; unique_frac: the distinct rows of the batch (+ the scores "
+                 "written) / scan time / 8 TB/s -- bytes that cannot come from a cache, a floor of what left the HBM pins")
+    del b
+    s.close()
+    return out
+
+
 def kernels_hash():
     """identifies the kernel source a profile belongs to (the GPU box has no .git)"""
     import hashlib
@@ -334,11 +472,14 @@ def make_index(cfg, dev, rank=0, world=1, hbm_budget=0, path=None):
     if path:
         return cobs_amd.Search(path, device=dev, shard_rank=rank, shard_count=world, hbm_budget=hbm_budget,
                                shard_mode=2 if hbm_budget else 0)
-    return cobs_amd.Search.synthetic(cfg["kind"], cfg["signature_sizes"], cfg["num_docs"],
-                                     page_size=cfg["page_size"], term_size=cfg["term_size"],
-                                     canonicalize=cfg["canonicalize"], num_hashes=cfg["num_hashes"],
-                                     seed=cfg["seed"], device=dev, shard_rank=rank, shard_count=world,
-                                     hbm_budget=hbm_budget)
+    s = cobs_amd.Search.synthetic(cfg["kind"], cfg["signature_sizes"], cfg["num_docs"],
+                                  page_size=cfg["page_size"], term_size=cfg["term_size"],
+                                  canonicalize=cfg["canonicalize"], num_hashes=cfg["num_hashes"],
+                                  seed=cfg["seed"], device=dev, shard_rank=rank, shard_count=world,
+                                  hbm_budget=hbm_budget)
+    if cfg.get("plants") and not hbm_budget:
+        apply_plants(s, cfg["plants"])          # true positives (a shard plants the documents it holds)
+    return s
 
 
 class ShardedRun:
@@ -513,9 +654,7 @@ def verify_sharded(run, cfg, world, rank, backend, corrupt=False, seconds=20.0, 
         gidx.append(torch.arange(int(i.slot_count), device=dev, dtype=torch.int64) + int(i.doc_offset) + int(i.slot_begin))
     gidx = torch.cat(gidx) if gidx else torch.zeros(0, dtype=torch.int64, device=dev)
     w_loc = (gidx % 1021) + 1
-    kind = 1 if cfg["kind"] == "compact" else 0
-    gen = O.Index.synthetic(kind, cfg["term_size"], cfg["canonicalize"], cfg["num_hashes"], cfg["page_size"],
-                            cfg["signature_sizes"], cfg["num_docs"], cfg["seed"])
+    gen = oracle_index(cfg, cfg.get("plants"))
     wn = (np.arange(total, dtype=np.int64) % 1021) + 1
     ok_exchange, ok_oracle = True, True
     n_all = n_exact = n_sum = 0
@@ -959,6 +1098,11 @@ def main():
     ap.add_argument("--topk-with-rows", action="store_true",
                     help="with --num-results: keep the score rows (K3 selects from them) instead of selecting per tile in K2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-plants", action="store_true",
+                    help="the purely random index of rounds 1-4 (no planted documents: no query reaches threshold 0.8)")
+    ap.add_argument("--hbm-side-scale", type=float, default=8.0,
+                    help="default one-GPU line: also scan the batch against the C3 geometry with S_p x this (8: 147 GB resident; 0 = skip) "
+                         "-> roofline.hbm_side")
     ap.add_argument("--exchange-chunks", type=int, default=0,
                     help="sharded runs: sub-batches the batch is cut into; hash(i+1) | scan(i) | exchange(i-1) overlap on their own "
                          "streams.  0 = automatic: 2 (1 for batches below 4000 queries and for an out-of-core run, whose passes are bound by PCIe)")
@@ -1105,6 +1249,8 @@ def run_bench(args, world, rank, local_rank, wd, emit):
     cfg = {"c3": c3_config, "c2": c2_config, "c4": c4_config}[base](args.scale)
     cfg["num_hashes"] = args.num_hashes
     budget = int(args.hbm_budget_gb * 1e9)
+    if args.config != "c5" and not budget and not args.no_plants:
+        cfg["plants"] = planted_documents(cfg, args.kmers)
     path = None
     wd.phase("index and batch set-up (%s)" % args.config, {"c4": 900, "c5": 1800}.get(args.config, 600) * max(1.0, args.scale))
     if args.config == "c5":
@@ -1353,11 +1499,33 @@ def run_bench(args, world, rank, local_rank, wd, emit):
         all_cpus = os.sched_getaffinity(0)
         bind_to_numa_node(numa_node)
         wd.phase("end-to-end calls and CPU baseline", 900)
-        out["end_to_end"] = end_to_end(s, batch, queries)
+        hit_q = planted_queries(cfg["plants"], args.queries, args.kmers) if cfg.get("plants") else None
+        out["end_to_end"] = end_to_end(s, batch, queries, hit_q)
         out["end_to_end"]["caller_numa_node"] = numa_node
         os.sched_setaffinity(0, all_cpus)
         out["cpu_baseline"] = cpu_baseline(s, cfg, queries, batch=batch)
         out["bit_exact_vs_oracle"] = out["cpu_baseline"]["bit_exact_vs_gpu"]
+    if (rank == 0 and world == 1 and not budget and not shard_index and args.config == "c3" and args.scale == 1.0
+            and args.hbm_side_scale > 0 and not args.no_cpu_baseline and not (args.hits_only and args.threshold > 0)
+            and not args.num_results):
+        # the pin-side view at full occupancy: the same batch against the same geometry at 8x the rows (147 GB resident);
+        # the 18.4 GB index goes first
+        wd.phase("hbm_side probe (C3 x %g)" % args.hbm_side_scale, 600)
+        try:
+            free_b, total_b = torch.cuda.mem_get_info()
+            need = sum(c3_config(args.hbm_side_scale)["signature_sizes"]) * 1664 + (8 << 30)
+            del batch
+            s.close()
+            torch.cuda.empty_cache()
+            free_b, total_b = torch.cuda.mem_get_info()
+            if free_b < need:
+                out["roofline"]["hbm_side"] = {"skipped": "needs %.0f GB of HBM, %.0f GB free" % (need / 1e9, free_b / 1e9)}
+            else:
+                out["roofline"]["hbm_side"] = hbm_side_probe(args, queries, dev, args.hbm_side_scale)
+                if out["roofline"]["hbm_side"].get("bit_exact_vs_oracle") is False:
+                    out["bit_exact_vs_oracle"] = False
+        except Exception as e:                                      # noqa: BLE001
+            out["roofline"]["hbm_side"] = {"skipped": "failed: %r" % (e,)}
     if rank == 0:
         # the line is only printed when it describes the run that was asked for
         assert out["n_gpus"] == args.gpus, (out["n_gpus"], args.gpus)

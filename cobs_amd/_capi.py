@@ -88,6 +88,7 @@ SYMBOLS = {
     "cobs_gpu_device_count": (_int, []),
     "cobs_gpu_open": (_int, [C.POINTER(_cp), _sz, C.POINTER(Options), C.POINTER(_vp)]),
     "cobs_gpu_open_synthetic": (_int, [C.POINTER(Synth), C.POINTER(Options), C.POINTER(_vp)]),
+    "cobs_gpu_plant": (_int, [_vp, _sz, _cp, _sz, C.POINTER(_u32), C.POINTER(_u32), _sz, _u64]),
     "cobs_gpu_close": (None, [_vp]),
     "cobs_gpu_set_tuning": (_int, [_vp, _cp, C.c_int64]),
     "cobs_gpu_plan_shards": (_int, [_cp, _u32, _u32, _pu64, _pu64, _pu64]),

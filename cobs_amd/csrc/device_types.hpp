@@ -252,6 +252,24 @@ struct SynthArgs {
     uint32_t pitch;
 };
 
+// True positives planted into a resident procedural index (cobs_gpu_plant, include/cobs_gpu_batch.h): the terms of one
+// text become terms of a list of documents, as index construction would set them (classic_index.cpp:40-73).
+struct PlantDoc {
+    uint8_t* col;               // address of (row 0, the byte that holds the document's bit); nullptr: not held by this shard
+    uint64_t sig;               // rows of the document's sub-index
+    uint32_t pitch;             // bytes between its rows
+    uint32_t bit;               // doc % 8
+    uint32_t doc;               // file-level document number (enters the keep rule)
+    uint32_t keep_permille;     // share of the text's terms this document holds
+};
+struct PlantArgs {
+    const uint8_t* text;
+    const PlantDoc* docs;
+    uint64_t salt;
+    uint32_t len, term_size, canonicalize, num_hashes, ndocs;
+    uint32_t* bad;              // set to 1 if the text holds a character outside ACGT (canonicalize != 0): nothing is planted for such terms
+};
+
 // rows of one sub-index of the procedural index, for the file writer
 struct SynthRowsArgs {
     uint8_t* dst;               // row r at dst + r * pitch

@@ -589,6 +589,67 @@ cobs_gpu_status cobs_gpu_read_rows(const cobs_gpu_index* ix, size_t f, uint32_t 
 
 uint64_t cobs_gpu_graph_replays(const cobs_gpu_index* ix) { return ix ? ix->graph_replays : 0; }
 
+// True positives for the procedural index: see include/cobs_gpu_batch.h.
+cobs_gpu_status cobs_gpu_plant(cobs_gpu_index* ix, size_t f, const char* text, size_t len, const uint32_t* docs,
+                               const uint32_t* keep_permille, size_t ndocs, uint64_t salt) {
+    if (!ix || f >= ix->parts.size() || (len && !text) || (ndocs && (!docs || !keep_permille)))
+        return fail(COBS_GPU_ERR_ARG, "bad argument");
+    return guarded([&]() -> cobs_gpu_status {
+        Part& p = ix->parts[f];
+        if (p.streamed) return fail(COBS_GPU_ERR_UNSUPPORTED, "the index is streamed: its rows are not resident");
+        if (len > 0xFFFFFFF0ull || ndocs > (1u << 20)) return fail(COBS_GPU_ERR_ARG, "text or document list too long");
+        if (len < p.meta.term_size || ndocs == 0) return COBS_GPU_OK;
+        HIP_TRY(hipSetDevice(ix->device));
+        const bool compact = p.meta.kind == IndexKind::Compact;
+        const uint64_t page_docs = compact ? 8 * p.meta.header_page_size : ~0ull;
+        std::vector<PlantDoc> h(ndocs);
+        for (size_t i = 0; i < ndocs; ++i) {
+            const uint64_t d = docs[i];
+            if (d >= p.meta.doc_names.size()) return fail(COBS_GPU_ERR_ARG, "document " + std::to_string(d) + " does not exist");
+            if (keep_permille[i] > 1000) return fail(COBS_GPU_ERR_ARG, "keep_permille beyond 1000");
+            const uint32_t fp = compact ? (uint32_t)(d / page_docs) : 0u;
+            const uint64_t byte = (compact ? d - (uint64_t)fp * page_docs : d) / 8;
+            PlantDoc pd{};
+            pd.col = nullptr;
+            pd.doc = (uint32_t)d;
+            pd.bit = (uint32_t)(d & 7u);
+            pd.keep_permille = keep_permille[i];
+            for (const Chunk& ch : p.chunks)
+                for (size_t v = 0; v < ch.vp.size() && !pd.col; ++v)
+                    if (ch.vp[v].fp == fp && byte >= ch.vp[v].col0 && byte < ch.vp[v].col0 + ch.vp[v].ncols && ch.d_data) {
+                        pd.col = ch.d_data + ch.pages[v].base + (byte - ch.vp[v].col0);
+                        pd.sig = ch.pages[v].sig;
+                        pd.pitch = ch.pitch;
+                    }
+            h[i] = pd;      // (a document of another shard: col stays NULL, the rank that holds it plants it)
+        }
+        DevBuf<uint8_t> d_text;
+        DevBuf<PlantDoc> d_docs;
+        DevBuf<uint32_t> d_bad;
+        HIP_TRY(d_text.reserve(len));
+        HIP_TRY(d_docs.reserve(ndocs));
+        HIP_TRY(d_bad.reserve(1));
+        HIP_TRY(hipMemcpy(d_text.p, text, len, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_docs.p, h.data(), ndocs * sizeof(PlantDoc), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(d_bad.p, 0, 4));
+        PlantArgs a{};
+        a.text = d_text.p;
+        a.docs = d_docs.p;
+        a.salt = salt;
+        a.len = (uint32_t)len;
+        a.term_size = p.meta.term_size;
+        a.canonicalize = p.meta.canonicalize;
+        a.num_hashes = (uint32_t)p.meta.num_hashes;
+        a.ndocs = (uint32_t)ndocs;
+        a.bad = d_bad.p;
+        HIP_TRY(launch_plant(a, nullptr));
+        uint32_t bad = 0;
+        HIP_TRY(hipMemcpy(&bad, d_bad.p, 4, hipMemcpyDeviceToHost));
+        if (bad) return fail(COBS_GPU_ERR_INVALID_BASE, "the planted text holds a character outside ACGT");
+        return COBS_GPU_OK;
+    });
+}
+
 cobs_gpu_status cobs_gpu_stream_counters(const cobs_gpu_index* ix, uint64_t out[2]) {
     if (!ix || !out) return fail(COBS_GPU_ERR_ARG, "NULL argument");
     out[0] = ix->stream.fetched_chunks;

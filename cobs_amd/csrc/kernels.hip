@@ -1759,6 +1759,40 @@ __global__ __launch_bounds__(256) void synth_kernel(SynthArgs a) {
     }
 }
 
+// cobs_gpu_plant: one thread per term of the text.  Document i holds term t iff mix64(salt ^ doc << 32 ^ t) % 1000 <
+// keep_permille (the checker restates this rule: oracle_plant); a held term sets, for each of its H hashes, bit doc % 8
+// of byte doc / 8 of row hash % S_p -- what classic_index.cpp:40-73 does for a document's own terms.
+__global__ __launch_bounds__(256) void plant_kernel(PlantArgs a) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t k = a.term_size;
+    if (a.len < k || t > a.len - k) return;
+    const uint8_t* text = a.text + t;
+    KmerView kv{text, k, 0u};
+    if (a.canonicalize != 0) {
+        for (uint32_t s = 0; s < k; ++s)
+            if (fwd_base(text[s]) == 0) { *a.bad = 1u; return; }
+        uint32_t mode = 1;
+        for (uint32_t s = 0; s < k / 2; ++s) {
+            const int f = (int)fwd_base(text[s]);
+            const int r = (int)rev_base(text[k - 1 - s]);
+            if (f < r) break;
+            if (f > r) { mode = 2; break; }
+        }
+        kv.mode = mode;
+    }
+    for (uint32_t j = 0; j < a.num_hashes; ++j) {
+        const uint64_t h = xxh64_view(kv, (uint64_t)j);
+        for (uint32_t i = 0; i < a.ndocs; ++i) {
+            const PlantDoc d = a.docs[i];
+            if (!d.col) continue;
+            if (mix64(a.salt ^ ((uint64_t)d.doc << 32) ^ (uint64_t)t) % 1000u >= d.keep_permille) continue;
+            uint8_t* byte = d.col + (h % d.sig) * (uint64_t)d.pitch;
+            const uintptr_t addr = reinterpret_cast<uintptr_t>(byte);
+            atomicOr(reinterpret_cast<uint32_t*>(addr & ~(uintptr_t)3), 1u << (8u * (uint32_t)(addr & 3u) + d.bit));
+        }
+    }
+}
+
 // rows [row0, row0 + nrows) of one sub-index of the procedural index, packed `pitch` bytes apart
 // (the file writer: cobs_gpu_write_synthetic)
 __global__ __launch_bounds__(256) void synth_rows_kernel(SynthRowsArgs a) {
@@ -1990,6 +2024,13 @@ hipError_t launch_combine(const CombineArgs& a, hipStream_t stream) {
 hipError_t launch_synth(const SynthArgs& a, hipStream_t stream) {
     if (a.npages == 0) return hipSuccess;
     hipLaunchKernelGGL(synth_kernel, dim3(2048, a.npages), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_plant(const PlantArgs& a, hipStream_t stream) {
+    if (a.len < a.term_size || a.ndocs == 0) return hipSuccess;
+    const uint32_t terms = a.len - a.term_size + 1;
+    hipLaunchKernelGGL(plant_kernel, dim3((terms + 255) / 256), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

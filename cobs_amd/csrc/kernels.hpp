@@ -51,6 +51,7 @@ hipError_t launch_random_build(const RandomBuildArgs& a, uint64_t ndocs, hipStre
 hipError_t launch_combine(const CombineArgs& a, hipStream_t stream);
 hipError_t launch_synth(const SynthArgs& a, hipStream_t stream);
 hipError_t launch_synth_rows(const SynthRowsArgs& a, hipStream_t stream);
+hipError_t launch_plant(const PlantArgs& a, hipStream_t stream);
 hipError_t launch_repitch(const RepitchArgs& a, hipStream_t stream);
 
 }  // namespace cobs_amd

@@ -194,6 +194,17 @@ class Search:
         check(self._lib.cobs_gpu_read_rows(self._h, file_no, page, row0, nrows, out.ctypes.data, width))
         return out
 
+    def plant(self, text, docs, keep_permille=1000, salt=0, file_no=0):
+        """True positives for a resident index (cobs_gpu_plant): documents `docs` additionally contain the terms of `text`,
+        document docs[i] the share keep_permille[i] / 1000 of them (one value = the same for all)."""
+        if isinstance(text, str):
+            text = text.encode()
+        docs = np.ascontiguousarray(docs, dtype=np.uint32)
+        keep = np.ascontiguousarray(np.broadcast_to(np.asarray(keep_permille, dtype=np.uint32), docs.shape))
+        u32p = C.POINTER(C.c_uint32)
+        check(self._lib.cobs_gpu_plant(self._h, file_no, text, len(text), docs.ctypes.data_as(u32p),
+                                       keep.ctypes.data_as(u32p), len(docs), int(salt)))
+
     # -- queries -------------------------------------------------------------
     def search(self, query, threshold=0.0, num_results=0):
         """Same contract as cobs_index.Search.search (python/module.cpp:372-386)."""

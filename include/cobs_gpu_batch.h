@@ -42,6 +42,18 @@ cobs_gpu_status cobs_gpu_open_synthetic(const cobs_gpu_synth* desc,
  * rows are produced on the device chunk by chunk and streamed to the file. */
 cobs_gpu_status cobs_gpu_write_synthetic(const cobs_gpu_synth* desc, const char* out_path, int device);
 
+/* True positives for a RESIDENT index (the procedural one above, or any index that is not streamed): the documents
+ * docs[0..ndocs) of file `file_no` additionally contain the terms of `text` -- document docs[i] holds term t (the
+ * term_size characters from position t) iff mix64(salt ^ (uint64_t)docs[i] << 32 ^ t) % 1000 < keep_permille[i]
+ * (mix64 = the splitmix64 finaliser the procedural bits use) -- and a held term sets, for each of the index's hash
+ * functions, the bit of the document in row hash % S_p of its sub-index, exactly what index construction does for a
+ * document's own terms (construction/classic_index.cpp:40-73).  Random bits alone give counts ~ Binomial(T, 0.3): no
+ * query ever reaches the CLI's default threshold 0.8; with planted documents the thresholded paths --
+ * selection, hit pool, D2H of hits, ranking, the hit exchange -- carry data at full size.  Documents a shard does not
+ * hold are skipped (every rank plants what it holds).  The checker restates the rule (oracle_plant). */
+cobs_gpu_status cobs_gpu_plant(cobs_gpu_index* ix, size_t file_no, const char* text, size_t len, const uint32_t* docs,
+                               const uint32_t* keep_permille, size_t ndocs, uint64_t salt);
+
 /* score slots per query held by THIS shard (== cobs_gpu_total_counts when
  * unsharded); device count rows have this many elements */
 uint64_t cobs_gpu_local_counts(const cobs_gpu_index* ix);

@@ -268,6 +268,9 @@ struct oracle_index {
     uint8_t* map; size_t map_len; int fd;
     const uint8_t** page_data;
     int synthetic; uint64_t seed;
+    /* planted true positives of a procedural index (oracle_plant): (page << 40 | row, bit of the row) pairs, sorted
+     * by key before the first lookup */
+    uint64_t* plant_key; uint32_t* plant_bit; size_t plant_n, plant_cap; int plant_sorted;
 };
 
 static const char MAGIC[] = "COBS:";
@@ -307,6 +310,7 @@ static void free_index(oracle_index* ix) {
     if (!ix) return;
     if (ix->names) { for (uint32_t i = 0; i < ix->num_docs; ++i) free(ix->names[i]); free(ix->names); }
     free(ix->sig); free((void*)ix->page_data);
+    free(ix->plant_key); free(ix->plant_bit);
     if (ix->map) munmap(ix->map, ix->map_len);
     if (ix->fd >= 0) close(ix->fd);
     free(ix);
@@ -494,6 +498,90 @@ static int create_hashes(const oracle_index* ix, const char* q, size_t qlen, uin
 }
 
 /* ------------------------------------------------------------------------ */
+/* True positives planted into a procedural index -- NOT part of the reference: the checker's restatement of the HIP
+ * library's cobs_gpu_plant (include/cobs_gpu_batch.h).  Document docs[i] additionally holds term t of `text` iff
+ * mix64(salt ^ (uint64_t)docs[i] << 32 ^ t) % 1000 < keep_permille[i]; a held term sets, for every hash function, the
+ * document's bit in row hash % S_p of its sub-index -- what construction does for a document's own terms
+ * (cobs/construction/classic_index.cpp:40-73: bit doc % 8 of byte doc / 8 of the row).  The hashes are the query
+ * side's (create_hashes above), so a query that contains the term finds the bit.                                   */
+
+static pthread_mutex_t g_plant_mu = PTHREAD_MUTEX_INITIALIZER;
+
+int oracle_plant(oracle_index* ix, const char* text, size_t len, const uint32_t* docs,
+                 const uint32_t* keep_permille, size_t ndocs, uint64_t salt) {
+    if (!ix->synthetic) return ORACLE_ERR_ARG;
+    uint32_t k = ix->term_size;
+    if (len < k || ndocs == 0) return ORACLE_OK;
+    size_t T = len - k + 1;
+    uint64_t H = ix->num_hashes;
+    uint64_t* hashes = (uint64_t*)malloc(T * H * sizeof(uint64_t));
+    int rc = create_hashes(ix, text, len, hashes);
+    if (rc != ORACLE_OK) { free(hashes); return rc; }
+    uint64_t page_docs = ix->kind == 0 ? ~0ull : 8 * ix->page_size;
+    pthread_mutex_lock(&g_plant_mu);
+    for (size_t i = 0; i < ndocs; ++i) {
+        uint64_t d = docs[i];
+        if (d >= ix->num_docs || keep_permille[i] > 1000) { pthread_mutex_unlock(&g_plant_mu); free(hashes); return ORACLE_ERR_ARG; }
+        uint32_t p = ix->kind == 0 ? 0 : (uint32_t)(d / page_docs);
+        uint32_t bit = (uint32_t)(ix->kind == 0 ? d : d - (uint64_t)p * page_docs);
+        for (size_t t = 0; t < T; ++t) {
+            if (mix64(salt ^ (d << 32) ^ (uint64_t)t) % 1000u >= keep_permille[i]) continue;
+            for (uint64_t j = 0; j < H; ++j) {
+                if (ix->plant_n == ix->plant_cap) {
+                    ix->plant_cap = ix->plant_cap ? 2 * ix->plant_cap : 1u << 16;
+                    ix->plant_key = (uint64_t*)realloc(ix->plant_key, ix->plant_cap * sizeof(uint64_t));
+                    ix->plant_bit = (uint32_t*)realloc(ix->plant_bit, ix->plant_cap * sizeof(uint32_t));
+                }
+                ix->plant_key[ix->plant_n] = ((uint64_t)p << 44) | (hashes[t * H + j] % ix->sig[p]);
+                ix->plant_bit[ix->plant_n] = bit;
+                ix->plant_n++;
+            }
+        }
+    }
+    ix->plant_sorted = 0;
+    pthread_mutex_unlock(&g_plant_mu);
+    free(hashes);
+    return ORACLE_OK;
+}
+
+/* sort the planted entries by (page, row): an index sort, then both arrays permuted */
+static const uint64_t* g_sort_keys;
+static int cmp_plant(const void* a, const void* b) {
+    uint64_t x = g_sort_keys[*(const uint32_t*)a], y = g_sort_keys[*(const uint32_t*)b];
+    return x < y ? -1 : x > y;
+}
+static void plant_sort(oracle_index* ix) {
+    pthread_mutex_lock(&g_plant_mu);
+    if (!ix->plant_sorted) {
+        size_t n = ix->plant_n;
+        uint32_t* idx = (uint32_t*)malloc(n * sizeof(uint32_t));
+        for (size_t i = 0; i < n; ++i) idx[i] = (uint32_t)i;
+        g_sort_keys = ix->plant_key;
+        qsort(idx, n, sizeof(uint32_t), cmp_plant);
+        uint64_t* k2 = (uint64_t*)malloc(n * sizeof(uint64_t));
+        uint32_t* b2 = (uint32_t*)malloc(n * sizeof(uint32_t));
+        for (size_t i = 0; i < n; ++i) { k2[i] = ix->plant_key[idx[i]]; b2[i] = ix->plant_bit[idx[i]]; }
+        free(ix->plant_key); free(ix->plant_bit); free(idx);
+        ix->plant_key = k2; ix->plant_bit = b2; ix->plant_cap = n;
+        __atomic_store_n(&ix->plant_sorted, 1, __ATOMIC_RELEASE);
+    }
+    pthread_mutex_unlock(&g_plant_mu);
+}
+
+/* OR the planted bits of (page, row) that fall into row bytes [begin, begin + size) into dst */
+static void plant_apply(const oracle_index* ix, uint32_t page, uint64_t row, uint64_t begin, uint64_t size, uint8_t* dst) {
+    if (ix->plant_n == 0) return;
+    if (!__atomic_load_n(&ix->plant_sorted, __ATOMIC_ACQUIRE)) plant_sort((oracle_index*)ix);
+    uint64_t key = ((uint64_t)page << 44) | row;
+    size_t lo = 0, hi = ix->plant_n;
+    while (lo < hi) { size_t mid = (lo + hi) / 2; if (ix->plant_key[mid] < key) lo = mid + 1; else hi = mid; }
+    for (; lo < ix->plant_n && ix->plant_key[lo] == key; ++lo) {
+        uint64_t byte = ix->plant_bit[lo] / 8;
+        if (byte >= begin && byte < begin + size) dst[byte - begin] |= (uint8_t)(1u << (ix->plant_bit[lo] & 7u));
+    }
+}
+
+/* ------------------------------------------------------------------------ */
 /* read_from_disk -- classic_index/mmap_search_file.cpp:27-40 and
  * compact_index/mmap_search_file.cpp:34-67                                   */
 
@@ -504,9 +592,10 @@ static void gather_rows(const oracle_index* ix, const uint64_t* hashes, size_t n
         for (size_t i = 0; i < nh; ++i) {
             uint64_t row = hashes[i] % ix->sig[0];
             uint8_t* dst = rows + i * buffer_size;
-            if (ix->synthetic)
+            if (ix->synthetic) {
                 oracle_synth_fill(0, ix->seed, 0, 1, ix->num_docs, 0, row, begin, size, dst);
-            else
+                plant_apply(ix, 0, row, begin, size, dst);
+            } else
                 memcpy(dst, ix->page_data[0] + begin + row * rsz, size);
         }
         return;
@@ -519,9 +608,10 @@ static void gather_rows(const oracle_index* ix, const uint64_t* hashes, size_t n
         for (size_t p = begin_page; p < end_page; ++p, ++j) {
             uint64_t row = hashes[i] % ix->sig[p];
             uint8_t* dst = rows + i * buffer_size + j * ps;
-            if (ix->synthetic)
+            if (ix->synthetic) {
                 oracle_synth_fill(1, ix->seed, ps, ix->num_pages, ix->num_docs, (uint32_t)p, row, 0, ps, dst);
-            else
+                plant_apply(ix, (uint32_t)p, row, 0, ps, dst);
+            } else
                 memcpy(dst, ix->page_data[p] + row * ps, ps);
         }
     }

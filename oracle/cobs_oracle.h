@@ -89,6 +89,11 @@ uint64_t oracle_data_offset(const oracle_index* ix);
 void oracle_synth_fill(int kind, uint64_t seed, uint64_t page_size, uint32_t num_pages,
                        uint32_t num_docs, uint32_t page, uint64_t row,
                        uint64_t byte_begin, uint64_t n, uint8_t* out);
+/* True positives for a procedural index (oracle_synthetic): documents docs[0..ndocs) additionally hold the terms of
+ * `text`, document docs[i] the terms t with mix64(salt ^ (uint64_t)docs[i] << 32 ^ t) % 1000 < keep_permille[i] --
+ * the checker's restatement of cobs_gpu_plant (include/cobs_gpu_batch.h); not part of the reference. */
+int oracle_plant(oracle_index* ix, const char* text, size_t len, const uint32_t* docs,
+                 const uint32_t* keep_permille, size_t ndocs, uint64_t salt);
 
 /* -- search ------------------------------------------------------------ */
 /* raw per-document counts of ONE index, length counts_size (incl. padding docs).

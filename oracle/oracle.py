@@ -76,6 +76,8 @@ def lib():
     L.oracle_signature_size.argtypes = [vp, u32]
     L.oracle_doc_name.restype = cp
     L.oracle_doc_name.argtypes = [vp, u32]
+    L.oracle_plant.restype = C.c_int
+    L.oracle_plant.argtypes = [vp, C.c_char_p, C.c_size_t, vp, vp, C.c_size_t, u64]
     L.oracle_synth_fill.restype = None
     L.oracle_synth_fill.argtypes = [C.c_int, u64, u64, u32, u32, u32, u64, u64, u64, vp]
     L.oracle_counts.restype = C.c_int
@@ -182,6 +184,15 @@ class Index:
         _check(lib().oracle_synthetic(kind, term_size, canonicalize, num_hashes, page_size,
                                       len(sigs), sigs.ctypes.data, num_docs, seed, C.byref(h)))
         return cls(h, keep=(sigs,))
+
+    def plant(self, text, docs, keep_permille=1000, salt=0):
+        """procedural index only: documents `docs` additionally contain the terms of `text` (the share keep_permille[i] / 1000
+        of them) -- same rule as cobs_amd.Search.plant"""
+        if isinstance(text, str):
+            text = text.encode()
+        docs = np.ascontiguousarray(docs, dtype=np.uint32)
+        keep = np.ascontiguousarray(np.broadcast_to(np.asarray(keep_permille, dtype=np.uint32), docs.shape))
+        _check(lib().oracle_plant(self._h, text, len(text), docs.ctypes.data, keep.ctypes.data, len(docs), int(salt)))
 
     def close(self):
         if self._h:

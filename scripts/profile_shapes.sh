@@ -16,6 +16,8 @@ export TMPDIR=/tmp
 declare -A SHAPES=(
   [c3]=""
   [c3q256]="--queries 256"
+  [c3x8]="--scale 8"
+  [c3x8q2500]="--scale 8 --queries 2500"
   [c2]="--config c2"
   [c4]="--config c4 --queries 1000"
   [c3h3]="--num-hashes 3 --queries 4000"
@@ -28,8 +30,8 @@ declare -A SHAPES=(
   [c3top10rows]="--num-results 10 --topk-with-rows"
   [reads100top10]="--queries 40000 --kmers 70 --num-results 10"
 )
-FULL="c3 c3q256 reads50"
-WANT=${*:-c3 c3q256 c2 c4 c3h3 reads50 reads100 reads150 c3hits reads100hits c3top10 c3top10rows reads100top10}
+FULL="c3 c3q256 c3x8 reads50"
+WANT=${*:-c3 c3q256 c3x8 c3x8q2500 c2 c4 c3h3 reads50 reads100 reads150 c3hits reads100hits c3top10 c3top10rows reads100top10}
 cd /tmp
 for shape in $WANT; do
   EXTRA=${SHAPES[$shape]}

@@ -38,6 +38,11 @@ def test_full_size_config(gpu_lib, oracle, name):
     cfg = {"c3": bench.c3_config, "c2": bench.c2_config, "c4": bench.c4_config}[name]()
     s = _open(gpu_lib, cfg)
     ix = _oracle_index(oracle, cfg)
+    # true positives (round 5): 64 sequences, each a part of 48 documents that hold 100 % ... 50 % of its terms --
+    # planted into the GPU's matrix by cobs_gpu_plant and into the checker's definition by oracle_plant
+    plants = bench.planted_documents(cfg)
+    bench.apply_plants(s, plants)
+    bench.apply_plants(ix, plants)
     nq = 256 if name != "c4" else 64              # C4: 1M documents, 245 sub-indexes, 68 GB
     queries = bench.make_queries(nq, 1000)
     b = gpu_lib.Batch(s)
@@ -93,11 +98,41 @@ def test_full_size_config(gpu_lib, oracle, name):
     sums3 = b3.counts_tensor().to(torch.int64).bitwise_and(0xFFFF).sum(dim=1).cpu().numpy()
     assert np.array_equal(sums1, sums3[::-1])
     assert int(sums1[0]) == int(c0.sum())
-    # on-device selection at full size: nothing reaches 0.8 on random data (like the
+    # on-device selection at full size: a RANDOM query reaches 0.8 nowhere (like the
     # reference's own benchmark), everything passes a threshold of one k-mer
     b.run(0.8)
     b.sync()
     assert b.hits_host(0) == []
+    # ... and queries that are mutated windows of the planted sequences DO have hits at the CLI's default threshold
+    # (src/cobs.cpp:486-489): the hit lists and their order (score desc, document asc: classic_search.cpp:127-156)
+    # against the checker's, through the score-writing pass, the hits-only pass, the limited pass and the host API
+    nh = 128 if name != "c4" else 32
+    hq = bench.planted_queries(plants, nh)
+    want = [[(d, sc) for (_, d, _n, sc) in oracle.search(ix, q, 0.8)] for q in hq]
+    assert sum(len(w_) for w_ in want) >= 10 * nh and min(len(w_) for w_ in want) >= 1      # the workload has hits ...
+    planted_below = 0
+    for i, q in enumerate(hq[:8]):                   # ... and planted documents on BOTH sides of the threshold
+        row = ix.counts(q)
+        docs = plants[i % len(plants)][1]
+        planted_below += int((row[docs] < int(np.ceil(0.8 * T))).sum())
+    assert planted_below > 0
+    bh = gpu_lib.Batch(s)
+    bh.set_queries(hq)
+    bh.run(0.8)
+    bh.sync()
+    for i in range(nh):
+        assert [(d, sc) for (_, d, sc) in bh.hits_host(i)] == want[i], (name, i)
+    bh.run_hits(0.8)
+    bh.sync()
+    for i in range(nh):
+        assert [(d, sc) for (_, d, sc) in bh.hits_host(i)] == want[i], (name, i, "hits only")
+    bh.run_topk(0.8, 5, keep_counts=False)
+    bh.sync()
+    for i in range(nh):
+        assert [(d, sc) for (_, d, sc) in bh.hits_host(i, 5)] == want[i][:5], (name, i, "top 5")
+    got = s.search_batch([q.decode() for q in hq[:16]], 0.8)
+    for i in range(16):
+        assert [(r.doc_name, r.score) for r in got[i]] == [("file_%06u" % d, sc) for (d, sc) in want[i]], (name, i, "search")
     b.run(0.25)
     b.sync()
     hits = b.hits_host(0, 50)

@@ -515,6 +515,11 @@ def _independent_counts(path, query):
         for sig, _h in params:
             pages.append((sig, np.frombuffer(raw, np.uint8, sig * ps, pos).reshape(sig, ps)))
             pos += sig * ps
+    return _counts_from_pages(pages, k, can, nh, query, canon)
+
+
+def _counts_from_pages(pages, k, can, nh, query, canon):
+    import xxhash
     T = len(query) - k + 1
     out = []
     for sig, m in pages:
@@ -530,6 +535,60 @@ def _independent_counts(path, query):
             acc += np.unpackbits(rowbits, bitorder="little")
         out.append(acc)
     return np.concatenate(out)
+
+
+def test_planted_documents_of_the_procedural_index_against_an_independent_restatement(oracle):
+    """round 5: the procedural benchmark index gets TRUE POSITIVES (oracle_plant / cobs_gpu_plant: documents that hold the
+    terms of a text, a share keep / 1000 of them by a stated rule).  The rule is this project's own, so it is pinned the way
+    the counting path is: written out a second time here -- the matrix materialised row by row, python-xxhash, the
+    canonicalisation from its description, mix64 in Python integers, bits set as classic_index.cpp:40-43 lays them out -- and
+    compared with the C checker's counts, compact and classic, H = 1 and 2"""
+    import xxhash
+    comp = {65: 84, 67: 71, 71: 67, 84: 65}
+    M = (1 << 64) - 1
+
+    def canon(kmer):
+        n = len(kmer)
+        for i in range(n // 2):
+            f, r = kmer[i], comp[kmer[n - 1 - i]]
+            if f < r:
+                return kmer
+            if f > r:
+                return bytes(comp[c] for c in reversed(kmer))
+        return kmer
+
+    def mix64(z):
+        z = (z + 0x9E3779B97F4A7C15) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        return z ^ (z >> 31)
+
+    text = oracle.random_sequence(260, 21)
+    for kind, H, ps, sigs, D in ((1, 1, 16, [211, 307, 401], 3 * 8 * 16 - 5), (1, 2, 8, [257, 263], 8 * 8 + 3), (0, 1, 0, [499], 77)):
+        k, seed, salt = 31, 6, 0xABCDEF
+        ix = oracle.Index.synthetic(kind, k, 1, H, ps, sigs, D, seed)
+        width = ps if kind else (D + 7) // 8
+        pages = [(sg, np.stack([oracle.synth_row(kind, seed, ps, len(sigs), D, p, r, width) for r in range(sg)]))
+                 for p, sg in enumerate(sigs)]
+        docs = [0, D - 1, D // 2, 9]
+        keep = [1000, 700, 333, 0]
+        ix.plant(text, docs, keep, salt=salt)
+        for d, kp in zip(docs, keep):
+            p = d // (8 * ps) if kind else 0
+            local = d - p * 8 * ps if kind else d
+            sg, m = pages[p]
+            for t in range(len(text) - k + 1):
+                if mix64(salt ^ ((d << 32) & M) ^ t) % 1000 >= kp:
+                    continue
+                for j in range(H):
+                    m[xxhash.xxh64_intdigest(canon(text[t:t + k]), seed=j) % sg, local // 8] |= 1 << (local % 8)
+        for q in (text, text[20:150], text[100:131], oracle.random_sequence(100, 3)):
+            want = _counts_from_pages(pages, k, 1, H, q, canon)
+            got = ix.counts(q).astype(np.int64)
+            assert np.array_equal(got, want), (kind, H)
+        full = ix.counts(text)
+        T = len(text) - k + 1
+        assert full[docs[0]] == T and full[docs[3]] < T // 2 and T // 2 < full[docs[1]] < T
 
 
 def test_oracle_against_an_independent_restatement(oracle, golden_dir, tmp_path):
