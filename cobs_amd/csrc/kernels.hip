@@ -1760,7 +1760,7 @@ __global__ __launch_bounds__(256) void synth_kernel(SynthArgs a) {
 }
 
 // cobs_gpu_plant: one thread per term of the text.  Document i holds term t iff mix64(salt ^ doc << 32 ^ t) % 1000 <
-// keep_permille (the checker restates this rule: oracle_plant); a held term sets, for each of its H hashes, bit doc % 8
+// keep_permille (the test suite's checker restates this rule); a held term sets, for each of its H hashes, bit doc % 8
 // of byte doc / 8 of row hash % S_p -- what classic_index.cpp:40-73 does for a document's own terms.
 __global__ __launch_bounds__(256) void plant_kernel(PlantArgs a) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;

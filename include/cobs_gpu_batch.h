@@ -50,7 +50,7 @@ cobs_gpu_status cobs_gpu_write_synthetic(const cobs_gpu_synth* desc, const char*
  * document's own terms (construction/classic_index.cpp:40-73).  Random bits alone give counts ~ Binomial(T, 0.3): no
  * query ever reaches the CLI's default threshold 0.8; with planted documents the thresholded paths --
  * selection, hit pool, D2H of hits, ranking, the hit exchange -- carry data at full size.  Documents a shard does not
- * hold are skipped (every rank plants what it holds).  The checker restates the rule (oracle_plant). */
+ * hold are skipped (every rank plants what it holds).  The test suite's checker restates the rule. */
 cobs_gpu_status cobs_gpu_plant(cobs_gpu_index* ix, size_t file_no, const char* text, size_t len, const uint32_t* docs,
                                const uint32_t* keep_permille, size_t ndocs, uint64_t salt);
 
