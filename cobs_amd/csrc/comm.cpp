@@ -759,23 +759,12 @@ cobs_gpu_status cobs_gpu_batch_exchange_hits(cobs_gpu_batch* b, cobs_gpu_comm* c
         }
         if (mine)
             HIP_TRY(hipMemcpyAsync(x.hits_all.p + off[me], b->hits.p, mine * sizeof(HitDev), hipMemcpyDeviceToDevice, st));
-        // (the bounded wait BEFORE the copy to pageable memory: that copy waits for the stream inside the runtime)
+        // (the bounded wait first: what follows waits for the stream inside the runtime)
         if (cobs_gpu_status ws = sync_bounded(c, st, "the exchange of the hit records"); ws != COBS_GPU_OK) return ws;
-        std::vector<HitDev> raw((size_t)total);
-        if (total)
-            HIP_TRY(hipMemcpyAsync(raw.data(), x.hits_all.p, total * sizeof(HitDev), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
         x.bytes_moved = (total - mine) * sizeof(HitDev);
-        // bucket by query (the order inside a bucket is fixed later by the ranking sort)
-        b->h_hit_off.assign(b->nq + 1, 0);
-        for (const HitDev& h : raw)
-            if (h.query < b->nq) b->h_hit_off[h.query + 1]++;
-        for (size_t i = 0; i < b->nq; ++i) b->h_hit_off[i + 1] += b->h_hit_off[i];
-        b->h_hits.resize(raw.size());
-        std::vector<size_t> cur(b->h_hit_off.begin(), b->h_hit_off.end() - 1);
-        for (const HitDev& h : raw)
-            if (h.query < b->nq) b->h_hits[cur[h.query]++] = h;
-        b->pool_fetched = true;
+        // the gathered pools of all shards, put into result order on the device (results.cpp: order_pool; round 4
+        // bucketed them with a counting sort on one host thread, after a copy to pageable memory)
+        if (cobs_gpu_status os = order_pool(b, x.hits_all.p, total, st); os != COBS_GPU_OK) return os;
         b->pool_global = true;
         return COBS_GPU_OK;
     });
@@ -886,20 +875,9 @@ cobs_gpu_status cobs_gpu_batch_exchange_hits_owned(cobs_gpu_batch* b, cobs_gpu_c
         if (xf[me].send_bytes)
             HIP_TRY(hipMemcpyAsync(recv + xf[me].recv_offset, send + xf[me].send_offset, xf[me].send_bytes, hipMemcpyDeviceToDevice, st));
         if (cobs_gpu_status ws = sync_bounded(c, st, "the owner-routed exchange of the hit records"); ws != COBS_GPU_OK) return ws;
-        std::vector<HitDev> raw((size_t)total);
-        if (total) HIP_TRY(hipMemcpyAsync(raw.data(), x.hits_all.p, total * sizeof(HitDev), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
         x.bytes_moved = tot[0] - xf[me].recv_bytes;
-        // bucket by query (the order inside a bucket is fixed later by the ranking sort)
-        b->h_hit_off.assign(b->nq + 1, 0);
-        for (const HitDev& h : raw)
-            if (h.query < b->nq) b->h_hit_off[h.query + 1]++;
-        for (size_t i = 0; i < b->nq; ++i) b->h_hit_off[i + 1] += b->h_hit_off[i];
-        b->h_hits.resize(raw.size());
-        std::vector<size_t> cur(b->h_hit_off.begin(), b->h_hit_off.end() - 1);
-        for (const HitDev& h : raw)
-            if (h.query < b->nq) b->h_hits[cur[h.query]++] = h;
-        b->pool_fetched = true;
+        // the records of the owned queries from every shard, put into result order on the device (order_pool)
+        if (cobs_gpu_status os = order_pool(b, x.hits_all.p, total, st); os != COBS_GPU_OK) return os;
         b->pool_global = true;
         b->pool_owned = true;
         b->own_q0 = q0;

@@ -93,6 +93,22 @@ struct BucketArgs {
     uint32_t nq, nranks;
 };
 
+// The hit pool of a thresholded pass put into RESULT order on the device (xchg_kernels.hip, results.cpp: order_pool):
+// records bucketed by query (count, scan, scatter), every query's bucket ordered as counts_to_result orders it
+// (score descending, then (file, document) ascending: classic_search.cpp:136-145; index order for a query with a single
+// hash in total, :134) -- the host then copies finished lists instead of sorting one query at a time.
+struct PoolArgs {
+    const HitDev* in;            // the pool, in the order the scan's atomics appended it
+    HitDev* tmp;                 // bucketed by query
+    HitDev* out;                 // ... and every bucket ordered
+    uint32_t* cnt;               // [nq + 1] records per query (zeroed before the count)
+    uint32_t* off;               // [nq + 1] first record of every query (exclusive scan of cnt)
+    uint32_t* cur;               // [nq] scatter cursors (zeroed)
+    const uint8_t* single;       // [nq] 1 = the query has a single hash in total (index order), or nullptr: none has
+    uint32_t n, nq;
+    uint32_t seg_max;            // buckets beyond this many records are left in pool order (the host orders those)
+};
+
 // Row-selective access to a chunk that is not resident (fetch_kernels.hip): fetch the rows K1's table names
 // from the registered file mapping into a gathered buffer shaped like a resident chunk.
 // Row-range chunks of a streamed sub-index (fetch_kernels.hip): K1's row indices of one sub-index rewritten for a

@@ -280,6 +280,11 @@ struct cobs_gpu_batch {
     std::vector<cobs_amd::HitDev> h_hits;       // pool copy, sorted by query
     std::vector<size_t> h_hit_off;
     bool pool_fetched = false;
+    bool pool_sorted = false;         // h_hits holds every query's records in RESULT order (ordered on the device: order_pool)
+    cobs_amd::DevBuf<uint32_t> pool_idx;                    // [3][nq + 1]: records per query | first record | scatter cursors
+    cobs_amd::DevBuf<cobs_amd::HitDev> pool_tmp, pool_out;  // the pool bucketed by query / every bucket ordered
+    cobs_amd::DevBuf<uint8_t> pool_single;                  // [nq] queries with a single hash in total (index order)
+    cobs_amd::PinnedBuf<uint8_t> h_pool;                    // landing buffer: offsets, then the ordered records
     // host copy of a window of score rows [rows_q0, rows_q1) of the last run (raw elem_bytes)
     cobs_amd::PinnedBuf<uint8_t> h_rows;
     size_t rows_q0 = 0, rows_q1 = 0;
@@ -370,6 +375,9 @@ void set_run_state(cobs_gpu_batch* b, double threshold, size_t topk, bool want_c
 void stage_thresholds(cobs_gpu_batch* b, double threshold);
 
 // ---- results.cpp
+// `n` hit records at d_pool (the batch's own pool, or the pools of all shards after an exchange) -> b->h_hits in result
+// order (query ascending, inside a query as counts_to_result orders it), b->h_hit_off; ordered on the device
+cobs_gpu_status order_pool(cobs_gpu_batch* b, const HitDev* d_pool, uint64_t n, hipStream_t st);
 cobs_gpu_status fetch_counts(cobs_gpu_batch* b, size_t q, uint32_t* counts);
 cobs_gpu_status rank_window(cobs_gpu_batch* b, size_t q0, size_t q1, size_t per_query, cobs_gpu_hit* hits);
 

@@ -299,6 +299,26 @@ static cobs_gpu_status search_batch_impl(cobs_gpu_index* ix, const char* const* 
                 if (st != COBS_GPU_ERR_UNSUPPORTED) return st;      // else: scores too wide for the counting sort
             }
         }
+        // a thresholded pass whose pool holds every hit: ordered on the device (results.cpp: order_pool), the finished
+        // lists of ALL queries of the pass are copied in one sweep (round 4: one guarded call + one partial_sort per query)
+        if (!overflow && sb->selected && sb->topk_k == 0 && !sb->graph_run && sb->h_nhits() <= sb->hit_cap) {
+            const double t0 = now_s();
+            if (!sb->pool_fetched) {
+                st = order_pool(sb, sb->hits.p, sb->h_nhits(), sb->own_stream);
+                if (st != COBS_GPU_OK) return st;
+            }
+            if (sb->pool_sorted && sb->h_hits.size() <= cap - used && (sb->h_hits.empty() || hits)) {
+                const cobs_amd::HitDev* rec = sb->h_hits.data();
+                const size_t n = sb->h_hits.size();
+                cobs_gpu_hit* dst = hits + used;
+                for (size_t i = 0; i < n; ++i) dst[i] = cobs_gpu_hit{rec[i].part, rec[i].doc, rec[i].score};
+                for (size_t q = ps.g0; q < ps.g1; ++q) hit_offsets[q + 1] = used + sb->h_hit_off[q - ps.g0 + 1];
+                used += n;
+                ix->timers[4] += now_s() - t0;
+                return COBS_GPU_OK;
+            }
+            ix->timers[4] += now_s() - t0;
+        }
         for (size_t q = ps.g0; q < ps.g1; ++q) {
             size_t n = 0;
             if (sb->selected && sb->pool_fetched && sb->h_nhits() <= sb->hit_cap &&

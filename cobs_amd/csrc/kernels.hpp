@@ -42,6 +42,10 @@ hipError_t launch_clear_flags(uint32_t* flags, hipStream_t stream);
 
 // Owner-routed hit exchange (xchg_kernels.hip): count == true -> records per owner into a.cursor, else scatter.
 hipError_t launch_bucket_hits(const BucketArgs& a, bool count, hipStream_t stream);
+// The hit pool in result order (xchg_kernels.hip): count per query, scan, scatter, one wave per query orders its bucket.
+// a.cnt ([nq + 1]) and a.cur ([nq]) must be zero.
+hipError_t launch_order_pool(const PoolArgs& a, hipStream_t stream);
+constexpr uint32_t kPoolSegMax = 1024;      // buckets the device orders (larger ones: the host)
 
 // Index construction: one thread per text position hashes its term and sets the bits.
 hipError_t launch_build(const BuildArgs& a, uint64_t total_bytes, hipStream_t stream);

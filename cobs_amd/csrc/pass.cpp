@@ -241,6 +241,7 @@ void cobs_amd::set_run_state(cobs_gpu_batch* b, double threshold, size_t topk, b
     b->ran = false;
     b->synced = false;
     b->pool_fetched = false;
+    b->pool_sorted = false;
     b->topk_fetched = false;
     b->rows_q0 = b->rows_q1 = 0;
     b->view_global = false;

@@ -42,7 +42,93 @@ __global__ __launch_bounds__(256) void bucket_hits_kernel(BucketArgs a) {
     }
 }
 
+// ---- the hit pool in result order (PoolArgs) ----
+__global__ __launch_bounds__(256) void pool_count_kernel(PoolArgs a) {
+    const uint32_t stride = gridDim.x * 256u;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < a.n; i += stride) {
+        const uint32_t q = a.in[i].query;
+        if (q < a.nq) atomicAdd(&a.cnt[q], 1u);
+    }
+}
+
+// exclusive scan of cnt[0 .. nq] by ONE work-group of 1024 threads (a pass holds up to a few 100 000 queries)
+__global__ __launch_bounds__(1024) void pool_scan_kernel(PoolArgs a) {
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x, total = a.nq + 1u;
+    const uint32_t per = (total + 1023u) / 1024u;
+    const uint32_t i0 = t * per, i1 = i0 + per < total ? i0 + per : total;
+    uint32_t s = 0;
+    for (uint32_t i = i0; i < i1; ++i) s += a.cnt[i];
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {          // Hillis-Steele over the 1024 partial sums
+        const uint32_t v = t >= d ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = t ? part[t - 1] : 0u;
+    for (uint32_t i = i0; i < i1; ++i) {
+        const uint32_t c = a.cnt[i];
+        a.off[i] = run;
+        run += c;
+    }
+}
+
+__global__ __launch_bounds__(256) void pool_scatter_kernel(PoolArgs a) {
+    const uint32_t stride = gridDim.x * 256u;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < a.n; i += stride) {
+        const HitDev h = a.in[i];
+        if (h.query < a.nq) a.tmp[a.off[h.query] + atomicAdd(&a.cur[h.query], 1u)] = h;
+    }
+}
+
+__device__ __forceinline__ bool pool_before(const HitDev& x, const HitDev& y, bool single) {
+    if (!single && x.score != y.score) return x.score > y.score;
+    if (x.part != y.part) return x.part < y.part;
+    return x.doc < y.doc;
+}
+
+// one wave per query: its bucket in LDS, every record placed at its RANK (the number of records that precede it:
+// (file, document) is unique inside a query, so the order is total and every rank is taken once)
+constexpr uint32_t kPoolSeg = 1024;
+__global__ __launch_bounds__(64) void pool_sort_kernel(PoolArgs a) {
+    __shared__ HitDev seg[kPoolSeg];
+    const uint32_t q = blockIdx.x;
+    const uint32_t b0 = a.off[q], n = a.off[q + 1] - b0;
+    if (n == 0) return;
+    const uint32_t lane = threadIdx.x;
+    if (n > a.seg_max || n > kPoolSeg) {           // (left in pool order: the host orders this one)
+        for (uint32_t i = lane; i < n; i += 64u) a.out[b0 + i] = a.tmp[b0 + i];
+        return;
+    }
+    for (uint32_t i = lane; i < n; i += 64u) seg[i] = a.tmp[b0 + i];
+    __syncthreads();
+    const bool single = a.single && a.single[q];
+    for (uint32_t i = lane; i < n; i += 64u) {
+        const HitDev me = seg[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; ++j) rank += pool_before(seg[j], me, single) ? 1u : 0u;
+        a.out[b0 + rank] = me;
+    }
+}
+
 }  // namespace
+
+hipError_t launch_order_pool(const PoolArgs& a, hipStream_t stream) {
+    if (a.nq == 0) return hipSuccess;
+    if (a.n) {
+        const uint32_t blocks = std::min<uint32_t>((a.n + 255u) / 256u, 4096u);
+        hipLaunchKernelGGL(pool_count_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    }
+    hipLaunchKernelGGL(pool_scan_kernel, dim3(1), dim3(1024), 0, stream, a);
+    if (a.n) {
+        const uint32_t blocks = std::min<uint32_t>((a.n + 255u) / 256u, 4096u);
+        hipLaunchKernelGGL(pool_scatter_kernel, dim3(blocks), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(pool_sort_kernel, dim3(a.nq), dim3(64), 0, stream, a);
+    }
+    return hipGetLastError();
+}
 
 hipError_t launch_bucket_hits(const BucketArgs& a, bool count, hipStream_t stream) {
     if (a.n == 0) return hipSuccess;

@@ -63,7 +63,57 @@ def main():
             for r, tb in errors:
                 print("rank %d (nsub %d):\n%s" % (r, nsub, tb), file=sys.stderr)
             raise SystemExit(1)
-    print("ok 3")
+    # the HIT path with real record counts (round 5): the index with planted documents, queries that are mutated windows
+    # of the planted sequences, the hits-only scan at the CLI's default threshold, the sizes-first exchange of the records --
+    # to every rank, and routed to query owners -- and the pools put into result order on the device
+    cfg = bench.c3_config(0.01)
+    cfg["plants"] = bench.planted_documents(cfg, 200, n_seq=8, docs_per_seq=24)
+    hq = bench.planted_queries(cfg["plants"], 61, 200)
+    gen = bench.oracle_index(cfg, cfg["plants"])
+    want_hits = [[(f, d, sc) for (f, d, _n, sc) in oracle.search(gen, q, 0.8)] for q in hq]
+    assert sum(len(w) for w in want_hits) > 5 * len(hq)
+    uid = Comm.unique_id()
+    errors = []
+
+    def hits_main(r):
+        try:
+            import torch
+            import cobs_amd
+            torch.cuda.set_device(0)
+            comm = Comm(uid, r, N, device=0)
+            s = bench.make_index(cfg, 0, r, N)
+            b = cobs_amd.Batch(s)
+            b.set_queries(hq)
+            for _ in range(2):
+                b.run_hits(0.8)
+                b.sync()
+                over, q0, qn = b.exchange_hits_owned(comm)
+                assert not over and (q0, qn) == (len(hq) * r // N, len(hq) * (r + 1) // N - len(hq) * r // N)
+                assert N == 1 or qn == 0 or b.exchange_bytes() > 0
+                for i in range(q0, q0 + qn):
+                    assert b.hits_host(i, 0) == want_hits[i], (r, i)
+                    assert b.hits_host(i, 3) == want_hits[i][:3], (r, i)
+                b.run(0.8)
+                b.sync()
+                assert b.exchange_hits(comm) is False
+                for i in range(len(hq)):
+                    assert b.hits_host(i, 0) == want_hits[i], (r, i, "to every rank")
+            del b
+            comm.close()
+            s.close()
+        except BaseException:
+            errors.append((r, traceback.format_exc()))
+
+    threads = [threading.Thread(target=hits_main, args=(r,)) for r in range(N)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        for r, tb in errors:
+            print("rank %d (hits):\n%s" % (r, tb), file=sys.stderr)
+        raise SystemExit(1)
+    print("ok 4")
 
 
 if __name__ == "__main__":
