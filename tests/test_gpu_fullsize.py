@@ -58,7 +58,7 @@ def test_full_size_config(gpu_lib, oracle, name):
     dev_sum = t_all.sum(dim=1).cpu().numpy()
     dev_wsum = (t_all * w).sum(dim=1).cpu().numpy()
     wn = (np.arange(t_all.shape[1], dtype=np.int64) % 1021) + 1
-    wants = _oracle_rows(ix, (name, nq), queries)
+    wants = _oracle_rows(ix, (name, nq, "with planted documents"), queries)
     for i in range(nq):
         want = wants[i]
         assert np.array_equal(b.counts_host(i), want), (name, i)
