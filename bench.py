@@ -1478,6 +1478,11 @@ def run_bench(args, world, rank, local_rank, wd, emit):
                             "gpu_numa_node": numa_node, "host_cpus_bound_to_that_node": numa_cpus,
                             "scan_launches_per_step": nlaunch, "chunks_fetched_by_rows": fetched, "chunks_copied_whole": whole,
                             "pcie_bytes_per_step_rank0": int(moved), "pcie_GBps_rank0": pcie}
+        buf_b, kept_b, pass_b, nch = s.stream_plan()
+        out["streaming"].update({"stream_buffer_bytes": buf_b, "resident_bytes": kept_b, "whole_pass_bytes": pass_b,
+                                 "streamed_chunks": nch,
+                                 "resident_is": "slices of the streamed file(s) the budget keeps in HBM beside the two stream buffers "
+                                                "(round 5: residency per slice, not per file): they do not cross PCIe again"})
     if shard_index and args.extras and not args.no_extras:
         del run, batch, s
         torch.cuda.empty_cache()

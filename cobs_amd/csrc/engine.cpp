@@ -74,6 +74,7 @@ Tuning Tuning::from_env() {
     if (const char* e = getenv("COBS_GPU_ROW_RANGES")) t.row_ranges = atoi(e) != 0;
     if (const char* e = getenv("COBS_GPU_STREAM_PACKED")) t.stream_packed = atoi(e) != 0;
     if (const char* e = getenv("COBS_GPU_ROW_RANGE_MIN")) t.row_range_min = (uint32_t)std::max(1, atoi(e));
+    if (const char* e = getenv("COBS_GPU_STREAM_BUF_KIB")) t.stream_buf_kib = (uint32_t)std::strtoul(e, nullptr, 0);
     if (const char* e = getenv("COBS_GPU_EXP")) t.exp = (uint32_t)std::strtoul(e, nullptr, 0);      // A/B variants, also under the test suite
     return t;
 }
@@ -178,14 +179,18 @@ static cobs_gpu_status stage_index(cobs_gpu_index* ix, std::vector<std::unique_p
             continue;
         }
         if (pt.synthetic) {
-            if (!pt.streamed) {
-                for (Chunk& c : pt.chunks) HIP_TRY(launch_synth(synth_args(pt, c, c.d_data), nullptr));
-                HIP_TRY(hipStreamSynchronize(nullptr));
-            }
+            // (resident chunks are generated once -- all chunks of a resident part, the kept ones of a streamed part;
+            // streamed chunks are regenerated at every pass)
+            for (Chunk& c : pt.chunks)
+                if (c.d_data) HIP_TRY(launch_synth(synth_args(pt, c, c.d_data), nullptr));
+            HIP_TRY(hipStreamSynchronize(nullptr));
             continue;
         }
         if (pt.streamed) {
-            pt.file = std::move(files[i]);       // chunks are read from the mapping at every pass
+            // the slices the budget keeps resident beside the stream buffers are uploaded once (plan.cpp: chunk_part)
+            st = upload_resident(pt, files[i]->data());
+            if (st != COBS_GPU_OK) return st;
+            pt.file = std::move(files[i]);       // the other chunks are read from the mapping at every pass
             // Pin the read-only mapping so that the copy engine reads it directly (no packing
             // through staging buffers).  Not every kernel/driver allows pinning file pages;
             // if it fails the staged path is used.
@@ -217,6 +222,7 @@ static cobs_gpu_status stage_index(cobs_gpu_index* ix, std::vector<std::unique_p
                 if (hipHostGetDevicePointer(&dp, pt.pin_base, 0) == hipSuccess && dp) {
                     pt.file_dev = static_cast<const uint8_t*>(dp) - lo;      // (offsets stay offsets into the file)
                     for (Chunk& c : pt.chunks) {
+                        if (c.resident) continue;
                         std::vector<uint64_t> src(c.vp.size());
                         for (size_t k = 0; k < c.vp.size(); ++k)
                             src[k] = pt.meta.page_offset(c.vp[k].fp) + c.vp[k].row0 * pt.meta.page_row_bytes() + c.vp[k].col0;
@@ -231,15 +237,20 @@ static cobs_gpu_status stage_index(cobs_gpu_index* ix, std::vector<std::unique_p
                     // pages 0, 1, 3 around a column-sliced page 2 returned a document of page 3 in place of one of
                     // page 2 with the same score: scripts/fuzz_soak.sh, seed 35.]
                     if (pt.chunks.size() > 1) {
-                        for (const Chunk& c : pt.chunks) {
+                        bool run_open = false;       // (a resident chunk between two streamed ones ends the run: unit order = document order)
+                        for (size_t ci = 0; ci < pt.chunks.size(); ++ci) {
+                            const Chunk& c = pt.chunks[ci];
+                            if (c.resident) { run_open = false; continue; }
                             Chunk* g = nullptr;
-                            if (!pt.fetch_groups.empty() && pt.fetch_groups.back().pitch == c.pitch) g = &pt.fetch_groups.back();
+                            if (run_open && !pt.fetch_groups.empty() && pt.fetch_groups.back().pitch == c.pitch) g = &pt.fetch_groups.back();
                             if (!g) {
                                 pt.fetch_groups.emplace_back();
                                 g = &pt.fetch_groups.back();
                                 g->pitch = c.pitch;
                                 g->cpp = c.cpp;
+                                g->first_chunk = (uint32_t)ci;
                             }
+                            run_open = true;
                             if (c.row_range) {
                                 // the row ranges of one sub-index are ONE unit here, with all of its rows: a pass that
                                 // fetches by rows gathers the looked-up rows wherever they are
@@ -663,6 +674,19 @@ cobs_gpu_status cobs_gpu_stream_traffic(const cobs_gpu_index* ix, uint64_t out[4
     out[1] = ix->stream.streamed_chunks;
     out[2] = ix->stream.fetched_bytes;
     out[3] = ix->stream.streamed_bytes;
+    return COBS_GPU_OK;
+}
+
+cobs_gpu_status cobs_gpu_stream_plan(const cobs_gpu_index* ix, uint64_t out[4]) {
+    if (!ix || !out) return fail(COBS_GPU_ERR_ARG, "NULL argument");
+    uint64_t chunks = 0;
+    for (const Part& p : ix->parts)
+        if (p.streamed)
+            for (const Chunk& c : p.chunks) chunks += c.resident ? 0 : 1;
+    out[0] = ix->stream.cap;
+    out[1] = ix->stream.resident_bytes;
+    out[2] = ix->stream.pass_bytes;
+    out[3] = chunks;
     return COBS_GPU_OK;
 }
 

@@ -105,6 +105,8 @@ struct Tuning {
     int tile_topk = 1;          // top-k passes without score rows select per tile in K2 (0: score rows + K3, A/B)
     int device_rank = 1;        // whole score rows are ranked on the device (0: by host threads, A/B and fallback)
     uint32_t rank_window_kib = 16u << 10;   // device-ranked records cross PCIe in pieces of this size (KiB)
+    uint32_t stream_buf_kib = 512u << 10;   // COBS_GPU_STREAM_BUF_KIB: upper bound of ONE of the two stream buffers of an out-of-core handle;
+                                            // what the budget leaves beyond them keeps slices of the streamed files resident (0: no bound)
     uint32_t row_range_min = 1024;  // ... unless a buffer holds fewer rows than this (then by columns); COBS_GPU_ROW_RANGE_MIN, tests
     uint32_t packed_width = 0;  // (set by the planner for a streamed part: chunks of this many columns keep that pitch)
     int stream_packed = 1;      // streamed chunks keep the file's row pitch (linear PCIe copies); 0: device pitch, 2-D copies (A/B)
@@ -145,9 +147,11 @@ struct Chunk {
     // A ROW-RANGE chunk: one sub-index too large for a stream buffer, cut by rows (all columns, `nrows` rows from `row0`) --
     // whole rows cross PCIe at the link's best rate, column slices do not (plan.cpp: chunk_part).  Its scan counts only
     // the terms whose row falls into the range; every range but the first writes partial scores that are ADDED to the rows.
+    bool resident = false;           // a chunk of a STREAMED part that stays in HBM (d_data): the budget had room for it beside the stream buffers
     bool row_range = false;
     uint32_t range_no = 0;           // 0 = the first range of its sub-index (writes the scores), > 0 = adds to them
     PageDev* d_pages_acc = nullptr;  // range_no > 0: the page with slot0 = 0 (partial scores go to a scratch matrix)
+    uint32_t first_chunk = 0;        // a fetch group (Part::fetch_groups): index of the first chunk of its run in Part::chunks
 };
 
 // One index file as held by this device (possibly only a shard of it).
@@ -202,6 +206,8 @@ struct StreamBufs {
     hipEvent_t hashed = nullptr;
     uint64_t fetched_chunks = 0, streamed_chunks = 0;   // diagnostics: how the chunks of all passes were brought in
     uint64_t fetched_bytes = 0, streamed_bytes = 0;     // ... and what that asked of PCIe: looked-up rows x pitch / the chunks' rows
+    uint64_t resident_bytes = 0;  // the plan: bytes of the streamed files' chunks that stay resident ...
+    uint64_t pass_bytes = 0;      // ... and row bytes a pass that copies every other chunk whole moves over PCIe
     size_t stage_need = 0;
     uint64_t seq = 0;             // chunks streamed so far: chunk goes to buffer seq % 2
     ~StreamBufs();
@@ -351,6 +357,7 @@ ScanGeom scan_geometry(const Chunk& c, uint64_t mean_blocks, uint64_t max_blocks
                        uint32_t forced_waves, int planes, bool idx64, const Tuning& tune);
 std::vector<VPage> held_slices(const IndexMeta& m, uint32_t rank, uint32_t count, uint32_t mode);
 cobs_gpu_status plan_part(Part& pt, const cobs_gpu_index* ix);
+cobs_gpu_status chunk_part(Part& pt, uint64_t cap, const Tuning& tune, uint64_t keep_bytes = 0, uint64_t* kept = nullptr);
 cobs_gpu_status plan_index(cobs_gpu_index* ix);
 // a replayed small pass brings this many hit-pool entries home inside the graph
 constexpr size_t kGraphPoolPrefix = 2048;

@@ -351,10 +351,19 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                    fetched_bytes(p, c, gathered) * ix->tune.row_fetch_alpha <= c.bytes;
         };
         bool all = !p.fetch_groups.empty();
-        for (const Chunk& c : p.chunks) all = all && (c.row_range || fetchable(c));    // (row ranges: their sub-index is one unit of the groups)
+        for (const Chunk& c : p.chunks) all = all && (c.resident || c.row_range || fetchable(c));    // (row ranges: their sub-index is one unit of the groups)
         for (const Chunk& g : p.fetch_groups) all = all && fetchable(g);
         grouped[f] = all;
-        for (const Chunk& c : all ? p.fetch_groups : p.chunks) units[f].push_back(&c);
+        if (!all) {
+            for (const Chunk& c : p.chunks) units[f].push_back(&c);
+        } else {
+            // resident chunks where they lie, every run of streamed chunks as its fetch group -- in chunk (= document) order
+            size_t gi = 0;
+            for (size_t ci = 0; ci < p.chunks.size(); ++ci) {
+                if (p.chunks[ci].resident) units[f].push_back(&p.chunks[ci]);
+                else if (gi < p.fetch_groups.size() && p.fetch_groups[gi].first_chunk == ci) units[f].push_back(&p.fetch_groups[gi++]);
+            }
+        }
     }
     for (size_t f = 0; f < ix->parts.size() && nq; ++f) {
         const Part& p = ix->parts[f];
@@ -440,7 +449,8 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
             const bool partial = c.row_range && c.range_no > 0;
             const PageDev* pages_dev = partial ? c.d_pages_acc : c.d_pages;
             const void* table_dev = b->work[f].table.p;
-            if (p.streamed) {
+            const bool stream_this = p.streamed && !c.resident;      // (a streamed file may keep some of its slices in HBM)
+            if (stream_this) {
                 // double buffer shared by all streamed files: the next chunk goes to the buffer
                 // whose last scan is done
                 buf = (int)(sbufs.seq++ & 1);
@@ -585,7 +595,7 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                 aa.elem_bytes = b->elem_bytes;
                 HIP_TRY(launch_add_scores(aa, st));
             }
-            if (p.streamed) {
+            if (stream_this) {
                 HIP_TRY(hipEventRecord(sbufs.scanned[buf], st));
                 sbufs.used[buf] = true;
             }

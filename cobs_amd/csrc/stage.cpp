@@ -44,7 +44,14 @@ cobs_gpu_status alloc_part(cobs_gpu_index* ix, Part& pt) {
     }
     StreamBufs& sb = ix->stream;
     size_t dev = 0, host = 0;
-    for (const Chunk& c : pt.chunks) { dev = std::max(dev, c.bytes); host = std::max(host, c.stage_bytes); }
+    for (Chunk& c : pt.chunks) {
+        if (c.resident) {            // a slice the budget keeps in HBM beside the stream buffers
+            HIP_TRY(hipMalloc((void**)&c.d_data, c.bytes));
+            continue;
+        }
+        dev = std::max(dev, c.bytes);
+        host = std::max(host, c.stage_bytes);
+    }
     sb.stage_need = std::max(sb.stage_need, host);
     for (int i = 0; i < 2; ++i) {
         if (sb.sbuf[i].cap < dev) {
@@ -92,6 +99,7 @@ cobs_gpu_status upload_resident(Part& pt, const uint8_t* file) {
     };
     int cur = 0;
     for (Chunk& c : pt.chunks) {
+        if (!c.d_data) continue;         // (a streamed chunk of a part that keeps only some of its slices resident)
         for (size_t lp = 0; lp < c.vp.size(); ++lp) {
             const PageDev& pd = c.pages[lp];
             const VPage& v = c.vp[lp];

@@ -351,6 +351,13 @@ class Search:
         check(self._lib.cobs_gpu_stream_traffic(self._h, C.byref(c)))
         return int(c[0]), int(c[1]), int(c[2]), int(c[3])
 
+    def stream_plan(self):
+        """out-of-core handles: (bytes of one stream buffer, bytes of the streamed files kept resident beside the buffers,
+        row bytes a whole-chunk pass moves over PCIe, streamed chunks)"""
+        c = (C.c_uint64 * 4)()
+        check(self._lib.cobs_gpu_stream_plan(self._h, C.byref(c)))
+        return int(c[0]), int(c[1]), int(c[2]), int(c[3])
+
     def timers(self, reset=False):
         t = (C.c_double * 5)()
         check(self._lib.cobs_gpu_timers(self._h, C.byref(t), 1 if reset else 0))

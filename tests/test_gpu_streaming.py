@@ -90,7 +90,7 @@ def test_random_budgets(gpu_lib, oracle, tmp_path, monkeypatch, no_pin):
         monkeypatch.setenv("COBS_GPU_NO_PIN", "1")
     monkeypatch.setenv("COBS_GPU_ROW_RANGE_MIN", "48")      # these indexes are small: let their oversized sub-indexes be cut by rows
     rng = np.random.default_rng(424242 + int(no_pin) + 100003 * int(os.environ.get("COBS_FUZZ_SEED", "0")))
-    done = 0
+    done = n_mixed = 0
     for idx in range(30):
         H = int(rng.choice([1, 1, 2]))
         q_long = oracle.random_sequence(500, 900 + idx)
@@ -110,12 +110,22 @@ def test_random_budgets(gpu_lib, oracle, tmp_path, monkeypatch, no_pin):
         budget = int(file_bytes * float(rng.choice([0.15, 0.3, 0.6, 0.9])))
         queries = [q_long[:200], q_long[100:131], q_long[:31 + int(rng.integers(0, 400))]]
         monkeypatch.setenv("COBS_GPU_STREAM_PACKED", str(idx % 2))
+        # round 5: the budget is spent per slice -- with the stream buffers bounded (here to a fraction of the budget, as
+        # 512 MiB is of a 6 GB budget) the rest keeps whole slices of the SAME file resident: the mixed plan
+        mixed = idx % 3 != 0
+        buf_kib = max(1, int(budget * float(rng.choice([0.08, 0.15, 0.3]))) // 1024) if mixed else 0
+        monkeypatch.setenv("COBS_GPU_STREAM_BUF_KIB", str(buf_kib))
         try:
             s = gpu_lib.Search(path, hbm_budget=budget)
         except gpu_lib.CobsGpuError as e:       # budget below two 16-byte column slices of the largest sub-index
             assert e.status == _capi.ERR_CAPACITY
             continue
         assert s.info(0).hbm_bytes <= budget
+        buf, kept, per_pass, nchunks = s.stream_plan()
+        assert 2 * buf + kept <= budget and (not mixed or buf <= max(buf_kib, 1) * 1024)
+        n_mixed += 1 if kept > 0 and nchunks > 0 else 0
+        if kept > 0:
+            assert per_pass < file_bytes          # what stays resident does not cross the link again
         # how the chunks come in: the engine's cost rule, rows whenever they fit, or always whole
         fetch_mode = int(rng.integers(0, 3))
         if fetch_mode == 1:
@@ -129,7 +139,7 @@ def test_random_budgets(gpu_lib, oracle, tmp_path, monkeypatch, no_pin):
         lim = int(rng.choice([0, 0, 5]))
         assert s.search_hits(queries, t, lim) == [cases.oracle_results([ix], q, t, lim) for q in queries], (path, budget, t, lim)
         done += 1
-    assert done >= 15
+    assert done >= 15 and n_mixed >= 5       # plans with resident AND streamed slices of one file were among them
 
 
 def test_budget_is_shared_by_all_files_of_a_handle(gpu_lib, oracle, tmp_path):
