@@ -105,7 +105,7 @@ struct Tuning {
     int tile_topk = 1;          // top-k passes without score rows select per tile in K2 (0: score rows + K3, A/B)
     int device_rank = 1;        // whole score rows are ranked on the device (0: by host threads, A/B and fallback)
     uint32_t rank_window_kib = 16u << 10;   // device-ranked records cross PCIe in pieces of this size (KiB)
-    uint32_t stream_buf_kib = 512u << 10;   // COBS_GPU_STREAM_BUF_KIB: upper bound of ONE of the two stream buffers of an out-of-core handle;
+    uint32_t stream_buf_kib = 256u << 10;   // COBS_GPU_STREAM_BUF_KIB: upper bound of ONE of the two stream buffers of an out-of-core handle;
                                             // what the budget leaves beyond them keeps slices of the streamed files resident (0: no bound)
     uint32_t row_range_min = 1024;  // ... unless a buffer holds fewer rows than this (then by columns); COBS_GPU_ROW_RANGE_MIN, tests
     uint32_t packed_width = 0;  // (set by the planner for a streamed part: chunks of this many columns keep that pitch)

@@ -250,10 +250,10 @@ cobs_gpu_status chunk_part(Part& pt, uint64_t cap, const Tuning& tune_in, uint64
     pt.streamed = cap != 0;
     pt.has_row_ranges = false;
     if (kept) *kept = 0;
-    // which slices stay resident: subset sum over the slices' sizes in units of 1/4096 of keep_bytes (>= 1 MiB)
+    // which slices stay resident: subset sum over the slices' sizes in units of 1/4096 of keep_bytes
     std::vector<bool> keep(pt.held.size(), false);
     if (cap != 0 && keep_bytes != 0 && !pt.held.empty()) {
-        const uint64_t unit = std::max<uint64_t>(1ull << 20, (keep_bytes + 4095) / 4096);
+        const uint64_t unit = std::max<uint64_t>(1, (keep_bytes + 4095) / 4096);
         const size_t W = (size_t)(keep_bytes / unit);
         std::vector<uint64_t> cost(pt.held.size());
         for (size_t i = 0; i < pt.held.size(); ++i)
@@ -381,8 +381,9 @@ cobs_gpu_status plan_index(cobs_gpu_index* ix) {
         cap = (ix->hbm_budget - kept) / 2;
         if (cap == 0) return fail(COBS_GPU_ERR_CAPACITY, "hbm budget too small");
     }
-    // The stream buffers need not be larger than what keeps the link busy: beyond stream_buf_kib (512 MiB: a chunk
-    // crosses PCIe in ~9 ms, its scan takes 2-3 ms) the rest of the budget holds slices of the streamed files RESIDENT.
+    // The stream buffers need not be larger than what keeps the link busy: beyond stream_buf_kib (256 MiB: a chunk
+    // crosses PCIe in ~5 ms, its scan takes 2-3 ms) the rest of the budget holds slices of the streamed files RESIDENT.
+    // (configs[4] on one GPU, 18.4 GB under 6 GB: buffers of 3 GB / 512 MiB / 256 MiB -> 323 / 239 / 229 ms per pass.)
     uint64_t spare = 0;
     if (cap) {
         const uint64_t want = (uint64_t)ix->tune.stream_buf_kib << 10;

@@ -101,7 +101,7 @@ cobs_gpu_status cobs_gpu_stream_traffic(const cobs_gpu_index* ix, uint64_t out[4
  * files' slices that stay RESIDENT beside them (the budget is spent per slice, not per file: what the buffers leave
  * over keeps the subset of whole slices with the most bytes in HBM), out[2] = row bytes a pass moves over PCIe when it
  * copies every other chunk whole, out[3] = number of those chunks.  COBS_GPU_STREAM_BUF_KIB (read when the index is
- * opened) bounds a stream buffer (default 512 MiB, 0 = half the budget as in rounds 1-4). */
+ * opened) bounds a stream buffer (default 256 MiB, 0 = half the budget as in rounds 1-4). */
 cobs_gpu_status cobs_gpu_stream_plan(const cobs_gpu_index* ix, uint64_t out[4]);
 
 #ifdef __cplusplus
