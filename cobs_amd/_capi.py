@@ -140,6 +140,7 @@ SYMBOLS = {
     "cobs_gpu_batch_sync": (_int, [_vp, _vp, C.POINTER(_sz)]),
     "cobs_gpu_batch_counts_device": (_vp, [_vp, C.POINTER(_u32), C.POINTER(_u64)]),
     "cobs_gpu_batch_counts_host": (_int, [_vp, _sz, _vp, _sz]),
+    "cobs_gpu_batch_score_histogram": (_int, [_vp, _pu64, _sz]),
     "cobs_gpu_batch_hits_host": (_int, [_vp, _sz, _sz, C.POINTER(Hit), _sz, C.POINTER(_sz)]),
     "cobs_gpu_batch_stats": (_int, [_vp, C.POINTER(_u64 * 4)]),
     "cobs_gpu_batch_kernel_ms": (_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),

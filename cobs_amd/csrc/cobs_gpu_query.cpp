@@ -35,7 +35,10 @@ static void usage() {
                  "        always lives in HBM, or is streamed through it under --hbm-budget)\n"
                  "       cobs_gpu_query classic-construct | compact-construct | classic-combine | compact-construct-combine ...\n"
                  "        (the construction sub-tools of `cobs`, same arguments; see cobs_gpu_tools.cpp)\n"
-                 "       cobs_gpu_query --benchmark -i INDEX [-k KMERS] [-q QUERIES] [-w WARMUP] [--seed S]\n"
+                 "       cobs_gpu_query --benchmark -i INDEX [-k KMERS] [-q QUERIES] [-w WARMUP] [--seed S] [--dist]\n"
+                 "       cobs_gpu_query benchmark-fpr INDEX [-k KMERS] [-q QUERIES] [-w WARMUP] [-d|--dist] [--seed S] [--device N[,M..]]\n"
+                 "        (`cobs benchmark-fpr`, same flags: -d / --dist adds the distribution of all scores,\n"
+                 "         RESULT name=benchmark_fpr fpr=<score> dist=<count> lines)\n"
                  "       cobs_gpu_query --write-synthetic OUT (--classic -n DOCS -s ROWS | --compact -n DOCS -p PAGE_SIZE\n"
                  "                      -s ROWS_0,ROWS_1,...) [--num-hashes H] [--seed S] [-d DEVICE]\n"
                  "        (a random-bit index file, density 0.3, for benchmarks of any size)\n"
@@ -47,8 +50,35 @@ static void usage() {
 // num_kmers + 30 characters from one std::mt19937(seed), default threshold 0 and
 // num_results 0, one RESULT line.  Here the queries run as one device batch; the
 // reference's t_io / t_and / t_add phases are one scan kernel (t_scan).
+// --dist (src/cobs.cpp:627-632, 664-670): the reference tallies counts[r.score]++ over every result of every query on
+// the host; here every shard's score rows are tallied on the device (cobs_gpu_batch_score_histogram), pass by pass.
+static bool score_distribution(const std::vector<cobs_gpu_index*>& shards, const std::vector<std::string>& queries,
+                               unsigned num_kmers, std::vector<uint64_t>& hist) {
+    hist.assign((size_t)num_kmers + 31, 0);
+    for (cobs_gpu_index* ix : shards) {
+        const uint64_t slots = std::max<uint64_t>(cobs_gpu_local_counts(ix), 1);
+        const size_t per_pass = (size_t)std::max<uint64_t>(1, (4ull << 30) / (slots * 4));      // <= 4 GiB of score rows per pass
+        cobs_gpu_batch* b = nullptr;
+        if (cobs_gpu_batch_create(ix, 0, 0, &b) != COBS_GPU_OK) return false;
+        bool ok = true;
+        for (size_t q0 = 0; q0 < queries.size() && ok; q0 += per_pass) {
+            const size_t n = std::min(per_pass, queries.size() - q0);
+            std::vector<const char*> qp(n);
+            std::vector<size_t> ql(n);
+            for (size_t i = 0; i < n; ++i) { qp[i] = queries[q0 + i].data(); ql[i] = queries[q0 + i].size(); }
+            size_t bad = 0;
+            ok = cobs_gpu_batch_set_queries(b, qp.data(), ql.data(), n) == COBS_GPU_OK &&
+                 cobs_gpu_batch_run(b, 0.0, nullptr) == COBS_GPU_OK && cobs_gpu_batch_sync(b, nullptr, &bad) == COBS_GPU_OK &&
+                 cobs_gpu_batch_score_histogram(b, hist.data(), hist.size()) == COBS_GPU_OK;
+        }
+        cobs_gpu_batch_destroy(b);
+        if (!ok) return false;
+    }
+    return true;
+}
+
 static int benchmark(cobs_gpu::BatchSearch& s, const std::string& index, unsigned num_kmers,
-                     unsigned num_queries, unsigned num_warmup, size_t seed) {
+                     unsigned num_queries, unsigned num_warmup, size_t seed, bool dist = false) {
     static const char basepairs[4] = {'A', 'C', 'G', 'T'};
     std::mt19937 rng(seed);
     auto make = [&](unsigned n) {
@@ -62,30 +92,42 @@ static int benchmark(cobs_gpu::BatchSearch& s, const std::string& index, unsigne
     std::vector<std::string> warm = make(num_warmup), queries = make(num_queries);
     std::vector<std::vector<cobs_gpu::SearchResult>> results;
     if (!warm.empty()) s.search_batch(warm, results);
-    double t[5];
-    cobs_gpu_timers(s.handle(), t, 1);
+    s.timer().reset();                       // (as benchmark_fpr_run does, src/cobs.cpp:623)
     const auto t0 = std::chrono::steady_clock::now();
     s.search_batch(queries, results);
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    cobs_gpu_timers(s.handle(), t, 0);
+    const cobs_gpu::Timer t = s.timer();     // a copy is a snapshot (:644)
+    // the reference's line (src/cobs.cpp:645-661) with its own keys -- t_io is the scan kernel (gather + AND + count are
+    // one kernel: t_and / t_add read 0), sse2 / aio do not apply -- and, behind them, the GPU path's own phases
     std::cout << "RESULT name=benchmark  index=" << index << " kmer_queries=" << num_kmers
               << " queries=" << num_queries << " warmup=" << num_warmup
-              << " results=" << (results.empty() ? 0 : results.back().size()) << " backend=gpu"
-              << " t_hashes=" << t[0] << " t_scan=" << t[2] << " t_h2d=" << t[1] << " t_d2h=" << t[3]
-              << " t_sort=" << t[4] << " t_total=" << wall << " queries_per_s=" << num_queries / wall
+              << " results=" << (results.empty() ? 0 : results.back().size()) << " sse2=off aio=off"
+              << " t_hashes=" << t.get("hashes") << " t_io=" << t.get("io") << " t_and=" << t.get("and rows")
+              << " t_add=" << t.get("add rows") << " t_sort=" << t.get("sort results") << " backend=gpu"
+              << " t_scan=" << t.get("scan") << " t_h2d=" << t.get("h2d") << " t_d2h=" << t.get("d2h")
+              << " t_rank=" << t.get("rank") << " t_total=" << wall << " queries_per_s=" << num_queries / wall
               << std::endl;
+    if (dist) {
+        results.clear();
+        results.shrink_to_fit();
+        std::vector<cobs_gpu_index*> shards;
+        if (auto* sh = dynamic_cast<cobs_gpu::ShardedClassicSearch*>(&s)) shards = sh->shard_handles();
+        else shards.push_back(s.handle());
+        std::vector<uint64_t> hist;
+        if (!score_distribution(shards, queries, num_kmers, hist)) {
+            std::fprintf(stderr, "EXCEPTION: %s\n", cobs_gpu_last_error());
+            return 1;
+        }
+        for (size_t sc = 0; sc < hist.size(); ++sc)      // std::map order: ascending scores, those that occur
+            if (hist[sc]) std::cout << "RESULT name=benchmark_fpr fpr=" << sc << " dist=" << hist[sc] << std::endl;
+    }
     return 0;
 }
 
 // `s.timer().print("search")` of the reference's process_query (src/cobs.cpp:468, cobs/util/timer.cpp:77-85):
 // one "TIMER info=search name=seconds ... total=seconds" line on stderr.  The reference's phases are hashes / io /
 // and rows (/ add rows); here: hashes (K1), h2d (query text), scan (K2: gather + AND + count), d2h, rank.
-static void print_timer(const cobs_gpu::BatchSearch& s) {
-    double t[5] = {0, 0, 0, 0, 0};
-    if (cobs_gpu_timers(s.handle(), t, 0) != COBS_GPU_OK) return;
-    std::cerr << "TIMER info=search hashes=" << t[0] << " h2d=" << t[1] << " scan=" << t[2] << " d2h=" << t[3]
-              << " rank=" << t[4] << " total=" << t[0] + t[1] + t[2] + t[3] + t[4] << std::endl;
-}
+static void print_timer(const cobs_gpu::BatchSearch& s) { s.timer().print("search"); }
 
 int cobs_gpu_tools_main(int argc, char** argv);      // cobs_gpu_tools.cpp: *-construct, classic-combine, compact-construct-combine
 
@@ -95,6 +137,10 @@ int main(int argc, char** argv) {
         if (rc >= 0) return rc;
         if (argc > 1 && std::string(argv[1]) == "query") { ++argv; --argc; }       // `cobs query ...`
     }
+    // `cobs benchmark-fpr IN_FILE [-k N] [-q N] [-w N] [-d|--dist] [--seed S]` (src/cobs.cpp:672-730): the index is the
+    // positional argument and -d means --dist, as there; the device list of this tool is spelled --device in this mode
+    const bool fpr_mode = argc > 1 && std::string(argv[1]) == "benchmark-fpr";
+    if (fpr_mode) { ++argv; --argc; }
     std::vector<std::string> index_paths;
     std::string query_line, query_file;
     double threshold = 0.8;
@@ -105,7 +151,7 @@ int main(int argc, char** argv) {
     uint64_t document_size = 1000000;
     bool synth_compact = false, force_sharded = false;
     uint64_t synth_docs = 10000, synth_page = 0, synth_hashes = 1;
-    bool bench = false;
+    bool bench = fpr_mode, dist = false;
     unsigned num_kmers = 1000, num_queries = 10000, num_warmup = 100;
     size_t seed = std::random_device{}();
     for (int i = 1; i < argc; ++i) {
@@ -118,6 +164,7 @@ int main(int argc, char** argv) {
         else if (a == "-f" || a == "--file") query_file = need("-f");
         else if (a == "-t" || a == "--threshold") threshold = std::atof(need("-t"));
         else if (a == "-l" || a == "--limit") num_results = (size_t)std::strtoull(need("-l"), nullptr, 10);
+        else if (a == "--dist" || (fpr_mode && a == "-d")) dist = true;
         else if (a == "-d" || a == "--device") {
             const std::string v = need("-d");
             for (size_t p = 0; p < v.size();) {
@@ -147,6 +194,7 @@ int main(int argc, char** argv) {
         else if (a == "--seed") seed = (size_t)std::strtoull(need("--seed"), nullptr, 10);
         else if (a == "-h" || a == "--help") { usage(); return 0; }
         else if (!a.empty() && a[0] == '-') { std::fprintf(stderr, "unknown flag %s\n", a.c_str()); usage(); return 1; }
+        else if (fpr_mode && index_paths.empty()) index_paths.push_back(a);
         else query_line = a;
     }
     const int device = devices.empty() ? -1 : devices[0];
@@ -202,7 +250,7 @@ int main(int argc, char** argv) {
         try {
             std::unique_ptr<cobs_gpu::BatchSearch> sp = open_index();
             cobs_gpu::BatchSearch& s = *sp;
-            return benchmark(s, index_paths[0], num_kmers, num_queries, num_warmup, seed);
+            return benchmark(s, index_paths[0], num_kmers, num_queries, num_warmup, seed, dist);
         } catch (const cobs_gpu::Error& e) {
             std::fprintf(stderr, "EXCEPTION: %s\n", e.what());
             return 1;

@@ -195,6 +195,17 @@ struct RankArgs {
     uint32_t pack_bits;          // 0: 8-byte records
 };
 
+// The distribution of the scores of a pass (rank_kernels.hip: score_hist_kernel) -- what `cobs benchmark-fpr --dist`
+// tallies result by result on the host (src/cobs.cpp:627-632): hist[s] += (query, real document) pairs with score s.
+struct HistRange { uint32_t begin, end; };       // local slots of one file's REAL documents (padding slots excluded)
+struct HistArgs {
+    const void* rows;            // score rows [nq][row_stride]
+    uint64_t row_stride;         // elements
+    const HistRange* ranges;
+    unsigned long long* hist;    // [nbins]; scores >= nbins fall into the last bin
+    uint32_t nranges, nq, nbins, score_bytes;
+};
+
 // Arguments of the construction kernel: set the signature bits of documents.
 // a stretch of term text whose k-grams are all terms (newlines included); otherwise a stretch is
 // sequences each followed by '\n' and no term holds a '\n'

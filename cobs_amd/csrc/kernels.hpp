@@ -31,6 +31,8 @@ hipError_t launch_topk(const TopkArgs& a, hipStream_t stream);
 
 // Ranking of every document (rank_kernels.hip): one pass of the stable radix sort by score; a.nq work-groups.
 hipError_t launch_rank(const RankArgs& a, bool first, bool last, hipStream_t stream);
+// Distribution of the scores of a pass over its real documents (rank_kernels.hip): nq x nranges work-groups.
+hipError_t launch_score_hist(const HistArgs& a, hipStream_t stream);
 
 // Row-selective out-of-core access (fetch_kernels.hip): one thread per (looked-up row, 16-byte piece).
 hipError_t launch_fetch_rows(const FetchArgs& a, bool idx64, hipStream_t stream);

@@ -267,7 +267,45 @@ hipError_t launch_rank_t(const RankArgs& a, bool first, bool last, size_t lds, h
     return go(rank_kernel<ST, false, false>);
 }
 
+// one work-group per (query, range): an LDS histogram of up to 4096 bins, flushed with one 64-bit atomic per
+// non-empty bin; wider score ranges go to global atomics directly (queries of more than 4095 terms)
+constexpr uint32_t kHistLds = 4096;
+template <typename ST>
+__global__ __launch_bounds__(256) void score_hist_kernel(HistArgs a) {
+    __shared__ uint32_t h[kHistLds];
+    const uint32_t q = blockIdx.x, r = blockIdx.y;
+    const bool lds = a.nbins <= kHistLds;
+    if (lds) {
+        for (uint32_t i = threadIdx.x; i < a.nbins; i += 256u) h[i] = 0u;
+        __syncthreads();
+    }
+    const ST* row = static_cast<const ST*>(a.rows) + (uint64_t)q * a.row_stride;
+    const HistRange rg = a.ranges[r];
+    for (uint32_t i = rg.begin + threadIdx.x; i < rg.end; i += 256u) {
+        uint32_t s = (uint32_t)row[i];
+        if (s >= a.nbins) s = a.nbins - 1u;
+        if (lds) atomicAdd(&h[s], 1u);
+        else atomicAdd(&a.hist[s], 1ull);
+    }
+    if (lds) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < a.nbins; i += 256u)
+            if (h[i]) atomicAdd(&a.hist[i], (unsigned long long)h[i]);
+    }
+}
+
 }  // namespace
+
+hipError_t launch_score_hist(const HistArgs& a, hipStream_t stream) {
+    if (a.nq == 0 || a.nranges == 0) return hipSuccess;
+    if (a.nbins == 0) return hipErrorInvalidValue;
+    const dim3 grid(a.nq, a.nranges);
+    if (a.score_bytes == 1) hipLaunchKernelGGL(score_hist_kernel<uint8_t>, grid, dim3(256), 0, stream, a);
+    else if (a.score_bytes == 2) hipLaunchKernelGGL(score_hist_kernel<uint16_t>, grid, dim3(256), 0, stream, a);
+    else if (a.score_bytes == 4) hipLaunchKernelGGL(score_hist_kernel<uint32_t>, grid, dim3(256), 0, stream, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
 
 hipError_t launch_rank(const RankArgs& a, bool first, bool last, hipStream_t stream) {
     if (a.nq == 0) return hipSuccess;

@@ -406,6 +406,46 @@ cobs_gpu_status cobs_gpu_batch_counts_host(cobs_gpu_batch* b, size_t q, uint32_t
     return fetch_counts(b, q, counts);
 }
 
+// `cobs benchmark-fpr --dist` (reference src/cobs.cpp:627-632, 664-670): the distribution of the scores of all results.
+// The reference walks every result of every query on the host (10 000 queries x 100 000 documents = 10^9 map updates);
+// here the score rows of the last run are tallied where they lie.
+cobs_gpu_status cobs_gpu_batch_score_histogram(cobs_gpu_batch* b, uint64_t* hist, size_t nbins) {
+    if (!b || !hist || nbins == 0 || nbins > (1u << 26)) return fail(COBS_GPU_ERR_ARG, "bad argument");
+    if (!b->ran || !b->have_counts || b->view_global) return fail(COBS_GPU_ERR_ARG, "run the batch with score rows first");
+    return guarded([&]() -> cobs_gpu_status {
+        const cobs_gpu_index* ix = b->ix;
+        HIP_TRY(hipSetDevice(ix->device));
+        std::vector<HistRange> ranges;
+        for (const Part& p : ix->parts) {
+            // the slots this shard holds that belong to real documents (padding documents of the last sub-index never score)
+            const uint64_t docs = p.meta.doc_names.size();
+            const uint64_t real = docs > p.slot_begin ? std::min<uint64_t>(docs - p.slot_begin, p.slot_count) : 0;
+            if (real) ranges.push_back(HistRange{(uint32_t)p.local_offset, (uint32_t)(p.local_offset + real)});
+        }
+        DevBuf<HistRange> d_ranges;
+        DevBuf<unsigned long long> d_hist;
+        HIP_TRY(d_ranges.reserve(std::max<size_t>(ranges.size(), 1)));
+        HIP_TRY(d_hist.reserve(nbins));
+        HIP_TRY(hipMemcpy(d_ranges.p, ranges.data(), ranges.size() * sizeof(HistRange), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(d_hist.p, 0, nbins * sizeof(unsigned long long)));
+        HIP_TRY(hipEventSynchronize(b->run_done));
+        HistArgs a{};
+        a.rows = b->counts.p;
+        a.row_stride = ix->local_counts;
+        a.ranges = d_ranges.p;
+        a.hist = d_hist.p;
+        a.nranges = (uint32_t)ranges.size();
+        a.nq = (uint32_t)b->nq;
+        a.nbins = (uint32_t)nbins;
+        a.score_bytes = b->elem_bytes;
+        HIP_TRY(launch_score_hist(a, nullptr));
+        std::vector<unsigned long long> h(nbins);
+        HIP_TRY(hipMemcpy(h.data(), d_hist.p, nbins * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < nbins; ++i) hist[i] += h[i];
+        return COBS_GPU_OK;
+    });
+}
+
 cobs_gpu_status cobs_gpu_batch_hits_host(cobs_gpu_batch* b, size_t q, size_t num_results,
                                          cobs_gpu_hit* hits, size_t cap, size_t* n_hits) {
     return guarded([&]() { return hits_host_impl(b, q, num_results, hits, cap, n_hits); });

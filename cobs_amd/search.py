@@ -538,6 +538,12 @@ class Batch:
         check(self._lib.cobs_gpu_batch_counts_host(self._h, query_no, out.ctypes.data, out.size))
         return out
 
+    def score_histogram(self, nbins):
+        """distribution of the scores of the last run over its real documents (`cobs benchmark-fpr --dist`) -> uint64[nbins]"""
+        h = np.zeros(nbins, dtype=np.uint64)
+        check(self._lib.cobs_gpu_batch_score_histogram(self._h, h.ctypes.data_as(C.POINTER(C.c_uint64)), nbins))
+        return h
+
     def hits_host(self, query_no, num_results=0):
         cap = max(1, self._s.total_counts if num_results == 0 else min(num_results, self._s.total_counts))
         hits = (Hit * cap)()

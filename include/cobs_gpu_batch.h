@@ -106,6 +106,10 @@ cobs_gpu_status cobs_gpu_batch_sync(cobs_gpu_batch* b, void* hip_stream, size_t*
 void* cobs_gpu_batch_counts_device(cobs_gpu_batch* b, uint32_t* elem_bytes, uint64_t* row_stride_bytes);
 /* D2H of one query's counts widened to u32 */
 cobs_gpu_status cobs_gpu_batch_counts_host(cobs_gpu_batch* b, size_t query_no, uint32_t* counts, size_t cap);
+/* `cobs benchmark-fpr --dist` (src/cobs.cpp:627-632: counts[r.score]++ over every result of every query): after a run
+ * that kept score rows, hist[s] += the (query, real document) pairs of the batch with score s (s >= nbins: the last
+ * bin); tallied on the device.  On a shard: of the documents it holds. */
+cobs_gpu_status cobs_gpu_batch_score_histogram(cobs_gpu_batch* b, uint64_t* hist, size_t nbins);
 /* D2H + rank the hits of query `query_no` of the last run */
 cobs_gpu_status cobs_gpu_batch_hits_host(cobs_gpu_batch* b, size_t query_no, size_t num_results,
                                          cobs_gpu_hit* hits, size_t cap, size_t* n_hits);

@@ -22,6 +22,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <iostream>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -46,11 +47,73 @@ public:
     cobs_gpu_status status;
 };
 
+//! The reference's Search carries a public `Timer timer_` with an accessor `timer()` (cobs/query/search.hpp:35-46,
+//! cobs/util/timer.hpp:19-55) that its callers read and reset: `s.timer().print("search")` (src/cobs.cpp:468),
+//! `s.timer().reset()` and `cobs::Timer t = s.timer(); t.get("hashes") ...` in benchmark_fpr_run (:623, :644-661).
+//! Same shape here, over the handle's phase timers (cobs_gpu_timers): get(name), reset(), print(info[, os]); a COPY is a
+//! snapshot (the reference copies the object to read it).  Names: the engine's own -- "hashes" (K1), "h2d" (query text),
+//! "scan" (K2: row gather + AND + count, ONE kernel), "d2h", "rank" -- and the reference's, so that its callers compile
+//! and print unchanged: "io" = the scan kernel (it is bound by the row gather the reference times as io), "and rows" and
+//! "add rows" = 0 (inside that kernel), "sort results" = d2h + rank.  An unknown name reads 0, as a fresh entry of the
+//! reference's timer does (timer.cpp:61-63).
+class Timer {
+public:
+    Timer() = default;
+    Timer(const Timer& o) { o.read(snap_); frozen_ = true; }
+    Timer& operator=(const Timer& o) {
+        if (this != &o) { o.read(snap_); frozen_ = true; ix_ = nullptr; }
+        return *this;
+    }
+    //! (the Search object that owns this timer names its index handle once it is open)
+    void bind(cobs_gpu_index* ix) { ix_ = ix; frozen_ = false; }
+    void reset() {
+        if (ix_ && !frozen_) (void)cobs_gpu_timers(ix_, nullptr, 1);
+        for (double& v : snap_) v = 0;
+    }
+    double get(const char* name) const {
+        double t[5];
+        read(t);
+        const std::string n(name ? name : "");
+        if (n == "hashes") return t[0];
+        if (n == "h2d") return t[1];
+        if (n == "scan" || n == "io") return t[2];
+        if (n == "d2h") return t[3];
+        if (n == "rank") return t[4];
+        if (n == "sort results") return t[3] + t[4];
+        if (n == "total") return t[0] + t[1] + t[2] + t[3] + t[4];
+        return 0.0;
+    }
+    //! "TIMER info=<info> name=seconds ... total=seconds" (timer.cpp:77-85)
+    void print(const char* info, std::ostream& os) const {
+        double t[5];
+        read(t);
+        os << "TIMER info=" << info << " hashes=" << t[0] << " h2d=" << t[1] << " scan=" << t[2] << " d2h=" << t[3]
+           << " rank=" << t[4] << " total=" << t[0] + t[1] + t[2] + t[3] + t[4] << std::endl;
+    }
+    void print(const char* info) const { print(info, std::cerr); }
+
+private:
+    void read(double out[5]) const {
+        for (int i = 0; i < 5; ++i) out[i] = snap_[i];
+        if (ix_ && !frozen_) (void)cobs_gpu_timers(ix_, out, 0);
+    }
+    cobs_gpu_index* ix_ = nullptr;
+    bool frozen_ = false;
+    double snap_[5] = {0, 0, 0, 0, 0};
+};
+
 class Search {
 public:
     virtual ~Search() = default;
+    //! Returns timer_ (cobs/query/search.hpp:35-38)
+    Timer& timer() { return timer_; }
+    const Timer& timer() const { return timer_; }
     virtual void search(const std::string& query, std::vector<SearchResult>& result,
                         double threshold = 0.0, size_t num_results = 0) = 0;
+
+public:
+    //! timer of different query phases
+    Timer timer_;
 };
 
 //! Search plus the batch call (the performance path; the reference loops queries serially)
@@ -124,15 +187,20 @@ public:
         o.device = device;
         o.hbm_budget_bytes = hbm_budget_bytes;
         check(cobs_gpu_open(cp.data(), cp.size(), &o, &ix_));
+        timer_.bind(ix_);
     }
 
     //! adopt an index handle that is already open (e.g. built by cobs_gpu_build_index_list)
-    explicit ClassicSearch(cobs_gpu_index* adopted) : ix_(adopted) {}
+    explicit ClassicSearch(cobs_gpu_index* adopted) : ix_(adopted) { timer_.bind(ix_); }
 
     ~ClassicSearch() override { cobs_gpu_close(ix_); }
     ClassicSearch(const ClassicSearch&) = delete;
     ClassicSearch& operator=(const ClassicSearch&) = delete;
-    ClassicSearch(ClassicSearch&& o) noexcept : ix_(o.ix_), hits_(std::move(o.hits_)) { o.ix_ = nullptr; }
+    ClassicSearch(ClassicSearch&& o) noexcept : ix_(o.ix_), hits_(std::move(o.hits_)) {
+        o.ix_ = nullptr;
+        o.timer_.bind(nullptr);
+        timer_.bind(ix_);
+    }
 
     void search(const std::string& query, std::vector<SearchResult>& result,
                 double threshold = 0.0, size_t num_results = 0) final {
@@ -212,6 +280,7 @@ public:
         o.struct_size = sizeof o;
         o.hbm_budget_bytes = hbm_budget_bytes;
         check(cobs_gpu_multi_open(cp.data(), cp.size(), devices.data(), devices.size(), &o, &m_));
+        timer_.bind(handle());
     }
     ~ShardedClassicSearch() override { cobs_gpu_multi_close(m_); }
     ShardedClassicSearch(const ShardedClassicSearch&) = delete;
@@ -259,6 +328,12 @@ public:
     }
 
     cobs_gpu_index* handle() const override { return cobs_gpu_multi_index(m_, 0); }
+    //! every rank's shard handle (each holds the score slots of its own documents)
+    std::vector<cobs_gpu_index*> shard_handles() const {
+        std::vector<cobs_gpu_index*> v;
+        for (size_t r = 0; r < cobs_gpu_multi_size(m_); ++r) v.push_back(cobs_gpu_multi_index(m_, r));
+        return v;
+    }
     //! ncclCommCount of the communicator the GPUs joined
     int comm_size() const { return (int)cobs_gpu_multi_size(m_); }
 

