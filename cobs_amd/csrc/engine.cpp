@@ -114,6 +114,8 @@ cobs_gpu_batch::~cobs_gpu_batch() {
     for (auto& r : ev) for (auto& e : r) if (e) (void)hipEventDestroy(e);
     if (run_done) (void)hipEventDestroy(run_done);
     if (done) (void)hipEventDestroy(done);
+    if (graph_t0) (void)hipEventDestroy(graph_t0);
+    if (graph_t1) (void)hipEventDestroy(graph_t1);
     if (own_stream) (void)hipStreamDestroy(own_stream);
     if (hashed) (void)hipEventDestroy(hashed);
     if (hash_stream) (void)hipStreamDestroy(hash_stream);

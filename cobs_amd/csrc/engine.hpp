@@ -313,6 +313,7 @@ struct cobs_gpu_batch {
     hipGraphExec_t graph_exec = nullptr;
     uint64_t graph_key = 0, graph_candidate = 0;
     bool graph_run = false;           // the last run was a graph replay
+    hipEvent_t graph_t0 = nullptr, graph_t1 = nullptr;   // ... bracketed by these (its device time goes to the "scan" timer as a whole)
     // results a replayed graph copies home by itself (pinned): flags | top-k counts | survivors | hit-pool prefix
     cobs_amd::PinnedBuf<uint8_t> h_res;
     size_t res_topk = 0, res_pool = 0, res_pool_n = 0;

@@ -181,7 +181,8 @@ cobs_gpu_status cobs_gpu_multi_search_batch(cobs_gpu_multi* m, const char* const
                                             size_t* hit_offsets, size_t* bad_query);
 
 /* phase timers of the host-buffer search API since the last reset, seconds:
- * out[0] hashes (K1), out[1] h2d, out[2] scan (K2), out[3] d2h, out[4] rank  */
+ * out[0] hashes (K1), out[1] h2d, out[2] scan (K2; a small pass replayed from a captured graph is timed as a whole: its
+ * device time -- hashing, scan, selection, its copies home -- goes here), out[3] d2h, out[4] rank  */
 cobs_gpu_status cobs_gpu_timers(cobs_gpu_index* ix, double out[5], int reset);
 
 #ifdef __cplusplus

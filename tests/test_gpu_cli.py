@@ -295,7 +295,8 @@ static void run(cobs_gpu::Search& s, const std::string& q) {
     const double h = t.get("hashes"), io = t.get("io"), sort = t.get("sort results");
     s.search(q, result);
     std::cout << "snapshot " << (t.get("hashes") == h && t.get("io") == io) << "\n";
-    std::cout << "positive " << (h > 0 && io > 0 && sort >= 0 && t.get("and rows") == 0 && t.get("no such timer") == 0) << "\n";
+    // (single queries are replayed from a captured graph: such a pass is timed as a whole under io / scan, its hashing included)
+    std::cout << "positive " << (h >= 0 && io > 0 && sort >= 0 && t.get("and rows") == 0 && t.get("no such timer") == 0) << "\n";
     std::cout << "live_grows " << (s.timer().get("io") > io) << "\n";
     std::ostringstream os;
     s.timer().print("search", os);
