@@ -129,6 +129,8 @@ SYMBOLS = {
     "cobs_gpu_search": (_int, [_vp, _cp, _sz, _dbl, _sz, C.POINTER(Hit), _sz, C.POINTER(_sz)]),
     "cobs_gpu_search_batch": (_int, [_vp, C.POINTER(_cp), C.POINTER(_sz), _sz, _dbl, _sz,
                                      C.POINTER(Hit), _sz, C.POINTER(_sz), C.POINTER(_sz)]),
+    "cobs_gpu_search_batch_view": (_int, [_vp, C.POINTER(_cp), C.POINTER(_sz), _sz, _dbl, _sz,
+                                          C.POINTER(C.POINTER(Hit)), C.POINTER(C.POINTER(_sz)), C.POINTER(_sz)]),
     "cobs_gpu_counts": (_int, [_vp, _cp, _sz, _vp, _sz]),
     "cobs_gpu_batch_create": (_int, [_vp, _sz, _sz, C.POINTER(_vp)]),
     "cobs_gpu_batch_destroy": (None, [_vp]),

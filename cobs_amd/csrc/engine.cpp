@@ -3,6 +3,7 @@
 // include/cobs_gpu.h.  There is no CPU fallback: without a HIP device every entry
 // point that needs one fails with COBS_GPU_ERR_NO_DEVICE.
 #include <hip/hip_runtime_api.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <chrono>
@@ -94,6 +95,24 @@ Part::~Part() {
     }
     if (d_tpages) (void)hipFree(d_tpages);
     if (file_pinned && file && pin_base) (void)hipHostUnregister(pin_base);       // (`file`: null in a moved-from Part)
+}
+
+cobs_gpu_status ResultArena::reserve(size_t n) {
+    if (n <= cap) return COBS_GPU_OK;
+    if (p) (void)munmap(p, round_up(cap * sizeof(cobs_gpu_hit), 2u << 20));
+    p = nullptr;
+    cap = 0;
+    const size_t bytes = round_up(n * sizeof(cobs_gpu_hit), 2u << 20);
+    void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) return fail(COBS_GPU_ERR_CAPACITY, "no memory for the result arena (" + std::to_string(bytes) + " bytes)");
+    (void)madvise(m, bytes, MADV_HUGEPAGE);
+    p = static_cast<cobs_gpu_hit*>(m);
+    cap = bytes / sizeof(cobs_gpu_hit);
+    return COBS_GPU_OK;
+}
+
+ResultArena::~ResultArena() {
+    if (p) (void)munmap(p, round_up(cap * sizeof(cobs_gpu_hit), 2u << 20));
 }
 
 StreamBufs::~StreamBufs() {

@@ -221,6 +221,16 @@ struct PartWork {    // per-file device workspace of a batch
     uint64_t table_entries = 0;
 };
 
+// cobs_gpu_search_batch_view: results in memory the handle owns (anonymous mapping, huge pages where the host offers
+// them on request; kept across calls, so its pages are faulted in once)
+struct ResultArena {
+    cobs_gpu_hit* p = nullptr;
+    size_t cap = 0;                  // records
+    std::vector<size_t> offs;
+    cobs_gpu_status reserve(size_t n);
+    ~ResultArena();
+};
+
 struct Exchange;     // comm.cpp: buffers of the RCCL exchange bound to a batch
 struct RankWork;     // rank.cpp: buffers of the on-device ranking of whole score rows
 
@@ -237,6 +247,7 @@ struct cobs_gpu_index {
     uint64_t total_counts = 0, local_counts = 0;
     bool peers_ranged = false;    // inside ONE sharded search call: some rank counts a streamed sub-index in row ranges -> every rank keeps score rows (agreed on per call, comm.cpp)
     double timers[5] = {0, 0, 0, 0, 0};
+    cobs_amd::ResultArena arena;  // cobs_gpu_search_batch_view
     uint64_t graph_replays = 0;   // small passes of the host API served by a captured hipGraph
     static constexpr int kScratch = 3;
     cobs_gpu_batch* scratch[kScratch] = {nullptr, nullptr, nullptr};   // workspaces of the host-buffer search API

@@ -54,6 +54,16 @@ cobs_gpu_status cobs_gpu_write_synthetic(const cobs_gpu_synth* desc, const char*
 cobs_gpu_status cobs_gpu_plant(cobs_gpu_index* ix, size_t file_no, const char* text, size_t len, const uint32_t* docs,
                                const uint32_t* keep_permille, size_t ndocs, uint64_t salt);
 
+/* cobs_gpu_search_batch with the results in memory the LIBRARY owns: *hits / *hit_offsets (nq + 1 entries) point into a
+ * result arena kept on the handle -- grown on demand, its pages faulted in once and reused by every later call (huge pages
+ * where the host offers them on request) -- and stay valid until the next search call on this handle.  The form for a
+ * caller that would otherwise allocate a fresh result array per call: the reference's default call returns one record per
+ * document and query (classic_search.cpp:450), 307 MB for 256 queries x 100 000 documents, and a fresh array costs
+ * 75 000 first-touch page faults per call.  (The reference's own callers keep ONE result vector: src/cobs.cpp:618-626.) */
+cobs_gpu_status cobs_gpu_search_batch_view(cobs_gpu_index* ix, const char* const* queries, const size_t* lens, size_t nq,
+                                           double threshold, size_t num_results, const cobs_gpu_hit** hits,
+                                           const size_t** hit_offsets, size_t* bad_query);
+
 /* score slots per query held by THIS shard (== cobs_gpu_total_counts when
  * unsharded); device count rows have this many elements */
 uint64_t cobs_gpu_local_counts(const cobs_gpu_index* ix);

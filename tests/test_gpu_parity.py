@@ -813,3 +813,79 @@ def test_hash_stream_pipelines_batches_without_changing_results(gpu_lib, oracle,
     b.sync()
     for i in range(len(sets[2])):
         assert np.array_equal(b.counts_host(i), want[2][i])
+
+
+# ---- round 5 ----------------------------------------------------------------------------------------------------------
+def test_results_in_the_library_arena_and_in_reused_buffers(gpu_lib, oracle, tmp_path):
+    """cobs_gpu_search_batch_view: the results of a call stay in an arena the handle owns (same lists as the array form,
+    for every kind of call; a later call reuses the memory).  And the Python mirror's own result buffers: a buffer nothing
+    references any more is reused by the next call, one that is still referenced is not"""
+    q_long = oracle.random_sequence(400, 3)
+    p = cases.make_compact(cases.tmp(tmp_path, "v.cobs_compact"), 1200, 32, [1500, 2100, 900, 1700, 1300], 1, 31, 1, 0.3, 8,
+                           planted={5: 1.0, 700: 0.9, 1100: 0.85}, query=q_long)
+    s = gpu_lib.Search(p, device=0)
+    queries = [q_long[:200], q_long[50:300], q_long[10:41], q_long[100:400]] * 9
+    addr = None
+    for thr, k in ((0.0, 0), (0.8, 0), (0.0, 7), (0.3, 3)):
+        offs_a, hits_a = s.search_arrays(queries, thr, k)
+        offs_v, hits_v = s.search_view(queries, thr, k)
+        assert np.array_equal(offs_a, offs_v) and np.array_equal(hits_a, hits_v), (thr, k)
+        if thr == 0.0 and k == 0:
+            addr = hits_v.ctypes.data
+            assert len(hits_v) == len(queries) * 1200
+    offs_v, hits_v = s.search_view(queries[:3], 0.0, 0)           # a smaller call: the same arena
+    assert hits_v.ctypes.data == addr
+    want = [cases.oracle_results([oracle.Index.open(p)], q, 0.0, 0) for q in queries[:3]]
+    assert [hits_v[int(offs_v[i]):int(offs_v[i + 1])].tolist() for i in range(3)] == want
+    # the mirror's buffers (results of >= 1 MiB): dropped -> reused; kept -> left alone
+    big = queries * 12                                            # 432 queries x 1200 documents x 12 bytes = 6 MB
+    o1, h1 = s.search_arrays(big, 0.0, 0)
+    a1 = h1.ctypes.data
+    first = h1[:5].tolist()
+    del o1, h1
+    o2, h2 = s.search_arrays(big, 0.0, 0)
+    assert h2.ctypes.data == a1 and h2[:5].tolist() == first      # the first call's buffer, used again
+    seg = h2[100:200]                                             # a slice keeps the buffer alive ...
+    del h2
+    o3, h3 = s.search_arrays(big, 0.0, 0)
+    assert h3.ctypes.data != a1                                   # ... so the next call does not write into it
+    assert seg.tolist() == h3[100:200].tolist()
+    res = s.search(q_long[:200])                                  # the lazy ResultList holds on to its buffer the same way
+    keep = [(r.doc_name, r.score) for r in res[:3]]
+    for _ in range(4):
+        s.search_arrays(big, 0.0, 0)
+    assert [(r.doc_name, r.score) for r in res[:3]] == keep
+
+
+def test_score_histogram_is_the_distribution_of_the_rows(gpu_lib, oracle, tmp_path):
+    """cobs_gpu_batch_score_histogram (`cobs benchmark-fpr --dist`, src/cobs.cpp:627-632) against the checker's rows: real
+    documents only, 8- and 16-bit scores, two files, a shard"""
+    import collections
+    q_long = oracle.random_sequence(700, 9)
+    pa = cases.make_compact(cases.tmp(tmp_path, "h.cobs_compact"), 3 * 8 * 24 - 7, 24, [800, 1200, 1000], 1, 31, 1, 0.3, 2,
+                            planted={3: 1.0}, query=q_long)
+    pb = cases.make_classic(cases.tmp(tmp_path, "h.cobs_classic"), 333, 901, 2, 31, 1, 0.4, 3)
+    ixs = [oracle.Index.open(pa), oracle.Index.open(pb)]
+    for queries in ([q_long[:100], q_long[40:200], q_long[:31]], [q_long, q_long[100:500]]):
+        nb = max(len(q) for q in queries) - 30 + 1
+        want = collections.Counter()
+        for q in queries:
+            for ix in ixs:
+                want.update(int(v) for v in ix.counts(q)[:ix.num_docs])
+        s = gpu_lib.Search([pa, pb], device=0)
+        b = gpu_lib.Batch(s)
+        b.set_queries(queries)
+        b.run(0.0)
+        b.sync()
+        h = b.score_histogram(nb)
+        assert {i: int(c) for i, c in enumerate(h) if c} == dict(want)
+        # the shards' distributions add up to the whole
+        tot = np.zeros(nb, dtype=np.uint64)
+        for r in range(3):
+            sr = gpu_lib.Search([pa, pb], device=0, shard_rank=r, shard_count=3)
+            br = gpu_lib.Batch(sr)
+            br.set_queries(queries)
+            br.run(0.0)
+            br.sync()
+            tot += br.score_histogram(nb)
+        assert np.array_equal(tot, h)
