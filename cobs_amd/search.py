@@ -209,7 +209,31 @@ class Search:
     # -- queries -------------------------------------------------------------
     def search(self, query, threshold=0.0, num_results=0):
         """Same contract as cobs_index.Search.search (python/module.cpp:372-386)."""
-        return self.search_batch([query], threshold, num_results)[0]
+        if type(self)._search_batch_call is not Search._search_batch_call:
+            return self.search_batch([query], threshold, num_results)[0]
+        # one query: cobs_gpu_search straight into a reused result buffer (no numpy marshalling of a batch of one)
+        q = query if type(query) is bytes else _as_bytes(query)
+        total = self.total_counts
+        if num_results > 0:
+            cap = min(num_results, total)
+        elif threshold <= 0:
+            cap = total
+        else:
+            cap = 1024
+        n = C.c_size_t(0)
+        while True:
+            hits = self._result_buffer(max(cap, 1))
+            st = self._lib.cobs_gpu_search(self._h, q, len(q), float(threshold), int(num_results),
+                                           C.cast(hits.ctypes.data, C.POINTER(Hit)), len(hits), C.byref(n))
+            if st == _capi.ERR_CAPACITY and n.value > cap:
+                cap = n.value
+                continue
+            check(st)
+            break
+        seg = hits[:n.value]
+        if n.value <= 64:
+            return [SearchResult(self.doc_name(f, d), s) for (f, d, s) in seg.tolist()]
+        return ResultList(self, seg)
 
     HIT_DTYPE = np.dtype([("file_no", "<u4"), ("doc", "<u4"), ("score", "<u4")])
 

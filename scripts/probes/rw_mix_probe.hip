@@ -61,6 +61,40 @@ __global__ __launch_bounds__(64) void probe(const uint8_t* table, uint64_t table
     if (wlines == 0 && acc.x == 0xdeadbeefu && acc.y == 0x12345u) scores[0] = 1;    // keep the loads
 }
 
+// ROW RANGES SIZED FOR THE L2 (round 5): the tile's column of ONE small sub-index (S_p x 128 bytes:
+// 32 ... 105 MB for the four smallest of C3 -- every row of it is looked up 10-40 times per 10k-query batch, from the
+// Infinity Cache today, L2 hit rate 5 %) cut into R row ranges of <= 3 MB; the grid runs (tile, range)-major, a wave
+// gathers only the lines of ITS range (1000 / R per query) and writes the tile's partial scores (16 lines per query,
+// as the full scan does ONCE per tile).  Against the same sub-index scanned as today.  The arithmetic-free ceiling of
+// the idea: what the memory system gives for the access pattern, before any kernel is built.
+__global__ __launch_bounds__(64) void probe_ranges(const uint8_t* table, uint64_t base, uint64_t rows, uint32_t pitch,
+                                                   uint8_t* scores, uint32_t nqg, uint32_t nranges, uint32_t trips,
+                                                   uint32_t wlines, uint64_t salt) {
+    const uint32_t lane = threadIdx.x, grp = lane >> 3, col = lane & 7u;
+    const uint32_t qg = blockIdx.x % nqg, tr = blockIdx.x / nqg;       // queries fastest, then ranges, then tiles
+    const uint32_t range = tr % nranges, tile = tr / nranges;
+    const uint64_t per = (rows + nranges - 1) / nranges, r0 = (uint64_t)range * per;
+    const uint64_t span = r0 + per <= rows ? per : rows - r0;
+    u32x4 acc = {0u, 0u, 0u, 0u};
+    u32x4 x[8];
+    for (uint32_t t = 0; t < trips; t += 8) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const uint64_t h = mix64(((uint64_t)blockIdx.x * 1024u + t + r) * 8u + grp + salt);
+            const uint64_t off = base + (r0 + h % span) * pitch + (uint64_t)tile * 128u;
+            x[r] = t + r < trips ? *reinterpret_cast<const u32x4*>(table + off + col * 16u) : acc;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc ^= x[r];
+    }
+    for (uint32_t i = lane; i < 8u * wlines * 8u; i += 64) {
+        const uint32_t q = i / (wlines * 8u), piece = i - q * wlines * 8u;
+        uint8_t* dst = scores + ((uint64_t)qg * 8u + q) * 200704u + (uint64_t)tile * 2048u + piece * 16u;
+        *reinterpret_cast<u32x4*>(dst) = acc;
+    }
+    if (wlines == 0 && acc.x == 0xdeadbeefu && acc.y == 0x12345u) scores[0] = 1;
+}
+
 int main(int argc, char** argv) {
     // optional: dynamic LDS bytes per work-group, to hold the occupancy at floor(160 KiB / lds) waves per CU
     // (the scan kernel runs 16 waves per CU at 125 VGPRs)
@@ -120,6 +154,47 @@ int main(int argc, char** argv) {
         const double wr = (double)tiles * nqg * 8.0 * m.wlines * 128.0;
         printf("%s  %8.3f ms   read %7.2f GB  written %6.2f GB (%4.1f %%)   %7.1f GB/s\n", m.name, best, rd / 1e9, wr / 1e9,
                100.0 * wr / (rd + wr), (rd + wr) / best / 1e6);
+    }
+    // ---- row ranges sized for the L2: the four smallest sub-indexes, 10 000 queries (the headline batch) ----
+    {
+        const uint32_t nq2 = 10000, nqg2 = nq2 / 8;
+        printf("# row ranges of <= 3 MB per tile column, (tile, range)-major, %u queries; per sub-index: today's pattern vs ranges\n", nq2);
+        double sum_now = 0, sum_rng = 0;
+        for (int p = 0; p < 4; ++p) {
+            const uint32_t R = (uint32_t)((pg.rows[p] * 128ull + (3u << 20) - 1) / (3u << 20));
+            const uint32_t trips_r = ((1000u + R - 1) / R + 7u) / 8u * 8u;       // a range's share of the 1000 terms, in blocks of 8
+            float now = 1e30f, rng = 1e30f, rng_nw = 1e30f;
+            for (int rep = 0; rep < 4; ++rep) {
+                float ms = 0;
+                hipEventRecord(e0);
+                hipLaunchKernelGGL(probe_ranges, dim3(13u * 1u * nqg2), dim3(64), lds, 0, table, pg.base[p], pg.rows[p], pitch, scores,
+                                   nqg2, 1u, 1000u, 16u, (uint64_t)rep * 7919u);
+                hipEventRecord(e1);
+                hipEventSynchronize(e1);
+                hipEventElapsedTime(&ms, e0, e1);
+                if (rep > 0 && ms < now) now = ms;
+                hipEventRecord(e0);
+                hipLaunchKernelGGL(probe_ranges, dim3(13u * R * nqg2), dim3(64), lds, 0, table, pg.base[p], pg.rows[p], pitch, scores,
+                                   nqg2, R, trips_r, 16u, (uint64_t)rep * 104729u);
+                hipEventRecord(e1);
+                hipEventSynchronize(e1);
+                hipEventElapsedTime(&ms, e0, e1);
+                if (rep > 0 && ms < rng) rng = ms;
+                hipEventRecord(e0);
+                hipLaunchKernelGGL(probe_ranges, dim3(13u * R * nqg2), dim3(64), lds, 0, table, pg.base[p], pg.rows[p], pitch, scores,
+                                   nqg2, R, trips_r, 0u, (uint64_t)rep * 15485863u);
+                hipEventRecord(e1);
+                hipEventSynchronize(e1);
+                hipEventElapsedTime(&ms, e0, e1);
+                if (rep > 0 && ms < rng_nw) rng_nw = ms;
+            }
+            printf("sub-index %d (%llu rows, column %.0f MB): today %7.3f ms | %2u ranges x %3u lines + 16 written each %7.3f ms | the same without the partial-score writes %7.3f ms\n",
+                   p, (unsigned long long)pg.rows[p], pg.rows[p] * 128.0 / 1e6, now, R, trips_r, rng, rng_nw);
+            sum_now += now;
+            sum_rng += rng;
+        }
+        printf("four smallest sub-indexes: today %.3f ms, in L2-sized row ranges %.3f ms (%+.1f %%)\n", sum_now, sum_rng,
+               100.0 * (sum_rng - sum_now) / sum_now);
     }
     return 0;
 }
