@@ -396,7 +396,8 @@ def hbm_side_probe(args, queries, dev, scale=8.0, exact_rows=16):
     of 2.5-40 times, the working set of a 128-byte tile column (S_p x 128 B: 256 MB ... 4 GB) no longer fits the 256 MB
     Infinity Cache, and 56 % of the algorithmic bytes are DISTINCT rows that have to cross the pins: `unique_frac` is a
     floor of the pin-side fraction from a grid that fills the device for 21 ms (cache_cold's 256 queries fill it for half
-    a millisecond).  A quarter of the batch on the same index repeats even less (unique / algorithmic 0.84).
+    a millisecond).  A quarter / a tenth of the batch on the same index repeat even less (unique / algorithmic 0.82 / 0.92)
+    and still fill the device for 5 / 2 ms.
     Parity: `exact_rows` rows of the batch element by element against rows the oracle regenerates for THAT index."""
     from oracle import oracle as O
     cfg = c3_config(scale)
@@ -410,7 +411,7 @@ def hbm_side_probe(args, queries, dev, scale=8.0, exact_rows=16):
            "workload": "the headline batch on the C3 geometry with S_p x %g (%.0f GB resident)"
                        % (scale, sum(cfg["signature_sizes"]) * row_bytes / 1e9)}
     b = cobs_amd.Batch(s)
-    for name, nq in (("batch", len(queries)), ("quarter_batch", max(1, len(queries) // 4))):
+    for name, nq in (("batch", len(queries)), ("quarter_batch", max(1, len(queries) // 4)), ("tenth_batch", max(1, len(queries) // 10))):
         b.set_queries(queries[:nq])
         for _ in range(2):
             b.run(0.0, 0)

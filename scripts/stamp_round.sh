@@ -5,7 +5,7 @@
 # gpurun_out/stamp_TAG/ (scratch); scripts/collect_shapes.py TAG + scripts/collect_stamp.sh TAG copy the summaries
 # into profiles/ (tracked).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/stamp_$TAG
 mkdir -p "$OUT"
@@ -17,8 +17,18 @@ python bench.py --config c2 --no-cpu-baseline > "$OUT/bench_c2.json" 2>/dev/null
 python bench.py --config c5 --no-cpu-baseline --steps 3 --warmup 1 > "$OUT/c5_bench.json" 2> "$OUT/c5_bench.err"
 python bench.py --config c5 --no-cpu-baseline --steps 5 --warmup 2 --queries 256 > "$OUT/c5_q256_bench.json" 2>/dev/null
 COBS_GPU_ROW_RANGES=0 python bench.py --config c5 --no-cpu-baseline --steps 3 --warmup 1 > "$OUT/c5_columns_bench.json" 2>/dev/null
+# round 4's plan (residency per FILE: the whole file streamed through two buffers of half the budget), and 512 MiB buffers
+COBS_GPU_STREAM_BUF_KIB=0 python bench.py --config c5 --no-cpu-baseline --steps 3 --warmup 1 > "$OUT/c5_per_file_bench.json" 2>/dev/null
+COBS_GPU_STREAM_BUF_KIB=524288 python bench.py --config c5 --no-cpu-baseline --steps 3 --warmup 1 > "$OUT/c5_buf512_bench.json" 2>/dev/null
 rm -f /tmp/cobs_c5_1.cobs_compact
+# configs[4] at its named size: a 184 GB file (tmpfs) under a 64 GB budget, per-slice residency and round 4's per-file plan
+timeout 1500 python bench.py --config c5 --scale 10 --hbm-budget-gb 64 --index-file /dev/shm/cobs_c5_10.cobs_compact \
+    --no-cpu-baseline --steps 2 --warmup 1 > "$OUT/c5_184GB_bench.json" 2> "$OUT/c5_184GB_bench.err"
+COBS_GPU_STREAM_BUF_KIB=0 timeout 1500 python bench.py --config c5 --scale 10 --hbm-budget-gb 64 --index-file /dev/shm/cobs_c5_10.cobs_compact \
+    --no-cpu-baseline --steps 2 --warmup 1 > "$OUT/c5_184GB_per_file_bench.json" 2> /dev/null
+rm -f /dev/shm/cobs_c5_10.cobs_compact
 python scripts/default_call.py 256 > "$OUT/default_call.txt" 2>&1
+python scripts/probes/fresh_buffer_probe.py > "$OUT/fresh_buffer_probe.txt" 2>&1
 python scripts/latency.py > "$OUT/latency.txt" 2>&1
 python scripts/row_fetch_bench.py 1.0 6 > "$OUT/c5_selective.txt" 2>&1
 scripts/probes/h2d_probe 4 > "$OUT/h2d_probe.txt" 2>&1
