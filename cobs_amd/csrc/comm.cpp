@@ -426,6 +426,8 @@ cobs_gpu_status cobs_gpu_comm_create(const uint8_t id[COBS_GPU_UNIQUE_ID_BYTES],
         }
         static std::atomic<uint64_t> next_serial{1};
         c->serial = next_serial.fetch_add(1);
+        // (a default time limit for callers that cannot set one -- the device-list handle's worker threads, the CLI's -d)
+        if (const char* e = getenv("COBS_GPU_COMM_TIMEOUT_MS")) c->timeout_ms = (uint32_t)std::strtoul(e, nullptr, 0);
         *out = c.release();
         return COBS_GPU_OK;
     });

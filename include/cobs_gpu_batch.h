@@ -146,7 +146,8 @@ int cobs_gpu_comm_size(const cobs_gpu_comm* c);     /* ncclCommCount, 0 on error
  * rank, before any collective.  A collective that a peer never enters does not fail, it waits: */
 /* ... with a time limit, the stream waits the library itself performs around collectives (layout and size exchanges,
  * status agreements, the row exchanges of cobs_gpu_sharded_search_batch) give up after timeout_ms, abort the
- * communicator and return COBS_GPU_ERR_RCCL.  0 (default) = wait for ever. */
+ * communicator and return COBS_GPU_ERR_RCCL.  0 = wait for ever (the default, unless COBS_GPU_COMM_TIMEOUT_MS is set in the
+ * environment when the communicator is created: the limit of communicators the library makes itself, cobs_gpu_multi_open). */
 void cobs_gpu_comm_set_timeout(cobs_gpu_comm* c, uint32_t timeout_ms);
 /* ... and what this rank entered last, as one line of text (RCCL calls entered / returned, the last call, whether its
  * stream is idle) -- callable from ANOTHER thread while the owner sits in a call: what a caller's watchdog prints

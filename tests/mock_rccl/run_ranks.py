@@ -12,7 +12,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-os.environ["COBS_GPU_TEST_RANKS_SHARE_A_DEVICE"] = "1"
 os.environ.setdefault("COBS_GPU_ROW_RANGE_MIN", "48")
 assert "libmockrccl.so" in os.environ.get("LD_PRELOAD", ""), "run me through tests/test_gpu_mock_ranks.py (LD_PRELOAD=cobs_amd/libmockrccl.so)"
 

@@ -63,7 +63,7 @@ def test_cli_device_list_over_three_ranks(mock_library, oracle, golden_dir, tmp_
     qf = tmp_path / "q.fa"
     qf.write_text(">first query\n%s\n%s\n\n;second\n%s\n" % (q50[:25], q50[25:], q50[3:40]))
     ixs = [oracle.Index.open(a), oracle.Index.open(b)]
-    env = dict(os.environ, LD_PRELOAD=mock, COBS_GPU_TEST_RANKS_SHARE_A_DEVICE="1", MOCK_RCCL_TIMEOUT_S="30")
+    env = dict(os.environ, LD_PRELOAD=mock, MOCK_RCCL_TIMEOUT_S="30")     # (the stand-in's marker symbol lets ranks share the device)
     for extra in (["-t", "0.05"], ["-t", "0"], ["-t", "0", "-l", "3"]):
         r = subprocess.run([tool, "-d", "0,0,0", "-i", a, "-i", b, "-f", str(qf)] + extra, capture_output=True, text=True,
                            timeout=300, env=env)
