@@ -127,18 +127,45 @@ struct AddScoresArgs {
     uint32_t nslots, nq, elem_bytes;
 };
 
-struct FetchArgs {
-    const uint8_t* file;         // device-visible address of the mapped index file
+// How many rows a batch LOOKS UP in every streamed piece of a file (count_rows_kernel): counter first + min(row / per,
+// n - 1) of the entry's sub-index (per == 0: one counter for the sub-index); first == 0xFFFFFFFF: not counted (resident).
+struct CountPage { uint64_t per; uint32_t first, n; };
+struct CountArgs {
     const void* table;           // K1's row indices (u32, or u64 when idx64)
-    void* table2;                // same layout: the rows' numbers inside the gathered buffer (written here)
     const uint64_t* blk_off;     // nq + 1
-    const PageDev* pages;        // the chunk's pages as resident data would hold them
+    const PageDev* tpages;       // the part's sub-indexes (sig: a row index >= sig is K1's padding)
+    const CountPage* cpages;     // [table_npages]
+    unsigned long long* counts;  // [ncounters], zeroed
+    uint32_t nq, table_npages, num_hashes, ncounters;
+};
+
+// The row-selective gather (gather_assign_kernel, gather_copy_kernel): exactly the looked-up rows of a unit's pages, packed.
+// A page = one slice of a sub-index (all of its rows, or a row range); its gathered rows sit at rows [slot0, slot0 + count)
+// of the buffer, its zero row at slot0 + count.
+struct GatherPage {
+    uint64_t src;                // file offset of (first row of the page, first held column)
+    uint64_t row0, nrows;        // rows of the sub-index the page covers
+    uint64_t slot0;              // first gathered row (rows of `pitch` bytes)
+    uint32_t count;              // looked-up rows in [row0, row0 + nrows): exact (count_rows_kernel)
+    uint32_t tpage;              // sub-index in the row-index table
+    uint32_t leader;             // the page of this unit whose row list this page uses (column slices of one sub-index share it)
+    uint32_t valid_bytes;        // row bytes of the slice (the rest of the pitch reads as zero)
+};
+struct GatherArgs {
+    const uint8_t* file;         // device-visible address of the mapped index file
+    const void* table;           // K1's row indices
+    void* table2;                // same layout: the gathered row of every entry (page-relative; count = the page's zero row)
+    const uint64_t* blk_off;     // nq + 1
+    const GatherPage* pages;
+    const PageDev* pages_in;     // the unit's pages as a resident chunk would hold them (slot0, doc0, ... are copied)
     PageDev* pages2;             // ... as the gathered buffer holds them (written here)
-    const uint64_t* page_src;    // [npages] file offset of (row 0, first held column) of every slice
-    uint8_t* dst;                // gathered rows: [npages][entries + 1] rows of `pitch` bytes (the last of each page all zero)
+    uint8_t* dst;                // the gathered rows
+    uint64_t* rowlist;           // [total slots] source row (relative to the page's row0) of every gathered row
+    unsigned long long* cursor;  // [npages], zeroed: slots handed out so far
     uint64_t entries;            // table entries per sub-index: (blk_off[nq] + nq) * 8 * num_hashes
+    uint64_t total_rows;         // gathered rows incl. the pages' zero rows
     uint64_t src_pitch;          // bytes between rows in the file
-    uint32_t nq, npages, table_npages, num_hashes, pitch, ncols;
+    uint32_t nq, npages, table_npages, num_hashes, pitch;
 };
 
 // Arguments of the top-k selection kernel K3 for one index file.

@@ -84,16 +84,15 @@ Part::~Part() {
     for (Chunk& c : chunks) {
         if (c.d_data) (void)hipFree(c.d_data);
         if (c.d_pages) (void)hipFree(c.d_pages);
-        if (c.d_src) (void)hipFree(c.d_src);
         if (c.d_pages_acc) (void)hipFree(c.d_pages_acc);
         for (auto* p2 : c.d_pages2) if (p2) (void)hipFree(p2);
     }
     for (Chunk& c : fetch_groups) {
         if (c.d_pages) (void)hipFree(c.d_pages);
-        if (c.d_src) (void)hipFree(c.d_src);
         for (auto* p2 : c.d_pages2) if (p2) (void)hipFree(p2);
     }
     if (d_tpages) (void)hipFree(d_tpages);
+    if (d_cpages) (void)hipFree(d_cpages);
     if (file_pinned && file && pin_base) (void)hipHostUnregister(pin_base);       // (`file`: null in a moved-from Part)
 }
 
@@ -242,15 +241,32 @@ static cobs_gpu_status stage_index(cobs_gpu_index* ix, std::vector<std::unique_p
                 void* dp = nullptr;
                 if (hipHostGetDevicePointer(&dp, pt.pin_base, 0) == hipSuccess && dp) {
                     pt.file_dev = static_cast<const uint8_t*>(dp) - lo;      // (offsets stay offsets into the file)
+                    // one look-up counter per streamed piece of every sub-index: a whole slice (column slices of one
+                    // sub-index see the same rows: one counter), or each of its row ranges (equal length but the last)
+                    pt.cpages.assign(pt.tpages.size(), CountPage{0, 0xFFFFFFFFu, 0});
+                    pt.ncounters = 0;
                     for (Chunk& c : pt.chunks) {
                         if (c.resident) continue;
-                        std::vector<uint64_t> src(c.vp.size());
-                        for (size_t k = 0; k < c.vp.size(); ++k)
-                            src[k] = pt.meta.page_offset(c.vp[k].fp) + c.vp[k].row0 * pt.meta.page_row_bytes() + c.vp[k].col0;
-                        HIP_TRY(hipMalloc((void**)&c.d_src, 8 * src.size()));
-                        HIP_TRY(hipMemcpy(c.d_src, src.data(), 8 * src.size(), hipMemcpyHostToDevice));
+                        c.fetch_ok = true;
+                        c.src.resize(c.vp.size());
+                        c.cp.resize(c.vp.size());
+                        for (size_t k = 0; k < c.vp.size(); ++k) {
+                            c.src[k] = pt.meta.page_offset(c.vp[k].fp) + c.vp[k].row0 * pt.meta.page_row_bytes() + c.vp[k].col0;
+                            CountPage& cpg = pt.cpages[c.vp[k].fp - pt.first_page];
+                            if (c.row_range) {
+                                if (c.range_no == 0) { cpg.first = pt.ncounters; cpg.per = c.vp[k].nrows; cpg.n = 0; }
+                                c.cp[k] = {cpg.first + c.range_no, 1u};
+                                cpg.n = std::max(cpg.n, c.range_no + 1u);
+                                pt.ncounters = std::max(pt.ncounters, cpg.first + c.range_no + 1u);
+                            } else {
+                                if (cpg.first == 0xFFFFFFFFu) { cpg.first = pt.ncounters++; cpg.per = 0; cpg.n = 1; }
+                                c.cp[k] = {cpg.first, 1u};
+                            }
+                        }
                         for (auto& p2 : c.d_pages2) HIP_TRY(hipMalloc((void**)&p2, sizeof(PageDev) * c.vp.size()));
                     }
+                    HIP_TRY(hipMalloc((void**)&pt.d_cpages, sizeof(CountPage) * std::max<size_t>(pt.cpages.size(), 1)));
+                    HIP_TRY(hipMemcpy(pt.d_cpages, pt.cpages.data(), sizeof(CountPage) * pt.cpages.size(), hipMemcpyHostToDevice));
                     // every RUN of consecutive chunks of equal pitch as one unit (pass.cpp uses them when every chunk is
                     // fetched by rows).  Runs, not all chunks of a pitch: the units of a pass are scanned in this
                     // order, and a top-k pass without score rows leaves its candidates in unit order, which K3 takes
@@ -294,12 +310,16 @@ static cobs_gpu_status stage_index(cobs_gpu_index* ix, std::vector<std::unique_p
                         }
                         for (Chunk& g : pt.fetch_groups) {
                             g.total_chunks = (uint32_t)g.vp.size() * g.cpp;
-                            std::vector<uint64_t> src(g.vp.size());
-                            for (size_t k = 0; k < g.vp.size(); ++k) src[k] = pt.meta.page_offset(g.vp[k].fp) + g.vp[k].col0;
+                            g.fetch_ok = true;
+                            g.src.resize(g.vp.size());
+                            g.cp.resize(g.vp.size());
+                            for (size_t k = 0; k < g.vp.size(); ++k) {
+                                g.src[k] = pt.meta.page_offset(g.vp[k].fp) + g.vp[k].col0;
+                                const CountPage& cpg = pt.cpages[g.vp[k].fp - pt.first_page];
+                                g.cp[k] = {cpg.first, cpg.n};          // (all row ranges of the sub-index)
+                            }
                             HIP_TRY(hipMalloc((void**)&g.d_pages, sizeof(PageDev) * g.pages.size()));
                             HIP_TRY(hipMemcpy(g.d_pages, g.pages.data(), sizeof(PageDev) * g.pages.size(), hipMemcpyHostToDevice));
-                            HIP_TRY(hipMalloc((void**)&g.d_src, 8 * src.size()));
-                            HIP_TRY(hipMemcpy(g.d_src, src.data(), 8 * src.size(), hipMemcpyHostToDevice));
                             for (auto& p2 : g.d_pages2) HIP_TRY(hipMalloc((void**)&p2, sizeof(PageDev) * g.vp.size()));
                         }
                     }

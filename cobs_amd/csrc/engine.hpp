@@ -141,8 +141,10 @@ struct Chunk {
     size_t bytes = 0;                // device bytes incl. zero rows
     size_t stage_bytes = 0;          // packed host bytes (rows x ncols)
     uint8_t* d_data = nullptr;       // resident chunk only
-    // streamed chunk of a file whose mapping is registered: what the row-selective pass needs on the device
-    uint64_t* d_src = nullptr;       // [vp.size()] file offset of (row 0, first held column) of every slice
+    // streamed chunk of a file whose mapping is registered: what the row-selective pass needs
+    std::vector<uint64_t> src;       // [vp.size()] file offset of (first row, first held column) of every slice
+    std::vector<std::pair<uint32_t, uint32_t>> cp;   // [vp.size()] (first, count) of the part's look-up counters that cover the page (count_rows_kernel)
+    bool fetch_ok = false;           // ... and it may be fetched row by row (registered mapping, not resident)
     PageDev* d_pages2[2] = {nullptr, nullptr};   // the pages as a gathered buffer holds them (written per pass), per stream buffer
     // A ROW-RANGE chunk: one sub-index too large for a stream buffer, cut by rows (all columns, `nrows` rows from `row0`) --
     // whole rows cross PCIe at the link's best rate, column slices do not (plan.cpp: chunk_part).  Its scan counts only
@@ -165,6 +167,11 @@ struct Part {
     std::vector<Chunk> fetch_groups;
     std::vector<PageDev> tpages;             // sub-indexes [first_page, end_page): pages of the row-index table
     PageDev* d_tpages = nullptr;
+    // streamed file with a registered mapping: one look-up counter per streamed piece of every sub-index (a whole slice,
+    // or each of its row ranges) -- a pass counts, right after K1, how many rows the batch looks up in each (pass.cpp)
+    std::vector<CountPage> cpages;           // [tpages]
+    CountPage* d_cpages = nullptr;
+    uint32_t ncounters = 0;
     bool streamed = false;
     bool has_row_ranges = false;             // some chunk is a row range: K2 cannot select on its partial counts (pass.cpp)
     bool idx64 = false;                      // a sub-index has >= 2^32 - 1 rows: 64-bit row-index table
@@ -203,6 +210,12 @@ struct StreamBufs {
     // row-selective passes: the row-index table of the gathered rows in buffer i, and the event after K1
     // (the fetch kernel on the copy stream reads K1's table)
     DevBuf<uint8_t> table2[2];
+    DevBuf<uint64_t> rowlist[2];              // source rows of the gathered rows in buffer i
+    DevBuf<unsigned long long> cursor[2];     // slot cursors of the gather, per page
+    DevBuf<GatherPage> gpages[2];
+    PinnedBuf<GatherPage> h_gpages[2];
+    DevBuf<unsigned long long> d_counts;      // look-up counters of the file being scanned (count_rows_kernel)
+    PinnedBuf<unsigned long long> h_counts;
     hipEvent_t hashed = nullptr;
     uint64_t fetched_chunks = 0, streamed_chunks = 0;   // diagnostics: how the chunks of all passes were brought in
     uint64_t fetched_bytes = 0, streamed_bytes = 0;     // ... and what that asked of PCIe: looked-up rows x pitch / the chunks' rows

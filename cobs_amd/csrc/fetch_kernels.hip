@@ -6,19 +6,28 @@
 // (aio_search_file.cpp:58-97).  Streaming a whole sub-index through HBM is the right thing only when a batch
 // looks up more bytes than the sub-index holds; for a single query it moves gigabytes to touch megabytes.
 //
-//   fetch_rows_kernel   for one streamed chunk (a group of equal-width sub-index slices): reads the row
-//                       indices K1 wrote, fetches exactly those rows from the index file -- whose mapping is
-//                       registered with HIP, so the loads go over PCIe straight from the page cache, 16
-//                       bytes per lane, a row's pieces on consecutive lanes (1 KiB per wave-load) -- into a
-//                       gathered buffer in HBM laid out like a resident chunk (same pitch, a zero row behind
-//                       every slice's rows), and writes the row-index table of that buffer (entry e -> gathered
-//                       row e; padding entries -> the zero row) plus the PageDev array describing it.  K2 then scans the
-//                       gathered buffer with the code it runs on resident data.
+//   count_rows_kernel   right after K1: how many rows does the batch look up in every streamed piece of the file (a whole
+//                       slice, or each row range of a sub-index that is cut by rows)?  One counter each; the host reads
+//                       them and decides per chunk -- exactly, not by expectation -- whether its looked-up rows are
+//                       fewer bytes than the chunk.
+//   gather_assign_kernel / gather_copy_kernel
+//                       for one unit (a streamed chunk, or a run of them merged): a slot of the gathered buffer for
+//                       exactly the looked-up rows of each of its pages (a wave-aggregated atomic per page: the order of
+//                       the slots does not matter), the second row-index table (entry -> its slot; padding entries and
+//                       rows outside a row range -> the page's zero row) and the PageDev array describing the buffer;
+//                       then the rows themselves, read from the index file -- whose mapping is registered with HIP, so
+//                       the loads go over PCIe straight from the page cache, 16 bytes per lane, a row's pieces on
+//                       consecutive lanes (1 KiB per wave-load) -- into the buffer, laid out like a resident chunk (same
+//                       pitch, a zero row behind every page's rows).  K2 then scans it with the code it runs on resident
+//                       data.  [Rounds 3-4 gave every table entry a slot: (entries + 1) x pitch bytes per page, which a
+//                       256 MiB stream buffer does not hold for 256 queries.  Packed, the gathered rows fit whenever
+//                       they are fewer bytes than the chunk -- which is when they are fetched at all.]
 //
 // A row looked up twice is fetched twice: the engine chooses this path only when the batch's lookups are a
-// fraction of the sub-index's rows (engine.cpp: run_impl), where repeats are rare.
+// fraction of the chunk's rows (pass.cpp: run_impl), where repeats are rare.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 
 #include "device_types.hpp"
@@ -49,51 +58,127 @@ __device__ __forceinline__ uint4 load16_any(const uint8_t* p, uint32_t nvalid) {
     return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
-template <typename IdxT>
-__global__ __launch_bounds__(256) void fetch_rows_kernel(FetchArgs a) {
-    const uint32_t cpp = a.pitch / 16u;
-    const uint64_t E = a.entries;
-    const uint64_t rows = (uint64_t)a.npages * (E + 1u);   // every page: its E gathered rows, then its zero row
-    const uint64_t gid = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    const uint64_t rowno = gid / cpp;                      // page-major gathered row
-    const uint32_t c = (uint32_t)(gid - rowno * cpp);
-    if (rowno >= rows) return;
-    uint8_t* out = a.dst + rowno * a.pitch + (uint64_t)c * 16u;
-    const uint32_t i = (uint32_t)(rowno / (E + 1u));       // page of the chunk
-    const uint64_t n = rowno - (uint64_t)i * (E + 1u);     // entry of that page: [query][block + padding block][hash][8]
-    if (n == E) {                                          // the page's zero row: what its padding entries point at
-        *reinterpret_cast<uint4*>(out) = make_uint4(0u, 0u, 0u, 0u);
-        return;
-    }
-    const PageDev pd = a.pages[i];
-    if (n == 0u && c == 0u) {                              // the page as the gathered buffer holds it
-        PageDev g = pd;
-        g.base = (uint64_t)i * (E + 1u) * a.pitch;
-        g.sig = E;
-        g.row0 = 0;
-        a.pages2[i] = g;
-    }
-    const uint64_t per = 8ull * a.num_hashes;
-    // query of entry n: the last q with (blk_off[q] + q) * per <= n
-    uint32_t lo = 0, hi = a.nq;
+// query of table entry n of ONE sub-index ([query][block + padding block][hash][8]): the last q with (blk_off[q] + q) * per <= n
+__device__ __forceinline__ uint32_t query_of_entry(const uint64_t* blk_off, uint32_t nq, uint64_t per, uint64_t n) {
+    uint32_t lo = 0, hi = nq;
     while (hi - lo > 1u) {
         const uint32_t mid = (lo + hi) >> 1;
-        if ((a.blk_off[mid] + mid) * per <= n) lo = mid; else hi = mid;
+        if ((blk_off[mid] + mid) * per <= n) lo = mid; else hi = mid;
     }
-    const uint64_t b0 = a.blk_off[lo];
-    const uint64_t nblk1 = a.blk_off[lo + 1] - b0 + 1u;   // blocks of the query incl. its padding block
-    const uint64_t within = n - (b0 + lo) * per;
-    const uint64_t e = ((b0 + lo) * a.table_npages + (uint64_t)pd.tpage * nblk1) * per + within;
-    // (a row-range chunk holds rows [row0, row0 + sig) of its sub-index: a row outside it -- and K1's padding row S_p,
-    // which lies beyond every range -- reads as the zero row; page_src points at the range's first row)
-    const uint64_t r = (uint64_t)reinterpret_cast<const IdxT*>(a.table)[e] - pd.row0;
-    const bool pad = r >= pd.sig;                          // K1 points padded terms at row S_p
-    if (c == 0u)
-        reinterpret_cast<IdxT*>(a.table2)[e] = (IdxT)(pad ? E : n);     // (several slices of one sub-index share these entries)
-    if (pad) return;                                       // never read: its table entry names the zero row
-    const uint32_t nvalid = pd.valid_bytes > c * 16u ? min(pd.valid_bytes - c * 16u, 16u) : 0u;   // slices of one pitch may differ in width
+    return lo;
+}
+
+// How many rows does the batch look up in every streamed piece of the file?  One thread per table entry of the part
+// (all sub-indexes); an LDS histogram per work-group when there are few counters, one 64-bit atomic per non-empty bin.
+constexpr uint32_t kCountLds = 2048;
+template <typename IdxT>
+__global__ __launch_bounds__(256) void count_rows_kernel(CountArgs a, uint64_t total) {
+    __shared__ uint32_t h[kCountLds];
+    const bool lds = a.ncounters <= kCountLds;
+    if (lds) {
+        for (uint32_t i = threadIdx.x; i < a.ncounters; i += 256u) h[i] = 0u;
+        __syncthreads();
+    }
+    const uint64_t per = 8ull * a.num_hashes;
+    for (uint64_t g = (uint64_t)blockIdx.x * 256u + threadIdx.x; g < total; g += (uint64_t)gridDim.x * 256u) {
+        // entry g of the whole table: [query][sub-index][block + padding block][hash][8]
+        const uint64_t perq = per * a.table_npages;
+        uint32_t lo = 0, hi = a.nq;
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((a.blk_off[mid] + mid) * perq <= g) lo = mid; else hi = mid;
+        }
+        const uint64_t nblk1 = a.blk_off[lo + 1] - a.blk_off[lo] + 1u;
+        const uint64_t within = g - (a.blk_off[lo] + lo) * perq;
+        const uint32_t p = (uint32_t)(within / (nblk1 * per));
+        const CountPage cp = a.cpages[p];
+        if (cp.first == 0xFFFFFFFFu) continue;
+        const uint64_t r = (uint64_t)reinterpret_cast<const IdxT*>(a.table)[g];
+        if (r >= a.tpages[p].sig) continue;               // K1 points padded terms at row S_p
+        uint32_t k = cp.first;
+        if (cp.per) {
+            const uint64_t i = r / cp.per;
+            k += (uint32_t)(i < cp.n ? i : cp.n - 1u);
+        }
+        if (lds) atomicAdd(&h[k], 1u);
+        else atomicAdd(&a.counts[k], 1ull);
+    }
+    if (lds) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < a.ncounters; i += 256u)
+            if (h[i]) atomicAdd(&a.counts[i], (unsigned long long)h[i]);
+    }
+}
+
+// Slots of the gathered buffer for exactly the looked-up rows of a unit's pages.  grid.y = page (leaders only do work),
+// grid.x over the table entries of its sub-index; a wave's lanes belong to one page: one atomic per wave.
+template <typename IdxT>
+__global__ __launch_bounds__(256) void gather_assign_kernel(GatherArgs a) {
+    const uint32_t i = blockIdx.y;
+    const GatherPage pg = a.pages[i];
+    if (pg.leader != i) return;
+    const uint64_t n = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint64_t per = 8ull * a.num_hashes;
+    bool in = false;
+    uint64_t e = 0, r = 0;
+    if (n < a.entries) {
+        const uint32_t q = query_of_entry(a.blk_off, a.nq, per, n);
+        const uint64_t b0 = a.blk_off[q];
+        const uint64_t nblk1 = a.blk_off[q + 1] - b0 + 1u;
+        e = ((b0 + q) * a.table_npages + (uint64_t)pg.tpage * nblk1) * per + (n - (b0 + q) * per);
+        // (a row outside the page's range -- and K1's padding row S_p, which lies beyond every range -- is not gathered:
+        // its entry names the page's zero row)
+        r = (uint64_t)reinterpret_cast<const IdxT*>(a.table)[e] - pg.row0;
+        in = r < pg.nrows;
+    }
+    const unsigned long long mask = __ballot(in);
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long base = 0;
+    if (mask) {
+        const uint32_t first = (uint32_t)__ffsll((long long)mask) - 1u;
+        if (lane == first) base = atomicAdd(&a.cursor[i], (unsigned long long)__popcll(mask));
+        base = __shfl(base, (int)first);
+    }
+    if (n >= a.entries) return;
+    const uint64_t slot = base + (uint64_t)__popcll(mask & ((1ull << lane) - 1ull));
+    reinterpret_cast<IdxT*>(a.table2)[e] = (IdxT)(in ? slot : (uint64_t)pg.count);
+    if (in && slot < pg.count) a.rowlist[pg.slot0 + slot] = r;      // (slot < count always: the counts are exact, or a bound)
+}
+
+// One thread per (gathered row, 16-byte piece): the row's pieces on consecutive lanes, read over PCIe straight from the
+// registered mapping of the index file (unaligned sources -- classic rows at odd file offsets -- through aligned dwords).
+__global__ __launch_bounds__(256) void gather_copy_kernel(GatherArgs a) {
+    const uint32_t cpp = a.pitch / 16u;
+    const uint64_t gid = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint64_t g = gid / cpp;                          // gathered row
+    const uint32_t c = (uint32_t)(gid - g * cpp);
+    if (g >= a.total_rows) return;
+    uint32_t lo = 0, hi = a.npages;                        // its page: the last i with slot0[i] <= g
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a.pages[mid].slot0 <= g) lo = mid; else hi = mid;
+    }
+    const GatherPage pg = a.pages[lo];
+    const uint64_t local = g - pg.slot0;
+    uint8_t* out = a.dst + g * a.pitch + (uint64_t)c * 16u;
+    if (local == 0u && c == 0u) {                          // the page as the gathered buffer holds it
+        PageDev d = a.pages_in[lo];
+        d.base = pg.slot0 * a.pitch;
+        d.sig = pg.count;
+        d.magic = 0;
+        d.row0 = 0;
+        a.pages2[lo] = d;
+    }
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (nvalid) v = load16_any(a.file + a.page_src[i] + r * a.src_pitch + (uint64_t)c * 16u, nvalid);
+    // rows [0, handed-out slots) are gathered rows, row `count` is the page's zero row; with exact counts the two meet,
+    // with a capacity per page (small batches: a place for every table entry) the rows in between are never named
+    const uint64_t have = a.cursor[pg.leader];
+    if (local != pg.count && local >= have) return;
+    if (local < have && local < pg.count) {
+        const uint64_t r = a.rowlist[a.pages[pg.leader].slot0 + local];
+        const uint32_t nvalid = pg.valid_bytes > c * 16u ? min(pg.valid_bytes - c * 16u, 16u) : 0u;
+        if (nvalid) v = load16_any(a.file + pg.src + r * a.src_pitch + (uint64_t)c * 16u, nvalid);
+    }
     *reinterpret_cast<uint4*>(out) = v;
 }
 
@@ -165,13 +250,24 @@ hipError_t launch_add_scores(const AddScoresArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_fetch_rows(const FetchArgs& a, bool idx64, hipStream_t stream) {
+hipError_t launch_count_rows(const CountArgs& a, uint64_t total_entries, bool idx64, hipStream_t stream) {
+    if (total_entries == 0 || a.nq == 0 || a.ncounters == 0) return hipSuccess;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((total_entries + 255u) / 256u, 8192u);
+    if (idx64) hipLaunchKernelGGL(count_rows_kernel<uint64_t>, dim3(blocks), dim3(256), 0, stream, a, total_entries);
+    else hipLaunchKernelGGL(count_rows_kernel<uint32_t>, dim3(blocks), dim3(256), 0, stream, a, total_entries);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather(const GatherArgs& a, bool idx64, hipStream_t stream) {
     if (a.npages == 0 || a.nq == 0 || a.entries == 0) return hipSuccess;
-    const uint64_t items = (uint64_t)a.npages * (a.entries + 1u) * (a.pitch / 16u);
-    const uint64_t blocks = (items + 255u) / 256u;
-    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    if (idx64) hipLaunchKernelGGL(fetch_rows_kernel<uint64_t>, dim3((uint32_t)blocks), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(fetch_rows_kernel<uint32_t>, dim3((uint32_t)blocks), dim3(256), 0, stream, a);
+    const uint64_t ablocks = (a.entries + 255u) / 256u;
+    const uint64_t items = a.total_rows * (a.pitch / 16u);
+    const uint64_t cblocks = (items + 255u) / 256u;
+    if (ablocks > 0x7FFFFFFFull || cblocks > 0x7FFFFFFFull || a.npages > 65535u) return hipErrorInvalidValue;
+    const dim3 agrid((uint32_t)ablocks, a.npages);
+    if (idx64) hipLaunchKernelGGL(gather_assign_kernel<uint64_t>, agrid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(gather_assign_kernel<uint32_t>, agrid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(gather_copy_kernel, dim3((uint32_t)cblocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

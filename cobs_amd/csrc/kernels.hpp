@@ -35,7 +35,10 @@ hipError_t launch_rank(const RankArgs& a, bool first, bool last, hipStream_t str
 hipError_t launch_score_hist(const HistArgs& a, hipStream_t stream);
 
 // Row-selective out-of-core access (fetch_kernels.hip): one thread per (looked-up row, 16-byte piece).
-hipError_t launch_fetch_rows(const FetchArgs& a, bool idx64, hipStream_t stream);
+// count_rows: how many rows the batch looks up in every streamed piece of a part (one counter per piece);
+// gather: slots for exactly those rows of a unit's pages (gather_assign_kernel), then the rows themselves (gather_copy_kernel).
+hipError_t launch_count_rows(const CountArgs& a, uint64_t total_entries, bool idx64, hipStream_t stream);
+hipError_t launch_gather(const GatherArgs& a, bool idx64, hipStream_t stream);
 // Row-range chunks of a streamed sub-index (fetch_kernels.hip): rewrite the `entries` row indices of one sub-index for
 // the rows a chunk holds; add a chunk's partial scores to the score rows.
 hipError_t launch_remap_rows(const RemapArgs& a, uint64_t entries, bool idx64, hipStream_t stream);

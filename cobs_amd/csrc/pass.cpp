@@ -38,14 +38,6 @@ uint64_t total_hashes(const cobs_gpu_batch* b, size_t q) {
     return n;
 }
 
-// bytes a row-selective fetch of chunk `c` moves over PCIe: the gathered rows -- of a ROW-RANGE chunk only the share
-// of the sub-index's lookups that falls into its range (the gathered buffer still has a place for every entry)
-uint64_t fetched_bytes(const Part& p, const Chunk& c, uint64_t gathered) {
-    if (!c.row_range || c.vp.empty()) return gathered;
-    const uint64_t sig = p.meta.signature_sizes[c.vp[0].fp];
-    return (uint64_t)((long double)gathered * (long double)c.pages[0].sig / (long double)std::max<uint64_t>(sig, 1));
-}
-
 uint32_t threshold_for(double threshold, uint64_t terms) {
     // classic_search.cpp:446-448: std::ceil(threshold * T) in double
     const double v = std::ceil(threshold * (double)terms);
@@ -332,28 +324,126 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
         for (size_t f = 0; f < ix->parts.size(); ++f)
             if (nq) HIP_TRY(hipMemcpyAsync(b->work[f].thr.p, b->h_thr_stage.p + f * nq, 4 * nq, hipMemcpyHostToDevice, st));
     }
+    std::vector<std::vector<bool>> fetch_unit(ix->parts.size());
+    hipEvent_t* ev = b->ev[b->run_seq % cobs_gpu_batch::kRing];
+    b->ev_split[b->run_seq % cobs_gpu_batch::kRing] = split;
+    HIP_TRY(hipEventRecord(ev[0], hs));
+    StreamBufs& sbufs = ix->stream;
+    // ---- K1 once per file and pass: the row-index table covers every held sub-index, the chunks (launches) of the file
+    // pick their sub-indexes by PageDev::tpage.  All files first: what a streamed file's pass looks like -- which of its
+    // chunks are copied whole, which are fetched row by row -- is decided from what the batch LOOKS UP (below).
+    std::vector<uint64_t> cnt_off(ix->parts.size() + 1, 0);
+    // (a SMALL batch needs no counting: if every streamed chunk is fetched by rows even when every table entry is given a
+    // slot -- E rows per page, the round-3 layout -- that bound is used as the pages' capacity and the pass has no host
+    // synchronisation before its scans: a single query against the 18.4 GB file)
+    std::vector<bool> by_bound(ix->parts.size(), false);
+    for (size_t f = 0; f < ix->parts.size(); ++f) {
+        const Part& p = ix->parts[f];
+        bool counted = nq && ix->tune.row_fetch != 0 && p.streamed && p.file_dev && !p.synthetic && p.ncounters;
+        if (counted) {
+            const uint64_t E = (b->work[f].h_blk_off[nq] + nq) * 8ull * p.meta.num_hashes;
+            auto fits = [&](const Chunk& c) {
+                const uint64_t rows = E * c.vp.size();
+                return c.fetch_ok && !c.resident && E < 0xFFFFFFF0ull && (rows + c.vp.size()) * (uint64_t)c.pitch <= sbufs.sbuf[0].cap &&
+                       rows * (uint64_t)c.pitch * ix->tune.row_fetch_alpha <= c.bytes;
+            };
+            bool all = true;
+            for (const Chunk& c : p.chunks) all = all && (c.resident || fits(c));
+            for (const Chunk& g : p.fetch_groups) all = all && fits(g);
+            if (all) { by_bound[f] = true; counted = false; }
+        }
+        cnt_off[f + 1] = cnt_off[f] + (counted ? p.ncounters : 0);
+    }
+    if (cnt_off.back()) {
+        HIP_TRY(sbufs.d_counts.reserve((size_t)cnt_off.back()));
+        HIP_TRY(sbufs.h_counts.reserve((size_t)cnt_off.back()));
+        HIP_TRY(hipMemsetAsync(sbufs.d_counts.p, 0, (size_t)cnt_off.back() * sizeof(unsigned long long), hs));
+    }
+    for (size_t f = 0; f < ix->parts.size(); ++f) {
+        Part& p = ix->parts[f];
+        if (nq == 0 || p.chunks.empty()) continue;
+        HashArgs ha;
+        ha.text = b->d_text;
+        ha.span_off = b->d_span_off;
+        ha.q_len = b->d_qlen;
+        ha.blk_off = b->work[f].blk_off;
+        ha.pages = p.d_tpages;
+        ha.table = b->work[f].table.p;
+        ha.err_query = b->flags.p;
+        ha.nq = (uint32_t)nq;
+        ha.npages = p.num_tpages();
+        ha.term_size = p.meta.term_size;
+        ha.canonicalize = p.meta.canonicalize;
+        ha.num_hashes = (uint32_t)p.meta.num_hashes;
+        ha.idx64 = p.idx64 ? 1u : 0u;
+        // (the kernel bounds itself by span_off[nq] on the device; the grid is rounded up so that a
+        // captured launch serves every batch of its shape class)
+        HIP_TRY(launch_hash(ha, round_up(b->span_off[nq], 1024), hs));
+        if (cnt_off[f + 1] > cnt_off[f]) {
+            // how many rows the batch looks up in every streamed piece of this file (one counter per whole slice / row range)
+            CountArgs ca;
+            ca.table = b->work[f].table.p;
+            ca.blk_off = b->work[f].blk_off;
+            ca.tpages = p.d_tpages;
+            ca.cpages = p.d_cpages;
+            ca.counts = sbufs.d_counts.p + cnt_off[f];
+            ca.nq = (uint32_t)nq;
+            ca.table_npages = p.num_tpages();
+            ca.num_hashes = (uint32_t)p.meta.num_hashes;
+            ca.ncounters = p.ncounters;
+            const uint64_t total = (b->work[f].h_blk_off[nq] + nq) * 8ull * p.meta.num_hashes * p.num_tpages();
+            HIP_TRY(launch_count_rows(ca, total, p.idx64, hs));
+        }
+    }
+    HIP_TRY(hipEventRecord(ev[1], hs));          // K1 / K2 split of the timing events
+    if (cnt_off.back()) {
+        HIP_TRY(hipMemcpyAsync(sbufs.h_counts.p, sbufs.d_counts.p, (size_t)cnt_off.back() * sizeof(unsigned long long),
+                               hipMemcpyDeviceToHost, hs));
+        HIP_TRY(hipStreamSynchronize(hs));       // (an out-of-core pass waits for its stream buffers anyway)
+    }
+    bool scan_marked = false;
+    if (split && nq) {       // the K2 launches wait for the tables (and for the flags fill)
+        HIP_TRY(hipEventRecord(b->hashed, hs));
+        HIP_TRY(hipStreamWaitEvent(st, b->hashed, 0));
+        HIP_TRY(hipEventRecord(ev[3], st));
+        scan_marked = true;
+    }
     // scan geometry of every (file, chunk); with tile-level top-k also the files' places in the candidate pool
     std::vector<std::vector<ScanGeom>> geoms(ix->parts.size());
     std::vector<uint64_t> cand_off(ix->parts.size() + 1, 0);
     std::vector<uint32_t> cand_tiles(ix->parts.size(), 0), cand_stride(ix->parts.size(), 0);
-    // the units of a file's pass: its chunks -- or, for a streamed file of which this batch would fetch EVERY chunk
-    // by rows, the chunks of equal pitch merged (one fetch + one scan per pitch: a single query against a file of ten
-    // chunks is 2-3 launch pairs instead of ten)
+    // the units of a file's pass: its chunks -- or, for a streamed file of which this batch fetches EVERY streamed chunk
+    // by rows, the runs of chunks of equal pitch merged (one gather + one scan per run: a single query against a file
+    // of fifty chunks is a handful of launch pairs)
     std::vector<std::vector<const Chunk*>> units(ix->parts.size());
-    std::vector<bool> grouped(ix->parts.size(), false);
+    // rows a row-selective fetch of unit `c` gathers (EXACT: counted on the device right after K1) and what they occupy
+    auto looked_up_rows = [&](size_t f, const Chunk& c) {
+        if (by_bound[f]) return (uint64_t)((b->work[f].h_blk_off[nq] + nq) * 8ull * ix->parts[f].meta.num_hashes * c.vp.size());
+        uint64_t n = 0;
+        for (const auto& cp : c.cp)
+            for (uint32_t k = 0; k < cp.second; ++k) n += sbufs.h_counts.p[cnt_off[f] + cp.first + k];
+        return n;
+    };
     for (size_t f = 0; f < ix->parts.size() && nq; ++f) {
         const Part& p = ix->parts[f];
         const uint64_t E = (b->work[f].h_blk_off[nq] + nq) * 8ull * p.meta.num_hashes;
+        // Whole chunk, or only the rows this batch looks up?  Fetching them moves (looked-up rows) x pitch bytes over PCIe
+        // at the rate random rows come in, copying the chunk moves all of its rows at the slab rate (row_fetch_alpha
+        // prices the difference); the gathered rows must fit a stream buffer -- they always do when they are fewer
+        // bytes than the chunk, whatever the buffers' size: the gather packs exactly the looked-up rows (round 5;
+        // until then the buffer had a place for every table entry, which 256 MiB buffers do not hold for 256 queries).
+        // The reference's mmap / AIO back-ends always take the first form (compact_index/mmap_search_file.cpp:34-67,
+        // aio_search_file.cpp:58-97).
         auto fetchable = [&](const Chunk& c) {
-            const uint64_t gathered = (E + 1) * c.vp.size() * (uint64_t)c.pitch;
-            return ix->tune.row_fetch != 0 && p.streamed && p.file_dev && c.d_src && !p.synthetic &&
-                   gathered <= ix->stream.sbuf[0].cap && E < 0xFFFFFFF0ull &&
-                   fetched_bytes(p, c, gathered) * ix->tune.row_fetch_alpha <= c.bytes;
+            if (!(cnt_off[f + 1] > cnt_off[f] || by_bound[f]) || !c.fetch_ok || c.resident || E >= 0xFFFFFFF0ull) return false;
+            const uint64_t rows = looked_up_rows(f, c);
+            const uint64_t gathered = (rows + c.vp.size()) * (uint64_t)c.pitch;
+            return gathered <= sbufs.sbuf[0].cap && rows * (uint64_t)c.pitch * ix->tune.row_fetch_alpha <= c.bytes &&
+                   rows < 0xFFFFFFF0ull;
         };
         bool all = !p.fetch_groups.empty();
-        for (const Chunk& c : p.chunks) all = all && (c.resident || c.row_range || fetchable(c));    // (row ranges: their sub-index is one unit of the groups)
+        for (const Chunk& c : p.chunks) all = all && (c.resident || fetchable(c));
         for (const Chunk& g : p.fetch_groups) all = all && fetchable(g);
-        grouped[f] = all;
         if (!all) {
             for (const Chunk& c : p.chunks) units[f].push_back(&c);
         } else {
@@ -364,6 +454,8 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                 else if (gi < p.fetch_groups.size() && p.fetch_groups[gi].first_chunk == ci) units[f].push_back(&p.fetch_groups[gi++]);
             }
         }
+        fetch_unit[f].resize(units[f].size());
+        for (size_t u = 0; u < units[f].size(); ++u) fetch_unit[f][u] = fetchable(*units[f][u]);
     }
     for (size_t f = 0; f < ix->parts.size() && nq; ++f) {
         const Part& p = ix->parts[f];
@@ -387,47 +479,10 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
             HIP_TRY(b->counts.reserve((size_t)(nq * ix->local_counts * b->elem_bytes)));
         }
     }
-    hipEvent_t* ev = b->ev[b->run_seq % cobs_gpu_batch::kRing];
-    b->ev_split[b->run_seq % cobs_gpu_batch::kRing] = split;
-    HIP_TRY(hipEventRecord(ev[0], hs));
-    bool hash_marked = false, scan_marked = false;
     uint64_t launches = 0;
-    StreamBufs& sbufs = ix->stream;
     for (size_t f = 0; f < ix->parts.size(); ++f) {
         Part& p = ix->parts[f];
         if (nq == 0 || p.chunks.empty() || units[f].empty()) continue;
-        {   // K1 once per file and pass: the row-index table covers every held sub-index,
-            // the chunks (launches) of the file pick their sub-indexes by PageDev::tpage
-            HashArgs ha;
-            ha.text = b->d_text;
-            ha.span_off = b->d_span_off;
-            ha.q_len = b->d_qlen;
-            ha.blk_off = b->work[f].blk_off;
-            ha.pages = p.d_tpages;
-            ha.table = b->work[f].table.p;
-            ha.err_query = b->flags.p;
-            ha.nq = (uint32_t)nq;
-            ha.npages = p.num_tpages();
-            ha.term_size = p.meta.term_size;
-            ha.canonicalize = p.meta.canonicalize;
-            ha.num_hashes = (uint32_t)p.meta.num_hashes;
-            ha.idx64 = p.idx64 ? 1u : 0u;
-            // (the kernel bounds itself by span_off[nq] on the device; the grid is rounded up so that a
-            // captured launch serves every batch of its shape class)
-            HIP_TRY(launch_hash(ha, round_up(b->span_off[nq], 1024), hs));
-            if (!hash_marked) {      // K1 / K2 split of the timing events: first file only
-                HIP_TRY(hipEventRecord(ev[1], hs));
-                hash_marked = true;
-            }
-            if (split) {             // this file's K2 launches wait for its table (and, the first time, for the flags fill)
-                HIP_TRY(hipEventRecord(b->hashed, hs));
-                HIP_TRY(hipStreamWaitEvent(st, b->hashed, 0));
-                if (!scan_marked) {
-                    HIP_TRY(hipEventRecord(ev[3], st));
-                    scan_marked = true;
-                }
-            }
-        }
         uint32_t tile_base = 0;
         bool fetch_ready = false;
         if (p.streamed && ((p.file_dev && ix->tune.row_fetch != 0) || p.has_row_ranges)) {
@@ -455,45 +510,63 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                 // whose last scan is done
                 buf = (int)(sbufs.seq++ & 1);
                 if (sbufs.used[buf]) HIP_TRY(hipEventSynchronize(sbufs.scanned[buf]));
-                // Whole chunk, or only the rows this batch looks up?  The table holds E entries per sub-index;
-                // fetching them row by row moves E x (slices) x pitch bytes over PCIe at the rate random rows
-                // come in, copying the chunk moves all of its rows at the slab rate (row_fetch_alpha prices
-                // the difference).  The reference's mmap / AIO back-ends always take the first form
-                // (compact_index/mmap_search_file.cpp:34-67, aio_search_file.cpp:58-97).
                 const uint64_t E = (b->work[f].h_blk_off[nq] + nq) * 8ull * p.meta.num_hashes;
-                const uint64_t gathered = (E + 1) * c.vp.size() * (uint64_t)c.pitch;
-                const bool fetch = grouped[f] ||
-                                   (ix->tune.row_fetch != 0 && p.file_dev && c.d_src && !p.synthetic &&
-                                    gathered <= sbufs.sbuf[buf].cap && E < 0xFFFFFFF0ull &&
-                                    fetched_bytes(p, c, gathered) * ix->tune.row_fetch_alpha <= c.bytes);
+                const bool fetch = fetch_unit[f][ci];
                 if (fetch) {
-                    if (!fetch_ready) {          // the fetch kernel reads K1's table: once per file and pass
+                    if (!fetch_ready) {          // the gather reads K1's table: once per file and pass
                         HIP_TRY(hipEventRecord(sbufs.hashed, st));
                         HIP_TRY(hipStreamWaitEvent(sbufs.copy_stream, sbufs.hashed, 0));
                         fetch_ready = true;
                     }
-                    FetchArgs fa;
-                    fa.file = p.file_dev;
-                    fa.table = b->work[f].table.p;
-                    fa.table2 = sbufs.table2[buf].p;
-                    fa.blk_off = b->work[f].blk_off;
-                    fa.pages = pages_dev;               // (a later row range: the page with slot0 = 0, see `partial`)
-                    fa.pages2 = c.d_pages2[buf];
-                    fa.page_src = c.d_src;
-                    fa.dst = sbufs.sbuf[buf].p;
-                    fa.entries = E;
-                    fa.src_pitch = p.meta.page_row_bytes();
-                    fa.nq = (uint32_t)nq;
-                    fa.npages = (uint32_t)c.vp.size();
-                    fa.table_npages = p.num_tpages();
-                    fa.num_hashes = (uint32_t)p.meta.num_hashes;
-                    fa.pitch = c.pitch;
-                    fa.ncols = (uint32_t)c.vp[0].ncols;
-                    HIP_TRY(launch_fetch_rows(fa, p.idx64, sbufs.copy_stream));
+                    // the unit's pages as the gather sees them: exactly the looked-up rows of each, packed, a zero row behind
+                    const size_t np = c.vp.size();
+                    HIP_TRY(sbufs.h_gpages[buf].reserve(np));
+                    HIP_TRY(sbufs.gpages[buf].reserve(np));
+                    HIP_TRY(sbufs.cursor[buf].reserve(np));
+                    GatherPage* gp = sbufs.h_gpages[buf].p;
+                    uint64_t slot = 0;
+                    for (size_t k = 0; k < np; ++k) {
+                        uint64_t cnt = by_bound[f] ? E : 0;       // (no count: a place for every table entry)
+                        for (uint32_t j = 0; j < c.cp[k].second && !by_bound[f]; ++j) cnt += sbufs.h_counts.p[cnt_off[f] + c.cp[k].first + j];
+                        gp[k].src = c.src[k];
+                        gp[k].row0 = c.pages[k].row0;
+                        gp[k].nrows = c.pages[k].sig;
+                        gp[k].slot0 = slot;
+                        gp[k].count = (uint32_t)cnt;
+                        gp[k].tpage = c.pages[k].tpage;
+                        gp[k].leader = (uint32_t)k;
+                        for (size_t j = 0; j < k; ++j)       // column slices of one sub-index share the row list of the first
+                            if (gp[j].tpage == gp[k].tpage && gp[j].row0 == gp[k].row0) { gp[k].leader = (uint32_t)j; break; }
+                        gp[k].valid_bytes = c.pages[k].valid_bytes;
+                        slot += cnt + 1;
+                    }
+                    HIP_TRY(sbufs.rowlist[buf].reserve((size_t)slot));
+                    HIP_TRY(hipMemcpyAsync(sbufs.gpages[buf].p, gp, np * sizeof(GatherPage), hipMemcpyHostToDevice, sbufs.copy_stream));
+                    HIP_TRY(hipMemsetAsync(sbufs.cursor[buf].p, 0, np * sizeof(unsigned long long), sbufs.copy_stream));
+                    GatherArgs ga;
+                    ga.file = p.file_dev;
+                    ga.table = b->work[f].table.p;
+                    ga.table2 = sbufs.table2[buf].p;
+                    ga.blk_off = b->work[f].blk_off;
+                    ga.pages = sbufs.gpages[buf].p;
+                    ga.pages_in = pages_dev;            // (a later row range: the page with slot0 = 0, see `partial`)
+                    ga.pages2 = c.d_pages2[buf];
+                    ga.dst = sbufs.sbuf[buf].p;
+                    ga.rowlist = sbufs.rowlist[buf].p;
+                    ga.cursor = sbufs.cursor[buf].p;
+                    ga.entries = E;
+                    ga.total_rows = slot;
+                    ga.src_pitch = p.meta.page_row_bytes();
+                    ga.nq = (uint32_t)nq;
+                    ga.npages = (uint32_t)np;
+                    ga.table_npages = p.num_tpages();
+                    ga.num_hashes = (uint32_t)p.meta.num_hashes;
+                    ga.pitch = c.pitch;
+                    HIP_TRY(launch_gather(ga, p.idx64, sbufs.copy_stream));
                     pages_dev = c.d_pages2[buf];
                     table_dev = sbufs.table2[buf].p;
                     ++sbufs.fetched_chunks;
-                    sbufs.fetched_bytes += fetched_bytes(p, c, gathered);
+                    sbufs.fetched_bytes += (slot - np) * (uint64_t)c.pitch;
                 } else {
                     cobs_gpu_status cs = stream_chunk_in(ix, p, c, buf);
                     if (cs != COBS_GPU_OK) return cs;
@@ -601,7 +674,6 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
             }
         }
     }
-    if (!hash_marked) HIP_TRY(hipEventRecord(ev[1], hs));
     if (split && !scan_marked) {         // (no file launched anything: keep the flags fill ordered before the caller's stream)
         HIP_TRY(hipEventRecord(b->hashed, hs));
         HIP_TRY(hipStreamWaitEvent(st, b->hashed, 0));
