@@ -325,6 +325,7 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
             if (nq) HIP_TRY(hipMemcpyAsync(b->work[f].thr.p, b->h_thr_stage.p + f * nq, 4 * nq, hipMemcpyHostToDevice, st));
     }
     std::vector<std::vector<bool>> fetch_unit(ix->parts.size());
+    std::vector<std::vector<uint32_t>> unit_merge(ix->parts.size());     // row ranges of one sub-index merged into the unit (>= 1)
     hipEvent_t* ev = b->ev[b->run_seq % cobs_gpu_batch::kRing];
     b->ev_split[b->run_seq % cobs_gpu_batch::kRing] = split;
     HIP_TRY(hipEventRecord(ev[0], hs));
@@ -445,7 +446,28 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
         for (const Chunk& c : p.chunks) all = all && (c.resident || fetchable(c));
         for (const Chunk& g : p.fetch_groups) all = all && fetchable(g);
         if (!all) {
-            for (const Chunk& c : p.chunks) units[f].push_back(&c);
+            // Consecutive ROW RANGES of one sub-index that are all fetched by rows share a gather and a scan while their
+            // looked-up rows fit a stream buffer together: a range's scan walks every term of every query whatever the
+            // range holds (terms outside it read the zero row), so 234 ranges of a 62 GB sub-index would be 234 full scans
+            // for 15.7 GB of looked-up rows -- merged, 59.
+            for (size_t ci = 0; ci < p.chunks.size();) {
+                const Chunk& c = p.chunks[ci];
+                uint32_t m = 1;
+                if (c.row_range && fetchable(c)) {
+                    uint64_t rows = looked_up_rows(f, c);
+                    while (ci + m < p.chunks.size()) {
+                        const Chunk& d = p.chunks[ci + m];
+                        if (!d.row_range || d.vp[0].fp != c.vp[0].fp || d.range_no != c.range_no + m || !fetchable(d)) break;
+                        const uint64_t more = looked_up_rows(f, d);
+                        if ((rows + more + 1) * (uint64_t)c.pitch > sbufs.sbuf[0].cap || rows + more >= 0xFFFFFFF0ull) break;
+                        rows += more;
+                        ++m;
+                    }
+                }
+                units[f].push_back(&c);
+                unit_merge[f].push_back(m);
+                ci += m;
+            }
         } else {
             // resident chunks where they lie, every run of streamed chunks as its fetch group -- in chunk (= document) order
             size_t gi = 0;
@@ -454,6 +476,7 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                 else if (gi < p.fetch_groups.size() && p.fetch_groups[gi].first_chunk == ci) units[f].push_back(&p.fetch_groups[gi++]);
             }
         }
+        unit_merge[f].resize(units[f].size(), 1u);
         fetch_unit[f].resize(units[f].size());
         for (size_t u = 0; u < units[f].size(); ++u) fetch_unit[f][u] = fetchable(*units[f][u]);
     }
@@ -531,6 +554,11 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                         gp[k].src = c.src[k];
                         gp[k].row0 = c.pages[k].row0;
                         gp[k].nrows = c.pages[k].sig;
+                        for (uint32_t m = 1; m < unit_merge[f][ci]; ++m) {      // (merged row ranges: one page, k == 0)
+                            const Chunk& d = (&c)[m];
+                            gp[k].nrows += d.pages[0].sig;
+                            cnt += sbufs.h_counts.p[cnt_off[f] + d.cp[0].first];
+                        }
                         gp[k].slot0 = slot;
                         gp[k].count = (uint32_t)cnt;
                         gp[k].tpage = c.pages[k].tpage;

@@ -335,3 +335,46 @@ def test_topk_ties_across_fetch_units_keep_document_order(gpu_lib, oracle, tmp_p
         if alpha == 0:
             assert s.stream_counters()[0] > 0 and s.stream_counters()[1] == 0    # every pass fetched by rows
         del s
+
+
+def test_fetched_row_ranges_share_a_scan_and_any_buffer_size_fetches(gpu_lib, oracle, tmp_path, monkeypatch):
+    """round 5: the row-selective fetch packs exactly the looked-up rows (counted on the device right after K1), so a chunk
+    is fetched whenever its looked-up rows are fewer bytes than the chunk -- whatever the stream buffers' size -- and
+    consecutive row ranges of one sub-index that are fetched share one gather and one scan.  A file whose first sub-index
+    is small (a batch looks up more than it holds: copied whole) and whose second is cut into many ranges: the ranges'
+    lookups arrive in fewer units than there are ranges; counts, thresholds and limits equal the oracle's; with every chunk
+    copied whole the results are the same"""
+    monkeypatch.setenv("COBS_GPU_ROW_RANGE_MIN", "48")
+    ps = 96
+    D = 2 * 8 * ps - 3
+    q_long = oracle.random_sequence(900, 77)
+    path = cases.make_compact(cases.tmp(tmp_path, "mr.cobs_compact"), D, ps, [300, 60013], 1, 31, 1, 0.3, 5,
+                              planted={0: 1.0, 8 * ps + 3: 0.95, D - 1: 0.85}, query=q_long)
+    ix = oracle.Index.open(path)
+    monkeypatch.setenv("COBS_GPU_STREAM_BUF_KIB", "256")        # 256 KiB buffers: 60 013 rows of pitch 128 in ~30 ranges
+    s = gpu_lib.Search(path, hbm_budget=600 * 1024)
+    buf, kept, per_pass, nchunks = s.stream_plan()
+    assert nchunks >= 20 and buf <= 256 * 1024
+    queries = [q_long[i * 7:i * 7 + 400] for i in range(24)] + [q_long[:31], q_long]      # ~9 000 lookups per sub-index
+    f0, w0 = s.stream_counters()
+    for q in queries[:3] + queries[-2:]:
+        assert np.array_equal(s.counts(q), ix.counts(q))
+    b = gpu_lib.Batch(s)
+    b.set_queries(queries)
+    f0, w0 = s.stream_counters()
+    b.run(0.0)
+    b.sync()
+    f1, w1 = s.stream_counters()
+    for i, q in enumerate(queries):
+        assert np.array_equal(b.counts_host(i), ix.counts(q)), i
+    # the small sub-index whole (its 300 rows are looked up 9 000 times), the large one by rows -- in fewer units than ranges
+    assert w1 - w0 >= 1 and 1 <= f1 - f0 < nchunks - 1, (f1 - f0, w1 - w0, nchunks)
+    assert b.stats()["scan_launches"] < nchunks
+    for t, lim in ((0.0, 5), (0.5, 0), (0.9, 0), (0.0, 0)):
+        assert s.search_hits(queries, t, lim) == [cases.oracle_results([ix], q, t, lim) for q in queries], (t, lim)
+    s.set_tuning("row_fetch", 0)
+    b.run(0.0)
+    b.sync()
+    assert b.stats()["scan_launches"] >= nchunks
+    for i, q in enumerate(queries):
+        assert np.array_equal(b.counts_host(i), ix.counts(q)), i
