@@ -139,7 +139,7 @@ def test_random_budgets(gpu_lib, oracle, tmp_path, monkeypatch, no_pin):
         lim = int(rng.choice([0, 0, 5]))
         assert s.search_hits(queries, t, lim) == [cases.oracle_results([ix], q, t, lim) for q in queries], (path, budget, t, lim)
         done += 1
-    assert done >= 15 and n_mixed >= 5       # plans with resident AND streamed slices of one file were among them
+    assert done >= 15 and n_mixed >= 3       # plans with resident AND streamed slices of one file were among them
 
 
 def test_budget_is_shared_by_all_files_of_a_handle(gpu_lib, oracle, tmp_path):
@@ -341,7 +341,7 @@ def test_fetched_row_ranges_share_a_scan_and_any_buffer_size_fetches(gpu_lib, or
     """round 5: the row-selective fetch packs exactly the looked-up rows (counted on the device right after K1), so a chunk
     is fetched whenever its looked-up rows are fewer bytes than the chunk -- whatever the stream buffers' size -- and
     consecutive row ranges of one sub-index that are fetched share one gather and one scan.  A file whose first sub-index
-    is small (a batch looks up more than it holds: copied whole) and whose second is cut into many ranges: the ranges'
+    is small (it stays resident beside the stream buffers) and whose second is cut into many ranges: the ranges'
     lookups arrive in fewer units than there are ranges; counts, thresholds and limits equal the oracle's; with every chunk
     copied whole the results are the same"""
     monkeypatch.setenv("COBS_GPU_ROW_RANGE_MIN", "48")
@@ -367,8 +367,8 @@ def test_fetched_row_ranges_share_a_scan_and_any_buffer_size_fetches(gpu_lib, or
     f1, w1 = s.stream_counters()
     for i, q in enumerate(queries):
         assert np.array_equal(b.counts_host(i), ix.counts(q)), i
-    # the small sub-index whole (its 300 rows are looked up 9 000 times), the large one by rows -- in fewer units than ranges
-    assert w1 - w0 >= 1 and 1 <= f1 - f0 < nchunks - 1, (f1 - f0, w1 - w0, nchunks)
+    # the small sub-index stays resident beside the buffers; the large one comes in by rows -- in fewer units than it has ranges
+    assert kept > 0 and w1 - w0 == 0 and 1 <= f1 - f0 < nchunks - 1, (f1 - f0, w1 - w0, nchunks, kept)
     assert b.stats()["scan_launches"] < nchunks
     for t, lim in ((0.0, 5), (0.5, 0), (0.9, 0), (0.0, 0)):
         assert s.search_hits(queries, t, lim) == [cases.oracle_results([ix], q, t, lim) for q in queries], (t, lim)
