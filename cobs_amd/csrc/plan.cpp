@@ -388,7 +388,15 @@ cobs_gpu_status plan_index(cobs_gpu_index* ix) {
     // crosses PCIe in ~5 ms, its scan takes 2-3 ms) the rest of the budget holds slices of the streamed files RESIDENT.
     // (configs[4] on one GPU, 18.4 GB under 6 GB: buffers of 3 GB / 512 MiB / 256 MiB -> 323 / 239 / 229 ms per pass.)
     uint64_t spare = 0;
-    if (cap) {
+    // (Small buffers are for chunks of whole ROWS.  A file that has to be cut by COLUMNS -- several hash functions, a
+    // procedural index, row ranges switched off -- crosses PCIe as 2-D copies whose rate falls with the slice width
+    // (profiles/r04_h2d_probe.txt: 56 GB/s whole rows, 43 at 288 bytes, 9.5 at 32): it keeps the wide buffers.)
+    bool by_columns = false;
+    for (size_t i = 0; i < ix->parts.size(); ++i)
+        if (!resident[i] && !ix->parts[i].held.empty() &&
+            (ix->parts[i].meta.num_hashes != 1 || ix->tune.row_ranges == 0 || ix->parts[i].synthetic))
+            by_columns = true;
+    if (cap && !by_columns) {
         const uint64_t want = (uint64_t)ix->tune.stream_buf_kib << 10;
         if (want && cap > want) {
             spare = 2 * (cap - want);
