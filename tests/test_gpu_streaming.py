@@ -122,7 +122,8 @@ def test_random_budgets(gpu_lib, oracle, tmp_path, monkeypatch, no_pin):
             continue
         assert s.info(0).hbm_bytes <= budget
         buf, kept, per_pass, nchunks = s.stream_plan()
-        assert 2 * buf + kept <= budget and (not mixed or buf <= max(buf_kib, 1) * 1024)
+        # (a file with several hash functions is cut by columns and keeps the wide buffers: column slices cross as 2-D copies)
+        assert 2 * buf + kept <= budget and (not mixed or H > 1 or buf <= max(buf_kib, 1) * 1024)
         n_mixed += 1 if kept > 0 and nchunks > 0 else 0
         if kept > 0:
             assert per_pass < file_bytes          # what stays resident does not cross the link again
