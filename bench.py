@@ -1372,6 +1372,8 @@ def run_bench(args, world, rank, local_rank, wd, emit):
     key = "%s_q%d_k%d_h%d%s%s" % (args.config, args.queries, args.kmers, args.num_hashes,
                                   "_hits" if args.hits_only and args.threshold > 0 else "",
                                   "_top%d%s" % (args.num_results, "rows" if args.topk_with_rows else "") if args.num_results else "")
+    if args.scale != 1.0:
+        key += "_x%g" % args.scale             # (another index: its own traffic entry)
     tr_path = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tr_path) and n_gpus == 1 and args.scale == 1.0 and not budget:
         try:
