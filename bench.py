@@ -887,6 +887,7 @@ class Watchdog(threading.Thread):
         self.notes, self.comm, self.extra = {}, None, {}
         self.stop_ev = threading.Event()
         self.fired = False
+        self.result_emitted = False         # rank 0 has printed the run's line: whatever goes wrong afterwards must not add another
         self.wake_r = None
 
     def phase(self, name, seconds=None):
@@ -936,6 +937,10 @@ class Watchdog(threading.Thread):
         st = self.state()
         sys.stderr.write("[bench watchdog] rank %d: %s -- %s\n" % (self.rank, why, json.dumps(st)))
         sys.stderr.flush()
+        if self.result_emitted:
+            # (a rank that hangs or dies in the shutdown: the measurement is complete and printed; stdout keeps its ONE line)
+            self.exit_fn(0)
+            return
         if self.peers is not None:
             try:
                 self.peers.set("wd/%d" % self.rank, json.dumps(st))
@@ -1197,6 +1202,8 @@ def main():
     def emit(line):
         _RESULT_STDOUT.write(json.dumps(line) + "\n")
         _RESULT_STDOUT.flush()
+        if "error" not in line:
+            wd.result_emitted = True
 
     wd = Watchdog(rank, world, emit, scale=args.deadline_scale)
     wd.catch_sigterm()
@@ -1564,6 +1571,7 @@ def run_bench(args, world, rank, local_rank, wd, emit):
         if shard_index and args.dist_backend == "nccl":
             assert out["rccl_ranks"] == args.gpus, (out["rccl_ranks"], args.gpus)
         emit(out)
+    wd.result_emitted = True            # (every rank: the run's line is out; a problem in the shutdown adds nothing to stdout)
     wd.phase("shutdown", 120)
     if world > 1:
         dist.barrier()              # (rank 0 has printed: nobody's exit makes the launcher end the others before that)
