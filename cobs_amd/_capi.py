@@ -157,6 +157,7 @@ SYMBOLS = {
     "cobs_gpu_stream_counters": (_int, [_vp, C.POINTER(C.c_uint64 * 2)]),
     "cobs_gpu_stream_traffic": (_int, [_vp, C.POINTER(C.c_uint64 * 4)]),
     "cobs_gpu_stream_plan": (_int, [_vp, C.POINTER(C.c_uint64 * 4)]),
+    "cobs_gpu_plan_stream": (_int, [_cp, _u64, _u32, _u32, _u32, C.POINTER(C.c_uint64 * 4), C.POINTER(C.c_uint8), _sz, C.POINTER(_sz)]),
     "cobs_gpu_timers": (_int, [_vp, C.POINTER(C.c_double * 5), _int]),
     "cobs_gpu_exchange_plan": (_int, [_pu64, _pu64, _pu64, _sz, _sz, _u64, _sz, _u32, _u32, _sz,
                                       C.POINTER(Xfer), C.POINTER(Copy2D), C.POINTER(_sz), _pu64]),

@@ -494,6 +494,48 @@ cobs_gpu_status cobs_gpu_plan_shards(const char* path, uint32_t shard_count, uin
     });
 }
 
+// The out-of-core plan of one index file as host arithmetic (no device): what cobs_gpu_open would keep resident and
+// what it would stream under `hbm_budget_bytes` (shard options as in cobs_gpu_open; COBS_GPU_* tuning from the
+// environment).  out as cobs_gpu_stream_plan; resident[i] (optional, `cap` entries) = 1 if held slice i stays in HBM.
+cobs_gpu_status cobs_gpu_plan_stream(const char* path, uint64_t hbm_budget_bytes, uint32_t shard_rank, uint32_t shard_count,
+                                     uint32_t shard_mode, uint64_t out[4], uint8_t* resident, size_t cap, size_t* n_slices) {
+    if (!path || !out || shard_count == 0 || shard_rank >= shard_count || shard_mode > 2) return fail(COBS_GPU_ERR_ARG, "bad argument");
+    return guarded([&]() -> cobs_gpu_status {
+        MappedFile file;
+        std::string err;
+        if (!file.open(path, err)) return fail(COBS_GPU_ERR_OPEN, err);
+        cobs_gpu_index ix;
+        ix.tune = Tuning::from_env();
+        ix.shard_rank = shard_rank;
+        ix.shard_count = shard_count;
+        ix.shard_mode = shard_mode;
+        ix.hbm_budget = hbm_budget_bytes;
+        ix.parts.emplace_back();
+        Part& pt = ix.parts.back();
+        if (!parse_index_header(file.data(), file.size(), pt.meta, err))
+            return fail(COBS_GPU_ERR_FORMAT, std::string("Could not open index path \"") + path + "\": " + err);
+        cobs_gpu_status st = plan_index(&ix);
+        if (st != COBS_GPU_OK) return st;
+        uint64_t chunks = 0;
+        std::vector<uint8_t> keep(pt.held.size(), pt.streamed ? 0 : 1);
+        for (const Chunk& c : pt.chunks) {
+            chunks += (pt.streamed && !c.resident) ? 1 : 0;
+            if (!c.resident) continue;
+            for (const VPage& v : c.vp)            // (a resident chunk of a streamed file holds whole slices)
+                for (size_t j = 0; j < pt.held.size(); ++j)
+                    if (pt.held[j].fp == v.fp && pt.held[j].col0 == v.col0 && pt.held[j].ncols == v.ncols) keep[j] = 1;
+        }
+        out[0] = ix.stream.cap;
+        out[1] = pt.streamed ? ix.stream.resident_bytes : pt.resident_bytes;
+        out[2] = ix.stream.pass_bytes;
+        out[3] = chunks;
+        if (n_slices) *n_slices = pt.held.size();
+        if (resident)
+            for (size_t i = 0; i < std::min(cap, keep.size()); ++i) resident[i] = keep[i];
+        return COBS_GPU_OK;
+    });
+}
+
 cobs_gpu_status cobs_gpu_set_tuning(cobs_gpu_index* ix, const char* key, int64_t value) {
     if (!ix || !key) return fail(COBS_GPU_ERR_ARG, "NULL argument");
     const std::string k = key;

@@ -103,6 +103,11 @@ cobs_gpu_status cobs_gpu_stream_traffic(const cobs_gpu_index* ix, uint64_t out[4
  * copies every other chunk whole, out[3] = number of those chunks.  COBS_GPU_STREAM_BUF_KIB (read when the index is
  * opened) bounds a stream buffer (default 256 MiB, 0 = half the budget as in rounds 1-4). */
 cobs_gpu_status cobs_gpu_stream_plan(const cobs_gpu_index* ix, uint64_t out[4]);
+/* The same plan as host arithmetic, without a device (what cobs_gpu_open would decide for `path` under the budget and
+ * the shard options): out as above (for a file that fits: out[1] = its bytes, the rest 0); resident[i] (optional, `cap`
+ * entries; *n_slices = how many there are) = 1 if the i-th held slice stays in HBM.  For tests of the planner. */
+cobs_gpu_status cobs_gpu_plan_stream(const char* path, uint64_t hbm_budget_bytes, uint32_t shard_rank, uint32_t shard_count,
+                                     uint32_t shard_mode, uint64_t out[4], uint8_t* resident, size_t cap, size_t* n_slices);
 
 #ifdef __cplusplus
 }

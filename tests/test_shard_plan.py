@@ -210,3 +210,56 @@ def test_hit_exchange_plan_routes_every_record_to_its_query_owner(oracle, tmp_pa
                     q0, q1 = nq * i // N, nq * (i + 1) // N
                     assert sorted(got) == sorted(h for h in hits if q0 <= h[0] < q1), (N, i, nq)
                 assert moved == sum(1 for r in range(N) for h in local[r] if owner(h[0]) != r)
+
+
+# ---- round 5: the out-of-core plan (residency per slice) as host arithmetic ----------------------------------------------
+def _plan_stream(path, budget, rank=0, count=1, mode=0):
+    import ctypes as C
+    from cobs_amd import _capi
+    out = (C.c_uint64 * 4)()
+    keep = (C.c_uint8 * 512)()
+    n = C.c_size_t(0)
+    _capi.check(_capi.load().cobs_gpu_plan_stream(path.encode(), budget, rank, count, mode, C.byref(out), keep, 512, C.byref(n)))
+    return [int(v) for v in out], [int(keep[i]) for i in range(n.value)]
+
+
+def test_budget_is_spent_per_slice(tmp_path, monkeypatch):
+    """plan.cpp: chunk_part / plan_index without a device.  The stream buffers are bounded (COBS_GPU_STREAM_BUF_KIB), what the
+    budget leaves beyond them keeps whole slices of the streamed file resident -- the smallest first, then whatever else
+    fits; a file cut by columns (two hash functions) keeps the wide buffers; everything stays inside the budget"""
+    from tests import cases
+    monkeypatch.setenv("COBS_GPU_ROW_RANGE_MIN", "48")
+    ps = 64
+    sigs = [300, 450, 700, 1100, 1700, 2600, 4000, 6200]           # the C3 shape in small: ratio ~1.5
+    D = 8 * 8 * ps - 9
+    p1 = cases.make_compact(cases.tmp(tmp_path, "pl.cobs_compact"), D, ps, sigs, 1, 31, 1, 0.3, 4)
+    file_bytes = sum(sigs) * ps
+    pitch = 128                                                     # 64-byte rows at the device pitch ... or packed: either way
+    # everything fits: resident, no buffers
+    out, keep = _plan_stream(p1, 0)
+    assert out[0] == 0 and out[3] == 0 and keep == [1] * 8
+    # a third of the file as budget, buffers of 1/12 of it each: the rest keeps the small sub-indexes
+    budget = file_bytes // 3
+    monkeypatch.setenv("COBS_GPU_STREAM_BUF_KIB", str(max(1, budget // 12 // 1024)))
+    out, keep = _plan_stream(p1, budget)
+    buf, kept, per_pass, nchunks = out
+    assert 0 < buf <= budget // 12 + 1024 and 2 * buf + kept <= budget
+    assert kept > 0 and per_pass < file_bytes and nchunks >= 3
+    first_streamed = keep.index(0)
+    assert first_streamed >= 2 and keep[:first_streamed] == [1] * first_streamed        # the smallest sub-indexes stay
+    assert per_pass == sum(s * ps for s, k in zip(sigs, keep) if not k)                   # what is not resident crosses the link
+    # round 4's plan on request: two buffers of half the budget, nothing of the file resident
+    monkeypatch.setenv("COBS_GPU_STREAM_BUF_KIB", "0")
+    out0, keep0 = _plan_stream(p1, budget)
+    assert keep0 == [0] * 8 and out0[1] == 0 and out0[2] == file_bytes and out0[0] * 2 <= budget
+    # a larger budget keeps more, never less
+    monkeypatch.setenv("COBS_GPU_STREAM_BUF_KIB", str(max(1, budget // 12 // 1024)))
+    out2, keep2 = _plan_stream(p1, 2 * budget)
+    assert out2[1] >= kept and sum(keep2) >= sum(keep) and out2[2] <= per_pass
+    # a shard plans its own slices under its own budget
+    outs, keeps = _plan_stream(p1, budget // 4, rank=1, count=2, mode=2)
+    assert 2 * outs[0] + outs[1] <= budget // 4 and len(keeps) >= 1
+    # two hash functions: cut by columns -> the wide buffers, nothing else resident
+    p2 = cases.make_compact(cases.tmp(tmp_path, "pl2.cobs_compact"), D, ps, sigs, 2, 31, 1, 0.3, 5)
+    outc, keepc = _plan_stream(p2, budget)
+    assert keepc == [0] * 8 and outc[1] == 0 and 2 * outc[0] <= budget and outc[0] > budget // 12 + 1024
