@@ -120,6 +120,18 @@ struct RemapArgs {
     uint64_t row0, nrows;
     uint32_t nq, tpage, table_npages, num_hashes;
 };
+// The terms a row-range unit actually HOLDS, per query (compact_*_kernel): a range's scan walks every term of every query
+// while 99 % of them name the zero row (their row lies in another range of the sub-index) -- 4.4 ms per unit for 10 000
+// queries x 1000 terms, issue-bound, where the in-range terms alone are a 12-term "read".  A second table with the same
+// layout but each query's in-range entries only, and its own block offsets.  One hash function, 32-bit indices.
+struct CompactArgs {
+    const uint32_t* table2;      // the unit's row-index table (entries naming no row == zero_idx)
+    uint32_t* table3;            // compact: [query][sub-index][blocks2 + 1][8] (only sub-index `tpage` is written)
+    const uint64_t* blk_off;     // nq + 1: blocks per query of table2
+    uint64_t* blk2;              // nq + 1: ... of table3 (exclusive scan of `cnt`)
+    uint32_t* cnt;               // [nq + 1] blocks of in-range terms per query
+    uint32_t nq, tpage, table_npages, zero_idx;
+};
 struct AddScoresArgs {
     void* dst;                   // score rows [nq][dst_stride] (elements of elem_bytes)
     const void* src;             // partial scores [nq][nslots]

@@ -119,6 +119,8 @@ StreamBufs::~StreamBufs() {
     for (auto& e : scanned) if (e) (void)hipEventDestroy(e);
     if (hashed) (void)hipEventDestroy(hashed);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    if (prep_stream) (void)hipStreamDestroy(prep_stream);
+    for (auto& e : assigned) if (e) (void)hipEventDestroy(e);
 }
 
 }  // namespace cobs_amd
@@ -563,6 +565,8 @@ cobs_gpu_status cobs_gpu_set_tuning(cobs_gpu_index* ix, const char* key, int64_t
         t.rank_window_kib = value > 0 ? (uint32_t)std::min<int64_t>(value, 1 << 20) : 16u << 10;
     } else if (k == "row_ranges") {
         return fail(COBS_GPU_ERR_ARG, "row_ranges shapes the chunks of an index: set COBS_GPU_ROW_RANGES before it is opened");
+    } else if (k == "compact_terms") {
+        t.compact_terms = value != 0;
     } else if (k == "rank_pack") {
         t.rank_pack = value != 0;
     } else if (k == "hash_stream") {

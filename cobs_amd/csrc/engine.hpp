@@ -111,6 +111,7 @@ struct Tuning {
     uint32_t packed_width = 0;  // (set by the planner for a streamed part: chunks of this many columns keep that pitch)
     int stream_packed = 1;      // streamed chunks keep the file's row pitch (linear PCIe copies); 0: device pitch, 2-D copies (A/B)
     int row_ranges = 1;         // a streamed sub-index larger than a stream buffer is cut by ROWS (H = 1; 0: by columns, A/B and fallback)
+    int compact_terms = 1;      // the scan of a row-range unit walks the terms the unit HOLDS (a compact second table), not every term (0: A/B)
     int rank_pack = 1;          // device-ranked records cross PCIe as one u32 where slot and score fit (0: always 8-byte pairs, A/B)
     int hash_stream = 0;        // K1 of a device-resident batch runs on the batch's own stream, K2 waits for it by event: the hashing
                                 // of one (sub-)batch overlaps the scan / exchange of another (the sharded multi-GPU flow)
@@ -204,12 +205,19 @@ struct StreamBufs {
     DevBuf<uint8_t> sbuf[2];
     PinnedBuf<uint8_t> stage[2];
     hipStream_t copy_stream = nullptr;
+    // the slot assignment of a row-selective gather runs beside the previous unit's copy (that kernel waits for PCIe, this one
+    // walks the row-index table): its own stream, and the event the copy of the same buffer waits for
+    hipStream_t prep_stream = nullptr;
+    hipEvent_t assigned[2] = {nullptr, nullptr};
     hipEvent_t copied[2] = {nullptr, nullptr}, scanned[2] = {nullptr, nullptr};
     bool used[2] = {false, false};
     uint64_t cap = 0;             // bytes per buffer
     // row-selective passes: the row-index table of the gathered rows in buffer i, and the event after K1
     // (the fetch kernel on the copy stream reads K1's table)
     DevBuf<uint8_t> table2[2];
+    DevBuf<uint32_t> table3[2];               // a row-range unit's in-range terms per query (compact table) ...
+    DevBuf<uint64_t> blk2[2];                 // ... its block offsets ...
+    DevBuf<uint32_t> blkcnt[2];               // ... and the per-query block counts they are scanned from
     DevBuf<uint64_t> rowlist[2];              // source rows of the gathered rows in buffer i
     DevBuf<unsigned long long> cursor[2];     // slot cursors of the gather, per page
     DevBuf<GatherPage> gpages[2];

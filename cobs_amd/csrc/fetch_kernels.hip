@@ -29,6 +29,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 
 #include "device_types.hpp"
 #include "kernels.hpp"
@@ -147,12 +148,9 @@ __global__ __launch_bounds__(256) void gather_assign_kernel(GatherArgs a) {
 
 // One thread per (gathered row, 16-byte piece): the row's pieces on consecutive lanes, read over PCIe straight from the
 // registered mapping of the index file (unaligned sources -- classic rows at odd file offsets -- through aligned dwords).
-__global__ __launch_bounds__(256) void gather_copy_kernel(GatherArgs a) {
-    const uint32_t cpp = a.pitch / 16u;
-    const uint64_t gid = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+__device__ __forceinline__ void gather_copy_piece(const GatherArgs& a, uint32_t cpp, uint64_t gid) {
     const uint64_t g = gid / cpp;                          // gathered row
     const uint32_t c = (uint32_t)(gid - g * cpp);
-    if (g >= a.total_rows) return;
     uint32_t lo = 0, hi = a.npages;                        // its page: the last i with slot0[i] <= g
     while (hi - lo > 1u) {
         const uint32_t mid = (lo + hi) >> 1;
@@ -182,6 +180,16 @@ __global__ __launch_bounds__(256) void gather_copy_kernel(GatherArgs a) {
     *reinterpret_cast<uint4*>(out) = v;
 }
 
+// A BOUNDED grid with a grid-stride loop: the kernel waits for PCIe (a few MB in flight saturate the link), and a grid of
+// one thread per piece -- 45 000 work-groups for a 186 MB unit -- filled every CU with waiting waves: the scan and the
+// partial-score addition of the previous unit, on their own streams, then took 3.4 ms instead of 0.2 for want of a slot.
+__global__ __launch_bounds__(256) void gather_copy_kernel(GatherArgs a) {
+    const uint32_t cpp = a.pitch / 16u;
+    const uint64_t items = a.total_rows * cpp;
+    for (uint64_t gid = (uint64_t)blockIdx.x * 256u + threadIdx.x; gid < items; gid += (uint64_t)gridDim.x * 256u)
+        gather_copy_piece(a, cpp, gid);
+}
+
 // Row-range chunk, streamed whole: K1's row indices of its sub-index, rewritten for a buffer that holds rows
 // [row0, row0 + nrows) only.  One thread per table entry of that sub-index ([query][block + padding block][hash][8]).
 template <typename IdxT>
@@ -201,6 +209,66 @@ __global__ __launch_bounds__(256) void remap_rows_kernel(RemapArgs a, uint64_t e
     reinterpret_cast<IdxT*>(a.table2)[e] = (IdxT)(r < a.nrows ? r : a.nrows);
 }
 
+// ---- the in-range terms of a row-range unit, per query (CompactArgs) ----
+// one wave per query: how many entries of its sub-index `tpage` name a row of the unit
+__global__ __launch_bounds__(64) void compact_count_kernel(CompactArgs a) {
+    const uint32_t q = blockIdx.x, lane = threadIdx.x;
+    const uint64_t b0 = a.blk_off[q];
+    const uint32_t nblk = (uint32_t)(a.blk_off[q + 1] - b0);
+    const uint32_t* t = a.table2 + ((b0 + q) * a.table_npages + (uint64_t)a.tpage * (nblk + 1u)) * 8ull;
+    uint32_t n = 0;
+    for (uint32_t i = lane; i < nblk * 8u; i += 64u) n += t[i] != a.zero_idx ? 1u : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) n += (uint32_t)__shfl_xor((int)n, off);
+    if (lane == 0u) a.cnt[q] = (n + 7u) / 8u;
+}
+
+// blk2 = exclusive scan of cnt[0 .. nq), blk2[nq] = total; ONE work-group of 1024 threads
+__global__ __launch_bounds__(1024) void compact_scan_kernel(CompactArgs a) {
+    __shared__ uint64_t part[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (a.nq + 1023u) / 1024u;
+    const uint32_t i0 = min(t * per, a.nq), i1 = min(i0 + per, a.nq);
+    uint64_t s = 0;
+    for (uint32_t i = i0; i < i1; ++i) s += a.cnt[i];
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {
+        const uint64_t v = t >= d ? part[t - d] : 0ull;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint64_t run = t ? part[t - 1] : 0ull;
+    for (uint32_t i = i0; i < i1; ++i) {
+        a.blk2[i] = run;
+        run += a.cnt[i];
+    }
+    if (t == 1023u) a.blk2[a.nq] = part[1023];
+}
+
+// one wave per query: its in-range entries packed to the front of its compact blocks, the rest (and the extra all-padding
+// block) point at the zero row
+__global__ __launch_bounds__(64) void compact_write_kernel(CompactArgs a) {
+    const uint32_t q = blockIdx.x, lane = threadIdx.x;
+    const uint64_t b0 = a.blk_off[q];
+    const uint32_t nblk = (uint32_t)(a.blk_off[q + 1] - b0);
+    const uint32_t* t = a.table2 + ((b0 + q) * a.table_npages + (uint64_t)a.tpage * (nblk + 1u)) * 8ull;
+    const uint64_t c0 = a.blk2[q];
+    const uint32_t nb2 = (uint32_t)(a.blk2[q + 1] - c0);
+    uint32_t* o = a.table3 + ((c0 + q) * a.table_npages + (uint64_t)a.tpage * (nb2 + 1u)) * 8ull;
+    uint32_t off = 0;
+    for (uint32_t i0 = 0; i0 < nblk * 8u; i0 += 64u) {
+        const uint32_t i = i0 + lane;
+        const uint32_t v = i < nblk * 8u ? t[i] : a.zero_idx;
+        const bool in = v != a.zero_idx;
+        const unsigned long long mask = __ballot(in);
+        if (in) o[off + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = v;
+        off += (uint32_t)__popcll(mask);
+    }
+    for (uint32_t i = off + lane; i < (nb2 + 1u) * 8u; i += 64u) o[i] = a.zero_idx;
+}
+
 // dst[q][dst_offset + i] += src[q][i]: whole 32-bit words (slots come in multiples of 8; the counters of a word
 // cannot carry into each other: every sum is a count of the query's terms, which the score type holds)
 __global__ __launch_bounds__(256) void add_scores_kernel(AddScoresArgs a) {
@@ -215,6 +283,14 @@ __global__ __launch_bounds__(256) void add_scores_kernel(AddScoresArgs a) {
 }
 
 }  // namespace
+
+hipError_t launch_compact_terms(const CompactArgs& a, hipStream_t stream) {
+    if (a.nq == 0) return hipSuccess;
+    hipLaunchKernelGGL(compact_count_kernel, dim3(a.nq), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, stream, a);
+    hipLaunchKernelGGL(compact_write_kernel, dim3(a.nq), dim3(64), 0, stream, a);
+    return hipGetLastError();
+}
 
 hipError_t launch_remap_rows(const RemapArgs& a, uint64_t entries, bool idx64, hipStream_t stream) {
     if (entries == 0 || a.nq == 0) return hipSuccess;
@@ -258,16 +334,23 @@ hipError_t launch_count_rows(const CountArgs& a, uint64_t total_entries, bool id
     return hipGetLastError();
 }
 
-hipError_t launch_gather(const GatherArgs& a, bool idx64, hipStream_t stream) {
+hipError_t launch_gather_assign(const GatherArgs& a, bool idx64, hipStream_t stream) {
     if (a.npages == 0 || a.nq == 0 || a.entries == 0) return hipSuccess;
     const uint64_t ablocks = (a.entries + 255u) / 256u;
-    const uint64_t items = a.total_rows * (a.pitch / 16u);
-    const uint64_t cblocks = (items + 255u) / 256u;
-    if (ablocks > 0x7FFFFFFFull || cblocks > 0x7FFFFFFFull || a.npages > 65535u) return hipErrorInvalidValue;
+    if (ablocks > 0x7FFFFFFFull || a.npages > 65535u) return hipErrorInvalidValue;
     const dim3 agrid((uint32_t)ablocks, a.npages);
     if (idx64) hipLaunchKernelGGL(gather_assign_kernel<uint64_t>, agrid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(gather_assign_kernel<uint32_t>, agrid, dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(gather_copy_kernel, dim3((uint32_t)cblocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_copy(const GatherArgs& a, uint32_t grid_limit, hipStream_t stream) {
+    if (a.npages == 0 || a.nq == 0 || a.entries == 0) return hipSuccess;
+    const uint64_t items = a.total_rows * (a.pitch / 16u);
+    const uint64_t cblocks = (items + 255u) / 256u;
+    static const uint64_t forced = getenv("COBS_GPU_GATHER_BLOCKS") ? std::strtoull(getenv("COBS_GPU_GATHER_BLOCKS"), nullptr, 0) : 0u;   // (A/B)
+    const uint64_t max_blocks = forced ? forced : std::max<uint32_t>(grid_limit, 1u);
+    hipLaunchKernelGGL(gather_copy_kernel, dim3((uint32_t)std::min<uint64_t>(cblocks, max_blocks)), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -38,11 +38,15 @@ hipError_t launch_score_hist(const HistArgs& a, hipStream_t stream);
 // count_rows: how many rows the batch looks up in every streamed piece of a part (one counter per piece);
 // gather: slots for exactly those rows of a unit's pages (gather_assign_kernel), then the rows themselves (gather_copy_kernel).
 hipError_t launch_count_rows(const CountArgs& a, uint64_t total_entries, bool idx64, hipStream_t stream);
-hipError_t launch_gather(const GatherArgs& a, bool idx64, hipStream_t stream);
+hipError_t launch_gather_assign(const GatherArgs& a, bool idx64, hipStream_t stream);
+// grid_limit: work-groups of the copy (a grid-stride loop): few when other kernels of the pass run beside it, see pass.cpp
+hipError_t launch_gather_copy(const GatherArgs& a, uint32_t grid_limit, hipStream_t stream);
 // Row-range chunks of a streamed sub-index (fetch_kernels.hip): rewrite the `entries` row indices of one sub-index for
 // the rows a chunk holds; add a chunk's partial scores to the score rows.
 hipError_t launch_remap_rows(const RemapArgs& a, uint64_t entries, bool idx64, hipStream_t stream);
 hipError_t launch_add_scores(const AddScoresArgs& a, hipStream_t stream);
+// a row-range unit's in-range terms per query: a compact second table + its block offsets (count, scan, write)
+hipError_t launch_compact_terms(const CompactArgs& a, hipStream_t stream);
 hipError_t launch_clear_flags(uint32_t* flags, hipStream_t stream);
 
 // Owner-routed hit exchange (xchg_kernels.hip): count == true -> records per owner into a.cursor, else scatter.

@@ -527,6 +527,9 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
             const bool partial = c.row_range && c.range_no > 0;
             const PageDev* pages_dev = partial ? c.d_pages_acc : c.d_pages;
             const void* table_dev = b->work[f].table.p;
+            bool unit_fetched = false;
+            uint64_t unit_rows = 0;
+            uint32_t unit_zero = 0;
             const bool stream_this = p.streamed && !c.resident;      // (a streamed file may keep some of its slices in HBM)
             if (stream_this) {
                 // double buffer shared by all streamed files: the next chunk goes to the buffer
@@ -539,6 +542,7 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                     if (!fetch_ready) {          // the gather reads K1's table: once per file and pass
                         HIP_TRY(hipEventRecord(sbufs.hashed, st));
                         HIP_TRY(hipStreamWaitEvent(sbufs.copy_stream, sbufs.hashed, 0));
+                        HIP_TRY(hipStreamWaitEvent(sbufs.prep_stream, sbufs.hashed, 0));
                         fetch_ready = true;
                     }
                     // the unit's pages as the gather sees them: exactly the looked-up rows of each, packed, a zero row behind
@@ -569,8 +573,11 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                         slot += cnt + 1;
                     }
                     HIP_TRY(sbufs.rowlist[buf].reserve((size_t)slot));
-                    HIP_TRY(hipMemcpyAsync(sbufs.gpages[buf].p, gp, np * sizeof(GatherPage), hipMemcpyHostToDevice, sbufs.copy_stream));
-                    HIP_TRY(hipMemsetAsync(sbufs.cursor[buf].p, 0, np * sizeof(unsigned long long), sbufs.copy_stream));
+                    // (the slot assignment on its own stream: it overlaps the copy of the previous unit -- 1.1 ms of table walking per
+                    // unit beside 3.6-4.2 ms of waiting for PCIe, profiles/r05_out_of_core_kernel_stats.csv; the last scan that read
+                    // this buffer's second table has finished: the host waited for scanned[buf] above)
+                    HIP_TRY(hipMemcpyAsync(sbufs.gpages[buf].p, gp, np * sizeof(GatherPage), hipMemcpyHostToDevice, sbufs.prep_stream));
+                    HIP_TRY(hipMemsetAsync(sbufs.cursor[buf].p, 0, np * sizeof(unsigned long long), sbufs.prep_stream));
                     GatherArgs ga;
                     ga.file = p.file_dev;
                     ga.table = b->work[f].table.p;
@@ -590,9 +597,22 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                     ga.table_npages = p.num_tpages();
                     ga.num_hashes = (uint32_t)p.meta.num_hashes;
                     ga.pitch = c.pitch;
-                    HIP_TRY(launch_gather(ga, p.idx64, sbufs.copy_stream));
+                    HIP_TRY(launch_gather_assign(ga, p.idx64, sbufs.prep_stream));
+                    HIP_TRY(hipEventRecord(sbufs.assigned[buf], sbufs.prep_stream));
+                    HIP_TRY(hipStreamWaitEvent(sbufs.copy_stream, sbufs.assigned[buf], 0));
+                    // A pass of MANY fetched units is a pipeline -- gather(i + 1) | compact + scan + add(i) --: the copy, which only
+                    // waits for PCIe, then runs on 128 work-groups so that the kernels beside it find CUs (the 184 GB file, 253
+                    // units: 1.20 s per pass with a grid of one thread per piece, 1.11 s with 256 work-groups, 1.03 s with 128);
+                    // a pass of a few units (a small batch) has nothing to overlap and takes the wide grid (256 queries: 24.1
+                    // against 25.4 ms).
+                    size_t fetched_units = 0;
+                    for (size_t u = 0; u < fetch_unit[f].size(); ++u) fetched_units += fetch_unit[f][u] ? 1 : 0;
+                    HIP_TRY(launch_gather_copy(ga, fetched_units > 16 ? 128u : 1024u, sbufs.copy_stream));
                     pages_dev = c.d_pages2[buf];
                     table_dev = sbufs.table2[buf].p;
+                    unit_fetched = true;
+                    unit_rows = slot - np;
+                    unit_zero = gp[0].count;
                     ++sbufs.fetched_chunks;
                     sbufs.fetched_bytes += (slot - np) * (uint64_t)c.pitch;
                 } else {
@@ -621,6 +641,49 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                     table_dev = sbufs.table2[buf].p;
                 }
             }
+            // A row-range unit: only the terms whose row it HOLDS count, every other entry of its table names the zero row --
+            // 99 % of them for a 256 MiB range of a 62 GB sub-index, and walking them all made the scan of such a unit
+            // issue-bound (4.4 ms for 10k queries; 254 units per pass of the 184 GB file: 1.2 s of scans beside 0.9 s of PCIe).
+            // Where few terms are in range the scan gets a compact table of them (compact_*_kernel) and its own block offsets.
+            const uint64_t* blk_dev = b->work[f].blk_off;
+            ScanGeom geom = geoms[f][ci];
+            if (stream_this && c.row_range && c.vp.size() == 1 && p.meta.num_hashes == 1 && !p.idx64 && ix->tune.compact_terms != 0 &&
+                !ix->tune.lds_staged && table_dev == (const void*)sbufs.table2[buf].p) {
+                const uint64_t E = (b->work[f].h_blk_off[nq] + nq) * 8ull;
+                uint64_t rows_in = unit_rows;                      // (a fetched unit: exact)
+                uint32_t zero_idx = unit_zero;
+                bool exact = unit_fetched;
+                if (!unit_fetched) {
+                    exact = cnt_off[f + 1] > cnt_off[f];
+                    zero_idx = (uint32_t)c.pages[0].sig;
+                    const uint64_t sig = p.meta.signature_sizes[c.vp[0].fp];
+                    rows_in = cnt_off[f + 1] > cnt_off[f] ? sbufs.h_counts.p[cnt_off[f] + c.cp[0].first]
+                                                          : (uint64_t)((long double)E * (long double)c.pages[0].sig / (long double)std::max<uint64_t>(sig, 1));
+                }
+                if (rows_in * 4 < E) {
+                    // blocks of the compact table: sum over queries of ceil(n / 8) + the padding blocks -- from the exact count, or
+                    // (no count: the mapping is not registered, row_fetch is off) no more than the table it is made from
+                    const uint64_t blocks_bound = exact ? rows_in / 8 + 2 * nq : b->work[f].h_blk_off[nq] + nq;
+                    HIP_TRY(sbufs.table3[buf].reserve((size_t)(blocks_bound * p.num_tpages() * 8)));
+                    HIP_TRY(sbufs.blk2[buf].reserve(nq + 1));
+                    HIP_TRY(sbufs.blkcnt[buf].reserve(nq + 1));
+                    CompactArgs ca;
+                    ca.table2 = reinterpret_cast<const uint32_t*>(sbufs.table2[buf].p);
+                    ca.table3 = sbufs.table3[buf].p;
+                    ca.blk_off = b->work[f].blk_off;
+                    ca.blk2 = sbufs.blk2[buf].p;
+                    ca.cnt = sbufs.blkcnt[buf].p;
+                    ca.nq = (uint32_t)nq;
+                    ca.tpage = c.pages[0].tpage;
+                    ca.table_npages = p.num_tpages();
+                    ca.zero_idx = zero_idx;
+                    HIP_TRY(launch_compact_terms(ca, st));
+                    table_dev = sbufs.table3[buf].p;
+                    blk_dev = sbufs.blk2[buf].p;
+                    const uint64_t mean2 = std::max<uint64_t>(1, (rows_in / std::max<size_t>(nq, 1) + 7) / 8);
+                    geom = scan_geometry(c, mean2, mean2 * 4 + 4, 1, ix->waves_per_group, b->planes, false, ix->tune);
+                }
+            }
             uint32_t part_slots = 0;
             if (partial) {
                 part_slots = (uint32_t)(c.vp[0].ncols * 8);
@@ -630,7 +693,7 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
             sa.blob = data;
             sa.pages = pages_dev;
             sa.table = table_dev;
-            sa.blk_off = b->work[f].blk_off;
+            sa.blk_off = blk_dev;
             sa.counts = partial ? b->counts_part.p : b->counts.p;
             sa.thresholds = b->selected ? b->work[f].thr.p : nullptr;
             sa.hits = b->hits.p;
@@ -649,7 +712,6 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
             sa.part = (uint32_t)f;
             sa.write_counts = b->have_counts ? 1 : 0;
             sa.idx64 = p.idx64 ? 1u : 0u;
-            const ScanGeom geom = geoms[f][ci];
             const int nwaves = geom.nwaves;
             sa.tile_w = geom.tile_w;
             sa.cand = b->topk_direct ? b->cand.p + cand_off[f] : nullptr;

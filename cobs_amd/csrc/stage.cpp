@@ -62,6 +62,8 @@ cobs_gpu_status alloc_part(cobs_gpu_index* ix, Part& pt) {
         if (!sb.scanned[i]) HIP_TRY(hipEventCreateWithFlags(&sb.scanned[i], hipEventDisableTiming));
     }
     if (!sb.copy_stream) HIP_TRY(hipStreamCreateWithFlags(&sb.copy_stream, hipStreamNonBlocking));
+    if (!sb.prep_stream) HIP_TRY(hipStreamCreateWithFlags(&sb.prep_stream, hipStreamNonBlocking));
+    for (auto& e : sb.assigned) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return COBS_GPU_OK;
 }
 
