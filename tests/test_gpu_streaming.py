@@ -379,3 +379,15 @@ def test_fetched_row_ranges_share_a_scan_and_any_buffer_size_fetches(gpu_lib, or
     assert b.stats()["scan_launches"] >= nchunks
     for i, q in enumerate(queries):
         assert np.array_equal(b.counts_host(i), ix.counts(q)), i
+    # the scans of row-range units walk a compact table of the terms each unit HOLDS (compact_*_kernel) -- here 1/30 of a
+    # query's terms per range; with the full tables (tuning key compact_terms = 0: every term, most of them naming the zero
+    # row) the results are the same, fetched and copied whole
+    for fetch in (0, 1):
+        s.set_tuning("row_fetch", fetch)
+        for compact in (0, 1):
+            s.set_tuning("compact_terms", compact)
+            b.run(0.0)
+            b.sync()
+            for i, q in enumerate(queries):
+                assert np.array_equal(b.counts_host(i), ix.counts(q)), (fetch, compact, i)
+            assert s.search_hits(queries[:6], 0.5, 3) == [cases.oracle_results([ix], q, 0.5, 3) for q in queries[:6]]
