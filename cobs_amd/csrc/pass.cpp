@@ -576,8 +576,15 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                     // (the slot assignment on its own stream: it overlaps the copy of the previous unit -- 1.1 ms of table walking per
                     // unit beside 3.6-4.2 ms of waiting for PCIe, profiles/r05_out_of_core_kernel_stats.csv; the last scan that read
                     // this buffer's second table has finished: the host waited for scanned[buf] above)
-                    HIP_TRY(hipMemcpyAsync(sbufs.gpages[buf].p, gp, np * sizeof(GatherPage), hipMemcpyHostToDevice, sbufs.prep_stream));
-                    HIP_TRY(hipMemsetAsync(sbufs.cursor[buf].p, 0, np * sizeof(unsigned long long), sbufs.prep_stream));
+                    // (... in a pass of several units -- 256 queries, 6 units: 24.1 against 25.1 ms; a pass of ONE has no previous copy
+                    // to hide behind and keeps the assignment on the copy stream, without the event hop)
+                    size_t fetched_units = 0;
+                    for (size_t u = 0; u < fetch_unit[f].size(); ++u) fetched_units += fetch_unit[f][u] ? 1 : 0;
+                    const bool pipelined = fetched_units > 16;
+                    const bool own_prep = fetched_units > 1;
+                    hipStream_t prep = own_prep ? sbufs.prep_stream : sbufs.copy_stream;
+                    HIP_TRY(hipMemcpyAsync(sbufs.gpages[buf].p, gp, np * sizeof(GatherPage), hipMemcpyHostToDevice, prep));
+                    HIP_TRY(hipMemsetAsync(sbufs.cursor[buf].p, 0, np * sizeof(unsigned long long), prep));
                     GatherArgs ga;
                     ga.file = p.file_dev;
                     ga.table = b->work[f].table.p;
@@ -597,17 +604,17 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                     ga.table_npages = p.num_tpages();
                     ga.num_hashes = (uint32_t)p.meta.num_hashes;
                     ga.pitch = c.pitch;
-                    HIP_TRY(launch_gather_assign(ga, p.idx64, sbufs.prep_stream));
-                    HIP_TRY(hipEventRecord(sbufs.assigned[buf], sbufs.prep_stream));
-                    HIP_TRY(hipStreamWaitEvent(sbufs.copy_stream, sbufs.assigned[buf], 0));
+                    HIP_TRY(launch_gather_assign(ga, p.idx64, prep));
+                    if (own_prep) {
+                        HIP_TRY(hipEventRecord(sbufs.assigned[buf], sbufs.prep_stream));
+                        HIP_TRY(hipStreamWaitEvent(sbufs.copy_stream, sbufs.assigned[buf], 0));
+                    }
                     // A pass of MANY fetched units is a pipeline -- gather(i + 1) | compact + scan + add(i) --: the copy, which only
                     // waits for PCIe, then runs on 128 work-groups so that the kernels beside it find CUs (the 184 GB file, 253
                     // units: 1.20 s per pass with a grid of one thread per piece, 1.11 s with 256 work-groups, 1.03 s with 128);
                     // a pass of a few units (a small batch) has nothing to overlap and takes the wide grid (256 queries: 24.1
                     // against 25.4 ms).
-                    size_t fetched_units = 0;
-                    for (size_t u = 0; u < fetch_unit[f].size(); ++u) fetched_units += fetch_unit[f][u] ? 1 : 0;
-                    HIP_TRY(launch_gather_copy(ga, fetched_units > 16 ? 128u : 1024u, sbufs.copy_stream));
+                    HIP_TRY(launch_gather_copy(ga, pipelined ? 128u : 1024u, sbufs.copy_stream));
                     pages_dev = c.d_pages2[buf];
                     table_dev = sbufs.table2[buf].p;
                     unit_fetched = true;

@@ -3,7 +3,7 @@
 # lives in plan.cpp / stage.cpp / pass.cpp, outside the kernels the traffic replay is keyed on), plus configs[4] at
 # its named size: a 184 GB file under a 64 GB budget.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=$(pwd)/gpurun_out/stamp_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
