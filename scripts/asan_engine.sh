@@ -4,9 +4,10 @@
 # suite on an MI355X box: builds cobs_amd/libcobs_gpu_asan.so out of tree objects in $TMPDIR and runs pytest with
 # COBS_GPU_LIBRARY pointing at it and the sanitizer runtime preloaded.
 #   gpurun -- 'bash scripts/asan_engine.sh tests/test_gpu_fuzz.py tests/test_gpu_streaming.py tests/test_gpu_rank.py'
-# Round 4 on MI355X: test_gpu_fuzz / _streaming / _rank / _rccl / _parity / _topk_tiles / _cli / _construct: 144 tests pass,
-# no sanitizer report from the library.  Not usable under the preload (and failing for that reason only): tests that
-# initialise torch's device runtime (dlopen of libcaffe2_nvrtc.so fails) and the CLI test that starts RCCL in a child.
+# Round 5 on MI355X (after the per-slice residency, packed gather, compact tables, device-side pool ordering, bounded
+# collectives): test_gpu_fuzz / _streaming / _rank / _rccl / _parity / _topk_tiles / _construct: 141 tests pass, no sanitizer
+# report from the library (round 4: 144 with _cli).  Not usable under the preload (and failing for that reason only, 5
+# tests): tests that initialise torch's device runtime (dlopen of libcaffe2_nvrtc.so fails).
 set -eu
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 W=${TMPDIR:-/tmp}/cobs_asan_engine
