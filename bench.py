@@ -284,7 +284,10 @@ def end_to_end(search, batch, queries, hit_queries=None):
             res[name]["queries_with_hits"] = int((per > 0).sum())
             res[name]["hits_per_query_max"] = int(per.max()) if len(per) else 0
             res[name]["is"] = ("queries that are mutated windows of the planted sequences: hit records selected in the scan, compacted "
-                               "into the pool, copied to the host and ordered there (phase_seconds: the library's own timers)")
+                               "into the pool, ordered on the device, copied home into the library's arena as the passes finish "
+                               "(grown there: the search runs ONCE) and handed over as one array.  The windows of one sequence share "
+                               "k-mers, i.e. index rows: the scan of this batch is cache-friendlier than the random batch's "
+                               "(compare threshold_0.8_random_queries, same call, 0 hits); phase_seconds: the library's own timers")
     # the reference's default call (threshold 0, no limit; what its own benchmark times, src/cobs.cpp:618-626):
     # EVERY document of every query in rank order.  The rows are ordered on the device (rank_kernels.hip) and
     # the finished 12-byte records cross PCIe; 256 queries per call into a result array the caller keeps.

@@ -154,6 +154,7 @@ SYMBOLS = {
     "cobs_gpu_multi_search_batch": (_int, [_vp, C.POINTER(_cp), C.POINTER(_sz), _sz, _dbl, _sz,
                                            C.POINTER(Hit), _sz, C.POINTER(_sz), C.POINTER(_sz)]),
     "cobs_gpu_graph_replays": (_u64, [_vp]),
+    "cobs_gpu_host_passes": (_u64, [_vp]),
     "cobs_gpu_stream_counters": (_int, [_vp, C.POINTER(C.c_uint64 * 2)]),
     "cobs_gpu_stream_traffic": (_int, [_vp, C.POINTER(C.c_uint64 * 4)]),
     "cobs_gpu_stream_plan": (_int, [_vp, C.POINTER(C.c_uint64 * 4)]),

@@ -110,6 +110,19 @@ cobs_gpu_status ResultArena::reserve(size_t n) {
     return COBS_GPU_OK;
 }
 
+cobs_gpu_status ResultArena::grow_keep(size_t n, size_t used) {
+    if (n <= cap) return COBS_GPU_OK;
+    if (!p || used == 0) return reserve(n);
+    const size_t old_bytes = round_up(cap * sizeof(cobs_gpu_hit), 2u << 20);
+    const size_t bytes = round_up(n * sizeof(cobs_gpu_hit), 2u << 20);
+    void* m = mremap(p, old_bytes, bytes, MREMAP_MAYMOVE);      // (pages move, nothing is copied)
+    if (m == MAP_FAILED) return fail(COBS_GPU_ERR_CAPACITY, "no memory for the result arena (" + std::to_string(bytes) + " bytes)");
+    (void)madvise(m, bytes, MADV_HUGEPAGE);
+    p = static_cast<cobs_gpu_hit*>(m);
+    cap = bytes / sizeof(cobs_gpu_hit);
+    return COBS_GPU_OK;
+}
+
 ResultArena::~ResultArena() {
     if (p) (void)munmap(p, round_up(cap * sizeof(cobs_gpu_hit), 2u << 20));
 }
@@ -686,6 +699,7 @@ cobs_gpu_status cobs_gpu_read_rows(const cobs_gpu_index* ix, size_t f, uint32_t 
 }
 
 uint64_t cobs_gpu_graph_replays(const cobs_gpu_index* ix) { return ix ? ix->graph_replays : 0; }
+uint64_t cobs_gpu_host_passes(const cobs_gpu_index* ix) { return ix ? ix->host_passes : 0; }
 
 // True positives for the procedural index: see include/cobs_gpu_batch.h.
 cobs_gpu_status cobs_gpu_plant(cobs_gpu_index* ix, size_t f, const char* text, size_t len, const uint32_t* docs,

@@ -248,7 +248,8 @@ struct ResultArena {
     cobs_gpu_hit* p = nullptr;
     size_t cap = 0;                  // records
     std::vector<size_t> offs;
-    cobs_gpu_status reserve(size_t n);
+    cobs_gpu_status reserve(size_t n);                     // contents are not kept
+    cobs_gpu_status grow_keep(size_t n, size_t used);      // the first `used` records are
     ~ResultArena();
 };
 
@@ -269,6 +270,7 @@ struct cobs_gpu_index {
     bool peers_ranged = false;    // inside ONE sharded search call: some rank counts a streamed sub-index in row ranges -> every rank keeps score rows (agreed on per call, comm.cpp)
     double timers[5] = {0, 0, 0, 0, 0};
     cobs_amd::ResultArena arena;  // cobs_gpu_search_batch_view
+    uint64_t host_passes = 0;     // device passes launched by the host-buffer calls
     uint64_t graph_replays = 0;   // small passes of the host API served by a captured hipGraph
     static constexpr int kScratch = 3;
     cobs_gpu_batch* scratch[kScratch] = {nullptr, nullptr, nullptr};   // workspaces of the host-buffer search API
@@ -341,6 +343,7 @@ struct cobs_gpu_batch {
     // host-buffer API only: the stream this scratch batch lives on and the event after its pass
     hipStream_t own_stream = nullptr;
     hipEvent_t done = nullptr;
+    hipEvent_t scan_after = nullptr;  // set for one run: its K2 launches wait for this event (the previous pass), its K1 does not
     // captured graph of a small pass (single-query latency path)
     hipGraphExec_t graph_exec = nullptr;
     uint64_t graph_key = 0, graph_candidate = 0;

@@ -40,13 +40,21 @@ static cobs_gpu_status host_pass_begin(cobs_gpu_index* ix, int slot, const char*
         HIP_TRY(hipEventCreateWithFlags(&ix->scratch[slot]->done, hipEventDisableTiming));
     }
     cobs_gpu_batch* b = ix->scratch[slot];
+    ix->host_passes++;
     double t0 = now_s();
     size_t bad_local = 0;
     cobs_gpu_status st = set_queries_on(b, queries, lens, nq, b->own_stream, false, &bad_local, index_base);
     if (st != COBS_GPU_OK && bad_at) *bad_at = bad_local;
     if (st != COBS_GPU_OK) return st;
     ix->timers[1] += now_s() - t0;
-    if (after) HIP_TRY(hipStreamWaitEvent(b->own_stream, after, 0));
+    // the previous pass: a large pass only keeps its SCAN behind it (run_impl waits between K1 and K2: upload and hashing
+    // of this pass run beside the scan of that one -- 0.12 ms of idle device per pass otherwise); small passes (a
+    // captured graph) and out-of-core passes (shared stream buffers) wait here
+    bool any_streamed_ = false;
+    for (const auto& p : ix->parts) any_streamed_ = any_streamed_ || p.streamed;
+    const bool scan_only_after = after && nq > 16 && !any_streamed_;
+    if (after && !scan_only_after) HIP_TRY(hipStreamWaitEvent(b->own_stream, after, 0));
+    b->scan_after = scan_only_after ? after : nullptr;
     // with a threshold and no limit only the selected hits travel back: skip the score rows,
     // unless the hit pool overflows (then the pass is repeated with them and ranked on the host)
     // ... and with a limit K2 / K3 select on the device (tile-level top-k where it applies): no score rows either
@@ -197,6 +205,7 @@ static cobs_gpu_status host_pass_begin(cobs_gpu_index* ix, int slot, const char*
         return COBS_GPU_OK;
     }
     st = run_impl(b, threshold, topk, b->own_stream, !hits_only);
+    b->scan_after = nullptr;
     if (st != COBS_GPU_OK) return st;
     HIP_TRY(hipEventRecord(b->done, b->own_stream));
     return COBS_GPU_OK;
@@ -236,7 +245,9 @@ static cobs_gpu_status run_host_batch(cobs_gpu_index* ix, const char* const* que
 static cobs_gpu_status search_batch_impl(cobs_gpu_index* ix, const char* const* queries, const size_t* lens,
                                          size_t nq, double threshold, size_t num_results,
                                          cobs_gpu_hit* hits, size_t cap, size_t* hit_offsets,
-                                         size_t* bad_query) {
+                                         size_t* bad_query, cobs_amd::ResultArena* grow = nullptr) {
+    // grow: `hits` is that arena (cobs_gpu_search_batch_view): a thresholded call whose hits outgrow it makes it larger in
+    // place of reporting ERR_CAPACITY -- the caller would have to run the whole search a second time for the size
     if (!ix || !hit_offsets) return fail(COBS_GPU_ERR_ARG, "NULL argument");
     if (nq && (!queries || !lens)) return fail(COBS_GPU_ERR_ARG, "NULL argument");
     size_t used = 0;
@@ -323,6 +334,14 @@ static cobs_gpu_status search_batch_impl(cobs_gpu_index* ix, const char* const* 
                 st = order_pool(sb, sb->hits.p, sb->h_nhits(), sb->own_stream);
                 if (st != COBS_GPU_OK) return st;
             }
+            if (grow && !overflow && sb->pool_sorted && sb->h_hits.size() > cap - used) {
+                // room for this pass and, at the rate so far, for the passes to come
+                const size_t have = used + sb->h_hits.size();
+                const size_t want = std::max<size_t>(have + have / 4 + 1024, (size_t)((double)have * (double)nq / (double)std::max<size_t>(ps.g1, 1) * 1.125));
+                if (cobs_gpu_status gs = grow->grow_keep(want, used); gs != COBS_GPU_OK) return gs;
+                hits = grow->p;
+                cap = grow->cap;
+            }
             if (sb->pool_sorted && sb->h_hits.size() <= cap - used && (sb->h_hits.empty() || hits)) {
                 const cobs_amd::HitDev* rec = sb->h_hits.data();
                 const size_t n = sb->h_hits.size();
@@ -331,6 +350,7 @@ static cobs_gpu_status search_batch_impl(cobs_gpu_index* ix, const char* const* 
                 for (size_t q = ps.g0; q < ps.g1; ++q) hit_offsets[q + 1] = used + sb->h_hit_off[q - ps.g0 + 1];
                 used += n;
                 ix->timers[4] += now_s() - t0;
+                if (ix->tune.trace) std::fprintf(stderr, "[cobs_gpu] pass of queries %zu..%zu: %zu hits ordered and handed over in %.3f ms\n", ps.g0, ps.g1, n, (now_s() - t0) * 1e3);
                 return COBS_GPU_OK;
             }
             ix->timers[4] += now_s() - t0;
@@ -468,7 +488,7 @@ cobs_gpu_status cobs_gpu_search_batch_view(cobs_gpu_index* ix, const char* const
         for (;;) {
             if (cobs_gpu_status rs = ar.reserve(std::max<size_t>(cap, 1)); rs != COBS_GPU_OK) return rs;
             const cobs_gpu_status st = search_batch_impl(ix, queries, lens, nq, threshold, num_results, ar.p, ar.cap,
-                                                         ar.offs.data(), bad_query);
+                                                         ar.offs.data(), bad_query, &ar);
             if (st == COBS_GPU_ERR_CAPACITY && ar.offs[nq] > ar.cap) {   // hit_offsets[nq] holds the needed size
                 cap = ar.offs[nq];
                 continue;

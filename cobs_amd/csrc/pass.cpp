@@ -409,6 +409,17 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
         HIP_TRY(hipEventRecord(ev[3], st));
         scan_marked = true;
     }
+    if (b->scan_after) {
+        // a pass of the host-buffer API: its upload and K1 ran beside the scan of the pass before it; the scans follow
+        // each other (host_api.cpp: host_pass_begin)
+        HIP_TRY(hipStreamWaitEvent(st, b->scan_after, 0));
+        b->scan_after = nullptr;
+        if (!scan_marked) {
+            HIP_TRY(hipEventRecord(ev[3], st));
+            b->ev_split[b->run_seq % cobs_gpu_batch::kRing] = true;
+            scan_marked = true;
+        }
+    }
     // scan geometry of every (file, chunk); with tile-level top-k also the files' places in the candidate pool
     std::vector<std::vector<ScanGeom>> geoms(ix->parts.size());
     std::vector<uint64_t> cand_off(ix->parts.size() + 1, 0);

@@ -215,6 +215,8 @@ cobs_gpu_status order_pool(cobs_gpu_batch* b, const HitDev* d_pool, uint64_t n, 
     if (nq == 0 || n == 0) return COBS_GPU_OK;
     if (n > 0xFFFFFFF0ull) return fail(COBS_GPU_ERR_UNSUPPORTED, "hit pool beyond 2^32 records");
     HIP_TRY(hipSetDevice(b->ix->device));
+    const bool trace = b->ix->tune.trace;
+    const double tr0 = trace ? now_s() : 0.0;
     HIP_TRY(b->pool_idx.reserve(3 * (nq + 1)));
     HIP_TRY(b->pool_tmp.reserve((size_t)n));
     HIP_TRY(b->pool_out.reserve((size_t)n));
@@ -241,11 +243,13 @@ cobs_gpu_status order_pool(cobs_gpu_batch* b, const HitDev* d_pool, uint64_t n, 
         HIP_TRY(hipStreamSynchronize(st));          // (`flags` is pageable and goes out of scope)
         a.single = b->pool_single.p;
     }
+    const double tr1 = trace ? now_s() : 0.0;
     HIP_TRY(hipMemsetAsync(b->pool_idx.p, 0, 3 * (nq + 1) * sizeof(uint32_t), st));
     HIP_TRY(launch_order_pool(a, st));
     HIP_TRY(hipMemcpyAsync(b->h_pool.p, a.off, (nq + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(b->h_pool.p + off_bytes, a.out, (size_t)n * sizeof(HitDev), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    const double tr2 = trace ? now_s() : 0.0;
     const uint32_t* off = reinterpret_cast<const uint32_t*>(b->h_pool.p);
     const HitDev* rec = reinterpret_cast<const HitDev*>(b->h_pool.p + off_bytes);
     for (size_t q = 0; q <= nq; ++q) b->h_hit_off[q] = off[q];
@@ -261,6 +265,9 @@ cobs_gpu_status order_pool(cobs_gpu_batch* b, const HitDev* d_pool, uint64_t n, 
             return x.doc < y.doc;
         });
     }
+    if (trace)
+        std::fprintf(stderr, "[cobs_gpu] hit pool of %llu records ordered: set-up %.3f ms, device + copy home %.3f ms, host lists %.3f ms\n",
+                     (unsigned long long)n, (tr1 - tr0) * 1e3, (tr2 - tr1) * 1e3, (now_s() - tr2) * 1e3);
     return COBS_GPU_OK;
 }
 

@@ -274,8 +274,24 @@ class Search:
             cap = nq * min(num_results, self.total_counts)
         elif threshold <= 0:
             cap = nq * self.total_counts          # every document is a result
+        elif type(self)._search_batch_call is not Search._search_batch_call:
+            cap = 16 * nq + 1024                  # (several GPUs behind one handle: grown on demand, the call repeated)
         else:
-            cap = 16 * nq + 1024                  # grown on demand (ERR_CAPACITY reports the size)
+            # the number of hits is only known when the search has run (ERR_CAPACITY reports it, and the WHOLE call would
+            # be made a second time): the view call collects them in the arena the library grows as the passes come
+            # home; the finished lists are copied out of it once (12 bytes per hit)
+            hp, op, bad = C.POINTER(Hit)(), C.POINTER(C.c_size_t)(), C.c_size_t(0)
+            check(self._lib.cobs_gpu_search_batch_view(self._h, arr, lens, nq, float(threshold), 0,
+                                                       C.byref(hp), C.byref(op), C.byref(bad)))
+            offs = np.array(np.ctypeslib.as_array(op, shape=(nq + 1,)).view(np.uint64))
+            n = int(offs[nq])
+            if out is not None and out.dtype == self.HIT_DTYPE and out.flags.c_contiguous and out.size >= n:
+                hits = out
+            else:
+                hits = self._result_buffer(max(n, 1))
+            if n:
+                C.memmove(hits.ctypes.data, hp, n * 12)
+            return offs, hits[:n]
         cap = max(1, cap)
         offs = np.zeros(nq + 1, dtype=np.uint64)
         bad = C.c_size_t(0)
@@ -402,6 +418,11 @@ class Search:
     def graph_replays(self):
         """small host-API passes served by a captured hipGraph so far"""
         return int(self._lib.cobs_gpu_graph_replays(self._h))
+
+    @property
+    def host_passes(self):
+        """device passes the host-buffer calls have launched on this handle so far"""
+        return int(self._lib.cobs_gpu_host_passes(self._h))
 
     def stream_counters(self):
         """out-of-core handles: (chunks fetched row by row, chunks copied whole) over all passes so far"""

@@ -85,6 +85,10 @@ cobs_gpu_status cobs_gpu_batch_phase_stamps(cobs_gpu_batch* b, uint64_t* out, si
  * parameters) comes along and replayed with one launch afterwards;
  * this counts the replays (diagnostics; tuning key "graph" = 0 turns the path off). */
 uint64_t cobs_gpu_graph_replays(const cobs_gpu_index* ix);
+/* Device passes the host-buffer calls (cobs_gpu_search, _search_batch, _search_batch_view, _counts) have launched on this
+ * handle so far, replays included: a call is cut into passes (cobs_gpu.h), and a call that came back with
+ * COBS_GPU_ERR_CAPACITY and was made again has paid for its passes twice -- the view call grows its arena instead. */
+uint64_t cobs_gpu_host_passes(const cobs_gpu_index* ix);
 
 /* Out-of-core handles (hbm_budget_bytes): how the chunks of all passes so far were brought into HBM.
  * out[0] = chunks whose looked-up rows were fetched one by one from the registered file mapping (a batch that

@@ -19,6 +19,7 @@
 // SearchResult::doc_name points into strings owned by the Search object.
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -228,7 +229,7 @@ public:
         size_t cap;
         if (num_results > 0) cap = (num_results > total ? total : num_results) * queries.size();
         else if (threshold <= 0.0) cap = total * queries.size();
-        else cap = 16 * queries.size() + 1024;
+        else cap = std::max<size_t>(16 * queries.size(), (size_t)(hits_per_query_ * 1.25 * (double)queries.size())) + 1024;
         size_t bad = 0;
         cobs_gpu_status st;
         for (;;) {
@@ -242,6 +243,8 @@ public:
             break;
         }
         check(st);
+        if (threshold > 0.0 && num_results == 0 && !queries.empty())       // sizes the next thresholded calls: no second run
+            hits_per_query_ = std::max((double)offs[queries.size()] / (double)queries.size(), 0.95 * hits_per_query_);
         results.resize(queries.size());
         for (size_t q = 0; q < queries.size(); ++q) {
             results[q].resize(offs[q + 1] - offs[q]);
@@ -264,6 +267,7 @@ private:
     }
     cobs_gpu_index* ix_ = nullptr;
     std::vector<cobs_gpu_hit> hits_;
+    double hits_per_query_ = 0.0;
 };
 
 //! The same operator over SEVERAL GPUs of one node, one process: the index is sharded by
@@ -304,7 +308,7 @@ public:
         size_t cap;
         if (num_results > 0) cap = (num_results > total ? total : num_results) * queries.size();
         else if (threshold <= 0.0) cap = total * queries.size();
-        else cap = 16 * queries.size() + 1024;
+        else cap = std::max<size_t>(16 * queries.size(), (size_t)(hits_per_query_ * 1.25 * (double)queries.size())) + 1024;
         size_t bad = 0;
         cobs_gpu_status st;
         for (;;) {
@@ -319,6 +323,8 @@ public:
             break;
         }
         check(st);
+        if (threshold > 0.0 && num_results == 0 && !queries.empty())       // sizes the next thresholded calls: no second run
+            hits_per_query_ = std::max((double)offs[queries.size()] / (double)queries.size(), 0.95 * hits_per_query_);
         results.resize(queries.size());
         for (size_t q = 0; q < queries.size(); ++q) {
             results[q].resize(offs[q + 1] - offs[q]);
@@ -343,6 +349,7 @@ private:
     }
     cobs_gpu_multi* m_ = nullptr;
     std::vector<cobs_gpu_hit> hits_;
+    double hits_per_query_ = 0.0;
 };
 
 }  // namespace cobs_gpu

@@ -889,3 +889,60 @@ def test_score_histogram_is_the_distribution_of_the_rows(gpu_lib, oracle, tmp_pa
             br.sync()
             tot += br.score_histogram(nb)
         assert np.array_equal(tot, h)
+
+
+def test_a_thresholded_call_with_many_hits_is_not_run_twice(gpu_lib, oracle, tmp_path):
+    """the number of hits of a thresholded call is not known before it has run.  cobs_gpu_search_batch reports
+    ERR_CAPACITY with the size, and the caller repeats the WHOLE search; the view call grows the arena it owns while the
+    passes come home (cobs_gpu_host_passes counts device passes), and the Python mirror's array form copies out of it"""
+    q_long = oracle.random_sequence(4000, 92)
+    p = cases.make_classic(cases.tmp(tmp_path, "many.cobs_classic"), 203, 1201, 1, 31, 1, 0.3, 14,
+                           planted={9: 1.0, 120: 0.7}, query=q_long[:120])
+    ix = oracle.Index.open(p)
+    rng = np.random.default_rng(23)
+    starts = rng.integers(0, 3900, size=70001)
+    lens = rng.integers(31, 90, size=70001)
+    queries = [q_long[int(a):int(a) + int(n)] for a, n in zip(starts, lens)]
+    s = gpu_lib.Search(p)
+    n0 = s.host_passes
+    s.search_arrays(queries, 0.0, 3)                      # a call whose result size is known beforehand
+    one_run = s.host_passes - n0
+    assert one_run >= 4
+    n0 = s.host_passes
+    offs_v, hits_v = s.search_view(queries, 0.3, 0)       # ~ 100 of 203 documents per query: far beyond the first guess
+    assert s.host_passes - n0 == one_run
+    assert len(hits_v) > 40 * len(queries)
+    offs_v, hits_v = np.array(offs_v), np.array(hits_v)
+    for i in [0, 1, 17500, 35000, 70000] + [int(x) for x in rng.integers(0, 70001, size=30)]:
+        want = [(f, d, sc) for (f, d, _n, sc) in oracle.search(ix, queries[i], 0.3, 0)]
+        assert hits_v[int(offs_v[i]):int(offs_v[i + 1])].tolist() == want, i
+    # the array form of the Python mirror goes through the arena too (one copy of the finished lists)
+    s2 = gpu_lib.Search(p)
+    n0 = s2.host_passes
+    offs_a, hits_a = s2.search_arrays(queries, 0.3, 0)
+    assert s2.host_passes - n0 == one_run
+    assert np.array_equal(offs_a, offs_v) and np.array_equal(hits_a, hits_v)
+    del offs_a, hits_a
+    # the C call into a caller's buffer: ERR_CAPACITY + the size, nothing written beyond the buffer; the caller repeats it
+    import ctypes as C
+    from cobs_amd import _capi
+    qs = queries[:20000]
+    arr = (C.c_char_p * len(qs))(*qs)
+    lens = (C.c_size_t * len(qs))(*[len(q) for q in qs])
+    offs_c = np.zeros(len(qs) + 1, dtype=np.uint64)
+    small = np.zeros(1000 + 8, dtype=s2.HIT_DTYPE)
+    small["score"][1000:] = 0xABCDEF
+    bad = C.c_size_t(0)
+    st = s2._lib.cobs_gpu_search_batch(s2._h, arr, lens, len(qs), 0.3, 0, C.cast(small.ctypes.data, C.POINTER(_capi.Hit)), 1000,
+                                       C.cast(offs_c.ctypes.data, C.POINTER(C.c_size_t)), C.byref(bad))
+    assert st == _capi.ERR_CAPACITY and int(offs_c[len(qs)]) == int(offs_v[len(qs)])
+    assert (small["score"][1000:] == 0xABCDEF).all()
+    full = np.zeros(int(offs_c[len(qs)]), dtype=s2.HIT_DTYPE)
+    st = s2._lib.cobs_gpu_search_batch(s2._h, arr, lens, len(qs), 0.3, 0, C.cast(full.ctypes.data, C.POINTER(_capi.Hit)), len(full),
+                                       C.cast(offs_c.ctypes.data, C.POINTER(C.c_size_t)), C.byref(bad))
+    assert st == 0 and np.array_equal(offs_c, offs_v[:len(qs) + 1]) and np.array_equal(full, hits_v[:len(full)])
+    # a smaller arena call afterwards, and one with fewer hits: same memory, right lists
+    offs_w, hits_w = s.search_view(queries[:5], 0.9, 0)
+    for i in range(5):
+        want = [(f, d, sc) for (f, d, _n, sc) in oracle.search(ix, queries[i], 0.9, 0)]
+        assert hits_w[int(offs_w[i]):int(offs_w[i + 1])].tolist() == want, i
