@@ -150,7 +150,9 @@ cobs_gpu_status cobs_gpu_search(cobs_gpu_index* ix, const char* query, size_t le
  * entries; hits of query i are hits[hit_offsets[i] .. hit_offsets[i+1]).  A query with
  * bad input fails the whole call; *bad_query (optional) receives its index.
  * If cap is too small the call returns COBS_GPU_ERR_CAPACITY and hit_offsets[nq]
- * holds the capacity a retry needs (hit_offsets stay valid, hits do not).      */
+ * holds the capacity a retry needs (hit_offsets stay valid, hits do not); the retry is
+ * the whole search again -- size a thresholded call by the hits per query of earlier calls,
+ * or use cobs_gpu_search_batch_view (cobs_gpu_batch.h), whose arena grows instead. */
 cobs_gpu_status cobs_gpu_search_batch(cobs_gpu_index* ix, const char* const* queries,
                                       const size_t* lens, size_t nq,
                                       double threshold, size_t num_results,

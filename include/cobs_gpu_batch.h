@@ -59,7 +59,10 @@ cobs_gpu_status cobs_gpu_plant(cobs_gpu_index* ix, size_t file_no, const char* t
  * where the host offers them on request) -- and stay valid until the next search call on this handle.  The form for a
  * caller that would otherwise allocate a fresh result array per call: the reference's default call returns one record per
  * document and query (classic_search.cpp:450), 307 MB for 256 queries x 100 000 documents, and a fresh array costs
- * 75 000 first-touch page faults per call.  (The reference's own callers keep ONE result vector: src/cobs.cpp:618-626.) */
+ * 75 000 first-touch page faults per call.  (The reference's own callers keep ONE result vector: src/cobs.cpp:618-626.)
+ * It is also the form for a THRESHOLDED call whose number of hits the caller cannot guess: the arena grows while the
+ * passes of the call come home, where cobs_gpu_search_batch can only report COBS_GPU_ERR_CAPACITY after the whole search
+ * has run and be called a second time. */
 cobs_gpu_status cobs_gpu_search_batch_view(cobs_gpu_index* ix, const char* const* queries, const size_t* lens, size_t nq,
                                            double threshold, size_t num_results, const cobs_gpu_hit** hits,
                                            const size_t** hit_offsets, size_t* bad_query);
