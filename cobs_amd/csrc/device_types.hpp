@@ -232,6 +232,21 @@ struct RankArgs {
     uint32_t limit;
     uint32_t score_bytes;
     uint32_t pack_bits;          // 0: 8-byte records
+    uint32_t* bin_count;         // a single pass (first and last) only, may be null: [nq][2^bits] records per bin, bin =
+                                 // 2^bits - 1 - score -- with them the ORDER of the slots alone tells every record's score
+};
+
+// The ranked records of full lists as a bit stream of slots (rank_kernels.hip: pack_slots_kernel): record p of query q --
+// in[q * in_stride + p] = score << slot_bits | slot -- becomes bits [p * slot_bits, (p + 1) * slot_bits) of the query's
+// `words` dwords; the scores travel as RankArgs::bin_count.  C3: 17 bits per result over PCIe instead of 32.
+struct SlotPackArgs {
+    const uint32_t* in;
+    uint32_t* out;               // [nq][words]
+    uint64_t in_stride;
+    uint32_t n;                  // records per query
+    uint32_t words;              // dwords per query: >= ceil(n * slot_bits / 32)
+    uint32_t slot_bits;          // 1 .. 31
+    uint32_t nq;
 };
 
 // The distribution of the scores of a pass (rank_kernels.hip: score_hist_kernel) -- what `cobs benchmark-fpr --dist`

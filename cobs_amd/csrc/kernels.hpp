@@ -31,6 +31,7 @@ hipError_t launch_topk(const TopkArgs& a, hipStream_t stream);
 
 // Ranking of every document (rank_kernels.hip): one pass of the stable radix sort by score; a.nq work-groups.
 hipError_t launch_rank(const RankArgs& a, bool first, bool last, hipStream_t stream);
+hipError_t launch_pack_slots(const SlotPackArgs& a, hipStream_t stream);
 // Distribution of the scores of a pass over its real documents (rank_kernels.hip): nq x nranges work-groups.
 hipError_t launch_score_hist(const HistArgs& a, hipStream_t stream);
 

@@ -154,6 +154,8 @@ struct RankWork {
     DevBuf<uint2> out[2];               // (slot, score) records of a span of queries, in rank order
     DevBuf<uint2> pairs[2];
     DevBuf<uint32_t> cnt[2];            // [span]: results per query; npass of multi-pass sorts behind it
+    DevBuf<uint32_t> packed[2];         // slim records: the slots of a span as a bit stream (SlotPackArgs)
+    DevBuf<uint32_t> bins[2];           // ... and its records per score (RankArgs::bin_count)
     DevBuf<RankPart> parts;
     DevBuf<uint8_t> by_score;
     PinnedBuf<uint8_t> land[kDepth];    // records of a piece, then its counts
@@ -173,6 +175,81 @@ namespace {
 
 constexpr size_t kSpanBytes = 512u << 20;      // records one kernel launch orders (two such device buffers)
 
+// records [first, first + cnt) of a source `rec(i, slot, score)` reads (called with ascending i) -> d[0 .. cnt)
+template <class Rec>
+void emit_hits(cobs_gpu_hit* d, size_t first, size_t cnt, const std::vector<RankPart>& parts, Rec rec) {
+    static_assert(sizeof(cobs_gpu_hit) == 12, "three u32 per result");
+    if (parts.size() == 1) {
+        const RankPart pt = parts[0];
+        const uint32_t bias = pt.doc_first - pt.slot0, f = pt.file_no;
+        size_t i = 0;
+#if defined(__SSE2__)
+        if ((reinterpret_cast<uintptr_t>(d) & 3u) == 0) {
+            for (; i < cnt && (reinterpret_cast<uintptr_t>(d + i) & 15u) != 0; ++i) {     // at most 3: 12 i mod 16
+                uint32_t slot, score;
+                rec(first + i, slot, score);
+                d[i] = cobs_gpu_hit{f, slot + bias, score};
+            }
+            for (; i + 4 <= cnt; i += 4) {
+                uint32_t sl[4], sc[4];
+                for (int j = 0; j < 4; ++j) { rec(first + i + j, sl[j], sc[j]); sl[j] += bias; }
+                __m128i* o = reinterpret_cast<__m128i*>(d + i);
+                _mm_stream_si128(o + 0, _mm_set_epi32((int)f, (int)sc[0], (int)sl[0], (int)f));
+                _mm_stream_si128(o + 1, _mm_set_epi32((int)sl[2], (int)f, (int)sc[1], (int)sl[1]));
+                _mm_stream_si128(o + 2, _mm_set_epi32((int)sc[3], (int)sl[3], (int)f, (int)sc[2]));
+            }
+            _mm_sfence();
+        }
+#endif
+        for (; i < cnt; ++i) {
+            uint32_t slot, score;
+            rec(first + i, slot, score);
+            d[i] = cobs_gpu_hit{f, slot + bias, score};
+        }
+        return;
+    }
+    for (size_t i = 0; i < cnt; ++i) {
+        uint32_t slot, score;
+        rec(first + i, slot, score);
+        size_t p = 0;
+        while (p + 1 < parts.size() && slot >= parts[p + 1].slot0) ++p;
+        d[i] = cobs_gpu_hit{parts[p].file_no, parts[p].doc_first + (slot - parts[p].slot0), score};
+    }
+}
+
+// The slim form of FULL lists (every real document of every query in score order: the reference's default call).  Per
+// query `words` dwords of slots -- record p = bits [p * slot_bits, (p + 1) * slot_bits) of that stream -- and `nbins`
+// counts, bin = nbins - 1 - score: the records are ordered by score, so the counts say where every score begins
+// (rank_kernels.hip: RankArgs::bin_count, pack_slots_kernel).  `nq` queries of `stride` records each -> dst.
+// (the stream of a query is read 8 bytes at a time: `words` leaves two dwords behind the last record)
+void expand_slim(ExpandPool* pool, cobs_gpu_hit* dst, const uint32_t* packed, const uint32_t* bins, size_t nq, size_t stride,
+                 size_t words, uint32_t slot_bits, uint32_t nbins, const std::vector<RankPart>& parts) {
+    const uint64_t smask = (1ull << slot_bits) - 1ull;
+    const size_t kPiece = 64u << 10;                         // records per job, at most; a job stays inside one query
+    const size_t per_q = std::max<size_t>(1, (stride + kPiece - 1) / kPiece);
+    const size_t job_n = (stride + per_q - 1) / per_q;       // (equal jobs: 100 000 records = 2 x 50 000, not 65 536 + 34 464)
+    auto work = [&](size_t j) {
+        const size_t q = j / per_q, p0 = (j % per_q) * job_n, p1 = std::min(stride, p0 + job_n);
+        if (p0 >= p1) return;
+        const uint32_t* bq = bins + q * nbins;
+        const uint8_t* pk = reinterpret_cast<const uint8_t*>(packed + q * words);
+        uint32_t bin = 0;
+        size_t upto = bq[0];                                 // records in bins [0, bin]
+        emit_hits(dst + q * stride + p0, p0, p1 - p0, parts, [=](size_t p, uint32_t& slot, uint32_t& score) mutable {
+            while (upto <= p && bin + 1u < nbins) upto += bq[++bin];
+            score = nbins - 1u - bin;
+            const uint64_t bit = (uint64_t)p * slot_bits;
+            uint64_t v;
+            std::memcpy(&v, pk + (bit >> 5) * 4u, 8);
+            slot = (uint32_t)((v >> (bit & 31u)) & smask);
+        });
+    };
+    const size_t jobs = nq * per_q;
+    if (jobs <= 1 || !pool) { for (size_t j = 0; j < jobs; ++j) work(j); return; }
+    const std::function<void(size_t)> job = work;
+    pool->run(jobs, job);
+}
+
 // `n` records of the pinned landing buffer -> cobs_gpu_hit records in caller memory, with the pool's threads: the slot
 // of the ranked row becomes (file, document).  pack_bits == 0: (slot, score) pairs of 8 bytes; else one u32 per record,
 // score << pack_bits | slot (the form the device writes whenever slot and score fit 32 bits together).
@@ -181,53 +258,14 @@ constexpr size_t kSpanBytes = 512u << 20;      // records one kernel launch orde
 // 16-byte non-temporal stores -- no read-for-ownership of 307 MB the caller has not looked at yet.
 void expand_records(ExpandPool* pool, cobs_gpu_hit* dst, const void* src, size_t n, uint32_t pack_bits,
                     const std::vector<RankPart>& parts) {
-    static_assert(sizeof(cobs_gpu_hit) == 12, "three u32 per result");
     const uint32_t smask = pack_bits ? (1u << pack_bits) - 1u : 0u;
     auto work = [&parts, pack_bits, smask](cobs_gpu_hit* d, const void* sv, size_t first, size_t cnt) {
-        auto emit = [&](auto rec) {
-            if (parts.size() == 1) {
-                const RankPart pt = parts[0];
-                const uint32_t bias = pt.doc_first - pt.slot0, f = pt.file_no;
-                size_t i = 0;
-#if defined(__SSE2__)
-                if ((reinterpret_cast<uintptr_t>(d) & 3u) == 0) {
-                    for (; i < cnt && (reinterpret_cast<uintptr_t>(d + i) & 15u) != 0; ++i) {     // at most 3: 12 i mod 16
-                        uint32_t slot, score;
-                        rec(first + i, slot, score);
-                        d[i] = cobs_gpu_hit{f, slot + bias, score};
-                    }
-                    for (; i + 4 <= cnt; i += 4) {
-                        uint32_t sl[4], sc[4];
-                        for (int j = 0; j < 4; ++j) { rec(first + i + j, sl[j], sc[j]); sl[j] += bias; }
-                        __m128i* o = reinterpret_cast<__m128i*>(d + i);
-                        _mm_stream_si128(o + 0, _mm_set_epi32((int)f, (int)sc[0], (int)sl[0], (int)f));
-                        _mm_stream_si128(o + 1, _mm_set_epi32((int)sl[2], (int)f, (int)sc[1], (int)sl[1]));
-                        _mm_stream_si128(o + 2, _mm_set_epi32((int)sc[3], (int)sl[3], (int)f, (int)sc[2]));
-                    }
-                    _mm_sfence();
-                }
-#endif
-                for (; i < cnt; ++i) {
-                    uint32_t slot, score;
-                    rec(first + i, slot, score);
-                    d[i] = cobs_gpu_hit{f, slot + bias, score};
-                }
-                return;
-            }
-            for (size_t i = 0; i < cnt; ++i) {
-                uint32_t slot, score;
-                rec(first + i, slot, score);
-                size_t p = 0;
-                while (p + 1 < parts.size() && slot >= parts[p + 1].slot0) ++p;
-                d[i] = cobs_gpu_hit{parts[p].file_no, parts[p].doc_first + (slot - parts[p].slot0), score};
-            }
-        };
         if (pack_bits) {
             const uint32_t* s = static_cast<const uint32_t*>(sv);
-            emit([=](size_t i, uint32_t& slot, uint32_t& score) { slot = s[i] & smask; score = s[i] >> pack_bits; });
+            emit_hits(d, first, cnt, parts, [=](size_t i, uint32_t& slot, uint32_t& score) { slot = s[i] & smask; score = s[i] >> pack_bits; });
         } else {
             const uint2* s = static_cast<const uint2*>(sv);
-            emit([=](size_t i, uint32_t& slot, uint32_t& score) { slot = s[i].x; score = s[i].y; });
+            emit_hits(d, first, cnt, parts, [=](size_t i, uint32_t& slot, uint32_t& score) { slot = s[i].x; score = s[i].y; });
         }
     };
     const size_t kPiece = 64u << 10;         // records per job
@@ -332,6 +370,14 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
     while (slot_bits < 32u && (1ull << slot_bits) < row_elems) ++slot_bits;
     const uint32_t pack_bits = (ix->tune.rank_pack != 0 && slot_bits + planes <= 32u) ? slot_bits : 0u;
     const size_t rec = pack_bits ? sizeof(uint32_t) : sizeof(uint2);
+    // FULL lists in score order (the reference's default call: threshold 0, no limit) cross PCIe slimmer still: the order
+    // of the slots plus the number of records per score say everything -- C3: 17 bits per result instead of 32, 54 MB
+    // instead of 102 MB for 256 queries (expand_slim above; tuning key rank_slim = 0: the 4-byte records, A/B)
+    bool slim = ix->tune.rank_slim != 0 && pack_bits != 0 && npasses == 1 && limit == 0 && !(b->threshold > 0.0) && stride == per_query;
+    for (size_t q = q_first; slim && q < q_first + nq; ++q) slim = by_score[q] != 0;
+    const uint32_t nbins = 1u << pbits;
+    const size_t words = slim ? (stride * pack_bits + 31) / 32 + 2 : 0;             // dwords of one query's slot stream
+    const size_t qbytes = slim ? (words + nbins) * sizeof(uint32_t) : stride * rec;  // what crosses PCIe per query
     // Two granularities.  A SPAN is what one kernel launch orders: up to 512 MiB of records -- one work-group per
     // query, and a work-group alone takes ~0.8 ms for 100 000 documents (dependent loads, one group per CU), so a
     // launch wants hundreds of queries to fill the device (launching per 32 MiB window left 84 % of the CUs idle and
@@ -341,14 +387,16 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
     // (a piece = what is in flight per stage of the PCIe | expansion pipeline: the head of a call is the first piece's
     // crossing, its tail the last piece's expansion, in between both overlap -- tuning key rank_window_kib)
     const size_t window = (size_t)std::max<uint32_t>(ix->tune.rank_window_kib, 256u) << 10;
-    const size_t pq = std::max<size_t>(1, std::min<size_t>(sq, window / (stride * rec)));   // queries per piece
-    const size_t land_bytes = (pq * stride * rec + 15) / 16 * 16;
+    const size_t pq = std::max<size_t>(1, std::min<size_t>(sq, window / qbytes));   // queries per piece
+    const size_t land_bytes = (pq * qbytes + 15) / 16 * 16;
     constexpr size_t kDepth = RankWork::kDepth;
     {   // the workspace: if the device or the pinned pool cannot give it, the caller ranks on the host as before
         bool ok = true;
         for (int i = 0; i < 2 && ok; ++i)
             ok = w.out[i].reserve((sq * stride * rec + sizeof(uint2) - 1) / sizeof(uint2)) == hipSuccess && w.cnt[i].reserve(2 * sq) == hipSuccess;
         for (size_t i = 0; i < kDepth && ok; ++i) ok = w.land[i].reserve(land_bytes + 4 * pq) == hipSuccess;
+        for (int i = 0; i < 2 && ok && slim; ++i)
+            ok = w.packed[i].reserve(sq * words) == hipSuccess && w.bins[i].reserve(sq * nbins) == hipSuccess;
         if (ok && npasses > 1)
             for (auto& pr : w.pairs) ok = ok && pr.reserve(sq * row_elems) == hipSuccess;
         if (!ok) {
@@ -385,12 +433,24 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
         a.limit = (uint32_t)std::min<size_t>(stride, 0xFFFFFFFFu);
         a.score_bytes = b->elem_bytes;
         a.pack_bits = pack_bits;
+        a.bin_count = slim ? w.bins[s].p : nullptr;
         for (uint32_t ps = 0; ps < npasses; ++ps) {
             a.shift = ps * pbits;
             a.bits = std::min(pbits, planes - a.shift);
             a.src = w.pairs[(ps + 1) & 1].p;
             a.dst = w.pairs[ps & 1].p;
             HIP_TRY(launch_rank(a, ps == 0, ps + 1 == npasses, st));
+        }
+        if (slim) {
+            SlotPackArgs pa{};
+            pa.in = reinterpret_cast<const uint32_t*>(w.out[s].p);
+            pa.out = w.packed[s].p;
+            pa.in_stride = stride;
+            pa.n = (uint32_t)stride;
+            pa.words = (uint32_t)words;
+            pa.slot_bits = pack_bits;
+            pa.nq = (uint32_t)n;
+            HIP_TRY(launch_pack_slots(pa, st));
         }
         HIP_TRY(hipEventRecord(w.ranked[s], st));
         return COBS_GPU_OK;
@@ -406,8 +466,15 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
         const int s = (int)(pc.span & 1), l = (int)(pi % kDepth);
         const size_t off = pc.q0 - pc.span * sq;                 // queries into the span
         HIP_TRY(hipStreamWaitEvent(w.copy_stream, w.ranked[s], 0));
-        HIP_TRY(hipMemcpyAsync(w.land[l].p, reinterpret_cast<const uint8_t*>(w.out[s].p) + off * stride * rec, pc.n * stride * rec,
-                               hipMemcpyDeviceToHost, w.copy_stream));
+        if (slim) {
+            HIP_TRY(hipMemcpyAsync(w.land[l].p, w.packed[s].p + off * words, pc.n * words * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                   w.copy_stream));
+            HIP_TRY(hipMemcpyAsync(w.land[l].p + pq * words * sizeof(uint32_t), w.bins[s].p + off * nbins, pc.n * nbins * sizeof(uint32_t),
+                                   hipMemcpyDeviceToHost, w.copy_stream));
+        } else {
+            HIP_TRY(hipMemcpyAsync(w.land[l].p, reinterpret_cast<const uint8_t*>(w.out[s].p) + off * stride * rec, pc.n * stride * rec,
+                                   hipMemcpyDeviceToHost, w.copy_stream));
+        }
         HIP_TRY(hipMemcpyAsync(w.land[l].p + land_bytes, w.cnt[s].p + off, 4 * pc.n, hipMemcpyDeviceToHost, w.copy_stream));
         HIP_TRY(hipEventRecord(w.landed[l], w.copy_stream));
         if (pc.last_of_span) {
@@ -453,7 +520,12 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
         for (size_t i = 0; i < wn.n; ++i) full = full && cnt[i] == stride;
         if (full && !*overflow && wn.n * stride <= cap - *used) {
             // every query of the piece yields `stride` results (the default call): one block
-            expand_records(expand_pool(ix->device), hits + *used, recs, wn.n * stride, pack_bits, parts);
+            if (slim)
+                expand_slim(expand_pool(ix->device), hits + *used, reinterpret_cast<const uint32_t*>(recs),
+                            reinterpret_cast<const uint32_t*>(recs + pq * words * sizeof(uint32_t)), wn.n, stride, words, pack_bits,
+                            nbins, parts);
+            else
+                expand_records(expand_pool(ix->device), hits + *used, recs, wn.n * stride, pack_bits, parts);
             for (size_t i = 0; i < wn.n; ++i) {
                 *used += stride;
                 hit_offsets[wn.q0 + i + 1] = *used;
@@ -463,18 +535,24 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
         }
         for (size_t i = 0; i < wn.n; ++i) {
             const size_t n = cnt[i];
-            if (!*overflow && n <= cap - *used)
-                expand_records(expand_pool(ix->device), hits + *used, recs + i * stride * rec, n, pack_bits, parts);
-            else
+            if (!*overflow && n <= cap - *used) {
+                if (slim)
+                    expand_slim(expand_pool(ix->device), hits + *used, reinterpret_cast<const uint32_t*>(recs) + i * words,
+                                reinterpret_cast<const uint32_t*>(recs + pq * words * sizeof(uint32_t)) + i * nbins, 1, n, words,
+                                pack_bits, nbins, parts);
+                else
+                    expand_records(expand_pool(ix->device), hits + *used, recs + i * stride * rec, n, pack_bits, parts);
+            } else
                 *overflow = true;
             *used += n;
             hit_offsets[wn.q0 + i + 1] = *used;
         }
     }
     if (trace)
-        std::fprintf(stderr, "[cobs_gpu] device ranking: %zu queries x %zu records in %zu pieces; first launches %.3f ms, "
-                     "waiting for windows %.3f ms, copying out of the landing buffers %.3f ms\n",
-                     nq, stride, pieces.size(), t_prep * 1e3, t_wait * 1e3, t_copy * 1e3);
+        std::fprintf(stderr, "[cobs_gpu] device ranking: %zu queries x %zu records in %zu pieces (%s, %zu bytes per query); first "
+                     "launches %.3f ms, waiting for windows %.3f ms, copying out of the landing buffers %.3f ms\n",
+                     nq, stride, pieces.size(), slim ? "slot streams + score counts" : pack_bits ? "4-byte records" : "8-byte records",
+                     qbytes, t_prep * 1e3, t_wait * 1e3, t_copy * 1e3);
     if (rs != COBS_GPU_OK) {                    // nothing of this batch may still be in flight when the caller sees the error
         (void)hipStreamSynchronize(st);
         (void)hipStreamSynchronize(w.copy_stream);

@@ -28,6 +28,7 @@
 // reads as 0 and the stable sort leaves index order.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 
 #include "../../include/cobs_gpu.h"
@@ -171,12 +172,15 @@ __global__ __launch_bounds__(256) void rank_kernel(RankArgs a) {
         __syncthreads();
         uint32_t run = partial[tid];
         for (uint32_t b = b0; b < b1; ++b) {
+            const uint32_t before = run;
 #pragma unroll
             for (uint32_t w = 0; w < 4; ++w) {
                 const uint32_t c = hist[w * NB + b];
                 hist[w * NB + b] = run;
                 run += c;
             }
+            if constexpr (FIRST && LAST)
+                if (a.bin_count) a.bin_count[(uint64_t)qb * NB + b] = run - before;
         }
         __syncthreads();
     }
@@ -267,6 +271,25 @@ hipError_t launch_rank_t(const RankArgs& a, bool first, bool last, size_t lds, h
     return go(rank_kernel<ST, false, false>);
 }
 
+// one thread per output dword: the records whose bits it holds (at most 32 / slot_bits + 2 of them, cached reads)
+__global__ __launch_bounds__(256) void pack_slots_kernel(SlotPackArgs a) {
+    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+    if (w >= a.words) return;
+    const uint32_t s = a.slot_bits, mask = (1u << s) - 1u;
+    const uint64_t bit0 = (uint64_t)w * 32u;
+    const uint32_t r0 = (uint32_t)(bit0 / s);
+    const uint32_t o = (uint32_t)(bit0 - (uint64_t)r0 * s);         // bits of record r0 that lie in earlier dwords
+    for (uint32_t q = blockIdx.y; q < a.nq; q += gridDim.y) {
+        const uint32_t* in = a.in + (uint64_t)q * a.in_stride;
+        uint32_t r = r0;
+        uint32_t val = r < a.n ? (in[r] & mask) >> o : 0u;
+        uint32_t filled = s - o;
+        for (++r; filled < 32u; ++r, filled += s)
+            if (r < a.n) val |= (in[r] & mask) << filled;
+        a.out[(uint64_t)q * a.words + w] = val;
+    }
+}
+
 // one work-group per (query, range): an LDS histogram of up to 4096 bins, flushed with one 64-bit atomic per
 // non-empty bin; wider score ranges go to global atomics directly (queries of more than 4095 terms)
 constexpr uint32_t kHistLds = 4096;
@@ -304,6 +327,13 @@ hipError_t launch_score_hist(const HistArgs& a, hipStream_t stream) {
     else if (a.score_bytes == 2) hipLaunchKernelGGL(score_hist_kernel<uint16_t>, grid, dim3(256), 0, stream, a);
     else if (a.score_bytes == 4) hipLaunchKernelGGL(score_hist_kernel<uint32_t>, grid, dim3(256), 0, stream, a);
     else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_slots(const SlotPackArgs& a, hipStream_t stream) {
+    if (a.nq == 0 || a.words == 0) return hipSuccess;
+    if (a.slot_bits == 0 || a.slot_bits > 31) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pack_slots_kernel, dim3((a.words + 255u) / 256u, std::min<uint32_t>(a.nq, 65535u)), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

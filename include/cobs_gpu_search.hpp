@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "cobs_gpu.h"
+#include "cobs_gpu_batch.h"      // cobs_gpu_search_batch_view
 
 namespace cobs_gpu {
 
@@ -229,9 +230,23 @@ public:
         size_t cap;
         if (num_results > 0) cap = (num_results > total ? total : num_results) * queries.size();
         else if (threshold <= 0.0) cap = total * queries.size();
-        else cap = std::max<size_t>(16 * queries.size(), (size_t)(hits_per_query_ * 1.25 * (double)queries.size())) + 1024;
+        else cap = 1;                                    // (thresholded without a limit: the view call below)
         size_t bad = 0;
         cobs_gpu_status st;
+        if (threshold > 0.0 && num_results == 0) {
+            // the number of hits is not known beforehand: collected in the arena the library grows as the passes come
+            // home (cobs_gpu_batch.h) -- into a vector of a guessed size the whole search could have to run twice
+            const cobs_gpu_hit* vh = nullptr;
+            const size_t* vo = nullptr;
+            check(cobs_gpu_search_batch_view(ix_, qp.data(), ql.data(), queries.size(), threshold, 0, &vh, &vo, &bad));
+            results.resize(queries.size());
+            for (size_t q = 0; q < queries.size(); ++q) {
+                results[q].resize(vo[q + 1] - vo[q]);
+                for (size_t i = vo[q]; i < vo[q + 1]; ++i)
+                    results[q][i - vo[q]] = SearchResult(cobs_gpu_doc_name(ix_, vh[i].file_no, vh[i].doc), vh[i].score);
+            }
+            return;
+        }
         for (;;) {
             hits_.resize(cap + 1);
             st = cobs_gpu_search_batch(ix_, qp.data(), ql.data(), queries.size(), threshold,
@@ -243,8 +258,6 @@ public:
             break;
         }
         check(st);
-        if (threshold > 0.0 && num_results == 0 && !queries.empty())       // sizes the next thresholded calls: no second run
-            hits_per_query_ = std::max((double)offs[queries.size()] / (double)queries.size(), 0.95 * hits_per_query_);
         results.resize(queries.size());
         for (size_t q = 0; q < queries.size(); ++q) {
             results[q].resize(offs[q + 1] - offs[q]);
@@ -267,7 +280,6 @@ private:
     }
     cobs_gpu_index* ix_ = nullptr;
     std::vector<cobs_gpu_hit> hits_;
-    double hits_per_query_ = 0.0;
 };
 
 //! The same operator over SEVERAL GPUs of one node, one process: the index is sharded by

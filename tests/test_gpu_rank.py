@@ -158,3 +158,60 @@ def test_more_than_2_pow_22_slots_fall_back_to_pairs(gpu_lib, oracle):
         assert int(offs[-1]) == 4 * ndocs
         for i in (0, 3):
             assert _same(offs, hits, i, oracle.search_arrays(ix, queries[i], 0.0, 0)), (kmers, i)
+
+
+def test_slot_streams_with_score_counts_agree_with_records(gpu_lib, oracle, tmp_path, monkeypatch, capfd):
+    """FULL lists (threshold 0, no limit: the reference's default call) cross PCIe as a bit stream of slots -- 17 bits per
+    result at 100 000 documents -- plus the number of records per score; tuning key rank_slim = 0 sends the 4-byte records.
+    Same results either way and the oracle's: one file, mixed score widths, pieces that cut the span, two files with odd
+    document counts, a shard; a batch that holds a single-k-mer query (index order: no score counts) takes the records."""
+    monkeypatch.setenv("COBS_GPU_TRACE", "1")
+    cfg = _c3_small()
+    s = _open(gpu_lib, cfg)
+    ix = _oracle_index(oracle, cfg)
+    queries = bench.make_queries(9, 1000, seed=41) + bench.make_queries(3, 40, seed=42)
+    capfd.readouterr()
+    offs, hits = s.search_arrays(queries, 0.0, 0)
+    assert "slot streams + score counts" in capfd.readouterr().err
+    for i in (0, 5, 8, 9, 11):
+        assert _same(offs, hits, i, oracle.search_arrays(ix, queries[i], 0.0, 0)), i
+    s.set_tuning("rank_slim", 0)
+    offs2, hits2 = s.search_arrays(queries, 0.0, 0)
+    assert "4-byte records" in capfd.readouterr().err
+    assert np.array_equal(offs, offs2) and np.array_equal(hits, hits2)
+    s.set_tuning("rank_slim", 1)
+    s.set_tuning("rank_window_kib", 256)                  # one query per piece
+    offs3, hits3 = s.search_arrays(queries, 0.0, 0)
+    assert np.array_equal(offs, offs3) and np.array_equal(hits, hits3)
+    capfd.readouterr()
+    mixed = queries[:5] + [bench.make_queries(1, 1, seed=43)[0]]
+    offs4, hits4 = s.search_arrays(mixed, 0.0, 0)
+    assert "4-byte records" in capfd.readouterr().err
+    assert np.array_equal(hits4[:500000], hits[:500000])
+    assert np.array_equal(hits4[500000:]["doc"], np.arange(100000))
+    # thresholds and limits do not take the path (their lists are not full)
+    offs5, hits5 = s.search_arrays(queries[:6], 0.0, 70000)
+    for i in (0, 5):
+        assert _same(offs5, hits5, i, oracle.search_arrays(ix, queries[i], 0.0, 70000)), i
+    # a shard: its own documents
+    sh = _open(gpu_lib, cfg, shard_rank=1, shard_count=3)
+    lo, cnt = int(sh.info(0).slot_begin), int(sh.info(0).slot_count)
+    capfd.readouterr()
+    offs6, hits6 = sh.search_arrays(queries[:6], 0.0, 0)
+    assert "slot streams + score counts" in capfd.readouterr().err
+    for i in (0, 5):
+        oi, od, osc = oracle.search_arrays(ix, queries[i], 0.0, 0)
+        keep = (od >= lo) & (od < lo + cnt)
+        assert _same(offs6, hits6, i, (oi[keep], od[keep], osc[keep])), i
+    # two files, 569 and 333 documents (10-bit slots, 8- and 16-bit scores)
+    q_long = oracle.random_sequence(700, 9)
+    pa = cases.make_compact(cases.tmp(tmp_path, "s.cobs_compact"), 3 * 8 * 24 - 7, 24, [800, 1200, 1000], 1, 31, 1, 0.3, 2,
+                            planted={3: 1.0}, query=q_long)
+    pb = cases.make_classic(cases.tmp(tmp_path, "s.cobs_classic"), 333, 901, 2, 31, 1, 0.4, 3)
+    ixs = [oracle.Index.open(pa), oracle.Index.open(pb)]
+    two = gpu_lib.Search([pa, pb], device=0)
+    for qs in ([q_long[:100], q_long[40:200], q_long[:33], q_long[7:90]], [q_long, q_long[100:500], q_long[3:640], q_long[50:400]]):
+        capfd.readouterr()
+        got = two.search_hits(qs, 0.0, 0)
+        assert "slot streams + score counts" in capfd.readouterr().err
+        assert got == [cases.oracle_results(ixs, q, 0.0, 0) for q in qs]
