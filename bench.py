@@ -305,7 +305,11 @@ def end_to_end(search, batch, queries, hit_queries=None):
     # what crosses PCIe per result: one u32 (score << slot_bits | slot) where both fit 32 bits, else an 8-byte pair (rank.cpp)
     terms = max(len(q) for q in queries[:nd]) - 30
     planes = next(p for p in (4, 8, 10, 12, 16, 20, 24, 32) if p >= max(terms, 1).bit_length())
-    rec = 4 if (max(search.total_counts - 1, 1)).bit_length() + planes <= 32 else 8
+    slot_bits = max((max(search.total_counts - 1, 1)).bit_length(), 1)
+    rec = 4 if slot_bits + planes <= 32 else 8
+    if rec == 4 and planes <= 12:
+        # full lists: a bit stream of slots + the records per score of every query (rank.cpp: expand_slim)
+        rec = ((search.total_counts * slot_bits + 31) // 32 + 2 + (1 << planes)) * 4 / search.total_counts
     # the same call into a FRESH array per call (first-touch page faults of 307 MB, which the library asks to be huge
     # pages), and with the results left in the arena the library keeps on the handle (cobs_gpu_search_batch_view)
     fresh = None
@@ -331,7 +335,7 @@ def end_to_end(search, batch, queries, hit_queries=None):
                                       "fresh_result_array": {"queries_per_s": round(nd / fresh, 1), "seconds": round(fresh, 5)},
                                       "library_arena_view": {"queries_per_s": round(nd / view, 1), "seconds": round(view, 5),
                                                              "same_results": same},
-                                      "results": int(len(hits)), "pcie_record_bytes": rec,
+                                      "results": int(len(hits)), "pcie_record_bytes": round(rec, 3),
                                       "pcie_record_GBps": round(len(hits) * rec / best / 1e9, 2),
                                       "host_result_GBps": round(len(hits) * 12 / best / 1e9, 2),
                                       "ranked": "on the device; compare cpu_baseline.full_search_with_ranking_1thread"}
