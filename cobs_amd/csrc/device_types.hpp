@@ -232,6 +232,8 @@ struct RankArgs {
     uint32_t limit;
     uint32_t score_bytes;
     uint32_t pack_bits;          // 0: 8-byte records
+    uint32_t* seg_hist;          // a single pass cut into segments: [nq][4 * nseg][2^bits] (rank_kernels.hip: SEG), else null
+    uint32_t nseg;               // segments per row (<= 1: one work-group per query)
     uint32_t* bin_count;         // a single pass (first and last) only, may be null: [nq][2^bits] records per bin, bin =
                                  // 2^bits - 1 - score -- with them the ORDER of the slots alone tells every record's score
 };

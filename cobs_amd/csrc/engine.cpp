@@ -584,6 +584,9 @@ cobs_gpu_status cobs_gpu_set_tuning(cobs_gpu_index* ix, const char* key, int64_t
         t.rank_pack = value != 0;
     } else if (k == "rank_slim") {
         t.rank_slim = value != 0;
+    } else if (k == "rank_segments") {
+        if (value < 0 || value > 64) return fail(COBS_GPU_ERR_ARG, "rank_segments: 0 (by row length) .. 64");
+        t.rank_segments = (int)value;
     } else if (k == "hash_stream") {
         t.hash_stream = value != 0;
     } else if (k == "tile_topk") {
@@ -600,7 +603,7 @@ cobs_gpu_status cobs_gpu_set_tuning(cobs_gpu_index* ix, const char* key, int64_t
     } else if (k == "phase_slots") {
         t.phase_slots = value > 0 ? (uint32_t)std::min<int64_t>(value, 1 << 20) : 0;
     } else {
-        return fail(COBS_GPU_ERR_ARG, "unknown tuning key (waves, tile_w, mq, pass_bytes, pipe_chars, graph, lds_staged, device_rank, rank_pack, rank_slim, rank_window_kib, hash_stream, tile_topk, row_fetch, row_fetch_alpha, min_score_bytes)");
+        return fail(COBS_GPU_ERR_ARG, "unknown tuning key (waves, tile_w, mq, pass_bytes, pipe_chars, graph, lds_staged, device_rank, rank_pack, rank_slim, rank_segments, rank_window_kib, hash_stream, tile_topk, row_fetch, row_fetch_alpha, min_score_bytes)");
     }
     return COBS_GPU_OK;
 }

@@ -112,6 +112,7 @@ struct Tuning {
     int stream_packed = 1;      // streamed chunks keep the file's row pitch (linear PCIe copies); 0: device pitch, 2-D copies (A/B)
     int row_ranges = 1;         // a streamed sub-index larger than a stream buffer is cut by ROWS (H = 1; 0: by columns, A/B and fallback)
     int compact_terms = 1;      // the scan of a row-range unit walks the terms the unit HOLDS (a compact second table), not every term (0: A/B)
+    int rank_segments = 0;      // segments a single-pass ranking cuts a row into (0: by row length, 1: one work-group per query)
     int rank_slim = 1;          // full lists of the default call cross PCIe as slot streams + score counts (0: records, A/B)
     int rank_pack = 1;          // device-ranked records cross PCIe as one u32 where slot and score fit (0: always 8-byte pairs, A/B)
     int hash_stream = 0;        // K1 of a device-resident batch runs on the batch's own stream, K2 waits for it by event: the hashing

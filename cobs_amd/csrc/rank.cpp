@@ -156,6 +156,7 @@ struct RankWork {
     DevBuf<uint32_t> cnt[2];            // [span]: results per query; npass of multi-pass sorts behind it
     DevBuf<uint32_t> packed[2];         // slim records: the slots of a span as a bit stream (SlotPackArgs)
     DevBuf<uint32_t> bins[2];           // ... and its records per score (RankArgs::bin_count)
+    DevBuf<uint32_t> seghist;           // single-pass sorts of long rows: histograms / positions of the segments (RankArgs::seg_hist)
     DevBuf<RankPart> parts;
     DevBuf<uint8_t> by_score;
     PinnedBuf<uint8_t> land[kDepth];    // records of a piece, then its counts
@@ -387,6 +388,15 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
     // (a piece = what is in flight per stage of the PCIe | expansion pipeline: the head of a call is the first piece's
     // crossing, its tail the last piece's expansion, in between both overlap -- tuning key rank_window_kib)
     const size_t window = (size_t)std::max<uint32_t>(ix->tune.rank_window_kib, 256u) << 10;
+    // A single-pass sort of a long row is cut into segments, a work-group each (rank_kernels.hip: SEG): one work-group per
+    // query is alone on its CU and latency-bound -- 0.36 ms for 100 000 documents however few queries there are, the
+    // head of every default call.  Tuning key rank_segments: 0 = by row length, 1 = off, else that many.
+    uint32_t nseg = 1;
+    if (npasses == 1) {
+        nseg = ix->tune.rank_segments > 0 ? (uint32_t)std::min(ix->tune.rank_segments, 64)
+                                          : (row_elems >= 65536 ? 8u : row_elems >= 16384 ? 4u : row_elems >= 8192 ? 2u : 1u);
+        if (sq > 65535u) nseg = 1;
+    }
     const size_t pq = std::max<size_t>(1, std::min<size_t>(sq, window / qbytes));   // queries per piece
     const size_t land_bytes = (pq * qbytes + 15) / 16 * 16;
     constexpr size_t kDepth = RankWork::kDepth;
@@ -395,6 +405,10 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
         for (int i = 0; i < 2 && ok; ++i)
             ok = w.out[i].reserve((sq * stride * rec + sizeof(uint2) - 1) / sizeof(uint2)) == hipSuccess && w.cnt[i].reserve(2 * sq) == hipSuccess;
         for (size_t i = 0; i < kDepth && ok; ++i) ok = w.land[i].reserve(land_bytes + 4 * pq) == hipSuccess;
+        if (ok && nseg > 1 && w.seghist.reserve(sq * 4u * nseg * (size_t)nbins) != hipSuccess) {
+            (void)hipGetLastError();
+            nseg = 1;
+        }
         for (int i = 0; i < 2 && ok && slim; ++i)
             ok = w.packed[i].reserve(sq * words) == hipSuccess && w.bins[i].reserve(sq * nbins) == hipSuccess;
         if (ok && npasses > 1)
@@ -434,6 +448,8 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
         a.score_bytes = b->elem_bytes;
         a.pack_bits = pack_bits;
         a.bin_count = slim ? w.bins[s].p : nullptr;
+        a.seg_hist = nseg > 1 ? w.seghist.p : nullptr;
+        a.nseg = nseg;
         for (uint32_t ps = 0; ps < npasses; ++ps) {
             a.shift = ps * pbits;
             a.bits = std::min(pbits, planes - a.shift);

@@ -83,7 +83,12 @@ __device__ __forceinline__ uint32_t part_of(const RankArgs& a, uint32_t slot) {
 
 // FIRST: elements are the slots of the score row; else (score, slot) pairs of the previous pass.
 // LAST: results leave as (slot, score) records in rank order; else as (score, slot) pairs for the next pass.
-template <typename ST, bool FIRST, bool LAST>
+// SEG (single-pass sorts of long rows; a work-group alone on its CU is latency-bound -- 0.36 ms for 100 000 documents,
+// the head of every default call): the row is cut into gridDim.x segments, a work-group per (segment, query).
+// SEG = 1 leaves the per-wave digit histograms of its segment in a.seg_hist [query][4 * segment + wave][2^bits];
+// rank_prefix_kernel turns them into first output positions in place; SEG = 2 starts from those and scatters its segment.
+// SEG = 0: one work-group does it all (every pass of the multi-pass sorts, short rows).
+template <typename ST, bool FIRST, bool LAST, int SEG>
 __global__ __launch_bounds__(256) void rank_kernel(RankArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t NB = 1u << a.bits;
@@ -92,7 +97,9 @@ __global__ __launch_bounds__(256) void rank_kernel(RankArgs a) {
     uint32_t* stage = partial + 256;                             // [4 waves][512] keys of one block (FIRST)
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t qb = blockIdx.x;                              // query inside the window
+    const uint32_t qb = SEG ? blockIdx.y : blockIdx.x;           // query inside the window
+    const uint32_t nranges = SEG ? gridDim.x * 4u : 4u;          // contiguous element ranges, one per wave
+    const uint32_t range0 = SEG ? blockIdx.x * 4u : 0u;          // ... the first of this work-group
     const uint32_t q = a.q0 + qb;                                // query inside the batch
     const bool by_score = a.by_score[q] != 0;
     const uint32_t dmask = NB - 1u;
@@ -101,8 +108,8 @@ __global__ __launch_bounds__(256) void rank_kernel(RankArgs a) {
     const uint32_t n = FIRST ? a.nslots : a.npass[qb];
     (void)row; (void)src;
     // wave w owns the contiguous element range [w0, w1), a multiple of 512 long
-    const uint32_t per = ((n + 3u) / 4u + 511u) / 512u * 512u;
-    const uint32_t w0 = min(wave * per, n), w1 = min(w0 + per, n);
+    const uint32_t per = ((n + nranges - 1u) / nranges + 511u) / 512u * 512u;
+    const uint32_t w0 = (uint32_t)min((uint64_t)(range0 + wave) * per, (uint64_t)n), w1 = min(w0 + per, n);
     uint32_t* myh = hist + wave * NB;
     uint32_t* mystage = stage + wave * 512u;
 
@@ -118,10 +125,17 @@ __global__ __launch_bounds__(256) void rank_kernel(RankArgs a) {
         for (int j = 0; j < 8; ++j) key[j] = (d + j < pt.ndocs && s[j] >= thr) ? s[j] : kInvalid;
     };
 
-    for (uint32_t i = tid; i < 4u * NB; i += 256) hist[i] = 0;
+    uint32_t* seg_rows = nullptr;                                // this work-group's four rows of a.seg_hist
+    if constexpr (SEG != 0) seg_rows = a.seg_hist + ((uint64_t)qb * nranges + range0) * NB;
+    if constexpr (SEG == 2) {
+        for (uint32_t i = tid; i < 4u * NB; i += 256) hist[i] = seg_rows[i];
+    } else {
+        for (uint32_t i = tid; i < 4u * NB; i += 256) hist[i] = 0;
+    }
     __syncthreads();
     // ---- (1) histograms
-    if constexpr (FIRST) {
+    if constexpr (SEG == 2) {
+    } else if constexpr (FIRST) {
         uint32_t cur[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nxt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (w0 + lane * 8u < w1) load8<ST>(row, w0 + lane * 8u, cur);
         for (uint32_t i0 = w0; i0 < w1; i0 += 512) {
@@ -143,8 +157,12 @@ __global__ __launch_bounds__(256) void rank_kernel(RankArgs a) {
             atomicAdd(&myh[dmask - (by_score ? (src[i].x >> a.shift) & dmask : 0u)], 1u);
     }
     __syncthreads();
+    if constexpr (SEG == 1) {
+        for (uint32_t i = tid; i < 4u * NB; i += 256) seg_rows[i] = hist[i];
+        return;
+    }
     // ---- (2) first output position of every (wave, bin): bins ascending (= digits descending), waves ascending
-    {
+    if constexpr (SEG == 0) {
         const uint32_t seg = (NB + 255u) / 256u;
         const uint32_t b0 = tid * seg, b1 = min(b0 + seg, NB);
         uint32_t sum = 0;
@@ -254,6 +272,52 @@ __global__ __launch_bounds__(256) void rank_kernel(RankArgs a) {
     }
 }
 
+// Between the two halves of a segmented single-pass sort: the histograms of the nranges = 4 * segments element ranges of
+// a query, a.seg_hist [query][range][2^bits], become the first output position of every (range, bin) -- bins ascending
+// (= digits descending), ranges ascending inside a bin: rank_kernel's step (2) over all the segments' waves.  One
+// work-group per query; also the query's result count and, for the slim records, its records per bin.
+__global__ __launch_bounds__(256) void rank_prefix_kernel(RankArgs a, uint32_t nranges) {
+    __shared__ uint32_t partial[256];
+    const uint32_t NB = 1u << a.bits;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t qb = blockIdx.x;
+    uint32_t* g = a.seg_hist + (uint64_t)qb * nranges * NB;
+    const uint32_t seg = (NB + 255u) / 256u;
+    const uint32_t b0 = min(tid * seg, NB), b1 = min(b0 + seg, NB);
+    uint32_t sum = 0;
+    for (uint32_t r = 0; r < nranges; ++r)
+        for (uint32_t b = b0; b < b1; ++b) sum += g[(uint64_t)r * NB + b];
+    partial[tid] = sum;
+    __syncthreads();
+    if (wave == 0u) {
+        const uint32_t p0 = partial[4 * lane], p1 = partial[4 * lane + 1], p2 = partial[4 * lane + 2], p3 = partial[4 * lane + 3];
+        uint32_t incl = p0 + p1 + p2 + p3;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off);
+            if (lane >= (uint32_t)off) incl += t;
+        }
+        const uint32_t ex = incl - (p0 + p1 + p2 + p3);
+        partial[4 * lane] = ex;
+        partial[4 * lane + 1] = ex + p0;
+        partial[4 * lane + 2] = ex + p0 + p1;
+        partial[4 * lane + 3] = ex + p0 + p1 + p2;
+        if (lane == 63u) a.out_count[qb] = min(incl, a.limit);
+    }
+    __syncthreads();
+    uint32_t run = partial[tid];
+    for (uint32_t b = b0; b < b1; ++b) {
+        const uint32_t before = run;
+        for (uint32_t r = 0; r < nranges; ++r) {
+            const uint32_t c = g[(uint64_t)r * NB + b];
+            g[(uint64_t)r * NB + b] = run;
+            run += c;
+        }
+        if (a.bin_count) a.bin_count[(uint64_t)qb * NB + b] = run - before;
+    }
+}
+
 template <typename ST>
 hipError_t launch_rank_t(const RankArgs& a, bool first, bool last, size_t lds, hipStream_t stream) {
     auto go = [&](auto kern) -> hipError_t {
@@ -265,10 +329,26 @@ hipError_t launch_rank_t(const RankArgs& a, bool first, bool last, size_t lds, h
         hipLaunchKernelGGL(kern, dim3(a.nq), dim3(256), lds, stream, a);
         return hipGetLastError();
     };
-    if (first && last) return go(rank_kernel<ST, true, true>);
-    if (first) return go(rank_kernel<ST, true, false>);
-    if (last) return go(rank_kernel<ST, false, true>);
-    return go(rank_kernel<ST, false, false>);
+    if (first && last && a.nseg > 1 && a.seg_hist && a.nq <= 65535u) {
+        auto seg = [&](auto kern) -> hipError_t {
+            if (lds > 48 * 1024) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+            }
+            hipLaunchKernelGGL(kern, dim3(a.nseg, a.nq), dim3(256), lds, stream, a);
+            return hipGetLastError();
+        };
+        hipError_t e = seg(rank_kernel<ST, true, true, 1>);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(rank_prefix_kernel, dim3(a.nq), dim3(256), 0, stream, a, a.nseg * 4u);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        return seg(rank_kernel<ST, true, true, 2>);
+    }
+    if (first && last) return go(rank_kernel<ST, true, true, 0>);
+    if (first) return go(rank_kernel<ST, true, false, 0>);
+    if (last) return go(rank_kernel<ST, false, true, 0>);
+    return go(rank_kernel<ST, false, false, 0>);
 }
 
 // one thread per output dword: the records whose bits it holds (at most 32 / slot_bits + 2 of them, cached reads)

@@ -17,13 +17,18 @@ keep = np.zeros(256 * s.total_counts, dtype=s.HIT_DTYPE)
 windows = [int(x) for x in sys.argv[1:]] or [16384]
 for win in windows:
     s.set_tuning("rank_window_kib", win)
-    for slim in (1, 0):
+    for slim, nseg in ((1, 0), (1, 1), (0, 1), (1, 0), (1, 1)):
         s.set_tuning("rank_slim", slim)
-        for _ in range(2):
-            s.search_packed(text, offs, 0.0, 0, out=keep)
-        best = 1e9
-        for _ in range(7):
-            t0 = time.perf_counter()
-            s.search_packed(text, offs, 0.0, 0, out=keep)
-            best = min(best, time.perf_counter() - t0)
-        print("window %6d KiB  rank_slim %d  default call of 256 queries: %.3f ms = %.1f k queries/s" % (win, slim, best * 1e3, 256 / best / 1e3), flush=True)
+        s.set_tuning("rank_segments", nseg)
+        for nq in (256, 64, 16):
+            o = np.ascontiguousarray(offs[:nq + 1])
+            t = text[:int(o[-1])]
+            for _ in range(2):
+                s.search_packed(t, o, 0.0, 0, out=keep)
+            best = 1e9
+            for _ in range(7):
+                t0 = time.perf_counter()
+                s.search_packed(t, o, 0.0, 0, out=keep)
+                best = min(best, time.perf_counter() - t0)
+            print("window %6d KiB  rank_slim %d  rank_segments %d  default call of %3d queries: %.3f ms = %.1f k queries/s"
+                  % (win, slim, nseg, nq, best * 1e3, nq / best / 1e3), flush=True)

@@ -215,3 +215,34 @@ def test_slot_streams_with_score_counts_agree_with_records(gpu_lib, oracle, tmp_
         got = two.search_hits(qs, 0.0, 0)
         assert "slot streams + score counts" in capfd.readouterr().err
         assert got == [cases.oracle_results(ixs, q, 0.0, 0) for q in qs]
+
+
+def test_segmented_single_pass_ranking_agrees_with_one_work_group_per_query(gpu_lib, oracle):
+    """a single-pass ranking of a long row is cut into segments, a work-group each (histograms, a prefix over all
+    segments' waves, scatter); tuning key rank_segments: 1 = one work-group per query, 0 = by row length (8 at 100 000
+    documents).  Same lists for 1 / 2 / 3 / 8 / 64 segments: full lists, a limit beyond K3, thresholds from the rows,
+    a single-k-mer query (index order), a shard whose slice is no multiple of anything"""
+    cfg = _c3_small()
+    ix = _oracle_index(oracle, cfg)
+    queries = bench.make_queries(7, 1000, seed=51) + bench.make_queries(2, 40, seed=52) + [bench.make_queries(1, 1, seed=53)[0]]
+    s = _open(gpu_lib, cfg)
+    s.set_tuning("rank_segments", 1)
+    base = {}
+    for thr, lim in ((0.0, 0), (0.0, 70000), (0.31, 0)):
+        base[(thr, lim)] = s.search_arrays(queries, thr, lim)
+    for i in (0, 6, 8, 9):
+        assert _same(*base[(0.0, 0)], i, oracle.search_arrays(ix, queries[i], 0.0, 0)), i
+        assert _same(*base[(0.0, 70000)], i, oracle.search_arrays(ix, queries[i], 0.0, 70000)), i
+        assert _same(*base[(0.31, 0)], i, oracle.search_arrays(ix, queries[i], 0.31, 0)), i
+    for nseg in (0, 2, 3, 8, 64):
+        s.set_tuning("rank_segments", nseg)
+        for key, (offs0, hits0) in base.items():
+            offs, hits = s.search_arrays(queries, *key)
+            assert np.array_equal(offs, offs0) and np.array_equal(hits, hits0), (nseg, key)
+    sh = _open(gpu_lib, cfg, shard_rank=2, shard_count=7)
+    sh.set_tuning("rank_segments", 1)
+    offs0, hits0 = sh.search_arrays(queries[:6], 0.0, 0)
+    for nseg in (0, 5):
+        sh.set_tuning("rank_segments", nseg)
+        offs, hits = sh.search_arrays(queries[:6], 0.0, 0)
+        assert np.array_equal(offs, offs0) and np.array_equal(hits, hits0), nseg
