@@ -124,8 +124,8 @@ void cobs_gpu_close(cobs_gpu_index* ix);
  * measured LDS-staged variant of the scan, headline shape only), "device_rank" / "tile_topk" / "row_fetch" (0 turns the
  * on-device ranking of whole rows / the tile-level top-k / the row-selective out-of-core pass off: A/B and fallback),
  * "row_fetch_alpha", "min_score_bytes" (2 / 4: score rows at least that wide -- the reference's
- * classic_search_disable_8bit / _16bit switches, classic_search.cpp:207-209); "rank_pack" / "rank_slim" / "rank_window_kib"
- * (how the ranked results of the default call cross PCIe: 4-byte records, slot streams, piece size), "compact_terms",
+ * classic_search_disable_8bit / _16bit switches, classic_search.cpp:207-209); "rank_pack" / "rank_slim" / "rank_window_kib" / "rank_segments"
+ * (how the ranked results of the default call cross PCIe: 4-byte records, slot streams, piece size; work-groups per row), "compact_terms",
  * "hash_stream": A/B switches named where DESIGN.md 3 describes what they switch.  0 / -1 = automatic. */
 cobs_gpu_status cobs_gpu_set_tuning(cobs_gpu_index* ix, const char* key, int64_t value);
 size_t cobs_gpu_num_files(const cobs_gpu_index* ix);
