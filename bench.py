@@ -353,6 +353,44 @@ def end_to_end(search, batch, queries, hit_queries=None):
     res["threshold_0_all_scores_to_pinned_host"] = {
         "queries_per_s": round(nq / dt, 1), "seconds": round(dt, 4),
         "d2h_GB": round(t.numel() * t.element_size() / 1e9, 3)}
+    # the same in four parts: the rows of part i cross PCIe while part i + 1 is scanned (SURVEY 8d mode iii is bound by
+    # the link, not by scan + link)
+    parts = 4 if nq >= 64 else 1
+    if parts > 1:
+        subs, offs_q = [], [nq * i // parts for i in range(parts + 1)]
+        for i in range(parts):
+            bi = cobs_amd.Batch(search)
+            bi.set_queries(queries[offs_q[i]:offs_q[i + 1]])
+            subs.append(bi)
+        scan_s, copy_s = torch.cuda.Stream(), torch.cuda.Stream()
+
+        def piped():
+            for i, bi in enumerate(subs):
+                bi.run(0.0, scan_s.cuda_stream)
+                ev = torch.cuda.Event()
+                ev.record(scan_s)
+                copy_s.wait_event(ev)
+                ti = bi.counts_tensor()
+                with torch.cuda.stream(copy_s):
+                    host[offs_q[i]:offs_q[i + 1]].copy_(ti, non_blocking=True)
+            torch.cuda.synchronize()
+            for bi in subs:
+                bi.sync(scan_s.cuda_stream)
+        piped()
+        best = None
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            piped()
+            dtp = time.perf_counter() - t0
+            best = dtp if best is None else min(best, dtp)
+        batch.run(0.0, 0)
+        batch.sync()
+        same = bool(torch.equal(host[:64].to(t.device), t[:64]) and torch.equal(host[-64:].to(t.device), t[-64:]))
+        res["threshold_0_all_scores_to_pinned_host"]["in_%d_parts_scan_beside_copy" % parts] = {
+            "queries_per_s": round(nq / best, 1), "seconds": round(best, 4),
+            "d2h_GBps": round(t.numel() * t.element_size() / best / 1e9, 1), "same_rows": same}
+        del subs
     return res
 
 
