@@ -367,7 +367,9 @@ class Search:
         elif threshold <= 0:
             cap = nq * self.total_counts
         else:
-            cap = 16 * nq + 1024
+            # (a buffer that proves too small costs a second, collective, run of the whole search: sized by the hits per
+            # query of the earlier thresholded calls on this handle -- the same on every rank, as the results are)
+            cap = max(16 * nq, int((0.0 if split else self.__dict__.get("_sharded_hits_per_query", 0.0)) * nq * 1.25)) + 1024
         cap = max(1, cap)
         offs = np.zeros(nq + 1, dtype=np.uint64)
         bad = C.c_size_t(0)
@@ -386,6 +388,8 @@ class Search:
             break
         if split:
             return _split_segments(hits, offs, nq, threshold, num_results, self)
+        if threshold > 0 and num_results == 0 and nq:
+            self._sharded_hits_per_query = max(int(offs[nq]) / nq, 0.95 * self.__dict__.get("_sharded_hits_per_query", 0.0))
         rows = hits[:int(offs[nq])].tolist()
         return [rows[int(offs[q]):int(offs[q + 1])] for q in range(nq)]
 
