@@ -345,6 +345,7 @@ struct cobs_gpu_batch {
     // host-buffer API only: the stream this scratch batch lives on and the event after its pass
     hipStream_t own_stream = nullptr;
     hipEvent_t done = nullptr;
+    hipEvent_t scan_end = nullptr;    // the event after the last K2 launch of the most recent run (one of its timing events)
     hipEvent_t scan_after = nullptr;  // set for one run: its K2 launches wait for this event (the previous pass), its K1 does not
     // captured graph of a small pass (single-query latency path)
     hipGraphExec_t graph_exec = nullptr;

@@ -418,7 +418,10 @@ static cobs_gpu_status search_batch_impl(cobs_gpu_index* ix, const char* const* 
             if (bad_query) *bad_query = first_bad;
             return st;
         }
-        prev_done = ix->scratch[slot]->done;
+        // the next pass's scan follows this pass's SCAN (its K3 / selection kernels may run beside it: other buffers);
+        // out-of-core passes share their stream buffers and follow the whole pass
+        prev_done = (!any_streamed && g1 - g0 > 16 && ix->scratch[slot]->scan_end) ? ix->scratch[slot]->scan_end
+                                                                                   : ix->scratch[slot]->done;
         inflight.push_back(Pass{g0, g1, slot});
         ++pass_no;
         if (nq == 0) break;

@@ -788,6 +788,7 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
         HIP_TRY(hipEventRecord(ev[3], st));
     }
     HIP_TRY(hipEventRecord(ev[2], st));
+    b->scan_end = ev[2];                 // (host-buffer passes chain their SCANS: the next one may start under this run's K3)
     if (use_topk && nq) {
         for (size_t f = 0; f < ix->parts.size(); ++f) {
             const Part& p = ix->parts[f];
