@@ -17,10 +17,10 @@ keep = np.zeros(256 * s.total_counts, dtype=s.HIT_DTYPE)
 windows = [int(x) for x in sys.argv[1:]] or [16384]
 for win in windows:
     s.set_tuning("rank_window_kib", win)
-    for slim, nseg in ((1, 0), (1, 1), (0, 1), (1, 0), (1, 1)):
+    for slim, nseg in ((1, 0), (1, 1), (0, 1), (1, 0), (1, 1)) if not os.environ.get("PROBE_SHORT") else ((1, 0), (1, 0), (1, 0)):
         s.set_tuning("rank_slim", slim)
         s.set_tuning("rank_segments", nseg)
-        for nq in (256, 64, 16):
+        for nq in ((256, 64, 16) if not os.environ.get("PROBE_SHORT") else (256,)):
             o = np.ascontiguousarray(offs[:nq + 1])
             t = text[:int(o[-1])]
             for _ in range(2):
