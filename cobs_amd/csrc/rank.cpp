@@ -186,9 +186,26 @@ namespace {
 
 constexpr size_t kSpanBytes = 512u << 20;      // records one kernel launch orders (two such device buffers)
 
-// records [first, first + cnt) of a source `rec(i, slot, score)` reads (called with ascending i) -> d[0 .. cnt)
-template <class Rec>
-void emit_hits(cobs_gpu_hit* d, size_t first, size_t cnt, const std::vector<RankPart>& parts, Rec rec) {
+// records [first, first + cnt) of a source -> d[0 .. cnt).  A source reads ONE record, `one(i, slot, score)`, or -- x86 --
+// FOUR, `four(i, slots, scores)` as two vectors, always with ascending i.  Four 12-byte results are three 16-byte
+// non-temporal stores built with shuffles (building them from scalars cost more than the stores: the expansion of the
+// default call ran at 170 GB/s where 8 threads of plain stores reach 300, scripts/probes/nt_store_probe.cpp).
+#if defined(__SSE2__)
+static inline void store4(cobs_gpu_hit* d, __m128i docs, __m128i scores, __m128 files) {
+    const __m128 A = _mm_castsi128_ps(_mm_unpacklo_epi32(docs, scores));    // d0 c0 d1 c1
+    const __m128 B = _mm_castsi128_ps(_mm_unpackhi_epi32(docs, scores));    // d2 c2 d3 c3
+    const __m128 t0 = _mm_shuffle_ps(files, A, _MM_SHUFFLE(1, 0, 0, 0));    // f  f  d0 c0
+    const __m128 u = _mm_shuffle_ps(files, B, _MM_SHUFFLE(0, 0, 0, 0));     // f  f  d2 d2
+    const __m128 v = _mm_shuffle_ps(B, files, _MM_SHUFFLE(0, 0, 1, 1));     // c2 c2 f  f
+    __m128i* o = reinterpret_cast<__m128i*>(d);
+    _mm_stream_si128(o + 0, _mm_shuffle_epi32(_mm_castps_si128(t0), _MM_SHUFFLE(0, 3, 2, 0)));   // f  d0 c0 f
+    _mm_stream_si128(o + 1, _mm_castps_si128(_mm_shuffle_ps(A, u, _MM_SHUFFLE(2, 0, 3, 2))));    // d1 c1 f  d2
+    _mm_stream_si128(o + 2, _mm_castps_si128(_mm_shuffle_ps(v, B, _MM_SHUFFLE(3, 2, 2, 0))));    // c2 f  d3 c3
+}
+#endif
+
+template <class Source>
+void emit_hits(cobs_gpu_hit* d, size_t first, size_t cnt, const std::vector<RankPart>& parts, Source src) {
     static_assert(sizeof(cobs_gpu_hit) == 12, "three u32 per result");
     if (parts.size() == 1) {
         const RankPart pt = parts[0];
@@ -198,35 +215,98 @@ void emit_hits(cobs_gpu_hit* d, size_t first, size_t cnt, const std::vector<Rank
         if ((reinterpret_cast<uintptr_t>(d) & 3u) == 0) {
             for (; i < cnt && (reinterpret_cast<uintptr_t>(d + i) & 15u) != 0; ++i) {     // at most 3: 12 i mod 16
                 uint32_t slot, score;
-                rec(first + i, slot, score);
+                src.one(first + i, slot, score);
                 d[i] = cobs_gpu_hit{f, slot + bias, score};
             }
+            const __m128i vbias = _mm_set1_epi32((int)bias);
+            const __m128 vf = _mm_castsi128_ps(_mm_set1_epi32((int)f));
             for (; i + 4 <= cnt; i += 4) {
-                uint32_t sl[4], sc[4];
-                for (int j = 0; j < 4; ++j) { rec(first + i + j, sl[j], sc[j]); sl[j] += bias; }
-                __m128i* o = reinterpret_cast<__m128i*>(d + i);
-                _mm_stream_si128(o + 0, _mm_set_epi32((int)f, (int)sc[0], (int)sl[0], (int)f));
-                _mm_stream_si128(o + 1, _mm_set_epi32((int)sl[2], (int)f, (int)sc[1], (int)sl[1]));
-                _mm_stream_si128(o + 2, _mm_set_epi32((int)sc[3], (int)sl[3], (int)f, (int)sc[2]));
+                __m128i sl, sc;
+                src.four(first + i, sl, sc);
+                store4(d + i, _mm_add_epi32(sl, vbias), sc, vf);
             }
             _mm_sfence();
         }
 #endif
         for (; i < cnt; ++i) {
             uint32_t slot, score;
-            rec(first + i, slot, score);
+            src.one(first + i, slot, score);
             d[i] = cobs_gpu_hit{f, slot + bias, score};
         }
         return;
     }
     for (size_t i = 0; i < cnt; ++i) {
         uint32_t slot, score;
-        rec(first + i, slot, score);
+        src.one(first + i, slot, score);
         size_t p = 0;
         while (p + 1 < parts.size() && slot >= parts[p + 1].slot0) ++p;
         d[i] = cobs_gpu_hit{parts[p].file_no, parts[p].doc_first + (slot - parts[p].slot0), score};
     }
 }
+
+// one u32 per record, score << pack_bits | slot
+struct PackedSource {
+    const uint32_t* s;
+    uint32_t smask, pack_bits;
+    void one(size_t i, uint32_t& slot, uint32_t& score) const { slot = s[i] & smask; score = s[i] >> pack_bits; }
+#if defined(__SSE2__)
+    void four(size_t i, __m128i& slots, __m128i& scores) const {
+        const __m128i r = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s + i));
+        slots = _mm_and_si128(r, _mm_set1_epi32((int)smask));
+        scores = _mm_srl_epi32(r, _mm_cvtsi32_si128((int)pack_bits));
+    }
+#endif
+};
+
+// (slot, score) pairs
+struct PairSource {
+    const uint2* s;
+    void one(size_t i, uint32_t& slot, uint32_t& score) const { slot = s[i].x; score = s[i].y; }
+#if defined(__SSE2__)
+    void four(size_t i, __m128i& slots, __m128i& scores) const {
+        const __m128 a = _mm_loadu_ps(reinterpret_cast<const float*>(s + i)), b = _mm_loadu_ps(reinterpret_cast<const float*>(s + i + 2));
+        slots = _mm_castps_si128(_mm_shuffle_ps(a, b, _MM_SHUFFLE(2, 0, 2, 0)));
+        scores = _mm_castps_si128(_mm_shuffle_ps(a, b, _MM_SHUFFLE(3, 1, 3, 1)));
+    }
+#endif
+};
+
+// the slim form of one query: a bit stream of slots in score order + the number of records per bin (bin = nbins - 1 - score)
+struct SlimSource {
+    const uint32_t* bq;        // [nbins]
+    const uint8_t* pk;         // the slot stream
+    uint32_t slot_bits, nbins;
+    uint64_t smask;
+    uint32_t bin = 0;
+    size_t upto = 0;           // records in bins [0, bin]
+    SlimSource(const uint32_t* bins, const uint32_t* packed, uint32_t sb, uint32_t nb)
+        : bq(bins), pk(reinterpret_cast<const uint8_t*>(packed)), slot_bits(sb), nbins(nb), smask((1ull << sb) - 1ull), upto(bins[0]) {}
+    uint32_t slot_at(size_t p) const {
+        const uint64_t bit = (uint64_t)p * slot_bits;
+        uint64_t v;
+        std::memcpy(&v, pk + (bit >> 5) * 4u, 8);
+        return (uint32_t)((v >> (bit & 31u)) & smask);
+    }
+    void seek(size_t p) { while (upto <= p && bin + 1u < nbins) upto += bq[++bin]; }
+    void one(size_t p, uint32_t& slot, uint32_t& score) {
+        seek(p);
+        score = nbins - 1u - bin;
+        slot = slot_at(p);
+    }
+#if defined(__SSE2__)
+    void four(size_t p, __m128i& slots, __m128i& scores) {
+        slots = _mm_set_epi32((int)slot_at(p + 3), (int)slot_at(p + 2), (int)slot_at(p + 1), (int)slot_at(p));
+        seek(p);
+        if (upto >= p + 4 || bin + 1u >= nbins) {            // the four share a score (runs are ~1000 records long)
+            scores = _mm_set1_epi32((int)(nbins - 1u - bin));
+            return;
+        }
+        uint32_t c[4];
+        for (int j = 0; j < 4; ++j) { seek(p + j); c[j] = nbins - 1u - bin; }
+        scores = _mm_set_epi32((int)c[3], (int)c[2], (int)c[1], (int)c[0]);
+    }
+#endif
+};
 
 // The slim form of FULL lists (every real document of every query in score order: the reference's default call).  Per
 // query `words` dwords of slots -- record p = bits [p * slot_bits, (p + 1) * slot_bits) of that stream -- and `nbins`
@@ -235,25 +315,13 @@ void emit_hits(cobs_gpu_hit* d, size_t first, size_t cnt, const std::vector<Rank
 // (the stream of a query is read 8 bytes at a time: `words` leaves two dwords behind the last record)
 void expand_slim(ExpandPool* pool, cobs_gpu_hit* dst, const uint32_t* packed, const uint32_t* bins, size_t nq, size_t stride,
                  size_t words, uint32_t slot_bits, uint32_t nbins, const std::vector<RankPart>& parts) {
-    const uint64_t smask = (1ull << slot_bits) - 1ull;
     const size_t kPiece = 64u << 10;                         // records per job, at most; a job stays inside one query
     const size_t per_q = std::max<size_t>(1, (stride + kPiece - 1) / kPiece);
     const size_t job_n = (stride + per_q - 1) / per_q;       // (equal jobs: 100 000 records = 2 x 50 000, not 65 536 + 34 464)
     auto work = [&](size_t j) {
         const size_t q = j / per_q, p0 = (j % per_q) * job_n, p1 = std::min(stride, p0 + job_n);
         if (p0 >= p1) return;
-        const uint32_t* bq = bins + q * nbins;
-        const uint8_t* pk = reinterpret_cast<const uint8_t*>(packed + q * words);
-        uint32_t bin = 0;
-        size_t upto = bq[0];                                 // records in bins [0, bin]
-        emit_hits(dst + q * stride + p0, p0, p1 - p0, parts, [=](size_t p, uint32_t& slot, uint32_t& score) mutable {
-            while (upto <= p && bin + 1u < nbins) upto += bq[++bin];
-            score = nbins - 1u - bin;
-            const uint64_t bit = (uint64_t)p * slot_bits;
-            uint64_t v;
-            std::memcpy(&v, pk + (bit >> 5) * 4u, 8);
-            slot = (uint32_t)((v >> (bit & 31u)) & smask);
-        });
+        emit_hits(dst + q * stride + p0, p0, p1 - p0, parts, SlimSource(bins + q * nbins, packed + q * words, slot_bits, nbins));
     };
     const size_t jobs = nq * per_q;
     if (jobs <= 1 || !pool) { for (size_t j = 0; j < jobs; ++j) work(j); return; }
@@ -271,13 +339,8 @@ void expand_records(ExpandPool* pool, cobs_gpu_hit* dst, const void* src, size_t
                     const std::vector<RankPart>& parts) {
     const uint32_t smask = pack_bits ? (1u << pack_bits) - 1u : 0u;
     auto work = [&parts, pack_bits, smask](cobs_gpu_hit* d, const void* sv, size_t first, size_t cnt) {
-        if (pack_bits) {
-            const uint32_t* s = static_cast<const uint32_t*>(sv);
-            emit_hits(d, first, cnt, parts, [=](size_t i, uint32_t& slot, uint32_t& score) { slot = s[i] & smask; score = s[i] >> pack_bits; });
-        } else {
-            const uint2* s = static_cast<const uint2*>(sv);
-            emit_hits(d, first, cnt, parts, [=](size_t i, uint32_t& slot, uint32_t& score) { slot = s[i].x; score = s[i].y; });
-        }
+        if (pack_bits) emit_hits(d, first, cnt, parts, PackedSource{static_cast<const uint32_t*>(sv), smask, pack_bits});
+        else emit_hits(d, first, cnt, parts, PairSource{static_cast<const uint2*>(sv)});
     };
     const size_t kPiece = 64u << 10;         // records per job
     const size_t jobs = (n + kPiece - 1) / kPiece;
