@@ -439,6 +439,8 @@ void destroy_exchange(Exchange* x);       // comm.cpp
 // rank.cpp: counts_to_result over the score rows of the last run, on the device
 void destroy_rank_work(RankWork* w);
 bool rank_on_device_applies(const cobs_gpu_batch* b, size_t nq);
+cobs_gpu_status rank_launch(cobs_gpu_batch* b, size_t q_first, size_t nq, size_t limit);
+void rank_cancel(cobs_gpu_batch* b);
 cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, size_t limit, cobs_gpu_hit* hits, size_t cap,
                                size_t* used, size_t* hit_offsets, bool* overflow);
 cobs_gpu_status open_zeroed(IndexMeta&& meta, const cobs_gpu_options* opts, cobs_gpu_index** out);

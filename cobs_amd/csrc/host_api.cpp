@@ -274,10 +274,19 @@ static cobs_gpu_status search_batch_impl(cobs_gpu_index* ix, const char* const* 
     const size_t max_pass = (!any_streamed && pipe_chars && total_chars >= pipe_chars && nq >= 64)
                                 ? (nq + 3) / 4 : std::max<size_t>(nq, 1);
     const size_t topk = num_results < ix->total_counts ? num_results : 0;   // bounded: K3 selects on the device
+    // Every document of every query (the reference's default call): the ordering kernels of a pass are queued right behind
+    // its scan (rank.cpp: rank_launch) -- no host round trip in between, and in a call of several passes they run, and the
+    // first pieces cross PCIe, while the host still expands the pass before.  (Cutting a one-pass call in two or four so
+    // that its later scans hide behind the first ordering was measured slower, EXPERIMENTS.md: the passes' kernels share
+    // the device and the smaller pieces expand less efficiently.)
+    const bool early_rank = ix->tune.device_rank != 0 && !(threshold > 0.0) && topk == 0 && !any_streamed;
     struct Pass { size_t g0, g1; int slot; };
     std::vector<Pass> inflight;                        // FIFO, at most `depth` entries
     auto drain = [&]() {                               // error paths: nothing may still use the scratch batches
-        for (const Pass& ps : inflight) (void)hipStreamSynchronize(ix->scratch[ps.slot]->own_stream);
+        for (const Pass& ps : inflight) {
+            (void)hipStreamSynchronize(ix->scratch[ps.slot]->own_stream);
+            rank_cancel(ix->scratch[ps.slot]);
+        }
         inflight.clear();
     };
     auto collect = [&](const Pass& ps) -> cobs_gpu_status {
@@ -418,6 +427,8 @@ static cobs_gpu_status search_batch_impl(cobs_gpu_index* ix, const char* const* 
             if (bad_query) *bad_query = first_bad;
             return st;
         }
+        if (early_rank && g1 - g0 > 16 && rank_on_device_applies(ix->scratch[slot], g1 - g0))
+            (void)rank_launch(ix->scratch[slot], 0, g1 - g0, num_results);      // (a failure shows when the pass is collected)
         // the next pass's scan follows this pass's SCAN (its K3 / selection kernels may run beside it: other buffers);
         // out-of-core passes share their stream buffers and follow the whole pass
         prev_done = (!any_streamed && g1 - g0 > 16 && ix->scratch[slot]->scan_end) ? ix->scratch[slot]->scan_end

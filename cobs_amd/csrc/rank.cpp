@@ -159,8 +159,30 @@ ExpandPool* expand_pool(int device) {
     return &pool;
 }
 
+// One ranking between its two halves: rank_launch (workspace, the ordering kernels of the first spans, the first two
+// pieces on their way over PCIe -- everything asynchronous) and the drain inside rank_on_device (pieces expanded into the
+// caller's array as they land).  The host-buffer API launches the ranking of a pass right behind its scan, so that it
+// runs while the pass BEFORE it is expanded (host_api.cpp).
+struct RankJob {
+    bool active = false;
+    size_t q_first = 0, nq = 0, limit = 0;
+    uint64_t run_seq = 0;               // the run of the batch whose rows it orders
+    std::vector<RankPart> parts;
+    std::vector<uint8_t> by_score;
+    size_t per_query = 0, stride = 0;
+    bool glob = false, slim = false;
+    uint64_t row_elems = 0;
+    uint32_t planes = 0, npasses = 0, pbits = 0, pack_bits = 0, nbins = 0, nseg = 1;
+    size_t rec = 0, words = 0, qbytes = 0, sq = 0, pq = 0, land_bytes = 0, nspans = 0;
+    struct Piece { size_t span, q0, n; bool last_of_span; };      // q0 relative to q_first
+    std::vector<Piece> pieces;
+    size_t spans_launched = 0, pieces_issued = 0;
+    double t_prep = 0;
+};
+
 struct RankWork {
     static constexpr int kDepth = 3;    // landing buffers: one being filled over PCIe, one queued, one being expanded
+    RankJob job;
     DevBuf<uint2> out[2];               // (slot, score) records of a span of queries, in rank order
     DevBuf<uint2> pairs[2];
     DevBuf<uint32_t> cnt[2];            // [span]: results per query; npass of multi-pass sorts behind it
@@ -173,6 +195,7 @@ struct RankWork {
     hipStream_t copy_stream = nullptr;
     hipEvent_t ranked[2] = {nullptr, nullptr}, drained[2] = {nullptr, nullptr}, landed[kDepth] = {nullptr, nullptr, nullptr};
     ~RankWork() {
+        if (copy_stream) (void)hipStreamSynchronize(copy_stream);      // (a job that was launched and never drained)
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
         for (auto e : ranked) if (e) (void)hipEventDestroy(e);
         for (auto e : drained) if (e) (void)hipEventDestroy(e);
@@ -364,17 +387,111 @@ bool rank_on_device_applies(const cobs_gpu_batch* b, size_t nq) {
     return true;
 }
 
-// Queries [q_first, q_first + nq) of the last (synced) run of `b`, ranked on the device.  Query q_first + i's results -- at most
-// `limit` (0 = all) -- are appended at hits + *used, hit_offsets[i + 1] = the new *used.  When the
-// caller's buffer is too small the offsets keep counting (the caller reports the needed capacity)
-// and *overflow is set; hits are then not valid, as in the host path.  COBS_GPU_ERR_UNSUPPORTED (nothing written
-// yet): the workspace could not be allocated, rank on the host.
-cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, size_t limit, cobs_gpu_hit* hits, size_t cap,
-                               size_t* used, size_t* hit_offsets, bool* overflow) {
+namespace {
+
+cobs_gpu_status job_launch_span(cobs_gpu_batch* b, RankWork& w, RankJob& j, size_t sp) {
+    hipStream_t st = b->own_stream;
+    const int s = (int)(sp & 1);
+    const size_t s0 = sp * j.sq, n = std::min(j.nq, s0 + j.sq) - s0;
+    if (sp >= 2) HIP_TRY(hipStreamWaitEvent(st, w.drained[s], 0));       // the span that used this buffer has crossed PCIe
+    RankArgs a{};
+    a.rows = j.glob ? (const void*)b->g_rows : (const void*)b->counts.p;
+    a.row_stride = j.row_elems;
+    a.row_q0 = j.glob ? (uint32_t)b->g_q0 : 0u;
+    a.parts = w.parts.p;
+    a.by_score = w.by_score.p;
+    a.npass = w.cnt[s].p + j.sq;
+    a.out = w.out[s].p;
+    a.out_count = w.cnt[s].p;
+    a.pair_stride = j.row_elems;
+    a.out_stride = j.stride;
+    a.nparts = (uint32_t)j.parts.size();
+    a.nslots = (uint32_t)j.row_elems;
+    a.q0 = (uint32_t)(j.q_first + s0);
+    a.nq = (uint32_t)n;
+    a.limit = (uint32_t)std::min<size_t>(j.stride, 0xFFFFFFFFu);
+    a.score_bytes = b->elem_bytes;
+    a.pack_bits = j.pack_bits;
+    a.bin_count = j.slim ? w.bins[s].p : nullptr;
+    a.seg_hist = j.nseg > 1 ? w.seghist.p : nullptr;
+    a.nseg = j.nseg;
+    for (uint32_t ps = 0; ps < j.npasses; ++ps) {
+        a.shift = ps * j.pbits;
+        a.bits = std::min(j.pbits, j.planes - a.shift);
+        a.src = w.pairs[(ps + 1) & 1].p;
+        a.dst = w.pairs[ps & 1].p;
+        HIP_TRY(launch_rank(a, ps == 0, ps + 1 == j.npasses, st));
+    }
+    if (j.slim) {
+        SlotPackArgs pa{};
+        pa.in = reinterpret_cast<const uint32_t*>(w.out[s].p);
+        pa.out = w.packed[s].p;
+        pa.in_stride = j.stride;
+        pa.n = (uint32_t)j.stride;
+        pa.words = (uint32_t)j.words;
+        pa.slot_bits = j.pack_bits;
+        pa.nq = (uint32_t)n;
+        HIP_TRY(launch_pack_slots(pa, st));
+    }
+    HIP_TRY(hipEventRecord(w.ranked[s], st));
+    return COBS_GPU_OK;
+}
+
+cobs_gpu_status job_issue_piece(cobs_gpu_batch* b, RankWork& w, RankJob& j, size_t pi) {
+    constexpr size_t kDepth = RankWork::kDepth;
+    const RankJob::Piece& pc = j.pieces[pi];
+    while (j.spans_launched <= pc.span) {                      // (a span is launched when its first piece is wanted ...
+        cobs_gpu_status ls = job_launch_span(b, w, j, j.spans_launched);
+        if (ls != COBS_GPU_OK) return ls;
+        ++j.spans_launched;
+    }
+    const int s = (int)(pc.span & 1), l = (int)(pi % kDepth);
+    const size_t off = pc.q0 - pc.span * j.sq;                 // queries into the span
+    HIP_TRY(hipStreamWaitEvent(w.copy_stream, w.ranked[s], 0));
+    if (j.slim) {
+        HIP_TRY(hipMemcpyAsync(w.land[l].p, w.packed[s].p + off * j.words, pc.n * j.words * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                               w.copy_stream));
+        HIP_TRY(hipMemcpyAsync(w.land[l].p + j.pq * j.words * sizeof(uint32_t), w.bins[s].p + off * j.nbins,
+                               pc.n * j.nbins * sizeof(uint32_t), hipMemcpyDeviceToHost, w.copy_stream));
+    } else {
+        HIP_TRY(hipMemcpyAsync(w.land[l].p, reinterpret_cast<const uint8_t*>(w.out[s].p) + off * j.stride * j.rec, pc.n * j.stride * j.rec,
+                               hipMemcpyDeviceToHost, w.copy_stream));
+    }
+    HIP_TRY(hipMemcpyAsync(w.land[l].p + j.land_bytes, w.cnt[s].p + off, 4 * pc.n, hipMemcpyDeviceToHost, w.copy_stream));
+    HIP_TRY(hipEventRecord(w.landed[l], w.copy_stream));
+    if (pc.last_of_span) {
+        HIP_TRY(hipEventRecord(w.drained[s], w.copy_stream));
+        if (j.spans_launched < j.nspans && j.spans_launched == pc.span + 2) {   // ... or as soon as its buffer drains: it is
+                                                                                // ordered while the span in between crosses)
+            cobs_gpu_status ls = job_launch_span(b, w, j, j.spans_launched);
+            if (ls != COBS_GPU_OK) return ls;
+            ++j.spans_launched;
+        }
+    }
+    ++j.pieces_issued;
+    return COBS_GPU_OK;
+}
+
+}  // namespace
+
+// a ranking that was launched and never drained (its call failed in between): nothing of it may still be in flight
+void rank_cancel(cobs_gpu_batch* b) {
+    if (!b || !b->rank || !b->rank->job.active) return;
+    (void)hipStreamSynchronize(b->own_stream);
+    if (b->rank->copy_stream) (void)hipStreamSynchronize(b->rank->copy_stream);
+    b->rank->job.active = false;
+}
+
+// The launch half: queries [q_first, q_first + nq) of the last run of `b` (its kernels may still be running on the batch's
+// stream: everything here is queued behind them), at most `limit` (0 = all) results per query.  COBS_GPU_ERR_UNSUPPORTED
+// (nothing launched): the workspace could not be allocated, rank on the host.
+cobs_gpu_status rank_launch(cobs_gpu_batch* b, size_t q_first, size_t nq, size_t limit) {
     cobs_gpu_index* ix = b->ix;
     HIP_TRY(hipSetDevice(ix->device));
     if (!b->rank) b->rank = new RankWork;
     RankWork& w = *b->rank;
+    rank_cancel(b);
+    RankJob& j = w.job;
     hipStream_t st = b->own_stream;             // the stream the pass ran on (host-buffer API)
     if (!w.copy_stream) {
         HIP_TRY(hipStreamCreateWithFlags(&w.copy_stream, hipStreamNonBlocking));
@@ -382,18 +499,24 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
         for (auto& e : w.drained) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto& e : w.landed) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
+    j.q_first = q_first;
+    j.nq = nq;
+    j.limit = limit;
+    j.run_seq = b->run_seq;
+    j.pieces.clear();
+    j.spans_launched = j.pieces_issued = 0;
     // the files' slices as the ranked rows hold them: this shard's slots back to back (local rows), or every
     // file whole at its document offset (global rows assembled by an exchange)
-    const bool glob = b->view_global;
-    const uint64_t row_elems = glob ? ix->total_counts : ix->local_counts;
-    std::vector<RankPart> parts;
-    size_t per_query = 0;
+    j.glob = b->view_global;
+    j.row_elems = j.glob ? ix->total_counts : ix->local_counts;
+    j.parts.clear();
+    j.per_query = 0;
     for (size_t f = 0; f < ix->parts.size(); ++f) {
         const Part& p = ix->parts[f];
         RankPart rp;
         rp.thr = b->threshold > 0.0 ? b->work[f].thr.p : nullptr;
         rp.file_no = (uint32_t)f;
-        if (glob) {
+        if (j.glob) {
             rp.slot0 = (uint32_t)p.doc_offset;
             rp.doc_first = 0;
             rp.ndocs = (uint32_t)p.meta.doc_names.size();
@@ -404,14 +527,126 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
             const uint64_t d1 = std::min<uint64_t>(p.slot_begin + p.slot_count, p.meta.doc_names.size());
             rp.ndocs = d1 > p.slot_begin ? (uint32_t)(d1 - p.slot_begin) : 0u;
         }
-        per_query += rp.ndocs;
-        parts.push_back(rp);
+        j.per_query += rp.ndocs;
+        j.parts.push_back(rp);
     }
-    if (parts.empty() || per_query == 0) {
+    j.stride = limit == 0 ? j.per_query : std::min(limit, j.per_query);
+    if (j.parts.empty() || j.per_query == 0) {          // nothing to rank: the drain half writes the empty lists
+        j.active = true;
+        return COBS_GPU_OK;
+    }
+    if (b->view_global && (q_first < b->g_q0 || q_first + nq > b->g_q0 + b->g_qn))
+        return fail(COBS_GPU_ERR_ARG, "this rank does not hold the exchanged rows of those queries");
+    j.by_score.resize(b->nq);
+    for (size_t q = 0; q < b->nq; ++q) j.by_score[q] = total_hashes(b, q) > 1 ? 1 : 0;   // max_counts <= 1: index order
+    const size_t stride = j.stride;
+
+    // radix passes of at most 12 bits over the score bits the scan produced
+    j.planes = (uint32_t)b->planes;
+    j.npasses = (j.planes + 11u) / 12u;
+    j.pbits = (j.planes + j.npasses - 1u) / j.npasses;
+    // record width: slot and score in one word where they fit (C3: 17 + 10 bits), else a pair -- the default call moves
+    // one record per (query, document) over PCIe and is bound by exactly those bytes
+    uint32_t slot_bits = 1;
+    while (slot_bits < 32u && (1ull << slot_bits) < j.row_elems) ++slot_bits;
+    j.pack_bits = (ix->tune.rank_pack != 0 && slot_bits + j.planes <= 32u) ? slot_bits : 0u;
+    j.rec = j.pack_bits ? sizeof(uint32_t) : sizeof(uint2);
+    // FULL lists in score order (the reference's default call: threshold 0, no limit) cross PCIe slimmer still: the order
+    // of the slots plus the number of records per score say everything -- C3: 17 bits per result instead of 32, 54 MB
+    // instead of 102 MB for 256 queries (expand_slim above; tuning key rank_slim = 0: the 4-byte records, A/B)
+    j.slim = ix->tune.rank_slim != 0 && j.pack_bits != 0 && j.npasses == 1 && limit == 0 && !(b->threshold > 0.0) && stride == j.per_query;
+    for (size_t q = q_first; j.slim && q < q_first + nq; ++q) j.slim = j.by_score[q] != 0;
+    j.nbins = 1u << j.pbits;
+    j.words = j.slim ? (stride * j.pack_bits + 31) / 32 + 2 : 0;                         // dwords of one query's slot stream
+    j.qbytes = j.slim ? (j.words + j.nbins) * sizeof(uint32_t) : stride * j.rec;         // what crosses PCIe per query
+    // Two granularities.  A SPAN is what one kernel launch orders: up to 512 MiB of records -- a launch wants hundreds of
+    // queries to fill the device (launching per 32 MiB window left 84 % of the CUs idle and made the call kernel-bound:
+    // profiles/r03_rank_kernel_stats.csv).  A PIECE is what crosses PCIe at a time: 16 MiB of a span's records into one
+    // of three pinned landing buffers, expanded by the host while the next piece crosses.
+    j.sq = std::max<size_t>(1, std::min<size_t>(nq, kSpanBytes / (stride * j.rec)));     // queries per span
+    // (a piece = what is in flight per stage of the PCIe | expansion pipeline: the head of a call is the first piece's
+    // crossing, its tail the last piece's expansion, in between both overlap -- tuning key rank_window_kib)
+    const size_t window = (size_t)std::max<uint32_t>(ix->tune.rank_window_kib, 256u) << 10;
+    // A single-pass sort of a long row is cut into segments, a work-group each (rank_kernels.hip: SEG): one work-group per
+    // query is alone on its CU and latency-bound -- 0.36 ms for 100 000 documents however few queries there are, the
+    // head of every default call.  Tuning key rank_segments: 0 = by row length, 1 = off, else that many.
+    j.nseg = 1;
+    if (j.npasses == 1) {
+        j.nseg = ix->tune.rank_segments > 0 ? (uint32_t)std::min(ix->tune.rank_segments, 64)
+                                            : (j.row_elems >= 65536 ? 8u : j.row_elems >= 16384 ? 4u : j.row_elems >= 8192 ? 2u : 1u);
+        if (j.sq > 65535u) j.nseg = 1;
+    }
+    j.pq = std::max<size_t>(1, std::min<size_t>(j.sq, window / j.qbytes));   // queries per piece
+    j.land_bytes = (j.pq * j.qbytes + 15) / 16 * 16;
+    constexpr size_t kDepth = RankWork::kDepth;
+    {   // the workspace: if the device or the pinned pool cannot give it, the caller ranks on the host as before
+        bool ok = w.parts.reserve(j.parts.size()) == hipSuccess && w.by_score.reserve(b->nq) == hipSuccess;
+        for (int i = 0; i < 2 && ok; ++i)
+            ok = w.out[i].reserve((j.sq * stride * j.rec + sizeof(uint2) - 1) / sizeof(uint2)) == hipSuccess && w.cnt[i].reserve(2 * j.sq) == hipSuccess;
+        for (size_t i = 0; i < kDepth && ok; ++i) ok = w.land[i].reserve(j.land_bytes + 4 * j.pq) == hipSuccess;
+        if (ok && j.nseg > 1 && w.seghist.reserve(j.sq * 4u * j.nseg * (size_t)j.nbins) != hipSuccess) {
+            (void)hipGetLastError();
+            j.nseg = 1;
+        }
+        for (int i = 0; i < 2 && ok && j.slim; ++i)
+            ok = w.packed[i].reserve(j.sq * j.words) == hipSuccess && w.bins[i].reserve(j.sq * j.nbins) == hipSuccess;
+        if (ok && j.npasses > 1)
+            for (auto& pr : w.pairs) ok = ok && pr.reserve(j.sq * j.row_elems) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            return COBS_GPU_ERR_UNSUPPORTED;
+        }
+    }
+    // (the two host vectors live in the job: the copies may read them after this function has returned)
+    HIP_TRY(hipMemcpyAsync(w.parts.p, j.parts.data(), j.parts.size() * sizeof(RankPart), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(w.by_score.p, j.by_score.data(), b->nq, hipMemcpyHostToDevice, st));
+    j.nspans = (nq + j.sq - 1) / j.sq;
+    for (size_t sp = 0; sp < j.nspans; ++sp) {
+        const size_t s0 = sp * j.sq, s1 = std::min(nq, s0 + j.sq);
+        for (size_t q0 = s0; q0 < s1; q0 += j.pq) j.pieces.push_back(RankJob::Piece{sp, q0, std::min(j.pq, s1 - q0), q0 + j.pq >= s1});
+    }
+    j.t_prep = now_s();
+    cobs_gpu_status rs = COBS_GPU_OK;
+    if (j.nspans > 1) {                          // both span buffers are free at the start: order two spans right away
+        rs = job_launch_span(b, w, j, 0);
+        if (rs == COBS_GPU_OK) rs = job_launch_span(b, w, j, 1);
+        j.spans_launched = rs == COBS_GPU_OK ? 2 : 0;
+    }
+    for (size_t pi = 0; rs == COBS_GPU_OK && pi < std::min<size_t>(2, j.pieces.size()); ++pi) rs = job_issue_piece(b, w, j, pi);
+    if (rs != COBS_GPU_OK) {                    // nothing of this batch may still be in flight when the caller sees the error
+        (void)hipStreamSynchronize(st);
+        (void)hipStreamSynchronize(w.copy_stream);
+        return rs;
+    }
+    j.t_prep = now_s() - j.t_prep;
+    j.active = true;
+    return COBS_GPU_OK;
+}
+
+// Queries [q_first, q_first + nq) of the last run of `b`, ranked on the device (the launch half above, unless the caller
+// has run it already for exactly these queries, and the drain half).  Query q_first + i's results -- at most
+// `limit` (0 = all) -- are appended at hits + *used, hit_offsets[i + 1] = the new *used.  When the
+// caller's buffer is too small the offsets keep counting (the caller reports the needed capacity)
+// and *overflow is set; hits are then not valid, as in the host path.  COBS_GPU_ERR_UNSUPPORTED (nothing written
+// yet): the workspace could not be allocated, rank on the host.
+cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, size_t limit, cobs_gpu_hit* hits, size_t cap,
+                               size_t* used, size_t* hit_offsets, bool* overflow) {
+    cobs_gpu_index* ix = b->ix;
+    HIP_TRY(hipSetDevice(ix->device));
+    if (!(b->rank && b->rank->job.active && b->rank->job.run_seq == b->run_seq && b->rank->job.q_first == q_first &&
+          b->rank->job.nq == nq && b->rank->job.limit == limit)) {
+        const cobs_gpu_status ls = rank_launch(b, q_first, nq, limit);
+        if (ls != COBS_GPU_OK) return ls;
+    }
+    RankWork& w = *b->rank;
+    RankJob& j = w.job;
+    j.active = false;
+    hipStream_t st = b->own_stream;
+    if (j.parts.empty() || j.per_query == 0) {
         for (size_t i = 0; i < nq; ++i) hit_offsets[i + 1] = *used;
         return COBS_GPU_OK;
     }
-    const size_t stride = limit == 0 ? per_query : std::min(limit, per_query);
+    const size_t stride = j.stride;
     // A large result range the caller has not touched yet is written through first-touch page faults (75 000 of them
     // for 256 queries x 100 000 documents): transparent huge pages, where the host offers them on request, cut that
     // to 150 (probe: 5.6 -> 4.9 ms per call into a fresh array, scripts/probes/fresh_buffer_probe.py; a kept array: 3.4).
@@ -424,197 +659,32 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
             if (a1 > a0) (void)madvise(reinterpret_cast<void*>(a0), a1 - a0, MADV_HUGEPAGE);
         }
     }
-    HIP_TRY(w.parts.reserve(parts.size()));
-    HIP_TRY(hipMemcpyAsync(w.parts.p, parts.data(), parts.size() * sizeof(RankPart), hipMemcpyHostToDevice, st));
-    if (b->view_global && (q_first < b->g_q0 || q_first + nq > b->g_q0 + b->g_qn))
-        return fail(COBS_GPU_ERR_ARG, "this rank does not hold the exchanged rows of those queries");
-    std::vector<uint8_t> by_score(b->nq);
-    for (size_t q = 0; q < b->nq; ++q) by_score[q] = total_hashes(b, q) > 1 ? 1 : 0;   // max_counts <= 1: index order
-    HIP_TRY(w.by_score.reserve(b->nq));
-    HIP_TRY(hipMemcpyAsync(w.by_score.p, by_score.data(), b->nq, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));          // the two host vectors may go; everything below is asynchronous
-
-    // radix passes of at most 12 bits over the score bits the scan produced
-    const uint32_t planes = (uint32_t)b->planes;
-    const uint32_t npasses = (planes + 11u) / 12u;
-    const uint32_t pbits = (planes + npasses - 1u) / npasses;
-    // record width: slot and score in one word where they fit (C3: 17 + 10 bits), else a pair -- the default call moves
-    // one record per (query, document) over PCIe and is bound by exactly those bytes
-    uint32_t slot_bits = 1;
-    while (slot_bits < 32u && (1ull << slot_bits) < row_elems) ++slot_bits;
-    const uint32_t pack_bits = (ix->tune.rank_pack != 0 && slot_bits + planes <= 32u) ? slot_bits : 0u;
-    const size_t rec = pack_bits ? sizeof(uint32_t) : sizeof(uint2);
-    // FULL lists in score order (the reference's default call: threshold 0, no limit) cross PCIe slimmer still: the order
-    // of the slots plus the number of records per score say everything -- C3: 17 bits per result instead of 32, 54 MB
-    // instead of 102 MB for 256 queries (expand_slim above; tuning key rank_slim = 0: the 4-byte records, A/B)
-    bool slim = ix->tune.rank_slim != 0 && pack_bits != 0 && npasses == 1 && limit == 0 && !(b->threshold > 0.0) && stride == per_query;
-    for (size_t q = q_first; slim && q < q_first + nq; ++q) slim = by_score[q] != 0;
-    const uint32_t nbins = 1u << pbits;
-    const size_t words = slim ? (stride * pack_bits + 31) / 32 + 2 : 0;             // dwords of one query's slot stream
-    const size_t qbytes = slim ? (words + nbins) * sizeof(uint32_t) : stride * rec;  // what crosses PCIe per query
-    // Two granularities.  A SPAN is what one kernel launch orders: up to 512 MiB of records -- one work-group per
-    // query, and a work-group alone takes ~0.8 ms for 100 000 documents (dependent loads, one group per CU), so a
-    // launch wants hundreds of queries to fill the device (launching per 32 MiB window left 84 % of the CUs idle and
-    // made the call kernel-bound: profiles/r03_rank_kernel_stats.csv).  A PIECE is what crosses PCIe at a time: 32 MiB
-    // of a span's records into one of three pinned landing buffers, expanded by the host while the next piece crosses.
-    const size_t sq = std::max<size_t>(1, std::min<size_t>(nq, kSpanBytes / (stride * rec)));     // queries per span
-    // (a piece = what is in flight per stage of the PCIe | expansion pipeline: the head of a call is the first piece's
-    // crossing, its tail the last piece's expansion, in between both overlap -- tuning key rank_window_kib)
-    const size_t window = (size_t)std::max<uint32_t>(ix->tune.rank_window_kib, 256u) << 10;
-    // A single-pass sort of a long row is cut into segments, a work-group each (rank_kernels.hip: SEG): one work-group per
-    // query is alone on its CU and latency-bound -- 0.36 ms for 100 000 documents however few queries there are, the
-    // head of every default call.  Tuning key rank_segments: 0 = by row length, 1 = off, else that many.
-    uint32_t nseg = 1;
-    if (npasses == 1) {
-        nseg = ix->tune.rank_segments > 0 ? (uint32_t)std::min(ix->tune.rank_segments, 64)
-                                          : (row_elems >= 65536 ? 8u : row_elems >= 16384 ? 4u : row_elems >= 8192 ? 2u : 1u);
-        if (sq > 65535u) nseg = 1;
-    }
-    const size_t pq = std::max<size_t>(1, std::min<size_t>(sq, window / qbytes));   // queries per piece
-    const size_t land_bytes = (pq * qbytes + 15) / 16 * 16;
     constexpr size_t kDepth = RankWork::kDepth;
-    {   // the workspace: if the device or the pinned pool cannot give it, the caller ranks on the host as before
-        bool ok = true;
-        for (int i = 0; i < 2 && ok; ++i)
-            ok = w.out[i].reserve((sq * stride * rec + sizeof(uint2) - 1) / sizeof(uint2)) == hipSuccess && w.cnt[i].reserve(2 * sq) == hipSuccess;
-        for (size_t i = 0; i < kDepth && ok; ++i) ok = w.land[i].reserve(land_bytes + 4 * pq) == hipSuccess;
-        if (ok && nseg > 1 && w.seghist.reserve(sq * 4u * nseg * (size_t)nbins) != hipSuccess) {
-            (void)hipGetLastError();
-            nseg = 1;
-        }
-        for (int i = 0; i < 2 && ok && slim; ++i)
-            ok = w.packed[i].reserve(sq * words) == hipSuccess && w.bins[i].reserve(sq * nbins) == hipSuccess;
-        if (ok && npasses > 1)
-            for (auto& pr : w.pairs) ok = ok && pr.reserve(sq * row_elems) == hipSuccess;
-        if (!ok) {
-            (void)hipGetLastError();
-            return COBS_GPU_ERR_UNSUPPORTED;
-        }
-    }
-    struct Piece { size_t span, q0, n; bool last_of_span; };      // q0 relative to q_first
-    std::vector<Piece> pieces;
-    const size_t nspans = (nq + sq - 1) / sq;
-    for (size_t sp = 0; sp < nspans; ++sp) {
-        const size_t s0 = sp * sq, s1 = std::min(nq, s0 + sq);
-        for (size_t q0 = s0; q0 < s1; q0 += pq) pieces.push_back(Piece{sp, q0, std::min(pq, s1 - q0), q0 + pq >= s1});
-    }
-    auto launch_span = [&](size_t sp) -> cobs_gpu_status {
-        const int s = (int)(sp & 1);
-        const size_t s0 = sp * sq, n = std::min(nq, s0 + sq) - s0;
-        if (sp >= 2) HIP_TRY(hipStreamWaitEvent(st, w.drained[s], 0));       // the span that used this buffer has crossed PCIe
-        RankArgs a{};
-        a.rows = glob ? (const void*)b->g_rows : (const void*)b->counts.p;
-        a.row_stride = row_elems;
-        a.row_q0 = glob ? (uint32_t)b->g_q0 : 0u;
-        a.parts = w.parts.p;
-        a.by_score = w.by_score.p;
-        a.npass = w.cnt[s].p + sq;
-        a.out = w.out[s].p;
-        a.out_count = w.cnt[s].p;
-        a.pair_stride = row_elems;
-        a.out_stride = stride;
-        a.nparts = (uint32_t)parts.size();
-        a.nslots = (uint32_t)row_elems;
-        a.q0 = (uint32_t)(q_first + s0);
-        a.nq = (uint32_t)n;
-        a.limit = (uint32_t)std::min<size_t>(stride, 0xFFFFFFFFu);
-        a.score_bytes = b->elem_bytes;
-        a.pack_bits = pack_bits;
-        a.bin_count = slim ? w.bins[s].p : nullptr;
-        a.seg_hist = nseg > 1 ? w.seghist.p : nullptr;
-        a.nseg = nseg;
-        for (uint32_t ps = 0; ps < npasses; ++ps) {
-            a.shift = ps * pbits;
-            a.bits = std::min(pbits, planes - a.shift);
-            a.src = w.pairs[(ps + 1) & 1].p;
-            a.dst = w.pairs[ps & 1].p;
-            HIP_TRY(launch_rank(a, ps == 0, ps + 1 == npasses, st));
-        }
-        if (slim) {
-            SlotPackArgs pa{};
-            pa.in = reinterpret_cast<const uint32_t*>(w.out[s].p);
-            pa.out = w.packed[s].p;
-            pa.in_stride = stride;
-            pa.n = (uint32_t)stride;
-            pa.words = (uint32_t)words;
-            pa.slot_bits = pack_bits;
-            pa.nq = (uint32_t)n;
-            HIP_TRY(launch_pack_slots(pa, st));
-        }
-        HIP_TRY(hipEventRecord(w.ranked[s], st));
-        return COBS_GPU_OK;
-    };
-    size_t spans_launched = 0, pieces_issued = 0;
-    auto issue_piece = [&](size_t pi) -> cobs_gpu_status {
-        const Piece& pc = pieces[pi];
-        while (spans_launched <= pc.span) {                      // (a span is launched when its first piece is wanted ...
-            cobs_gpu_status ls = launch_span(spans_launched);
-            if (ls != COBS_GPU_OK) return ls;
-            ++spans_launched;
-        }
-        const int s = (int)(pc.span & 1), l = (int)(pi % kDepth);
-        const size_t off = pc.q0 - pc.span * sq;                 // queries into the span
-        HIP_TRY(hipStreamWaitEvent(w.copy_stream, w.ranked[s], 0));
-        if (slim) {
-            HIP_TRY(hipMemcpyAsync(w.land[l].p, w.packed[s].p + off * words, pc.n * words * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                                   w.copy_stream));
-            HIP_TRY(hipMemcpyAsync(w.land[l].p + pq * words * sizeof(uint32_t), w.bins[s].p + off * nbins, pc.n * nbins * sizeof(uint32_t),
-                                   hipMemcpyDeviceToHost, w.copy_stream));
-        } else {
-            HIP_TRY(hipMemcpyAsync(w.land[l].p, reinterpret_cast<const uint8_t*>(w.out[s].p) + off * stride * rec, pc.n * stride * rec,
-                                   hipMemcpyDeviceToHost, w.copy_stream));
-        }
-        HIP_TRY(hipMemcpyAsync(w.land[l].p + land_bytes, w.cnt[s].p + off, 4 * pc.n, hipMemcpyDeviceToHost, w.copy_stream));
-        HIP_TRY(hipEventRecord(w.landed[l], w.copy_stream));
-        if (pc.last_of_span) {
-            HIP_TRY(hipEventRecord(w.drained[s], w.copy_stream));
-            if (spans_launched < nspans && spans_launched == pc.span + 2) {   // ... or as soon as its buffer drains: it is
-                                                                              // ordered while the span in between crosses)
-                cobs_gpu_status ls = launch_span(spans_launched);
-                if (ls != COBS_GPU_OK) return ls;
-                ++spans_launched;
-            }
-        }
-        ++pieces_issued;
-        return COBS_GPU_OK;
-    };
     const bool trace = ix->tune.trace;
-    double t_wait = 0, t_copy = 0, t_prep = now_s();
+    double t_wait = 0, t_copy = 0;
     cobs_gpu_status rs = COBS_GPU_OK;
-    if (nspans > 1) {                            // both span buffers are free at the start: order two spans right away
-        rs = launch_span(0);
-        if (rs == COBS_GPU_OK) rs = launch_span(1);
-        spans_launched = rs == COBS_GPU_OK ? 2 : 0;
-    }
-    for (size_t pi = 0; rs == COBS_GPU_OK && pi < std::min<size_t>(2, pieces.size()); ++pi) rs = issue_piece(pi);
-    if (rs != COBS_GPU_OK) {                    // nothing of this batch may still be in flight when the caller sees the error
-        (void)hipStreamSynchronize(st);
-        (void)hipStreamSynchronize(w.copy_stream);
-        return rs;
-    }
-    t_prep = now_s() - t_prep;
-    for (size_t wi = 0; wi < pieces.size(); ++wi) {
+    for (size_t wi = 0; wi < j.pieces.size(); ++wi) {
         // two pieces ahead: while the host expands piece wi out of its landing buffer, piece wi+1 crosses PCIe and
         // piece wi+2 is queued behind it (into the landing buffer the host left at iteration wi-1)
-        if (wi + 2 < pieces.size() && (rs = issue_piece(wi + 2)) != COBS_GPU_OK) break;
+        if (wi + 2 < j.pieces.size() && (rs = job_issue_piece(b, w, j, wi + 2)) != COBS_GPU_OK) break;
         const int s = (int)(wi % kDepth);
         double t0 = now_s();
         if (hipEventSynchronize(w.landed[s]) != hipSuccess) { rs = hip_fail(hipGetLastError(), "rank window"); break; }
         t_wait += now_s() - t0;
         t0 = now_s();
-        const Piece& wn = pieces[wi];
-        const uint32_t* cnt = reinterpret_cast<const uint32_t*>(w.land[s].p + land_bytes);
+        const RankJob::Piece& wn = j.pieces[wi];
+        const uint32_t* cnt = reinterpret_cast<const uint32_t*>(w.land[s].p + j.land_bytes);
         const uint8_t* recs = w.land[s].p;
+        const uint32_t* bins_at = reinterpret_cast<const uint32_t*>(recs + j.pq * j.words * sizeof(uint32_t));
         bool full = true;
         for (size_t i = 0; i < wn.n; ++i) full = full && cnt[i] == stride;
         if (full && !*overflow && wn.n * stride <= cap - *used) {
             // every query of the piece yields `stride` results (the default call): one block
-            if (slim)
-                expand_slim(expand_pool(ix->device), hits + *used, reinterpret_cast<const uint32_t*>(recs),
-                            reinterpret_cast<const uint32_t*>(recs + pq * words * sizeof(uint32_t)), wn.n, stride, words, pack_bits,
-                            nbins, parts);
+            if (j.slim)
+                expand_slim(expand_pool(ix->device), hits + *used, reinterpret_cast<const uint32_t*>(recs), bins_at, wn.n, stride,
+                            j.words, j.pack_bits, j.nbins, j.parts);
             else
-                expand_records(expand_pool(ix->device), hits + *used, recs, wn.n * stride, pack_bits, parts);
+                expand_records(expand_pool(ix->device), hits + *used, recs, wn.n * stride, j.pack_bits, j.parts);
             for (size_t i = 0; i < wn.n; ++i) {
                 *used += stride;
                 hit_offsets[wn.q0 + i + 1] = *used;
@@ -625,12 +695,11 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
         for (size_t i = 0; i < wn.n; ++i) {
             const size_t n = cnt[i];
             if (!*overflow && n <= cap - *used) {
-                if (slim)
-                    expand_slim(expand_pool(ix->device), hits + *used, reinterpret_cast<const uint32_t*>(recs) + i * words,
-                                reinterpret_cast<const uint32_t*>(recs + pq * words * sizeof(uint32_t)) + i * nbins, 1, n, words,
-                                pack_bits, nbins, parts);
+                if (j.slim)
+                    expand_slim(expand_pool(ix->device), hits + *used, reinterpret_cast<const uint32_t*>(recs) + i * j.words,
+                                bins_at + i * j.nbins, 1, n, j.words, j.pack_bits, j.nbins, j.parts);
                 else
-                    expand_records(expand_pool(ix->device), hits + *used, recs + i * stride * rec, n, pack_bits, parts);
+                    expand_records(expand_pool(ix->device), hits + *used, recs + i * stride * j.rec, n, j.pack_bits, j.parts);
             } else
                 *overflow = true;
             *used += n;
@@ -640,8 +709,8 @@ cobs_gpu_status rank_on_device(cobs_gpu_batch* b, size_t q_first, size_t nq, siz
     if (trace)
         std::fprintf(stderr, "[cobs_gpu] device ranking: %zu queries x %zu records in %zu pieces (%s, %zu bytes per query); first "
                      "launches %.3f ms, waiting for windows %.3f ms, copying out of the landing buffers %.3f ms\n",
-                     nq, stride, pieces.size(), slim ? "slot streams + score counts" : pack_bits ? "4-byte records" : "8-byte records",
-                     qbytes, t_prep * 1e3, t_wait * 1e3, t_copy * 1e3);
+                     nq, stride, j.pieces.size(), j.slim ? "slot streams + score counts" : j.pack_bits ? "4-byte records" : "8-byte records",
+                     j.qbytes, j.t_prep * 1e3, t_wait * 1e3, t_copy * 1e3);
     if (rs != COBS_GPU_OK) {                    // nothing of this batch may still be in flight when the caller sees the error
         (void)hipStreamSynchronize(st);
         (void)hipStreamSynchronize(w.copy_stream);
