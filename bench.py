@@ -297,7 +297,7 @@ def end_to_end(search, batch, queries, hit_queries=None):
     keep = np.zeros(nd * search.total_counts, dtype=search.HIT_DTYPE)
     search.search_packed(sub_text, sub_offs, 0.0, 0, out=keep)
     best = None
-    for _ in range(3):
+    for _ in range(7):
         t0 = time.perf_counter()
         offs, hits = search.search_packed(sub_text, sub_offs, 0.0, 0, out=keep)
         dt = time.perf_counter() - t0
@@ -313,7 +313,7 @@ def end_to_end(search, batch, queries, hit_queries=None):
     # the same call into a FRESH array per call (first-touch page faults of 307 MB, which the library asks to be huge
     # pages), and with the results left in the arena the library keeps on the handle (cobs_gpu_search_batch_view)
     fresh = None
-    for _ in range(3):
+    for _ in range(5):
         buf = np.empty(nd * search.total_counts, dtype=search.HIT_DTYPE)
         t0 = time.perf_counter()
         search.search_packed(sub_text, sub_offs, 0.0, 0, out=buf)
@@ -323,7 +323,7 @@ def end_to_end(search, batch, queries, hit_queries=None):
     qlist = [bytes(q) for q in queries[:nd]]
     search.search_view(qlist, 0.0, 0)
     view = None
-    for _ in range(3):
+    for _ in range(7):
         t0 = time.perf_counter()
         vo, vh = search.search_view(qlist, 0.0, 0)
         dt = time.perf_counter() - t0
