@@ -21,11 +21,7 @@ Either way the printed line carries n_gpus == --gpus == rccl_ranks, or the run f
 import argparse
 import json
 import os
-import select
-import signal
-import subprocess
 import sys
-import threading
 import time
 import traceback
 
@@ -37,6 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import cobs_amd  # noqa: E402
+from cobs_amd.launch import (Watchdog, _StorePeers, bind_to_numa_node, gpu_numa_node, launch_plan,  # noqa: E402,F401
+                             run_preflight, visible_devices)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 PCIE_PEAK_GBS = 63.0       # PCIe Gen5 x16 (MI355X_MICROARCH.md: 63 GB/s spec), the bound of the out-of-core configuration
@@ -247,6 +245,14 @@ def cpu_baseline(search, cfg, queries, seconds_target=12.0, check_queries=4, bat
     return res
 
 
+def pack_queries(qs):
+    """the query text as one host buffer + offsets (search_packed / sharded_search_arrays)"""
+    t = np.frombuffer(b"".join(qs), dtype=np.uint8)
+    o = np.zeros(len(qs) + 1, dtype=np.uint64)
+    np.cumsum([len(q) for q in qs], out=o[1:])
+    return t, o
+
+
 def end_to_end(search, batch, queries, hit_queries=None):
     """PCIe-inclusive rates of the host-buffer API on the same batch (never `value`):
     query text H2D + K1 + K2 (+ selection) + D2H of the results + host ordering.
@@ -255,12 +261,7 @@ def end_to_end(search, batch, queries, hit_queries=None):
     res = {}
     nq = len(queries)
 
-    def packed(qs):
-        # the query text as one host buffer + offsets (search_packed); the passes of a call are pipelined
-        t = np.frombuffer(b"".join(qs), dtype=np.uint8)
-        o = np.zeros(len(qs) + 1, dtype=np.uint64)
-        np.cumsum([len(q) for q in qs], out=o[1:])
-        return t, o
+    packed = pack_queries
     text, offsets = packed(queries)
     cases_ = [("threshold_0.8_random_queries", 0.8, 0, text, offsets), ("threshold_0_top10", 0.0, 10, text, offsets)]
     if hit_queries:
@@ -353,44 +354,6 @@ def end_to_end(search, batch, queries, hit_queries=None):
     res["threshold_0_all_scores_to_pinned_host"] = {
         "queries_per_s": round(nq / dt, 1), "seconds": round(dt, 4),
         "d2h_GB": round(t.numel() * t.element_size() / 1e9, 3)}
-    # the same in four parts: the rows of part i cross PCIe while part i + 1 is scanned (SURVEY 8d mode iii is bound by
-    # the link, not by scan + link)
-    parts = 4 if nq >= 64 else 1
-    if parts > 1:
-        subs, offs_q = [], [nq * i // parts for i in range(parts + 1)]
-        for i in range(parts):
-            bi = cobs_amd.Batch(search)
-            bi.set_queries(queries[offs_q[i]:offs_q[i + 1]])
-            subs.append(bi)
-        scan_s, copy_s = torch.cuda.Stream(), torch.cuda.Stream()
-
-        def piped():
-            for i, bi in enumerate(subs):
-                bi.run(0.0, scan_s.cuda_stream)
-                ev = torch.cuda.Event()
-                ev.record(scan_s)
-                copy_s.wait_event(ev)
-                ti = bi.counts_tensor()
-                with torch.cuda.stream(copy_s):
-                    host[offs_q[i]:offs_q[i + 1]].copy_(ti, non_blocking=True)
-            torch.cuda.synchronize()
-            for bi in subs:
-                bi.sync(scan_s.cuda_stream)
-        piped()
-        best = None
-        for _ in range(2):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            piped()
-            dtp = time.perf_counter() - t0
-            best = dtp if best is None else min(best, dtp)
-        batch.run(0.0, 0)
-        batch.sync()
-        same = bool(torch.equal(host[:64].to(t.device), t[:64]) and torch.equal(host[-64:].to(t.device), t[-64:]))
-        res["threshold_0_all_scores_to_pinned_host"]["in_%d_parts_scan_beside_copy" % parts] = {
-            "queries_per_s": round(nq / best, 1), "seconds": round(best, 4),
-            "d2h_GBps": round(t.numel() * t.element_size() / best / 1e9, 1), "same_rows": same}
-        del subs
     return res
 
 
@@ -504,37 +467,6 @@ def kernels_hash():
     return h.hexdigest()[:16]
 
 
-def gpu_numa_node(dev):
-    """the NUMA node the GPU's PCIe root sits on (sysfs), or None"""
-    try:
-        pr = torch.cuda.get_device_properties(dev)
-        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
-        with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
-            n = int(f.read().strip())
-        return n if n >= 0 else None
-    except Exception:                                               # noqa: BLE001
-        return None
-
-
-def bind_to_numa_node(node):
-    """this process (and the host threads the library starts: staging copies, pinned buffers they first touch) on the CPUs
-    of `node` -- with 8 ranks on two sockets every rank's host side then sits next to its GPU.  -> CPUs bound to, or 0"""
-    if node is None:
-        return 0
-    try:
-        cpus = set()
-        with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
-            for part in f.read().strip().split(","):
-                a, _, b = part.partition("-")
-                cpus.update(range(int(a), int(b or a) + 1))
-        cpus &= os.sched_getaffinity(0)
-        if cpus:
-            os.sched_setaffinity(0, cpus)
-        return len(cpus)
-    except Exception:                                               # noqa: BLE001
-        return 0
-
-
 def make_index(cfg, dev, rank=0, world=1, hbm_budget=0, path=None):
     # Which balance a shard split wants: a RESIDENT shard's time is the work of its gather -- the columns it holds
     # (shard_mode 0); a shard STREAMED under an HBM budget is bound by the bytes that cross its PCIe link per pass --
@@ -553,19 +485,14 @@ def make_index(cfg, dev, rank=0, world=1, hbm_budget=0, path=None):
 
 
 class ShardedRun:
-    """north_star's multi-GPU layout: the index sharded by sub-index block over the ranks
-    (equal work per rank: a cut may fall inside a sub-index), ONE query batch shared by all ranks,
-    every rank scans its slice for the whole batch, then one exchange of the per-document counts
-    over RCCL / xGMI inside libcobs_gpu.so (comm.cpp).  mode ALLTOALL: rank j ends up with the
-    complete count rows (global document order) of the queries [nq*j/N, nq*(j+1)/N) -- every
-    count crosses the fabric once; ALLGATHER: every rank ends up with every row.
-    The batch is cut into nsub sub-batches (the reference's own loop is per batch of documents,
-    classic_search.cpp:355-400; here the cut is over queries): K1 of a sub-batch runs on the batch's own
-    stream (tuning key hash_stream), K2 on the scan stream, the exchange on the exchange stream, tied by
-    events only -- hash(i+1) | scan(i) | exchange(i-1) overlap, also across steps (scan i of step s+1 waits
-    for exchange i of step s, whose source it overwrites, and for nothing else).
-    --dist-backend gloo (several ranks on ONE GPU, smoke tests only) executes the library's own
-    exchange plan (cobs_gpu_exchange_plan) with torch.distributed transfers instead of RCCL."""
+    """north_star's multi-GPU layout: the index sharded by sub-index block over the ranks (equal work per rank: a cut may
+    fall inside a sub-index), ONE query batch shared by all ranks, every rank scans its slice for the whole batch, then
+    one exchange of the per-document counts over RCCL / xGMI.  The step is the LIBRARY's (cobs_gpu_sharded_batch_step,
+    sharded.cpp): the batch cut into nsub sub-batches whose hashing, scan and exchange overlap on three streams tied by
+    events, also across steps -- this class only builds the index and calls it.  mode ALLTOALL: rank j ends up with the
+    complete count rows (global document order) of the queries [nq*j/N, nq*(j+1)/N); ALLGATHER: every rank with every row.
+    comm None (--dist-backend gloo: several ranks on ONE GPU, or the preflight's last resort) executes the library's own
+    exchange plan (cobs_gpu_exchange_plan) with torch.distributed transfers through host memory instead."""
 
     def __init__(self, cfg, queries, world, rank, dev, comm, nsub=1, threshold=0.0, mode=None, hbm_budget=0,
                  path=None, backend="nccl"):
@@ -575,6 +502,14 @@ class ShardedRun:
         self.threshold = threshold
         self.s = make_index(cfg, dev, rank, world, hbm_budget, path)
         nsub = max(1, min(nsub, len(queries)))
+        self.steps_seen = 0
+        if comm is not None:
+            self.sb = cobs_amd.ShardedBatch(self.s, comm, nsub)
+            self.sb.set_queries(queries)
+            self.sub = self.sb.subs
+            self.sub_queries = [queries[b.q_begin:b.q_begin + b.nq] for b in self.sub]
+            return
+        from cobs_amd.distributed import shard_slots
         self.sub, self.sub_queries = [], []
         for i in range(nsub):
             bi = cobs_amd.Batch(self.s)
@@ -582,96 +517,53 @@ class ShardedRun:
             bi.set_queries(qi)
             self.sub.append(bi)
             self.sub_queries.append(qi)
-        self.layouts = None
-        if comm is not None:
-            if nsub > 1:
-                self.s.set_tuning("hash_stream", 1)
-            self.scan_stream, self.x_stream = torch.cuda.Stream(), torch.cuda.Stream()
-            self.x_done = [None] * nsub
-        else:
-            from cobs_amd.distributed import shard_slots
-            self.layouts = shard_slots(self.s, None)
-        self.x_events = []                  # (begin, end) of every exchange since the last reset (timing events)
-        self.x_host_s = 0.0                 # gloo path: host seconds inside the exchange
-        self.steps_seen = 0
-        self.tied = False
-        self.rows = [None] * nsub           # gloo path: (q_begin, q_count, assembled rows) of the last step
+        self.layouts = shard_slots(self.s, None)
+        self.x_host_s = 0.0                 # host seconds inside the exchange
+        self.rows = [None] * nsub           # (q_begin, q_count, assembled rows) of the last step
         self.moved = 0
 
     def step(self):
         self.steps_seen += 1
-        if self.comm is None:                       # gloo smoke path: the library's plan, torch.distributed transfers
-            from cobs_amd.distributed import exchange_counts_by_plan
-            self.moved = 0
-            for i, bi in enumerate(self.sub):
-                bi.run(self.threshold, 0)
-                bi.sync()
-                t0 = time.perf_counter()
-                local = bi.counts_tensor()
-                self.rows[i] = exchange_counts_by_plan(local, self.layouts, self.s.total_counts, len(self.sub_queries[i]),
-                                                       self.mode, None)
-                torch.cuda.synchronize()
-                self.x_host_s += time.perf_counter() - t0
-                q0, qn, rows = self.rows[i]
-                mine = self.layouts[self.rank]
-                self.moved += qn * (self.s.total_counts - sum(c for (_, c, _) in mine)) * rows.element_size()
+        if self.comm is not None:
+            self.sb.step(self.threshold, self.mode)
             return
-        ss, xs = self.scan_stream, self.x_stream
-        if not self.tied:                            # once: everything queued so far on the current stream comes first
-            ss.wait_stream(torch.cuda.current_stream())
-            xs.wait_stream(torch.cuda.current_stream())
-            self.tied = True
+        from cobs_amd.distributed import exchange_counts_by_plan
+        self.moved = 0
         for i, bi in enumerate(self.sub):
-            if self.x_done[i] is not None:
-                ss.wait_event(self.x_done[i])        # the previous step's exchange read the count rows this scan overwrites
-            bi.run(self.threshold, ss.cuda_stream)
-            scanned = torch.cuda.Event()
-            scanned.record(ss)
-            xs.wait_event(scanned)
-            xb, xe = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            xb.record(xs)
-            bi.exchange_counts(self.comm, self.mode, xs.cuda_stream)
-            xe.record(xs)
-            self.x_done[i] = xe
-            self.x_events.append((xb, xe))
-
-    def _sync_all(self):
-        for bi in self.sub:
-            bi.sync(self.scan_stream.cuda_stream if self.comm is not None else 0)
-        torch.cuda.synchronize()
+            bi.run(self.threshold, 0)
+            bi.sync()
+            t0 = time.perf_counter()
+            self.rows[i] = exchange_counts_by_plan(bi.counts_tensor(), self.layouts, self.s.total_counts, len(self.sub_queries[i]),
+                                                   self.mode, None)
+            torch.cuda.synchronize()
+            self.x_host_s += time.perf_counter() - t0
+            q0, qn, rows = self.rows[i]
+            self.moved += qn * (self.s.total_counts - sum(c for (_, c, _) in self.layouts[self.rank])) * rows.element_size()
 
     def finish(self):
         """-> per step on this rank, summed over the sub-batches:
         (scan ms, hash ms, exchange ms, algorithmic bytes, bytes received)"""
-        self._sync_all()
-        scan = hsh = algo = moved = 0
-        for bi in self.sub:
-            ms = bi.kernel_ms()
-            scan += ms["scan_ms"]
-            hsh += ms["hash_ms"]
-            algo += bi.stats()["algorithmic_bytes"]
-            moved += bi.exchange_bytes() if self.comm is not None else 0
-        if self.comm is None:
-            moved = self.moved
-        steps = max(self.steps_seen, 1)
         if self.comm is not None:
-            xms = sum(b.elapsed_time(e) for (b, e) in self.x_events) / steps
-        else:
-            xms = self.x_host_s * 1e3 / steps
-        return scan, hsh, xms, algo, moved
+            self.sb.sync()
+            t = self.sb.times()
+            return t["scan_ms"], t["hash_ms"], t["exchange_ms"], t["algorithmic_bytes"], t["received_bytes"]
+        scan = hsh = algo = 0
+        for bi in self.sub:
+            bi.sync()
+            ms = bi.kernel_ms()
+            scan, hsh, algo = scan + ms["scan_ms"], hsh + ms["hash_ms"], algo + bi.stats()["algorithmic_bytes"]
+        return scan, hsh, self.x_host_s * 1e3 / max(self.steps_seen, 1), algo, self.moved
 
     def drop_warmup_events(self):
-        self._sync_all()
-        for bi in self.sub:
-            bi.kernel_ms()
-        self.x_events, self.x_host_s, self.steps_seen = [], 0.0, 0
+        self.finish()
+        self.steps_seen = 0
+        if self.comm is None:
+            self.x_host_s = 0.0
 
     def owned_rows(self, i):
         """after the last step: (first query, query count, rows [count, total_counts]) this rank holds of sub-batch i,
         in GLOBAL document order -- what the exchange assembled"""
-        if self.comm is None:
-            return self.rows[i]
-        return self.sub[i].global_counts_tensor()
+        return self.rows[i] if self.comm is None else self.sub[i].global_counts_tensor()
 
     def local_rows(self, i):
         return self.sub[i].counts_tensor()
@@ -892,6 +784,35 @@ def side_measurements(args, cfg, queries, world, rank, dev, comm):
     return out
 
 
+def sharded_product_calls(s, comm, cfg, args, world):
+    """N > 1 (and --one-rank-sharded), never `value`: what a CALLER of the multi-GPU layout gets -- host buffers in,
+    finished result lists out -- from cobs_gpu_sharded_search_batch (the call behind cobs_gpu_multi_search_batch,
+    cobs_gpu::ShardedClassicSearch and `cobs_gpu_query -d`): passes pipelined inside the library, one all-gathered
+    status record per pass, hit records exchanged over the communicator and ordered on the device (sharded.cpp)."""
+    res = {}
+    hit_q = planted_queries(cfg["plants"], args.queries, args.kmers)
+    text, offs = pack_queries(hit_q)
+    s.sharded_search_arrays(comm, (text, offs), 0.8, 0)          # sizes the workspaces and the result buffer
+    best, n_hits = None, 0
+    for _ in range(3):
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        o, h = s.sharded_search_arrays(comm, (text, offs), 0.8, 0)
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        best, n_hits = dt if best is None else min(best, dt), int(len(h))
+    res["sharded_search_batch_threshold_0.8"] = {
+        "queries_per_s": round(len(hit_q) / best, 1), "seconds": round(best, 4), "hits": n_hits, "ranks": world,
+        "is": "cobs_gpu_sharded_search_batch on every rank, the planted batch (queries with hits) at the CLI's default threshold: "
+              "upload + K1 of pass i+1 | K2 of pass i | agreement, hit exchange and ordering of pass i-1, inside the library; "
+              "every rank returns every query's list; max over ranks, best of 3"}
+    return res
+
+
 def workload_text(args, cfg):
     if args.config == "c2":
         return ("BASELINE configs[1]: synthetic classic index, %d docs x %d rows, batch of %d queries x %d k-mers"
@@ -913,241 +834,6 @@ def workload_text(args, cfg):
 
 
 METRIC = "k-mer queries/sec + achieved HBM GB/s, 100k-doc compact index, 1000-kmer query"
-
-
-class Watchdog(threading.Thread):
-    """A run of N ranks must not end as a silent driver time-out: a collective that one rank never
-    enters does not fail, it waits.  One watchdog thread per rank: the main thread names the PHASE it is in and how long
-    that may take; when a phase overruns -- or the launcher sends SIGTERM because another rank died -- every rank prints
-    what it was doing (phase, step, what its communicator entered last, whether that stream is idle) to stderr and
-    leaves it for rank 0, and rank 0 emits ONE JSON line with "error" and the ranks' states, then every rank exits
-    non-zero.  Deadlines are the same on every rank and phases are aligned by barriers, so all ranks fire together."""
-
-    def __init__(self, rank, world, emit, peers=None, exit_fn=os._exit, scale=1.0, grace=3.0):
-        super().__init__(daemon=True, name="bench-watchdog")
-        self.rank, self.world, self.emit, self.peers, self.exit_fn = rank, world, emit, peers, exit_fn
-        self.scale, self.grace = scale, grace
-        self.lock = threading.Lock()
-        self.phase_name, self.deadline, self.t_phase = "start", None, time.time()
-        self.notes, self.comm, self.extra = {}, None, {}
-        self.stop_ev = threading.Event()
-        self.fired = False
-        self.result_emitted = False         # rank 0 has printed the run's line: whatever goes wrong afterwards must not add another
-        self.wake_r = None
-
-    def phase(self, name, seconds=None):
-        with self.lock:
-            self.phase_name, self.t_phase = name, time.time()
-            self.deadline = None if seconds is None else self.t_phase + seconds * self.scale
-
-    def note(self, **kv):
-        with self.lock:
-            self.notes.update(kv)
-
-    def attach(self, comm):
-        self.comm = comm
-
-    def done(self):
-        self.stop_ev.set()
-
-    def catch_sigterm(self):
-        """main thread only.  The launcher answers a dead rank with SIGTERM to the others; a Python handler would wait
-        for the main thread to come back from the call it is stuck in -- the wake-up descriptor is written by the C-level
-        handler at once and read by this thread."""
-        r, w = os.pipe()
-        os.set_blocking(w, False)
-        signal.signal(signal.SIGTERM, lambda *_: None)
-        signal.set_wakeup_fd(w, warn_on_full_buffer=False)
-        self.wake_r = r
-
-    def state(self):
-        with self.lock:
-            st = {"rank": self.rank, "phase": self.phase_name, "seconds_in_phase": round(time.time() - self.t_phase, 1),
-                  "deadline_s": None if self.deadline is None else round(self.deadline - self.t_phase, 1)}
-            st.update(self.notes)
-        comm = self.comm
-        if comm is not None:
-            box = []
-            t = threading.Thread(target=lambda: box.append(comm.state()), daemon=True)      # (a query of a wedged runtime may block too)
-            t.start()
-            t.join(2.0)
-            st["comm"] = box[0] if box else "no answer from the runtime within 2 s"
-        return st
-
-    def fail(self, why, code=4):
-        """-> does not return: states to stderr / to rank 0, the error line from rank 0, exit"""
-        if self.fired:
-            return
-        self.fired = True
-        st = self.state()
-        sys.stderr.write("[bench watchdog] rank %d: %s -- %s\n" % (self.rank, why, json.dumps(st)))
-        sys.stderr.flush()
-        if self.result_emitted:
-            # (a rank that hangs or dies in the shutdown: the measurement is complete and printed; stdout keeps its ONE line)
-            self.exit_fn(0)
-            return
-        if self.peers is not None:
-            try:
-                self.peers.set("wd/%d" % self.rank, json.dumps(st))
-            except Exception:                                       # noqa: BLE001
-                pass
-        if self.rank == 0:
-            states = {0: st}
-            t_end = time.time() + self.grace
-            for r in range(1, self.world):
-                got = None
-                while self.peers is not None and got is None:
-                    try:
-                        got = self.peers.get("wd/%d" % r)
-                    except Exception:                               # noqa: BLE001
-                        got = None
-                    if got is not None or time.time() > t_end:
-                        break
-                    time.sleep(0.1)
-                states[r] = json.loads(got) if got else "no state received within %.0f s" % self.grace
-            line = {"metric": METRIC, "value": None, "unit": "queries/s", "n_gpus": self.world, "higher_is_better": True,
-                    "error": why, "phase": st["phase"], "watchdog": {"per_rank": [states[r] for r in range(self.world)]}}
-            line.update(self.extra)
-            try:
-                self.emit(line)
-            except Exception:                                       # noqa: BLE001
-                pass
-        else:
-            time.sleep(self.grace + 2.0)        # (the launcher kills every rank as soon as one exits: let rank 0 print first)
-        self.exit_fn(code)
-
-    def run(self):
-        while not self.stop_ev.is_set():
-            if self.wake_r is not None:
-                ready, _, _ = select.select([self.wake_r], [], [], 0.25)
-                if ready:
-                    sigs = os.read(self.wake_r, 64)
-                    if signal.SIGTERM in sigs:
-                        self.fail("terminated by the launcher (SIGTERM) in phase '%s': another rank failed or the run was timed out"
-                                  % self.phase_name, code=143)
-            else:
-                self.stop_ev.wait(0.25)
-            with self.lock:
-                late = self.deadline is not None and time.time() > self.deadline
-                name, limit = self.phase_name, (self.deadline or 0) - self.t_phase
-            if late:
-                self.fail("phase '%s' did not finish within %.0f s" % (name, limit))
-
-
-class _StorePeers:
-    """the ranks' states for rank 0, through the store torch.distributed's rendezvous runs on (served by the launcher /
-    rank 0 in a background thread: it answers while the main threads are stuck)"""
-    def __init__(self, store):
-        self.store = store
-    def set(self, key, value):
-        self.store.set("cobs_bench/" + key, value)
-    def get(self, key):
-        if not self.store.check(["cobs_bench/" + key]):
-            return None
-        return self.store.get("cobs_bench/" + key).decode()
-
-
-def other_ipc_mode(v):
-    return "1" if v == "0" else "0"
-
-
-def preflight_child(args):
-    """one rank of one preflight attempt, in its OWN process (HSA_ENABLE_IPC_MODE_LEGACY is read once, when the ROCm
-    runtime initialises: another value needs another process; and a hang in ncclCommInitRank can only be ended by
-    killing the process that sits in it).  Prints one JSON line."""
-    res = {"ok": False, "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
-    try:
-        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-        store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"]), None, False,
-                              timeout=__import__("datetime").timedelta(seconds=args.preflight_seconds))
-        key = "cobs_bench/pf/%s/uid" % args.preflight_child
-        dev = args.preflight_device
-        torch.cuda.set_device(dev)
-        from cobs_amd.distributed import Comm
-        if rank == 0:
-            store.set(key, Comm.unique_id())
-        uid = store.get(key)
-        t0 = time.time()
-        comm = Comm(uid, rank, world, device=dev)
-        res["comm_init_s"] = round(time.time() - t0, 2)
-        res["rccl_ranks"] = comm.size
-        res.update(comm.preflight(timeout_ms=int(args.preflight_seconds * 400), big_bytes=args.preflight_big_mib << 20))
-        comm.close()
-        res["ok"] = True
-    except BaseException as e:                                      # noqa: BLE001
-        res["error"] = "%s: %s" % (type(e).__name__, str(e)[:400])
-    _RESULT_STDOUT.write(json.dumps(res) + "\n")
-    _RESULT_STDOUT.flush()
-    os._exit(0 if res["ok"] else 5)
-
-
-def run_preflight(args, world, rank, device, wd):
-    """Before the index is built: does a communicator of these ranks come up AND move bytes --
-    uneven grouped send / receive all-to-all, all-gather, all-reduce, every byte checked, each step under a time limit
-    (cobs_gpu_comm_preflight) -- under the HSA_ENABLE_IPC_MODE_LEGACY value of the environment?  If not, once more
-    under the other value; if neither works the run falls back to the host transport (torch.distributed / gloo: the
-    library's own exchange plan, the bytes through host memory) and says so.  Every attempt is one child process per
-    rank; the ranks agree on each attempt's outcome over the (gloo) process group.
-    -> (dict for the JSON line, transport "rccl" | "gloo")"""
-    info = {"attempts": []}
-    first = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    for attempt, mode in enumerate((first, other_ipc_mode(first))):
-        wd.phase("preflight attempt %d (HSA_ENABLE_IPC_MODE_LEGACY=%s)" % (attempt, mode), args.preflight_seconds + 45)
-        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=mode)
-        cmd = [sys.executable, os.path.abspath(__file__), "--preflight-child", "a%d" % attempt, "--preflight-device", str(device),
-               "--preflight-seconds", str(args.preflight_seconds), "--preflight-big-mib", str(args.preflight_big_mib)]
-        mine = {"ok": False}
-        t0 = time.time()
-        try:
-            child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-            try:
-                out, err = child.communicate(timeout=args.preflight_seconds)
-                lines = [ln for ln in out.splitlines() if ln.startswith("{")]
-                mine = json.loads(lines[-1]) if lines else {"ok": False, "error": "no result line; exit code %d; stderr: %s"
-                                                            % (child.returncode, err[-300:])}
-            except subprocess.TimeoutExpired:
-                child.kill()
-                child.communicate()
-                mine = {"ok": False, "error": "no answer within %g s (killed): the communicator did not come up or a collective hung"
-                                              % args.preflight_seconds}
-        except Exception as e:                                      # noqa: BLE001
-            mine = {"ok": False, "error": "could not run the preflight child: %r" % (e,)}
-        mine["seconds"] = round(time.time() - t0, 2)
-        every = [None] * world
-        dist.all_gather_object(every, mine)
-        ok = all(bool(r and r.get("ok")) for r in every)
-        rec = {"HSA_ENABLE_IPC_MODE_LEGACY": mode, "ok": ok, "seconds_max": max(r.get("seconds", 0) for r in every)}
-        if ok:
-            rec["comm_init_s_max"] = max(r.get("comm_init_s", 0) for r in every)
-            for k in ("alltoall_us", "allgather_us", "allreduce_us", "big_alltoall_us"):
-                if all(k in r for r in every):
-                    rec[k + "_max"] = max(r[k] for r in every)
-            if all("big_alltoall_recv_GBps" in r for r in every):
-                rec["big_alltoall_recv_GBps_min"] = min(r["big_alltoall_recv_GBps"] for r in every)
-                rec["big_alltoall_MiB_per_pair"] = args.preflight_big_mib
-        else:
-            rec["errors"] = {str(i): r.get("error", "?") for i, r in enumerate(every) if not (r and r.get("ok"))}
-        info["attempts"].append(rec)
-        if ok:
-            os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = mode     # (this process has not initialised the ROCm runtime yet)
-            info["ipc_mode_legacy_used"] = mode
-            info["transport"] = "rccl"
-            return info, "rccl"
-    info["transport"] = "gloo"
-    info["fallback"] = ("RCCL did not pass the preflight under either IPC mode: the exchange of this run goes through host memory "
-                        "(torch.distributed / gloo executing the library's own exchange plan) -- a slow but true number")
-    return info, "gloo"
-
-
-def launch_plan(gpus, argv):
-    """`python bench.py --gpus N` started without a launcher: the command that runs the N ranks
-    (one process per GPU, rendezvous on 127.0.0.1, a free port)."""
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
-            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
 def main():
@@ -1201,8 +887,6 @@ def main():
                     help="N>1: skip the RCCL preflight (communicator + first collectives in child processes, with the IPC-mode fallback)")
     ap.add_argument("--preflight-seconds", type=float, default=75.0, help="time limit of one preflight attempt")
     ap.add_argument("--preflight-big-mib", type=int, default=8, help="the preflight's timed all-to-all: MiB per pair of ranks (0 = none)")
-    ap.add_argument("--preflight-child", default="", help=argparse.SUPPRESS)
-    ap.add_argument("--preflight-device", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--deadline-scale", type=float, default=1.0,
                     help="the watchdog's phase deadlines times this (a phase that overruns ends the run with an error line instead of a hang)")
     ap.add_argument("--step-deadline", type=float, default=0.0,
@@ -1214,15 +898,13 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
-    if args.preflight_child:
-        preflight_child(args)
 
     launched = "WORLD_SIZE" in os.environ
     if args.dry_run_launch:
         plan = {"gpus": args.gpus, "launched_by": "torch.distributed.run (environment)" if launched else
                 ("self" if args.gpus > 1 else "none: one process"),
                 "command": None if launched or args.gpus == 1 else
-                launch_plan(args.gpus, [a for a in sys.argv[1:] if a != "--dry-run-launch"]),
+                launch_plan(args.gpus, [a for a in sys.argv[1:] if a != "--dry-run-launch"], __file__),
                 "ranks": args.gpus, "devices": list(range(args.gpus))}
         _RESULT_STDOUT.write(json.dumps(plan) + "\n")
         _RESULT_STDOUT.flush()
@@ -1235,7 +917,7 @@ def main():
             raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible" % (args.gpus, visible_devices()))
         sys.stderr.flush()
         os.dup2(_RESULT_STDOUT.fileno(), 1)
-        cmd = launch_plan(args.gpus, sys.argv[1:])
+        cmd = launch_plan(args.gpus, sys.argv[1:], __file__)
         os.execv(cmd[0], cmd)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1250,7 +932,7 @@ def main():
         if "error" not in line:
             wd.result_emitted = True
 
-    wd = Watchdog(rank, world, emit, scale=args.deadline_scale)
+    wd = Watchdog(rank, world, emit, scale=args.deadline_scale, metric=METRIC)
     wd.catch_sigterm()
     wd.start()
     try:
@@ -1265,16 +947,6 @@ def main():
         wd.fail("rank %d failed in phase '%s': %s: %s" % (rank, wd.phase_name, type(e).__name__, str(e)[:500]), code=1)
     finally:
         wd.done()
-
-
-def visible_devices():
-    """HIP devices visible to this job, counted by a child process (so that the caller does not initialise the runtime)"""
-    try:
-        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True,
-                           text=True, timeout=300)
-        return int(r.stdout.strip().splitlines()[-1])
-    except Exception:                                               # noqa: BLE001
-        return 0
 
 
 def run_bench(args, world, rank, local_rank, wd, emit):
@@ -1535,6 +1207,10 @@ def run_bench(args, world, rank, local_rank, wd, emit):
         info = s.info(0)
         out["shard_rank0"] = {"hbm_bytes": int(info.hbm_bytes), "slot_begin": int(info.slot_begin),
                               "slot_count": int(info.slot_count)}
+        ok_pc = comm is not None and bool(cfg.get("plants")) and not budget
+        if all_ranks_ok(ok_pc, args.dist_backend) and ok_pc:
+            wd.phase("the product call (cobs_gpu_sharded_search_batch)", 600)
+            out["end_to_end"] = sharded_product_calls(s, comm, cfg, args, world)
     if budget:
         info = s.info(0)
         index_bytes = sum(cfg["signature_sizes"]) * (cfg["page_size"] or (cfg["num_docs"] + 7) // 8)

@@ -10,10 +10,10 @@ from .construct import (ClassicIndexParameters, CompactIndexParameters, Document
                         classic_construct, classic_construct_list, compact_construct,
                         compact_construct_list, disable_cache, write_synthetic, build_search,
                         classic_combine, compact_combine, classic_construct_random, DocumentEntry, FileType)
-from .search import Batch, MultiSearch, Search, SearchResult  # noqa: F401
+from .search import Batch, MultiSearch, Search, SearchResult, ShardedBatch  # noqa: F401
 
 __version__ = "0.2.0"
-__all__ = ["Search", "MultiSearch", "SearchResult", "Batch", "CobsGpuError", "DocumentList", "DocumentEntry", "FileType",
+__all__ = ["Search", "MultiSearch", "SearchResult", "Batch", "ShardedBatch", "CobsGpuError", "DocumentList", "DocumentEntry", "FileType",
            "ClassicIndexParameters",
            "CompactIndexParameters", "classic_construct", "classic_construct_list", "compact_construct",
            "compact_construct_list", "disable_cache", "write_synthetic", "build_search", "classic_combine", "compact_combine",

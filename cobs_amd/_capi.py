@@ -182,6 +182,14 @@ SYMBOLS = {
                                              C.POINTER(Hit), _sz, C.POINTER(_sz), C.POINTER(_sz)]),
     "cobs_gpu_sharded_search_batch_split": (_int, [_vp, _vp, C.POINTER(_cp), C.POINTER(_sz), _sz, _dbl, _sz,
                                                    C.POINTER(Hit), _sz, C.POINTER(_sz), C.POINTER(_sz)]),
+    "cobs_gpu_sharded_batch_create": (_int, [_vp, _vp, _u32, C.POINTER(_vp)]),
+    "cobs_gpu_sharded_batch_destroy": (None, [_vp]),
+    "cobs_gpu_sharded_batch_set_queries": (_int, [_vp, C.POINTER(_cp), C.POINTER(_sz), _sz]),
+    "cobs_gpu_sharded_batch_step": (_int, [_vp, _dbl, _u32]),
+    "cobs_gpu_sharded_batch_sync": (_int, [_vp, C.POINTER(_sz)]),
+    "cobs_gpu_sharded_batch_subs": (_sz, [_vp]),
+    "cobs_gpu_sharded_batch_sub": (_vp, [_vp, _sz, C.POINTER(_sz), C.POINTER(_sz)]),
+    "cobs_gpu_sharded_batch_times": (_int, [_vp, C.POINTER(C.c_double * 8)]),
 }
 
 _lib = None

@@ -27,8 +27,6 @@
 // device-to-device copies, so that everything downstream (K3, ranking, D2H) sees the same
 // layout as on one GPU.  All calls are collective: every rank of the communicator makes the
 // same call with the same batch contents.
-#include <rccl/rccl.h>
-
 #include <unistd.h>
 
 #include <atomic>
@@ -41,165 +39,15 @@
 #include <thread>
 #include <vector>
 
-#include "engine.hpp"
+#include "comm.hpp"
 
 using namespace cobs_amd;
 
-struct cobs_gpu_comm {
-    ncclComm_t comm = nullptr;
-    int rank = 0, nranks = 1, device = 0;
-    uint64_t serial = 0;          // never reused: a batch remembers which communicator its layout came from
-    // What this rank entered last -- read by the CALLER's watchdog from another thread (cobs_gpu_comm_state) when a
-    // step does not come back: a collective that a peer never enters does not fail, it waits.
-    std::atomic<const char*> last_op{"none"};
-    std::atomic<uint64_t> entered{0}, returned{0};
-    std::atomic<void*> last_stream{nullptr};
-    // A failed RCCL call leaves the peers' state unknown: the communicator is not used again (every later call fails
-    // at once, on this rank, before any collective), and where the status says it is dead it is aborted -- after an
-    // open group has been closed (GroupScope), never inside one.
-    std::atomic<bool> broken{false};
-    bool group_open = false, abort_wanted = false;
-    std::string broken_why;
-    uint32_t timeout_ms = 0;      // > 0: the stream waits this file owns give up after that long (sync_bounded)
-};
-
 namespace cobs_amd {
-
-// per-batch exchange workspace
-struct Exchange {
-    uint64_t bound = 0;                          // serial of the communicator the layout below was gathered on
-    size_t nparts = 0;
-    std::vector<uint64_t> layout;                // [rank][part][2] = slot_begin, slot_count
-    std::vector<uint64_t> local_n;               // [rank] score slots per query on that rank
-    DevBuf<uint8_t> staging;                     // received slices, rank after rank
-    DevBuf<uint8_t> global;                      // assembled rows
-    DevBuf<uint64_t> d_meta;                     // small device scratch for size exchanges
-    // ... and its PINNED host side: a copy to or from pageable memory makes hipMemcpyAsync wait for the stream, i.e.
-    // for the collective in front of it -- inside the runtime, where no time limit reaches (sync_bounded below)
-    PinnedBuf<uint64_t> h_meta;
-    DevBuf<HitDev> hits_all;                     // gathered hit pools
-    DevBuf<HitDev> hits_bucketed;                // this rank's pool, bucketed by the rank that owns each record's query
-    DevBuf<unsigned long long> d_cursor;         // [nranks] bucket counts / cursors
-    DevBuf<uint2> topk_all;
-    DevBuf<uint32_t> topk_cnt_all;
-    uint64_t bytes_moved = 0;                    // bytes this rank received over the fabric in the last exchange
-};
-
 void destroy_exchange(Exchange* x) { delete x; }
-
 }  // namespace cobs_amd
 
 namespace {
-
-cobs_gpu_status nccl_fail(ncclResult_t r, const char* what) {
-    return fail(COBS_GPU_ERR_RCCL, std::string(what) + ": " + ncclGetErrorString(r));
-}
-
-// (calls that involve no communicator: ncclGetUniqueId, ncclCommInitRank)
-#define NCCL_TRY(expr)                                         \
-    do {                                                       \
-        ncclResult_t _r = (expr);                              \
-        if (_r != ncclSuccess) return nccl_fail(_r, #expr);    \
-    } while (0)
-
-void comm_settle(cobs_gpu_comm* c) {
-    if (c->abort_wanted && c->comm && !c->group_open) {
-        (void)ncclCommAbort(c->comm);       // frees the communicator and releases kernels of it that wait for peers
-        c->comm = nullptr;
-        c->abort_wanted = false;
-    }
-}
-
-// statuses after which the communicator itself is gone (a wrong argument or a misuse leaves it alive)
-bool comm_is_dead(ncclResult_t r) {
-    return r == ncclUnhandledCudaError || r == ncclSystemError || r == ncclInternalError || r == ncclRemoteError;
-}
-
-cobs_gpu_status comm_fail(cobs_gpu_comm* c, ncclResult_t r, const char* what) {
-    if (!c->broken.load()) {
-        c->broken_why = std::string(what) + ": " + ncclGetErrorString(r);
-        c->broken.store(true);
-    }
-    if (comm_is_dead(r)) c->abort_wanted = true;
-    comm_settle(c);
-    return nccl_fail(r, what);
-}
-
-cobs_gpu_status comm_usable(const cobs_gpu_comm* c) {
-    if (c->broken.load() || !c->comm)
-        return fail(COBS_GPU_ERR_RCCL, "the communicator is unusable after an earlier failure (" + c->broken_why +
-                                       "): destroy it and create a new one on every rank");
-    return COBS_GPU_OK;
-}
-
-// every RCCL call on a communicator: counted for the watchdog, a failure marks the communicator
-#define NCCL_C(c, st, expr)                                                    \
-    do {                                                                       \
-        (c)->last_op.store(#expr);                                             \
-        (c)->last_stream.store((void*)(st));                                   \
-        (c)->entered.fetch_add(1);                                             \
-        ncclResult_t _r = (expr);                                              \
-        (c)->returned.fetch_add(1);                                            \
-        if (_r != ncclSuccess) return comm_fail((c), _r, #expr);               \
-    } while (0)
-
-// ncclGroupStart ... ncclGroupEnd with the end GUARANTEED: a send or receive that fails inside the group returns from
-// the function through NCCL_C, and this scope's destructor still closes the group -- RCCL's group state is per
-// thread, an open group would swallow every later call of this thread into a group that is never launched -- and only
-// then lets comm_settle abort a dead communicator.  [VERDICT r4 9a: NCCL_TRY inside a group returned without closing it.]
-struct GroupScope {
-    cobs_gpu_comm* c;
-    bool open = false;
-    explicit GroupScope(cobs_gpu_comm* c_) : c(c_) {}
-    cobs_gpu_status start() {
-        NCCL_C(c, nullptr, ncclGroupStart());
-        open = c->group_open = true;
-        return COBS_GPU_OK;
-    }
-    cobs_gpu_status end(hipStream_t st) {
-        open = c->group_open = false;
-        NCCL_C(c, st, ncclGroupEnd());
-        return COBS_GPU_OK;
-    }
-    ~GroupScope() {
-        if (open) {
-            (void)ncclGroupEnd();
-            c->group_open = false;
-            comm_settle(c);
-        }
-    }
-};
-#define GROUP_START(g) do { cobs_gpu_status _gs = (g).start(); if (_gs != COBS_GPU_OK) return _gs; } while (0)
-#define GROUP_END(g, st) do { cobs_gpu_status _gs = (g).end(st); if (_gs != COBS_GPU_OK) return _gs; } while (0)
-
-// Wait for a stream that carries a collective.  With a time limit on the communicator (cobs_gpu_comm_set_timeout) the
-// wait gives up after it: a peer that never entered the collective would otherwise keep this rank here for ever.
-// The communicator is aborted then (its kernels stop waiting) and the call fails with ERR_RCCL.
-cobs_gpu_status sync_bounded(cobs_gpu_comm* c, hipStream_t st, const char* what) {
-    if (!c || c->timeout_ms == 0) {
-        HIP_TRY(hipStreamSynchronize(st));
-        return COBS_GPU_OK;
-    }
-    const auto t0 = std::chrono::steady_clock::now();
-    for (unsigned spin = 0;; ++spin) {
-        const hipError_t e = hipStreamQuery(st);
-        if (e == hipSuccess) return COBS_GPU_OK;
-        if (e != hipErrorNotReady) { (void)hipGetLastError(); HIP_TRY(e); }
-        (void)hipGetLastError();
-        if (spin > 4000) std::this_thread::sleep_for(std::chrono::microseconds(100));
-        const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
-        if (ms > (long long)c->timeout_ms) {
-            if (!c->broken.load()) {
-                c->broken_why = std::string(what) + " did not complete within " + std::to_string(c->timeout_ms) +
-                                " ms (last call: " + c->last_op.load() + "): a peer never entered it, or the fabric stalled";
-                c->broken.store(true);
-            }
-            c->abort_wanted = true;
-            comm_settle(c);
-            return fail(COBS_GPU_ERR_RCCL, c->broken_why);
-        }
-    }
-}
 
 // every rank's score-slot layout, gathered once per (batch, communicator)
 cobs_gpu_status bind_layout(cobs_gpu_batch* b, cobs_gpu_comm* c, hipStream_t st) {
@@ -316,24 +164,6 @@ XferPlan plan_exchange(const uint64_t* layout /*[N][F][2]*/, const uint64_t* doc
         }
     }
     return p;
-}
-
-// max over all ranks of a status word (one tiny ncclAllReduce)
-cobs_gpu_status agree(cobs_gpu_comm* c, cobs_gpu_batch* b, hipStream_t st, uint32_t mine, uint32_t* worst) {
-    if (cobs_gpu_status us = comm_usable(c); us != COBS_GPU_OK) return us;
-    if (!b->xchg) b->xchg = new Exchange;
-    Exchange& x = *b->xchg;
-    HIP_TRY(x.d_meta.reserve(64));
-    HIP_TRY(x.h_meta.reserve(64));
-    uint32_t* d = reinterpret_cast<uint32_t*>(x.d_meta.p);
-    uint32_t* h = reinterpret_cast<uint32_t*>(x.h_meta.p);
-    h[0] = mine;
-    HIP_TRY(hipMemcpyAsync(d, h, 4, hipMemcpyHostToDevice, st));
-    NCCL_C(c, st, ncclAllReduce(d, d + 1, 1, ncclUint32, ncclMax, c->comm, st));
-    HIP_TRY(hipMemcpyAsync(h + 1, d + 1, 4, hipMemcpyDeviceToHost, st));
-    if (cobs_gpu_status ws = sync_bounded(c, st, "the ranks' agreement (all-reduce of a status word)"); ws != COBS_GPU_OK) return ws;
-    *worst = h[1];
-    return COBS_GPU_OK;
 }
 
 }  // namespace
@@ -722,11 +552,11 @@ cobs_gpu_status cobs_gpu_batch_exchange_hits(cobs_gpu_batch* b, cobs_gpu_comm* c
         if (cobs_gpu_status us = comm_usable(c); us != COBS_GPU_OK) return us;
         if (!b->xchg) b->xchg = new Exchange;
         Exchange& x = *b->xchg;
-        const size_t N = (size_t)c->nranks, me = (size_t)c->rank;
-        // A handle whose streamed sub-indexes are counted in row ranges keeps score rows instead of selecting hits
-        // (pass.cpp: set_run_state) -- a property of THIS rank's shard and budget.  Such a rank must not leave the
-        // collective with an error of its own while its peers wait in it [ADVICE r4]: it travels through the size
-        // exchange as an impossible fill, every rank sees *overflow = 1 and repeats the pass with score rows.
+        const size_t N = (size_t)c->nranks;
+        // A rank whose last run kept score rows instead of a hit pool (the caller repeated the pass with rows after an
+        // overflow, say) must not leave the collective with an error of its own while its peers wait in it [ADVICE r4]:
+        // it travels through the size exchange as an impossible fill, every rank sees *overflow = 1.  (Until round 6 a
+        // handle with row-range chunks was always in that state; its scans select now: pass.cpp, acc_mode.)
         const bool no_pool = !b->selected;
         // sizes first
         const uint64_t mine = no_pool ? ~0ull : b->h_nhits();
@@ -739,34 +569,17 @@ cobs_gpu_status cobs_gpu_batch_exchange_hits(cobs_gpu_batch* b, cobs_gpu_comm* c
         if (cobs_gpu_status ws = sync_bounded(c, st, "the all-gather of the hit-pool fills"); ws != COBS_GPU_OK) return ws;
         const std::vector<uint64_t> n(x.h_meta.p + 1, x.h_meta.p + 1 + N);
         bool over = false;
-        uint64_t total = 0;
-        std::vector<uint64_t> off(N + 1, 0);
-        for (size_t r = 0; r < N; ++r) {
-            over = over || n[r] > b->hit_cap;       // the pool capacity is a function of the batch: equal on all ranks
-            off[r + 1] = off[r] + n[r];
-            total += n[r];
-        }
+        for (size_t r = 0; r < N; ++r) over = over || n[r] > b->hit_cap;       // the pool capacity is a function of the batch: equal on all ranks
         if (overflow) *overflow = over ? 1 : 0;
         if (over) return COBS_GPU_OK;
-        HIP_TRY(x.hits_all.reserve(std::max<size_t>((size_t)total, 1)));
-        if (N > 1) {
-            GroupScope grp(c);
-            GROUP_START(grp);
-            for (size_t j = 0; j < N; ++j) {
-                if (j == me) continue;
-                if (mine) NCCL_C(c, st, ncclSend(b->hits.p, mine * sizeof(HitDev), ncclUint8, (int)j, c->comm, st));
-                if (n[j]) NCCL_C(c, st, ncclRecv(x.hits_all.p + off[j], n[j] * sizeof(HitDev), ncclUint8, (int)j, c->comm, st));
-            }
-            GROUP_END(grp, st);
-        }
-        if (mine)
-            HIP_TRY(hipMemcpyAsync(x.hits_all.p + off[me], b->hits.p, mine * sizeof(HitDev), hipMemcpyDeviceToDevice, st));
+        const HitDev* pool = nullptr;
+        uint64_t got = 0;
+        if (cobs_gpu_status ls = xchg_hits_launch(b, c, st, n.data(), &pool, &got); ls != COBS_GPU_OK) return ls;
         // (the bounded wait first: what follows waits for the stream inside the runtime)
         if (cobs_gpu_status ws = sync_bounded(c, st, "the exchange of the hit records"); ws != COBS_GPU_OK) return ws;
-        x.bytes_moved = (total - mine) * sizeof(HitDev);
         // the gathered pools of all shards, put into result order on the device (results.cpp: order_pool; round 4
         // bucketed them with a counting sort on one host thread, after a copy to pageable memory)
-        if (cobs_gpu_status os = order_pool(b, x.hits_all.p, total, st); os != COBS_GPU_OK) return os;
+        if (cobs_gpu_status os = order_pool(b, pool, got, st); os != COBS_GPU_OK) return os;
         b->pool_global = true;
         return COBS_GPU_OK;
     });
@@ -816,8 +629,8 @@ cobs_gpu_status cobs_gpu_batch_exchange_hits_owned(cobs_gpu_batch* b, cobs_gpu_c
         const uint64_t q0 = (uint64_t)b->nq * me / N, q1 = (uint64_t)b->nq * (me + 1) / N;
         if (q_begin) *q_begin = q0;
         if (q_count) *q_count = q1 - q0;
-        // (a rank that kept score rows instead of a hit pool -- row-range chunks, see cobs_gpu_batch_exchange_hits --
-        // reports an overflow: every rank then repeats the pass with score rows)
+        // (a rank that kept score rows instead of a hit pool, see cobs_gpu_batch_exchange_hits, reports an overflow:
+        // every rank then repeats the pass with score rows)
         const bool no_pool = !b->selected;
         const uint64_t mine = no_pool ? 0 : std::min<uint64_t>(b->h_nhits(), b->hit_cap);     // an overflowed pool is not routed (see below)
         const bool over_here = no_pool || b->h_nhits() > b->hit_cap;
@@ -929,259 +742,100 @@ cobs_gpu_status cobs_gpu_batch_exchange_topk(cobs_gpu_batch* b, cobs_gpu_comm* c
     if (!b->ran || b->topk_k == 0) return fail(COBS_GPU_ERR_ARG, "run the batch with num_results > 0 first");
     return guarded([&]() -> cobs_gpu_status {
         hipStream_t st = (hipStream_t)hip_stream;
-        HIP_TRY(hipSetDevice(b->ix->device));
-        if (cobs_gpu_status us = comm_usable(c); us != COBS_GPU_OK) return us;
-        if (!b->xchg) b->xchg = new Exchange;
-        Exchange& x = *b->xchg;
-        const size_t N = (size_t)c->nranks, k = b->topk_k, nq = b->nq, np = b->ix->parts.size();
-        const size_t ne = k * nq * np, nc = nq * np;
-        HIP_TRY(x.topk_all.reserve(std::max<size_t>(N * ne, 1)));
-        HIP_TRY(x.topk_cnt_all.reserve(std::max<size_t>(N * nc, 1)));
-        if (ne) NCCL_C(c, st, ncclAllGather(b->topk_out.p, x.topk_all.p, ne * sizeof(uint2), ncclUint8, c->comm, st));
-        if (nc) NCCL_C(c, st, ncclAllGather(b->topk_cnt.p, x.topk_cnt_all.p, nc * 4, ncclUint8, c->comm, st));
-        if (cobs_gpu_status ws = sync_bounded(c, st, "the all-gather of the shards' best-of lists"); ws != COBS_GPU_OK) return ws;
-        std::vector<uint2> all(N * ne);
-        std::vector<uint32_t> cnt(N * nc);
-        if (ne) HIP_TRY(hipMemcpyAsync(all.data(), x.topk_all.p, N * ne * sizeof(uint2), hipMemcpyDeviceToHost, st));
-        if (nc) HIP_TRY(hipMemcpyAsync(cnt.data(), x.topk_cnt_all.p, N * nc * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        x.bytes_moved = (N - 1) * (ne * sizeof(uint2) + nc * 4);
-        // [file][query][rank * k]: the candidates of all ranks side by side, packed to the front
-        b->h_topk.assign(N * ne, make_uint2(0, 0));
-        b->h_topk_cnt.assign(nc, 0);
-        for (size_t f = 0; f < np; ++f)
-            for (size_t q = 0; q < nq; ++q) {
-                uint2* dst = b->h_topk.data() + (f * nq + q) * (N * k);
-                uint32_t m = 0;
-                for (size_t r = 0; r < N; ++r) {
-                    const uint2* src = all.data() + r * ne + (f * nq + q) * k;
-                    const uint32_t cr = std::min<uint32_t>(cnt[r * nc + f * nq + q], (uint32_t)k);
-                    for (uint32_t i = 0; i < cr; ++i) dst[m++] = src[i];
-                }
-                b->h_topk_cnt[f * nq + q] = m;
-            }
-        b->topk_stride = (uint32_t)(N * k);
-        b->topk_fetched = true;
-        return COBS_GPU_OK;
+        if (cobs_gpu_status ls = xchg_topk_launch(b, c, st); ls != COBS_GPU_OK) return ls;
+        return xchg_topk_collect(b, c, st);
     });
-}
-
-// ClassicSearch::search over the sharded index: every rank calls this with the same queries and
-// gets the same, global, result (hits ordered as cobs_gpu_search_batch orders them).
-// split (cobs_gpu_sharded_search_batch_split): for the all-documents call (threshold <= 0, no limit) the ranks SHARE
-// the ranking instead of repeating it -- the count rows go all-to-all to query owners, rank j orders the queries
-// [n*j/N, n*(j+1)/N) of every pass and writes their results (and offsets) at their final places of the caller's arrays.
-static cobs_gpu_status sharded_search_impl(cobs_gpu_index* ix, cobs_gpu_comm* c, const char* const* queries,
-                                           const size_t* lens, size_t nq, double threshold, size_t num_results,
-                                           cobs_gpu_hit* hits, size_t cap, size_t* hit_offsets, size_t* bad_query, bool split) {
-    if (!ix || !c || !hit_offsets) return fail(COBS_GPU_ERR_ARG, "NULL argument");
-    if (nq && (!queries || !lens)) return fail(COBS_GPU_ERR_ARG, "NULL argument");
-    return guarded([&]() -> cobs_gpu_status {
-        HIP_TRY(hipSetDevice(ix->device));
-        if (!ix->scratch[0]) {
-            cobs_gpu_status cs = cobs_gpu_batch_create(ix, 0, 0, &ix->scratch[0]);
-            if (cs != COBS_GPU_OK) return cs;
-            HIP_TRY(hipStreamCreateWithFlags(&ix->scratch[0]->own_stream, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&ix->scratch[0]->done, hipEventDisableTiming));
-        }
-        cobs_gpu_batch* b = ix->scratch[0];
-        hipStream_t st = b->own_stream;
-        size_t used = 0;
-        bool overflow = false;
-        // Passes bounded like the single-GPU API (score rows / tables below the workspace limit) --
-        // from quantities that are the SAME on every rank (whole-file geometry, not this shard's):
-        // all ranks must cut the batch at the same places, every pass is a set of collectives.
-        uint32_t min_term = 0xFFFFFFFFu;
-        uint64_t table_per_char = 0;
-        for (const auto& p : ix->parts) {
-            min_term = std::min(min_term, p.meta.term_size);
-            table_per_char += 4ull * p.meta.num_hashes * std::max<uint32_t>(p.meta.num_pages(), 1) * (p.idx64 ? 2 : 1);
-        }
-        const size_t topk = num_results < ix->total_counts ? num_results : 0;
-        const bool all_docs = threshold <= 0.0 && topk == 0;
-        // shared ranking: every query yields one result per real document, so every result's place is known up front
-        const bool shared = split && all_docs;
-        if (!shared || c->rank == 0) hit_offsets[0] = 0;          // (shared arrays: every entry has exactly one writer)
-        size_t per_query = 0;
-        for (const auto& p : ix->parts) per_query += p.meta.doc_names.size();
-        if (shared) {
-            if (cap < nq * per_query || (nq * per_query && !hits)) {      // the same on every rank: nobody enters a collective
-                if (c->rank == 0)           // (ranks of one process share the array: one writer)
-                    for (size_t q = 0; q < nq; ++q) hit_offsets[q + 1] = (q + 1) * per_query;
-                return fail(COBS_GPU_ERR_CAPACITY, "hit buffer too small; hit_offsets[nq] holds the needed size");
-            }
-        }
-        {
-            // Which exchange a pass takes depends on whether its scan selected hits itself (run_impl); a rank whose
-            // streamed shard is counted in row ranges cannot -- then no rank does.  Agreed on in EVERY call (4 bytes):
-            // a guard kept on the handle is local state -- a rank that reopened its index but kept the communicator
-            // would enter this all-reduce while its peers skip it [ADVICE r4].  The flag lives for this call only
-            // (PeersRanged), so that the handle behaves as before in a later search outside the communicator.
-            uint32_t mine = 0, any = 0;
-            for (const auto& p : ix->parts) mine |= p.has_row_ranges ? 1u : 0u;
-            cobs_gpu_status as = agree(c, b, st, mine, &any);
-            if (as != COBS_GPU_OK) return as;
-            ix->peers_ranged = any != 0;
-        }
-        struct PeersRanged {
-            cobs_gpu_index* ix;
-            ~PeersRanged() { ix->peers_ranged = false; }
-        } peers_ranged_scope{ix};
-        size_t g0 = 0;
-        do {
-            size_t g1 = g0;
-            uint64_t tb = 0, max_terms = 1;
-            while (g1 < nq) {
-                const uint64_t terms = lens[g1] >= min_term ? lens[g1] - min_term + 1 : 1;
-                const uint64_t mt = std::max(max_terms, terms);
-                const int planes = scan_planes_for(mt);
-                const uint64_t eb = planes > 0 ? scan_score_bytes(planes) : 4u;
-                // local rows (bounded by the whole vector), plus the assembled global rows where the pass exchanges rows:
-                // the all-documents mode, and a thresholded pass when some rank keeps score rows instead of a hit pool
-                const bool rows_travel = all_docs || (ix->peers_ranged && threshold > 0.0);
-                const uint64_t sb = (uint64_t)(g1 - g0 + 1) * (ix->total_counts + (rows_travel ? ix->total_counts : 0)) * eb;
-                const uint64_t t = (uint64_t)(lens[g1] + 16) * table_per_char;
-                if (g1 > g0 && (sb > ix->tune.pass_bytes || tb + t > ix->tune.pass_bytes)) break;
-                max_terms = mt;
-                tb += t;
-                ++g1;
-            }
-            size_t bad = 0;
-            // no score rows for a pass that selects on the device: hits into the pool, or -- with a limit -- the
-            // k best of every tile (run_impl keeps the rows anyway where that does not apply, e.g. a query with
-            // a single hash in total; b->have_counts says which)
-            const bool hits_only = threshold > 0.0 && topk == 0;
-            cobs_gpu_status s = set_queries_on(b, queries + g0, lens + g0, g1 - g0, st, false, &bad, g0);
-            if (s == COBS_GPU_OK) s = run_impl(b, threshold, topk, st, !(hits_only || topk > 0));
-            if (s == COBS_GPU_OK) {
-                s = cobs_gpu_batch_sync(b, st, &bad);
-                if (s == COBS_GPU_ERR_INVALID_BASE)       // the message names the query by its index in the call
-                    s = fail(s, "Invalid DNA base pair in query string. Only ACGT are allowed. (query " +
-                                std::to_string(g0 + bad) + ")");
-            }
-            if (s != COBS_GPU_OK && bad_query) *bad_query = g0 + bad;
-            // Every rank must know whether the scan went through EVERYWHERE before anybody enters the
-            // exchange: a rank that failed alone (out of memory, ...) would leave the others waiting in
-            // a collective.  Bad input fails identically on every rank that HASHES the queries -- a rank whose shard
-            // is empty (more ranks than sub-index blocks) does not, so the ranks also agree on the first invalid
-            // query and all report it.  [Eight ranks on a four-block index answered an invalid query with "the pass
-            // failed on another rank (status 4)": found by tests/test_gpu_mock_ranks.py, the first run of this code
-            // with more than one rank.]
-            const uint32_t my_bad = s == COBS_GPU_ERR_INVALID_BASE ? 0xFFFFFFFFu - (uint32_t)(g0 + bad) : 0u;
-            auto all_ranks_ok = [&](cobs_gpu_status mine, bool scan_step = false) -> cobs_gpu_status {
-                const std::string keep = mine != COBS_GPU_OK ? std::string(cobs_gpu_last_error()) : std::string();
-                uint32_t worst = 0;
-                const cobs_gpu_status as = agree(c, b, st, (uint32_t)mine, &worst);
-                if (as != COBS_GPU_OK) return as;
-                if (worst == COBS_GPU_ERR_INVALID_BASE && scan_step) {      // (every rank takes this branch: `worst` is the same everywhere)
-                    uint32_t first = 0;
-                    const cobs_gpu_status bs = agree(c, b, st, my_bad, &first);      // max of 2^32-1 - index: the lowest index
-                    if (bs != COBS_GPU_OK) return bs;
-                    if (mine == COBS_GPU_OK || mine == COBS_GPU_ERR_INVALID_BASE) {
-                        if (bad_query) *bad_query = 0xFFFFFFFFu - first;
-                        return fail(COBS_GPU_ERR_INVALID_BASE, "Invalid DNA base pair in query string. Only ACGT are allowed. (query " +
-                                                               std::to_string(0xFFFFFFFFu - first) + ")");
-                    }
-                }
-                if (mine != COBS_GPU_OK) return fail(mine, keep);
-                if (worst != COBS_GPU_OK)
-                    return fail(COBS_GPU_ERR_RCCL, "the pass failed on another rank (status " + std::to_string(worst) + ")");
-                return COBS_GPU_OK;
-            };
-            if ((s = all_ranks_ok(s, true)) != COBS_GPU_OK) return s;
-            // (a handle whose streamed sub-indexes are counted in row ranges keeps score rows instead of selecting in K2,
-            // pass.cpp: set_run_state; peers_ranged above makes that the same on every rank)
-            bool need_rows = (!hits_only && b->topk_k == 0) || (hits_only && !b->selected);
-            if (b->topk_k) {
-                s = cobs_gpu_batch_exchange_topk(b, c, st);
-                if (s != COBS_GPU_OK) return s;
-                // a query with a single hash in total is NOT ordered by score (max_counts <= 1,
-                // classic_search.cpp:134,177): its result is the first documents in index order, which
-                // K3's per-shard best-of lists do not determine -- such a pass also needs the rows
-                for (size_t q = 0; q < g1 - g0 && !need_rows; ++q) need_rows = total_hashes(b, q) <= 1;
-            } else if (b->selected) {
-                int over = 0;
-                s = cobs_gpu_batch_exchange_hits(b, c, st, &over);
-                if (s != COBS_GPU_OK) return s;
-                if (over) {     // some shard selected more hits than the pool holds: score rows instead
-                    s = run_impl(b, threshold, topk, st, true);
-                    if (s == COBS_GPU_OK) s = cobs_gpu_batch_sync(b, st, &bad);
-                    // the repeated pass may fail on one rank alone (its score rows did not fit, ...): agree
-                    // again before the row exchange, or the others wait in that collective for ever
-                    if ((s = all_ranks_ok(s)) != COBS_GPU_OK) return s;
-                    b->selected = false;
-                    need_rows = true;
-                }
-            }
-            if (need_rows && shared) {
-                // each count row to the rank that owns its query; that rank orders it and writes the results where
-                // they belong: the ranking and its PCIe traffic are divided by the number of GPUs
-                s = cobs_gpu_batch_exchange_counts(b, c, COBS_GPU_XCHG_ALLTOALL, st);
-                if (s != COBS_GPU_OK) return s;
-                if ((s = sync_bounded(c, st, "the all-to-all of the count rows")) != COBS_GPU_OK) return s;
-                const size_t q0 = (size_t)b->g_q0, qn = (size_t)b->g_qn;         // owned queries of this pass
-                size_t u = (g0 + q0) * per_query;
-                bool ovf = false;
-                // a rank may fail alone while it orders ITS queries (workspace, a D2H copy, ...): the status is agreed
-                // on before anybody goes on to the next pass's collectives, or the others would wait there for ever
-                cobs_gpu_status rs = COBS_GPU_ERR_UNSUPPORTED;
-                if (qn && ix->tune.device_rank != 0 && rank_on_device_applies(b, qn))
-                    rs = rank_on_device(b, q0, qn, 0, hits, cap, &u, hit_offsets + g0 + q0, &ovf);
-                if (rs == COBS_GPU_ERR_UNSUPPORTED) {
-                    rs = COBS_GPU_OK;
-                    u = (g0 + q0) * per_query;
-                    for (size_t q = q0; q < q0 + qn && rs == COBS_GPU_OK; ++q) {
-                        size_t n = 0;
-                        rs = cobs_gpu_batch_hits_host(b, q, 0, hits + u, cap - u, &n);
-                        u += n;
-                        hit_offsets[g0 + q + 1] = u;
-                    }
-                }
-                if (rs == COBS_GPU_OK && (ovf || u != (g0 + q0 + qn) * per_query))
-                    rs = fail(COBS_GPU_ERR_ARG, "a query did not yield one result per document");
-                if ((s = all_ranks_ok(rs)) != COBS_GPU_OK) return s;
-                g0 = g1;
-                continue;
-            }
-            if (need_rows) {
-                // every rank ranks every query (the contract of this call): all slices to all ranks
-                s = cobs_gpu_batch_exchange_counts(b, c, COBS_GPU_XCHG_ALLGATHER, st);
-                if (s != COBS_GPU_OK) return s;
-                if ((s = sync_bounded(c, st, "the all-gather of the count rows")) != COBS_GPU_OK) return s;
-            }
-            if (need_rows && ix->tune.device_rank != 0 && rank_on_device_applies(b, g1 - g0)) {
-                // whole (assembled, global) rows: ordered on the device, the records cross PCIe (rank.cpp) -- on a
-                // host thread this loop ranks ~90 queries x 100 000 documents per second
-                s = rank_on_device(b, 0, g1 - g0, num_results, hits, cap, &used, hit_offsets + g0, &overflow);
-                if (s == COBS_GPU_OK) { g0 = g1; continue; }
-                if (s != COBS_GPU_ERR_UNSUPPORTED) return s;       // (no room for its workspace: the host loop below)
-            }
-            for (size_t q = g0; q < g1; ++q) {
-                size_t n = 0;
-                s = cobs_gpu_batch_hits_host(b, q - g0, num_results, overflow ? nullptr : hits + used,
-                                             overflow ? 0 : cap - used, &n);
-                if (s == COBS_GPU_ERR_CAPACITY || (overflow && s == COBS_GPU_ERR_ARG)) overflow = true;
-                else if (s != COBS_GPU_OK) return s;
-                used += n;
-                hit_offsets[q + 1] = used;
-            }
-            g0 = g1;
-        } while (g0 < nq);
-        if (overflow) return fail(COBS_GPU_ERR_CAPACITY, "hit buffer too small; hit_offsets[nq] holds the needed size");
-        return COBS_GPU_OK;
-    });
-}
-
-cobs_gpu_status cobs_gpu_sharded_search_batch(cobs_gpu_index* ix, cobs_gpu_comm* c, const char* const* queries,
-                                              const size_t* lens, size_t nq, double threshold, size_t num_results,
-                                              cobs_gpu_hit* hits, size_t cap, size_t* hit_offsets, size_t* bad_query) {
-    return sharded_search_impl(ix, c, queries, lens, nq, threshold, num_results, hits, cap, hit_offsets, bad_query, false);
-}
-
-cobs_gpu_status cobs_gpu_sharded_search_batch_split(cobs_gpu_index* ix, cobs_gpu_comm* c, const char* const* queries,
-                                                    const size_t* lens, size_t nq, double threshold, size_t num_results,
-                                                    cobs_gpu_hit* hits, size_t cap, size_t* hit_offsets, size_t* bad_query) {
-    return sharded_search_impl(ix, c, queries, lens, nq, threshold, num_results, hits, cap, hit_offsets, bad_query, true);
 }
 
 }  // extern "C"
+
+namespace cobs_amd {
+
+cobs_gpu_status xchg_hits_launch(cobs_gpu_batch* b, cobs_gpu_comm* c, hipStream_t st, const uint64_t* n, const HitDev** pool,
+                                 uint64_t* total_out) {
+    HIP_TRY(hipSetDevice(b->ix->device));
+    if (cobs_gpu_status us = comm_usable(c); us != COBS_GPU_OK) return us;
+    if (!b->xchg) b->xchg = new Exchange;
+    Exchange& x = *b->xchg;
+    const size_t N = (size_t)c->nranks, me = (size_t)c->rank;
+    const uint64_t mine = n[me];
+    if (N == 1) {                       // one rank: the pool where the scan left it
+        *pool = b->hits.p;
+        *total_out = mine;
+        x.bytes_moved = 0;
+        return COBS_GPU_OK;
+    }
+    uint64_t total = 0;
+    std::vector<uint64_t> off(N + 1, 0);
+    for (size_t r = 0; r < N; ++r) {
+        off[r + 1] = off[r] + n[r];
+        total += n[r];
+    }
+    HIP_TRY(x.hits_all.reserve(std::max<size_t>((size_t)total, 1)));
+    {
+        GroupScope grp(c);
+        GROUP_START(grp);
+        for (size_t j = 0; j < N; ++j) {
+            if (j == me) continue;
+            if (mine) NCCL_C(c, st, ncclSend(b->hits.p, mine * sizeof(HitDev), ncclUint8, (int)j, c->comm, st));
+            if (n[j]) NCCL_C(c, st, ncclRecv(x.hits_all.p + off[j], n[j] * sizeof(HitDev), ncclUint8, (int)j, c->comm, st));
+        }
+        GROUP_END(grp, st);
+    }
+    if (mine)
+        HIP_TRY(hipMemcpyAsync(x.hits_all.p + off[me], b->hits.p, mine * sizeof(HitDev), hipMemcpyDeviceToDevice, st));
+    x.bytes_moved = (total - mine) * sizeof(HitDev);
+    *pool = x.hits_all.p;
+    *total_out = total;
+    return COBS_GPU_OK;
+}
+
+cobs_gpu_status xchg_topk_launch(cobs_gpu_batch* b, cobs_gpu_comm* c, hipStream_t st) {
+    HIP_TRY(hipSetDevice(b->ix->device));
+    if (cobs_gpu_status us = comm_usable(c); us != COBS_GPU_OK) return us;
+    if (!b->xchg) b->xchg = new Exchange;
+    Exchange& x = *b->xchg;
+    const size_t N = (size_t)c->nranks, k = b->topk_k, nq = b->nq, np = b->ix->parts.size();
+    const size_t ne = k * nq * np, nc = nq * np;
+    HIP_TRY(x.topk_all.reserve(std::max<size_t>(N * ne, 1)));
+    HIP_TRY(x.topk_cnt_all.reserve(std::max<size_t>(N * nc, 1)));
+    // (pinned landing: a copy to pageable memory would wait for the stream -- for the collective -- inside the runtime)
+    HIP_TRY(x.h_topk.reserve(std::max<size_t>(N * ne * sizeof(uint2) + N * nc * 4, 16)));
+    if (ne) NCCL_C(c, st, ncclAllGather(b->topk_out.p, x.topk_all.p, ne * sizeof(uint2), ncclUint8, c->comm, st));
+    if (nc) NCCL_C(c, st, ncclAllGather(b->topk_cnt.p, x.topk_cnt_all.p, nc * 4, ncclUint8, c->comm, st));
+    if (ne) HIP_TRY(hipMemcpyAsync(x.h_topk.p, x.topk_all.p, N * ne * sizeof(uint2), hipMemcpyDeviceToHost, st));
+    if (nc) HIP_TRY(hipMemcpyAsync(x.h_topk.p + N * ne * sizeof(uint2), x.topk_cnt_all.p, N * nc * 4, hipMemcpyDeviceToHost, st));
+    x.bytes_moved = (N - 1) * (ne * sizeof(uint2) + nc * 4);
+    return COBS_GPU_OK;
+}
+
+cobs_gpu_status xchg_topk_collect(cobs_gpu_batch* b, cobs_gpu_comm* c, hipStream_t st, bool waited) {
+    HIP_TRY(hipSetDevice(b->ix->device));
+    if (!b->xchg) return fail(COBS_GPU_ERR_ARG, "no exchange of best-of lists is in flight");
+    Exchange& x = *b->xchg;
+    const size_t N = (size_t)c->nranks, k = b->topk_k, nq = b->nq, np = b->ix->parts.size();
+    const size_t ne = k * nq * np, nc = nq * np;
+    if (!waited)
+        if (cobs_gpu_status ws = sync_bounded(c, st, "the all-gather of the shards' best-of lists"); ws != COBS_GPU_OK) return ws;
+    const uint2* all = reinterpret_cast<const uint2*>(x.h_topk.p);
+    const uint32_t* cnt = reinterpret_cast<const uint32_t*>(x.h_topk.p + N * ne * sizeof(uint2));
+    // [file][query][rank * k]: the candidates of all ranks side by side, packed to the front
+    b->h_topk.assign(N * ne, make_uint2(0, 0));
+    b->h_topk_cnt.assign(nc, 0);
+    for (size_t f = 0; f < np; ++f)
+        for (size_t q = 0; q < nq; ++q) {
+            uint2* dst = b->h_topk.data() + (f * nq + q) * (N * k);
+            uint32_t m = 0;
+            for (size_t r = 0; r < N; ++r) {
+                const uint2* src = all + r * ne + (f * nq + q) * k;
+                const uint32_t cr = std::min<uint32_t>(cnt[r * nc + f * nq + q], (uint32_t)k);
+                for (uint32_t i = 0; i < cr; ++i) dst[m++] = src[i];
+            }
+            b->h_topk_cnt[f * nq + q] = m;
+        }
+    b->topk_stride = (uint32_t)(N * k);
+    b->topk_fetched = true;
+    return COBS_GPU_OK;
+}
+
+}  // namespace cobs_amd

@@ -138,6 +138,19 @@ struct AddScoresArgs {
     uint64_t dst_stride, dst_offset;   // elements
     uint32_t nslots, nq, elem_bytes;
 };
+// counts_to_result's filter (reference classic_search.cpp:127-132) over the ACCUMULATED scores of one sub-index whose row
+// ranges were scanned one after the other (select_rows_kernel): what K2's epilogue does for a sub-index it sees whole.
+struct SelectRowsArgs {
+    const void* scores;          // [nq][stride] scores of ONE sub-index slice (elements of elem_bytes), slot 0 = document doc0
+    const uint32_t* thresholds;  // [nq] ceil(threshold * T)
+    HitDev* hits;                // the batch's hit pool ...
+    unsigned long long* hit_count;   // ... and its 64-bit fill
+    uint64_t stride;             // elements between the queries' rows (a multiple of 8)
+    uint32_t nslots;             // slots that belong to the slice (valid row bytes x 8)
+    uint32_t nq, elem_bytes;
+    uint32_t doc0, num_docs;     // file-level document of slot 0 | real documents of the file
+    uint32_t part, hit_cap;
+};
 
 // How many rows a batch LOOKS UP in every streamed piece of a file (count_rows_kernel): counter first + min(row / per,
 // n - 1) of the entry's sub-index (per == 0: one counter for the sub-index); first == 0xFFFFFFFF: not counted (resident).
@@ -198,6 +211,9 @@ struct TopkArgs {
     uint32_t levels;             // ceil(score_bits / level_bits): 1, 2 or 3
     uint32_t score_bytes;        // 1 (planes <= 8), 2 (<= 16) or 4
     uint32_t sort_limit;         // order the survivors on the device when there are at most this many (0 = never)
+    uint32_t out_stride;         // entries between the queries' outputs (0 = k)
+    uint32_t pad_out;            // != 0: the entries of `out` beyond the survivors are marked unused (document 0xFFFFFFFF) --
+                                 // the output is ONE TILE of K2's candidate pool (a sub-index counted in row ranges)
     uint32_t from_pool;          // counts = candidate pool of K2 ([nq][counts_stride] (document, score) entries, the first
                                  // nslots in use; counts_stride a multiple of 8) instead of score rows
 };

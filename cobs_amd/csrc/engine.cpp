@@ -154,7 +154,10 @@ cobs_gpu_batch::~cobs_gpu_batch() {
     if (hash_stream) (void)hipStreamDestroy(hash_stream);
 }
 
-cobs_gpu_index::~cobs_gpu_index() { for (auto* b : scratch) delete b; }
+cobs_gpu_index::~cobs_gpu_index() {
+    for (auto* b : scratch) delete b;
+    if (xchg_stream) (void)hipStreamDestroy(xchg_stream);
+}
 
 namespace {
 

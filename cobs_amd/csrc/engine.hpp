@@ -269,13 +269,13 @@ struct cobs_gpu_index {
     std::vector<cobs_amd::Part> parts;
     cobs_amd::StreamBufs stream;
     uint64_t total_counts = 0, local_counts = 0;
-    bool peers_ranged = false;    // inside ONE sharded search call: some rank counts a streamed sub-index in row ranges -> every rank keeps score rows (agreed on per call, comm.cpp)
     double timers[5] = {0, 0, 0, 0, 0};
     cobs_amd::ResultArena arena;  // cobs_gpu_search_batch_view
     uint64_t host_passes = 0;     // device passes launched by the host-buffer calls
     uint64_t graph_replays = 0;   // small passes of the host API served by a captured hipGraph
     static constexpr int kScratch = 3;
     cobs_gpu_batch* scratch[kScratch] = {nullptr, nullptr, nullptr};   // workspaces of the host-buffer search API
+    hipStream_t xchg_stream = nullptr;   // sharded search: the stream the ranks' agreements and exchanges of its passes run on (sharded.cpp)
     ~cobs_gpu_index();
 };
 
@@ -296,6 +296,7 @@ struct cobs_gpu_batch {
     std::vector<cobs_amd::PartWork> work;
     cobs_amd::DevBuf<uint8_t> counts;
     cobs_amd::DevBuf<uint8_t> counts_part;   // partial scores of a row-range chunk (streamed index), added to `counts`
+    cobs_amd::DevBuf<uint8_t> counts_acc;    // ... or, in a pass without score rows, to this: the scores of ONE sub-index, selected from after its last range
     uint32_t elem_bytes = 2;
     int planes = 0;
     uint64_t max_terms = 0;              // longest query of the batch, in terms
@@ -323,6 +324,9 @@ struct cobs_gpu_batch {
     std::vector<size_t> h_hit_off;
     bool pool_fetched = false;
     bool pool_sorted = false;         // h_hits holds every query's records in RESULT order (ordered on the device: order_pool)
+    bool pool_pending = false;        // order_pool_launch queued the ordering of pool_n records and their copy home; order_pool_collect publishes them
+    uint64_t pool_n = 0;
+    cobs_amd::PinnedBuf<uint8_t> h_single;                  // staging of pool_single
     cobs_amd::DevBuf<uint32_t> pool_idx;                    // [3][nq + 1]: records per query | first record | scatter cursors
     cobs_amd::DevBuf<cobs_amd::HitDev> pool_tmp, pool_out;  // the pool bucketed by query / every bucket ordered
     cobs_amd::DevBuf<uint8_t> pool_single;                  // [nq] queries with a single hash in total (index order)
@@ -424,6 +428,12 @@ void stage_thresholds(cobs_gpu_batch* b, double threshold);
 // `n` hit records at d_pool (the batch's own pool, or the pools of all shards after an exchange) -> b->h_hits in result
 // order (query ascending, inside a query as counts_to_result orders it), b->h_hit_off; ordered on the device
 cobs_gpu_status order_pool(cobs_gpu_batch* b, const HitDev* d_pool, uint64_t n, hipStream_t st);
+// ... in two halves: everything queued on `st` (ERR_UNSUPPORTED, nothing queued: beyond the device ordering's indices) | waited for and published
+cobs_gpu_status order_pool_launch(cobs_gpu_batch* b, const HitDev* d_pool, uint64_t n, hipStream_t st);
+cobs_gpu_status order_pool_collect(cobs_gpu_batch* b, hipStream_t st, bool waited = false);     // waited: the caller saw an event behind the copy home
+// the ordered lists of a whole pass into the caller's arrays in one sweep (false: they do not fit, nothing written)
+bool hand_over_pool(cobs_gpu_batch* sb, size_t g0, size_t g1, cobs_gpu_hit** hits, size_t* cap, size_t* used, size_t* hit_offsets,
+                    ResultArena* grow, size_t nq_call, cobs_gpu_status* status);
 cobs_gpu_status fetch_counts(cobs_gpu_batch* b, size_t q, uint32_t* counts);
 cobs_gpu_status rank_window(cobs_gpu_batch* b, size_t q0, size_t q1, size_t per_query, cobs_gpu_hit* hits);
 

@@ -289,6 +289,12 @@ static cobs_gpu_status search_batch_impl(cobs_gpu_index* ix, const char* const* 
         }
         inflight.clear();
     };
+    // a pass that failed while it was collected has left `inflight` already: nothing of IT may stay in flight either
+    // (with early_rank its ordering kernels and D2H pieces were queued when it began) [ADVICE r5]
+    auto settle = [&](const Pass& ps) {
+        (void)hipStreamSynchronize(ix->scratch[ps.slot]->own_stream);
+        rank_cancel(ix->scratch[ps.slot]);
+    };
     auto collect = [&](const Pass& ps) -> cobs_gpu_status {
         size_t bad = 0;
         const double te0 = now_s();
@@ -343,25 +349,14 @@ static cobs_gpu_status search_batch_impl(cobs_gpu_index* ix, const char* const* 
                 st = order_pool(sb, sb->hits.p, sb->h_nhits(), sb->own_stream);
                 if (st != COBS_GPU_OK) return st;
             }
-            if (grow && !overflow && sb->pool_sorted && sb->h_hits.size() > cap - used) {
-                // room for this pass and, at the rate so far, for the passes to come
-                const size_t have = used + sb->h_hits.size();
-                const size_t want = std::max<size_t>(have + have / 4 + 1024, (size_t)((double)have * (double)nq / (double)std::max<size_t>(ps.g1, 1) * 1.125));
-                if (cobs_gpu_status gs = grow->grow_keep(want, used); gs != COBS_GPU_OK) return gs;
-                hits = grow->p;
-                cap = grow->cap;
-            }
-            if (sb->pool_sorted && sb->h_hits.size() <= cap - used && (sb->h_hits.empty() || hits)) {
-                const cobs_amd::HitDev* rec = sb->h_hits.data();
-                const size_t n = sb->h_hits.size();
-                cobs_gpu_hit* dst = hits + used;
-                for (size_t i = 0; i < n; ++i) dst[i] = cobs_gpu_hit{rec[i].part, rec[i].doc, rec[i].score};
-                for (size_t q = ps.g0; q < ps.g1; ++q) hit_offsets[q + 1] = used + sb->h_hit_off[q - ps.g0 + 1];
-                used += n;
+            cobs_gpu_status hs = COBS_GPU_OK;
+            const size_t n = sb->h_hits.size();
+            if (hand_over_pool(sb, ps.g0, ps.g1, &hits, &cap, &used, hit_offsets, grow, nq, &hs)) {
                 ix->timers[4] += now_s() - t0;
                 if (ix->tune.trace) std::fprintf(stderr, "[cobs_gpu] pass of queries %zu..%zu: %zu hits ordered and handed over in %.3f ms\n", ps.g0, ps.g1, n, (now_s() - t0) * 1e3);
                 return COBS_GPU_OK;
             }
+            if (hs != COBS_GPU_OK) return hs;
             ix->timers[4] += now_s() - t0;
         }
         for (size_t q = ps.g0; q < ps.g1; ++q) {
@@ -403,7 +398,7 @@ static cobs_gpu_status search_batch_impl(cobs_gpu_index* ix, const char* const* 
             const Pass oldest = inflight.front();
             inflight.erase(inflight.begin());
             cobs_gpu_status st = collect(oldest);
-            if (st != COBS_GPU_OK) { drain(); return st; }
+            if (st != COBS_GPU_OK) { settle(oldest); drain(); return st; }
         }
         const int slot = (int)(pass_no % depth);
         size_t bad_local = 0;
@@ -421,6 +416,7 @@ static cobs_gpu_status search_batch_impl(cobs_gpu_index* ix, const char* const* 
                 const std::string keep = last_error_text();
                 earlier = collect(ps);
                 if (earlier == COBS_GPU_OK) last_error_text() = keep;
+                else settle(ps);
             }
             drain();
             if (earlier != COBS_GPU_OK) return earlier;
@@ -442,7 +438,7 @@ static cobs_gpu_status search_batch_impl(cobs_gpu_index* ix, const char* const* 
         const Pass ps = inflight.front();
         inflight.erase(inflight.begin());
         cobs_gpu_status st = collect(ps);
-        if (st != COBS_GPU_OK) { drain(); return st; }
+        if (st != COBS_GPU_OK) { settle(ps); drain(); return st; }
     }
     if (overflow) return fail(COBS_GPU_ERR_CAPACITY, "hit buffer too small; hit_offsets[nq] holds the needed size");
     return COBS_GPU_OK;

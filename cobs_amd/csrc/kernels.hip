@@ -1423,7 +1423,7 @@ __global__ __launch_bounds__(256) void topk_kernel(TopkArgs a) {
     if (tid == 0) sh[5] = 0;                      // emission cursor of the documents above the cut
     __syncthreads();
     // ---- emission
-    uint2* out = a.out + (uint64_t)q * k;
+    uint2* out = a.out + (uint64_t)q * (a.out_stride ? a.out_stride : k);
     for (uint32_t i0 = w0; i0 < w1; i0 += 512) {
         const uint32_t i = i0 + lane * 8u;
         uint32_t s8[8], d8[8];
@@ -1465,7 +1465,10 @@ __global__ __launch_bounds__(256) void topk_kernel(TopkArgs a) {
     }
     __syncthreads();
     const uint32_t cnt = take_all ? sh[5] : n_above + (eq_total < need_eq ? eq_total : need_eq);
-    if (tid == 0) a.out_count[q] = cnt;
+    if (tid == 0 && a.out_count) a.out_count[q] = cnt;
+    // (one tile of the candidate pool: what the survivors leave of its k entries is marked unused, as tile_topk does)
+    if (a.pad_out)
+        for (uint32_t i = cnt + tid; i < k; i += 256) out[i] = make_uint2(0xFFFFFFFFu, 0u);
     // ---- order the survivors: (score desc, doc asc) = ascending (~score << 32 | doc)
     if (a.sort_limit && cnt > 1u && cnt <= a.sort_limit) {      // block-uniform condition
         __syncthreads();                          // everybody has read sh[]: the key area may overlap it
@@ -1496,6 +1499,48 @@ __global__ __launch_bounds__(256) void topk_kernel(TopkArgs a) {
             const unsigned long long kv = key[i];
             out[i] = make_uint2((uint32_t)kv, ~(uint32_t)(kv >> 32));
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The threshold filter over ACCUMULATED scores (reference classic_search.cpp:127-132).  A streamed sub-index that is
+// larger than a stream buffer is counted row range by row range (pass.cpp): K2 sees partial counts there and cannot
+// compare them with a threshold.  Its ranges add up in a scratch matrix of the sub-index's own width (no score rows of
+// the whole index), and after the last range this kernel does what K2's epilogue does for a sub-index it sees whole:
+// score >= threshold over real documents -> (query, file, document, score) records into the batch's hit pool, one
+// wave-aggregated atomic per wave.  One thread per (query, 8 consecutive slots).
+template <typename ST>
+__global__ __launch_bounds__(256) void select_rows_kernel(SelectRowsArgs a) {
+    const uint32_t groups = (a.nslots + 7u) / 8u;
+    const uint64_t gid = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t qq = gid / groups;
+    const bool live = qq < a.nq;                      // (no early return: the scan below runs over whole waves)
+    const uint32_t q = live ? (uint32_t)qq : 0u;
+    const uint32_t i = (uint32_t)(gid - qq * groups) * 8u;
+    uint32_t s8[8];
+    uint32_t mask = 0u;
+    if (live) {
+        load_scores8<ST>(reinterpret_cast<const ST*>(a.scores) + (uint64_t)q * a.stride, i, s8);
+        const uint32_t thr = a.thresholds[q];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (i + j < a.nslots && a.doc0 + i + j < a.num_docs && s8[j] >= thr) mask |= 1u << j;
+    }
+    if (__any(mask != 0u)) {
+        const uint32_t n = (uint32_t)__popc(mask);
+        const uint32_t incl = wave_incl_scan_dpp(n);
+        const uint32_t total = __shfl(incl, 63);
+        unsigned long long base = 0ull;
+        if (lane == 63u) base = atomicAdd(a.hit_count, (unsigned long long)total);
+        base = __shfl(base, 63);
+        unsigned long long pos = base + incl - n;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (mask & (1u << j)) {
+                if (pos < a.hit_cap) a.hits[pos] = HitDev{q, a.part, a.doc0 + i + (uint32_t)j, s8[j]};
+                ++pos;
+            }
     }
 }
 
@@ -1985,6 +2030,17 @@ hipError_t launch_topk(const TopkArgs& a, hipStream_t stream) {
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3(a.nq), dim3(256), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_select_rows(const SelectRowsArgs& a, hipStream_t stream) {
+    if (a.nq == 0 || a.nslots == 0) return hipSuccess;
+    if ((a.stride % 8u) != 0 || (a.elem_bytes != 1 && a.elem_bytes != 2 && a.elem_bytes != 4)) return hipErrorInvalidValue;
+    const uint64_t items = (uint64_t)a.nq * ((a.nslots + 7u) / 8u);
+    const uint64_t blocks = (items + 255u) / 256u;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    auto kern = a.elem_bytes == 1 ? select_rows_kernel<uint8_t> : a.elem_bytes == 2 ? select_rows_kernel<uint16_t> : select_rows_kernel<uint32_t>;
+    hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -46,6 +46,8 @@ hipError_t launch_gather_copy(const GatherArgs& a, uint32_t grid_limit, hipStrea
 // the rows a chunk holds; add a chunk's partial scores to the score rows.
 hipError_t launch_remap_rows(const RemapArgs& a, uint64_t entries, bool idx64, hipStream_t stream);
 hipError_t launch_add_scores(const AddScoresArgs& a, hipStream_t stream);
+// ... and the threshold filter over the scores a sub-index's row ranges added up (kernels.hip: select_rows_kernel)
+hipError_t launch_select_rows(const SelectRowsArgs& a, hipStream_t stream);
 // a row-range unit's in-range terms per query: a compact second table + its block offsets (count, scan, write)
 hipError_t launch_compact_terms(const CompactArgs& a, hipStream_t stream);
 hipError_t launch_clear_flags(uint32_t* flags, hipStream_t stream);
@@ -56,6 +58,8 @@ hipError_t launch_bucket_hits(const BucketArgs& a, bool count, hipStream_t strea
 // a.cnt ([nq + 1]) and a.cur ([nq]) must be zero.
 hipError_t launch_order_pool(const PoolArgs& a, hipStream_t stream);
 constexpr uint32_t kPoolSegMax = 1024;      // buckets the device orders (larger ones: the host)
+// One rank's record of a sharded pass (sharded.cpp): status | first invalid query word | hit-pool fill | extra, 4 x u64.
+hipError_t launch_pass_meta(const uint32_t* flags, uint64_t* rec, uint64_t status, uint64_t extra, hipStream_t stream);
 
 // Index construction: one thread per text position hashes its term and sets the bits.
 hipError_t launch_build(const BuildArgs& a, uint64_t total_bytes, hipStream_t stream);

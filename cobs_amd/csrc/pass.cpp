@@ -259,15 +259,10 @@ void cobs_amd::set_run_state(cobs_gpu_batch* b, double threshold, size_t topk, b
         for (size_t q = 0; ok && q < b->nq; ++q) ok = total_hashes(b, q) > 1;
         b->topk_direct = ok;
     }
-    // A streamed sub-index cut into ROW ranges is counted range by range: K2 sees partial counts and cannot compare
-    // them with a threshold or pick a tile's best.  Such a handle keeps score rows; hits and limits come from them
-    // (K3 from rows, the ranking kernel, or the host filter -- the paths a hit-pool overflow takes anyway).
-    bool ranged = ix->peers_ranged;          // (comm.cpp: the ranks of a sharded search take the same exchange path)
-    for (const Part& p : ix->parts) ranged = ranged || p.has_row_ranges;
-    if (ranged) {
-        b->selected = false;
-        b->topk_direct = false;
-    }
+    // (A streamed sub-index cut into ROW ranges is counted range by range: K2 sees partial counts there.  Its ranges add
+    // up in a scratch matrix of the sub-index's own width and the selection runs over that after the last range --
+    // run_impl, `acc_mode` --, so such a handle selects like any other.  Until round 6 it kept score rows of the whole
+    // index instead and answered hits and limits from them.)
     b->have_counts = want_counts || (!b->selected && !b->topk_direct);
 }
 
@@ -497,7 +492,10 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
             const Chunk& c = *cp;
             geoms[f].push_back(scan_geometry(c, b->work[f].h_blk_off[nq] / nq, (b->max_terms + 7) / 8, p.meta.num_hashes,
                                              ix->waves_per_group, b->planes, p.idx64, ix->tune));
-            cand_tiles[f] += (c.total_chunks + geoms[f].back().tile_w - 1) / geoms[f].back().tile_w;
+            // (a sub-index counted in row ranges is ONE tile of the candidate pool: its k best come from the accumulated
+            // scores after the last range, below)
+            if (c.row_range) cand_tiles[f] += c.range_no == 0 ? 1u : 0u;
+            else cand_tiles[f] += (c.total_chunks + geoms[f].back().tile_w - 1) / geoms[f].back().tile_w;
         }
         cand_stride[f] = (uint32_t)round_up((uint64_t)cand_tiles[f] * topk, 8);
         cand_off[f + 1] = cand_off[f] + (b->topk_direct ? (uint64_t)nq * cand_stride[f] : 0);
@@ -536,7 +534,13 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
             // a later row range of a sub-index: its partial scores go to a scratch matrix and are added to the rows
             // (however the range's rows come in: streamed whole, or only the looked-up ones fetched)
             const bool partial = c.row_range && c.range_no > 0;
-            const PageDev* pages_dev = partial ? c.d_pages_acc : c.d_pages;
+            // A pass that selects in the scan (hits into the pool, a tile's k best) and keeps no score rows: the ranges of
+            // such a sub-index add up in a scratch matrix of its own width (first range: written there, later ones: added),
+            // and the selection runs over that matrix after its last range -- the same hit pool / candidate pool the
+            // resident path fills (reference: the filter is the same whatever back-end gathered the rows,
+            // classic_search.cpp:127-145).  C3's largest sub-index, 10k queries: 250 MB of scratch instead of 2 GB of rows.
+            const bool acc_mode = c.row_range && !b->have_counts && (b->selected || b->topk_direct);
+            const PageDev* pages_dev = (partial || acc_mode) ? c.d_pages_acc : c.d_pages;
             const void* table_dev = b->work[f].table.p;
             bool unit_fetched = false;
             uint64_t unit_rows = 0;
@@ -703,21 +707,22 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                 }
             }
             uint32_t part_slots = 0;
-            if (partial) {
+            if (partial || acc_mode) {
                 part_slots = (uint32_t)(c.vp[0].ncols * 8);
-                HIP_TRY(b->counts_part.reserve((size_t)nq * part_slots * b->elem_bytes));
+                if (partial) HIP_TRY(b->counts_part.reserve((size_t)nq * part_slots * b->elem_bytes));
+                if (acc_mode) HIP_TRY(b->counts_acc.reserve((size_t)nq * part_slots * b->elem_bytes));
             }
             ScanArgs sa;
             sa.blob = data;
             sa.pages = pages_dev;
             sa.table = table_dev;
             sa.blk_off = blk_dev;
-            sa.counts = partial ? b->counts_part.p : b->counts.p;
-            sa.thresholds = b->selected ? b->work[f].thr.p : nullptr;
+            sa.counts = partial ? b->counts_part.p : acc_mode ? b->counts_acc.p : b->counts.p;
+            sa.thresholds = (b->selected && !acc_mode) ? b->work[f].thr.p : nullptr;
             sa.hits = b->hits.p;
             sa.hit_count = reinterpret_cast<unsigned long long*>(b->flags.p + 2);
-            sa.counts_stride = partial ? part_slots : ix->local_counts;
-            sa.counts_offset = partial ? 0 : p.local_offset;
+            sa.counts_stride = (partial || acc_mode) ? part_slots : ix->local_counts;
+            sa.counts_offset = (partial || acc_mode) ? 0 : p.local_offset;
             sa.hit_cap = b->hit_cap;
             sa.nq = (uint32_t)nq;
             sa.npages = (uint32_t)c.vp.size();
@@ -728,16 +733,17 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
             sa.num_hashes = (uint32_t)p.meta.num_hashes;
             sa.num_docs = (uint32_t)p.meta.doc_names.size();
             sa.part = (uint32_t)f;
-            sa.write_counts = b->have_counts ? 1 : 0;
+            sa.write_counts = (b->have_counts || acc_mode) ? 1 : 0;
             sa.idx64 = p.idx64 ? 1u : 0u;
             const int nwaves = geom.nwaves;
             sa.tile_w = geom.tile_w;
-            sa.cand = b->topk_direct ? b->cand.p + cand_off[f] : nullptr;
-            sa.topk_k = b->topk_direct ? (uint32_t)topk : 0u;
+            const bool tile_select = b->topk_direct && !acc_mode;
+            sa.cand = tile_select ? b->cand.p + cand_off[f] : nullptr;
+            sa.topk_k = tile_select ? (uint32_t)topk : 0u;
             sa.cand_stride = cand_stride[f];
             sa.tile_base = tile_base;
             // K2 filters by threshold only when it selects: into the hit pool, or the tile's k best
-            if (b->topk_direct) sa.thresholds = need_thr ? b->work[f].thr.p : nullptr;
+            if (tile_select) sa.thresholds = need_thr ? b->work[f].thr.p : nullptr;
             sa.dbg = nullptr;
             sa.dbg_every = 1;
             sa.dbg_slots = 0;
@@ -763,18 +769,64 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                 sa.dbg_every = (uint32_t)std::max<uint64_t>(1, groups / sa.dbg_slots);
             }
             HIP_TRY(launch_scan(sa, ntiles, b->planes, nwaves, geom.multi_query, st));
-            tile_base += ntiles;
+            if (!acc_mode) tile_base += ntiles;
             ++launches;
             if (partial) {
                 AddScoresArgs aa;
-                aa.dst = b->counts.p;
+                aa.dst = acc_mode ? b->counts_acc.p : b->counts.p;
                 aa.src = b->counts_part.p;
-                aa.dst_stride = ix->local_counts;
-                aa.dst_offset = p.local_offset + c.pages[0].slot0;
+                aa.dst_stride = acc_mode ? part_slots : ix->local_counts;
+                aa.dst_offset = acc_mode ? 0 : p.local_offset + c.pages[0].slot0;
                 aa.nslots = part_slots;
                 aa.nq = (uint32_t)nq;
                 aa.elem_bytes = b->elem_bytes;
                 HIP_TRY(launch_add_scores(aa, st));
+            }
+            // the last range of the sub-index in this pass (its ranges are consecutive units): select from what they added up
+            const bool last_range = acc_mode && (ci + 1 == units[f].size() || !units[f][ci + 1]->row_range ||
+                                                 units[f][ci + 1]->vp[0].fp != c.vp[0].fp);
+            if (last_range) {
+                const uint32_t nvalid = std::min<uint32_t>(part_slots, c.pages[0].valid_bytes * 8u);
+                if (b->selected) {
+                    SelectRowsArgs sr;
+                    sr.scores = b->counts_acc.p;
+                    sr.thresholds = b->work[f].thr.p;
+                    sr.hits = b->hits.p;
+                    sr.hit_count = reinterpret_cast<unsigned long long*>(b->flags.p + 2);
+                    sr.stride = part_slots;
+                    sr.nslots = nvalid;
+                    sr.nq = (uint32_t)nq;
+                    sr.elem_bytes = b->elem_bytes;
+                    sr.doc0 = c.pages[0].doc0;
+                    sr.num_docs = (uint32_t)p.meta.doc_names.size();
+                    sr.part = (uint32_t)f;
+                    sr.hit_cap = b->hit_cap;
+                    HIP_TRY(launch_select_rows(sr, st));
+                } else {
+                    // the sub-index's k best under (score desc, document asc) as ONE tile of the candidate pool: K3 over its
+                    // accumulated rows, ordered -- K3's merge only needs equal scores in document order inside a tile
+                    TopkArgs ta{};
+                    ta.counts = b->counts_acc.p;
+                    ta.score_bytes = b->elem_bytes;
+                    ta.thresholds = need_thr ? b->work[f].thr.p : nullptr;
+                    ta.out = b->cand.p + cand_off[f] + (uint64_t)tile_base * topk;
+                    ta.out_count = nullptr;
+                    ta.out_stride = cand_stride[f];
+                    ta.pad_out = 1;
+                    ta.counts_stride = part_slots;
+                    ta.counts_offset = 0;
+                    ta.nslots = nvalid;
+                    ta.doc_base = c.pages[0].doc0;
+                    ta.num_docs = (uint32_t)p.meta.doc_names.size();
+                    ta.k = (uint32_t)topk;
+                    ta.nq = (uint32_t)nq;
+                    ta.score_bits = (uint32_t)b->planes;
+                    ta.levels = ((uint32_t)b->planes + 11u) / 12u;
+                    ta.level_bits = ((uint32_t)b->planes + ta.levels - 1u) / ta.levels;
+                    ta.sort_limit = (uint32_t)topk;
+                    HIP_TRY(launch_topk(ta, st));
+                }
+                tile_base += 1;
             }
             if (stream_this) {
                 HIP_TRY(hipEventRecord(sbufs.scanned[buf], st));
@@ -792,7 +844,7 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
     if (use_topk && nq) {
         for (size_t f = 0; f < ix->parts.size(); ++f) {
             const Part& p = ix->parts[f];
-            TopkArgs ta;
+            TopkArgs ta{};
             ta.counts = b->counts.p;
             ta.score_bytes = b->elem_bytes;
             ta.thresholds = need_thr ? b->work[f].thr.p : nullptr;

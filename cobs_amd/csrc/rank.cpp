@@ -192,6 +192,8 @@ struct RankWork {
     DevBuf<RankPart> parts;
     DevBuf<uint8_t> by_score;
     PinnedBuf<uint8_t> land[kDepth];    // records of a piece, then its counts
+    PinnedBuf<uint8_t> h_stage;         // parts | by_score on their way to the device: pinned, so that the launch half never waits
+                                        // for the stream (a copy from pageable memory does, inside the runtime) [ADVICE r5]
     hipStream_t copy_stream = nullptr;
     hipEvent_t ranked[2] = {nullptr, nullptr}, drained[2] = {nullptr, nullptr}, landed[kDepth] = {nullptr, nullptr, nullptr};
     ~RankWork() {
@@ -580,7 +582,8 @@ cobs_gpu_status rank_launch(cobs_gpu_batch* b, size_t q_first, size_t nq, size_t
     j.land_bytes = (j.pq * j.qbytes + 15) / 16 * 16;
     constexpr size_t kDepth = RankWork::kDepth;
     {   // the workspace: if the device or the pinned pool cannot give it, the caller ranks on the host as before
-        bool ok = w.parts.reserve(j.parts.size()) == hipSuccess && w.by_score.reserve(b->nq) == hipSuccess;
+        bool ok = w.parts.reserve(j.parts.size()) == hipSuccess && w.by_score.reserve(b->nq) == hipSuccess &&
+                  w.h_stage.reserve(round_up(j.parts.size() * sizeof(RankPart), 16) + b->nq) == hipSuccess;
         for (int i = 0; i < 2 && ok; ++i)
             ok = w.out[i].reserve((j.sq * stride * j.rec + sizeof(uint2) - 1) / sizeof(uint2)) == hipSuccess && w.cnt[i].reserve(2 * j.sq) == hipSuccess;
         for (size_t i = 0; i < kDepth && ok; ++i) ok = w.land[i].reserve(j.land_bytes + 4 * j.pq) == hipSuccess;
@@ -597,9 +600,12 @@ cobs_gpu_status rank_launch(cobs_gpu_batch* b, size_t q_first, size_t nq, size_t
             return COBS_GPU_ERR_UNSUPPORTED;
         }
     }
-    // (the two host vectors live in the job: the copies may read them after this function has returned)
-    HIP_TRY(hipMemcpyAsync(w.parts.p, j.parts.data(), j.parts.size() * sizeof(RankPart), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(w.by_score.p, j.by_score.data(), b->nq, hipMemcpyHostToDevice, st));
+    // (through pinned staging the job owns: rank_cancel above waited for whatever read it before)
+    uint8_t* h_by_score = w.h_stage.p + round_up(j.parts.size() * sizeof(RankPart), 16);
+    std::memcpy(w.h_stage.p, j.parts.data(), j.parts.size() * sizeof(RankPart));
+    std::memcpy(h_by_score, j.by_score.data(), b->nq);
+    HIP_TRY(hipMemcpyAsync(w.parts.p, w.h_stage.p, j.parts.size() * sizeof(RankPart), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(w.by_score.p, h_by_score, b->nq, hipMemcpyHostToDevice, st));
     j.nspans = (nq + j.sq - 1) / j.sq;
     for (size_t sp = 0; sp < j.nspans; ++sp) {
         const size_t s0 = sp * j.sq, s1 = std::min(nq, s0 + j.sq);

@@ -206,17 +206,47 @@ cobs_gpu_status rank_window(cobs_gpu_batch* b, size_t q0, size_t q1, size_t per_
 // ranks its bucket), then ONE copy home.  [Round 4 copied the pool to pageable memory, bucketed it with a counting
 // scatter on one host thread and ran std::partial_sort per query: 15.7 ms for the 264 000 hits of a 10k-query pass
 // (1.6 us per query, most of it per-call overhead) next to 19 ms of scan.]
-cobs_gpu_status order_pool(cobs_gpu_batch* b, const HitDev* d_pool, uint64_t n, hipStream_t st) {
+// Two halves, so that a pass's pool is ordered and crosses PCIe under the scan of the next pass (host_api.cpp,
+// sharded.cpp): order_pool_launch queues everything on `st` and returns; order_pool_collect waits for `st` and
+// publishes the host lists.  The batch says "pool fetched / sorted" only after the collect half went through
+// [ADVICE r5: the flags were set before the first fallible step, a failed ordering left an empty pool that later
+// calls answered 0 hits from].
+static bool order_less(const HitDev& x, const HitDev& y, bool single) {
+    if (!single && x.score != y.score) return x.score > y.score;
+    if (x.part != y.part) return x.part < y.part;
+    return x.doc < y.doc;
+}
+
+// (a pool beyond the 32-bit indices of the device ordering: bucketed and ordered on the host, as round 4 did)
+static cobs_gpu_status order_pool_host(cobs_gpu_batch* b, const HitDev* d_pool, uint64_t n, hipStream_t st) {
     const size_t nq = b->nq;
-    b->h_hit_off.assign(nq + 1, 0);
-    b->h_hits.clear();
-    b->pool_fetched = true;
-    b->pool_sorted = true;
-    if (nq == 0 || n == 0) return COBS_GPU_OK;
-    if (n > 0xFFFFFFF0ull) return fail(COBS_GPU_ERR_UNSUPPORTED, "hit pool beyond 2^32 records");
+    std::vector<HitDev> raw((size_t)n);
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(raw.data(), d_pool, (size_t)n * sizeof(HitDev), hipMemcpyDeviceToHost));
+    std::vector<size_t> off(nq + 1, 0);
+    for (const HitDev& h : raw) if (h.query < nq) off[h.query + 1]++;
+    for (size_t q = 0; q < nq; ++q) off[q + 1] += off[q];
+    std::vector<HitDev> out(off[nq]);
+    std::vector<size_t> cur(off.begin(), off.end() - 1);
+    for (const HitDev& h : raw) if (h.query < nq) out[cur[h.query]++] = h;
+    for (size_t q = 0; q < nq; ++q) {
+        const bool single = total_hashes(b, q) <= 1;
+        std::sort(out.begin() + off[q], out.begin() + off[q + 1], [single](const HitDev& x, const HitDev& y) { return order_less(x, y, single); });
+    }
+    b->h_hits.swap(out);
+    b->h_hit_off.swap(off);
+    b->pool_pending = false;
+    b->pool_fetched = b->pool_sorted = true;
+    return COBS_GPU_OK;
+}
+
+cobs_gpu_status order_pool_launch(cobs_gpu_batch* b, const HitDev* d_pool, uint64_t n, hipStream_t st) {
+    const size_t nq = b->nq;
+    b->pool_fetched = b->pool_sorted = b->pool_pending = false;
+    b->pool_n = 0;
+    if (nq == 0 || n == 0) { b->pool_pending = true; return COBS_GPU_OK; }
+    if (n > 0x7FFFFFFFull) return COBS_GPU_ERR_UNSUPPORTED;        // (order_pool: the host path)
     HIP_TRY(hipSetDevice(b->ix->device));
-    const bool trace = b->ix->tune.trace;
-    const double tr0 = trace ? now_s() : 0.0;
     HIP_TRY(b->pool_idx.reserve(3 * (nq + 1)));
     HIP_TRY(b->pool_tmp.reserve((size_t)n));
     HIP_TRY(b->pool_out.reserve((size_t)n));
@@ -237,21 +267,37 @@ cobs_gpu_status order_pool(cobs_gpu_batch* b, const HitDev* d_pool, uint64_t n, 
     a.seg_max = kPoolSegMax;
     if (any_single) {
         HIP_TRY(b->pool_single.reserve(nq));
-        std::vector<uint8_t> flags(nq);
-        for (size_t q = 0; q < nq; ++q) flags[q] = total_hashes(b, q) <= 1 ? 1 : 0;
-        HIP_TRY(hipMemcpyAsync(b->pool_single.p, flags.data(), nq, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));          // (`flags` is pageable and goes out of scope)
+        HIP_TRY(b->h_single.reserve(nq));               // (pinned: the copy leaves when the stream gets to it)
+        for (size_t q = 0; q < nq; ++q) b->h_single.p[q] = total_hashes(b, q) <= 1 ? 1 : 0;
+        HIP_TRY(hipMemcpyAsync(b->pool_single.p, b->h_single.p, nq, hipMemcpyHostToDevice, st));
         a.single = b->pool_single.p;
     }
-    const double tr1 = trace ? now_s() : 0.0;
     HIP_TRY(hipMemsetAsync(b->pool_idx.p, 0, 3 * (nq + 1) * sizeof(uint32_t), st));
     HIP_TRY(launch_order_pool(a, st));
     HIP_TRY(hipMemcpyAsync(b->h_pool.p, a.off, (nq + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(b->h_pool.p + off_bytes, a.out, (size_t)n * sizeof(HitDev), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    const double tr2 = trace ? now_s() : 0.0;
+    b->pool_n = n;
+    b->pool_pending = true;
+    return COBS_GPU_OK;
+}
+
+cobs_gpu_status order_pool_collect(cobs_gpu_batch* b, hipStream_t st, bool waited) {
+    if (!b->pool_pending) return fail(COBS_GPU_ERR_ARG, "no hit pool is being ordered");
+    b->pool_pending = false;
+    const size_t nq = b->nq;
+    const uint64_t n = b->pool_n;
+    if (nq == 0 || n == 0) {
+        b->h_hit_off.assign(nq + 1, 0);
+        b->h_hits.clear();
+        b->pool_fetched = b->pool_sorted = true;
+        return COBS_GPU_OK;
+    }
+    HIP_TRY(hipSetDevice(b->ix->device));
+    if (!waited) HIP_TRY(hipStreamSynchronize(st));
+    const size_t off_bytes = round_up((nq + 1) * sizeof(uint32_t), 16);
     const uint32_t* off = reinterpret_cast<const uint32_t*>(b->h_pool.p);
     const HitDev* rec = reinterpret_cast<const HitDev*>(b->h_pool.p + off_bytes);
+    b->h_hit_off.resize(nq + 1);
     for (size_t q = 0; q <= nq; ++q) b->h_hit_off[q] = off[q];
     const size_t kept = off[nq];                    // (records whose query number is out of range are dropped, as before)
     b->h_hits.assign(rec, rec + kept);
@@ -259,16 +305,48 @@ cobs_gpu_status order_pool(cobs_gpu_batch* b, const HitDev* d_pool, uint64_t n, 
         const size_t s0 = off[q], s1 = off[q + 1];
         if (s1 - s0 <= kPoolSegMax) continue;
         const bool single = total_hashes(b, q) <= 1;
-        std::sort(b->h_hits.begin() + s0, b->h_hits.begin() + s1, [single](const HitDev& x, const HitDev& y) {
-            if (!single && x.score != y.score) return x.score > y.score;
-            if (x.part != y.part) return x.part < y.part;
-            return x.doc < y.doc;
-        });
+        std::sort(b->h_hits.begin() + s0, b->h_hits.begin() + s1, [single](const HitDev& x, const HitDev& y) { return order_less(x, y, single); });
     }
-    if (trace)
-        std::fprintf(stderr, "[cobs_gpu] hit pool of %llu records ordered: set-up %.3f ms, device + copy home %.3f ms, host lists %.3f ms\n",
-                     (unsigned long long)n, (tr1 - tr0) * 1e3, (tr2 - tr1) * 1e3, (now_s() - tr2) * 1e3);
+    b->pool_fetched = b->pool_sorted = true;
     return COBS_GPU_OK;
+}
+
+cobs_gpu_status order_pool(cobs_gpu_batch* b, const HitDev* d_pool, uint64_t n, hipStream_t st) {
+    const bool trace = b->ix->tune.trace;
+    const double tr0 = trace ? now_s() : 0.0;
+    cobs_gpu_status s = order_pool_launch(b, d_pool, n, st);
+    if (s == COBS_GPU_ERR_UNSUPPORTED) return order_pool_host(b, d_pool, n, st);
+    if (s == COBS_GPU_OK) s = order_pool_collect(b, st);
+    if (s != COBS_GPU_OK) b->pool_fetched = b->pool_sorted = b->pool_pending = false;
+    if (trace)
+        std::fprintf(stderr, "[cobs_gpu] hit pool of %llu records ordered in %.3f ms\n", (unsigned long long)n, (now_s() - tr0) * 1e3);
+    return s;
+}
+
+// The finished lists of ALL queries of a pass whose pool is in result order (order_pool), handed over in one sweep:
+// query `i` of the pass is query g0 + i of the call; its records go behind *used, hit_offsets[g0 + i + 1] = the new
+// *used.  grow: `hits` is that arena (cobs_gpu_search_batch_view) -- made larger in place of reporting an overflow,
+// for this pass and, at the rate so far, for the passes to come (nq_call = queries of the whole call).
+// Returns false (nothing written) when the lists do not fit: the caller counts them query by query.
+bool hand_over_pool(cobs_gpu_batch* sb, size_t g0, size_t g1, cobs_gpu_hit** hits, size_t* cap, size_t* used, size_t* hit_offsets,
+                    ResultArena* grow, size_t nq_call, cobs_gpu_status* status) {
+    *status = COBS_GPU_OK;
+    if (!sb->pool_sorted) return false;
+    if (grow && sb->h_hits.size() > *cap - *used) {
+        const size_t have = *used + sb->h_hits.size();
+        const size_t want = std::max<size_t>(have + have / 4 + 1024, (size_t)((double)have * (double)nq_call / (double)std::max<size_t>(g1, 1) * 1.125));
+        if (cobs_gpu_status gs = grow->grow_keep(want, *used); gs != COBS_GPU_OK) { *status = gs; return false; }
+        *hits = grow->p;
+        *cap = grow->cap;
+    }
+    if (sb->h_hits.size() > *cap - *used || (!sb->h_hits.empty() && !*hits)) return false;
+    const HitDev* rec = sb->h_hits.data();
+    const size_t n = sb->h_hits.size();
+    cobs_gpu_hit* dst = *hits + *used;
+    for (size_t i = 0; i < n; ++i) dst[i] = cobs_gpu_hit{rec[i].part, rec[i].doc, rec[i].score};
+    for (size_t q = g0; q < g1; ++q) hit_offsets[q + 1] = *used + sb->h_hit_off[q - g0 + 1];
+    *used += n;
+    return true;
 }
 
 static cobs_gpu_status hits_host_impl(cobs_gpu_batch* b, size_t q, size_t num_results,

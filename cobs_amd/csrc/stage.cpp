@@ -28,7 +28,7 @@ cobs_gpu_status alloc_part(cobs_gpu_index* ix, Part& pt) {
     for (Chunk& c : pt.chunks) {
         HIP_TRY(hipMalloc((void**)&c.d_pages, sizeof(PageDev) * c.pages.size()));
         HIP_TRY(hipMemcpy(c.d_pages, c.pages.data(), sizeof(PageDev) * c.pages.size(), hipMemcpyHostToDevice));
-        if (c.row_range && c.range_no > 0) {     // its partial scores go to a scratch matrix of the slice's own width
+        if (c.row_range) {     // partial scores (a later range, or any range of a pass without score rows) go to a scratch matrix of the slice's own width
             std::vector<PageDev> acc = c.pages;
             for (PageDev& pd : acc) pd.slot0 = 0;
             HIP_TRY(hipMalloc((void**)&c.d_pages_acc, sizeof(PageDev) * acc.size()));

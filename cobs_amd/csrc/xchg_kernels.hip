@@ -44,8 +44,8 @@ __global__ __launch_bounds__(256) void bucket_hits_kernel(BucketArgs a) {
 
 // ---- the hit pool in result order (PoolArgs) ----
 __global__ __launch_bounds__(256) void pool_count_kernel(PoolArgs a) {
-    const uint32_t stride = gridDim.x * 256u;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < a.n; i += stride) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;          // (64-bit: i + stride must not wrap for n near 2^32)
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < a.n; i += stride) {
         const uint32_t q = a.in[i].query;
         if (q < a.nq) atomicAdd(&a.cnt[q], 1u);
     }
@@ -76,8 +76,8 @@ __global__ __launch_bounds__(1024) void pool_scan_kernel(PoolArgs a) {
 }
 
 __global__ __launch_bounds__(256) void pool_scatter_kernel(PoolArgs a) {
-    const uint32_t stride = gridDim.x * 256u;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < a.n; i += stride) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < a.n; i += stride) {
         const HitDev h = a.in[i];
         if (h.query < a.nq) a.tmp[a.off[h.query] + atomicAdd(&a.cur[h.query], 1u)] = h;
     }
@@ -113,7 +113,23 @@ __global__ __launch_bounds__(64) void pool_sort_kernel(PoolArgs a) {
     }
 }
 
+// What the ranks of a sharded search agree on after the scan of a pass, as ONE record per rank that an all-gather
+// carries (sharded.cpp): the rank's host-side status, K1's first invalid query, the fill of its hit pool -- read from
+// the batch's flag words where the scan left them, no host round trip in between.
+__global__ void pass_meta_kernel(const uint32_t* flags, uint64_t* rec, uint64_t status, uint64_t extra) {
+    if (threadIdx.x != 0u) return;
+    rec[0] = status;
+    rec[1] = flags ? flags[0] : 0u;
+    rec[2] = flags ? ((uint64_t)flags[3] << 32 | flags[2]) : 0ull;
+    rec[3] = extra;
+}
+
 }  // namespace
+
+hipError_t launch_pass_meta(const uint32_t* flags, uint64_t* rec, uint64_t status, uint64_t extra, hipStream_t stream) {
+    hipLaunchKernelGGL(pass_meta_kernel, dim3(1), dim3(64), 0, stream, flags, rec, status, extra);
+    return hipGetLastError();
+}
 
 hipError_t launch_order_pool(const PoolArgs& a, hipStream_t stream) {
     if (a.nq == 0) return hipSuccess;

@@ -236,6 +236,7 @@ class Search:
         return ResultList(self, seg)
 
     HIT_DTYPE = np.dtype([("file_no", "<u4"), ("doc", "<u4"), ("score", "<u4")])
+    reuse_result_buffers = True     # see _result_buffer
 
     def search_arrays(self, queries, threshold=0.0, num_results=0, out=None):
         """-> (offsets uint64 [nq + 1], hits structured array of (file_no, doc, score)):
@@ -246,12 +247,9 @@ class Search:
         np.cumsum(np.fromiter(map(len, qs), dtype=np.uint64, count=len(qs)), out=offsets[1:])
         return self.search_packed(b"".join(qs), offsets, threshold, num_results, out=out)
 
-    def search_packed(self, text, offsets, threshold=0.0, num_results=0, out=None):
-        """The same for queries packed back to back: query i is text[offsets[i]:offsets[i + 1]]
-        (text: bytes or a uint8 array, e.g. the sequence lines of a FASTQ block; offsets: nq + 1
-        integers).  No per-query Python objects: the pointer array is built with numpy.
-        out: an optional HIT_DTYPE array to receive the hits (a caller that repeats large calls keeps
-        one buffer instead of page-faulting a fresh one per call); it is used when large enough."""
+    @staticmethod
+    def _packed_args(text, offsets):
+        """-> (char** queries, size_t* lens, nq, what keeps them alive) for queries packed back to back"""
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         nq = len(offsets) - 1
         if nq < 0:
@@ -270,6 +268,15 @@ class Search:
         lens_np = np.ascontiguousarray(lens_np)
         arr = C.cast(ptrs_np.ctypes.data, C.POINTER(C.c_char_p))
         lens = C.cast(lens_np.ctypes.data, C.POINTER(C.c_size_t))
+        return arr, lens, nq, (text, ptrs_np, lens_np)
+
+    def search_packed(self, text, offsets, threshold=0.0, num_results=0, out=None):
+        """The same for queries packed back to back: query i is text[offsets[i]:offsets[i + 1]]
+        (text: bytes or a uint8 array, e.g. the sequence lines of a FASTQ block; offsets: nq + 1
+        integers).  No per-query Python objects: the pointer array is built with numpy.
+        out: an optional HIT_DTYPE array to receive the hits (a caller that repeats large calls keeps
+        one buffer instead of page-faulting a fresh one per call); it is used when large enough."""
+        arr, lens, nq, _keep = self._packed_args(text, offsets)
         if num_results > 0:
             cap = nq * min(num_results, self.total_counts)
         elif threshold <= 0:
@@ -322,6 +329,13 @@ class Search:
         drops the results of one call before it makes the next never allocates; one that keeps them gets fresh memory."""
         need = cap * self.HIT_DTYPE.itemsize
         pool = self.__dict__.setdefault("_result_pool", [])
+        # "Nothing references it" is read off CPython's reference count of the raw buffer: exact there for every numpy
+        # object made from the results (views keep the raw buffer through .base); a raw address taken from a result
+        # (.ctypes.data) dangles once the result is dropped whether or not the memory is used again.  An interpreter
+        # without reference counts gets a fresh buffer per call, and Search.reuse_result_buffers = False turns the
+        # reuse off for a caller that wants that anyway [ADVICE r5].
+        if not (self.reuse_result_buffers and sys.implementation.name == "cpython"):
+            return np.empty(max(need, 1), dtype=np.uint8)[:need].view(self.HIT_DTYPE)
         for i in range(len(pool)):
             # references: the pool's, and getrefcount's argument
             if pool[i].nbytes >= need and sys.getrefcount(pool[i]) == 2:
@@ -353,15 +367,17 @@ class Search:
         raw = np.ctypeslib.as_array(C.cast(hp, C.POINTER(C.c_uint8)), shape=(n * 12,))
         return offs, raw.view(self.HIT_DTYPE)
 
-    def sharded_search_hits(self, comm, queries, threshold=0.0, num_results=0, split=False):
-        """cobs_gpu_sharded_search_batch: collective over `comm` (every rank, same queries);
-        -> per query the GLOBAL list of (file_no, doc, score) in result order.
-        split=True: cobs_gpu_sharded_search_batch_split -- for the all-documents search the ranks share the
-        ranking and this rank's return holds the results of the queries it owns (empty lists for the others)."""
-        qs = [q if type(q) is bytes else _as_bytes(q) for q in queries]
-        nq = len(qs)
-        arr = (C.c_char_p * max(nq, 1))(*qs)
-        lens = (C.c_size_t * max(nq, 1))(*[len(q) for q in qs])
+    def sharded_search_arrays(self, comm, queries, threshold=0.0, num_results=0, split=False):
+        """cobs_gpu_sharded_search_batch[_split]: collective over `comm` (every rank, same queries)
+        -> (offsets uint64 [nq + 1], hits HIT_DTYPE array), the GLOBAL results in result order (split: see below).
+        queries: a list, or a (text, offsets) pair of queries packed back to back."""
+        if isinstance(queries, tuple):         # (text, offsets): queries packed back to back, as search_packed takes them
+            arr, lens, nq, _keep = self._packed_args(*queries)
+        else:
+            qs = [q if type(q) is bytes else _as_bytes(q) for q in queries]
+            nq = len(qs)
+            arr = (C.c_char_p * max(nq, 1))(*qs)
+            lens = (C.c_size_t * max(nq, 1))(*[len(q) for q in qs])
         if num_results > 0:
             cap = nq * min(num_results, self.total_counts)
         elif threshold <= 0:
@@ -373,23 +389,30 @@ class Search:
         cap = max(1, cap)
         offs = np.zeros(nq + 1, dtype=np.uint64)
         bad = C.c_size_t(0)
+        fn = self._lib.cobs_gpu_sharded_search_batch_split if split else self._lib.cobs_gpu_sharded_search_batch
         while True:
             hits = np.empty(cap, dtype=self.HIT_DTYPE)
-            fn = self._lib.cobs_gpu_sharded_search_batch_split if split else self._lib.cobs_gpu_sharded_search_batch
             offs[:] = 0
-            st = fn(
-                self._h, comm._h, arr, lens, nq, float(threshold), int(num_results),
-                C.cast(hits.ctypes.data, C.POINTER(Hit)), cap,
-                C.cast(offs.ctypes.data, C.POINTER(C.c_size_t)), C.byref(bad))
+            st = fn(self._h, comm._h, arr, lens, nq, float(threshold), int(num_results),
+                    C.cast(hits.ctypes.data, C.POINTER(Hit)), cap,
+                    C.cast(offs.ctypes.data, C.POINTER(C.c_size_t)), C.byref(bad))
             if st == _capi.ERR_CAPACITY and int(offs[nq]) > cap:
                 cap = int(offs[nq])
                 continue
             check(st)
             break
+        if threshold > 0 and num_results == 0 and nq and not split:
+            self._sharded_hits_per_query = max(int(offs[nq]) / nq, 0.95 * self.__dict__.get("_sharded_hits_per_query", 0.0))
+        return offs, hits[:int(offs[nq])] if not split else hits
+
+    def sharded_search_hits(self, comm, queries, threshold=0.0, num_results=0, split=False):
+        """-> per query the GLOBAL list of (file_no, doc, score) in result order.
+        split=True: cobs_gpu_sharded_search_batch_split -- for the all-documents search the ranks share the
+        ranking and this rank's return holds the results of the queries it owns (empty lists for the others)."""
+        offs, hits = self.sharded_search_arrays(comm, queries, threshold, num_results, split)
+        nq = len(queries)
         if split:
             return _split_segments(hits, offs, nq, threshold, num_results, self)
-        if threshold > 0 and num_results == 0 and nq:
-            self._sharded_hits_per_query = max(int(offs[nq]) / nq, 0.95 * self.__dict__.get("_sharded_hits_per_query", 0.0))
         rows = hits[:int(offs[nq])].tolist()
         return [rows[int(offs[q]):int(offs[q + 1])] for q in range(nq)]
 
@@ -513,16 +536,21 @@ class Batch:
     """Device-resident query batch (cobs_gpu_batch_*): inputs are copied to HBM
     once, run() launches the hot path asynchronously, counts stay in HBM."""
 
-    def __init__(self, search, max_queries=0, max_query_len=0):
+    def __init__(self, search, max_queries=0, max_query_len=0, _borrowed=None):
         self._s = search
         self._lib = search._lib
         self._h = C.c_void_p()
-        check(self._lib.cobs_gpu_batch_create(search._h, max_queries, max_query_len, C.byref(self._h)))
+        self._owned = _borrowed is None
+        if _borrowed is not None:           # a sub-batch of a ShardedBatch: the library object owns it
+            self._h = C.c_void_p(_borrowed)
+        else:
+            check(self._lib.cobs_gpu_batch_create(search._h, max_queries, max_query_len, C.byref(self._h)))
         self.nq = 0
 
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.cobs_gpu_batch_destroy(self._h)
+            if self._owned:
+                self._lib.cobs_gpu_batch_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -656,3 +684,63 @@ class Batch:
 
 
 __all__ = ["Search", "SearchResult", "Batch", "CobsGpuError"]
+
+
+class ShardedBatch:
+    """The device-resident form of the sharded search (cobs_gpu_sharded_batch_*): ONE batch of queries, uploaded once;
+    step() scans it on this rank's shard and exchanges the count rows over the communicator -- cut into sub-batches
+    whose hashing, scan and exchange overlap inside the library (three streams tied by events), also across steps.
+    Collective: every rank makes the same calls.  sub(i) are the sub-batches as Batch views (global / local count rows)."""
+
+    def __init__(self, search, comm, sub_batches=1):
+        self._s, self._comm = search, comm
+        self._lib = search._lib
+        self._h = C.c_void_p()
+        check(self._lib.cobs_gpu_sharded_batch_create(search._h, comm._h, int(sub_batches), C.byref(self._h)))
+        self.nq = 0
+        self._subs = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            for b in self._subs:
+                b.close()
+            self._lib.cobs_gpu_sharded_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_queries(self, queries):
+        qs = [_as_bytes(q) for q in queries]
+        arr = (C.c_char_p * max(len(qs), 1))(*qs)
+        lens = (C.c_size_t * max(len(qs), 1))(*[len(q) for q in qs])
+        check(self._lib.cobs_gpu_sharded_batch_set_queries(self._h, arr, lens, len(qs)))
+        self.nq = len(qs)
+        self._subs = []
+        for i in range(int(self._lib.cobs_gpu_sharded_batch_subs(self._h))):
+            q0, qn = C.c_size_t(0), C.c_size_t(0)
+            h = self._lib.cobs_gpu_sharded_batch_sub(self._h, i, C.byref(q0), C.byref(qn))
+            b = Batch(self._s, _borrowed=h)
+            b.nq, b.q_begin = int(qn.value), int(q0.value)
+            self._subs.append(b)
+
+    @property
+    def subs(self):
+        return list(self._subs)
+
+    def step(self, threshold=0.0, mode=_capi.XCHG_ALLTOALL):
+        check(self._lib.cobs_gpu_sharded_batch_step(self._h, float(threshold), int(mode)))
+
+    def sync(self):
+        bad = C.c_size_t(0)
+        check(self._lib.cobs_gpu_sharded_batch_sync(self._h, C.byref(bad)))
+
+    def times(self):
+        """after sync(): per step, summed over the sub-batches, averaged over the steps since the previous call"""
+        t = (C.c_double * 8)()
+        check(self._lib.cobs_gpu_sharded_batch_times(self._h, C.byref(t)))
+        return {"scan_ms": t[0], "hash_ms": t[1], "exchange_ms": t[2], "algorithmic_bytes": int(t[3]),
+                "received_bytes": int(t[4]), "scan_launches": int(t[5]), "steps": int(t[6])}

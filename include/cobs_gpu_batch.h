@@ -213,6 +213,40 @@ cobs_gpu_status cobs_gpu_sharded_search_batch_split(cobs_gpu_index* ix, cobs_gpu
                                                     const size_t* lens, size_t nq, double threshold, size_t num_results,
                                                     cobs_gpu_hit* hits, size_t cap, size_t* hit_offsets, size_t* bad_query);
 
+/* How both calls above run (round 6): the call is cut into passes that overlap inside the library, as the reference
+ * parallelises inside search() (parallel_for over document batches, classic_search.cpp:355-400): upload + hashing of
+ * pass i+1 | scan of pass i | the ranks' agreement, the exchange over RCCL and the ordering of the results of pass i-1,
+ * on their own streams tied by events.  After a scan the ranks agree through ONE all-gathered record per pass (status,
+ * first invalid query, hit-pool fill; written by the device, read once per pass while the next pass scans).  All ranks
+ * must have set the tuning keys that cut passes (pass_bytes, pipe_chars) alike. */
+
+/* ---- the device-resident form of the sharded search: what `bench.py --gpus N` times ----
+ * ONE batch of queries, uploaded once; a step scans it on every rank against that rank's shard and leaves the count rows
+ * on the device in global document order (cobs_gpu_batch_global_counts_device of every sub-batch).  The batch is cut
+ * into `sub_batches` sub-batches over the queries -- the reference's own loop is per batch of documents,
+ * classic_search.cpp:355-400 -- whose hashing (the sub-batch's own stream), scan (scan stream) and exchange (exchange
+ * stream) overlap, also across steps: hash(i+1) | scan(i) | exchange(i-1).  Collective: every rank makes the same calls.
+ * More than one sub-batch sets the handle's tuning key hash_stream. */
+typedef struct cobs_gpu_sharded_batch cobs_gpu_sharded_batch;
+cobs_gpu_status cobs_gpu_sharded_batch_create(cobs_gpu_index* ix, cobs_gpu_comm* c, uint32_t sub_batches,
+                                              cobs_gpu_sharded_batch** out);
+void cobs_gpu_sharded_batch_destroy(cobs_gpu_sharded_batch* sb);
+/* sub-batch i holds the queries [nq*i/S, nq*(i+1)/S); synchronous (one upload per sub-batch) */
+cobs_gpu_status cobs_gpu_sharded_batch_set_queries(cobs_gpu_sharded_batch* sb, const char* const* queries, const size_t* lens,
+                                                   size_t nq);
+/* one step, asynchronous: every sub-batch hashed, scanned, its count rows exchanged (mode: cobs_gpu_exchange_mode) */
+cobs_gpu_status cobs_gpu_sharded_batch_step(cobs_gpu_sharded_batch* sb, double threshold, uint32_t mode);
+/* waits for everything queued (the exchange stream under the communicator's time limit); invalid queries are reported
+ * here, *bad_query = index in the batch */
+cobs_gpu_status cobs_gpu_sharded_batch_sync(cobs_gpu_sharded_batch* sb, size_t* bad_query);
+size_t cobs_gpu_sharded_batch_subs(const cobs_gpu_sharded_batch* sb);
+/* sub-batch i (owned by sb) and its queries: for the batch-level accessors (global / local count rows, stats) */
+cobs_gpu_batch* cobs_gpu_sharded_batch_sub(cobs_gpu_sharded_batch* sb, size_t i, size_t* q_begin, size_t* q_count);
+/* After a sync; per step, summed over the sub-batches, averaged over the steps since the previous call (at most 64):
+ * out = scan ms | hash ms | exchange ms | algorithmic bytes | bytes received from other ranks |
+ * scan launches | steps averaged over | 0 -- HIP events on the streams the kernels and collectives ran on. */
+cobs_gpu_status cobs_gpu_sharded_batch_times(cobs_gpu_sharded_batch* sb, double out[8]);
+
 #ifdef __cplusplus
 }
 #endif

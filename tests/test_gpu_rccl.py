@@ -306,3 +306,97 @@ def test_a_collective_that_does_not_finish_in_time_fails_instead_of_hanging(gpu_
     pf = c2.preflight(timeout_ms=20000)                     # the real collectives of a one-rank communicator
     assert pf["allgather_us"] > 0 and pf["allreduce_us"] > 0
     c2.close()
+
+
+def test_sharded_search_is_a_pipeline_of_passes(gpu_lib, oracle, tmp_path, comm):
+    """round 6: cobs_gpu_sharded_search_batch cuts a call into passes that overlap inside the library (upload + K1 of
+    pass i+1 | K2 of pass i | agreement, exchange and ordering of pass i-1 on the exchange stream; three scratch
+    batches in rotation; ONE all-gathered status record per pass).  A call of 1..9 passes, every result path -- hits
+    through the pool, a limit through the shards' best-of lists (and through score rows where a query has a single hash),
+    every document through the row exchange, the shared ranking -- against the one-GPU call and the oracle; an invalid
+    query in a LATER pass is named by its index in the call and leaves nothing in flight (the next call works); a
+    result buffer that is too small reports the needed size."""
+    from cobs_amd import _capi
+    import ctypes as C
+    paths, base = _files(oracle, tmp_path)
+    ixs = [oracle.Index.open(p) for p in paths]
+    q_long = base[0]
+    queries = [q_long[(7 * i) % 200:(7 * i) % 200 + 31 + (37 * i) % 260] for i in range(23)]
+    queries[4] = q_long[:31]                          # a single hash in the compact file: index order, rows travel
+    s = gpu_lib.Search(paths, device=0)
+    cases_ = ((0.0, 0), (0.3, 0), (0.9, 0), (0.3, 4), (0.0, 6), (0.0, 1))
+    for per_pass in (0, 9, 3):                        # one pass | three passes | eight passes (the rotation wraps twice)
+        s.set_tuning("pass_bytes", 0 if per_pass == 0 else per_pass * 2 * s.total_counts * 2)
+        for t, lim in cases_:
+            want = [cases.oracle_results(ixs, q, t, lim) for q in queries]
+            assert s.sharded_search_hits(comm, queries, t, lim) == want, (per_pass, t, lim)
+            assert s.search_hits(queries, t, lim) == want, (per_pass, t, lim)
+            if lim == 0:
+                assert s.sharded_search_hits(comm, queries, t, lim, split=True) == want, (per_pass, t, lim, "split")
+        # an invalid character in the last pass: every earlier pass has been launched, agreed on and exchanged by then
+        bad = list(queries)
+        bad[21] = bad[21][:12] + b"N" + bad[21][13:]
+        for t, lim in ((0.0, 0), (0.3, 0), (0.0, 3)):
+            with pytest.raises(gpu_lib.CobsGpuError) as e:
+                s.sharded_search_hits(comm, bad, t, lim)
+            assert e.value.status == _capi.ERR_INVALID_BASE and "(query 21)" in str(e.value), str(e.value)
+            assert s.sharded_search_hits(comm, queries[:5], t, lim) == [cases.oracle_results(ixs, q, t, lim) for q in queries[:5]]
+        # a query shorter than the term size (host-side check of a later pass)
+        short = list(queries)
+        short[20] = b"ACGT"
+        with pytest.raises(gpu_lib.CobsGpuError) as e:
+            s.sharded_search_hits(comm, short, 0.3, 0)
+        assert e.value.status == _capi.ERR_QUERY_TOO_SHORT and "(query 20)" in str(e.value), str(e.value)
+    # capacity: the call says what it needs, nothing is written past the buffer
+    lib = _capi.load()
+    nq = len(queries)
+    arr = (C.c_char_p * nq)(*queries)
+    lens = (C.c_size_t * nq)(*[len(q) for q in queries])
+    offs = (C.c_size_t * (nq + 1))()
+    hits = (_capi.Hit * 8)()
+    bad_q = C.c_size_t(0)
+    want = [cases.oracle_results(ixs, q, 0.3, 0) for q in queries]
+    st = lib.cobs_gpu_sharded_search_batch(s._h, comm._h, arr, lens, nq, 0.3, 0, hits, 8, offs, C.byref(bad_q))
+    assert st == _capi.ERR_CAPACITY and offs[nq] == sum(len(w) for w in want) > 8
+
+
+def test_sharded_batch_object(gpu_lib, oracle, tmp_path, comm):
+    """cobs_gpu_sharded_batch_*: the device-resident form of the sharded search that bench.py --gpus N times -- the batch
+    cut into sub-batches whose hashing, scan and exchange overlap on the library's own three streams, also across
+    steps.  1, 2, 3 and 7 sub-batches (more than some have queries), every exchange mode, several steps in flight:
+    the rows every sub-batch ends up with equal the oracle's, the times and byte counts are there, an invalid query is
+    reported by its index in the batch."""
+    from cobs_amd import _capi
+    paths, base = _files(oracle, tmp_path)
+    ixs = [oracle.Index.open(p) for p in paths]
+    q_long = base[0]
+    queries = [q_long[(11 * i) % 150:(11 * i) % 150 + 40 + (53 * i) % 300] for i in range(13)]
+    want = np.stack([np.concatenate([ix.counts(q) for ix in ixs]) for q in queries])
+    s = gpu_lib.Search(paths, device=0)
+    for nsub in (1, 2, 3, 7):
+        sb = gpu_lib.ShardedBatch(s, comm, nsub)
+        sb.set_queries(queries)
+        assert len(sb.subs) == nsub and sum(b.nq for b in sb.subs) == len(queries)
+        for mode in (_capi.XCHG_ALLTOALL, _capi.XCHG_ALLGATHER, _capi.XCHG_REDUCE):
+            for _ in range(3):
+                sb.step(0.0, mode)
+            sb.sync()
+            for b in sb.subs:
+                if b.nq == 0:
+                    continue
+                q0, qn, rows = b.global_counts_tensor()
+                assert (q0, qn) == (0, b.nq)
+                got = rows.cpu().numpy()          # (u8 / u16 scores by the sub-batch's longest query, as signed torch types)
+                got = got.astype(np.int64) & ((1 << (8 * got.itemsize)) - 1)
+                assert np.array_equal(got, want[b.q_begin:b.q_begin + b.nq]), (nsub, mode)
+            t = sb.times()
+            assert t["steps"] == 3 and t["scan_ms"] > 0 and t["exchange_ms"] > 0 and t["received_bytes"] == 0
+            assert t["algorithmic_bytes"] == sum(b.stats()["algorithmic_bytes"] for b in sb.subs)
+        bad = list(queries)
+        bad[9] = bad[9][:5] + b"N" + bad[9][6:]
+        sb.set_queries(bad)
+        sb.step(0.0)
+        with pytest.raises(gpu_lib.CobsGpuError) as e:
+            sb.sync()
+        assert e.value.status == _capi.ERR_INVALID_BASE and "(query 9)" in str(e.value), str(e.value)
+        sb.close()

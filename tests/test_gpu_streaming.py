@@ -248,7 +248,8 @@ def test_row_range_chunks(gpu_lib, oracle, tmp_path, monkeypatch, kind, no_pin):
     """A streamed sub-index larger than a stream buffer, ONE hash function: cut by ROWS (whole rows cross PCIe at the
     link's best rate; plan.cpp) -- each range's scan counts the terms whose row falls into it, later ranges add their
     partial scores to the rows.  Counts, thresholds, limits, the all-documents ranking, 8- and 16-bit scores, the
-    hits-only entry point and the sharded search on a one-rank communicator equal the oracle's; with
+    hits-only and limit-only entry points (selection from the accumulated scores of a sub-index, no score rows: round 6),
+    the hit exchanges and the sharded search on a one-rank communicator equal the oracle's; with
     COBS_GPU_ROW_RANGES=0 the same file is cut by columns and gives the same results."""
     from cobs_amd.distributed import Comm
     if no_pin == "1":
@@ -286,11 +287,45 @@ def test_row_range_chunks(gpu_lib, oracle, tmp_path, monkeypatch, kind, no_pin):
     assert b.counts_device()[1] == 1
     for i, q in enumerate(short):
         assert np.array_equal(b.counts_host(i), ix.counts(q))
-    # the hits-only entry point keeps score rows on such a handle and answers from them
+    # round 6: the hits-only entry point SELECTS on such a handle too -- the ranges of a sub-index add up in a scratch
+    # matrix of its own width, the threshold filter runs over that after the last range (select_rows_kernel) and fills the
+    # hit pool the resident path fills; no score rows of the whole index (the run's algorithmic bytes hold no score bytes)
+    for qs_ in (short, queries):
+        b.set_queries(qs_)
+        b.run(0.0)
+        b.sync()
+        with_rows = b.stats()["algorithmic_bytes"]
+        for t in (0.4, 0.9, 0.05):
+            b.run_hits(t)
+            b.sync()
+            assert b.stats()["algorithmic_bytes"] == with_rows - len(qs_) * s.local_counts * b.counts_device()[1], "score rows were written"
+            for i, q in enumerate(qs_):
+                assert b.hits_host(i) == cases.oracle_results([ix], q, t, 0), (t, i)
+                assert b.hits_host(i, 2) == cases.oracle_results([ix], q, t, 2), (t, i)
+        # ... and a limit without score rows: the sub-index's k best from the accumulated scores are ONE tile of the
+        # candidate pool K3 merges (ties at the cut in document order, across the ranged and the whole sub-indexes)
+        for t, lim in ((0.0, 1), (0.0, 3), (0.0, 17), (0.3, 5), (0.0, 128)):
+            b.run_topk(t, lim, keep_counts=False)
+            b.sync()
+            if all(len(q) > 31 for q in qs_):        # (a query with a single hash in total is index order: such a batch keeps its rows)
+                assert b.stats()["algorithmic_bytes"] == with_rows - len(qs_) * s.local_counts * b.counts_device()[1], "score rows were written"
+            for i, q in enumerate(qs_):
+                assert b.hits_host(i, lim) == cases.oracle_results([ix], q, t, lim), (t, lim, i)
+    # the hit exchanges of the multi-GPU layout take such a handle like any other (they refused it until round 6)
+    xc = Comm(Comm.unique_id(), 0, 1, device=0)
+    b.set_queries(short)
     b.run_hits(0.4)
     b.sync()
+    assert b.exchange_hits(xc) is False
     for i, q in enumerate(short):
         assert b.hits_host(i) == cases.oracle_results([ix], q, 0.4, 0)
+    b.run_hits(0.4)
+    b.sync()
+    over, q0, qn = b.exchange_hits_owned(xc)
+    assert not over and (q0, qn) == (0, len(short))
+    for i, q in enumerate(short):
+        assert b.hits_host(i) == cases.oracle_results([ix], q, 0.4, 0)
+    xc.close()
     # every document ranked (the device ranking reads the accumulated rows), limits, thresholds in one call each
     for t, lim in ((0.0, 0), (0.0, 7), (0.35, 0)):
         got = s.search_hits(short, t, lim)
@@ -299,7 +334,7 @@ def test_row_range_chunks(gpu_lib, oracle, tmp_path, monkeypatch, kind, no_pin):
     s.set_tuning("row_fetch", 1)
     one = s.search_hits([q_long], 0.0, 5)
     assert one == [cases.oracle_results([ix], q_long, 0.0, 5)]
-    # the sharded search over a one-rank communicator: a ranged rank keeps rows, the ranks agree on that
+    # the sharded search over a one-rank communicator (its thresholded passes select on the device here too)
     comm = Comm(Comm.unique_id(), 0, 1, device=0)
     for t, lim in ((0.4, 0), (0.0, 3), (0.0, 0)):
         got = s.sharded_search_hits(comm, short, t, lim)
