@@ -17,7 +17,7 @@ SRC=$REPO/cobs_amd/csrc
 # device-side ASan and aborts on a plain gfx950 ("out of memory") -- the host code only needs the HIP host API
 RT=$(g++ -print-file-name=libasan.so)
 OBJS=""
-for f in engine plan geometry stage pass results host_api rank comm multi index_file documents build; do
+for f in engine plan geometry stage pass results host_api rank comm sharded multi index_file documents build; do
   g++ -O1 -g -std=c++17 -fPIC -fsanitize=address -fno-omit-frame-pointer -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include \
       -Wno-deprecated-declarations -c "$SRC/$f.cpp" -o "$W/$f.o" &
   OBJS="$OBJS $W/$f.o"
