@@ -391,7 +391,7 @@ class Search:
         bad = C.c_size_t(0)
         fn = self._lib.cobs_gpu_sharded_search_batch_split if split else self._lib.cobs_gpu_sharded_search_batch
         while True:
-            hits = np.empty(cap, dtype=self.HIT_DTYPE)
+            hits = self._result_buffer(cap)        # (a buffer of an earlier call that nothing references any more: its pages are there)
             offs[:] = 0
             st = fn(self._h, comm._h, arr, lens, nq, float(threshold), int(num_results),
                     C.cast(hits.ctypes.data, C.POINTER(Hit)), cap,

@@ -307,7 +307,9 @@ def test_row_range_chunks(gpu_lib, oracle, tmp_path, monkeypatch, kind, no_pin):
         for t, lim in ((0.0, 1), (0.0, 3), (0.0, 17), (0.3, 5), (0.0, 128)):
             b.run_topk(t, lim, keep_counts=False)
             b.sync()
-            if all(len(q) > 31 for q in qs_):        # (a query with a single hash in total is index order: such a batch keeps its rows)
+            # (a query with a single hash in total is index order: such a batch keeps its rows; and so does a pass whose
+            # candidate pool -- tiles x k entries of 8 bytes -- would be larger than the rows it replaces: k = 128 here)
+            if all(len(q) > 31 for q in qs_) and lim <= 17:
                 assert b.stats()["algorithmic_bytes"] == with_rows - len(qs_) * s.local_counts * b.counts_device()[1], "score rows were written"
             for i, q in enumerate(qs_):
                 assert b.hits_host(i, lim) == cases.oracle_results([ix], q, t, lim), (t, lim, i)
