@@ -175,6 +175,9 @@ struct GatherPage {
     uint32_t tpage;              // sub-index in the row-index table
     uint32_t leader;             // the page of this unit whose row list this page uses (column slices of one sub-index share it)
     uint32_t valid_bytes;        // row bytes of the slice (the rest of the pitch reads as zero)
+    uint64_t bm_off;             // leader pages: first word of the page's row bitmap (one bit per row of [row0, row0 + nrows)) ...
+    uint32_t bm_words;           // ... and its length in 32-bit words
+    uint32_t reserved;
 };
 struct GatherArgs {
     const uint8_t* file;         // device-visible address of the mapped index file
@@ -186,7 +189,10 @@ struct GatherArgs {
     PageDev* pages2;             // ... as the gathered buffer holds them (written here)
     uint8_t* dst;                // the gathered rows
     uint64_t* rowlist;           // [total slots] source row (relative to the page's row0) of every gathered row
-    unsigned long long* cursor;  // [npages], zeroed: slots handed out so far
+    unsigned long long* cursor;  // [npages]: DISTINCT looked-up rows of every leader page = slots in use (gather_rank_kernel)
+    uint32_t* bitmap;            // the leader pages' row bitmaps (zeroed): bit r = some entry looks up row r (gather_mark_kernel)
+    uint32_t* bprefix;           // same shape: set bits in front of every word -- a row's slot is bprefix + the bits below it
+    unsigned long long* fetched_bytes;   // accounting: += (distinct rows x pitch) of every page (what the unit asks of PCIe)
     uint64_t entries;            // table entries per sub-index: (blk_off[nq] + nq) * 8 * num_hashes
     uint64_t total_rows;         // gathered rows incl. the pages' zero rows
     uint64_t src_pitch;          // bytes between rows in the file

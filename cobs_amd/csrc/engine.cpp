@@ -781,7 +781,16 @@ cobs_gpu_status cobs_gpu_stream_traffic(const cobs_gpu_index* ix, uint64_t out[4
     if (!ix || !out) return fail(COBS_GPU_ERR_ARG, "NULL argument");
     out[0] = ix->stream.fetched_chunks;
     out[1] = ix->stream.streamed_chunks;
-    out[2] = ix->stream.fetched_bytes;
+    // the fetched units' bytes: distinct looked-up rows x pitch, counted by the gather itself (a row looked up by several
+    // terms of a batch crosses PCIe once since round 6)
+    out[2] = 0;
+    if (ix->stream.d_fetched.p) {
+        unsigned long long v = 0;
+        HIP_TRY(hipSetDevice(ix->device));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(&v, ix->stream.d_fetched.p, sizeof v, hipMemcpyDeviceToHost));
+        out[2] = v;
+    }
     out[3] = ix->stream.streamed_bytes;
     return COBS_GPU_OK;
 }

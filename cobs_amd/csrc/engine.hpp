@@ -221,14 +221,16 @@ struct StreamBufs {
     DevBuf<uint64_t> blk2[2];                 // ... its block offsets ...
     DevBuf<uint32_t> blkcnt[2];               // ... and the per-query block counts they are scanned from
     DevBuf<uint64_t> rowlist[2];              // source rows of the gathered rows in buffer i
-    DevBuf<unsigned long long> cursor[2];     // slot cursors of the gather, per page
+    DevBuf<unsigned long long> cursor[2];     // distinct looked-up rows of the gather's pages
+    DevBuf<uint32_t> bitmap[2], bprefix[2];   // row bitmaps of a unit's leader pages and the set bits in front of every word
+    DevBuf<unsigned long long> d_fetched;     // bytes the gathers of all passes so far asked of PCIe (distinct rows x pitch)
     DevBuf<GatherPage> gpages[2];
     PinnedBuf<GatherPage> h_gpages[2];
     DevBuf<unsigned long long> d_counts;      // look-up counters of the file being scanned (count_rows_kernel)
     PinnedBuf<unsigned long long> h_counts;
     hipEvent_t hashed = nullptr;
     uint64_t fetched_chunks = 0, streamed_chunks = 0;   // diagnostics: how the chunks of all passes were brought in
-    uint64_t fetched_bytes = 0, streamed_bytes = 0;     // ... and what that asked of PCIe: looked-up rows x pitch / the chunks' rows
+    uint64_t lookup_bytes = 0, streamed_bytes = 0;      // ... looked-up rows x pitch of the fetched units (with repeats) / the rows of the chunks copied whole
     uint64_t resident_bytes = 0;  // the plan: bytes of the streamed files' chunks that stay resident ...
     uint64_t pass_bytes = 0;      // ... and row bytes a pass that copies every other chunk whole moves over PCIe
     size_t stage_need = 0;

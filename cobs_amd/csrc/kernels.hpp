@@ -37,9 +37,10 @@ hipError_t launch_score_hist(const HistArgs& a, hipStream_t stream);
 
 // Row-selective out-of-core access (fetch_kernels.hip): one thread per (looked-up row, 16-byte piece).
 // count_rows: how many rows the batch looks up in every streamed piece of a part (one counter per piece);
-// gather: slots for exactly those rows of a unit's pages (gather_assign_kernel), then the rows themselves (gather_copy_kernel).
+// gather: slots for exactly the DISTINCT looked-up rows of a unit's pages, ascending (gather_mark / _rank / _assign / _list_kernel;
+// a.bitmap zeroed), then the rows themselves (gather_copy_kernel).
 hipError_t launch_count_rows(const CountArgs& a, uint64_t total_entries, bool idx64, hipStream_t stream);
-hipError_t launch_gather_assign(const GatherArgs& a, bool idx64, hipStream_t stream);
+hipError_t launch_gather_assign(const GatherArgs& a, bool idx64, uint32_t max_words, hipStream_t stream);
 // grid_limit: work-groups of the copy (a grid-stride loop): few when other kernels of the pass run beside it, see pass.cpp
 hipError_t launch_gather_copy(const GatherArgs& a, uint32_t grid_limit, hipStream_t stream);
 // Row-range chunks of a streamed sub-index (fetch_kernels.hip): rewrite the `entries` row indices of one sub-index for

@@ -566,7 +566,8 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                     HIP_TRY(sbufs.gpages[buf].reserve(np));
                     HIP_TRY(sbufs.cursor[buf].reserve(np));
                     GatherPage* gp = sbufs.h_gpages[buf].p;
-                    uint64_t slot = 0;
+                    uint64_t slot = 0, bm_words = 0;
+                    uint32_t bm_max = 0;
                     for (size_t k = 0; k < np; ++k) {
                         uint64_t cnt = by_bound[f] ? E : 0;       // (no count: a place for every table entry)
                         for (uint32_t j = 0; j < c.cp[k].second && !by_bound[f]; ++j) cnt += sbufs.h_counts.p[cnt_off[f] + c.cp[k].first + j];
@@ -585,9 +586,27 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                         for (size_t j = 0; j < k; ++j)       // column slices of one sub-index share the row list of the first
                             if (gp[j].tpage == gp[k].tpage && gp[j].row0 == gp[k].row0) { gp[k].leader = (uint32_t)j; break; }
                         gp[k].valid_bytes = c.pages[k].valid_bytes;
+                        // the row bitmap of a leader page (one bit per row of its range): the gather hands a slot to every
+                        // DISTINCT looked-up row -- `cnt`, the look-ups, bounds them and stays the page's capacity
+                        gp[k].bm_off = bm_words;
+                        gp[k].bm_words = 0;
+                        gp[k].reserved = 0;
+                        if (gp[k].leader == (uint32_t)k) {
+                            const uint64_t w = (gp[k].nrows + 31u) / 32u;
+                            if (w > 0xFFFFFFF0ull) return fail(COBS_GPU_ERR_UNSUPPORTED, "sub-index too large for a row-selective fetch");
+                            gp[k].bm_words = (uint32_t)w;
+                            bm_words += w;
+                            bm_max = std::max(bm_max, (uint32_t)w);
+                        }
                         slot += cnt + 1;
                     }
                     HIP_TRY(sbufs.rowlist[buf].reserve((size_t)slot));
+                    HIP_TRY(sbufs.bitmap[buf].reserve((size_t)std::max<uint64_t>(bm_words, 1)));
+                    HIP_TRY(sbufs.bprefix[buf].reserve((size_t)std::max<uint64_t>(bm_words, 1)));
+                    if (!sbufs.d_fetched.p) {
+                        HIP_TRY(sbufs.d_fetched.reserve(1));
+                        HIP_TRY(hipMemset(sbufs.d_fetched.p, 0, sizeof(unsigned long long)));
+                    }
                     // (the slot assignment on its own stream: it overlaps the copy of the previous unit -- 1.1 ms of table walking per
                     // unit beside 3.6-4.2 ms of waiting for PCIe, profiles/r05_out_of_core_kernel_stats.csv; the last scan that read
                     // this buffer's second table has finished: the host waited for scanned[buf] above)
@@ -600,6 +619,7 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                     hipStream_t prep = own_prep ? sbufs.prep_stream : sbufs.copy_stream;
                     HIP_TRY(hipMemcpyAsync(sbufs.gpages[buf].p, gp, np * sizeof(GatherPage), hipMemcpyHostToDevice, prep));
                     HIP_TRY(hipMemsetAsync(sbufs.cursor[buf].p, 0, np * sizeof(unsigned long long), prep));
+                    HIP_TRY(hipMemsetAsync(sbufs.bitmap[buf].p, 0, (size_t)bm_words * sizeof(uint32_t), prep));
                     GatherArgs ga;
                     ga.file = p.file_dev;
                     ga.table = b->work[f].table.p;
@@ -611,6 +631,9 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                     ga.dst = sbufs.sbuf[buf].p;
                     ga.rowlist = sbufs.rowlist[buf].p;
                     ga.cursor = sbufs.cursor[buf].p;
+                    ga.bitmap = sbufs.bitmap[buf].p;
+                    ga.bprefix = sbufs.bprefix[buf].p;
+                    ga.fetched_bytes = sbufs.d_fetched.p;
                     ga.entries = E;
                     ga.total_rows = slot;
                     ga.src_pitch = p.meta.page_row_bytes();
@@ -619,7 +642,7 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                     ga.table_npages = p.num_tpages();
                     ga.num_hashes = (uint32_t)p.meta.num_hashes;
                     ga.pitch = c.pitch;
-                    HIP_TRY(launch_gather_assign(ga, p.idx64, prep));
+                    HIP_TRY(launch_gather_assign(ga, p.idx64, bm_max, prep));
                     if (own_prep) {
                         HIP_TRY(hipEventRecord(sbufs.assigned[buf], sbufs.prep_stream));
                         HIP_TRY(hipStreamWaitEvent(sbufs.copy_stream, sbufs.assigned[buf], 0));
@@ -636,7 +659,7 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                     unit_rows = slot - np;
                     unit_zero = gp[0].count;
                     ++sbufs.fetched_chunks;
-                    sbufs.fetched_bytes += (slot - np) * (uint64_t)c.pitch;
+                    sbufs.lookup_bytes += (slot - np) * (uint64_t)c.pitch;       // (what crosses PCIe: the DISTINCT rows, counted on the device)
                 } else {
                     cobs_gpu_status cs = stream_chunk_in(ix, p, c, buf);
                     if (cs != COBS_GPU_OK) return cs;

@@ -428,3 +428,50 @@ def test_fetched_row_ranges_share_a_scan_and_any_buffer_size_fetches(gpu_lib, or
             for i, q in enumerate(queries):
                 assert np.array_equal(b.counts_host(i), ix.counts(q)), (fetch, compact, i)
             assert s.search_hits(queries[:6], 0.5, 3) == [cases.oracle_results([ix], q, 0.5, 3) for q in queries[:6]]
+
+
+def test_a_row_looked_up_twice_crosses_pcie_once(gpu_lib, oracle, tmp_path, monkeypatch):
+    """round 6: the row-selective fetch hands a slot of the gathered buffer to every DISTINCT looked-up row (a bitmap per
+    page, ranked: gather_mark / _rank / _assign / _list_kernel), in ascending row order -- until then a row that several
+    terms of a batch look up crossed PCIe once per look-up (17 % of the bytes of the 184 GB pass).  A batch that repeats
+    its queries asks PCIe for exactly the bytes of the batch without the repeats (cobs_gpu_stream_traffic: counted by the
+    gather on the device), and for no more than the DISTINCT rows of its terms (the checker's own row numbers); counts,
+    thresholds and limits equal the oracle's, over whole sub-indexes, row ranges and column slices (H = 2)."""
+    monkeypatch.setenv("COBS_GPU_ROW_RANGE_MIN", "48")
+    monkeypatch.setenv("COBS_GPU_STREAM_BUF_KIB", "512")
+    q_long = oracle.random_sequence(900, 1234)
+    base = [q_long[i * 11:i * 11 + 300] for i in range(12)]          # overlapping windows: shared k-mers = shared rows
+    for H, sigs, budget in ((1, [2000, 40009, 3000], 1500 * 1024), (2, [2000, 9001, 3000], 900 * 1024)):
+        ps = 96
+        D = 3 * 8 * ps - 7
+        path = cases.make_compact(cases.tmp(tmp_path, "dd%d.cobs_compact" % H), D, ps, sigs, H, 31, 1, 0.3, 21 + H,
+                                  planted={0: 1.0, 8 * ps + 3: 0.95, D - 1: 0.85}, query=q_long)
+        ix = oracle.Index.open(path)
+        s = gpu_lib.Search(path, hbm_budget=budget)
+        b = gpu_lib.Batch(s)
+
+        def traffic(qs):
+            b.set_queries(qs)
+            t0, f0 = s.stream_traffic(), s.stream_counters()
+            b.run(0.0)
+            b.sync()
+            t1, f1 = s.stream_traffic(), s.stream_counters()
+            for i, q in enumerate(qs):
+                assert np.array_equal(b.counts_host(i), ix.counts(q)), (H, i)
+            return t1[2] - t0[2], f1[0] - f0[0], f1[1] - f0[1]
+
+        once, fetched, whole = traffic(base)
+        assert fetched > 0 and once > 0
+        again, fetched3, _ = traffic(base * 3)
+        if fetched3 == fetched:          # (the same units came in by rows: the repeats cost PCIe nothing)
+            assert again == once, (H, once, again)
+        # no more than the distinct (sub-index, row) pairs of the batch, at the widest pitch of the file
+        rows = set()
+        for q in base:
+            hs, _good = oracle.term_hashes(q, 31, 1, H)
+            for p, S in enumerate(sigs):
+                rows.update((p, int(h) % S) for h in hs.reshape(-1))
+        assert once <= len(rows) * 128, (H, once, len(rows))
+        for t, lim in ((0.0, 4), (0.5, 0), (0.0, 0)):
+            assert s.search_hits(base * 2, t, lim) == [cases.oracle_results([ix], q, t, lim) for q in base * 2], (H, t, lim)
+        del b, s
