@@ -321,6 +321,8 @@ struct cobs_gpu_batch {
     bool have_counts = false;         // the last run wrote the score rows
     double threshold = 0.0;
     uint32_t h_flags[4] = {0, 0, 0, 0};
+    cobs_amd::PinnedBuf<uint32_t> h_flags_pin;   // host-buffer passes: the flag words land here right behind the pass's kernels ...
+    bool flags_landing = false;                  // ... (queued: `done` follows them)
     uint64_t h_nhits() const { return (uint64_t)h_flags[3] << 32 | h_flags[2]; }
     std::vector<cobs_amd::HitDev> h_hits;       // pool copy, sorted by query
     std::vector<size_t> h_hit_off;

@@ -40,6 +40,7 @@ static cobs_gpu_status host_pass_begin(cobs_gpu_index* ix, int slot, const char*
         HIP_TRY(hipEventCreateWithFlags(&ix->scratch[slot]->done, hipEventDisableTiming));
     }
     cobs_gpu_batch* b = ix->scratch[slot];
+    b->flags_landing = false;
     ix->host_passes++;
     double t0 = now_s();
     size_t bad_local = 0;
@@ -207,13 +208,35 @@ static cobs_gpu_status host_pass_begin(cobs_gpu_index* ix, int slot, const char*
     st = run_impl(b, threshold, topk, b->own_stream, !hits_only);
     b->scan_after = nullptr;
     if (st != COBS_GPU_OK) return st;
+    // the pass's flag words (first invalid query, hit-pool fill) land in pinned memory right behind its kernels, `done`
+    // after them: collecting the pass waits for THAT event, not for the stream -- with early_rank the ordering kernels of
+    // the pass are queued on the same stream next, and cobs_gpu_batch_sync used to wait for them too before the first
+    // piece could be expanded (the sharded call, which waits for the scan's event only, answered the default call of 256
+    // queries in 2.88 ms against 3.17 here: profiles/r06_latency.txt)
+    HIP_TRY(b->h_flags_pin.reserve(4));
+    HIP_TRY(hipMemcpyAsync(b->h_flags_pin.p, b->flags.p, 16, hipMemcpyDeviceToHost, b->own_stream));
+    b->flags_landing = true;
     HIP_TRY(hipEventRecord(b->done, b->own_stream));
     return COBS_GPU_OK;
 }
 
 static cobs_gpu_status host_pass_end(cobs_gpu_index* ix, int slot, double threshold, size_t topk, size_t* bad_query) {
     cobs_gpu_batch* b = ix->scratch[slot];
-    cobs_gpu_status st = cobs_gpu_batch_sync(b, b->own_stream, bad_query);
+    cobs_gpu_status st;
+    if (b->flags_landing) {
+        b->flags_landing = false;
+        HIP_TRY(hipEventSynchronize(b->done));
+        std::memcpy(b->h_flags, b->h_flags_pin.p, sizeof b->h_flags);
+        b->synced = true;
+        st = COBS_GPU_OK;
+        if (b->h_flags[0] != 0u) {           // K1 keeps 2^32-1 - (first query with a non-ACGT character)
+            if (bad_query) *bad_query = 0xFFFFFFFFu - b->h_flags[0];
+            st = fail(COBS_GPU_ERR_INVALID_BASE, "Invalid DNA base pair in query string. Only ACGT are allowed. (query " +
+                                                 std::to_string(0xFFFFFFFFu - b->h_flags[0]) + ")");
+        }
+    } else {
+        st = cobs_gpu_batch_sync(b, b->own_stream, bad_query);
+    }
     if (st == COBS_GPU_OK && !b->have_counts && b->h_nhits() > b->hit_cap) {
         st = run_impl(b, threshold, topk, b->own_stream, true);
         if (st != COBS_GPU_OK) return st;

@@ -227,7 +227,7 @@ def watchdog_case(N):
             if r == N - 1 and i == 2:
                 time.sleep(1e6)             # this rank never enters the exchange of step 2
             run.step()
-            run._sync_all()
+            run.sb.sync()
 
     ts = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(N)]
     for t in ts:
