@@ -393,6 +393,17 @@ __device__ __forceinline__ void retire_pair(uint32_t (&pl)[4][NP], const uint32_
     }
 }
 
+// Half a block (generic-H row loop, round 6): four row words into planes 0..1 of one column word; the first half
+// leaves its carry into plane 2 ("fours") pending, the second half adds both fours into plane 2 and returns the eights.
+template <int NP>
+__device__ __forceinline__ uint32_t absorb4(uint32_t (&pl)[NP], uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) {
+    uint32_t t2a, t2b, f4;
+    csa(t2a, pl[0], pl[0], x0, x1);
+    csa(t2b, pl[0], pl[0], x2, x3);
+    csa(f4, pl[1], pl[1], t2a, t2b);
+    return f4;
+}
+
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <bool NT>
@@ -428,6 +439,14 @@ __device__ __forceinline__ void issue_rows(uint4 (&X)[8], const uint8_t* lane_ba
     X[5] = load_row<NT>(lane_base, i.b.y, pitch);
     X[6] = load_row<NT>(lane_base, i.b.z, pitch);
     X[7] = load_row<NT>(lane_base, i.b.w, pitch);
+}
+
+template <bool NT>
+__device__ __forceinline__ void issue_rows4(uint4 (&X)[4], const uint8_t* lane_base, uint32_t pitch, const uint4& i) {
+    X[0] = load_row<NT>(lane_base, i.x, pitch);
+    X[1] = load_row<NT>(lane_base, i.y, pitch);
+    X[2] = load_row<NT>(lane_base, i.z, pitch);
+    X[3] = load_row<NT>(lane_base, i.w, pitch);
 }
 
 __device__ __forceinline__ uint64_t u64_of(uint32_t lo, uint32_t hi) { return (uint64_t)hi << 32 | lo; }
@@ -704,7 +723,7 @@ __device__ __forceinline__ void tile_topk(const ScanArgs& a, const uint32_t (&pl
 // (the tile_topk instantiations of up to 10 planes are held to the 128 VGPRs of four waves per SIMD, like the
 // kernels whose epilogue they replace: the selection's masks would otherwise cost the multi-query ones a wave)
 template <int NP, int NW, bool H1, typename OutT, bool MQ, typename IdxT, bool LDSS = false, bool TK = false>
-__global__ __launch_bounds__(NW * 64, (TK && H1 && NP <= 10) ? 4 : 1) void scan_kernel(ScanArgs a) {
+__global__ __launch_bounds__(NW * 64, (((TK && H1) || (!H1 && sizeof(IdxT) == 4 && !LDSS)) && NP <= 10) ? 4 : 1) void scan_kernel(ScanArgs a) {
     // row loads stay temporal: non-temporal loads measured 18 % slower (they bypass the Infinity Cache)
     constexpr bool NT = false;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -897,8 +916,73 @@ __global__ __launch_bounds__(NW * 64, (TK && H1 && NP <= 10) ? 4 : 1) void scan_
                 retire_single<NP>(pl, ea);
             }
         }
+    } else if constexpr (sizeof(IdxT) == 4) {
+        // general H (aggregate_rows, reference classic_search.cpp:279-307: AND the H hash rows of each term, then count),
+        // 32-bit row indices -- in HALF blocks of four terms (round 6).  Whole blocks kept three 8-row register sets live
+        // (two in flight + the AND accumulator: 96 VGPRs beside 40 of planes), 189-215 VGPRs, two waves per SIMD; with
+        // four-row sets (48 VGPRs) these instantiations fit the 128 VGPRs of FOUR waves per SIMD like the H = 1 kernels:
+        // the same row bytes in flight per SIMD, twice the waves to hide a gather's latency behind.  The (block, half,
+        // hash) triples of a wave form one stream of sub-trips through the usual three-stage pipeline -- row indices of
+        // sub-trip s+2 | row loads of s+1 | AND / CSA of s; a block's first half folds into planes 0..1 and leaves its
+        // fours pending, the second half adds both fours into plane 2 and ripples the eights.
+        if (nw > 0) {
+            uint4 XA[4], XB[4], ACC[4];
+            uint32_t f4a[4] = {0u, 0u, 0u, 0u};
+            const uint32_t total = nw * H * 2u;        // (even: the pipeline below always ends on a pair)
+            uint32_t li = 0, lh = 0, lj = 0;           // (trip, half, hash) of the next index load
+            auto next_idx = [&]() -> uint4 {           // trips >= nw point at the padding block
+                const uint4 r = *reinterpret_cast<const uint4*>(tab + blk_of(li) + 8u * lj + 4u * lh);
+                if (++lj == H) { lj = 0; if (++lh == 2u) { lh = 0; ++li; } }
+                return r;
+            };
+            uint32_t cj = 0, ch = 0;                   // hash / half of the sub-trip being consumed
+            auto consume = [&](const uint4 (&X)[4]) {
+                if (cj == 0) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) ACC[t] = X[t];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { ACC[t].x &= X[t].x; ACC[t].y &= X[t].y; ACC[t].z &= X[t].z; ACC[t].w &= X[t].w; }
+                }
+                if (++cj == H) {
+                    cj = 0;
+                    const uint32_t g0 = absorb4<NP>(pl[0], ACC[0].x, ACC[1].x, ACC[2].x, ACC[3].x);
+                    const uint32_t g1 = absorb4<NP>(pl[1], ACC[0].y, ACC[1].y, ACC[2].y, ACC[3].y);
+                    const uint32_t g2 = absorb4<NP>(pl[2], ACC[0].z, ACC[1].z, ACC[2].z, ACC[3].z);
+                    const uint32_t g3 = absorb4<NP>(pl[3], ACC[0].w, ACC[1].w, ACC[2].w, ACC[3].w);
+                    if (ch == 0u) {
+                        f4a[0] = g0; f4a[1] = g1; f4a[2] = g2; f4a[3] = g3;
+                        ch = 1u;
+                    } else {
+                        const uint32_t g[4] = {g0, g1, g2, g3};
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            uint32_t e8;
+                            csa(e8, pl[w][2], pl[w][2], f4a[w], g[w]);
+                            ripple<NP, 3>(pl[w], e8);
+                        }
+                        ch = 0u;
+                    }
+                }
+            };
+            uint4 i0 = next_idx();
+            issue_rows4<NT>(XA, lane_base, pitch, i0);
+            uint4 i1 = next_idx();
+            uint32_t sidx = 0;
+            for (; sidx + 2 < total; sidx += 2) {
+                i0 = next_idx();
+                issue_rows4<NT>(XB, lane_base, pitch, i1);
+                consume(XA);
+                i1 = next_idx();
+                issue_rows4<NT>(XA, lane_base, pitch, i0);
+                consume(XB);
+            }
+            issue_rows4<NT>(XB, lane_base, pitch, i1);
+            consume(XA);
+            consume(XB);
+        }
     } else {
-        // general H: AND the H hash rows of each term first (aggregate_rows), then count.
+        // general H, 64-bit row indices (a sub-index of 2^32 - 1 rows or more): whole blocks.
         // The (block, hash) pairs of a wave form one stream of "sub-trips" that runs through the
         // same three-stage pipeline as the H = 1 loop -- row indices of sub-trip s+2 | row loads of
         // s+1 | AND / CSA of s -- so that 8..16 rows are always in flight (the first version
