@@ -5,5 +5,5 @@ set -eu
 HERE=$(cd "$(dirname "$0")" && pwd)
 REPO=$(cd "$HERE/../.." && pwd)
 g++ -O1 -g -std=c++17 -fPIC -shared -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Wall -Wno-deprecated-declarations \
-    "$HERE/mock_rccl.cpp" -o "$REPO/cobs_amd/libmockrccl.so" -L/opt/rocm/lib -lamdhip64 -lpthread -Wl,-rpath,/opt/rocm/lib
+    "$HERE/mock_rccl.cpp" -o "$REPO/cobs_amd/libmockrccl.so" -L/opt/rocm/lib -lamdhip64 -lpthread -ldl -Wl,-rpath,/opt/rocm/lib
 echo "built cobs_amd/libmockrccl.so"

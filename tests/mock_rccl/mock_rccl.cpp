@@ -23,6 +23,7 @@
 // Semantics kept: operations are stream-ordered (the mock synchronises the stream it is given, exchanges, and
 // returns; later work on that stream sees the data), in-place operation (sendbuff inside recvbuff) is allowed, a
 // group's sends and receives complete together at ncclGroupEnd.
+#include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
@@ -166,8 +167,54 @@ ncclResult_t exchange(ncclComm* c, Posted&& mine, Take take) {
 
 }  // namespace
 
+// ---- virtual device ordinals (round 6) ----
+// With MOCK_RCCL_VIRTUAL_DEVICES=N in the environment the process sees N HIP devices -- all of them the one GPU of
+// the box: hipGetDeviceCount answers N, hipSetDevice(d) remembers d for the calling thread and selects device 0,
+// hipGetDevice answers the thread's d, hipDeviceGetPCIBusId answers for device 0.  Preloaded, these definitions come
+// before libamdhip64's for the SHIPPED libcobs_gpu.so, whose device-list handle (multi.cpp) then runs with ordinals
+// 0 .. N-1 as it does on an N-GPU node: the range and duplicate checks of cobs_gpu_multi_open, a communicator and an index
+// handle per ordinal, every hipSetDevice(ix->device) of the pass / exchange / ranking code with an ordinal other than 0,
+// the NUMA look-up of the ranking's host threads (until now every rank of the stand-in was "device 0").
+static int virtual_devices() {
+    static const int n = [] { const char* e = getenv("MOCK_RCCL_VIRTUAL_DEVICES"); return e ? atoi(e) : 0; }();
+    return n;
+}
+static thread_local int t_virtual_device = 0;
+template <typename F>
+static F real_hip(const char* name) {
+    static_assert(sizeof(F) == sizeof(void*), "function pointer");
+    void* p = dlsym(RTLD_NEXT, name);
+    if (!p) { std::fprintf(stderr, "[mock rccl] no %s behind the stand-in\n", name); std::abort(); }
+    F f;
+    std::memcpy(&f, &p, sizeof f);
+    return f;
+}
 extern "C" {
 
+// ---- virtual device ordinals: the HIP entry points the stand-in answers itself (see above the extern "C" block) ----
+hipError_t hipGetDeviceCount(int* count) {
+    static auto real = real_hip<hipError_t (*)(int*)>("hipGetDeviceCount");
+    const hipError_t e = real(count);
+    if (e == hipSuccess && virtual_devices() > 0 && count && *count > 0) *count = virtual_devices();
+    return e;
+}
+hipError_t hipSetDevice(int d) {
+    static auto real = real_hip<hipError_t (*)(int)>("hipSetDevice");
+    if (virtual_devices() <= 0) return real(d);
+    if (d < 0 || d >= virtual_devices()) return hipErrorInvalidDevice;
+    t_virtual_device = d;
+    return real(0);
+}
+hipError_t hipGetDevice(int* d) {
+    static auto real = real_hip<hipError_t (*)(int*)>("hipGetDevice");
+    const hipError_t e = real(d);
+    if (e == hipSuccess && virtual_devices() > 0 && d) *d = t_virtual_device;
+    return e;
+}
+hipError_t hipDeviceGetPCIBusId(char* buf, int len, int d) {
+    static auto real = real_hip<hipError_t (*)(char*, int, int)>("hipDeviceGetPCIBusId");
+    return real(buf, len, virtual_devices() > 0 ? 0 : d);
+}
 // ---- test controls (symbols only this stand-in defines) ----
 // multi.cpp refuses a device that is listed twice unless this symbol exists in the process
 int mock_rccl_ranks_may_share_a_device = 1;

@@ -21,6 +21,12 @@ from oracle import oracle  # noqa: E402
 from tests import cases  # noqa: E402
 
 
+def DEVICES(n):
+    """the device list of the handle: ordinals 0 .. N-1 when the stand-in virtualises them (MOCK_RCCL_VIRTUAL_DEVICES, all of
+    them the one GPU), else N times device 0 (the stand-in's marker symbol lets ranks share a device)"""
+    return list(range(n)) if int(os.environ.get("MOCK_RCCL_VIRTUAL_DEVICES", "0")) >= n else [0] * n
+
+
 def main():
     N = int(sys.argv[1])
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -58,7 +64,7 @@ def main():
         if rng.random() < 0.3:
             budget = int(sum(os.path.getsize(p) for p in paths) * 0.7 / N) + 70000
         try:
-            s = cobs_amd.MultiSearch(paths if len(paths) > 1 else paths[0], [0] * N, hbm_budget=budget, shard_mode=mode)
+            s = cobs_amd.MultiSearch(paths if len(paths) > 1 else paths[0], DEVICES(N), hbm_budget=budget, shard_mode=mode)
         except cobs_amd.CobsGpuError as e:
             assert budget and e.status == _capi.ERR_CAPACITY, (paths, budget, e)
             continue
@@ -101,7 +107,7 @@ def main():
         nq = 260 * N
         queries = [q_long[o:o + int(n)] for o, n in zip(rng.integers(0, 200, size=nq), rng.choice([40, 60, 100, 300], size=nq))]
         ix = oracle.Index.open(path)
-        s = cobs_amd.MultiSearch(path, [0] * N)
+        s = cobs_amd.MultiSearch(path, DEVICES(N))
         for t, lim in ((0.01, 0), (0.0, 0)):
             want = [cases.oracle_results([ix], q, t, lim) for q in queries]
             assert sum(len(w) for w in want) > N * (1 << 20)

@@ -37,6 +37,27 @@ def test_device_list_handle_over_n_ranks_sharing_the_gpu(mock_library, ranks):
     assert "[mock rccl]" not in r.stderr, r.stderr[-6000:]
 
 
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_device_list_handle_with_distinct_device_ordinals(mock_library, ranks):
+    """round 6: the same, with the stand-in virtualising the device ordinals
+    (MOCK_RCCL_VIRTUAL_DEVICES: hipGetDeviceCount answers N, hipSetDevice(d) selects the one GPU and remembers d for the
+    thread) -- cobs_gpu_multi_open with devices [0, 1, .., N-1] as on an N-GPU node: the range and duplicate checks,
+    one communicator and one index handle per ordinal, every hipSetDevice(ix->device) of the pass / exchange / ranking
+    code with an ordinal other than 0.  An ordinal beyond the count is refused before any rank meets another."""
+    env = dict(os.environ, LD_PRELOAD=mock_library, MOCK_RCCL_VIRTUAL_DEVICES=str(ranks))
+    seed = os.environ.get("COBS_FUZZ_SEED", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mock_rccl", "run_ranks.py"), str(ranks), seed],
+                       capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0 and r.stdout.strip().startswith("ok "), r.stdout[-3000:] + r.stderr[-6000:]
+    assert "[mock rccl]" not in r.stderr, r.stderr[-6000:]
+    code = ("import sys; sys.path.insert(0, %r); import cobs_amd\n"
+            "try:\n    cobs_amd.MultiSearch(%r, [0, %d])\n    print('opened')\n"
+            "except cobs_amd.CobsGpuError as e:\n    print('refused', e.status, e)\n") % (
+                ROOT, os.path.join(ROOT, "tests", "golden", "c1.cobs_compact"), ranks)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert "refused 7" in r.stdout and "out of range" in r.stdout, r.stdout + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("ranks", [2, 3, 5])
 def test_batch_exchange_entry_points_over_n_ranks(mock_library, ranks):
     """cobs_gpu_batch_exchange_counts (all-gather / all-to-all to query owners / all-reduce), _exchange_hits,
