@@ -45,6 +45,11 @@ ScanGeom scan_geometry(const Chunk& c, uint64_t mean_blocks, uint64_t max_blocks
         g.tile_w = 16;
         g.nwaves = std::min(4, g.nwaves * 2);
     }
+    // The generic-H row loop works in half blocks since round 6 (kernels.hip): its one- and two-wave instantiations fit the
+    // 128 VGPRs of four waves per SIMD (123-125 at 10 planes; 133-149 above: three), the four-wave one does not without
+    // spilling into its row loop (45 ms against 22.3 for C3 with three hash functions).  Two waves per group cost a long
+    // query nothing: 22.32 ms with two, 22.34 with one (profiles/r06_generic_h_ab.txt).
+    if (num_hashes > 1 && !idx64) g.nwaves = std::min(g.nwaves, 2);
     if (g.tile_w < 16) {
         // when even the largest sub-index fits the Infinity Cache with 256-byte slices, 16-chunk
         // tiles win (half the merge/expand work; C2: 7.3 vs 6.8 TB/s); otherwise 128-byte slices

@@ -721,9 +721,11 @@ __device__ __forceinline__ void tile_topk(const ScanArgs& a, const uint32_t (&pl
 // instantiations, so that the kernels that write scores keep their register budget (as a run-time branch
 // it cost the 100-bp multi-query kernel its fourth wave per SIMD: 126 -> 131 VGPRs).
 // (the tile_topk instantiations of up to 10 planes are held to the 128 VGPRs of four waves per SIMD, like the
-// kernels whose epilogue they replace: the selection's masks would otherwise cost the multi-query ones a wave)
+// kernels whose epilogue they replace: the selection's masks would otherwise cost the multi-query ones a wave;
+// so are the generic-H instantiations of one and two waves per group, whose half-block row loop fits them -- the
+// four-wave one would spill in that loop and is left to the compiler: geometry.cpp does not choose it)
 template <int NP, int NW, bool H1, typename OutT, bool MQ, typename IdxT, bool LDSS = false, bool TK = false>
-__global__ __launch_bounds__(NW * 64, (((TK && H1) || (!H1 && sizeof(IdxT) == 4 && !LDSS)) && NP <= 10) ? 4 : 1) void scan_kernel(ScanArgs a) {
+__global__ __launch_bounds__(NW * 64, (((TK && H1) || (!H1 && sizeof(IdxT) == 4 && !LDSS && (NW <= 2 || TK))) && NP <= 10) ? 4 : 1) void scan_kernel(ScanArgs a) {
     // row loads stay temporal: non-temporal loads measured 18 % slower (they bypass the Infinity Cache)
     constexpr bool NT = false;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
