@@ -197,6 +197,7 @@ struct GatherArgs {
     uint64_t total_rows;         // gathered rows incl. the pages' zero rows
     uint64_t src_pitch;          // bytes between rows in the file
     uint32_t nq, npages, table_npages, num_hashes, pitch;
+    uint32_t exp;                // experimental variants of the copy under A/B measurement (COBS_GPU_GATHER_EXP: 1 = non-temporal loads, 2 = two pieces per thread in flight)
 };
 
 // Arguments of the top-k selection kernel K3 for one index file.

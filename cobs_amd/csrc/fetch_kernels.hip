@@ -39,10 +39,15 @@ namespace cobs_amd {
 namespace {
 
 // 16 bytes from an arbitrarily aligned address, reading only aligned dwords that hold wanted bytes
+template <bool NT = false>
 __device__ __forceinline__ uint4 load16_any(const uint8_t* p, uint32_t nvalid) {
     const uint32_t mis = (uint32_t)((uintptr_t)p & 3u);
     const uint32_t* w = reinterpret_cast<const uint32_t*>(p - mis);
-    if (mis == 0u && nvalid == 16u && ((uintptr_t)p & 15u) == 0u) return *reinterpret_cast<const uint4*>(p);
+    if (mis == 0u && nvalid == 16u && ((uintptr_t)p & 15u) == 0u) {
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        if (NT) { const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p)); return make_uint4(v.x, v.y, v.z, v.w); }
+        return *reinterpret_cast<const uint4*>(p);
+    }
     uint32_t r[5];
 #pragma unroll
     for (uint32_t j = 0; j < 5; ++j) r[j] = (4u * j < mis + nvalid) ? w[j] : 0u;
@@ -208,7 +213,8 @@ __global__ __launch_bounds__(256) void gather_list_kernel(GatherArgs a) {
 
 // One thread per (gathered row, 16-byte piece): the row's pieces on consecutive lanes, read over PCIe straight from the
 // registered mapping of the index file (unaligned sources -- classic rows at odd file offsets -- through aligned dwords).
-__device__ __forceinline__ void gather_copy_piece(const GatherArgs& a, uint32_t cpp, uint64_t gid) {
+struct CopyPiece { const uint8_t* src; uint8_t* out; uint32_t nvalid; bool store; };
+__device__ __forceinline__ CopyPiece gather_copy_plan(const GatherArgs& a, uint32_t cpp, uint64_t gid) {
     const uint64_t g = gid / cpp;                          // gathered row
     const uint32_t c = (uint32_t)(gid - g * cpp);
     uint32_t lo = 0, hi = a.npages;                        // its page: the last i with slot0[i] <= g
@@ -218,7 +224,13 @@ __device__ __forceinline__ void gather_copy_piece(const GatherArgs& a, uint32_t 
     }
     const GatherPage pg = a.pages[lo];
     const uint64_t local = g - pg.slot0;
-    uint8_t* out = a.dst + g * a.pitch + (uint64_t)c * 16u;
+    CopyPiece p;
+    p.out = a.dst + g * a.pitch + (uint64_t)c * 16u;
+    p.src = nullptr;
+    p.nvalid = 0;
+    // rows [0, distinct rows) are gathered rows, row `count` is the page's zero row; the counts bound the distinct rows
+    // (a capacity per page), the rows in between are never named
+    const uint64_t have = a.cursor[pg.leader];
     if (local == 0u && c == 0u) {                          // the page as the gathered buffer holds it
         PageDev d = a.pages_in[lo];
         d.base = pg.slot0 * a.pitch;
@@ -226,19 +238,24 @@ __device__ __forceinline__ void gather_copy_piece(const GatherArgs& a, uint32_t 
         d.magic = 0;
         d.row0 = 0;
         a.pages2[lo] = d;
-        if (a.fetched_bytes) atomicAdd(a.fetched_bytes, (unsigned long long)min(a.cursor[pg.leader], (unsigned long long)pg.count) * a.pitch);
+        if (a.fetched_bytes) atomicAdd(a.fetched_bytes, (unsigned long long)min(have, (unsigned long long)pg.count) * a.pitch);
     }
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    // rows [0, handed-out slots) are gathered rows, row `count` is the page's zero row; with exact counts the two meet,
-    // with a capacity per page (small batches: a place for every table entry) the rows in between are never named
-    const uint64_t have = a.cursor[pg.leader];
-    if (local != pg.count && local >= have) return;
+    p.store = local == pg.count || local < have;
     if (local < have && local < pg.count) {
         const uint64_t r = a.rowlist[a.pages[pg.leader].slot0 + local];
-        const uint32_t nvalid = pg.valid_bytes > c * 16u ? min(pg.valid_bytes - c * 16u, 16u) : 0u;
-        if (nvalid) v = load16_any(a.file + pg.src + r * a.src_pitch + (uint64_t)c * 16u, nvalid);
+        p.nvalid = pg.valid_bytes > c * 16u ? min(pg.valid_bytes - c * 16u, 16u) : 0u;
+        p.src = a.file + pg.src + r * a.src_pitch + (uint64_t)c * 16u;
     }
-    *reinterpret_cast<uint4*>(out) = v;
+    return p;
+}
+template <bool NT>
+__device__ __forceinline__ uint4 gather_copy_load(const CopyPiece& p) {
+    return p.nvalid ? load16_any<NT>(p.src, p.nvalid) : make_uint4(0u, 0u, 0u, 0u);
+}
+__device__ __forceinline__ void gather_copy_piece(const GatherArgs& a, uint32_t cpp, uint64_t gid) {
+    const CopyPiece p = gather_copy_plan(a, cpp, gid);
+    if (!p.store) return;
+    *reinterpret_cast<uint4*>(p.out) = (a.exp & 1u) ? gather_copy_load<true>(p) : gather_copy_load<false>(p);
 }
 
 // A BOUNDED grid with a grid-stride loop: the kernel waits for PCIe (a few MB in flight saturate the link), and a grid of
@@ -247,8 +264,17 @@ __device__ __forceinline__ void gather_copy_piece(const GatherArgs& a, uint32_t 
 __global__ __launch_bounds__(256) void gather_copy_kernel(GatherArgs a) {
     const uint32_t cpp = a.pitch / 16u;
     const uint64_t items = a.total_rows * cpp;
-    for (uint64_t gid = (uint64_t)blockIdx.x * 256u + threadIdx.x; gid < items; gid += (uint64_t)gridDim.x * 256u)
-        gather_copy_piece(a, cpp, gid);
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    uint64_t gid = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (a.exp & 2u) {
+        for (; gid + stride < items; gid += 2u * stride) {          // two pieces per thread in flight over PCIe
+            const CopyPiece p0 = gather_copy_plan(a, cpp, gid), p1 = gather_copy_plan(a, cpp, gid + stride);
+            const uint4 v0 = gather_copy_load<false>(p0), v1 = gather_copy_load<false>(p1);
+            if (p0.store) *reinterpret_cast<uint4*>(p0.out) = v0;
+            if (p1.store) *reinterpret_cast<uint4*>(p1.out) = v1;
+        }
+    }
+    for (; gid < items; gid += stride) gather_copy_piece(a, cpp, gid);
 }
 
 // Row-range chunk, streamed whole: K1's row indices of its sub-index, rewritten for a buffer that holds rows

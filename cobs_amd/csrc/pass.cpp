@@ -642,6 +642,8 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                     ga.table_npages = p.num_tpages();
                     ga.num_hashes = (uint32_t)p.meta.num_hashes;
                     ga.pitch = c.pitch;
+                    static const uint32_t gather_exp = getenv("COBS_GPU_GATHER_EXP") ? (uint32_t)std::strtoul(getenv("COBS_GPU_GATHER_EXP"), nullptr, 0) : 0u;   // (A/B)
+                    ga.exp = gather_exp;
                     HIP_TRY(launch_gather_assign(ga, p.idx64, bm_max, prep));
                     if (own_prep) {
                         HIP_TRY(hipEventRecord(sbufs.assigned[buf], sbufs.prep_stream));
