@@ -642,7 +642,9 @@ cobs_gpu_status cobs_amd::run_impl(cobs_gpu_batch* b, double threshold, size_t t
                     ga.table_npages = p.num_tpages();
                     ga.num_hashes = (uint32_t)p.meta.num_hashes;
                     ga.pitch = c.pitch;
-                    static const uint32_t gather_exp = getenv("COBS_GPU_GATHER_EXP") ? (uint32_t)std::strtoul(getenv("COBS_GPU_GATHER_EXP"), nullptr, 0) : 0u;   // (A/B)
+                    // (two pieces per thread in flight over PCIe: 801 / 798 ms against 817 / 818 per 184 GB pass on one box, with
+                    // non-temporal loads 822: profiles/r06_gather_blocks_ab.txt; COBS_GPU_GATHER_EXP is the A/B switch)
+                    static const uint32_t gather_exp = getenv("COBS_GPU_GATHER_EXP") ? (uint32_t)std::strtoul(getenv("COBS_GPU_GATHER_EXP"), nullptr, 0) : 2u;
                     ga.exp = gather_exp;
                     HIP_TRY(launch_gather_assign(ga, p.idx64, bm_max, prep));
                     if (own_prep) {

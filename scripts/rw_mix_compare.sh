@@ -1,10 +1,10 @@
 #!/bin/bash
 # scripts/rw_mix_compare.sh -- the read/write-mix probe and the scan kernel on the SAME box (boxes differ by +-4 %):
 # scripts/probes/rw_mix_probe (all waves / 32 / 16 waves per CU) next to bench.py's HIP-event scan times of the
-# shapes it models.  Output: gpurun_out/r03_rw_mix_compare.txt
+# shapes it models.  Output: $1 (default gpurun_out/rw_mix_compare.txt)
 set -u
-OUT=gpurun_out/r03_rw_mix_compare.txt
-mkdir -p gpurun_out
+OUT=${1:-gpurun_out/rw_mix_compare.txt}
+mkdir -p "$(dirname "$OUT")"
 [ -x scripts/probes/rw_mix_probe ] || hipcc --offload-arch=gfx950 -O3 scripts/probes/rw_mix_probe.hip -o scripts/probes/rw_mix_probe
 {
   for l in 0 5120 10240; do scripts/probes/rw_mix_probe $l | grep -v "anywhere\|gather only"; done
