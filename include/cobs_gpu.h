@@ -70,10 +70,11 @@ typedef struct cobs_gpu_options {
      * per chunk overlapping the next chunk's copy (the successor of the reference's
      * mmap / AIO back-ends, util/query.cpp:38-88, compact_index/aio_search_file.cpp).
      * A handle with row-range chunks counts such a sub-index range by range (partial
-     * scores are added up), so its passes always keep score rows: the hits-only and
-     * top-k-only runs and every search call give the same results, selected from the
-     * rows; cobs_gpu_batch_exchange_hits / _hits_owned are not available on it
-     * (cobs_gpu_sharded_search_batch takes the row exchange by itself). */
+     * scores are added up); a pass without score rows (hits only, a limit only) adds them
+     * up in a scratch matrix of the sub-index's own width and selects from that after the
+     * sub-index's last range, so such a handle behaves like any other: same results, the
+     * hit exchanges of cobs_gpu_batch.h included (round 6; it kept score rows of the whole
+     * index until then). */
     uint64_t hbm_budget_bytes;
 } cobs_gpu_options;
 

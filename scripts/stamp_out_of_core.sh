@@ -3,7 +3,7 @@
 # lives in plan.cpp / stage.cpp / pass.cpp, outside the kernels the traffic replay is keyed on), plus configs[4] at
 # its named size: a 184 GB file under a 64 GB budget.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=$(pwd)/gpurun_out/stamp_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -19,6 +19,10 @@ if [ "${2:-}" = "full" ]; then
   # (the box's /tmp is a 79 GB overlay; /dev/shm is tmpfs over its 3 TB of RAM)
   timeout 1500 python bench.py --config c5 --scale 10 --hbm-budget-gb 64 --index-file /dev/shm/cobs_c5_10.cobs_compact \
       --no-cpu-baseline --steps 2 --warmup 1 > "$OUT/c5_184GB_bench.json" 2> "$OUT/c5_184GB_bench.err"
+  # the same pass at the CLI's default threshold, hits only: the three streamed sub-indexes are counted in row ranges, the
+  # selection runs after each one's last range -- no score rows (round 6; rounds 4-5 wrote 2 GB of them per pass)
+  timeout 900 python bench.py --config c5 --scale 10 --hbm-budget-gb 64 --index-file /dev/shm/cobs_c5_10.cobs_compact \
+      --no-cpu-baseline --steps 2 --warmup 1 --threshold 0.8 --hits-only > "$OUT/c5_184GB_hits_bench.json" 2> /dev/null
   rm -f /dev/shm/cobs_c5_10.cobs_compact
 fi
 grep -h '"metric"' "$OUT"/c5*_bench.json | python -c "
