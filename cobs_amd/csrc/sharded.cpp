@@ -324,8 +324,7 @@ cobs_gpu_status sharded_search_impl(cobs_gpu_index* ix, cobs_gpu_comm* c, const 
             if (ps.pool) {
                 if ((s = event_bounded(c, x.x_done, "the exchange of the hit records")) != COBS_GPU_OK) return s;
                 if (ps.pool_host) {
-                    Exchange& xx = *b->xchg;
-                    s = order_pool(b, N == 1 ? b->hits.p : xx.hits_all.p, b->pool_n, xs);
+                    s = order_pool(b, N == 1 ? b->hits.p : x.hits_all.p, b->pool_n, xs);
                 } else {
                     s = order_pool_collect(b, nullptr, true);
                 }
