@@ -313,6 +313,20 @@ def test_row_range_chunks(gpu_lib, oracle, tmp_path, monkeypatch, kind, no_pin):
                 assert b.stats()["algorithmic_bytes"] == with_rows - len(qs_) * s.local_counts * b.counts_device()[1], "score rows were written"
             for i, q in enumerate(qs_):
                 assert b.hits_host(i, lim) == cases.oracle_results([ix], q, t, lim), (t, lim, i)
+    # 32-bit scores through the same accumulation and selection: one query of 66 000 terms (the reference's third Score
+    # width, classic_search.cpp:487-504) beside a short one
+    wide = [oracle.random_sequence(66030, 4242), q_long[:200]]
+    b.set_queries(wide)
+    assert b.counts_device()[1] == 4
+    for t in (0.28, 0.31):
+        b.run_hits(t)
+        b.sync()
+        for i, q in enumerate(wide):
+            assert b.hits_host(i) == cases.oracle_results([ix], q, t, 0), (t, i)
+    b.run_topk(0.0, 9, keep_counts=False)
+    b.sync()
+    for i, q in enumerate(wide):
+        assert b.hits_host(i, 9) == cases.oracle_results([ix], q, 0.0, 9), i
     # the hit exchanges of the multi-GPU layout take such a handle like any other (they refused it until round 6)
     xc = Comm(Comm.unique_id(), 0, 1, device=0)
     b.set_queries(short)
