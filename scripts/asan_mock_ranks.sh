@@ -1,0 +1,25 @@
+#!/bin/bash
+# scripts/asan_mock_ranks.sh [N ...] -- the multi-GPU host code (sharded.cpp, comm.cpp, multi.cpp: worker threads, the
+# pipeline of passes, the exchanges) under AddressSanitizer WITH more than one rank: the sanitized build of the library
+# (scripts/asan_engine.sh, built first) driven by tests/mock_rccl/run_ranks.py and run_batch_ranks.py over the
+# stand-in communicator, N thread-ranks on the one GPU (default N = 2 3; with virtual device ordinals for the first).
+# The sanitizer runtime is preloaded BEFORE the stand-in.   gpurun -- 'bash scripts/asan_mock_ranks.sh'
+set -u
+REPO=$(cd "$(dirname "$0")/.." && pwd)
+cd "$REPO"
+bash scripts/asan_engine.sh > /dev/null || exit 1
+bash tests/mock_rccl/build.sh > /dev/null || exit 1
+RT=$(g++ -print-file-name=libasan.so)
+export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0:halt_on_error=1
+export COBS_GPU_LIBRARY="$REPO/cobs_amd/libcobs_gpu_asan.so" MOCK_RCCL_TIMEOUT_S=60
+PRE="$RT $(g++ -print-file-name=libstdc++.so.6) $REPO/cobs_amd/libmockrccl.so"
+rc=0
+first=1
+for n in ${*:-2 3}; do
+  v=0; [ $first = 1 ] && v=$n; first=0
+  echo "== run_ranks.py $n (virtual device ordinals: $v)"
+  MOCK_RCCL_VIRTUAL_DEVICES=$v LD_PRELOAD="$PRE" timeout 1500 python tests/mock_rccl/run_ranks.py "$n" 0 2>&1 | tail -3 || rc=1
+  echo "== run_batch_ranks.py $n"
+  LD_PRELOAD="$PRE" timeout 1500 python tests/mock_rccl/run_batch_ranks.py "$n" 0 2>&1 | tail -3 || rc=1
+done
+exit $rc
