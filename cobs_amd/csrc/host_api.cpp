@@ -366,7 +366,9 @@ static cobs_gpu_status search_batch_impl(cobs_gpu_index* ix, const char* const* 
         }
         // a thresholded pass whose pool holds every hit: ordered on the device (results.cpp: order_pool), the finished
         // lists of ALL queries of the pass are copied in one sweep (round 4: one guarded call + one partial_sort per query)
-        if (!overflow && sb->selected && sb->topk_k == 0 && !sb->graph_run && sb->h_nhits() <= sb->hit_cap) {
+        // (not with a limit: a limit too large for K3 -- k > 65536 -- runs as a thresholded pass whose lists are cut per query
+        // below; until round 6 the sweep handed such a call every hit)
+        if (!overflow && sb->selected && sb->topk_k == 0 && topk == 0 && !sb->graph_run && sb->h_nhits() <= sb->hit_cap) {
             const double t0 = now_s();
             if (!sb->pool_fetched) {
                 st = order_pool(sb, sb->hits.p, sb->h_nhits(), sb->own_stream);

@@ -331,7 +331,8 @@ cobs_gpu_status sharded_search_impl(cobs_gpu_index* ix, cobs_gpu_comm* c, const 
                 if (s != COBS_GPU_OK) return s;
                 b->pool_global = true;
                 cobs_gpu_status hs = COBS_GPU_OK;
-                if (!overflow && hand_over_pool(b, ps.g0, ps.g1, &hits, &cap, &used, hit_offsets, nullptr, nq, &hs)) return COBS_GPU_OK;
+                // (one sweep for the whole pass -- unless the call has a limit, too large for K3, that cuts every list: below)
+                if (!overflow && topk == 0 && hand_over_pool(b, ps.g0, ps.g1, &hits, &cap, &used, hit_offsets, nullptr, nq, &hs)) return COBS_GPU_OK;
                 if (hs != COBS_GPU_OK) return hs;
             } else if (b->topk_k) {
                 if ((s = event_bounded(c, x.x_done, "the all-gather of the shards' best-of lists")) != COBS_GPU_OK) return s;

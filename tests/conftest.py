@@ -56,3 +56,12 @@ def gpu_lib():
     lib = _capi.load()
     assert lib.cobs_gpu_device_count() > 0, "no HIP device visible"
     return cobs_amd
+
+
+@pytest.fixture(scope="module")
+def comm_one_rank(gpu_lib):
+    """a one-rank RCCL communicator (the real library: what the multi-GPU entry points run over on a one-GPU box)"""
+    from cobs_amd.distributed import Comm
+    c = Comm(Comm.unique_id(), 0, 1, device=0)
+    yield c
+    c.close()

@@ -946,3 +946,24 @@ def test_a_thresholded_call_with_many_hits_is_not_run_twice(gpu_lib, oracle, tmp
     for i in range(5):
         want = [(f, d, sc) for (f, d, _n, sc) in oracle.search(ix, queries[i], 0.9, 0)]
         assert hits_w[int(offs_w[i]):int(offs_w[i + 1])].tolist() == want, i
+
+
+def test_a_limit_too_large_for_k3_with_a_threshold_cuts_every_list(gpu_lib, oracle, comm_one_rank):
+    """num_results beyond what K3 selects on the device (k > 65536) AND a threshold: the pass runs as a thresholded one
+    (hits into the pool, ordered on the device) and every query's list is cut at the limit -- counts_to_result's
+    `num_results = min(num_results, #passing)`, classic_search.cpp:133-147.  [Until round 6 the one-sweep hand-over of an
+    ordered pool returned every hit of such a call: found while the sharded call was given the same sweep.]  A procedural
+    index of 70 000 documents (70 sub-indexes), almost every document above a low threshold; the one-GPU call, the sharded
+    call on a one-rank communicator and the checker agree, with and without the limit."""
+    ps, P = 125, 70
+    D = P * 8 * ps - 11
+    sigs = [1009 + 2 * p for p in range(P)]
+    s = gpu_lib.Search.synthetic("compact", sigs, D, page_size=ps, seed=31)
+    ix = oracle.Index.synthetic(1, 31, 1, 1, ps, sigs, D, 31)
+    qs = [oracle.random_sequence(130, 500 + i) for i in range(3)]
+    for t, lim in ((0.05, 66000), (0.05, 0), (0.28, 66000), (0.0, 66000)):
+        want = [cases.oracle_results([ix], q, t, lim) for q in qs]
+        if (t, lim) == (0.05, 66000):
+            assert all(len(w) == 66000 for w in want)
+        assert s.search_hits(qs, t, lim) == want, (t, lim)
+        assert s.sharded_search_hits(comm_one_rank, qs, t, lim) == want, (t, lim, "sharded")
