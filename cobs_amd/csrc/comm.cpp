@@ -790,6 +790,10 @@ cobs_gpu_status xchg_hits_launch(cobs_gpu_batch* b, cobs_gpu_comm* c, hipStream_
     return COBS_GPU_OK;
 }
 
+// The shards' best-of lists: all-gathered, merged ON THE DEVICE into the global k best of every (file, query) -- K3's pool
+// mode over the lists laid side by side (merge_lists_kernel) --, and on their way into pinned memory.  [Until round 6
+// the N x k candidates of every (file, query) crossed PCIe and every query's list was merged by a host sort: ~0.5 us
+// per query at eight ranks, several times the 2.4 ms a rank scans for at N = 8.]
 cobs_gpu_status xchg_topk_launch(cobs_gpu_batch* b, cobs_gpu_comm* c, hipStream_t st) {
     HIP_TRY(hipSetDevice(b->ix->device));
     if (cobs_gpu_status us = comm_usable(c); us != COBS_GPU_OK) return us;
@@ -797,15 +801,50 @@ cobs_gpu_status xchg_topk_launch(cobs_gpu_batch* b, cobs_gpu_comm* c, hipStream_
     Exchange& x = *b->xchg;
     const size_t N = (size_t)c->nranks, k = b->topk_k, nq = b->nq, np = b->ix->parts.size();
     const size_t ne = k * nq * np, nc = nq * np;
+    const size_t stride = (size_t)round_up(N * k, 8);
+    if (N * k > 0xFFFFFFF0ull) return fail(COBS_GPU_ERR_UNSUPPORTED, "too many candidates per query");
     HIP_TRY(x.topk_all.reserve(std::max<size_t>(N * ne, 1)));
     HIP_TRY(x.topk_cnt_all.reserve(std::max<size_t>(N * nc, 1)));
+    HIP_TRY(x.topk_merge.reserve(std::max<size_t>(nc * stride, 1)));
+    HIP_TRY(x.topk_final.reserve(std::max<size_t>(ne, 1)));
+    HIP_TRY(x.topk_final_cnt.reserve(std::max<size_t>(nc, 1)));
+    // (the device merge cuts ties at the k-th score by POSITION, which is document order only where every shard's list is
+    // ordered: k up to kTopkSortLimit.  Beyond that the lists travel home as they are and the host sorts: merged = false)
+    x.topk_merged = k <= kTopkSortLimit;
     // (pinned landing: a copy to pageable memory would wait for the stream -- for the collective -- inside the runtime)
-    HIP_TRY(x.h_topk.reserve(std::max<size_t>(N * ne * sizeof(uint2) + N * nc * 4, 16)));
+    HIP_TRY(x.h_topk.reserve(std::max<size_t>((x.topk_merged ? 1 : N) * (ne * sizeof(uint2) + nc * 4), 16)));
     if (ne) NCCL_C(c, st, ncclAllGather(b->topk_out.p, x.topk_all.p, ne * sizeof(uint2), ncclUint8, c->comm, st));
     if (nc) NCCL_C(c, st, ncclAllGather(b->topk_cnt.p, x.topk_cnt_all.p, nc * 4, ncclUint8, c->comm, st));
-    if (ne) HIP_TRY(hipMemcpyAsync(x.h_topk.p, x.topk_all.p, N * ne * sizeof(uint2), hipMemcpyDeviceToHost, st));
-    if (nc) HIP_TRY(hipMemcpyAsync(x.h_topk.p + N * ne * sizeof(uint2), x.topk_cnt_all.p, N * nc * 4, hipMemcpyDeviceToHost, st));
     x.bytes_moved = (N - 1) * (ne * sizeof(uint2) + nc * 4);
+    if (ne == 0) return COBS_GPU_OK;
+    if (!x.topk_merged) {
+        HIP_TRY(hipMemcpyAsync(x.h_topk.p, x.topk_all.p, N * ne * sizeof(uint2), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(x.h_topk.p + N * ne * sizeof(uint2), x.topk_cnt_all.p, N * nc * 4, hipMemcpyDeviceToHost, st));
+        return COBS_GPU_OK;
+    }
+    HIP_TRY(launch_merge_lists(x.topk_all.p, x.topk_cnt_all.p, x.topk_merge.p, (uint32_t)N, nc, (uint32_t)k, (uint32_t)stride, st));
+    for (size_t f = 0; f < np; ++f) {
+        TopkArgs ta{};
+        ta.counts = x.topk_merge.p + f * nq * stride;
+        ta.from_pool = 1;
+        ta.counts_stride = stride;
+        ta.counts_offset = 0;
+        ta.nslots = (uint32_t)(N * k);
+        ta.thresholds = nullptr;                 // (every shard applied the threshold when it selected)
+        ta.out = x.topk_final.p + f * nq * k;
+        ta.out_count = x.topk_final_cnt.p + f * nq;
+        ta.k = (uint32_t)k;
+        ta.nq = (uint32_t)nq;
+        ta.score_bytes = b->elem_bytes;
+        ta.score_bits = (uint32_t)b->planes;
+        ta.levels = ((uint32_t)b->planes + 11u) / 12u;
+        ta.level_bits = ((uint32_t)b->planes + ta.levels - 1u) / ta.levels;
+        ta.sort_limit = k <= kTopkSortLimit ? (uint32_t)k : 0u;
+        ta.num_docs = (uint32_t)b->ix->parts[f].meta.doc_names.size();
+        HIP_TRY(launch_topk(ta, st));
+    }
+    HIP_TRY(hipMemcpyAsync(x.h_topk.p, x.topk_final.p, ne * sizeof(uint2), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(x.h_topk.p + ne * sizeof(uint2), x.topk_final_cnt.p, nc * 4, hipMemcpyDeviceToHost, st));
     return COBS_GPU_OK;
 }
 
@@ -813,27 +852,39 @@ cobs_gpu_status xchg_topk_collect(cobs_gpu_batch* b, cobs_gpu_comm* c, hipStream
     HIP_TRY(hipSetDevice(b->ix->device));
     if (!b->xchg) return fail(COBS_GPU_ERR_ARG, "no exchange of best-of lists is in flight");
     Exchange& x = *b->xchg;
-    const size_t N = (size_t)c->nranks, k = b->topk_k, nq = b->nq, np = b->ix->parts.size();
+    const size_t k = b->topk_k, nq = b->nq, np = b->ix->parts.size();
     const size_t ne = k * nq * np, nc = nq * np;
     if (!waited)
         if (cobs_gpu_status ws = sync_bounded(c, st, "the all-gather of the shards' best-of lists"); ws != COBS_GPU_OK) return ws;
-    const uint2* all = reinterpret_cast<const uint2*>(x.h_topk.p);
-    const uint32_t* cnt = reinterpret_cast<const uint32_t*>(x.h_topk.p + N * ne * sizeof(uint2));
-    // [file][query][rank * k]: the candidates of all ranks side by side, packed to the front
-    b->h_topk.assign(N * ne, make_uint2(0, 0));
-    b->h_topk_cnt.assign(nc, 0);
-    for (size_t f = 0; f < np; ++f)
-        for (size_t q = 0; q < nq; ++q) {
-            uint2* dst = b->h_topk.data() + (f * nq + q) * (N * k);
-            uint32_t m = 0;
-            for (size_t r = 0; r < N; ++r) {
-                const uint2* src = all + r * ne + (f * nq + q) * k;
-                const uint32_t cr = std::min<uint32_t>(cnt[r * nc + f * nq + q], (uint32_t)k);
-                for (uint32_t i = 0; i < cr; ++i) dst[m++] = src[i];
+    if (!x.topk_merged && ne) {
+        // [file][query][rank * k]: the candidates of all ranks side by side, packed to the front; merged per query on the host
+        const size_t N = (size_t)c->nranks;
+        const uint2* all = reinterpret_cast<const uint2*>(x.h_topk.p);
+        const uint32_t* cnt_all = reinterpret_cast<const uint32_t*>(x.h_topk.p + N * ne * sizeof(uint2));
+        b->h_topk.assign(N * ne, make_uint2(0, 0));
+        b->h_topk_cnt.assign(nc, 0);
+        for (size_t f = 0; f < np; ++f)
+            for (size_t q = 0; q < nq; ++q) {
+                uint2* dst = b->h_topk.data() + (f * nq + q) * (N * k);
+                uint32_t m = 0;
+                for (size_t r = 0; r < N; ++r) {
+                    const uint2* src = all + r * ne + (f * nq + q) * k;
+                    const uint32_t cr = std::min<uint32_t>(cnt_all[r * nc + f * nq + q], (uint32_t)k);
+                    for (uint32_t i = 0; i < cr; ++i) dst[m++] = src[i];
+                }
+                b->h_topk_cnt[f * nq + q] = m;
             }
-            b->h_topk_cnt[f * nq + q] = m;
-        }
-    b->topk_stride = (uint32_t)(N * k);
+        b->topk_stride = (uint32_t)(N * k);
+        b->topk_fetched = true;
+        return COBS_GPU_OK;
+    }
+    // [file][query][k]: the global k best of every (file, query), in result order where K3 orders them -- the layout a
+    // one-GPU run leaves, so that cobs_gpu_batch_hits_host reads it the same way (no per-rank stride any more)
+    const uint2* fin = reinterpret_cast<const uint2*>(x.h_topk.p);
+    const uint32_t* cnt = reinterpret_cast<const uint32_t*>(x.h_topk.p + ne * sizeof(uint2));
+    b->h_topk.assign(fin, fin + ne);
+    b->h_topk_cnt.assign(cnt, cnt + nc);
+    b->topk_stride = 0;
     b->topk_fetched = true;
     return COBS_GPU_OK;
 }

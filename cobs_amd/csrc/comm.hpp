@@ -50,7 +50,10 @@ struct Exchange {
     DevBuf<unsigned long long> d_cursor;         // [nranks] bucket counts / cursors
     DevBuf<uint2> topk_all;
     DevBuf<uint32_t> topk_cnt_all;
-    PinnedBuf<uint8_t> h_topk;                   // ... as they land on the host: [rank] lists, then [rank] counts
+    DevBuf<uint2> topk_merge, topk_final;        // ... side by side per (file, query) | merged by K3: the global k best, [file][query][k]
+    DevBuf<uint32_t> topk_final_cnt;
+    bool topk_merged = false;                    // the last exchange of best-of lists merged them on the device
+    PinnedBuf<uint8_t> h_topk;                   // ... as they land on the host: the merged lists, then their counts
     uint64_t bytes_moved = 0;                    // bytes this rank received over the fabric in the last exchange
     // the ranks' agreement on a pass of the sharded search (sharded.cpp): one record per rank, all-gathered
     DevBuf<uint64_t> d_pass;                     // [1 + N][4]: this rank's record, then every rank's

@@ -59,6 +59,10 @@ hipError_t launch_bucket_hits(const BucketArgs& a, bool count, hipStream_t strea
 // a.cnt ([nq + 1]) and a.cur ([nq]) must be zero.
 hipError_t launch_order_pool(const PoolArgs& a, hipStream_t stream);
 constexpr uint32_t kPoolSegMax = 1024;      // buckets the device orders (larger ones: the host)
+// The all-gathered best-of lists of the shards ([rank][lists][k] + counts) side by side per list for K3's pool mode
+// ([lists][stride], stride >= nranks * k and a multiple of 8; unused entries marked).
+hipError_t launch_merge_lists(const uint2* all, const uint32_t* cnt, uint2* out, uint32_t nranks, uint64_t lists, uint32_t k,
+                              uint32_t stride, hipStream_t stream);
 // One rank's record of a sharded pass (sharded.cpp): status | first invalid query word | hit-pool fill | extra, 4 x u64.
 hipError_t launch_pass_meta(const uint32_t* flags, uint64_t* rec, uint64_t status, uint64_t extra, hipStream_t stream);
 

@@ -113,6 +113,22 @@ __global__ __launch_bounds__(64) void pool_sort_kernel(PoolArgs a) {
     }
 }
 
+// The shards' best-of lists of a limited search, all-gathered as [rank][file][query][k] with their counts, laid side by
+// side per (file, query) for K3's pool mode: [file][query][stride] with rank r's entries at [r * k, r * k + count) and
+// everything else marked unused (document 0xFFFFFFFF).  A rank holds a contiguous range of a file's documents and its
+// list is in (score desc, document asc) order, so equal scores stay in document order by position -- what the merge
+// needs to cut ties at the k-th score as counts_to_result does (classic_search.cpp:136-145).
+__global__ __launch_bounds__(256) void merge_lists_kernel(const uint2* all, const uint32_t* cnt, uint2* out, uint32_t nranks,
+                                                          uint64_t lists, uint32_t k, uint32_t stride) {
+    const uint64_t idx = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (idx >= lists * stride) return;
+    const uint64_t fq = idx / stride;
+    const uint32_t j = (uint32_t)(idx - fq * stride), r = j / k, i = j - r * k;
+    uint2 v = make_uint2(0xFFFFFFFFu, 0u);
+    if (r < nranks && i < min(cnt[(uint64_t)r * lists + fq], k)) v = all[((uint64_t)r * lists + fq) * k + i];
+    out[idx] = v;
+}
+
 // What the ranks of a sharded search agree on after the scan of a pass, as ONE record per rank that an all-gather
 // carries (sharded.cpp): the rank's host-side status, K1's first invalid query, the fill of its hit pool -- read from
 // the batch's flag words where the scan left them, no host round trip in between.
@@ -125,6 +141,15 @@ __global__ void pass_meta_kernel(const uint32_t* flags, uint64_t* rec, uint64_t 
 }
 
 }  // namespace
+
+hipError_t launch_merge_lists(const uint2* all, const uint32_t* cnt, uint2* out, uint32_t nranks, uint64_t lists, uint32_t k,
+                              uint32_t stride, hipStream_t stream) {
+    if (lists == 0 || k == 0) return hipSuccess;
+    const uint64_t blocks = (lists * stride + 255u) / 256u;
+    if (blocks > 0x7FFFFFFFull || stride < (uint64_t)nranks * k) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(merge_lists_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, all, cnt, out, nranks, lists, k, stride);
+    return hipGetLastError();
+}
 
 hipError_t launch_pass_meta(const uint32_t* flags, uint64_t* rec, uint64_t status, uint64_t extra, hipStream_t stream) {
     hipLaunchKernelGGL(pass_meta_kernel, dim3(1), dim3(64), 0, stream, flags, rec, status, extra);
