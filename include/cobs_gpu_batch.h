@@ -191,8 +191,9 @@ cobs_gpu_status cobs_gpu_batch_exchange_hits(cobs_gpu_batch* b, cobs_gpu_comm* c
  * (*q_begin / *q_count, optional); cobs_gpu_batch_hits_host then answers for them and refuses the others. */
 cobs_gpu_status cobs_gpu_batch_exchange_hits_owned(cobs_gpu_batch* b, cobs_gpu_comm* c, void* hip_stream, int* overflow,
                                                    uint64_t* q_begin, uint64_t* q_count);
-/* After a run with num_results > 0: all-gather the k best documents of every shard; cobs_gpu_batch_hits_host then
- * merges them into the global k best.  Not for a query with a single hash in total: the reference does not order
+/* After a run with num_results > 0: all-gather the k best documents of every shard and merge them on the device into
+ * the global k best of every (file, query) (K3 over the gathered lists; k > 8192: merged per query on the host);
+ * cobs_gpu_batch_hits_host then answers from them.  Not for a query with a single hash in total: the reference does not order
  * such a result by score (max_counts <= 1, classic_search.cpp:134,177), it is the first documents in index order,
  * which per-shard best-of lists do not determine -- exchange the score rows for such a batch
  * (cobs_gpu_batch_exchange_counts; cobs_gpu_sharded_search_batch does). */
