@@ -611,3 +611,47 @@ def test_oracle_against_an_independent_restatement(oracle, golden_dir, tmp_path)
         ix = oracle.Index.open(p)
         for qq in (q, q[:31 if ix.term_size <= 31 else ix.term_size], q[40:140]):
             assert np.array_equal(_independent_counts(p, qq), ix.counts(qq).astype(np.int64)), p
+
+
+def _independent_results(paths, query, threshold, num_results):
+    """counts_to_result restated a second time, on top of _independent_counts (nothing shared with oracle/): per index
+    threshold_i = ceil(threshold * T_i) in double (classic_search.cpp:444-449), only real documents pass the filter
+    (:127-132, :166-175), the order is score descending then (index, document) ascending -- unless the query has ONE
+    hash in total over all indexes, then index order (:134-145, :177-188) -- and num_results == 0 means all (:450)."""
+    import math
+    import struct
+    rows, total_hashes = [], 0
+    for f, p in enumerate(paths):
+        raw = open(p, "rb").read()
+        if raw.startswith(b"COBS:CLASSIC_INDEX"):
+            _, k, _can, ndocs, _sig, nh = struct.unpack_from("<IIBIQQ", raw, 18)
+        else:
+            _, k, _can, nparams, ndocs, _ps = struct.unpack_from("<IIBIIQ", raw, 18)
+            nh = struct.unpack_from("<QQ", raw, 18 + 25)[1]
+        T = len(query) - k + 1
+        total_hashes += T * nh
+        thr = math.ceil(threshold * T)
+        counts = _independent_counts(p, query)
+        rows += [(f, d, int(counts[d])) for d in range(ndocs) if counts[d] >= thr]
+    if total_hashes > 1:
+        rows.sort(key=lambda r: (-r[2], r[0], r[1]))
+    return rows[:num_results] if num_results else rows
+
+
+def test_oracle_ranking_against_an_independent_restatement(oracle, tmp_path):
+    """the ORDER of the results -- thresholds, limits that cut runs of equal scores, several indexes with different term
+    sizes, the single-hash case -- from a second restatement of counts_to_result against the C oracle's (both written
+    from reference classic_search.cpp:109-202, 444-451; the hit counts below them are pinned the same way above)"""
+    q = oracle.random_sequence(140, 77)
+    a = cases.make_compact(cases.tmp(tmp_path, "r1.cobs_compact"), 2 * 8 * 8 + 5, 8, [97, 131, 151], 1, 31, 1, 0.55, 5,
+                           planted={3: 1.0, 40: 0.8}, query=q)                 # dense filter, few rows: many equal scores
+    b = cases.make_classic(cases.tmp(tmp_path, "r2.cobs_classic"), 61, 89, 2, 21, 1, 0.6, 6, planted={7: 0.9}, query=q)
+    c = cases.make_classic(cases.tmp(tmp_path, "r3.cobs_classic"), 33, 53, 1, 31, 0, 0.5, 7)
+    for paths in ([a], [b], [a, b], [c, a, b], [c]):
+        ixs = [oracle.Index.open(p) for p in paths]
+        kmax = max(ix.term_size for ix in ixs)
+        for qq in (q, q[:kmax], q[:kmax + 1], q[10:10 + kmax + 7], q[5:100]):
+            for t in (0.0, 0.3, 0.5, 0.9, 1.0):
+                for lim in (0, 1, 2, 5, 17, 1000):
+                    got = [(f, d, s) for (f, d, _n, s) in oracle.search(ixs, qq, t, lim)]
+                    assert got == _independent_results(paths, qq, t, lim), (paths, len(qq), t, lim)
