@@ -97,8 +97,9 @@ uint64_t cobs_gpu_host_passes(const cobs_gpu_index* ix);
  * Tuning keys "row_fetch" (0 = always whole) and "row_fetch_alpha" (fetch when alpha x looked-up bytes <= the
  * chunk's bytes; default 1, 0 = whenever the rows fit a stream buffer) steer the choice. */
 cobs_gpu_status cobs_gpu_stream_counters(const cobs_gpu_index* ix, uint64_t out[2]);
-/* The same two counters in out[0] / out[1] plus out[2] / out[3] = the bytes those two ways asked of PCIe (looked-up
- * rows x row pitch; the rows of the whole chunks).  (Its own symbol: round 4 had widened cobs_gpu_stream_counters to
+/* The same two counters in out[0] / out[1] plus out[2] / out[3] = the bytes those two ways asked of PCIe (the DISTINCT
+ * looked-up rows x row pitch -- a row that several terms of a batch look up crosses once since round 6; counted by the
+ * gather on the device, so this call waits for the device --; the rows of the whole chunks).  (Its own symbol: round 4 had widened cobs_gpu_stream_counters to
  * four words under the old name, which writes past the two-word buffer of a caller built against the older header.) */
 cobs_gpu_status cobs_gpu_stream_traffic(const cobs_gpu_index* ix, uint64_t out[4]);
 /* The plan of an out-of-core handle: out[0] = bytes of ONE of its two stream buffers, out[1] = bytes of the streamed
