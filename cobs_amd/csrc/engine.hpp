@@ -438,6 +438,9 @@ cobs_gpu_status order_pool_collect(cobs_gpu_batch* b, hipStream_t st, bool waite
 // the ordered lists of a whole pass into the caller's arrays in one sweep (false: they do not fit, nothing written)
 bool hand_over_pool(cobs_gpu_batch* sb, size_t g0, size_t g1, cobs_gpu_hit** hits, size_t* cap, size_t* used, size_t* hit_offsets,
                     ResultArena* grow, size_t nq_call, cobs_gpu_status* status);
+// ... and the ordered best-of lists of a limited pass over one file (false: not that case, nothing written)
+bool hand_over_topk(cobs_gpu_batch* b, size_t g0, size_t g1, size_t num_results, cobs_gpu_hit* hits, size_t cap, size_t* used,
+                    size_t* hit_offsets, cobs_gpu_status* status);
 cobs_gpu_status fetch_counts(cobs_gpu_batch* b, size_t q, uint32_t* counts);
 cobs_gpu_status rank_window(cobs_gpu_batch* b, size_t q0, size_t q1, size_t per_query, cobs_gpu_hit* hits);
 

@@ -384,6 +384,15 @@ static cobs_gpu_status search_batch_impl(cobs_gpu_index* ix, const char* const* 
             if (hs != COBS_GPU_OK) return hs;
             ix->timers[4] += now_s() - t0;
         }
+        // a limited pass over one file whose lists K3 ordered: one sweep (results.cpp: hand_over_topk)
+        if (!overflow && sb->topk_k != 0) {
+            const double t0 = now_s();
+            cobs_gpu_status hs = COBS_GPU_OK;
+            const bool done = hand_over_topk(sb, ps.g0, ps.g1, num_results, hits, cap, &used, hit_offsets, &hs);
+            ix->timers[4] += now_s() - t0;
+            if (done) return COBS_GPU_OK;
+            if (hs != COBS_GPU_OK) return hs;
+        }
         for (size_t q = ps.g0; q < ps.g1; ++q) {
             size_t n = 0;
             if (sb->selected && sb->pool_fetched && sb->h_nhits() <= sb->hit_cap &&

@@ -337,6 +337,9 @@ cobs_gpu_status sharded_search_impl(cobs_gpu_index* ix, cobs_gpu_comm* c, const 
             } else if (b->topk_k) {
                 if ((s = event_bounded(c, x.x_done, "the all-gather of the shards' best-of lists")) != COBS_GPU_OK) return s;
                 if ((s = xchg_topk_collect(b, c, xs, true)) != COBS_GPU_OK) return s;
+                cobs_gpu_status hs = COBS_GPU_OK;
+                if (!overflow && !ps.need_rows && hand_over_topk(b, ps.g0, ps.g1, num_results, hits, cap, &used, hit_offsets, &hs)) return COBS_GPU_OK;
+                if (hs != COBS_GPU_OK) return hs;
             }
             if (ps.need_rows && shared) {
                 // the rank that owns a query orders it and writes the results where they belong: the ranking and its PCIe
