@@ -124,12 +124,20 @@ cobs_gpu_status check_meta(const IndexMeta& m) {
 // sub-indexes / row-byte columns never combine, so any cut of the (sub-index, column) space
 // gives independent shards; reference compact_index/mmap_search_file.cpp:22-27,
 // search_file.cpp:30-32).  The unit is one 16-byte column chunk of one sub-index.
-//   mode 0 (default): equal WORK per shard.  The scan is a gather: a query term looks up ONE row in every sub-index,
-//     so what a shard does per term is the row BYTES it holds (its columns), whatever the number of rows behind them.
-//     A column chunk costs 1, or 1.1 in a sub-index whose 128-byte tile column (rows x 128 B) exceeds half the
-//     256 MiB Infinity Cache (measured, scripts/shard_times.py: the 8 sub-indexes of C3 one per GPU scan a 10k-query
-//     batch in 2.17 / 2.21 / 2.25 / 2.28 | 2.53 / 2.43 / 2.41 / 2.41 ms).  A cut may fall inside a sub-index, on a
-//     multiple of 8 chunks (whole 128-byte lines); one within 3 % of a shard's share of a sub-index boundary snaps to it.
+//   mode 0 (default): equal scan TIME per shard.  The scan is a gather: a query term looks up ONE row in every sub-index,
+//     so what a shard does per term follows the 128-byte LINES of a row it holds (its columns), whatever the number of
+//     rows behind them -- and a line of a sub-index whose tile column (rows x 128 B) fits the 256 MiB Infinity Cache
+//     beside its neighbours comes in faster than one that leaves the HBM pins every time.  Measured
+//     (scripts/shard_times.py: the 8 sub-indexes of C3 one per GPU, 13 lines each, scan a 10k-query batch in 2.14 / 2.20 /
+//     2.24 / 2.29 | 2.53 / 2.52 / 2.53 / 2.58 ms; tile columns 32 ... 105 | 156 ... 512 MB; least squares over that run
+//     and the 8-way splits of rounds 5 and 6, 24 shards: 0.845 / 0.885 / 0.905 / 0.906 | 1.00 of a large sub-index's line,
+//     residuals up to 3 % = what two boxes differ by): a line costs min(0.905, 0.765 + 0.0025 per MB of column) up to
+//     128 MiB of column, 1 above.  The unit of a cut is a whole line
+//     (8 chunks; rows below 256 bytes: a chunk) -- a line shared by two shards is fetched by both -- and a row's last,
+//     partial line costs a whole one.  The cuts are the contiguous partition of the lines with the smallest maximum
+//     (binary search over the bound + greedy packing), each cut then as close to its equal share as that bound allows;
+//     a sub-index boundary within 3 % of a share is preferred.  [Until round 6: a chunk cost 1 or 1.1, cuts at the
+//     share rounded to 8 chunks -- shards of 12 to 14 lines, C3 over 8 GPUs 2.31 ... 2.55 ms, balance 0.942.]
 //     (Rounds 1-3 balanced the shards' BYTES in HBM, i.e. rows x columns: the shard with the small sub-indexes held
 //     3.4x the columns of the one with the largest and took 7.6 ms against 0.95 ms -- a 2.5x speed-up on 8 GPUs.)
 //   mode 1: whole sub-indexes, equal COUNT per shard (compact), 16-byte columns (classic).
@@ -137,6 +145,93 @@ cobs_gpu_status check_meta(const IndexMeta& m) {
 //     evenly; the scan times are then as uneven as the sub-indexes' signature sizes.
 // The held slices are contiguous in score-slot order: [tail columns of the first sub-index]
 // [whole sub-indexes] [head columns of the last].
+namespace {
+
+// mode 0: the cuts (global chunk positions, [count + 1]) of the min-max partition of the lines
+std::vector<uint64_t> time_balanced_cuts(const IndexMeta& m, uint32_t count) {
+    const uint64_t prb = m.page_row_bytes();
+    const uint32_t P = m.num_pages();
+    const uint64_t nch = (prb + 15) / 16;
+    const uint64_t u = nch >= 16 ? 8 : 1;                       // chunks per tile: a 128-byte line, or a chunk of a narrow row
+    const uint64_t tp = (nch + u - 1) / u;                      // tiles per sub-index
+    const uint64_t n = (uint64_t)P * tp;
+    std::vector<long double> w(P), before(P + 1, 0.0L);         // cost of a tile of p; of all tiles of the sub-indexes before p
+    for (uint32_t p = 0; p < P; ++p) {
+        const long double col_mb = (long double)m.signature_sizes[p] * 128.0L / 1e6L;
+        const long double rel = m.signature_sizes[p] * 128ull > (128ull << 20) ? 1.0L : std::min(0.905L, 0.765L + 0.0025L * col_mb);
+        w[p] = rel * (long double)u;
+        before[p + 1] = before[p] + w[p] * (long double)tp;
+    }
+    const long double total = before[P];
+    auto pre = [&](uint64_t t) -> long double {                 // cost of the tiles [0, t)
+        const uint64_t p = t / tp;
+        return p >= P ? total : before[p] + w[p] * (long double)(t - p * tp);
+    };
+    // the furthest tile position from `t` whose tiles [t, .) cost at most `budget`
+    auto advance = [&](uint64_t t, long double budget) -> uint64_t {
+        budget *= 1.0L + 1e-12L;
+        while (t < n) {
+            const uint64_t p = t / tp, left = (p + 1) * tp - t;
+            const long double all = w[p] * (long double)left;
+            if (all <= budget) { budget -= all; t += left; continue; }
+            return t + (uint64_t)(budget / w[p]);
+        }
+        return n;
+    };
+    // the earliest tile position before `t` whose tiles [., t) cost at most `budget`
+    auto retreat = [&](uint64_t t, long double budget) -> uint64_t {
+        budget *= 1.0L + 1e-12L;
+        while (t > 0) {
+            const uint64_t p = (t - 1) / tp, have = t - p * tp;
+            const long double all = w[p] * (long double)have;
+            if (all <= budget) { budget -= all; t -= have; continue; }
+            return t - (uint64_t)(budget / w[p]);
+        }
+        return 0;
+    };
+    auto fits = [&](long double bound) {
+        uint64_t t = 0;
+        for (uint32_t r = 0; r < count && t < n; ++r) t = advance(t, bound);
+        return t >= n;
+    };
+    long double lo = 0.0L, hi = total;
+    for (uint32_t p = 0; p < P; ++p) lo = std::max(lo, w[p]);
+    if (!fits(lo)) {
+        for (int it = 0; it < 80; ++it) {
+            const long double mid = (lo + hi) / 2;
+            if (fits(mid)) hi = mid; else lo = mid;
+        }
+    } else {
+        hi = lo;
+    }
+    const long double bound = hi;
+    // earliest start of shard r when the shards behind it are packed from the end
+    std::vector<uint64_t> start_min(count + 1, n);
+    for (uint32_t r = count; r-- > 0;) start_min[r] = retreat(start_min[r + 1], bound);
+    const long double share = total / count, tol = 0.03L * share;
+    std::vector<uint64_t> tiles(count + 1, 0);
+    tiles[count] = n;
+    for (uint32_t r = 1; r < count; ++r) {
+        const long double ideal = share * r;
+        uint64_t t = advance(0, ideal);                                          // pre(t) <= ideal < pre(t + 1)
+        if (t < n && pre(t + 1) - ideal < ideal - pre(t)) ++t;
+        // a sub-index boundary close enough to the share: whole sub-indexes on both sides
+        const uint64_t b0 = t / tp * tp, b1 = std::min<uint64_t>(n, b0 + tp);
+        if (ideal - pre(b0) <= tol) t = b0;
+        else if (pre(b1) - ideal <= tol) t = b1;
+        const uint64_t least = std::max(start_min[r], tiles[r - 1]), most = advance(tiles[r - 1], bound);
+        tiles[r] = std::min(std::max(t, least), std::max(most, least));
+    }
+    std::vector<uint64_t> cuts(count + 1, 0);
+    for (uint32_t r = 0; r <= count; ++r) {
+        const uint64_t p = tiles[r] / tp, k = tiles[r] - p * tp;
+        cuts[r] = p >= P ? (uint64_t)P * nch : p * nch + std::min(nch, k * u);
+    }
+    return cuts;
+}
+
+}  // namespace
+
 std::vector<VPage> held_slices(const IndexMeta& m, uint32_t rank, uint32_t count, uint32_t mode) {
     const uint64_t prb = m.page_row_bytes();
     const uint32_t P = m.num_pages();
@@ -146,11 +241,6 @@ std::vector<VPage> held_slices(const IndexMeta& m, uint32_t rank, uint32_t count
         for (uint32_t p = 0; p < P; ++p) out.push_back(VPage{p, 0, prb});
         return out;
     }
-    // cost of one column chunk of sub-index p
-    auto weight = [&](uint32_t p) -> long double {
-        if (mode == 2) return (long double)m.signature_sizes[p];
-        return m.signature_sizes[p] * 128ull > (128ull << 20) ? 1.1L : 1.0L;
-    };
     // a cut is a global chunk position in [0, P * nch]
     auto cut_of = [&](uint32_t r) -> uint64_t {
         if (r == 0) return 0;
@@ -159,25 +249,33 @@ std::vector<VPage> held_slices(const IndexMeta& m, uint32_t rank, uint32_t count
             if (m.kind == IndexKind::Compact) return (uint64_t)((uint64_t)P * r / count) * nch;
             return nch * r / count;
         }
+        // mode 2: equal bytes in HBM (a chunk of sub-index p weighs its rows)
         long double total = 0;
-        for (uint32_t p = 0; p < P; ++p) total += weight(p) * nch;
+        for (uint32_t p = 0; p < P; ++p) total += (long double)m.signature_sizes[p] * nch;
         const long double share = total / count, ideal = share * r;
         long double acc = 0;
         for (uint32_t p = 0; p < P; ++p) {
-            const long double w = weight(p) * nch;
+            const long double w = (long double)m.signature_sizes[p] * nch;
             if (acc + w < ideal) { acc += w; continue; }
             // the cut falls into sub-index p
             const long double tol = 0.03L * share;
             if (ideal - acc <= tol) return (uint64_t)p * nch;
             if (acc + w - ideal <= tol) return (uint64_t)(p + 1) * nch;
-            uint64_t c = (uint64_t)((ideal - acc) / weight(p) + 0.5L);
-            if (mode == 0 && nch >= 16) c = (c + 4) / 8 * 8;     // whole 128-byte lines on both sides of the cut
+            uint64_t c = (uint64_t)((ideal - acc) / (long double)m.signature_sizes[p] + 0.5L);
             if (c > nch) c = nch;
             return (uint64_t)p * nch + c;
         }
         return (uint64_t)P * nch;
     };
-    const uint64_t c0 = cut_of(rank), c1 = std::max(cut_of(rank + 1), c0);
+    uint64_t c0, c1;
+    if (mode == 0 || mode > 2) {
+        const std::vector<uint64_t> cuts = time_balanced_cuts(m, count);
+        c0 = cuts[std::min(rank, count)];
+        c1 = std::max(cuts[std::min(rank + 1, count)], c0);
+    } else {
+        c0 = cut_of(rank);
+        c1 = std::max(cut_of(rank + 1), c0);
+    }
     for (uint64_t c = c0; c < c1;) {
         const uint32_t p = (uint32_t)(c / nch);
         const uint64_t in = c - (uint64_t)p * nch;

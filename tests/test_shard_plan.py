@@ -47,8 +47,8 @@ def test_shards_are_a_partition_of_the_score_slots(oracle, tmp_path, golden_dir,
 def test_default_mode_balances_work_not_bytes(oracle, tmp_path):
     """sub-indexes whose sizes differ 16x (the shape of BASELINE configs[2]).  The scan is a gather -- a term looks up
     one row in every sub-index -- so a shard's time follows the COLUMNS (score slots) it holds: mode 0 gives every
-    shard about the same number of slots (a chunk of a sub-index whose tile column overflows half the Infinity Cache
-    counts 1.1), whatever that does to its bytes; mode 2 equalises the bytes in HBM (rounds 1-3's default), which
+    shard about the same scan time (whole 128-byte lines, a line of a sub-index whose tile column stays in the Infinity
+    Cache counts 0.77-0.91 of one that does not: plan.cpp time_balanced_cuts), whatever that does to its bytes; mode 2 equalises the bytes in HBM (rounds 1-3's default), which
     leaves the shard of the small sub-indexes with several times the slots of the others"""
     ratio = 16.0 ** (1.0 / 7.0)
     sigs = [int(300 * ratio ** p) for p in range(8)]
