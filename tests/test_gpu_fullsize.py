@@ -413,7 +413,7 @@ def _check_shard_union(lib, begins, counts, local, eb, total, wants, nshards):
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_c4_eight_shards_in_turn(gpu_lib, oracle, mode):
     """BASELINE configs[3] at its own geometry -- 1 M documents, 245 sub-indexes, 68 GB -- cut into the 8 shards an
-    8-GPU node holds (mode 0: equal work = equal columns; mode 1: whole sub-indexes; mode 2: equal bytes, 8.5 GB each,
+    8-GPU node holds (mode 0: equal scan time ~ equal columns, lines of cache-resident columns discounted; mode 1: whole sub-indexes; mode 2: equal bytes, 8.5 GB each,
     cuts inside sub-indexes), every shard on this GPU in turn, 64 queries: the slot ranges partition counts_size, the union of the shards' rows is the
     oracle's, and the all-to-all / all-gather plans of the 8 ranks assemble those rows into the oracle's
     (everything of the N = 8 run but the xGMI transfers themselves).
@@ -435,9 +435,12 @@ def test_c4_eight_shards_in_turn(gpu_lib, oracle, mode):
         assert max(hbm) < 1.1 * min(hbm) and 8.0e9 < min(hbm) and max(hbm) < 9.5e9
     elif mode == 1:     # whole sub-indexes: every cut on a sub-index boundary
         assert all(b[0] % (8 * cfg["page_size"]) == 0 for b in begins)
-    else:               # work-balanced: every shard holds about an eighth of the score slots (a gather's cost is its columns)
+    else:               # time-balanced: a gather's cost is its columns (128-byte lines), and a line of a sub-index whose tile
+        # column stays in the Infinity Cache costs 0.77-0.91 of one that does not (plan.cpp: time_balanced_cuts) -- the
+        # shards of the small sub-indexes hold up to 1.3x the score slots of the shard of the largest, never less
         slots = [c[0] for c in counts]
-        assert max(slots) < 1.15 * min(slots) and sum(slots) == ix.counts_size
+        assert max(slots) < 1.35 * min(slots) and sum(slots) == ix.counts_size
+        assert slots[0] >= slots[-1] and all(a >= b - 1024 for a, b in zip(slots, slots[1:]))
     _check_shard_union(_capi.load(), begins, counts, local, eb, ix.counts_size, wants, 8)
 
 
