@@ -57,8 +57,9 @@ typedef struct cobs_gpu_options {
     uint32_t waves_per_group; /* waves that split one query's terms: 1, 2 or 4; 0 = chosen by query length */
     /* how a file is cut into shard_count shards (the unit is a 16-byte column chunk of one sub-index;
      * every shard holds a contiguous range of score slots):
-     *   0 = equal WORK per shard: a term looks up one row in every sub-index, so a shard's scan time follows the row
-     *       bytes (columns) it holds, not its bytes in HBM; a cut may fall inside a sub-index (column range)
+     *   0 = equal scan TIME per shard: a term looks up one row in every sub-index, so a shard's scan time follows the
+     *       128-byte lines of a row (columns) it holds, not its bytes in HBM -- a line of a sub-index whose tile column
+     *       stays in the Infinity Cache priced lower; a cut may fall inside a sub-index, on a whole line
      *   1 = whole sub-indexes, equal count per shard (classic: 16-byte columns)
      *   2 = equal bytes in HBM per shard (rows x columns): balances the footprint, not the scan time       */
     uint32_t shard_mode;
