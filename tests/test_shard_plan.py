@@ -75,6 +75,59 @@ def test_default_mode_balances_work_not_bytes(oracle, tmp_path):
     assert all(b % (8 * 16) == 0 for b in begin)
 
 
+def _line_weight(sig):
+    """plan.cpp time_balanced_cuts: what a 128-byte line of a sub-index of `sig` rows costs"""
+    col = sig * 128
+    return 1.0 if col > (128 << 20) else min(0.905, 0.765 + 0.0025 * col / 1e6)
+
+
+def _best_maximum(costs, n):
+    """smallest maximum of a contiguous partition of `costs` into n groups (binary search + greedy, as the planner)"""
+    lo, hi = max(costs), sum(costs)
+    for _ in range(60):
+        mid, groups, acc = (lo + hi) / 2, 1, 0.0
+        for c in costs:
+            if acc + c > mid * (1 + 1e-12):
+                groups, acc = groups + 1, 0.0
+            acc += c
+        lo, hi = (lo, mid) if groups <= n else (mid, hi)
+    return hi
+
+
+def test_default_mode_reaches_the_smallest_maximum_over_whole_lines(tmp_path):
+    """BASELINE configs[2]'s geometry as a SPARSE file (header + 18.4 GB of holes: the planner reads the header only):
+    mode 0 cuts on whole 128-byte lines, and the dearest shard -- lines priced by where their tile column lives, a row's
+    partial last line a whole one -- costs what the best contiguous partition of the 104 lines costs.  The 8-way split is
+    15 / 14 / 14 / 13 / 12 / 12 / 12 / 12 lines (scripts/shard_times.py on it: mean / max scan time 0.959)."""
+    import bench
+    cfg = bench.c3_config()
+    sigs, ps = cfg["signature_sizes"], cfg["page_size"]
+    hdr = _compact_header(cfg["num_docs"], ps, [(s, 1) for s in sigs])
+    path = str(tmp_path / "c3_sparse.cobs_compact")
+    with open(path, "wb") as f:
+        f.write(hdr)
+        f.truncate(len(hdr) + sum(sigs) * ps)
+    lines = (ps + 127) // 128                                        # 12 full lines + 32 bytes
+    costs = [_line_weight(s) for s in sigs for _ in range(lines)]
+    slots_of_line = [min(1024, 8 * ps - 1024 * i) for _ in sigs for i in range(lines)]
+    for n in (2, 3, 4, 5, 8, 16):
+        begin, count, _ = _plan(path, n, 0)
+        assert sum(count) == 8 * ps * len(sigs)
+        got, pos, li = [], 0, 0
+        for r in range(n):                                         # every shard is a run of whole lines
+            assert begin[r] == pos
+            k, acc = 0, 0
+            while acc < count[r]:
+                acc += slots_of_line[li + k]
+                k += 1
+            assert acc == count[r], (n, r)
+            got.append(sum(costs[li:li + k]))
+            li, pos = li + k, pos + count[r]
+        assert max(got) <= _best_maximum(costs, n) * (1 + 1e-9), (n, got)
+        if n == 8:
+            assert count == [14592, 13568, 13568, 12544, 11520, 11520, 11520, 11520]
+
+
 def _classic_header(ndocs, sig, nh=1, names=None):
     h = b"COBS:CLASSIC_INDEX" + struct.pack("<IIBIQQ", 1, 31, 1, ndocs, sig, nh)
     for i in range(ndocs if names is None else names):
