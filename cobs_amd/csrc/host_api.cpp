@@ -294,8 +294,19 @@ static cobs_gpu_status search_batch_impl(cobs_gpu_index* ix, const char* const* 
     uint64_t total_chars = 0;
     for (size_t q = 0; q < nq; ++q) total_chars += lens[q];
     const uint64_t pipe_chars = ix->tune.pipe_chars;   // 0 = never cut for pipelining
-    const size_t max_pass = (!any_streamed && pipe_chars && total_chars >= pipe_chars && nq >= 64)
-                                ? (nq + 3) / 4 : std::max<size_t>(nq, 1);
+    // (the first quarter goes as two passes, 1/16 and 3/16 of the call: what the call waits for before its first scan
+    // starts -- staging, upload and K1 of pass 0 -- is a sixteenth of the call's, and every later pass is staged under a
+    // scan at least a third of its own size)
+    const bool piped = !any_streamed && pipe_chars && total_chars >= pipe_chars && nq >= 64;
+    static const bool split_first = !(getenv("COBS_GPU_SPLIT_FIRST") && getenv("COBS_GPU_SPLIT_FIRST")[0] == '0');     // (A/B switch)
+    auto pass_cap = [&](size_t pass_index) -> size_t {
+        if (!piped) return std::max<size_t>(nq, 1);
+        const size_t quarter = (nq + 3) / 4;
+        if (!split_first) return quarter;
+        if (pass_index == 0) return std::max<size_t>(16, quarter / 4);
+        if (pass_index == 1) return std::max<size_t>(16, quarter - quarter / 4);
+        return quarter;
+    };
     const size_t topk = num_results < ix->total_counts ? num_results : 0;   // bounded: K3 selects on the device
     // Every document of every query (the reference's default call): the ordering kernels of a pass are queued right behind
     // its scan (rank.cpp: rank_launch) -- no host round trip in between, and in a call of several passes they run, and the
@@ -416,7 +427,7 @@ static cobs_gpu_status search_batch_impl(cobs_gpu_index* ix, const char* const* 
     while (g0 < nq || (nq == 0 && g0 == 0)) {
         size_t g1 = g0;
         uint64_t table_bytes = 0, max_terms = 1;
-        while (g1 < nq && g1 - g0 < max_pass) {
+        while (g1 < nq && g1 - g0 < pass_cap(pass_no)) {
             // score rows of the pass: queries x slots x the score width its longest query needs
             const uint64_t terms = lens[g1] >= min_term ? lens[g1] - min_term + 1 : 1;
             const uint64_t mt = std::max(max_terms, terms);

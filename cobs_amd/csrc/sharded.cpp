@@ -130,8 +130,17 @@ cobs_gpu_status sharded_search_impl(cobs_gpu_index* ix, cobs_gpu_comm* c, const 
         }
         uint64_t total_chars = 0;
         for (size_t q = 0; q < nq; ++q) total_chars += lens[q];
-        const size_t max_pass = (ix->tune.pipe_chars && total_chars >= ix->tune.pipe_chars && nq >= 64) ? (nq + 3) / 4
-                                                                                                         : std::max<size_t>(nq, 1);
+        // (the first quarter as two passes, 1 / 16 and 3 / 16 of the call, as the one-GPU call cuts: host_api.cpp)
+        const bool piped = ix->tune.pipe_chars && total_chars >= ix->tune.pipe_chars && nq >= 64;
+        static const bool split_first = !(getenv("COBS_GPU_SPLIT_FIRST") && getenv("COBS_GPU_SPLIT_FIRST")[0] == '0');     // (A/B switch)
+        auto pass_cap = [&](size_t pass_index) -> size_t {
+            if (!piped) return std::max<size_t>(nq, 1);
+            const size_t quarter = (nq + 3) / 4;
+            if (!split_first) return quarter;
+            if (pass_index == 0) return std::max<size_t>(16, quarter / 4);
+            if (pass_index == 1) return std::max<size_t>(16, quarter - quarter / 4);
+            return quarter;
+        };
         struct Pass {
             size_t g0 = 0, g1 = 0;
             int slot = 0;
@@ -148,7 +157,7 @@ cobs_gpu_status sharded_search_impl(cobs_gpu_index* ix, cobs_gpu_comm* c, const 
         for (size_t g0 = 0; g0 < nq || passes.empty();) {
             size_t g1 = g0;
             uint64_t tb = 0, max_terms = 1;
-            while (g1 < nq && g1 - g0 < max_pass) {
+            while (g1 < nq && g1 - g0 < pass_cap(passes.size())) {
                 const uint64_t terms = lens[g1] >= min_term ? lens[g1] - min_term + 1 : 1;
                 const uint64_t mt = std::max(max_terms, terms);
                 const int planes = scan_planes_for(mt);
