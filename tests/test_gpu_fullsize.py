@@ -43,7 +43,7 @@ def test_full_size_config(gpu_lib, oracle, name):
     plants = bench.planted_documents(cfg)
     bench.apply_plants(s, plants)
     bench.apply_plants(ix, plants)
-    nq = 256 if name != "c4" else 64              # C4: 1M documents, 245 sub-indexes, 68 GB
+    nq = 256 if name != "c4" else 32              # C4: 1M documents, 245 sub-indexes, 68 GB (the checker regenerates 245 000 rows per query)
     queries = bench.make_queries(nq, 1000)
     b = gpu_lib.Batch(s)
     b.set_queries(queries)
@@ -414,14 +414,14 @@ def _check_shard_union(lib, begins, counts, local, eb, total, wants, nshards):
 def test_c4_eight_shards_in_turn(gpu_lib, oracle, mode):
     """BASELINE configs[3] at its own geometry -- 1 M documents, 245 sub-indexes, 68 GB -- cut into the 8 shards an
     8-GPU node holds (mode 0: equal scan time ~ equal columns, lines of cache-resident columns discounted; mode 1: whole sub-indexes; mode 2: equal bytes, 8.5 GB each,
-    cuts inside sub-indexes), every shard on this GPU in turn, 64 queries: the slot ranges partition counts_size, the union of the shards' rows is the
+    cuts inside sub-indexes), every shard on this GPU in turn, 32 queries: the slot ranges partition counts_size, the union of the shards' rows is the
     oracle's, and the all-to-all / all-gather plans of the 8 ranks assemble those rows into the oracle's
     (everything of the N = 8 run but the xGMI transfers themselves).
     Shard boundary: reference cobs/query/compact_index/mmap_search_file.cpp:22-27, search_file.cpp:30-32."""
     from cobs_amd import _capi
     cfg = bench.c4_config()
     ix = _oracle_index(oracle, cfg)
-    nq = 64
+    nq = 32
     queries = bench.make_queries(nq, 1000)
     wants = _oracle_rows(ix, ("c4", nq), queries)
 
