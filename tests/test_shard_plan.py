@@ -28,8 +28,8 @@ def test_shards_are_a_partition_of_the_score_slots(oracle, tmp_path, golden_dir,
     pc = cases.make_compact(cases.tmp(tmp_path, "p.cobs_compact"), 700, 16, [800, 900, 1000, 1100, 1200, 1300], 2)
     pk = cases.make_classic(cases.tmp(tmp_path, "p.cobs_classic"), 3000, 1999, 1)
     pw = cases.make_compact(cases.tmp(tmp_path, "w.cobs_compact"), 5000, 200, [300, 5000, 700, 9000], 1)
-    # rows of 400 bytes (25 chunks: cuts of the work-balanced mode are rounded to 8 chunks) and sub-indexes on both
-    # sides of the 1.1 weight (rows x 128 B above / below half the Infinity Cache is decided by the header alone)
+    # rows of 400 bytes (25 chunks: cuts of the time-balanced mode fall on whole 128-byte lines, 8 chunks) and sub-indexes
+    # whose lines are priced differently (by rows x 128 B against half the Infinity Cache: decided by the header alone)
     pr = cases.make_compact(cases.tmp(tmp_path, "r.cobs_compact"), 3 * 8 * 400 - 1, 400, [64, 2000, 128], 1)
     for p in (pc, pk, pw, pr, os.path.join(golden_dir, "c1.cobs_compact"), os.path.join(golden_dir, "c1.cobs_classic")):
         ix = oracle.Index.open(p)
